@@ -1,0 +1,65 @@
+"""ctypes binding of libellc_hip.so (the C ABI declared in include/ellc_abi.h).
+
+There is no fallback: if the HIP library is missing or a GPU call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libellc_hip.so")
+MAX_LEVELS = 8
+
+# every symbol include/ellc_abi.h declares (checked by tests/test_abi_symbols.py against the header text)
+ABI_SYMBOLS = [
+    "ellc_abi_version", "ellc_default_config", "ellc_ctx_create", "ellc_ctx_destroy", "ellc_last_error", "ellc_sync", "ellc_stream",
+    "ellc_frame_upload", "ellc_keyframe_upload", "ellc_keyframe_from_frame", "ellc_get_image_level", "ellc_get_gradient",
+    "ellc_get_max_gradient", "ellc_keyframe_set_depth", "ellc_keyframe_set_depth_level", "ellc_keyframe_get_depth_level",
+    "ellc_keyframe_set_weights", "ellc_keyframe_get_weights", "ellc_keyframe_finalise_weights", "ellc_align", "ellc_align_enqueue",
+    "ellc_align_fetch", "ellc_gn_iterate", "ellc_concatenate_relative_pose", "ellc_concatenate_origin_pose", "ellc_se3_exp",
+    "ellc_se3_log", "ellc_depth_set_state", "ellc_depth_get_state", "ellc_depth_set_keyframe", "ellc_depth_propagate",
+    "ellc_depth_observe", "ellc_depth_fill_holes", "ellc_depth_regularize", "ellc_depth_make_inv_depth_one",
+    "ellc_depth_update_depth_image", "ellc_depth_create_keyframe", "ellc_depth_seeds", "ellc_profile_gn_kernel", "ellc_profile_align",
+]
+
+
+class EllcConfig(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("levels", C.c_int),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("max_iter", C.c_int * MAX_LEVELS), ("early_exit", C.c_int),
+                ("max_keyframes", C.c_int), ("max_frames", C.c_int), ("max_batch", C.c_int), ("device", C.c_int)]
+
+
+class EllcHypotheses(C.Structure):
+    _fields_ = [("invDepth", C.c_void_p), ("invDepthSmoothed", C.c_void_p), ("variance", C.c_void_p), ("varianceSmoothed", C.c_void_p),
+                ("validity_counter", C.c_void_p), ("blacklisted", C.c_void_p), ("isValid", C.c_void_p)]
+
+
+class EllcError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile libellc_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC]
+    if not verbose:
+        args.insert(1, "-s")
+    subprocess.check_call(args)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise EllcError("libellc_hip.so is not built (%s). Run __graft_entry__.build() / make -C %s; "
+                            "there is no CPU fallback for the product path." % (SO_PATH, CSRC))
+        _lib = C.CDLL(SO_PATH)
+        _lib.ellc_last_error.restype = C.c_char_p
+        _lib.ellc_stream.restype = C.c_void_p
+        for name in ABI_SYMBOLS:
+            getattr(_lib, name)  # raises AttributeError if the library does not export it
+    return _lib

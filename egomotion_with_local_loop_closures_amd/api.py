@@ -1,0 +1,265 @@
+"""Thin Python view of the C ABI (numpy in / numpy out). All compute happens in libellc_hip.so on the GPU."""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import EllcConfig, EllcHypotheses, EllcError, MAX_LEVELS
+
+MODE_FCA = 0
+MODE_ICA = 1
+HYP_FIELDS = ("invDepth", "invDepthSmoothed", "variance", "varianceSmoothed", "validity", "blacklisted", "valid")
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_config(width, height, levels=4, **kw):
+    cfg = EllcConfig()
+    _lib.lib().ellc_default_config(C.byref(cfg), width, height, levels)
+    for k, v in kw.items():
+        if k == "max_iter":
+            mi = list(v) + [12] * (MAX_LEVELS - len(v))
+            for i in range(MAX_LEVELS):
+                cfg.max_iter[i] = mi[i]
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+class Context:
+    """One HIP stream + resident keyframe / frame slots + one depth map (ellc_ctx)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self._l = _lib.lib()
+        h = C.c_void_p()
+        st = self._l.ellc_ctx_create(C.byref(cfg), C.byref(h))
+        self.h = h
+        if st != 0:
+            msg = self._l.ellc_last_error(h).decode() if h else "context creation failed"
+            if h:
+                self._l.ellc_ctx_destroy(h)
+                self.h = None
+            raise EllcError("ellc_ctx_create -> %d: %s" % (st, msg))
+        self.levels = cfg.levels
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._l.ellc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st, what):
+        if st != 0:
+            raise EllcError("%s -> %d: %s" % (what, st, self._l.ellc_last_error(self.h).decode()))
+
+    def sync(self):
+        self._ck(self._l.ellc_sync(self.h), "ellc_sync")
+
+    def level_shape(self, level):
+        return (self.cfg.height >> level, self.cfg.width >> level)
+
+    # ---- frame side
+    def frame_upload(self, slot, image):
+        image = np.ascontiguousarray(image, np.uint8)
+        assert image.shape == (self.cfg.height, self.cfg.width)
+        self._ck(self._l.ellc_frame_upload(self.h, slot, _p(image)), "ellc_frame_upload")
+
+    def keyframe_upload(self, slot, image):
+        image = np.ascontiguousarray(image, np.uint8)
+        assert image.shape == (self.cfg.height, self.cfg.width)
+        self._ck(self._l.ellc_keyframe_upload(self.h, slot, _p(image)), "ellc_keyframe_upload")
+
+    def keyframe_from_frame(self, kf_slot, frame_slot):
+        self._ck(self._l.ellc_keyframe_from_frame(self.h, kf_slot, frame_slot), "ellc_keyframe_from_frame")
+
+    def image_level(self, is_kf, slot, level):
+        sw, sh, c, r = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._l.ellc_get_image_level(self.h, int(is_kf), slot, level, None, C.byref(sw), C.byref(sh), C.byref(c), C.byref(r)),
+                 "ellc_get_image_level")
+        out = np.zeros((sh.value, sw.value), np.uint8)
+        self._ck(self._l.ellc_get_image_level(self.h, int(is_kf), slot, level, _p(out), None, None, None, None), "ellc_get_image_level")
+        return out, (r.value, c.value)
+
+    def gradient(self, is_kf, slot, level):
+        shp = self.level_shape(level)
+        gx = np.zeros(shp, np.float32); gy = np.zeros(shp, np.float32)
+        self._ck(self._l.ellc_get_gradient(self.h, int(is_kf), slot, level, _p(gx), _p(gy)), "ellc_get_gradient")
+        return gx, gy
+
+    def max_gradient(self, is_kf, slot):
+        out = np.zeros((self.cfg.height, self.cfg.width), np.float32)
+        n = C.c_int(0)
+        self._ck(self._l.ellc_get_max_gradient(self.h, int(is_kf), slot, _p(out), C.byref(n)), "ellc_get_max_gradient")
+        return out, n.value
+
+    # ---- keyframe depth / weights
+    def keyframe_set_depth(self, slot, depth0, var0):
+        d = np.ascontiguousarray(depth0, np.float32); v = np.ascontiguousarray(var0, np.float32)
+        self._ck(self._l.ellc_keyframe_set_depth(self.h, slot, _p(d), _p(v)), "ellc_keyframe_set_depth")
+
+    def keyframe_set_depth_level(self, slot, level, depth, var):
+        d = np.ascontiguousarray(depth, np.float32); v = np.ascontiguousarray(var, np.float32)
+        self._ck(self._l.ellc_keyframe_set_depth_level(self.h, slot, level, _p(d), _p(v)), "ellc_keyframe_set_depth_level")
+
+    def keyframe_depth_level(self, slot, level):
+        shp = self.level_shape(level)
+        d = np.zeros(shp, np.float32); v = np.zeros(shp, np.float32)
+        self._ck(self._l.ellc_keyframe_get_depth_level(self.h, slot, level, _p(d), _p(v)), "ellc_keyframe_get_depth_level")
+        return d, v
+
+    def keyframe_set_weights(self, slot, level, w, num_added=1):
+        w = np.ascontiguousarray(w, np.float32)
+        self._ck(self._l.ellc_keyframe_set_weights(self.h, slot, level, _p(w), num_added), "ellc_keyframe_set_weights")
+
+    def keyframe_weights(self, slot, level):
+        w = np.zeros(self.level_shape(level), np.float32)
+        n = C.c_int(0)
+        self._ck(self._l.ellc_keyframe_get_weights(self.h, slot, level, _p(w), C.byref(n)), "ellc_keyframe_get_weights")
+        return w, n.value
+
+    def keyframe_finalise_weights(self, slot):
+        self._ck(self._l.ellc_keyframe_finalise_weights(self.h, slot), "ellc_keyframe_finalise_weights")
+
+    # ---- alignment
+    def _batch(self, kf_slots, frame_slots, init_pose):
+        kf = np.ascontiguousarray(kf_slots, np.int32).reshape(-1)
+        fr = np.ascontiguousarray(frame_slots, np.int32).reshape(-1)
+        B = kf.size
+        assert fr.size == B
+        ip = np.zeros((B, 6), np.float32) if init_pose is None else np.ascontiguousarray(init_pose, np.float32).reshape(B, 6)
+        return B, kf, fr, ip
+
+    def align(self, kf_slots, frame_slots, init_pose=None, mode=MODE_FCA, save_weights=False):
+        B, kf, fr, ip = self._batch(kf_slots, frame_slots, init_pose)
+        pose = np.zeros((B, 6), np.float32); iters = np.zeros((B, self.levels), np.int32); wgt = np.zeros(B, np.float32)
+        self._ck(self._l.ellc_align(self.h, B, _p(kf), _p(fr), _p(ip), mode, int(save_weights), _p(pose), _p(iters), _p(wgt)), "ellc_align")
+        return pose, iters, wgt
+
+    def align_enqueue(self, kf_slots, frame_slots, init_pose=None, mode=MODE_FCA, save_weights=False):
+        B, kf, fr, ip = self._batch(kf_slots, frame_slots, init_pose)
+        self._ck(self._l.ellc_align_enqueue(self.h, B, _p(kf), _p(fr), _p(ip), mode, int(save_weights)), "ellc_align_enqueue")
+        return B
+
+    def align_fetch(self, B):
+        pose = np.zeros((B, 6), np.float32); iters = np.zeros((B, self.levels), np.int32); wgt = np.zeros(B, np.float32)
+        self._ck(self._l.ellc_align_fetch(self.h, B, _p(pose), _p(iters), _p(wgt)), "ellc_align_fetch")
+        return pose, iters, wgt
+
+    def gn_iterate(self, kf_slot, frame_slot, level, pose, mode=MODE_FCA, it=0, planes=False):
+        pose = np.ascontiguousarray(pose, np.float32)
+        H = np.zeros((6, 6), np.float32); b = np.zeros(6, np.float32); d = np.zeros(6, np.float32); p = np.zeros(6, np.float32)
+        w = C.c_float(0)
+        shp = self.level_shape(level)
+        pl = np.zeros((10,) + shp, np.float32) if planes else None
+        self._ck(self._l.ellc_gn_iterate(self.h, kf_slot, frame_slot, level, mode, it, _p(pose), _p(H), _p(b), _p(d), _p(p), C.byref(w), _p(pl)),
+                 "ellc_gn_iterate")
+        out = dict(H=H, b=b, delta=d, pose=p, weighted=w.value)
+        if planes:
+            out.update(residual=pl[0], weight=pl[1], warpedX=pl[2], warpedY=pl[3], J=pl[4:10])
+        return out
+
+    # ---- depth map
+    def _hyp(self, st):
+        arrs = [np.ascontiguousarray(st["invDepth"], np.float32), np.ascontiguousarray(st["invDepthSmoothed"], np.float32),
+                np.ascontiguousarray(st["variance"], np.float32), np.ascontiguousarray(st["varianceSmoothed"], np.float32),
+                np.ascontiguousarray(st["validity"], np.int32), np.ascontiguousarray(st["blacklisted"], np.int32),
+                np.ascontiguousarray(st["valid"], np.uint8)]
+        h = EllcHypotheses(*[a.ctypes.data for a in arrs])
+        return h, arrs
+
+    def depth_set_state(self, st):
+        h, keep = self._hyp(st)
+        self._ck(self._l.ellc_depth_set_state(self.h, C.byref(h)), "ellc_depth_set_state")
+
+    def depth_get_state(self):
+        shp = (self.cfg.height, self.cfg.width)
+        st = dict(invDepth=np.zeros(shp, np.float32), invDepthSmoothed=np.zeros(shp, np.float32), variance=np.zeros(shp, np.float32),
+                  varianceSmoothed=np.zeros(shp, np.float32), validity=np.zeros(shp, np.int32), blacklisted=np.zeros(shp, np.int32),
+                  valid=np.zeros(shp, np.uint8))
+        h, keep = self._hyp(st)
+        self._ck(self._l.ellc_depth_get_state(self.h, C.byref(h)), "ellc_depth_get_state")
+        return dict(zip(HYP_FIELDS, keep))
+
+    def depth_set_keyframe(self, slot):
+        self._ck(self._l.ellc_depth_set_keyframe(self.h, slot), "ellc_depth_set_keyframe")
+
+    def depth_propagate(self, new_kf_slot, pose_new_wrt_old):
+        p = np.ascontiguousarray(pose_new_wrt_old, np.float32)
+        self._ck(self._l.ellc_depth_propagate(self.h, new_kf_slot, _p(p)), "ellc_depth_propagate")
+
+    def depth_observe(self, frame_slot, pose_frame_wrt_kf):
+        p = np.ascontiguousarray(pose_frame_wrt_kf, np.float32)
+        self._ck(self._l.ellc_depth_observe(self.h, frame_slot, _p(p)), "ellc_depth_observe")
+
+    def depth_fill_holes(self):
+        self._ck(self._l.ellc_depth_fill_holes(self.h), "ellc_depth_fill_holes")
+
+    def depth_regularize(self, remove_occlusions=False):
+        self._ck(self._l.ellc_depth_regularize(self.h, int(remove_occlusions)), "ellc_depth_regularize")
+
+    def depth_make_inv_depth_one(self):
+        f = C.c_float(0)
+        self._ck(self._l.ellc_depth_make_inv_depth_one(self.h, C.byref(f)), "ellc_depth_make_inv_depth_one")
+        return f.value
+
+    def depth_update_depth_image(self):
+        self._ck(self._l.ellc_depth_update_depth_image(self.h), "ellc_depth_update_depth_image")
+
+    def depth_create_keyframe(self, new_kf_slot, pose_new_wrt_old):
+        p = np.ascontiguousarray(pose_new_wrt_old, np.float32)
+        f = C.c_float(0)
+        self._ck(self._l.ellc_depth_create_keyframe(self.h, new_kf_slot, _p(p), C.byref(f)), "ellc_depth_create_keyframe")
+        return f.value
+
+    def depth_seeds(self):
+        f = C.c_float(0)
+        self._ck(self._l.ellc_depth_seeds(self.h, C.byref(f)), "ellc_depth_seeds")
+        return f.value
+
+    # ---- measurement hooks
+    def profile_gn_kernel(self, kf_slots, frame_slots, level, reps=20):
+        B, kf, fr, _ = self._batch(kf_slots, frame_slots, None)
+        ms = C.c_float(0); by = C.c_double(0); v = C.c_longlong(0)
+        self._ck(self._l.ellc_profile_gn_kernel(self.h, B, _p(kf), _p(fr), level, reps, C.byref(ms), C.byref(by), C.byref(v)),
+                 "ellc_profile_gn_kernel")
+        return ms.value, by.value, v.value
+
+    def profile_align(self, kf_slots, frame_slots, init_pose=None, mode=MODE_FCA, reps=5):
+        B, kf, fr, ip = self._batch(kf_slots, frame_slots, init_pose)
+        ms = C.c_float(0)
+        self._ck(self._l.ellc_profile_align(self.h, B, _p(kf), _p(fr), _p(ip), mode, reps, C.byref(ms)), "ellc_profile_align")
+        return ms.value
+
+
+def concatenate_relative_pose(a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    o = np.zeros(6, np.float32)
+    _lib.lib().ellc_concatenate_relative_pose(_p(a), _p(b), _p(o))
+    return o
+
+
+def concatenate_origin_pose(a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    o = np.zeros(6, np.float32)
+    _lib.lib().ellc_concatenate_origin_pose(_p(a), _p(b), _p(o))
+    return o
+
+
+def se3_exp(pose):
+    p = np.ascontiguousarray(pose, np.float32)
+    T = np.zeros(16, np.float32)
+    _lib.lib().ellc_se3_exp(_p(p), _p(T))
+    return T.reshape(4, 4)
+
+
+def se3_log(T):
+    T = np.ascontiguousarray(T, np.float32).reshape(16)
+    p = np.zeros(6, np.float32)
+    _lib.lib().ellc_se3_log(_p(T), _p(p))
+    return p

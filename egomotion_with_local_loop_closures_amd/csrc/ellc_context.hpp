@@ -1,0 +1,78 @@
+// Host-side context behind the C ABI (include/ellc_abi.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <array>
+#include "../../include/ellc_abi.h"
+#include "ellc_device.hpp"
+
+namespace ellc {
+
+struct DepthSoA {   // DepthHypothesis.h:14-40, live fields, structure of arrays
+  float* invDepth = nullptr;
+  float* invDepthSmoothed = nullptr;
+  float* variance = nullptr;
+  float* varianceSmoothed = nullptr;
+  int* validity = nullptr;
+  int* blacklisted = nullptr;
+  uint8_t* isValid = nullptr;
+};
+
+}  // namespace ellc
+
+struct ellc_ctx {
+  ellc_config cfg;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int L = 0;
+  ellc::LevelGeom geom_h[ELLC_MAX_LEVELS];
+  ellc::LevelGeom* geom_d = nullptr;
+  std::vector<void*> allocs;                 // everything hipMalloc'ed (freed on destroy)
+  std::vector<void*> host_allocs;            // hipHostMalloc'ed
+  std::vector<ellc::KfLevelDev> kf_tab_h;    // [L][max_kf]
+  std::vector<ellc::FrLevelDev> fr_tab_h;    // [L][max_fr]
+  ellc::KfLevelDev* kf_tab_d = nullptr;
+  ellc::FrLevelDev* fr_tab_d = nullptr;
+  std::vector<char> kf_has_image, kf_has_depth, fr_has_image;
+  std::vector<std::array<int, ELLC_MAX_LEVELS>> kf_num_weights;
+  std::vector<float*> kf_maxgrad, fr_maxgrad;
+  std::vector<int*> kf_maxgrad_count, fr_maxgrad_count;
+  std::vector<char> kf_maxgrad_valid, fr_maxgrad_valid;
+  // alignment work buffers
+  int *kf_slot_d = nullptr, *fr_slot_d = nullptr, *uniq_slot_d = nullptr;
+  int *kf_slot_h = nullptr, *fr_slot_h = nullptr, *uniq_slot_h = nullptr;   // pinned
+  float *init_pose_d = nullptr, *init_pose_h = nullptr;
+  ellc::AlignState *state_d = nullptr, *state_h = nullptr;
+  float* partials_d = nullptr;
+  float* planes_d = nullptr;
+  float *scratch_a = nullptr, *scratch_b = nullptr;   // W*H f32 each
+  int tile_begin[ELLC_MAX_LEVELS + 1];
+  int cap[ELLC_MAX_LEVELS];                            // compact capacity per level (= n)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // depth map (one per context)
+  ellc::DepthSoA dm_cur, dm_oth;
+  int dm_kf_slot = -1;
+  bool dm_ready = false;
+  float dm_depth_scale = 1.0f, dm_global_scale = 1.0f;
+  float *dm_deptharr0 = nullptr, *dm_vararr0 = nullptr;     // level-0 arrays in the reference's array convention
+  // propagate scratch
+  int *pr_tgt = nullptr, *pr_winner = nullptr, *pr_val = nullptr, *pr_remaining = nullptr;
+  float *pr_id = nullptr, *pr_var = nullptr;
+  double* red_scratch = nullptr;                            // reductions (rescale factor)
+  float Kinv[9], Kmat[9];
+};
+
+namespace ellc {
+ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg);
+#define ELLC_HIP(ctx, expr)                                                                               \
+  do {                                                                                                    \
+    hipError_t e__ = (expr);                                                                              \
+    if (e__ != hipSuccess) return ellc::fail(ctx, ELLC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+int choose_nblk(const ellc_ctx* c, int level, int B);
+ellc_status run_prep(ellc_ctx* c, int n_unique);
+ellc_status build_depth_pyramid(ellc_ctx* c, int slot);
+ellc_status build_maxgrad(ellc_ctx* c, bool is_kf, int slot);
+}  // namespace ellc

@@ -1,0 +1,62 @@
+// Device-side data layout shared by the HIP kernels and the context (host) code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ELLC_MAX_LEVELS 8
+#define ELLC_PART_STRIDE 32     // floats per block partial record (27 used: 21 upper-triangular H + 6 b)
+#define ELLC_NBLK_MAX 256       // max accumulate-blocks per alignment
+#define ELLC_GN_THREADS 256
+
+namespace ellc {
+
+// Geometry of one pyramid level. cols/rows are the sizes the reference iterates (height/2^l), sw/sh the
+// stored image sizes (pyrDown rounds up; they differ for odd sizes — Frame.cpp:110-117 vs :175-179).
+struct LevelGeom {
+  int cols, rows, sw, sh;
+  int n;                      // cols*rows
+  float fx, fy, cx, cy;       // GetIntrinsic(level), UserDefinedFunc.cpp:34-50
+  // per-level Jacobian tables (values that depend on the column or the row only; double where the
+  // reference's pow() promotes the sub-expression to double, PixelWisePyramid.cpp:296-303)
+  const double* colA;         // fx + u^2/fx              [cols]
+  const float* colB;          // (fy*u)/fx                [cols]
+  const double* rowA;         // -(fy + v^2/fy)           [rows]
+  const float* rowB;          // -((fx*v)/fy)             [rows]
+};
+
+// One keyframe (template) slot at one level: dense planes + the compacted list of pixels with depth > 0
+// (frame::calculateNonZeroDepthPts, Frame.cpp:295-301) in raster order.
+struct KfLevelDev {
+  uint8_t* img;               // sw*sh
+  float* depth;               // n   (frame::depth_pyramid[l])
+  float* var;                 // n   (depthMap::depthvararrptr[l])
+  float* weight;              // n   (frame::weight_pyramid[l])
+  uint32_t* cxy;              // compact: y<<16 | x
+  float* cZ;                  // compact depth
+  float* cVar;                // compact variance
+  float* cI;                  // compact keyframe intensity (as f32)
+  float* cW;                  // compact saved weight (ICA)
+  float* wlast;               // compact weight of the most recent iteration (for saveWeights)
+  float* sd;                  // ICA steepest-descent planes, 6 x cap (plane k at sd + k*cap)
+  int* count;                 // V = number of compact entries
+  int* tile_count;            // per-tile counts / offsets scratch (n/1024+1)
+};
+
+struct FrLevelDev {
+  uint8_t* img;               // sw*sh
+};
+
+// Per-alignment state that persists across the launches of one ellc_align.
+struct AlignState {
+  float pose[6];
+  float S[12];                // exp(pose^) rounded to f32: r11 r12 r13 t1 | r21.. t2 | r31.. t3
+  float delta[6];
+  float weighted;
+  int level_done;             // level terminated by weightedPose < 1 (-1: none)
+  int iters[ELLC_MAX_LEVELS];
+  float H[36];
+  float b[6];
+  float Hinv[36];
+};
+
+}  // namespace ellc

@@ -1,0 +1,683 @@
+// libellc_hip.so — C ABI implementation (context, uploads, alignment scheduling). gfx950 only.
+// Reference interfaces replaced by each entry point are cited in include/ellc_abi.h.
+#include "ellc_context.hpp"
+#include "ellc_kernels_image.hpp"
+#include "ellc_kernels_gn.hpp"
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+
+using namespace ellc;
+
+namespace ellc {
+
+ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg) {
+  if (c) c->err = msg;
+  return s;
+}
+
+template <class T>
+static ellc_status dev_alloc(ellc_ctx* c, T** p, size_t count) {
+  void* q = nullptr;
+  size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  ELLC_HIP(c, hipMalloc(&q, bytes));
+  ELLC_HIP(c, hipMemsetAsync(q, 0, bytes, c->stream));
+  c->allocs.push_back(q);
+  *p = (T*)q;
+  return ELLC_OK;
+}
+template <class T>
+static ellc_status host_alloc(ellc_ctx* c, T** p, size_t count) {
+  void* q = nullptr;
+  ELLC_HIP(c, hipHostMalloc(&q, std::max<size_t>(count * sizeof(T), 16), hipHostMallocDefault));
+  c->host_allocs.push_back(q);
+  *p = (T*)q;
+  return ELLC_OK;
+}
+
+int choose_nblk(const ellc_ctx* c, int level, int B) {
+  const int n = c->geom_h[level].n;
+  const int by_px = std::max(1, n / 1024);
+  const int target = std::max(1, 2048 / std::max(1, B));
+  return std::min(ELLC_NBLK_MAX, std::min(by_px, target));
+}
+
+static dim3 grid2d(int w, int h, dim3 blk) { return dim3((w + blk.x - 1) / blk.x, (h + blk.y - 1) / blk.y); }
+
+// upload + build the u8 pyramid for the level table entries `img[l]`
+static ellc_status upload_pyramid(ellc_ctx* c, uint8_t* const* img, const uint8_t* host) {
+  const LevelGeom* g = c->geom_h;
+  ELLC_HIP(c, hipMemcpyAsync(img[0], host, (size_t)g[0].sw * g[0].sh, hipMemcpyHostToDevice, c->stream));
+  for (int l = 1; l < c->L; l++) {
+    dim3 blk(32, 8);
+    hipLaunchKernelGGL(pyr_down_u8, grid2d(g[l].sw, g[l].sh, blk), blk, 0, c->stream, img[l - 1], g[l - 1].sw, g[l - 1].sh, img[l],
+                       g[l].sw, g[l].sh);
+  }
+  ELLC_HIP(c, hipGetLastError());
+  // the host buffer may be pageable: make the copy complete before returning to the caller
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  return ELLC_OK;
+}
+
+ellc_status build_maxgrad(ellc_ctx* c, bool is_kf, int slot) {
+  const LevelGeom& g = c->geom_h[0];
+  const uint8_t* img = is_kf ? c->kf_tab_h[slot].img : c->fr_tab_h[slot].img;
+  float* out = is_kf ? c->kf_maxgrad[slot] : c->fr_maxgrad[slot];
+  int* cnt = is_kf ? c->kf_maxgrad_count[slot] : c->fr_maxgrad_count[slot];
+  dim3 blk(32, 8), grd = grid2d(g.cols, g.rows, blk);
+  ELLC_HIP(c, hipMemsetAsync(cnt, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(maxgrad_magnitude, grd, blk, 0, c->stream, img, g.sw, g.cols, g.rows, c->scratch_a);
+  hipLaunchKernelGGL(maxgrad_vertical, grd, blk, 0, c->stream, c->scratch_a, g.cols, g.rows, c->scratch_b);
+  hipLaunchKernelGGL(maxgrad_horizontal, grd, blk, 0, c->stream, c->scratch_a, c->scratch_b, g.cols, g.rows, out, cnt);
+  ELLC_HIP(c, hipGetLastError());
+  (is_kf ? c->kf_maxgrad_valid : c->fr_maxgrad_valid)[slot] = 1;
+  return ELLC_OK;
+}
+
+ellc_status build_depth_pyramid(ellc_ctx* c, int slot) {
+  for (int l = 1; l < c->L; l++) {
+    const KfLevelDev& s = c->kf_tab_h[(l - 1) * c->cfg.max_keyframes + slot];
+    const KfLevelDev& d = c->kf_tab_h[l * c->cfg.max_keyframes + slot];
+    const int w = c->cfg.width >> l, h = c->cfg.height >> l;
+    dim3 blk(32, 8);
+    hipLaunchKernelGGL(depth_pyr_level, grid2d(w, h, blk), blk, 0, c->stream, s.depth, s.var, d.depth, d.var, w, h);
+  }
+  ELLC_HIP(c, hipGetLastError());
+  return ELLC_OK;
+}
+
+ellc_status run_prep(ellc_ctx* c, int n_unique) {
+  PrepArgs a;
+  a.geom = c->geom_d;
+  a.kf_tab = c->kf_tab_d;
+  a.slots = c->uniq_slot_d;
+  a.levels = c->L;
+  a.max_kf = c->cfg.max_keyframes;
+  for (int l = 0; l <= ELLC_MAX_LEVELS; l++) a.tile_begin[l] = c->tile_begin[std::min(l, c->L)];
+  const int tiles = c->tile_begin[c->L];
+  hipLaunchKernelGGL(prep_count, dim3(tiles, n_unique), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(prep_scan, dim3(c->L, n_unique), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(prep_scatter, dim3(tiles, n_unique), dim3(256), 0, c->stream, a);
+  ELLC_HIP(c, hipGetLastError());
+  return ELLC_OK;
+}
+
+static bool slot_ok(int s, int n) { return s >= 0 && s < n; }
+
+static GnArgs make_gn_args(ellc_ctx* c, int level, int B, int save_w, float* planes) {
+  GnArgs a;
+  a.geom = c->geom_d;
+  a.kf_tab = c->kf_tab_d;
+  a.fr_tab = c->fr_tab_d;
+  a.kf_slot = c->kf_slot_d;
+  a.fr_slot = c->fr_slot_d;
+  a.state = c->state_d;
+  a.partials = c->partials_d;
+  a.planes = planes;
+  a.level = level;
+  a.max_kf = c->cfg.max_keyframes;
+  a.max_fr = c->cfg.max_frames;
+  a.nblk = choose_nblk(c, level, B);
+  a.save_w = save_w;
+  return a;
+}
+
+static void launch_solve(ellc_ctx* c, int level, int B, int nblk, int mode, int early_exit) {
+  SolveArgs s;
+  s.state = c->state_d;
+  s.partials = c->partials_d;
+  s.level = level;
+  s.nblk = nblk;
+  s.mode = mode;
+  s.early_exit = early_exit;
+  hipLaunchKernelGGL(gn_solve, dim3(B), dim3(64), 0, c->stream, s);
+}
+
+// stage slots / initial poses on the device and list the unique keyframe slots
+static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int* n_unique) {
+  if (B < 1 || B > c->cfg.max_batch) return fail(c, ELLC_ERR_BAD_ARG, "B out of range");
+  if (!kf_slots || !frame_slots) return fail(c, ELLC_ERR_BAD_ARG, "null slot arrays");
+  int nu = 0;
+  for (int b = 0; b < B; b++) {
+    if (!slot_ok(kf_slots[b], c->cfg.max_keyframes) || !slot_ok(frame_slots[b], c->cfg.max_frames))
+      return fail(c, ELLC_ERR_BAD_ARG, "slot index out of range");
+    if (!c->kf_has_image[kf_slots[b]] || !c->kf_has_depth[kf_slots[b]]) return fail(c, ELLC_ERR_NOT_READY, "keyframe slot lacks image or depth");
+    if (!c->fr_has_image[frame_slots[b]]) return fail(c, ELLC_ERR_NOT_READY, "frame slot lacks image");
+    c->kf_slot_h[b] = kf_slots[b];
+    c->fr_slot_h[b] = frame_slots[b];
+    bool seen = false;
+    for (int u = 0; u < nu; u++) seen = seen || (c->uniq_slot_h[u] == kf_slots[b]);
+    if (!seen) c->uniq_slot_h[nu++] = kf_slots[b];
+    for (int i = 0; i < 6; i++) c->init_pose_h[b * 6 + i] = init_pose ? init_pose[b * 6 + i] : 0.0f;
+  }
+  ELLC_HIP(c, hipMemcpyAsync(c->kf_slot_d, c->kf_slot_h, B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipMemcpyAsync(c->fr_slot_d, c->fr_slot_h, B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipMemcpyAsync(c->uniq_slot_d, c->uniq_slot_h, nu * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipMemcpyAsync(c->init_pose_d, c->init_pose_h, B * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  *n_unique = nu;
+  return ELLC_OK;
+}
+
+// the level / iteration schedule of GetImagePoseEstimate (ImageFunc.cpp:150-292) as a launch sequence
+static ellc_status enqueue_schedule(ellc_ctx* c, int B, int mode, int save_weights) {
+  for (int level = c->L - 1; level >= 0; level--) {
+    GnArgs a = make_gn_args(c, level, B, (save_weights && mode == ELLC_MODE_FCA) ? 1 : 0, nullptr);
+    const dim3 grd(a.nblk, B), blk(ELLC_GN_THREADS);
+    for (int it = 0; it < c->cfg.max_iter[level]; it++) {
+      if (mode == ELLC_MODE_FCA) {
+        hipLaunchKernelGGL(gn_fca_accumulate<false>, grd, blk, 0, c->stream, a);
+        launch_solve(c, level, B, a.nblk, 0, c->cfg.early_exit);
+      } else {
+        if (it == 0) {
+          hipLaunchKernelGGL(gn_ica_precompute, grd, blk, 0, c->stream, a, c->cap[level]);
+          launch_solve(c, level, B, a.nblk, 1, 0);
+        }
+        hipLaunchKernelGGL(gn_ica_iterate<false>, grd, blk, 0, c->stream, a, c->cap[level]);
+        launch_solve(c, level, B, a.nblk, 2, c->cfg.early_exit);
+      }
+    }
+    if (save_weights && mode == ELLC_MODE_FCA) {
+      hipLaunchKernelGGL(gn_add_saved_weights, dim3(64, B), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, level,
+                         c->cfg.max_keyframes);
+    }
+  }
+  ELLC_HIP(c, hipGetLastError());
+  return ELLC_OK;
+}
+
+}  // namespace ellc
+
+// =====================================================================================================
+extern "C" {
+
+int ellc_abi_version(void) { return ELLC_ABI_VERSION; }
+
+void ellc_default_config(ellc_config* cfg, int width, int height, int levels) {
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->width = width;
+  cfg->height = height;
+  cfg->levels = levels;
+  cfg->fx = cfg->fy = 0.855f * (float)width;   // same fx/W ratio as ExternVariable.h:53 (410.6/480)
+  cfg->cx = (float)width / 2.0f;
+  cfg->cy = (float)height / 2.0f;
+  const int mi[ELLC_MAX_LEVELS] = {4, 7, 9, 12, 12, 12, 12, 12};   // main.cpp:34
+  for (int i = 0; i < ELLC_MAX_LEVELS; i++) cfg->max_iter[i] = mi[i];
+  cfg->early_exit = 1;
+  cfg->max_keyframes = 4;
+  cfg->max_frames = 4;
+  cfg->max_batch = 4;
+  cfg->device = 0;
+}
+
+const char* ellc_last_error(const ellc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+void* ellc_stream(ellc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+ellc_status ellc_sync(ellc_ctx* c) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  return ELLC_OK;
+}
+
+ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
+  if (!cfg || !out) return ELLC_ERR_BAD_ARG;
+  *out = nullptr;
+  if (cfg->width < 16 || cfg->height < 16 || cfg->width > 65535 || cfg->height > 65535) return ELLC_ERR_BAD_ARG;
+  if (cfg->levels < 1 || cfg->levels > ELLC_MAX_LEVELS) return ELLC_ERR_BAD_ARG;
+  if ((cfg->width >> (cfg->levels - 1)) < 4 || (cfg->height >> (cfg->levels - 1)) < 4) return ELLC_ERR_BAD_ARG;
+  if (cfg->max_keyframes < 1 || cfg->max_frames < 1 || cfg->max_batch < 1) return ELLC_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ELLC_ERR_NO_DEVICE;
+  if (cfg->device < 0 || cfg->device >= ndev) return ELLC_ERR_BAD_ARG;
+  ellc_ctx* c = new ellc_ctx();
+  c->cfg = *cfg;
+  c->L = cfg->levels;
+  if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+    delete c;
+    return ELLC_ERR_HIP;
+  }
+#define TRY(expr) do { ellc_status s__ = (expr); if (s__ != ELLC_OK) { *out = c; return s__; } } while (0)
+  hipEventCreate(&c->ev0);
+  hipEventCreate(&c->ev1);
+  // ---- level geometry + Jacobian tables (UserDefinedFunc.cpp:34-50; PixelWisePyramid.cpp:296-303)
+  int sw = cfg->width, sh = cfg->height;
+  c->tile_begin[0] = 0;
+  for (int l = 0; l < c->L; l++) {
+    LevelGeom& g = c->geom_h[l];
+    g.cols = cfg->width >> l;
+    g.rows = cfg->height >> l;
+    g.sw = sw;
+    g.sh = sh;
+    g.n = g.cols * g.rows;
+    const double s = std::pow(2.0, l);
+    g.fx = (float)((double)cfg->fx / s);
+    g.fy = (float)((double)cfg->fy / s);
+    g.cx = (float)((double)cfg->cx / s);
+    g.cy = (float)((double)cfg->cy / s);
+    std::vector<double> colA(g.cols), rowA(g.rows);
+    std::vector<float> colB(g.cols), rowB(g.rows);
+    for (int x = 0; x < g.cols; x++) {
+      const float u = -g.cx + (float)x;
+      colA[x] = (double)g.fx + (std::pow((double)u, 2) / (double)g.fx);
+      colB[x] = (g.fy * u) / g.fx;
+    }
+    for (int y = 0; y < g.rows; y++) {
+      const float v = -g.cy + (float)y;
+      rowA[y] = -((double)g.fy + (std::pow((double)v, 2) / (double)g.fy));
+      rowB[y] = -(g.fx * v / g.fy);
+    }
+    double *dA, *dR;
+    float *dB, *dRB;
+    TRY(dev_alloc(c, &dA, g.cols)); TRY(dev_alloc(c, &dR, g.rows)); TRY(dev_alloc(c, &dB, g.cols)); TRY(dev_alloc(c, &dRB, g.rows));
+    hipMemcpy(dA, colA.data(), g.cols * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dR, rowA.data(), g.rows * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dB, colB.data(), g.cols * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dRB, rowB.data(), g.rows * 4, hipMemcpyHostToDevice);
+    g.colA = dA; g.rowA = dR; g.colB = dB; g.rowB = dRB;
+    c->cap[l] = g.n;
+    c->tile_begin[l + 1] = c->tile_begin[l] + (g.n + ELLC_TILE - 1) / ELLC_TILE;
+    sw = (sw + 1) / 2;
+    sh = (sh + 1) / 2;
+  }
+  TRY(dev_alloc(c, &c->geom_d, ELLC_MAX_LEVELS));
+  hipMemcpy(c->geom_d, c->geom_h, sizeof(LevelGeom) * c->L, hipMemcpyHostToDevice);
+  // ---- slots
+  const int MK = cfg->max_keyframes, MF = cfg->max_frames;
+  c->kf_tab_h.assign((size_t)c->L * MK, KfLevelDev());
+  c->fr_tab_h.assign((size_t)c->L * MF, FrLevelDev());
+  for (int l = 0; l < c->L; l++) {
+    const LevelGeom& g = c->geom_h[l];
+    const size_t n = g.n, ni = (size_t)g.sw * g.sh;
+    const int tiles = c->tile_begin[l + 1] - c->tile_begin[l];
+    for (int s = 0; s < MK; s++) {
+      KfLevelDev& k = c->kf_tab_h[(size_t)l * MK + s];
+      TRY(dev_alloc(c, &k.img, ni));
+      TRY(dev_alloc(c, &k.depth, n)); TRY(dev_alloc(c, &k.var, n)); TRY(dev_alloc(c, &k.weight, n));
+      TRY(dev_alloc(c, &k.cxy, n)); TRY(dev_alloc(c, &k.cZ, n)); TRY(dev_alloc(c, &k.cVar, n)); TRY(dev_alloc(c, &k.cI, n));
+      TRY(dev_alloc(c, &k.cW, n)); TRY(dev_alloc(c, &k.wlast, n)); TRY(dev_alloc(c, &k.sd, 6 * n));
+      TRY(dev_alloc(c, &k.count, 4)); TRY(dev_alloc(c, &k.tile_count, tiles + 1));
+    }
+    for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni));
+  }
+  TRY(dev_alloc(c, &c->kf_tab_d, c->kf_tab_h.size()));
+  TRY(dev_alloc(c, &c->fr_tab_d, c->fr_tab_h.size()));
+  hipMemcpy(c->kf_tab_d, c->kf_tab_h.data(), c->kf_tab_h.size() * sizeof(KfLevelDev), hipMemcpyHostToDevice);
+  hipMemcpy(c->fr_tab_d, c->fr_tab_h.data(), c->fr_tab_h.size() * sizeof(FrLevelDev), hipMemcpyHostToDevice);
+  c->kf_has_image.assign(MK, 0); c->kf_has_depth.assign(MK, 0); c->fr_has_image.assign(MF, 0);
+  c->kf_num_weights.assign(MK, std::array<int, ELLC_MAX_LEVELS>{});
+  c->kf_maxgrad.assign(MK, nullptr); c->fr_maxgrad.assign(MF, nullptr);
+  c->kf_maxgrad_count.assign(MK, nullptr); c->fr_maxgrad_count.assign(MF, nullptr);
+  c->kf_maxgrad_valid.assign(MK, 0); c->fr_maxgrad_valid.assign(MF, 0);
+  const size_t n0 = (size_t)cfg->width * cfg->height;
+  for (int s = 0; s < MK; s++) { TRY(dev_alloc(c, &c->kf_maxgrad[s], n0)); TRY(dev_alloc(c, &c->kf_maxgrad_count[s], 4)); }
+  for (int s = 0; s < MF; s++) { TRY(dev_alloc(c, &c->fr_maxgrad[s], n0)); TRY(dev_alloc(c, &c->fr_maxgrad_count[s], 4)); }
+  // ---- alignment work buffers
+  const int MB = cfg->max_batch;
+  TRY(dev_alloc(c, &c->kf_slot_d, MB)); TRY(dev_alloc(c, &c->fr_slot_d, MB)); TRY(dev_alloc(c, &c->uniq_slot_d, MB));
+  TRY(host_alloc(c, &c->kf_slot_h, MB)); TRY(host_alloc(c, &c->fr_slot_h, MB)); TRY(host_alloc(c, &c->uniq_slot_h, MB));
+  TRY(dev_alloc(c, &c->init_pose_d, MB * 6)); TRY(host_alloc(c, &c->init_pose_h, MB * 6));
+  TRY(dev_alloc(c, &c->state_d, MB)); TRY(host_alloc(c, &c->state_h, MB));
+  TRY(dev_alloc(c, &c->partials_d, (size_t)MB * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
+  TRY(dev_alloc(c, &c->planes_d, 10 * n0));
+  TRY(dev_alloc(c, &c->scratch_a, n0)); TRY(dev_alloc(c, &c->scratch_b, n0));
+  // ---- depth map state
+  DepthSoA* ds[2] = {&c->dm_cur, &c->dm_oth};
+  for (int i = 0; i < 2; i++) {
+    TRY(dev_alloc(c, &ds[i]->invDepth, n0)); TRY(dev_alloc(c, &ds[i]->invDepthSmoothed, n0));
+    TRY(dev_alloc(c, &ds[i]->variance, n0)); TRY(dev_alloc(c, &ds[i]->varianceSmoothed, n0));
+    TRY(dev_alloc(c, &ds[i]->validity, n0)); TRY(dev_alloc(c, &ds[i]->blacklisted, n0)); TRY(dev_alloc(c, &ds[i]->isValid, n0));
+  }
+  TRY(dev_alloc(c, &c->dm_deptharr0, n0)); TRY(dev_alloc(c, &c->dm_vararr0, n0));
+  TRY(dev_alloc(c, &c->pr_tgt, n0)); TRY(dev_alloc(c, &c->pr_winner, n0)); TRY(dev_alloc(c, &c->pr_val, n0));
+  TRY(dev_alloc(c, &c->pr_id, n0)); TRY(dev_alloc(c, &c->pr_var, n0)); TRY(dev_alloc(c, &c->pr_remaining, 4));
+  TRY(dev_alloc(c, &c->red_scratch, 4096));
+  // K and Kinv (EigenInitialization.cpp:20-34): cv 3x3 f32 inverse = f32 cofactors scaled by 1/det in double
+  {
+    const float K[9] = {cfg->fx, 0, cfg->cx, 0, cfg->fy, cfg->cy, 0, 0, 1};
+    std::memcpy(c->Kmat, K, sizeof(K));
+#define S(i, j) K[(i) * 3 + (j)]
+    double d = S(0, 0) * ((double)S(1, 1) * S(2, 2) - (double)S(1, 2) * S(2, 1)) - S(0, 1) * ((double)S(1, 0) * S(2, 2) - (double)S(1, 2) * S(2, 0)) +
+               S(0, 2) * ((double)S(1, 0) * S(2, 1) - (double)S(1, 1) * S(2, 0));
+    d = (d != 0.) ? 1. / d : 0.;
+    c->Kinv[0] = (float)((S(1, 1) * S(2, 2) - S(1, 2) * S(2, 1)) * d);
+    c->Kinv[1] = (float)((S(0, 2) * S(2, 1) - S(0, 1) * S(2, 2)) * d);
+    c->Kinv[2] = (float)((S(0, 1) * S(1, 2) - S(0, 2) * S(1, 1)) * d);
+    c->Kinv[3] = (float)((S(1, 2) * S(2, 0) - S(1, 0) * S(2, 2)) * d);
+    c->Kinv[4] = (float)((S(0, 0) * S(2, 2) - S(0, 2) * S(2, 0)) * d);
+    c->Kinv[5] = (float)((S(0, 2) * S(1, 0) - S(0, 0) * S(1, 2)) * d);
+    c->Kinv[6] = (float)((S(1, 0) * S(2, 1) - S(1, 1) * S(2, 0)) * d);
+    c->Kinv[7] = (float)((S(0, 1) * S(2, 0) - S(0, 0) * S(2, 1)) * d);
+    c->Kinv[8] = (float)((S(0, 0) * S(1, 1) - S(0, 1) * S(1, 0)) * d);
+#undef S
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { *out = c; return fail(c, ELLC_ERR_HIP, "initial sync failed"); }
+#undef TRY
+  *out = c;
+  return ELLC_OK;
+}
+
+ellc_status ellc_ctx_destroy(ellc_ctx* c) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  hipStreamSynchronize(c->stream);
+  for (void* p : c->allocs) hipFree(p);
+  for (void* p : c->host_allocs) hipHostFree(p);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  hipStreamDestroy(c->stream);
+  delete c;
+  return ELLC_OK;
+}
+
+// ---- frame side ----------------------------------------------------------------------------------
+ellc_status ellc_frame_upload(ellc_ctx* c, int slot, const uint8_t* image) {
+  if (!c || !image || !slot_ok(slot, c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_frame_upload: bad argument");
+  uint8_t* img[ELLC_MAX_LEVELS];
+  for (int l = 0; l < c->L; l++) img[l] = c->fr_tab_h[(size_t)l * c->cfg.max_frames + slot].img;
+  ellc_status s = upload_pyramid(c, img, image);
+  if (s != ELLC_OK) return s;
+  c->fr_has_image[slot] = 1;
+  c->fr_maxgrad_valid[slot] = 0;
+  return ELLC_OK;
+}
+
+ellc_status ellc_keyframe_upload(ellc_ctx* c, int slot, const uint8_t* image) {
+  if (!c || !image || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_keyframe_upload: bad argument");
+  uint8_t* img[ELLC_MAX_LEVELS];
+  for (int l = 0; l < c->L; l++) img[l] = c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + slot].img;
+  ellc_status s = upload_pyramid(c, img, image);
+  if (s != ELLC_OK) return s;
+  c->kf_has_image[slot] = 1;
+  for (int l = 0; l < c->L; l++) {   // frame::frame zeroes weight_pyramid / numWeightsAdded (Frame.cpp:114-122)
+    ELLC_HIP(c, hipMemsetAsync(c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + slot].weight, 0, (size_t)c->geom_h[l].n * 4, c->stream));
+    c->kf_num_weights[slot][l] = 0;
+  }
+  return build_maxgrad(c, true, slot);
+}
+
+ellc_status ellc_keyframe_from_frame(ellc_ctx* c, int kf_slot, int frame_slot) {
+  if (!c || !slot_ok(kf_slot, c->cfg.max_keyframes) || !slot_ok(frame_slot, c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "bad slot");
+  if (!c->fr_has_image[frame_slot]) return fail(c, ELLC_ERR_NOT_READY, "frame slot empty");
+  for (int l = 0; l < c->L; l++) {
+    const LevelGeom& g = c->geom_h[l];
+    ELLC_HIP(c, hipMemcpyAsync(c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + kf_slot].img, c->fr_tab_h[(size_t)l * c->cfg.max_frames + frame_slot].img,
+                               (size_t)g.sw * g.sh, hipMemcpyDeviceToDevice, c->stream));
+    ELLC_HIP(c, hipMemsetAsync(c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + kf_slot].weight, 0, (size_t)g.n * 4, c->stream));
+    c->kf_num_weights[kf_slot][l] = 0;
+  }
+  c->kf_has_image[kf_slot] = 1;
+  c->kf_has_depth[kf_slot] = 0;
+  return build_maxgrad(c, true, kf_slot);
+}
+
+ellc_status ellc_get_image_level(ellc_ctx* c, int is_kf, int slot, int level, uint8_t* out, int* stored_w, int* stored_h, int* cols, int* rows) {
+  if (!c || level < 0 || level >= c->L || !slot_ok(slot, is_kf ? c->cfg.max_keyframes : c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (!(is_kf ? c->kf_has_image[slot] : c->fr_has_image[slot])) return fail(c, ELLC_ERR_NOT_READY, "slot empty");
+  const LevelGeom& g = c->geom_h[level];
+  if (stored_w) *stored_w = g.sw;
+  if (stored_h) *stored_h = g.sh;
+  if (cols) *cols = g.cols;
+  if (rows) *rows = g.rows;
+  if (out) {
+    const uint8_t* src = is_kf ? c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + slot].img : c->fr_tab_h[(size_t)level * c->cfg.max_frames + slot].img;
+    ELLC_HIP(c, hipMemcpyAsync(out, src, (size_t)g.sw * g.sh, hipMemcpyDeviceToHost, c->stream));
+    ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return ELLC_OK;
+}
+
+ellc_status ellc_get_gradient(ellc_ctx* c, int is_kf, int slot, int level, float* gx, float* gy) {
+  if (!c || !gx || !gy || level < 0 || level >= c->L || !slot_ok(slot, is_kf ? c->cfg.max_keyframes : c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (!(is_kf ? c->kf_has_image[slot] : c->fr_has_image[slot])) return fail(c, ELLC_ERR_NOT_READY, "slot empty");
+  const LevelGeom& g = c->geom_h[level];
+  const uint8_t* src = is_kf ? c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + slot].img : c->fr_tab_h[(size_t)level * c->cfg.max_frames + slot].img;
+  dim3 blk(32, 8);
+  hipLaunchKernelGGL(gradient_planes, grid2d(g.cols, g.rows, blk), blk, 0, c->stream, src, g.sw, g.cols, g.rows, c->scratch_a, c->scratch_b);
+  ELLC_HIP(c, hipGetLastError());
+  ELLC_HIP(c, hipMemcpyAsync(gx, c->scratch_a, (size_t)g.n * 4, hipMemcpyDeviceToHost, c->stream));
+  ELLC_HIP(c, hipMemcpyAsync(gy, c->scratch_b, (size_t)g.n * 4, hipMemcpyDeviceToHost, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  return ELLC_OK;
+}
+
+ellc_status ellc_get_max_gradient(ellc_ctx* c, int is_kf, int slot, float* out, int* n_substantial) {
+  if (!c || !slot_ok(slot, is_kf ? c->cfg.max_keyframes : c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (!(is_kf ? c->kf_has_image[slot] : c->fr_has_image[slot])) return fail(c, ELLC_ERR_NOT_READY, "slot empty");
+  if (!(is_kf ? c->kf_maxgrad_valid[slot] : c->fr_maxgrad_valid[slot])) {
+    ellc_status s = build_maxgrad(c, is_kf != 0, slot);
+    if (s != ELLC_OK) return s;
+  }
+  const size_t n0 = (size_t)c->cfg.width * c->cfg.height;
+  if (out) ELLC_HIP(c, hipMemcpyAsync(out, is_kf ? c->kf_maxgrad[slot] : c->fr_maxgrad[slot], n0 * 4, hipMemcpyDeviceToHost, c->stream));
+  if (n_substantial) ELLC_HIP(c, hipMemcpyAsync(n_substantial, is_kf ? c->kf_maxgrad_count[slot] : c->fr_maxgrad_count[slot], 4, hipMemcpyDeviceToHost, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  return ELLC_OK;
+}
+
+// ---- keyframe depth / variance / weights -----------------------------------------------------------
+ellc_status ellc_keyframe_set_depth(ellc_ctx* c, int slot, const float* depth0, const float* var0) {
+  if (!c || !depth0 || !var0 || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  const KfLevelDev& k = c->kf_tab_h[slot];
+  const size_t n0 = (size_t)c->geom_h[0].n;
+  ELLC_HIP(c, hipMemcpyAsync(k.depth, depth0, n0 * 4, hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipMemcpyAsync(k.var, var0, n0 * 4, hipMemcpyHostToDevice, c->stream));
+  ellc_status s = build_depth_pyramid(c, slot);
+  if (s != ELLC_OK) return s;
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  c->kf_has_depth[slot] = 1;
+  return ELLC_OK;
+}
+
+ellc_status ellc_keyframe_set_depth_level(ellc_ctx* c, int slot, int level, const float* depth, const float* var) {
+  if (!c || !depth || !var || level < 0 || level >= c->L || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  const KfLevelDev& k = c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + slot];
+  ELLC_HIP(c, hipMemcpyAsync(k.depth, depth, (size_t)c->geom_h[level].n * 4, hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipMemcpyAsync(k.var, var, (size_t)c->geom_h[level].n * 4, hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  c->kf_has_depth[slot] = 1;
+  return ELLC_OK;
+}
+
+ellc_status ellc_keyframe_get_depth_level(ellc_ctx* c, int slot, int level, float* depth, float* var) {
+  if (!c || level < 0 || level >= c->L || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  const KfLevelDev& k = c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + slot];
+  if (depth) ELLC_HIP(c, hipMemcpyAsync(depth, k.depth, (size_t)c->geom_h[level].n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (var) ELLC_HIP(c, hipMemcpyAsync(var, k.var, (size_t)c->geom_h[level].n * 4, hipMemcpyDeviceToHost, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  return ELLC_OK;
+}
+
+ellc_status ellc_keyframe_set_weights(ellc_ctx* c, int slot, int level, const float* w, int num_added) {
+  if (!c || !w || level < 0 || level >= c->L || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  const KfLevelDev& k = c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + slot];
+  ELLC_HIP(c, hipMemcpyAsync(k.weight, w, (size_t)c->geom_h[level].n * 4, hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  c->kf_num_weights[slot][level] = num_added;
+  return ELLC_OK;
+}
+
+ellc_status ellc_keyframe_get_weights(ellc_ctx* c, int slot, int level, float* w, int* num_added) {
+  if (!c || level < 0 || level >= c->L || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  const KfLevelDev& k = c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + slot];
+  if (w) {
+    ELLC_HIP(c, hipMemcpyAsync(w, k.weight, (size_t)c->geom_h[level].n * 4, hipMemcpyDeviceToHost, c->stream));
+    ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  if (num_added) *num_added = c->kf_num_weights[slot][level];
+  return ELLC_OK;
+}
+
+ellc_status ellc_keyframe_finalise_weights(ellc_ctx* c, int slot) {
+  if (!c || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  for (int l = c->L - 1; l >= 0; l--) {
+    const int na = c->kf_num_weights[slot][l];
+    if (na > 0) {
+      const int n = c->geom_h[l].n;
+      const float s = (float)(1.0 / (double)na);
+      hipLaunchKernelGGL(scale_plane, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + slot].weight, n, s);
+    }
+  }
+  ELLC_HIP(c, hipGetLastError());
+  return ELLC_OK;
+}
+
+// ---- alignment -------------------------------------------------------------------------------------
+ellc_status ellc_align_enqueue(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int save_weights) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  if (mode != ELLC_MODE_FCA && mode != ELLC_MODE_ICA) return fail(c, ELLC_ERR_BAD_ARG, "unknown mode");
+  int nu = 0;
+  ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
+  if (s != ELLC_OK) return s;
+  s = run_prep(c, nu);   // mask / count per level: updationOnPyrChange, ImageFunc.cpp:158
+  if (s != ELLC_OK) return s;
+  hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
+  s = enqueue_schedule(c, B, mode, save_weights);
+  if (s != ELLC_OK) return s;
+  if (save_weights && mode == ELLC_MODE_FCA)
+    for (int b = 0; b < B; b++)
+      for (int l = 0; l < c->L; l++) c->kf_num_weights[kf_slots[b]][l]++;
+  return ELLC_OK;
+}
+
+ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters, float* out_weighted) {
+  if (!c || B < 1 || B > c->cfg.max_batch) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  ELLC_HIP(c, hipMemcpyAsync(c->state_h, c->state_d, sizeof(AlignState) * B, hipMemcpyDeviceToHost, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  for (int b = 0; b < B; b++) {
+    if (out_pose) std::memcpy(out_pose + b * 6, c->state_h[b].pose, 24);
+    if (out_iters) for (int l = 0; l < c->L; l++) out_iters[b * c->L + l] = c->state_h[b].iters[l];
+    if (out_weighted) out_weighted[b] = c->state_h[b].weighted;
+  }
+  return ELLC_OK;
+}
+
+ellc_status ellc_align(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int save_weights,
+                       float* out_pose, int* out_iters, float* out_weighted) {
+  ellc_status s = ellc_align_enqueue(c, B, kf_slots, frame_slots, init_pose, mode, save_weights);
+  if (s != ELLC_OK) return s;
+  return ellc_align_fetch(c, B, out_pose, out_iters, out_weighted);
+}
+
+// set pose / S of state[0] without touching Hinv (ICA iterations reuse the level's precomputed inverse)
+__global__ void gn_set_pose0(AlignState* state, const float* pose) {
+  AlignState& st = state[0];
+  float p[6], S[12];
+  for (int i = 0; i < 6; i++) { p[i] = pose[i]; st.pose[i] = p[i]; }
+  exp_se3_f32(p, S);
+  for (int i = 0; i < 12; i++) st.S[i] = S[i];
+  st.level_done = -1;
+}
+
+ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level, int mode, int iter, const float* pose, float* H36, float* b6,
+                            float* delta6, float* new_pose6, float* weighted, float* planes) {
+  if (!c || !pose || level < 0 || level >= c->L) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  int nu = 0;
+  ellc_status s = stage_batch(c, 1, &kf_slot, &frame_slot, pose, &nu);
+  if (s != ELLC_OK) return s;
+  s = run_prep(c, nu);
+  if (s != ELLC_OK) return s;
+  hipLaunchKernelGGL(gn_set_pose0, dim3(1), dim3(1), 0, c->stream, c->state_d, c->init_pose_d);
+  const size_t n = (size_t)c->geom_h[level].n;
+  if (planes) ELLC_HIP(c, hipMemsetAsync(c->planes_d, 0, 10 * n * 4, c->stream));
+  GnArgs a = make_gn_args(c, level, 1, 0, planes ? c->planes_d : nullptr);
+  const dim3 grd(a.nblk, 1), blk(ELLC_GN_THREADS);
+  if (mode == ELLC_MODE_FCA) {
+    if (planes) hipLaunchKernelGGL(gn_fca_accumulate<true>, grd, blk, 0, c->stream, a);
+    else hipLaunchKernelGGL(gn_fca_accumulate<false>, grd, blk, 0, c->stream, a);
+    launch_solve(c, level, 1, a.nblk, 0, 0);
+  } else {
+    if (iter == 0) {
+      hipLaunchKernelGGL(gn_ica_precompute, grd, blk, 0, c->stream, a, c->cap[level]);
+      launch_solve(c, level, 1, a.nblk, 1, 0);
+    }
+    if (planes) hipLaunchKernelGGL(gn_ica_iterate<true>, grd, blk, 0, c->stream, a, c->cap[level]);
+    else hipLaunchKernelGGL(gn_ica_iterate<false>, grd, blk, 0, c->stream, a, c->cap[level]);
+    launch_solve(c, level, 1, a.nblk, 2, 0);
+  }
+  ELLC_HIP(c, hipGetLastError());
+  ELLC_HIP(c, hipMemcpyAsync(c->state_h, c->state_d, sizeof(AlignState), hipMemcpyDeviceToHost, c->stream));
+  if (planes) {
+    // masked pixels: savedWarpedPoints = -2 (PixelWisePyramid.cpp:218-219); the kernel only touches valid pixels
+    ELLC_HIP(c, hipMemcpyAsync(planes, c->planes_d, 10 * n * 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  const AlignState& st = c->state_h[0];
+  if (H36) std::memcpy(H36, st.H, 144);
+  if (b6) std::memcpy(b6, st.b, 24);
+  if (delta6) std::memcpy(delta6, st.delta, 24);
+  if (new_pose6) std::memcpy(new_pose6, st.pose, 24);
+  if (weighted) *weighted = st.weighted;
+  return ELLC_OK;
+}
+
+void ellc_concatenate_relative_pose(const float* a, const float* b, float* dest) {
+  float o[6];
+  concat_relative_f32(a, b, o);
+  std::memcpy(dest, o, sizeof(o));
+}
+void ellc_concatenate_origin_pose(const float* a, const float* b, float* dest) {
+  float o[6];
+  concat_origin_f32(a, b, o);
+  std::memcpy(dest, o, sizeof(o));
+}
+void ellc_se3_exp(const float* pose6, float* T16) {
+  float S[12];
+  exp_se3_f32(pose6, S);
+  std::memcpy(T16, S, sizeof(S));
+  T16[12] = T16[13] = T16[14] = 0.0f;
+  T16[15] = 1.0f;
+}
+void ellc_se3_log(const float* T16, float* pose6) {
+  float S[12];
+  std::memcpy(S, T16, sizeof(S));
+  log_se3_f32(S, pose6);
+}
+
+// ---- measurement hooks -------------------------------------------------------------------------------
+ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, int level, int reps, float* avg_ms,
+                                   double* algorithmic_bytes, long long* valid_pixels) {
+  if (!c || level < 0 || level >= c->L || reps < 1) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  int nu = 0;
+  ellc_status s = stage_batch(c, B, kf_slots, frame_slots, nullptr, &nu);
+  if (s != ELLC_OK) return s;
+  s = run_prep(c, nu);
+  if (s != ELLC_OK) return s;
+  hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
+  GnArgs a = make_gn_args(c, level, B, 0, nullptr);
+  const dim3 grd(a.nblk, B), blk(ELLC_GN_THREADS);
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL(gn_fca_accumulate<false>, grd, blk, 0, c->stream, a);
+  ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(gn_fca_accumulate<false>, grd, blk, 0, c->stream, a);
+  ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
+  ELLC_HIP(c, hipEventSynchronize(c->ev1));
+  float ms = 0;
+  ELLC_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  if (avg_ms) *avg_ms = ms / reps;
+  long long V = 0;
+  for (int b = 0; b < B; b++) {
+    int v = 0;
+    ELLC_HIP(c, hipMemcpy(&v, c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + kf_slots[b]].count, 4, hipMemcpyDeviceToHost));
+    V += v;
+  }
+  if (valid_pixels) *valid_pixels = V;
+  if (algorithmic_bytes) *algorithmic_bytes = 4.0 * (double)c->geom_h[level].n * B + 14.0 * (double)V;
+  return ELLC_OK;
+}
+
+ellc_status ellc_profile_align(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int reps, float* avg_ms) {
+  if (!c || reps < 1) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  ellc_status s = ellc_align_enqueue(c, B, kf_slots, frame_slots, init_pose, mode, 0);
+  if (s != ELLC_OK) return s;
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < reps; i++) {
+    s = ellc_align_enqueue(c, B, kf_slots, frame_slots, init_pose, mode, 0);
+    if (s != ELLC_OK) return s;
+  }
+  ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
+  ELLC_HIP(c, hipEventSynchronize(c->ev1));
+  float ms = 0;
+  ELLC_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  if (avg_ms) *avg_ms = ms / reps;
+  return ELLC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,484 @@
+// Gauss-Newton kernels for gfx950: per-pixel warp / bilinear taps / 1x6 Jacobian / robust weight and the
+// 6x6 normal-equation reduction (reference: PixelWisePyramid::calculatePixelWise, PixelWisePyramid.cpp:58-413;
+// constant-weight variant :561-913), and the per-alignment solve + se(3) update (:441-491).
+//
+// Arithmetic contract: every per-pixel quantity (warped point, taps, J, residual, weight) is computed with
+// the reference's expression order in IEEE f32 — or f64 where the reference's pow() promotes — with
+// contraction disabled for the translation unit, so it is bit-identical to the CPU path. Only the
+// *summation order* of the 27 accumulators differs (per-thread FMA chains, wave DPP tree, fixed-order
+// f64 combine of block partials instead of three serial row bands).
+#pragma once
+#include "ellc_device.hpp"
+#include "ellc_se3.hpp"
+
+namespace ellc {
+
+// ---------------------------------------------------------------------------------------------------
+// wave-wide sum (64 lanes) with DPP row operations; total lands in lane 63 and is broadcast.
+__device__ __forceinline__ float wave_sum(float v) {
+  int x;
+#define ELLC_DPP_ADD(ctrl, rmask)                                                                         \
+  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false);                \
+  v += __builtin_bit_cast(float, x);
+  ELLC_DPP_ADD(0xB1, 0xf)   // quad_perm [1,0,3,2]
+  ELLC_DPP_ADD(0x4E, 0xf)   // quad_perm [2,3,0,1]
+  ELLC_DPP_ADD(0x141, 0xf)  // row_half_mirror
+  ELLC_DPP_ADD(0x140, 0xf)  // row_mirror
+  ELLC_DPP_ADD(0x142, 0xa)  // row_bcast:15 into rows 1,3
+  ELLC_DPP_ADD(0x143, 0xc)  // row_bcast:31 into rows 2,3
+#undef ELLC_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// ExternVariable.h:232
+__device__ __forceinline__ float unzero_f(float v) {
+  const double d = (double)v;
+  const double r = (d < 0.0) ? ((d > -1e-10) ? -1e-10 : d) : ((d < 1e-10) ? 1e-10 : d);
+  return (float)r;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct Taps {
+  float I;      // u8 tap (Frame.h:181-279), -1 when all four taps are out of bounds
+  float gx, gy; // gradient taps (Frame.h:283-394) on frame::calculateGradient's planes (Frame.cpp:185-285)
+};
+
+// The three bilinear taps of one warped point. The gradient planes are never materialised: the four
+// gradient samples are rebuilt from the u8 image with the reference's border rules (interior central
+// difference x0.5, one-sided without 0.5 on the border), which is exact in f32.
+template <bool WANT_GRAD>
+__device__ __forceinline__ Taps tap_point(const uint8_t* __restrict__ img, int sw, int cols, int rows, float x1, float y1) {
+  Taps o;
+  if (x1 != x1 || y1 != y1) {  // NaN: reference behaviour undefined; treated as out of bounds
+    o.I = -1.0f; o.gx = 0.0f; o.gy = 0.0f;
+    return o;
+  }
+  const float fx0 = floorf(x1), fy0 = floorf(y1);
+  const float wx = x1 - fx0, wy = y1 - fy0;
+  const float nC = (float)(cols - 1), nR = (float)(rows - 1);
+  const bool xf_bad = (fx0 < 0.0f) || (fx0 > nC);
+  const bool xc_bad = (x1 < 0.0f) || (x1 > nC);
+  const bool yf_bad = (fy0 < 0.0f) || (fy0 > nR);
+  const bool yc_bad = (y1 < 0.0f) || (y1 > nR);
+  const bool v00 = !(xf_bad || yf_bad), v01 = !(xc_bad || yf_bad), v10 = !(xf_bad || yc_bad), v11 = !(xc_bad || yc_bad);
+  if (!(v00 || v01 || v10 || v11)) {
+    o.I = -1.0f; o.gx = 0.0f; o.gy = 0.0f;   // gradient taps: four zero samples interpolate to 0
+    return o;
+  }
+  const int x0 = (int)fminf(fmaxf(fx0, -4.0f), nC + 4.0f);
+  const int y0 = (int)fminf(fmaxf(fy0, -4.0f), nR + 4.0f);
+  const int xb = clampi(x0, 0, cols - 1), xc = clampi(x0 + 1, 0, cols - 1);
+  const int yb = clampi(y0, 0, rows - 1), yc = clampi(y0 + 1, 0, rows - 1);
+  const uint8_t* rb = img + (size_t)yb * sw;
+  const uint8_t* rc = img + (size_t)yc * sw;
+  const float Pbb = (float)rb[xb], Pbc = (float)rb[xc], Pcb = (float)rc[xb], Pcc = (float)rc[xc];
+  const float omx = 1.0f - wx, omy = 1.0f - wy;
+  {
+    const float p00 = v00 ? Pbb : 0.0f, p01 = v01 ? Pbc : 0.0f, p10 = v10 ? Pcb : 0.0f, p11 = v11 ? Pcc : 0.0f;
+    const float top = (omx * p00) + (wx * p01);
+    const float btm = (omx * p10) + (wx * p11);
+    o.I = (omy * top) + (wy * btm);
+  }
+  if (WANT_GRAD) {
+    const int xa = clampi(x0 - 1, 0, cols - 1), xd = clampi(x0 + 2, 0, cols - 1);
+    const int ya = clampi(y0 - 1, 0, rows - 1), yd = clampi(y0 + 2, 0, rows - 1);
+    const uint8_t* ra = img + (size_t)ya * sw;
+    const uint8_t* rd = img + (size_t)yd * sw;
+    const float Pba = (float)rb[xa], Pbd = (float)rb[xd], Pca = (float)rc[xa], Pcd = (float)rc[xd];
+    const float Pab = (float)ra[xb], Pac = (float)ra[xc], Pdb = (float)rd[xb], Pdc = (float)rd[xc];
+    // scale 1 on the border column/row of the tap itself, 0.5 inside
+    const float sx0 = (x0 <= 0 || x0 >= cols - 1) ? 1.0f : 0.5f;
+    const float sx1 = (x0 + 1 <= 0 || x0 + 1 >= cols - 1) ? 1.0f : 0.5f;
+    const float sy0 = (y0 <= 0 || y0 >= rows - 1) ? 1.0f : 0.5f;
+    const float sy1 = (y0 + 1 <= 0 || y0 + 1 >= rows - 1) ? 1.0f : 0.5f;
+    // d/dx at (yb,x0) (yb,x0+1) (yc,x0) (yc,x0+1)
+    float g00 = sx0 * (Pbc - Pba), g01 = sx1 * (Pbd - Pbb), g10 = sx0 * (Pcc - Pca), g11 = sx1 * (Pcd - Pcb);
+    g00 = v00 ? g00 : 0.0f; g01 = v01 ? g01 : 0.0f; g10 = v10 ? g10 : 0.0f; g11 = v11 ? g11 : 0.0f;
+    float top = (omx * g00) + (wx * g01);
+    float btm = (omx * g10) + (wx * g11);
+    o.gx = (omy * top) + (wy * btm);
+    // d/dy at the same four positions
+    float h00 = sy0 * (Pcb - Pab), h01 = sy0 * (Pcc - Pac), h10 = sy1 * (Pdb - Pbb), h11 = sy1 * (Pdc - Pbc);
+    h00 = v00 ? h00 : 0.0f; h01 = v01 ? h01 : 0.0f; h10 = v10 ? h10 : 0.0f; h11 = v11 ? h11 : 0.0f;
+    top = (omx * h00) + (wx * h01);
+    btm = (omx * h10) + (wx * h11);
+    o.gy = (omy * top) + (wy * btm);
+  } else {
+    o.gx = 0.0f; o.gy = 0.0f;
+  }
+  return o;
+}
+
+struct Warp { float px, py, pz, wx, wy; };
+
+// PixelWisePyramid.cpp:236-262
+__device__ __forceinline__ Warp warp_pixel(int x, int y, float Z, const LevelGeom& g, const float* S) {
+  const float X = ((float)x - g.cx) * Z / g.fx;
+  const float Y = ((float)y - g.cy) * Z / g.fy;
+  Warp o;
+  o.px = (S[0] * X) + (S[1] * Y) + (S[2] * Z) + (S[3]);
+  o.py = (S[4] * X) + (S[5] * Y) + (S[6] * Z) + (S[7]);
+  o.pz = (S[8] * X) + (S[9] * Y) + (S[10] * Z) + (S[11]);
+  o.pz = unzero_f(o.pz);
+  o.wx = ((o.px / o.pz) * g.fx) + g.cx;
+  o.wy = ((o.py / o.pz) * g.fy) + g.cy;
+  return o;
+}
+
+// PixelWisePyramid.cpp:296-320: 1x6 steepest-descent row at the reference pixel / reference depth
+__device__ __forceinline__ void jacobian_row(float gradx, float grady, int x, int y, float Z, const LevelGeom& g, float J[6]) {
+  const float u = -g.cx + (float)x;
+  const float v = -g.cy + (float)y;
+  const float vu = v * u;
+  const float jb0 = (float)((double)grady * g.rowA[y]);
+  const float jt0 = gradx * (-vu / g.fy);
+  const float jb1 = grady * (vu / g.fx);
+  const float jt1 = (float)((double)gradx * g.colA[x]);
+  const float jb2 = grady * g.colB[x];
+  const float jt2 = gradx * g.rowB[y];
+  const double invZ = 1.0 / (double)Z;
+  const float jt3 = (float)((double)gradx * ((double)g.fx * invZ));
+  const float jb4 = (float)((double)grady * ((double)g.fy * invZ));
+  const float jb5 = (float)((double)grady * ((double)(-v) * invZ));
+  const float jt5 = (float)((double)gradx * ((double)(-u) * invZ));
+  J[0] = jt0 + jb0;
+  J[1] = jt1 + jb1;
+  J[2] = jt2 + jb2;
+  J[3] = jt3 + 0.0f;
+  J[4] = 0.0f + jb4;
+  J[5] = jt5 + jb5;
+}
+
+// PixelWisePyramid.cpp:341-358
+__device__ __forceinline__ float fca_weight(const Warp& w, float Z, float residual, float gradx, float grady, float s,
+                                            const LevelGeom& g, float tx, float ty, float tz) {
+  const float d = 1.0f / Z;
+  const float gx = g.fx * gradx;
+  const float gy = g.fy * grady;
+  const float den = (w.pz * w.pz) * d;
+  const float g0 = (tx * w.pz - tz * w.px) / den;
+  const float g1 = (ty * w.pz - tz * w.py) / den;
+  const float drpdd = gx * g0 + gy * g1;
+  const float w_p = 1.0f / (16.0f + (s * drpdd) * drpdd);
+  const float weighted_rp = fabsf(residual * sqrtf(w_p));
+  const float wh = fabsf(weighted_rp < 1.5f ? 1.0f : 1.5f / weighted_rp);
+  return wh * w_p;
+}
+
+struct GnArgs {
+  const LevelGeom* geom;        // [levels]
+  const KfLevelDev* kf_tab;     // [levels][max_kf]
+  const FrLevelDev* fr_tab;     // [levels][max_fr]
+  const int* kf_slot;           // [B]
+  const int* fr_slot;           // [B]
+  AlignState* state;            // [B]
+  float* partials;              // [B][ELLC_NBLK_MAX][ELLC_PART_STRIDE]
+  float* planes;                // debug: 10 planes of n floats (B must be 1), else null
+  int level, max_kf, max_fr, nblk;
+  int save_w;                   // write per-pixel weights of this iteration into kf.wlast
+};
+
+// block reduction of NV per-thread accumulators; thread 0..NV-1 of the block ends up writing value j.
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float* __restrict__ out) {
+  __shared__ float red[ELLC_GN_THREADS / 64][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const float s = wave_sum(acc[j]);
+    if (lane == 0) red[wave][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    float s = red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < ELLC_GN_THREADS / 64; w++) s += red[w][threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// FCA accumulate: grid (nblk, B). Each block owns a contiguous chunk of the alignment's compact pixel
+// list and writes one 27-float partial record.
+template <bool DEBUG>
+__global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
+  const int b = blockIdx.y;
+  const AlignState& st = a.state[b];
+  if (st.level_done == a.level) return;
+  const LevelGeom g = a.geom[a.level];
+  const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
+  const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
+  const int V = *K.count;
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = blockIdx.x * chunk;
+  const int end = min(V, begin + chunk);
+  float S[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) S[i] = st.S[i];
+  const float tx = S[3], ty = S[7], tz = S[11];
+  const uint8_t* __restrict__ cur = F.img;
+
+  float acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; i++) acc[i] = 0.0f;
+
+  for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
+    const uint32_t xy = K.cxy[i];
+    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+    const float Z = K.cZ[i];
+    const float var = K.cVar[i];
+    const float Ikf = K.cI[i];
+    const Warp w = warp_pixel(x, y, Z, g, S);
+    const Taps t = tap_point<true>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
+    float J[6];
+    jacobian_row(t.gx, t.gy, x, y, Z, g, J);
+    const bool oob = (t.I == -1.0f);
+    const float residual = oob ? 0.0f : (t.I - Ikf);
+    const float wgt = oob ? 0.0f : fca_weight(w, Z, residual, t.gx, t.gy, 1.0f * var, g, tx, ty, tz);
+    if (a.save_w) K.wlast[i] = wgt;
+    if (DEBUG) {
+      const size_t n = (size_t)g.n, p = (size_t)y * g.cols + x;
+      a.planes[0 * n + p] = residual;
+      a.planes[1 * n + p] = wgt;
+      a.planes[2 * n + p] = oob ? -1.0f : w.wx;
+      a.planes[3 * n + p] = oob ? -1.0f : w.wy;
+#pragma unroll
+      for (int k = 0; k < 6; k++) a.planes[(4 + k) * n + p] = J[k];
+    }
+    // H += (w J)^T J (upper triangle), b += J (r w)   (PixelWisePyramid.cpp:364-374)
+    const float rw = residual * wgt;
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const float wJ = J[r] * wgt;
+#pragma unroll
+      for (int c = r; c < 6; c++) { acc[q] = __builtin_fmaf(wJ, J[c], acc[q]); q++; }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) acc[21 + r] = __builtin_fmaf(J[r], rw, acc[21 + r]);
+  }
+  block_reduce_store<27>(acc, a.partials + ((size_t)b * ELLC_NBLK_MAX + blockIdx.x) * ELLC_PART_STRIDE);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ICA precompute (PixelWisePyramid.cpp:561-680 + H = WSD*SD^T :938): template-gradient Jacobian at the
+// integer pixel, stored as 6 compact planes; H partials with the constant weights.
+__global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_precompute(GnArgs a, int cap) {
+  const int b = blockIdx.y;
+  const AlignState& st = a.state[b];
+  if (st.level_done == a.level) return;
+  const LevelGeom g = a.geom[a.level];
+  const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
+  const int V = *K.count;
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = blockIdx.x * chunk;
+  const int end = min(V, begin + chunk);
+  const uint8_t* __restrict__ img = K.img;
+  float acc[21];
+#pragma unroll
+  for (int i = 0; i < 21; i++) acc[i] = 0.0f;
+  for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
+    const uint32_t xy = K.cxy[i];
+    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+    const float Z = K.cZ[i];
+    // frame::calculateGradient of the keyframe level image at (y,x)  (Frame.cpp:185-285)
+    const int xm = clampi(x - 1, 0, g.cols - 1), xp = clampi(x + 1, 0, g.cols - 1);
+    const int ym = clampi(y - 1, 0, g.rows - 1), yp = clampi(y + 1, 0, g.rows - 1);
+    const float sx = (x == 0 || x == g.cols - 1) ? 1.0f : 0.5f;
+    const float sy = (y == 0 || y == g.rows - 1) ? 1.0f : 0.5f;
+    const float gradx = sx * ((float)img[(size_t)y * g.sw + xp] - (float)img[(size_t)y * g.sw + xm]);
+    const float grady = sy * ((float)img[(size_t)yp * g.sw + x] - (float)img[(size_t)ym * g.sw + x]);
+    float J[6];
+    jacobian_row(gradx, grady, x, y, Z, g, J);
+    const float wgt = K.cW[i];
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      K.sd[(size_t)r * cap + i] = J[r];
+      const float wJ = J[r] * wgt;   // weightedSteepestDescent (:664-669)
+#pragma unroll
+      for (int c = r; c < 6; c++) { acc[q] = __builtin_fmaf(wJ, J[c], acc[q]); q++; }
+    }
+  }
+  float acc27[27];
+#pragma unroll
+  for (int i = 0; i < 21; i++) acc27[i] = acc[i];
+#pragma unroll
+  for (int i = 21; i < 27; i++) acc27[i] = 0.0f;
+  block_reduce_store<27>(acc27, a.partials + ((size_t)b * ELLC_NBLK_MAX + blockIdx.x) * ELLC_PART_STRIDE);
+}
+
+// ICA iterate (PixelWisePyramid.cpp:687-913): warp, u8 tap, residual, b += SD * (r * w)
+template <bool DEBUG>
+__global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int cap) {
+  const int b = blockIdx.y;
+  const AlignState& st = a.state[b];
+  if (st.level_done == a.level) return;
+  const LevelGeom g = a.geom[a.level];
+  const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
+  const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
+  const int V = *K.count;
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = blockIdx.x * chunk;
+  const int end = min(V, begin + chunk);
+  float S[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) S[i] = st.S[i];
+  const uint8_t* __restrict__ cur = F.img;
+  float acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; i++) acc[i] = 0.0f;
+  for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
+    const uint32_t xy = K.cxy[i];
+    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+    const float Z = K.cZ[i];
+    const Warp w = warp_pixel(x, y, Z, g, S);
+    const Taps t = tap_point<false>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
+    const bool oob = (t.I == -1.0f);
+    const float residual = oob ? 0.0f : (t.I - K.cI[i]);
+    const float wgt = K.cW[i];
+    const float rw = residual * wgt;
+    if (DEBUG) {
+      const size_t n = (size_t)g.n, p = (size_t)y * g.cols + x;
+      a.planes[0 * n + p] = residual;
+      a.planes[1 * n + p] = wgt;
+      a.planes[2 * n + p] = oob ? -1.0f : w.wx;
+      a.planes[3 * n + p] = oob ? -1.0f : w.wy;
+#pragma unroll
+      for (int k = 0; k < 6; k++) a.planes[(4 + k) * n + p] = K.sd[(size_t)k * cap + i];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) acc[21 + r] = __builtin_fmaf(K.sd[(size_t)r * cap + i], rw, acc[21 + r]);
+  }
+  block_reduce_store<27>(acc, a.partials + ((size_t)b * ELLC_NBLK_MAX + blockIdx.x) * ELLC_PART_STRIDE);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cv::Mat::inv(DECOMP_LU) on a 6x6 f32 matrix (OpenCV 3.0.0 LUImpl on (A | I), partial pivoting,
+// |pivot| < FLT_EPSILON => singular => all-zero inverse; PixelWisePyramid.cpp:451).
+__device__ inline void lu_inverse6(const float* Hin, float* out) {
+  float A[36];
+  for (int i = 0; i < 36; i++) { A[i] = Hin[i]; out[i] = 0.0f; }
+  for (int i = 0; i < 6; i++) out[i * 6 + i] = 1.0f;
+  for (int i = 0; i < 6; i++) {
+    int k = i;
+    for (int j = i + 1; j < 6; j++)
+      if (fabsf(A[j * 6 + i]) > fabsf(A[k * 6 + i])) k = j;
+    if (fabsf(A[k * 6 + i]) < 1.1920928955078125e-07f) {
+      for (int q = 0; q < 36; q++) out[q] = 0.0f;
+      return;
+    }
+    if (k != i) {
+      for (int j = i; j < 6; j++) { const float t = A[i * 6 + j]; A[i * 6 + j] = A[k * 6 + j]; A[k * 6 + j] = t; }
+      for (int j = 0; j < 6; j++) { const float t = out[i * 6 + j]; out[i * 6 + j] = out[k * 6 + j]; out[k * 6 + j] = t; }
+    }
+    const float d = -1.0f / A[i * 6 + i];
+    for (int j = i + 1; j < 6; j++) {
+      const float alpha = A[j * 6 + i] * d;
+      for (int q = i + 1; q < 6; q++) A[j * 6 + q] += alpha * A[i * 6 + q];
+      for (int q = 0; q < 6; q++) out[j * 6 + q] += alpha * out[i * 6 + q];
+    }
+  }
+  for (int i = 5; i >= 0; i--)
+    for (int j = 0; j < 6; j++) {
+      float s = out[i * 6 + j];
+      for (int q = i + 1; q < 6; q++) s -= A[i * 6 + q] * out[q * 6 + j];
+      out[i * 6 + j] = s / A[i * 6 + i];
+    }
+}
+
+struct SolveArgs {
+  AlignState* state;
+  const float* partials;
+  int level, nblk;
+  int mode;         // 0 FCA: H and b from partials; 1 ICA-precompute: H only (stores Hinv); 2 ICA-iterate: b only
+  int early_exit;
+};
+
+// One 64-thread block per alignment: fixed-order f64 combine of the block partials, 6x6 solve,
+// weightedPose and pose <- log(exp(delta^) exp(pose^))  (PixelWisePyramid.cpp:441-491).
+__global__ __launch_bounds__(64) void gn_solve(SolveArgs a) {
+  const int b = blockIdx.x;
+  AlignState& st = a.state[b];
+  if (st.level_done == a.level) return;
+  __shared__ double sums[32];
+  const int lane = threadIdx.x;
+  if (lane < 27) {
+    const float* p = a.partials + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE + lane;
+    double s = 0.0;
+    for (int k = 0; k < a.nblk; k++) s += (double)p[(size_t)k * ELLC_PART_STRIDE];
+    sums[lane] = s;
+  }
+  __syncthreads();
+  if (lane != 0) return;
+  if (a.mode != 2) {
+    int q = 0;
+    for (int r = 0; r < 6; r++)
+      for (int c = r; c < 6; c++) {
+        const float v = (float)sums[q++];
+        st.H[r * 6 + c] = v;
+        st.H[c * 6 + r] = v;
+      }
+    float Hinv[36];
+    lu_inverse6(st.H, Hinv);
+    for (int i = 0; i < 36; i++) st.Hinv[i] = Hinv[i];
+    if (a.mode == 1) return;
+  }
+  float bb[6];
+  for (int i = 0; i < 6; i++) { bb[i] = (float)sums[21 + i]; st.b[i] = bb[i]; }
+  // delta = -(Hinv * b)  (cv::gemm f32: products accumulated in double, rounded once)
+  float delta[6];
+  for (int i = 0; i < 6; i++) {
+    double s = 0.0;
+    for (int k = 0; k < 6; k++) s += (double)bb[k] * (double)st.Hinv[i * 6 + k];
+    delta[i] = -(float)s;
+    st.delta[i] = delta[i];
+  }
+  const float weighted = fabsf(delta[0] * 100000.0f) + fabsf(delta[1] * 100000.0f) + fabsf(delta[2] * 100000.0f) +
+                         fabsf(delta[3] * 10000.0f) + fabsf(delta[4] * 10000.0f) + fabsf(delta[5] * 10000.0f);
+  st.weighted = weighted;
+  // pose <- log(exp(delta) * exp(pose)); exp(pose) is the f32 matrix the pixel pass used
+  float D[12], C[12], np[6], S[12];
+  exp_se3_f32(delta, D);
+  for (int i = 0; i < 12; i++) S[i] = st.S[i];
+  compose_f32(D, S, C);
+  log_se3_f32(C, np);
+  exp_se3_f32(np, S);
+  for (int i = 0; i < 6; i++) st.pose[i] = np[i];
+  for (int i = 0; i < 12; i++) st.S[i] = S[i];
+  st.iters[a.level] += 1;
+  if (a.early_exit && weighted < 1.0f) st.level_done = a.level;   // ImageFunc.cpp:251-252
+}
+
+// initial state from the caller's initial relative pose
+__global__ void gn_init_state(AlignState* state, const float* init_pose, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  AlignState& st = state[b];
+  float p[6];
+  for (int i = 0; i < 6; i++) { p[i] = init_pose[b * 6 + i]; st.pose[i] = p[i]; st.delta[i] = 0.0f; }
+  float S[12];
+  exp_se3_f32(p, S);
+  for (int i = 0; i < 12; i++) st.S[i] = S[i];
+  st.weighted = 0.0f;
+  st.level_done = -1;
+  for (int l = 0; l < ELLC_MAX_LEVELS; l++) st.iters[l] = 0;
+  for (int i = 0; i < 36; i++) { st.H[i] = 0.0f; st.Hinv[i] = 0.0f; }
+  for (int i = 0; i < 6; i++) st.b[i] = 0.0f;
+}
+
+// PixelWisePyramid::saveWeights(true) (:544-549): weight_pyramid[l] += display_weightimg (masked pixels add 0)
+__global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, int level, int max_kf) {
+  const int b = blockIdx.y;
+  const KfLevelDev& K = kf_tab[level * max_kf + kf_slot[b]];
+  const int V = *K.count;
+  const int cols = geom[level].cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+    const uint32_t xy = K.cxy[i];
+    const size_t p = (size_t)(xy >> 16) * cols + (xy & 0xffffu);
+    K.weight[p] = K.weight[p] + K.wlast[i];
+  }
+}
+
+}  // namespace ellc

@@ -1,0 +1,243 @@
+// Image-side kernels: u8 pyramid (cv::pyrDown restated), gradient planes, max-gradient map, depth/variance
+// pyramid, and the per-level compaction of the keyframe's valid (depth > 0) pixels.
+#pragma once
+#include "ellc_device.hpp"
+
+namespace ellc {
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
+  return p;
+}
+
+// frame::constructImagePyramids (Frame.cpp:170-182) — cv::pyrDown on CV_8UC1: separable [1 4 6 4 1],
+// BORDER_REFLECT_101, integer accumulation, (sum + 128) >> 8, dst = ((w+1)/2, (h+1)/2).
+__global__ void pyr_down_u8(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst, int dw, int dh) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dw || y >= dh) return;
+  const int wk[5] = {1, 4, 6, 4, 1};
+  int cxs[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) cxs[k] = reflect101(2 * x + k - 2, sw);
+  int v = 0;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const uint8_t* r = src + (size_t)reflect101(2 * y + j - 2, sh) * sw;
+    int h = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) h += wk[k] * (int)r[cxs[k]];
+    v += wk[j] * h;
+  }
+  dst[(size_t)y * dw + x] = (uint8_t)((v + 128) >> 8);
+}
+
+// frame::calculateGradient (Frame.cpp:185-285) at one level, planes rows x cols
+__device__ __forceinline__ void grad_at(const uint8_t* __restrict__ img, int sw, int cols, int rows, int x, int y, float& gx, float& gy) {
+  const int xm = x > 0 ? x - 1 : 0, xp = x < cols - 1 ? x + 1 : cols - 1;
+  const int ym = y > 0 ? y - 1 : 0, yp = y < rows - 1 ? y + 1 : rows - 1;
+  const float sx = (x == 0 || x == cols - 1) ? 1.0f : 0.5f;
+  const float sy = (y == 0 || y == rows - 1) ? 1.0f : 0.5f;
+  const float dx = (float)img[(size_t)y * sw + xp] - (float)img[(size_t)y * sw + xm];
+  const float dy = (float)img[(size_t)yp * sw + x] - (float)img[(size_t)ym * sw + x];
+  gx = (x == 0 || x == cols - 1) ? dx : 0.5f * dx;
+  gy = (y == 0 || y == rows - 1) ? dy : 0.5f * dy;
+  (void)sx; (void)sy;
+}
+
+__global__ void gradient_planes(const uint8_t* __restrict__ img, int sw, int cols, int rows, float* __restrict__ gx, float* __restrict__ gy) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  float a, b;
+  grad_at(img, sw, cols, rows, x, y, a, b);
+  gx[(size_t)y * cols + x] = a;
+  gy[(size_t)y * cols + x] = b;
+}
+
+// frame::buildMaxGradients (Frame.cpp:618-674), three passes
+__global__ void maxgrad_magnitude(const uint8_t* __restrict__ img, int sw, int w, int h, float* __restrict__ mag) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  float gx, gy;
+  grad_at(img, sw, w, h, x, y, gx, gy);
+  const float a = gx * gx, b = gy * gy;
+  mag[(size_t)y * w + x] = sqrtf(a + b);
+}
+__global__ void maxgrad_vertical(const float* __restrict__ mag, int w, int h, float* __restrict__ tmp) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  float v = 0.0f;
+  if (y >= 1 && y < h - 1) {
+    const float g1 = fmaxf(mag[(size_t)y * w + x], mag[(size_t)(y - 1) * w + x]);
+    v = fmaxf(g1, mag[(size_t)(y + 1) * w + x]);
+  }
+  tmp[(size_t)y * w + x] = v;
+}
+__global__ void maxgrad_horizontal(const float* __restrict__ mag, const float* __restrict__ tmp, int w, int h, float* __restrict__ out, int* count) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  float v = mag[(size_t)y * w + x];   // border pixels keep the raw magnitude
+  if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
+    const float g1 = fmaxf(tmp[(size_t)y * w + x - 1], tmp[(size_t)y * w + x]);
+    v = fmaxf(g1, tmp[(size_t)y * w + x + 1]);
+    if (v >= 5.0f) atomicAdd(count, 1);   // MIN_ABS_GRAD_DECREASE
+  }
+  out[(size_t)y * w + x] = v;
+}
+
+// depthMap::buildInvVarDepth, one level (DepthPropagation.cpp:1637-1719); the reference's source stride
+// is 2*width of the destination. src_depth_is_mat: level-0 source holds keyFrame->depth (0 = invalid).
+__global__ void depth_pyr_level(const float* __restrict__ sd, const float* __restrict__ sv, float* __restrict__ dd, float* __restrict__ dv,
+                                int width, int height) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= width || y >= height) return;
+  const int sw = 2 * width;
+  const int idx = 2 * (x + y * sw);
+  const int offs[4] = {0, 1, sw, sw + 1};
+  float idepthSumsSum = 0.0f, ivarSumsSum = 0.0f;
+  int num = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const float var = sv[idx + offs[q]];
+    if (var > 0.0f) {
+      const float ivar = 1.0f / var;
+      ivarSumsSum += ivar;
+      idepthSumsSum += ivar * 1.0f / sd[idx + offs[q]];
+      num++;
+    }
+  }
+  const int o = x + y * width;
+  if (num > 0) {
+    dd[o] = ivarSumsSum / idepthSumsSum;
+    dv[o] = (float)num / ivarSumsSum;
+  } else {
+    dd[o] = 0.0f;
+    dv[o] = -1.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Compaction of the keyframe's valid pixels (mask = depth_pyramid[l] > 0, Frame.cpp:295-301), raster
+// order preserved. Three launches cover all levels of all listed keyframe slots.
+#define ELLC_TILE 1024
+
+struct PrepArgs {
+  const LevelGeom* geom;
+  const KfLevelDev* kf_tab;
+  const int* slots;            // unique keyframe slots
+  int levels, max_kf;
+  int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
+};
+
+__device__ __forceinline__ int prep_level_of(const PrepArgs& a, int tile, int& local) {
+  int l = 0;
+  while (l + 1 < a.levels && tile >= a.tile_begin[l + 1]) l++;
+  local = tile - a.tile_begin[l];
+  return l;
+}
+
+__global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
+  int local;
+  const int level = prep_level_of(a, blockIdx.x, local);
+  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const int n = a.geom[level].n;
+  const int base = local * ELLC_TILE + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = base + j;
+    if (i < n && K.depth[i] > 0.0f) c++;
+  }
+  __shared__ int ws[4];
+  const unsigned long long m0 = 0;
+  (void)m0;
+  // wave totals through LDS
+  int v = c;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) K.tile_count[local] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// one block per (level, slot): exclusive scan of the tile counts in place, total -> count
+__global__ __launch_bounds__(256) void prep_scan(PrepArgs a) {
+  const int level = blockIdx.x;
+  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const int T = a.tile_begin[level + 1] - a.tile_begin[level];
+  const int per = (T + 255) / 256;
+  const int t0 = threadIdx.x * per;
+  int s = 0;
+  for (int i = t0; i < min(T, t0 + per); i++) s += K.tile_count[i];
+  __shared__ int sc[256];
+  sc[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = (threadIdx.x >= off) ? sc[threadIdx.x - off] : 0;
+    __syncthreads();
+    sc[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = sc[threadIdx.x] - s;   // exclusive prefix of this thread's span
+  for (int i = t0; i < min(T, t0 + per); i++) {
+    const int c = K.tile_count[i];
+    K.tile_count[i] = run;
+    run += c;
+  }
+  if (threadIdx.x == 255) *K.count = sc[255];
+}
+
+__global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
+  int local;
+  const int level = prep_level_of(a, blockIdx.x, local);
+  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const LevelGeom& g = a.geom[level];
+  const int n = g.n;
+  const int base = local * ELLC_TILE + threadIdx.x * 4;
+  float d[4];
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = base + j;
+    d[j] = (i < n) ? K.depth[i] : 0.0f;
+    if (d[j] > 0.0f) c++;
+  }
+  // block exclusive scan of c
+  __shared__ int sc[256];
+  sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = (threadIdx.x >= off) ? sc[threadIdx.x - off] : 0;
+    __syncthreads();
+    sc[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int pos = K.tile_count[local] + sc[threadIdx.x] - c;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (d[j] > 0.0f) {
+      const int i = base + j;
+      const int y = i / g.cols, x = i - y * g.cols;
+      K.cxy[pos] = ((uint32_t)y << 16) | (uint32_t)x;
+      K.cZ[pos] = d[j];
+      K.cVar[pos] = K.var[i];
+      K.cI[pos] = (float)K.img[(size_t)y * g.sw + x];
+      K.cW[pos] = K.weight[i];
+      pos++;
+    }
+  }
+}
+
+// frame::finaliseWeights (Frame.cpp:678-695): weight_pyramid[l] /= numWeightsAdded[l] — cv evaluates
+// Mat / int as a*(1/n) through convertTo (32f -> 32f, f32 work type): v * (float)(1.0/n) + 0.
+__global__ void scale_plane(float* p, int n, float s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = p[i] * s + 0.0f;
+}
+
+}  // namespace ellc

@@ -1,0 +1,178 @@
+// se(3) <-> SE(3) in closed form, evaluated in double and rounded to f32 at the interface, for the
+// Gauss-Newton pose update  pose <- log(exp(delta^) * exp(pose^))  (reference: frame::concatenateRelativePose,
+// Frame.cpp:503-530; the reference calls Eigen's 4x4 f32 matrix exp/log, which this replaces).
+// Usable from host and device code.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define ELLC_HD __host__ __device__ __forceinline__
+#else
+#define ELLC_HD inline
+#endif
+
+namespace ellc {
+
+struct Rt {          // rigid transform, rotation row-major + translation, double
+  double R[9];
+  double t[3];
+};
+
+// sin(t)/t, (1-cos t)/t^2, (t-sin t)/t^3 as functions of q = t^2
+ELLC_HD void sinc_family(double q, double& s1, double& s2, double& s3) {
+  if (q < 1e-2) {
+    // alternating series in q, truncated where the next term is < 1e-19 for q < 0.01
+    s1 = 1.0 - q * (1.0 / 6.0) * (1.0 - q * (1.0 / 20.0) * (1.0 - q * (1.0 / 42.0) * (1.0 - q * (1.0 / 72.0) * (1.0 - q / 110.0))));
+    s2 = 0.5 * (1.0 - q * (1.0 / 12.0) * (1.0 - q * (1.0 / 30.0) * (1.0 - q * (1.0 / 56.0) * (1.0 - q * (1.0 / 90.0) * (1.0 - q / 132.0)))));
+    s3 = (1.0 / 6.0) * (1.0 - q * (1.0 / 20.0) * (1.0 - q * (1.0 / 42.0) * (1.0 - q * (1.0 / 72.0) * (1.0 - q * (1.0 / 110.0) * (1.0 - q / 156.0)))));
+  } else {
+    double t = sqrt(q);
+    double st = sin(t);
+    double sh = sin(0.5 * t);
+    s1 = st / t;
+    s2 = 2.0 * sh * sh / q;
+    s3 = (t - st) / (q * t);
+  }
+}
+
+// exp: twist [w v] -> (R, t)
+ELLC_HD void exp_se3(const double xi[6], Rt& o) {
+  const double a = xi[0], b = xi[1], c = xi[2];
+  const double q = a * a + b * b + c * c;
+  double s1, s2, s3;
+  sinc_family(q, s1, s2, s3);
+  // R = I + s1 [w]x + s2 [w]x^2,  V = I + s2 [w]x + s3 [w]x^2, with [w]x^2 = w w^T - q I
+  const double aa = a * a - q, bb = b * b - q, cc = c * c - q, ab = a * b, ac = a * c, bc = b * c;
+  o.R[0] = 1.0 + s2 * aa;      o.R[1] = -s1 * c + s2 * ab;  o.R[2] = s1 * b + s2 * ac;
+  o.R[3] = s1 * c + s2 * ab;   o.R[4] = 1.0 + s2 * bb;      o.R[5] = -s1 * a + s2 * bc;
+  o.R[6] = -s1 * b + s2 * ac;  o.R[7] = s1 * a + s2 * bc;   o.R[8] = 1.0 + s2 * cc;
+  const double vx = xi[3], vy = xi[4], vz = xi[5];
+  o.t[0] = (1.0 + s3 * aa) * vx + (-s2 * c + s3 * ab) * vy + (s2 * b + s3 * ac) * vz;
+  o.t[1] = (s2 * c + s3 * ab) * vx + (1.0 + s3 * bb) * vy + (-s2 * a + s3 * bc) * vz;
+  o.t[2] = (-s2 * b + s3 * ac) * vx + (s2 * a + s3 * bc) * vy + (1.0 + s3 * cc) * vz;
+}
+
+// log: (R, t) -> twist (principal branch, angle in [0, pi])
+ELLC_HD void log_se3(const Rt& m, double xi[6]) {
+  const double* R = m.R;
+  const double cs = 0.5 * (R[0] + R[4] + R[8] - 1.0);
+  const double hx = 0.5 * (R[7] - R[5]), hy = 0.5 * (R[2] - R[6]), hz = 0.5 * (R[3] - R[1]);
+  const double sn = sqrt(hx * hx + hy * hy + hz * hz);
+  const double ang = atan2(sn, cs);
+  double a, b, c;
+  if (cs > -0.99) {
+    double k;
+    if (sn < 1e-4) { const double s2 = sn * sn; k = 1.0 + s2 * (1.0 / 6.0) + s2 * s2 * (3.0 / 40.0); }
+    else k = ang / sn;
+    a = hx * k; b = hy * k; c = hz * k;
+  } else {
+    // rotation close to pi: magnitude of the axis from the diagonal, signs from the skew / symmetric parts
+    const double d = 1.0 - cs;
+    double ux = sqrt(fmax(0.0, (R[0] - cs) / d)), uy = sqrt(fmax(0.0, (R[4] - cs) / d)), uz = sqrt(fmax(0.0, (R[8] - cs) / d));
+    if (sn > 1e-12) {
+      if (hx < 0) ux = -ux;
+      if (hy < 0) uy = -uy;
+      if (hz < 0) uz = -uz;
+    } else {
+      const double pxy = R[1] + R[3], pxz = R[2] + R[6], pyz = R[5] + R[7];
+      if (ux >= uy && ux >= uz) { if (pxy < 0) uy = -uy; if (pxz < 0) uz = -uz; }
+      else if (uy >= uz) { if (pxy < 0) ux = -ux; if (pyz < 0) uz = -uz; }
+      else { if (pxz < 0) ux = -ux; if (pyz < 0) uy = -uy; }
+    }
+    const double n = sqrt(ux * ux + uy * uy + uz * uz);
+    const double s = (n > 0) ? ang / n : 0.0;
+    a = ux * s; b = uy * s; c = uz * s;
+  }
+  const double q = a * a + b * b + c * c;
+  // V^-1 = I - 1/2 [w]x + g [w]x^2, g = (1 - s1/(2 s2)) / q
+  double g;
+  if (q < 1e-2) {
+    g = (1.0 / 12.0) * (1.0 + q * (1.0 / 60.0) * (1.0 + q * (1.0 / 42.0) * (1.0 + q * (1.0 / 40.0) * (1.0 + q * (10.0 / 396.0)))));
+  } else {
+    double s1, s2, s3;
+    sinc_family(q, s1, s2, s3);
+    g = (1.0 - s1 / (2.0 * s2)) / q;
+  }
+  const double aa = a * a - q, bb = b * b - q, cc = c * c - q, ab = a * b, ac = a * c, bc = b * c;
+  const double tx = m.t[0], ty = m.t[1], tz = m.t[2];
+  xi[0] = a; xi[1] = b; xi[2] = c;
+  xi[3] = (1.0 + g * aa) * tx + (0.5 * c + g * ab) * ty + (-0.5 * b + g * ac) * tz;
+  xi[4] = (-0.5 * c + g * ab) * tx + (1.0 + g * bb) * ty + (0.5 * a + g * bc) * tz;
+  xi[5] = (0.5 * b + g * ac) * tx + (-0.5 * a + g * bc) * ty + (1.0 + g * cc) * tz;
+}
+
+// f32 interface: pose6 -> 12 floats [r11 r12 r13 t1 | r21 r22 r23 t2 | r31 r32 r33 t3]
+ELLC_HD void exp_se3_f32(const float pose[6], float S[12]) {
+  double xi[6];
+  for (int i = 0; i < 6; i++) xi[i] = (double)pose[i];
+  Rt m;
+  exp_se3(xi, m);
+  for (int r = 0; r < 3; r++) {
+    S[r * 4 + 0] = (float)m.R[r * 3 + 0];
+    S[r * 4 + 1] = (float)m.R[r * 3 + 1];
+    S[r * 4 + 2] = (float)m.R[r * 3 + 2];
+    S[r * 4 + 3] = (float)m.t[r];
+  }
+}
+
+ELLC_HD void load_f32(const float S[12], Rt& m) {
+  for (int r = 0; r < 3; r++) {
+    m.R[r * 3 + 0] = (double)S[r * 4 + 0];
+    m.R[r * 3 + 1] = (double)S[r * 4 + 1];
+    m.R[r * 3 + 2] = (double)S[r * 4 + 2];
+    m.t[r] = (double)S[r * 4 + 3];
+  }
+}
+
+// C = A * B on f32-held transforms; products summed in double, entries rounded once to f32
+ELLC_HD void compose_f32(const float A[12], const float B[12], float C[12]) {
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) {
+      double s = 0.0;
+      for (int k = 0; k < 3; k++) s += (double)A[r * 4 + k] * (double)B[k * 4 + c];
+      C[r * 4 + c] = (float)s;
+    }
+    double s = 0.0;
+    for (int k = 0; k < 3; k++) s += (double)A[r * 4 + k] * (double)B[k * 4 + 3];
+    s += (double)A[r * 4 + 3];  // * 1 (homogeneous row of B)
+    C[r * 4 + 3] = (float)s;
+  }
+}
+
+ELLC_HD void invert_f32(const float A[12], float Ai[12]) {
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) Ai[r * 4 + c] = A[c * 4 + r];
+    double s = 0.0;
+    for (int k = 0; k < 3; k++) s += (double)A[k * 4 + r] * (double)A[k * 4 + 3];
+    Ai[r * 4 + 3] = (float)(-s);
+  }
+}
+
+ELLC_HD void log_se3_f32(const float S[12], float pose[6]) {
+  Rt m;
+  load_f32(S, m);
+  double xi[6];
+  log_se3(m, xi);
+  for (int i = 0; i < 6; i++) pose[i] = (float)xi[i];
+}
+
+// dest = log(exp(a) * exp(b))      (frame::concatenateRelativePose, Frame.cpp:503-530)
+ELLC_HD void concat_relative_f32(const float a[6], const float b[6], float dest[6]) {
+  float A[12], B[12], C[12];
+  exp_se3_f32(a, A);
+  exp_se3_f32(b, B);
+  compose_f32(A, B, C);
+  log_se3_f32(C, dest);
+}
+
+// dest = log(exp(a) * exp(b)^-1)   (frame::concatenateOriginPose, Frame.cpp:534-562)
+ELLC_HD void concat_origin_f32(const float a[6], const float b[6], float dest[6]) {
+  float A[12], B[12], Bi[12], C[12];
+  exp_se3_f32(a, A);
+  exp_se3_f32(b, B);
+  invert_f32(B, Bi);
+  compose_f32(A, Bi, C);
+  log_se3_f32(C, dest);
+}
+
+}  // namespace ellc

@@ -1,0 +1,179 @@
+/*
+ * ellc_abi.h — C ABI of libellc_hip.so, the MI355X (gfx950) implementation of ELLC's per-keyframe
+ * data-parallel hot path: pyramidal direct image alignment (Gauss-Newton on se(3)) and the semi-dense
+ * inverse-depth map update.
+ *
+ * The reference has no plugin/FFI layer: the seam is the C++ object API that main.cpp and
+ * GlobalOptimize.cpp call (frame, PixelWisePyramid, depthMap, GetImagePoseEstimate).  Each entry point
+ * below names the reference member(s) it replaces (file:line under the reference's src/).  The C++
+ * facade with the reference's own class/method names lives in ellc_facade.hpp and calls only this ABI.
+ *
+ * Conventions
+ *   - every function returns an ellc_status (0 = ok, negative = error); numeric degeneracy is not an
+ *     error (singular 6x6 H => zero update, as cv::Mat::inv returns zeros, PixelWisePyramid.cpp:451).
+ *   - all pointers are HOST pointers unless the parameter name ends in _dev.
+ *   - pose = 6 f32 [wx wy wz vx vy vz] (rotation first, PixelWisePyramid.cpp:153).
+ *   - images are u8 row-major W x H; depth / variance / weights are f32 row-major.
+ *   - a context owns one HIP stream; calls on one context are serialised by the caller, calls on
+ *     different contexts are independent (the reference's loop-closure thread, GlobalOptimize.cpp:241).
+ */
+#ifndef ELLC_ABI_H
+#define ELLC_ABI_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELLC_MAX_LEVELS 8
+#define ELLC_ABI_VERSION 1
+
+typedef enum {
+  ELLC_OK = 0,
+  ELLC_ERR_BAD_ARG = -1,
+  ELLC_ERR_HIP = -2,
+  ELLC_ERR_NOT_READY = -3,   /* slot never uploaded, depth map not initialised, ... */
+  ELLC_ERR_NO_DEVICE = -4,
+  ELLC_ERR_CAPACITY = -5
+} ellc_status;
+
+typedef enum {
+  ELLC_MODE_FCA = 0,  /* forward-compositional, per-iteration weights: calculatePixelWiseParallel, PixelWisePyramid.cpp:416-455 */
+  ELLC_MODE_ICA = 1   /* constant saved weights, template gradient: calculatePixelWiseParallelInvCompositional, :917-974 */
+} ellc_mode;
+
+/* Run-time form of the compile-time constants in ExternVariable.h:39-59 and main.cpp:34. */
+typedef struct {
+  int width, height;            /* ORIG_COLS, ORIG_ROWS */
+  int levels;                   /* MAX_PYRAMID_LEVEL (reference: 4) */
+  float fx, fy, cx, cy;         /* ORIG_FX, ORIG_FY, ORIG_CX, ORIG_CY */
+  int max_iter[ELLC_MAX_LEVELS];/* util::MAX_ITER, index = pyramid level (0 = finest) */
+  int early_exit;               /* 1: stop a level when weightedPose < 1 (ImageFunc.cpp:251-252) */
+  int max_keyframes;            /* keyframe (reference-side) slots resident in HBM */
+  int max_frames;               /* current-frame slots resident in HBM */
+  int max_batch;                /* largest B accepted by ellc_align */
+  int device;                   /* HIP device ordinal */
+} ellc_config;
+
+typedef struct ellc_ctx ellc_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+int ellc_abi_version(void);
+void ellc_default_config(ellc_config* cfg, int width, int height, int levels);
+ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out);
+ellc_status ellc_ctx_destroy(ellc_ctx* ctx);
+const char* ellc_last_error(const ellc_ctx* ctx);   /* human-readable text of the last failure */
+ellc_status ellc_sync(ellc_ctx* ctx);               /* hipStreamSynchronize on the context stream */
+void* ellc_stream(ellc_ctx* ctx);                   /* the context's hipStream_t (for event timing by callers) */
+
+/* ---- frame side: frame::frame / constructImagePyramids / calculateGradient / buildMaxGradients
+ *      (Frame.cpp:78-124, 170-182, 185-285, 618-674) -------------------------------------------------- */
+/* Upload a W x H u8 image into a current-frame slot; builds the u8 pyramid on device (cv::pyrDown). */
+ellc_status ellc_frame_upload(ellc_ctx* ctx, int slot, const uint8_t* image);
+/* Same for a keyframe slot (the reference-side / template frame of an alignment). Also builds
+ * maxAbsGradient (level 0). */
+ellc_status ellc_keyframe_upload(ellc_ctx* ctx, int slot, const uint8_t* image);
+/* Copy a frame slot's pyramid into a keyframe slot on device (depthMap::createKeyFrame makes the tracked
+ * frame the next keyframe, DepthPropagation.cpp:1772). */
+ellc_status ellc_keyframe_from_frame(ellc_ctx* ctx, int kf_slot, int frame_slot);
+/* Read back pyramid level `level` of a slot (is_keyframe selects the slot table). out holds
+ * stored_w*stored_h bytes; stored sizes follow pyrDown's ceil rule. Any size pointer may be NULL. */
+ellc_status ellc_get_image_level(ellc_ctx* ctx, int is_keyframe, int slot, int level, uint8_t* out,
+                                 int* stored_w, int* stored_h, int* cols, int* rows);
+/* frame::calculateGradient at `level` (Frame.cpp:185-285): gx, gy each rows*cols f32. */
+ellc_status ellc_get_gradient(ellc_ctx* ctx, int is_keyframe, int slot, int level, float* gx, float* gy);
+/* frame::buildMaxGradients (Frame.cpp:618-674): W*H f32 and the count of pixels >= MIN_ABS_GRAD_DECREASE. */
+ellc_status ellc_get_max_gradient(ellc_ctx* ctx, int is_keyframe, int slot, float* out, int* n_substantial);
+
+/* ---- keyframe depth / variance / weights pyramids -------------------------------------------------- */
+/* keyFrame->depth (0 = no hypothesis) and depthMap::depthvararrpyr0 (-1 = none), W*H f32 each; builds
+ * levels 1.. on device as depthMap::buildInvVarDepth + mapDepthArr2Mat do (DepthPropagation.cpp:1637-1746). */
+ellc_status ellc_keyframe_set_depth(ellc_ctx* ctx, int slot, const float* depth0, const float* var0);
+/* Explicit per-level override: frame::depth_pyramid[level] and depthMap::depthvararrptr[level]. */
+ellc_status ellc_keyframe_set_depth_level(ellc_ctx* ctx, int slot, int level, const float* depth, const float* var);
+ellc_status ellc_keyframe_get_depth_level(ellc_ctx* ctx, int slot, int level, float* depth, float* var);
+/* frame::weight_pyramid[level] / numWeightsAdded[level] (Frame.h:57,73). */
+ellc_status ellc_keyframe_set_weights(ellc_ctx* ctx, int slot, int level, const float* weights, int num_added);
+ellc_status ellc_keyframe_get_weights(ellc_ctx* ctx, int slot, int level, float* weights, int* num_added);
+/* frame::finaliseWeights (Frame.cpp:678-695). */
+ellc_status ellc_keyframe_finalise_weights(ellc_ctx* ctx, int slot);
+
+/* ---- alignment: GetImagePoseEstimate (ImageFunc.cpp:49-315) ----------------------------------------
+ * B independent alignments: alignment b aligns frame slot frame_slots[b] to keyframe slot kf_slots[b],
+ * starting from init_pose[b] (the relative pose the reference derives at ImageFunc.cpp:106), visiting
+ * levels (levels-1 .. 0) with up to max_iter[level] Gauss-Newton iterations each.
+ *   mode            ELLC_MODE_FCA or ELLC_MODE_ICA (fromLoopClosure with FLAG_DO_CONST_WEIGHT_POSE_ESTIMATION)
+ *   save_weights    1: add the last executed iteration's weights of every level into the keyframe's
+ *                   weight_pyramid (PixelWisePyramid::saveWeights(true), :544-549; ImageFunc.cpp:280-288)
+ *   out_pose        B*6 f32 relative poses
+ *   out_iters       B*levels ints: iterations executed per level (may be NULL)
+ *   out_weighted    B f32: weightedPose of the last executed iteration (may be NULL)
+ */
+ellc_status ellc_align(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, const float* init_pose,
+                       int mode, int save_weights, float* out_pose, int* out_iters, float* out_weighted);
+/* Asynchronous form: enqueue only; results stay on device until ellc_align_fetch. */
+ellc_status ellc_align_enqueue(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, const float* init_pose,
+                               int mode, int save_weights);
+ellc_status ellc_align_fetch(ellc_ctx* ctx, int B, float* out_pose, int* out_iters, float* out_weighted);
+
+/* One Gauss-Newton iteration at one level, for parity tests (PixelWisePyramid::calculatePixelWiseParallel
+ * or ...InvCompositional(iter)): returns H (6x6 row-major), b, delta = -Hinv*b, the updated pose
+ * log(exp(delta)*exp(pose)) and weightedPose (:460-491). iter == 0 in ICA mode runs the precompute.
+ * planes (optional, may be NULL): 10 f32 planes rows*cols each in this order: residual, weight,
+ * warpedX, warpedY, J0..J5 (display_iterationres, display_weightimg, savedWarpedPointsX/Y, steepest descent). */
+ellc_status ellc_gn_iterate(ellc_ctx* ctx, int kf_slot, int frame_slot, int level, int mode, int iter, const float* pose,
+                            float* H36, float* b6, float* delta6, float* new_pose6, float* weighted, float* planes);
+
+/* se(3) helpers used by callers (frame::concatenateRelativePose Frame.cpp:503-530,
+ * frame::concatenateOriginPose :534-562); host-side, no device work. */
+void ellc_concatenate_relative_pose(const float* src_1wrt2, const float* src_2wrt3, float* dest_1wrt3);
+void ellc_concatenate_origin_pose(const float* src_1wrt0, const float* src_2wrt0, float* dest_1wrt2);
+void ellc_se3_exp(const float* pose6, float* T16);
+void ellc_se3_log(const float* T16, float* pose6);
+
+/* ---- semi-dense depth map: class depthMap (DepthPropagation.cpp) -----------------------------------
+ * One depth map per context (the reference's currentDepthMap). State is SoA on device:
+ * invDepth, invDepthSmoothed, variance, varianceSmoothed f32; validity_counter, blacklisted i32; isValid u8
+ * (DepthHypothesis.h:14-40, live fields). */
+typedef struct {
+  float* invDepth; float* invDepthSmoothed; float* variance; float* varianceSmoothed;
+  int32_t* validity_counter; int32_t* blacklisted; uint8_t* isValid;
+} ellc_hypotheses;   /* seven host arrays of W*H elements */
+
+ellc_status ellc_depth_set_state(ellc_ctx* ctx, const ellc_hypotheses* host);
+ellc_status ellc_depth_get_state(ellc_ctx* ctx, const ellc_hypotheses* host);
+/* depthMap::keyFrame = keyframe slot (main.cpp:232, 307; DepthPropagation.cpp:1772). */
+ellc_status ellc_depth_set_keyframe(ellc_ctx* ctx, int kf_slot);
+/* depthMap::propagateDepth(new_keyframe) (:1003-1157). new_kf_slot holds the new keyframe's image;
+ * pose_new_wrt_old = new_keyframe->poseWrtOrigin (old keyframe is the origin). */
+ellc_status ellc_depth_propagate(ellc_ctx* ctx, int new_kf_slot, const float* pose_new_wrt_old);
+/* depthMap::observeDepthRowParallel (:1932-1958, :191-263, line stereo :397-885) against frame slot
+ * `frame_slot` whose pose w.r.t. the keyframe is pose_frame_wrt_kf (frame::poseWrtOrigin). */
+ellc_status ellc_depth_observe(ellc_ctx* ctx, int frame_slot, const float* pose_frame_wrt_kf);
+ellc_status ellc_depth_fill_holes(ellc_ctx* ctx);                         /* fillDepthHoles :1317-1400 */
+ellc_status ellc_depth_regularize(ellc_ctx* ctx, int remove_occlusions);  /* regularizeDepthMap :1436-1543 */
+ellc_status ellc_depth_make_inv_depth_one(ellc_ctx* ctx, float* rescale_factor); /* makeInvDepthOne :1546-1587 */
+/* depthMap::updateDepthImage (:1254-1315): exports depth / variance pyramids into the keyframe slot
+ * (what GetImagePoseEstimate then reads). */
+ellc_status ellc_depth_update_depth_image(ellc_ctx* ctx);
+/* depthMap::createKeyFrame(new_keyframe) (:1758-1794): propagate, regularise(occlusions), fill+regularise,
+ * rescale, export; the new slot becomes the depth map's keyframe. */
+ellc_status ellc_depth_create_keyframe(ellc_ctx* ctx, int new_kf_slot, const float* pose_new_wrt_old, float* rescale_factor);
+ellc_status ellc_depth_seeds(ellc_ctx* ctx, float* percent);              /* calculate_no_of_Seeds :1804-1830 */
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------------- */
+/* Launch the dominant kernel (FCA residual/Jacobian/accumulate at `level` over a batch) `reps` times on
+ * the context stream between two HIP events; returns the average milliseconds per launch and the
+ * algorithmic bytes one launch covers (4*N + 14*V summed over the batch). */
+ellc_status ellc_profile_gn_kernel(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, int level, int reps,
+                                   float* avg_ms, double* algorithmic_bytes, long long* valid_pixels);
+/* Time `reps` full ellc_align_enqueue passes with HIP events on the context stream (ms per pass). */
+ellc_status ellc_profile_align(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, const float* init_pose,
+                               int mode, int reps, float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELLC_ABI_H */

@@ -442,9 +442,9 @@ void Frame::buildMaxGradients() { build_max_gradients(gradientx, gradienty, maxA
 void Frame::finaliseWeights() {
   for (int l = cfg.levels - 1; l >= 0; l--)
     if (numWeightsAdded[l] > 0) {
-      // cv: Mat / int -> MatExpr scale by 1.0/n in double, result rounded to f32
-      double s = 1.0 / (double)numWeightsAdded[l];
-      for (auto& v : weight_pyramid[l].d) v = (float)((double)v * s);
+      // cv: Mat / int -> MatExpr a*(1/n) -> convertTo(32f->32f): work type f32, scale = (float)(1.0/n)
+      float s = (float)(1.0 / (double)numWeightsAdded[l]);
+      for (auto& v : weight_pyramid[l].d) v = v * s + 0.0f;
     }
 }
 
