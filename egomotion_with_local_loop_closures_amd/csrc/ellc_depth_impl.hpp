@@ -1,0 +1,267 @@
+// Semi-dense depth map entry points of the C ABI (class depthMap, DepthPropagation.cpp).
+// Included at the end of ellc_hip.hip (the library is one translation unit).
+#pragma once
+#include "ellc_context.hpp"
+#include "ellc_kernels_depth.hpp"
+#include <cstring>
+
+using namespace ellc;
+
+namespace {
+
+dim3 grid2(int w, int h, dim3 blk) { return dim3((w + blk.x - 1) / blk.x, (h + blk.y - 1) / blk.y); }
+
+// frame::calculateSE3poseOtherWrtThis (Frame.cpp:376-413) for a frame whose poseWrtOrigin is `pose`
+// against the keyframe (poseWrtOrigin = 0): 12-float [R|t] of Other-w.r.t.-This and This-w.r.t.-Other,
+// plus K*R, K*t of both (f32 products, summed left to right as Eigen's 3x3 f32 product does).
+struct RelMats {
+  float otw[12], two[12];
+  float K_two_r[9], K_two_t[3];
+};
+RelMats relative_matrices(const ellc_ctx* c, const float* pose) {
+  RelMats m;
+  const float zero[6] = {0, 0, 0, 0, 0, 0};
+  float rel[6];
+  concat_origin_f32(zero, pose, rel);   // concatenateOriginPose(other->poseWrtOrigin, poseWrtOrigin, .)
+  exp_se3_f32(rel, m.otw);
+  invert_f32(m.otw, m.two);
+  for (int r = 0; r < 3; r++) {
+    for (int q = 0; q < 3; q++) {
+      float s = 0;
+      for (int k = 0; k < 3; k++) s += c->Kmat[r * 3 + k] * m.two[k * 4 + q];
+      m.K_two_r[r * 3 + q] = s;
+    }
+    float s = 0;
+    for (int k = 0; k < 3; k++) s += c->Kmat[r * 3 + k] * m.two[k * 4 + 3];
+    m.K_two_t[r] = s;
+  }
+  return m;
+}
+
+void swap_maps(ellc_ctx* c) { std::swap(c->dm_cur, c->dm_oth); }
+
+ellc_status need_map(ellc_ctx* c) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  if (!c->dm_ready) return fail(c, ELLC_ERR_NOT_READY, "depth map: call ellc_depth_set_state and ellc_depth_set_keyframe first");
+  return ELLC_OK;
+}
+
+ellc_status do_regularize(ellc_ctx* c, int removeOcclusions) {
+  const int W = c->cfg.width, H = c->cfg.height;
+  dim3 blk(32, 8);
+  hipLaunchKernelGGL(dm_regularize, grid2(W, H, blk), blk, 0, c->stream, c->dm_cur, c->dm_oth, W, H, removeOcclusions);
+  ELLC_HIP(c, hipGetLastError());
+  swap_maps(c);
+  return ELLC_OK;
+}
+
+ellc_status do_fill_holes(ellc_ctx* c) {
+  const int W = c->cfg.width, H = c->cfg.height;
+  dim3 blk(32, 8);
+  hipLaunchKernelGGL(dm_fill_holes, grid2(W, H, blk), blk, 0, c->stream, c->dm_cur, c->dm_oth, c->kf_maxgrad[c->dm_kf_slot], W, H);
+  ELLC_HIP(c, hipGetLastError());
+  swap_maps(c);
+  return ELLC_OK;
+}
+
+ellc_status do_rescale(ellc_ctx* c, float* factor_out) {
+  const int n = c->cfg.width * c->cfg.height;
+  const int nb = 256;
+  hipLaunchKernelGGL(dm_sum_stage1, dim3(nb), dim3(256), 0, c->stream, c->dm_cur, n, c->red_scratch);
+  hipLaunchKernelGGL(dm_sum_stage2, dim3(1), dim3(64), 0, c->stream, c->red_scratch, nb, c->red_scratch + 2 * nb);
+  const float* factor_d = (const float*)(c->red_scratch + 2 * nb + 2);
+  hipLaunchKernelGGL(dm_rescale, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dm_cur, n, factor_d);
+  ELLC_HIP(c, hipGetLastError());
+  float f = 0;
+  ELLC_HIP(c, hipMemcpyAsync(&f, factor_d, 4, hipMemcpyDeviceToHost, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  c->dm_depth_scale = f;
+  c->dm_global_scale *= f;   // util::GLOABL_DEPTH_SCALE, kept per context
+  if (factor_out) *factor_out = f;
+  return ELLC_OK;
+}
+
+ellc_status do_update_depth_image(ellc_ctx* c) {
+  const int W = c->cfg.width, H = c->cfg.height;
+  const KfLevelDev& k = c->kf_tab_h[c->dm_kf_slot];
+  dim3 blk(32, 8);
+  hipLaunchKernelGGL(dm_export_level0, grid2(W, H, blk), blk, 0, c->stream, c->dm_cur, k.depth, k.var, W, H);
+  ELLC_HIP(c, hipGetLastError());
+  ellc_status s = build_depth_pyramid(c, c->dm_kf_slot);   // buildInvVarDepth + mapDepthArr2Mat
+  if (s != ELLC_OK) return s;
+  c->kf_has_depth[c->dm_kf_slot] = 1;
+  return ELLC_OK;
+}
+
+ellc_status do_propagate(ellc_ctx* c, int new_kf_slot, const float* pose_new_wrt_old) {
+  if (new_kf_slot < 0 || new_kf_slot >= c->cfg.max_keyframes || !pose_new_wrt_old) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (!c->kf_has_image[new_kf_slot]) return fail(c, ELLC_ERR_NOT_READY, "new keyframe slot has no image");
+  if (!c->kf_maxgrad_valid[new_kf_slot]) {
+    ellc_status s = build_maxgrad(c, true, new_kf_slot);
+    if (s != ELLC_OK) return s;
+  }
+  const int W = c->cfg.width, H = c->cfg.height, n = W * H;
+  const RelMats m = relative_matrices(c, pose_new_wrt_old);
+  PropArgs a;
+  a.src = c->dm_cur;
+  a.dst = c->dm_oth;
+  a.oldImg = c->kf_tab_h[c->dm_kf_slot].img;
+  a.newImg = c->kf_tab_h[new_kf_slot].img;
+  a.newMaxGrad = c->kf_maxgrad[new_kf_slot];
+  a.W = W; a.H = H; a.sw = c->geom_h[0].sw;
+  for (int r = 0; r < 3; r++) {
+    for (int q = 0; q < 3; q++) a.R[r * 3 + q] = m.two[r * 4 + q];
+    a.t[r] = m.two[r * 4 + 3];
+  }
+  a.fx = c->cfg.fx; a.fy = c->cfg.fy; a.cx = c->cfg.cx; a.cy = c->cfg.cy;
+  a.fxi = c->Kinv[0]; a.cxi = c->Kinv[2]; a.fyi = c->Kinv[4]; a.cyi = c->Kinv[5];
+  a.tgt = c->pr_tgt; a.nid = c->pr_id; a.nvar = c->pr_var; a.nval = c->pr_val; a.winner = c->pr_winner; a.remaining = c->pr_remaining;
+  dim3 blk(32, 8);
+  hipLaunchKernelGGL(dm_prop_project, grid2(W, H, blk), blk, 0, c->stream, a);
+  // rounds: at most as many as the deepest collision chain; checked every 4 rounds
+  for (int guard = 0; guard < 64; guard++) {
+    int remaining = 0;
+    for (int r = 0; r < 4; r++) {
+      ELLC_HIP(c, hipMemsetAsync(c->pr_remaining, 0, 4, c->stream));
+      hipLaunchKernelGGL(dm_prop_select, dim3((n + 255) / 256), dim3(256), 0, c->stream, a, n);
+      hipLaunchKernelGGL(dm_prop_apply, dim3((n + 255) / 256), dim3(256), 0, c->stream, a, n);
+    }
+    ELLC_HIP(c, hipGetLastError());
+    ELLC_HIP(c, hipMemcpyAsync(&remaining, c->pr_remaining, 4, hipMemcpyDeviceToHost, c->stream));
+    ELLC_HIP(c, hipStreamSynchronize(c->stream));
+    if (remaining == 0) break;
+  }
+  swap_maps(c);   // std::swap(currentDepthHypothesis, otherDepthHypothesis) (:1154)
+  return ELLC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+ellc_status ellc_depth_set_state(ellc_ctx* c, const ellc_hypotheses* h) {
+  if (!c || !h || !h->invDepth || !h->invDepthSmoothed || !h->variance || !h->varianceSmoothed || !h->validity_counter || !h->blacklisted || !h->isValid)
+    return fail(c, ELLC_ERR_BAD_ARG, "ellc_depth_set_state: null array");
+  const size_t n = (size_t)c->cfg.width * c->cfg.height;
+  const DepthSoA& d = c->dm_cur;
+  ELLC_HIP(c, hipMemcpyAsync(d.invDepth, h->invDepth, n * 4, hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipMemcpyAsync(d.invDepthSmoothed, h->invDepthSmoothed, n * 4, hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipMemcpyAsync(d.variance, h->variance, n * 4, hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipMemcpyAsync(d.varianceSmoothed, h->varianceSmoothed, n * 4, hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipMemcpyAsync(d.validity, h->validity_counter, n * 4, hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipMemcpyAsync(d.blacklisted, h->blacklisted, n * 4, hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipMemcpyAsync(d.isValid, h->isValid, n, hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  c->dm_ready = (c->dm_kf_slot >= 0);
+  return ELLC_OK;
+}
+
+ellc_status ellc_depth_get_state(ellc_ctx* c, const ellc_hypotheses* h) {
+  if (!c || !h) return fail(c, ELLC_ERR_BAD_ARG, "ellc_depth_get_state: null");
+  const size_t n = (size_t)c->cfg.width * c->cfg.height;
+  const DepthSoA& d = c->dm_cur;
+  if (h->invDepth) ELLC_HIP(c, hipMemcpyAsync(h->invDepth, d.invDepth, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (h->invDepthSmoothed) ELLC_HIP(c, hipMemcpyAsync(h->invDepthSmoothed, d.invDepthSmoothed, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (h->variance) ELLC_HIP(c, hipMemcpyAsync(h->variance, d.variance, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (h->varianceSmoothed) ELLC_HIP(c, hipMemcpyAsync(h->varianceSmoothed, d.varianceSmoothed, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (h->validity_counter) ELLC_HIP(c, hipMemcpyAsync(h->validity_counter, d.validity, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (h->blacklisted) ELLC_HIP(c, hipMemcpyAsync(h->blacklisted, d.blacklisted, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (h->isValid) ELLC_HIP(c, hipMemcpyAsync(h->isValid, d.isValid, n, hipMemcpyDeviceToHost, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  return ELLC_OK;
+}
+
+ellc_status ellc_depth_set_keyframe(ellc_ctx* c, int kf_slot) {
+  if (!c || kf_slot < 0 || kf_slot >= c->cfg.max_keyframes) return fail(c, ELLC_ERR_BAD_ARG, "bad keyframe slot");
+  if (!c->kf_has_image[kf_slot]) return fail(c, ELLC_ERR_NOT_READY, "keyframe slot has no image");
+  c->dm_kf_slot = kf_slot;
+  c->dm_ready = true;
+  return ELLC_OK;
+}
+
+ellc_status ellc_depth_propagate(ellc_ctx* c, int new_kf_slot, const float* pose_new_wrt_old) {
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  return do_propagate(c, new_kf_slot, pose_new_wrt_old);
+}
+
+ellc_status ellc_depth_observe(ellc_ctx* c, int frame_slot, const float* pose_frame_wrt_kf) {
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  if (frame_slot < 0 || frame_slot >= c->cfg.max_frames || !pose_frame_wrt_kf) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (!c->fr_has_image[frame_slot]) return fail(c, ELLC_ERR_NOT_READY, "frame slot has no image");
+  const RelMats m = relative_matrices(c, pose_frame_wrt_kf);   // observeDepthRowParallel :1935
+  ObsArgs a;
+  a.s = c->dm_cur;
+  a.kfImg = c->kf_tab_h[c->dm_kf_slot].img;
+  a.curImg = c->fr_tab_h[frame_slot].img;
+  a.kfMaxGrad = c->kf_maxgrad[c->dm_kf_slot];
+  a.W = c->cfg.width; a.H = c->cfg.height; a.sw = c->geom_h[0].sw;
+  a.fx = c->cfg.fx; a.fy = c->cfg.fy; a.cx = c->cfg.cx; a.cy = c->cfg.cy;
+  a.fxi = c->Kinv[0]; a.cxi = c->Kinv[2]; a.fyi = c->Kinv[4]; a.cyi = c->Kinv[5];
+  for (int r = 0; r < 3; r++) {
+    a.otw_t[r] = m.otw[r * 4 + 3];
+    a.Kt[r] = m.K_two_t[r];
+    a.tt[r] = m.two[r * 4 + 3];
+    for (int q = 0; q < 3; q++) {
+      a.Kr[r * 3 + q] = m.K_two_r[r * 3 + q];
+      a.Rr[r * 3 + q] = m.two[r * 4 + q];
+    }
+  }
+  dim3 blk(32, 8);
+  hipLaunchKernelGGL(dm_observe, grid2(a.W, a.H, blk), blk, 0, c->stream, a);
+  ELLC_HIP(c, hipGetLastError());
+  return ELLC_OK;
+}
+
+ellc_status ellc_depth_fill_holes(ellc_ctx* c) {
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  return do_fill_holes(c);
+}
+
+ellc_status ellc_depth_regularize(ellc_ctx* c, int remove_occlusions) {
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  return do_regularize(c, remove_occlusions);
+}
+
+ellc_status ellc_depth_make_inv_depth_one(ellc_ctx* c, float* rescale_factor) {
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  return do_rescale(c, rescale_factor);
+}
+
+ellc_status ellc_depth_update_depth_image(ellc_ctx* c) {
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  return do_update_depth_image(c);
+}
+
+ellc_status ellc_depth_create_keyframe(ellc_ctx* c, int new_kf_slot, const float* pose_new_wrt_old, float* rescale_factor) {
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  if ((s = do_propagate(c, new_kf_slot, pose_new_wrt_old)) != ELLC_OK) return s;   // :1769
+  c->dm_kf_slot = new_kf_slot;                                                     // :1772
+  if ((s = do_regularize(c, 1)) != ELLC_OK) return s;                              // :1775
+  if ((s = do_fill_holes(c)) != ELLC_OK) return s;                                 // :1777 doRegularization(false)
+  if ((s = do_regularize(c, 0)) != ELLC_OK) return s;
+  if ((s = do_rescale(c, rescale_factor)) != ELLC_OK) return s;                    // :1779
+  return do_update_depth_image(c);                                                 // :1781
+}
+
+ellc_status ellc_depth_seeds(ellc_ctx* c, float* percent) {
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  const int n = c->cfg.width * c->cfg.height;
+  ELLC_HIP(c, hipMemsetAsync(c->pr_remaining, 0, 4, c->stream));
+  hipLaunchKernelGGL(dm_count_valid, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dm_cur, n, c->pr_remaining);
+  ELLC_HIP(c, hipGetLastError());
+  int cnt = 0;
+  ELLC_HIP(c, hipMemcpyAsync(&cnt, c->pr_remaining, 4, hipMemcpyDeviceToHost, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  if (percent) *percent = (float)cnt / (float)n * 100;   // count/(W*H)*100 (:1829)
+  return ELLC_OK;
+}
+
+}  // extern "C"

@@ -130,7 +130,7 @@ static void launch_solve(ellc_ctx* c, int level, int B, int nblk, int mode, int 
   s.nblk = nblk;
   s.mode = mode;
   s.early_exit = early_exit;
-  hipLaunchKernelGGL(gn_solve, dim3(B), dim3(64), 0, c->stream, s);
+  hipLaunchKernelGGL(gn_solve, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, s);
 }
 
 // stage slots / initial poses on the device and list the unique keyframe slots
@@ -681,3 +681,5 @@ ellc_status ellc_profile_align(ellc_ctx* c, int B, const int* kf_slots, const in
 }
 
 }  // extern "C"
+
+#include "ellc_depth_impl.hpp"

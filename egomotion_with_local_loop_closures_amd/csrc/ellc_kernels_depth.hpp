@@ -1,0 +1,646 @@
+// Semi-dense inverse-depth map kernels (reference: class depthMap, DepthPropagation.cpp). One thread per
+// pixel; hypotheses are held structure-of-arrays. Per-pixel arithmetic follows the reference's f32 expression
+// order with contraction off, so every stage except the global rescale sum is bit-reproducible on the CPU.
+#pragma once
+#include "ellc_context.hpp"
+#include "ellc_kernels_gn.hpp"
+
+namespace ellc {
+
+// ExternVariable.h constants (line numbers in comments)
+#define DM_MIN_ABS_GRAD_CREATE 1.0f        // :81
+#define DM_MIN_ABS_GRAD_DECREASE 5.0f      // :82
+#define DM_MIN_BLACKLIST (-1)              // :83
+#define DM_MAX_DIFF_CONSTANT (40.0f * 40.0f)   // :85
+#define DM_MAX_DIFF_GRAD_MULT (0.5f * 0.5f)    // :86
+#define DM_VAR_RANDOM_INIT_INITIAL 0.125f  // :88
+#define DM_MIN_EPL_GRAD_SQUARED (2.0f * 2.0f)      // :92
+#define DM_MIN_EPL_LENGTH_SQUARED (1.0f * 1.0f)    // :93
+#define DM_MIN_EPL_ANGLE_SQUARED (0.3f * 0.3f)     // :94
+#define DM_MIN_DEPTH 0.05f                 // :98
+#define DM_MAX_EPL_LENGTH_CROP 30.0f       // :101
+#define DM_MIN_EPL_LENGTH_CROP 3.0f        // :102
+#define DM_GRADIENT_SAMPLE_DIST 1.0f       // :105
+#define DM_SAMPLE_POINT_TO_BORDER 7.0f     // :108
+#define DM_MAX_ERROR_STEREO 1300.0f        // :111
+#define DM_MIN_DISTANCE_ERROR_STEREO 1.5f  // :112
+#define DM_STEREO_EPL_VAR_FAC 2.0f         // :115
+#define DM_DIVISION_EPS 1e-10f             // :117
+#define DM_CAMERA_PIXEL_NOISE 16           // :120
+#define DM_VALIDITY_COUNTER_INITIAL_OBSERVE 5   // :122
+#define DM_SUCC_VAR_INC_FAC 1.01f          // :124
+#define DM_FAIL_VAR_INC_FAC 1.1f           // :125
+#define DM_MAX_VAR (0.5f * 0.5f)           // :126
+#define DM_VALIDITY_COUNTER_MAX 5.0f       // :133
+#define DM_VALIDITY_COUNTER_MAX_VARIABLE 250.0f // :134
+#define DM_VALIDITY_COUNTER_DEC 5.0f       // :135
+#define DM_VALIDITY_COUNTER_INC 5.0f       // :136
+#define DM_VAL_SUM_MIN_FOR_CREATE 30.0f    // :141
+#define DM_VAL_SUM_MIN_FOR_UNBLACKLIST 100.0f   // :142
+#define DM_VAL_SUM_MIN_FOR_KEEP 24.0f      // :143
+#define DM_REG_DIST_VAR (0.075f * 0.075f * 1.0f * 1.0f)   // :145
+
+struct Hyp {
+  float id, ids, var, vars;
+  int validity, bl;
+  bool valid;
+};
+__device__ __forceinline__ Hyp hyp_load(const DepthSoA& s, int i) {
+  Hyp h;
+  h.id = s.invDepth[i]; h.ids = s.invDepthSmoothed[i]; h.var = s.variance[i]; h.vars = s.varianceSmoothed[i];
+  h.validity = s.validity[i]; h.bl = s.blacklisted[i]; h.valid = s.isValid[i] != 0;
+  return h;
+}
+__device__ __forceinline__ void hyp_store(const DepthSoA& s, int i, const Hyp& h) {
+  s.invDepth[i] = h.id; s.invDepthSmoothed[i] = h.ids; s.variance[i] = h.var; s.varianceSmoothed[i] = h.vars;
+  s.validity[i] = h.validity; s.blacklisted[i] = h.bl; s.isValid[i] = h.valid ? 1 : 0;
+}
+
+// u8 tap without the out-of-bounds sentinel (Frame.h:181, checkOutfBound = 0)
+__device__ __forceinline__ float tap_plain(const uint8_t* img, int sw, int cols, int rows, float x, float y) {
+  const Taps t = tap_point<false>(img, sw, cols, rows, x, y);
+  return (t.I == -1.0f) ? 0.0f : t.I;   // four zero samples interpolate to 0 (NaN coordinates: reference UB)
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthMap::regularizeDepthMap (:1436-1543). Reads `in` (the memcpy snapshot), writes every pixel of `out`.
+__global__ void dm_regularize(DepthSoA in, DepthSoA out, int W, int H, int removeOcclusions) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) return;
+  const int i = x + y * W;
+  Hyp d = hyp_load(in, i);
+  if (y >= 3 && y < H - 3 && x >= 2 && x < W - 2 && d.valid) {
+    float sum = 0.0f, val_sum = 0.0f, sumIvar = 0.0f;
+    int numOccluding = 0, numNotOccluding = 0;
+    for (int dx = -2; dx <= 2; dx++)
+      for (int dy = -2; dy <= 2; dy++) {
+        const int j = i + dx + dy * W;
+        if (!in.isValid[j]) continue;
+        const float sid = in.invDepth[j], svar = in.variance[j];
+        const float diff = sid - d.id;
+        if (1.0f * diff * diff > svar + d.var) {
+          if (removeOcclusions && sid > d.id) numOccluding++;
+          continue;
+        }
+        val_sum += (float)in.validity[j];
+        if (removeOcclusions) numNotOccluding++;
+        const float distFac = (float)(dx * dx + dy * dy) * DM_REG_DIST_VAR;
+        const float ivar = 1.0f / (svar + distFac);
+        sum += sid * ivar;
+        sumIvar += ivar;
+      }
+    if (val_sum < (float)(int)DM_VAL_SUM_MIN_FOR_KEEP) {
+      d.valid = false;
+      d.bl--;
+    } else if (removeOcclusions && numOccluding > numNotOccluding) {
+      d.valid = false;
+    } else {
+      sum = sum / sumIvar;
+      d.ids = unzero_f(sum);
+      d.vars = 1.0f / sumIvar;
+    }
+  }
+  hyp_store(out, i, d);
+}
+
+// depthMap::fillDepthHoles (:1317-1400) with buildValIntegralBuffer (:1403-1432) folded in: the reference
+// indexes a per-row prefix sum as if it were a 2-D integral image, which evaluates to
+//   val = sum_{x-2..x+2} validity(row y+2) - sum_{x-2..x+2} validity(row y-3)
+// with rows outside [3, H-3) contributing 0 (never written, zero-initialised).
+__global__ void dm_fill_holes(DepthSoA in, DepthSoA out, const float* __restrict__ maxgrad, int W, int H) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) return;
+  const int i = x + y * W;
+  Hyp d = hyp_load(in, i);
+  if (y >= 3 && y < H - 3 && x >= 3 && x < W - 2 && !d.valid && !(maxgrad[i] < DM_MIN_ABS_GRAD_DECREASE)) {
+    int val = 0;
+    const int ya = y + 2, yb = y - 3;
+    if (ya >= 3 && ya < H - 3)
+      for (int xx = x - 2; xx <= x + 2; xx++) { const int j = xx + ya * W; if (in.isValid[j]) val += in.validity[j]; }
+    if (yb >= 3 && yb < H - 3)
+      for (int xx = x - 2; xx <= x + 2; xx++) { const int j = xx + yb * W; if (in.isValid[j]) val -= in.validity[j]; }
+    if ((d.bl >= DM_MIN_BLACKLIST && (float)val > DM_VAL_SUM_MIN_FOR_CREATE) || (float)val > DM_VAL_SUM_MIN_FOR_UNBLACKLIST) {
+      float sumIdepthObs = 0.0f, sumIVarObs = 0.0f;
+      for (int yy = y - 2; yy < y + 3; yy++)
+        for (int xx = x - 2; xx < x + 3; xx++) {
+          const int j = xx + yy * W;
+          if (!in.isValid[j]) continue;
+          const float v = in.variance[j];
+          sumIdepthObs += in.invDepth[j] / v;
+          sumIVarObs += 1.0f / v;
+        }
+      float idepthObs = sumIdepthObs / sumIVarObs;
+      d.id = unzero_f(idepthObs);
+      d.var = DM_VAR_RANDOM_INIT_INITIAL;
+      d.validity = 0;
+      d.valid = true;
+      d.bl = 0;
+      d.ids = -1.0f;
+      d.vars = -1.0f;
+    }
+  }
+  hyp_store(out, i, d);
+}
+
+// depthMap::updateDepthImage (:1254-1315), per-pixel part: invalidate the 3-px border, export level 0
+__global__ void dm_export_level0(DepthSoA s, float* __restrict__ depthMat, float* __restrict__ vararr, int W, int H) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) return;
+  const int i = x + y * W;
+  bool valid = s.isValid[i] != 0;
+  if (y < 3 || y >= H - 3 || x < 3 || x >= W - 3) {
+    valid = false;
+    s.isValid[i] = 0;
+  }
+  const float ids = s.invDepthSmoothed[i];
+  if (valid && ids >= -0.05f) {
+    depthMat[i] = 1.0f / ids;
+    vararr[i] = s.varianceSmoothed[i];
+  } else {
+    depthMat[i] = 0.0f;
+    vararr[i] = -1.0f;
+  }
+}
+
+// depthMap::makeInvDepthOne (:1546-1587): sum of invDepthSmoothed over valid pixels and their count.
+// Stage 1: per-block f64 partials (fixed order); stage 2: one block combines them in block order.
+__global__ __launch_bounds__(256) void dm_sum_stage1(DepthSoA s, int n, double* __restrict__ part) {
+  double acc = 0.0, cnt = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    if (s.isValid[i]) { acc += (double)s.invDepthSmoothed[i]; cnt += 1.0; }
+  __shared__ double sa[256], sc[256];
+  sa[threadIdx.x] = acc; sc[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) { sa[threadIdx.x] += sa[threadIdx.x + off]; sc[threadIdx.x] += sc[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = sa[0]; part[2 * blockIdx.x + 1] = sc[0]; }
+}
+__global__ void dm_sum_stage2(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0, c = 0.0;
+  for (int b = 0; b < nblocks; b++) { a += part[2 * b]; c += part[2 * b + 1]; }
+  out[0] = a;
+  out[1] = c;
+  const float num = (float)c, sum = (float)a;
+  ((float*)(out + 2))[0] = num / sum;   // rescaleFactor = numIdepth / sumIdepth (f32)
+}
+__global__ void dm_rescale(DepthSoA s, int n, const float* __restrict__ factor) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !s.isValid[i]) return;
+  const float f = *factor, f2 = f * f;
+  s.invDepth[i] *= f;
+  s.invDepthSmoothed[i] *= f;
+  s.variance[i] *= f2;
+  s.varianceSmoothed[i] *= f2;
+}
+
+__global__ void dm_count_valid(DepthSoA s, int n, int* count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool v = (i < n) && s.isValid[i];
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthMap::propagateDepth (:1003-1157). The reference is a serial raster-order scatter whose collisions are
+// resolved by read-modify-write on the target. Here: (1) every valid source computes its candidate and target
+// in parallel; (2) rounds: in round r each target accepts the r-th source (in raster order) that maps to it
+// — selected with atomicMin on the source index — and applies the reference's occlusion / EKF-merge fold.
+// Targets are independent of one another, so this reproduces the serial result exactly.
+struct PropArgs {
+  DepthSoA src, dst;
+  const uint8_t* oldImg;     // old keyframe level-0 image
+  const uint8_t* newImg;     // new keyframe level-0 image
+  const float* newMaxGrad;   // new keyframe maxAbsGradient
+  int W, H, sw;
+  float R[9], t[3];          // new <- old (SE3poseThisWrtOther of the new keyframe)
+  float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
+  int* tgt; float* nid; float* nvar; int* nval; int* winner; int* remaining;
+};
+
+__global__ void dm_prop_project(PropArgs a) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= a.W || y >= a.H) return;
+  const int i = x + y * a.W;
+  // wipe the destination map (:1009-1014) and the per-target selection slot
+  a.dst.isValid[i] = 0;
+  a.dst.blacklisted[i] = 0;
+  a.winner[i] = 0x7fffffff;
+  int target = -1;
+  float new_idepth = 0.0f, new_var = 0.0f;
+  if (a.src.isValid[i]) {
+    const float ids = a.src.invDepthSmoothed[i];
+    const float k0 = (float)x * a.fxi + a.cxi, k1 = (float)y * a.fyi + a.cyi, k2 = 1.0f;
+    float pn[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const float s = (a.R[r * 3 + 0] * k0 + a.R[r * 3 + 1] * k1) + a.R[r * 3 + 2] * k2;
+      pn[r] = s / ids + a.t[r];
+    }
+    new_idepth = 1.0f / pn[2];
+    const float u_new = pn[0] * new_idepth * a.fx + a.cx;
+    const float v_new = pn[1] * new_idepth * a.fy + a.cy;
+    if (u_new > 2.1f && v_new > 2.1f && u_new < (float)a.W - 3.1f && v_new < (float)a.H - 3.1f) {
+      const int newIDX = (int)(u_new + 0.5f) + ((int)(v_new + 0.5f)) * a.W;
+      const float destAbsGrad = a.newMaxGrad[i];   // read at the SOURCE coordinates (Q14)
+      const float sourceColor = (float)a.oldImg[(size_t)y * a.sw + x];
+      const float destColor = tap_plain(a.newImg, a.sw, a.W, a.H, u_new, v_new);
+      const float residual = destColor - sourceColor;
+      const bool drop = (residual * residual / (DM_MAX_DIFF_CONSTANT + DM_MAX_DIFF_GRAD_MULT * destAbsGrad * destAbsGrad) > 1.0f) ||
+                        (destAbsGrad < DM_MIN_ABS_GRAD_DECREASE);
+      if (!drop) {
+        float r4 = new_idepth / ids;
+        r4 *= r4;
+        r4 *= r4;
+        new_var = r4 * a.src.invDepth[i];   // sic: inverse depth, not variance (Q14)
+        target = newIDX;
+      }
+    }
+  }
+  a.tgt[i] = target;
+  a.nid[i] = new_idepth;
+  a.nvar[i] = new_var;
+  a.nval[i] = a.src.validity[i];
+}
+
+__global__ void dm_prop_select(PropArgs a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = a.tgt[i];
+  if (t >= 0) atomicMin(&a.winner[t], i);
+}
+
+__global__ void dm_prop_apply(PropArgs a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = a.tgt[i];
+  if (t < 0) return;
+  if (a.winner[t] != i) {   // a lower-indexed source goes first; try again next round
+    atomicAdd(a.remaining, 1);
+    return;
+  }
+  const float new_idepth = a.nid[i], new_var = a.nvar[i];
+  const int src_validity = a.nval[i];
+  bool tvalid = a.dst.isValid[t] != 0;
+  bool skip = false;
+  if (tvalid) {   // occlusion check (:1090-1107)
+    const float tid = a.dst.invDepth[t];
+    const float diff = tid - new_idepth;
+    if (1.0f * diff * diff > new_var + a.dst.variance[t]) {
+      if (new_idepth < tid) skip = true;
+      else tvalid = false;
+    }
+  }
+  if (!skip) {
+    if (!tvalid) {
+      a.dst.invDepth[t] = new_idepth;
+      a.dst.variance[t] = new_var;
+      a.dst.varianceSmoothed[t] = -1.0f;
+      a.dst.invDepthSmoothed[t] = -1.0f;
+      a.dst.validity[t] = src_validity;
+      a.dst.isValid[t] = 1;
+      a.dst.blacklisted[t] = 0;
+    } else {   // EKF merge (:1124-1148)
+      const float tvar = a.dst.variance[t], tid = a.dst.invDepth[t];
+      const float w = new_var / (tvar + new_var);
+      const float merged = w * tid + (1.0f - w) * new_idepth;
+      int mv = src_validity + a.dst.validity[t];
+      if ((float)mv > DM_VALIDITY_COUNTER_MAX + DM_VALIDITY_COUNTER_MAX_VARIABLE) mv = (int)(DM_VALIDITY_COUNTER_MAX + DM_VALIDITY_COUNTER_MAX_VARIABLE);
+      a.dst.invDepth[t] = merged;
+      a.dst.variance[t] = 1.0f / (1.0f / tvar + 1.0f / new_var);
+      a.dst.validity[t] = mv;
+      a.dst.isValid[t] = 1;
+      a.dst.blacklisted[t] = 0;
+      a.dst.invDepthSmoothed[t] = -1.0f;
+      a.dst.varianceSmoothed[t] = -1.0f;
+    }
+  }
+  a.tgt[i] = -1;              // this source is done
+  a.winner[t] = 0x7fffffff;   // only the winner of the round resets its target's slot
+}
+
+// ------------------------------------------------------------------------------------------------
+// observe: depthMap::observeDepthRow (:191-263) -> observeDepthCreate (:267-308) / observeDepthUpdate (:888-999)
+// with makeAndCheckEPL (:311-384) and doLineStereo (:397-885).
+struct ObsArgs {
+  DepthSoA s;
+  const uint8_t* kfImg;      // keyframe level-0 image
+  const uint8_t* curImg;     // current frame level-0 image
+  const float* kfMaxGrad;
+  int W, H, sw;
+  float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
+  float otw_t[3];            // SE3poseOtherWrtThis_t of the current frame (keyframe w.r.t. current)
+  float Kr[9], Kt[3];        // K_SE3poseThisWrtOther_r / _t
+  float Rr[9], tt[3];        // SE3poseThisWrtOther_r / _t
+};
+
+__device__ __forceinline__ float dot3f(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+__device__ inline bool make_and_check_epl(const ObsArgs& a, int x, int y, float& pepx, float& pepy) {
+  const float epx = -a.fx * a.otw_t[0] + a.otw_t[2] * ((float)x - a.cx);
+  const float epy = -a.fy * a.otw_t[1] + a.otw_t[2] * ((float)y - a.cy);
+  const float se = epx + epy;
+  if (se != se) return false;
+  const float eplLengthSquared = epx * epx + epy * epy;
+  if (eplLengthSquared < DM_MIN_EPL_LENGTH_SQUARED) return false;
+  const uint8_t* c = a.kfImg + (size_t)y * a.sw;
+  const float gx = (float)((int)c[x + 1] - (int)c[x - 1]);
+  const float gy = (float)((int)c[x + a.sw] - (int)c[x - a.sw]);
+  float eplGradSquared = gx * epx + gy * epy;
+  eplGradSquared = eplGradSquared * eplGradSquared / eplLengthSquared;
+  if (eplGradSquared < DM_MIN_EPL_GRAD_SQUARED) return false;
+  if (eplGradSquared / (gx * gx + gy * gy) < DM_MIN_EPL_ANGLE_SQUARED) return false;
+  const float fac = DM_GRADIENT_SAMPLE_DIST / sqrtf(eplLengthSquared);
+  pepx = epx * fac;
+  pepy = epy * fac;
+  return true;
+}
+
+// returns the reference's float error code / best error; outputs valid when the return value is >= 0
+__device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float epxn, float epyn, float min_idepth, float prior_idepth,
+                                       float max_idepth, float& result_idepth, float& result_var) {
+  const int W = a.W, H = a.H;
+  const float NaNf = __builtin_nanf("");
+  float KinvP[3] = {a.fxi * u + a.cxi, a.fyi * v + a.cyi, 1.0f};
+  float pInf[3] = {dot3f(a.Kr, KinvP), dot3f(a.Kr + 3, KinvP), dot3f(a.Kr + 6, KinvP)};
+  const float pRealZ = pInf[2] / prior_idepth + a.Kt[2];
+  const float rescaleFactor = pRealZ * prior_idepth;
+  const float firstX = u - 2 * epxn * rescaleFactor, firstY = v - 2 * epyn * rescaleFactor;
+  const float lastX = u + 2 * epxn * rescaleFactor, lastY = v + 2 * epyn * rescaleFactor;
+  if (firstX <= 0 || firstX >= (float)(W - 2) || firstY <= 0 || firstY >= (float)(H - 2) || lastX <= 0 || lastX >= (float)(W - 2) ||
+      lastY <= 0 || lastY >= (float)(H - 2))
+    return -1.0f;
+  if (!(rescaleFactor > 0.7f && rescaleFactor < 1.4f)) return -1.0f;
+
+  const float realVal_p1 = tap_plain(a.kfImg, a.sw, W, H, u + epxn * rescaleFactor, v + epyn * rescaleFactor);
+  const float realVal_m1 = tap_plain(a.kfImg, a.sw, W, H, u - epxn * rescaleFactor, v - epyn * rescaleFactor);
+  const float realVal = tap_plain(a.kfImg, a.sw, W, H, u, v);
+  const float realVal_m2 = tap_plain(a.kfImg, a.sw, W, H, u - 2 * epxn * rescaleFactor, v - 2 * epyn * rescaleFactor);
+  const float realVal_p2 = tap_plain(a.kfImg, a.sw, W, H, u + 2 * epxn * rescaleFactor, v + 2 * epyn * rescaleFactor);
+
+  float pClose[3] = {pInf[0] + a.Kt[0] * max_idepth, pInf[1] + a.Kt[1] * max_idepth, pInf[2] + a.Kt[2] * max_idepth};
+  if (pClose[2] < 0.001f) {
+    max_idepth = (0.001f - pInf[2]) / a.Kt[2];
+    for (int i = 0; i < 3; i++) pClose[i] = pInf[i] + a.Kt[i] * max_idepth;
+  }
+  { const float z = pClose[2]; for (int i = 0; i < 3; i++) pClose[i] = pClose[i] / z; }
+  float pFar[3] = {pInf[0] + a.Kt[0] * min_idepth, pInf[1] + a.Kt[1] * min_idepth, pInf[2] + a.Kt[2] * min_idepth};
+  if (pFar[2] < 0.001f || max_idepth < min_idepth) return -1.0f;
+  { const float z = pFar[2]; for (int i = 0; i < 3; i++) pFar[i] = pFar[i] / z; }
+  { const float q = pFar[0] + pClose[0]; if (q != q) return -4.0f; }
+
+  float incx = pClose[0] - pFar[0];
+  float incy = pClose[1] - pFar[1];
+  const float eplLength = sqrtf(incx * incx + incy * incy);
+  if (eplLength == 0.0f || isinf(eplLength)) return -4.0f;   // reference: (!eplLength) > 0 || isinf
+  if (eplLength > DM_MAX_EPL_LENGTH_CROP) {
+    pClose[0] = pFar[0] + incx * DM_MAX_EPL_LENGTH_CROP / eplLength;
+    pClose[1] = pFar[1] + incy * DM_MAX_EPL_LENGTH_CROP / eplLength;
+  }
+  incx *= DM_GRADIENT_SAMPLE_DIST / eplLength;
+  incy *= DM_GRADIENT_SAMPLE_DIST / eplLength;
+  pFar[0] -= incx; pFar[1] -= incy;
+  pClose[0] += incx; pClose[1] += incy;
+  if (eplLength < DM_MIN_EPL_LENGTH_CROP) {
+    const float pad = (DM_MIN_EPL_LENGTH_CROP - (eplLength)) / 2.0f;
+    pFar[0] -= incx * pad; pFar[1] -= incy * pad;
+    pClose[0] += incx * pad; pClose[1] += incy * pad;
+  }
+  const float Bd = DM_SAMPLE_POINT_TO_BORDER;
+  const float WB = (float)W - Bd, HB = (float)H - Bd;
+  if (pFar[0] <= Bd || pFar[0] >= WB || pFar[1] <= Bd || pFar[1] >= HB) return -1.0f;
+  if (pClose[0] <= Bd || pClose[0] >= WB || pClose[1] <= Bd || pClose[1] >= HB) {
+    if (pClose[0] <= Bd) {
+      const float toAdd = (Bd - pClose[0]) / incx;
+      pClose[0] += toAdd * incx; pClose[1] += toAdd * incy;
+    } else if (pClose[0] >= WB) {
+      const float toAdd = (WB - pClose[0]) / incx;
+      pClose[0] += toAdd * incx; pClose[1] += toAdd * incy;
+    }
+    if (pClose[1] <= Bd) {
+      const float toAdd = (Bd - pClose[1]) / incy;
+      pClose[0] += toAdd * incx; pClose[1] += toAdd * incy;
+    } else if (pClose[1] >= HB) {
+      const float toAdd = (HB - pClose[1]) / incy;
+      pClose[0] += toAdd * incx; pClose[1] += toAdd * incy;
+    }
+    const float fincx = pClose[0] - pFar[0];
+    const float fincy = pClose[1] - pFar[1];
+    const float newEplLength = sqrtf(fincx * fincx + fincy * fincy);
+    if (pClose[0] <= Bd || pClose[0] >= WB || pClose[1] <= Bd || pClose[1] >= HB || newEplLength < 8.0f) return -1.0f;
+  }
+
+  float cpx = pFar[0], cpy = pFar[1];
+  float val_cp_m2 = tap_plain(a.curImg, a.sw, W, H, cpx - 2.0f * incx, cpy - 2.0f * incy);
+  float val_cp_m1 = tap_plain(a.curImg, a.sw, W, H, cpx - incx, cpy - incy);
+  float val_cp = tap_plain(a.curImg, a.sw, W, H, cpx, cpy);
+  float val_cp_p1 = tap_plain(a.curImg, a.sw, W, H, cpx + incx, cpy + incy);
+  float val_cp_p2;
+
+  int loopCounter = 0;
+  float best_match_x = -1, best_match_y = -1;
+  float best_match_err = __builtin_inff(), second_best_match_err = __builtin_inff();   // float = 1e50
+  float best_match_errPre = NaNf, best_match_errPost = NaNf, best_match_DiffErrPre = NaNf, best_match_DiffErrPost = NaNf;
+  bool bestWasLastLoop = false;
+  float eeLast = -1;
+  float e1A = NaNf, e1B = NaNf, e2A = NaNf, e2B = NaNf, e3A = NaNf, e3B = NaNf, e4A = NaNf, e4B = NaNf, e5A = NaNf, e5B = NaNf;
+  int loopCBest = -1, loopCSecond = -1;
+  // the walk is bounded: the segment is at most MAX_EPL_LENGTH_CROP + padding long and inside the image
+  const int loopCap = W + H;
+  while ((((incx < 0) == (cpx > pClose[0]) && (incy < 0) == (cpy > pClose[1])) || loopCounter == 0) && loopCounter < loopCap) {
+    val_cp_p2 = tap_plain(a.curImg, a.sw, W, H, cpx + 2 * incx, cpy + 2 * incy);
+    float ee = 0;
+    if (loopCounter % 2 == 0) {
+      e1A = val_cp_p2 - realVal_p2; ee += e1A * e1A;
+      e2A = val_cp_p1 - realVal_p1; ee += e2A * e2A;
+      e3A = val_cp - realVal;       ee += e3A * e3A;
+      e4A = val_cp_m1 - realVal_m1; ee += e4A * e4A;
+      e5A = val_cp_m2 - realVal_m2; ee += e5A * e5A;
+    } else {
+      e1B = val_cp_p2 - realVal_p2; ee += e1B * e1B;
+      e2B = val_cp_p1 - realVal_p1; ee += e2B * e2B;
+      e3B = val_cp - realVal;       ee += e3B * e3B;
+      e4B = val_cp_m1 - realVal_m1; ee += e4B * e4B;
+      e5B = val_cp_m2 - realVal_m2; ee += e5B * e5B;
+    }
+    if (ee < best_match_err) {
+      second_best_match_err = best_match_err;
+      loopCSecond = loopCBest;
+      best_match_err = ee;
+      loopCBest = loopCounter;
+      best_match_errPre = eeLast;
+      best_match_DiffErrPre = e1A * e1B + e2A * e2B + e3A * e3B + e4A * e4B + e5A * e5B;
+      best_match_errPost = -1;
+      best_match_DiffErrPost = -1;
+      best_match_x = cpx;
+      best_match_y = cpy;
+      bestWasLastLoop = true;
+    } else {
+      if (bestWasLastLoop) {
+        best_match_errPost = ee;
+        best_match_DiffErrPost = e1A * e1B + e2A * e2B + e3A * e3B + e4A * e4B + e5A * e5B;
+        bestWasLastLoop = false;
+      }
+      if (ee < second_best_match_err) {
+        second_best_match_err = ee;
+        loopCSecond = loopCounter;
+      }
+    }
+    eeLast = ee;
+    val_cp_m2 = val_cp_m1; val_cp_m1 = val_cp; val_cp = val_cp_p1; val_cp_p1 = val_cp_p2;
+    cpx += incx;
+    cpy += incy;
+    loopCounter++;
+  }
+  if (best_match_err > 4.0f * DM_MAX_ERROR_STEREO) return -3.0f;
+  {
+    int dl = loopCBest - loopCSecond;
+    if (dl < 0) dl = -dl;
+    if ((float)dl > 1.0f && DM_MIN_DISTANCE_ERROR_STEREO * best_match_err > second_best_match_err) return -2.0f;
+  }
+  bool didSubpixel = false;
+  {
+    const float gradPre_pre = -(best_match_errPre - best_match_DiffErrPre);
+    const float gradPre_this = +(best_match_err - best_match_DiffErrPre);
+    const float gradPost_this = -(best_match_err - best_match_DiffErrPost);
+    const float gradPost_post = +(best_match_errPost - best_match_DiffErrPost);
+    bool interpPost = false, interpPre = false;
+    if (best_match_errPre < 0 || best_match_errPost < 0) {
+    } else if ((gradPre_pre < 0) ^ (gradPre_this < 0)) {
+      if ((gradPost_post < 0) ^ (gradPost_this < 0)) {
+      } else interpPre = true;
+    } else if ((gradPost_post < 0) ^ (gradPost_this < 0)) {
+      interpPost = true;
+    }
+    if (interpPre) {
+      const float d = gradPre_this / (gradPre_this - gradPre_pre);
+      best_match_x -= d * incx;
+      best_match_y -= d * incy;
+      best_match_err = best_match_err - 2 * d * gradPre_this - (gradPre_pre - gradPre_this) * d * d;
+      didSubpixel = true;
+    } else if (interpPost) {
+      const float d = gradPost_this / (gradPost_this - gradPost_post);
+      best_match_x += d * incx;
+      best_match_y += d * incy;
+      best_match_err = best_match_err + 2 * d * gradPost_this + (gradPost_post - gradPost_this) * d * d;
+      didSubpixel = true;
+    }
+  }
+  const float sampleDist = DM_GRADIENT_SAMPLE_DIST * rescaleFactor;
+  float gradAlongLine = 0;
+  float tmp = realVal_p2 - realVal_p1; gradAlongLine += tmp * tmp;
+  tmp = realVal_p1 - realVal; gradAlongLine += tmp * tmp;
+  tmp = realVal - realVal_m1; gradAlongLine += tmp * tmp;
+  tmp = realVal_m1 - realVal_m2; gradAlongLine += tmp * tmp;
+  gradAlongLine /= sampleDist * sampleDist;
+  if (best_match_err > DM_MAX_ERROR_STEREO + sqrtf(gradAlongLine) * 20) return -3.0f;
+
+  float idnew_best_match, alpha;
+  if (incx * incx > incy * incy) {
+    const float oldX = a.fxi * best_match_x + a.cxi;
+    const float nominator = (oldX * a.tt[2] - a.tt[0]);
+    const float dot0 = dot3f(KinvP, a.Rr);
+    const float dot2 = dot3f(KinvP, a.Rr + 6);
+    idnew_best_match = (dot0 - oldX * dot2) / nominator;
+    alpha = incx * a.fxi * (dot0 * a.tt[2] - dot2 * a.tt[0]) / (nominator * nominator);
+  } else {
+    const float oldY = a.fyi * best_match_y + a.cyi;
+    const float nominator = (oldY * a.tt[2] - a.tt[1]);
+    const float dot1 = dot3f(KinvP, a.Rr + 3);
+    const float dot2 = dot3f(KinvP, a.Rr + 6);
+    idnew_best_match = (dot1 - oldY * dot2) / nominator;
+    alpha = incy * a.fxi * (dot1 * a.tt[2] - dot2 * a.tt[1]) / (nominator * nominator);   // FX_INV, as the reference (Q19)
+  }
+  if (idnew_best_match < 0) return -2.0f;
+  const float photoDispError = 4.0f * (float)DM_CAMERA_PIXEL_NOISE / (gradAlongLine + DM_DIVISION_EPS);
+  const float trackingErrorFac = 0.25f * 1.0f;
+  const Taps gt = tap_point<true>(a.kfImg, a.sw, W, H, u, v);
+  const float g0 = gt.gx, g1 = gt.gy;
+  float geoDispError = (g0 * epxn + g1 * epyn) + DM_DIVISION_EPS;
+  geoDispError = trackingErrorFac * trackingErrorFac * (g0 * g0 + g1 * g1) / (geoDispError * geoDispError);
+  result_var = alpha * alpha * ((didSubpixel ? 0.05f : 0.5f) * sampleDist * sampleDist + geoDispError + photoDispError);
+  result_idepth = idnew_best_match;
+  return best_match_err;
+}
+
+__global__ __launch_bounds__(256) void dm_observe(ObsArgs a) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x < 3 || x >= a.W - 3 || y < 3 || y >= a.H - 3) return;
+  const int idx = x + y * a.W;
+  Hyp t = hyp_load(a.s, idx);
+  const bool hasHypothesis = t.valid;
+  const float mg = a.kfMaxGrad[idx];
+  if (hasHypothesis && mg < DM_MIN_ABS_GRAD_DECREASE) {
+    a.s.isValid[idx] = 0;
+    return;
+  }
+  if (mg < DM_MIN_ABS_GRAD_CREATE || t.bl < DM_MIN_BLACKLIST) return;
+  float epx, epy;
+  if (!make_and_check_epl(a, x, y, epx, epy)) return;   // create: -1 / update: -5, no state change
+  if (!hasHypothesis) {
+    // observeDepthCreate
+    float rid = 0.0f, rvar = 0.0f;
+    const float error = do_line_stereo(a, (float)x, (float)y, epx, epy, 0.0f, 1.0f, 1.0f / DM_MIN_DEPTH, rid, rvar);
+    if (error == -3.0f || error == -2.0f) t.bl--;
+    if (error < 0 || rvar > DM_MAX_VAR) {
+      a.s.blacklisted[idx] = t.bl;
+      return;
+    }
+    t.id = unzero_f(rid);
+    t.var = rvar;
+    t.ids = -1.0f;
+    t.vars = -1.0f;
+    t.validity = DM_VALIDITY_COUNTER_INITIAL_OBSERVE;
+    t.valid = true;
+    t.bl = 0;
+    hyp_store(a.s, idx, t);
+  } else {
+    // observeDepthUpdate
+    const float sv = sqrtf(t.vars);
+    float min_idepth = t.ids - sv * DM_STEREO_EPL_VAR_FAC;
+    float max_idepth = t.ids + sv * DM_STEREO_EPL_VAR_FAC;
+    if (min_idepth < 0) min_idepth = 0;
+    if (max_idepth > 1 / DM_MIN_DEPTH) max_idepth = 1 / DM_MIN_DEPTH;
+    float rid = 0.0f, rvar = 0.0f;
+    const float error = do_line_stereo(a, (float)x, (float)y, epx, epy, min_idepth, t.ids, max_idepth, rid, rvar);
+    const float diff = rid - t.ids;
+    if (error == -1.0f) return;
+    if (error == -2.0f) {
+      t.validity = (int)((float)t.validity - DM_VALIDITY_COUNTER_DEC);
+      if (t.validity < 0) t.validity = 0;
+      t.var *= DM_FAIL_VAR_INC_FAC;
+      if (t.var > DM_MAX_VAR) {
+        t.valid = false;
+        t.bl--;
+      }
+      hyp_store(a.s, idx, t);
+      return;
+    }
+    if (error == -3.0f || error == -4.0f) return;
+    if (1.0f * diff * diff > rvar + t.vars) {
+      t.var *= DM_FAIL_VAR_INC_FAC;
+      if (t.var > DM_MAX_VAR) t.valid = false;
+      hyp_store(a.s, idx, t);
+      return;
+    }
+    float id_var = t.var * DM_SUCC_VAR_INC_FAC;
+    const float w = rvar / (rvar + id_var);
+    const float new_idepth = (1 - w) * rid + w * t.id;
+    t.id = unzero_f(new_idepth);
+    id_var = id_var * w;
+    if (id_var < t.var) t.var = id_var;
+    t.validity = (int)((float)t.validity + DM_VALIDITY_COUNTER_INC);
+    const float cap = DM_VALIDITY_COUNTER_MAX + mg * (DM_VALIDITY_COUNTER_MAX_VARIABLE) / 255.0f;
+    if ((float)t.validity > cap) t.validity = (int)cap;
+    hyp_store(a.s, idx, t);
+  }
+}
+
+}  // namespace ellc

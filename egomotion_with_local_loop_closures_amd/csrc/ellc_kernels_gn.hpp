@@ -357,35 +357,59 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
 // ---------------------------------------------------------------------------------------------------
 // cv::Mat::inv(DECOMP_LU) on a 6x6 f32 matrix (OpenCV 3.0.0 LUImpl on (A | I), partial pivoting,
 // |pivot| < FLT_EPSILON => singular => all-zero inverse; PixelWisePyramid.cpp:451).
-__device__ inline void lu_inverse6(const float* Hin, float* out) {
+// Lane j (0..5) of a wave carries right-hand-side column j; every lane eliminates its own copy of A, so
+// the rounding sequence per entry is the scalar algorithm's. All indices are compile-time (registers only).
+// On return x[i] = Hinv[i][lane].
+__device__ __forceinline__ void lu_inverse6_lanes(const float (&Hin)[36], int lane, float (&x)[6]) {
   float A[36];
-  for (int i = 0; i < 36; i++) { A[i] = Hin[i]; out[i] = 0.0f; }
-  for (int i = 0; i < 6; i++) out[i * 6 + i] = 1.0f;
+#pragma unroll
+  for (int i = 0; i < 36; i++) A[i] = Hin[i];
+#pragma unroll
+  for (int i = 0; i < 6; i++) x[i] = (i == lane) ? 1.0f : 0.0f;
+  bool singular = false;
+#pragma unroll
   for (int i = 0; i < 6; i++) {
     int k = i;
-    for (int j = i + 1; j < 6; j++)
-      if (fabsf(A[j * 6 + i]) > fabsf(A[k * 6 + i])) k = j;
-    if (fabsf(A[k * 6 + i]) < 1.1920928955078125e-07f) {
-      for (int q = 0; q < 36; q++) out[q] = 0.0f;
-      return;
+    float best = fabsf(A[i * 6 + i]);
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) {
+      const float v = fabsf(A[j * 6 + i]);
+      if (v > best) { best = v; k = j; }
     }
-    if (k != i) {
-      for (int j = i; j < 6; j++) { const float t = A[i * 6 + j]; A[i * 6 + j] = A[k * 6 + j]; A[k * 6 + j] = t; }
-      for (int j = 0; j < 6; j++) { const float t = out[i * 6 + j]; out[i * 6 + j] = out[k * 6 + j]; out[k * 6 + j] = t; }
+    if (best < 1.1920928955078125e-07f) singular = true;
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) {
+      const bool sw = (k == j);
+#pragma unroll
+      for (int q = i; q < 6; q++) {
+        const float a = A[i * 6 + q], b = A[j * 6 + q];
+        A[i * 6 + q] = sw ? b : a;
+        A[j * 6 + q] = sw ? a : b;
+      }
+      const float a = x[i], b = x[j];
+      x[i] = sw ? b : a;
+      x[j] = sw ? a : b;
     }
     const float d = -1.0f / A[i * 6 + i];
+#pragma unroll
     for (int j = i + 1; j < 6; j++) {
       const float alpha = A[j * 6 + i] * d;
+#pragma unroll
       for (int q = i + 1; q < 6; q++) A[j * 6 + q] += alpha * A[i * 6 + q];
-      for (int q = 0; q < 6; q++) out[j * 6 + q] += alpha * out[i * 6 + q];
+      x[j] += alpha * x[i];
     }
   }
-  for (int i = 5; i >= 0; i--)
-    for (int j = 0; j < 6; j++) {
-      float s = out[i * 6 + j];
-      for (int q = i + 1; q < 6; q++) s -= A[i * 6 + q] * out[q * 6 + j];
-      out[i * 6 + j] = s / A[i * 6 + i];
-    }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    float s = x[i];
+#pragma unroll
+    for (int q = i + 1; q < 6; q++) s -= A[i * 6 + q] * x[q];
+    x[i] = s / A[i * 6 + i];
+  }
+  if (singular) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = 0.0f;
+  }
 }
 
 struct SolveArgs {
@@ -396,57 +420,104 @@ struct SolveArgs {
   int early_exit;
 };
 
-// One 64-thread block per alignment: fixed-order f64 combine of the block partials, 6x6 solve,
-// weightedPose and pose <- log(exp(delta^) exp(pose^))  (PixelWisePyramid.cpp:441-491).
-__global__ __launch_bounds__(64) void gn_solve(SolveArgs a) {
+#define ELLC_SOLVE_THREADS 256
+
+// One block per alignment: fixed-order f64 combine of the block partials (all 256 threads load in parallel),
+// 6x6 LU inverse across six lanes, weightedPose and pose <- log(exp(delta^) exp(pose^)) on one lane
+// (PixelWisePyramid.cpp:441-491). Everything between the loads and the final stores lives in registers / LDS.
+__global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_solve(SolveArgs a) {
   const int b = blockIdx.x;
   AlignState& st = a.state[b];
   if (st.level_done == a.level) return;
+  __shared__ double part[ELLC_SOLVE_THREADS / 32][32];
   __shared__ double sums[32];
-  const int lane = threadIdx.x;
-  if (lane < 27) {
-    const float* p = a.partials + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE + lane;
+  __shared__ float sHinv[36];
+  __shared__ double sprod[36];
+  __shared__ float sdelta[6];
+  const int t = threadIdx.x;
+  const int comp = t & 31, grp = t >> 5;
+  {
+    const float* p = a.partials + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE + comp;
     double s = 0.0;
-    for (int k = 0; k < a.nblk; k++) s += (double)p[(size_t)k * ELLC_PART_STRIDE];
-    sums[lane] = s;
+    for (int k = grp; k < a.nblk; k += ELLC_SOLVE_THREADS / 32) s += (double)p[(size_t)k * ELLC_PART_STRIDE];
+    part[grp][comp] = s;
+  }
+  if (a.mode == 2 && t < 36) sHinv[t] = st.Hinv[t];   // ICA iterate: the level's precomputed inverse
+  __syncthreads();
+  if (t < 27) {
+    double s = part[0][t];
+#pragma unroll
+    for (int g = 1; g < ELLC_SOLVE_THREADS / 32; g++) s += part[g][t];
+    sums[t] = s;
   }
   __syncthreads();
-  if (lane != 0) return;
+  if (t >= 64) return;   // wave 0 finishes the job (no block-wide barrier below this line)
+  const int lane = t;
   if (a.mode != 2) {
-    int q = 0;
-    for (int r = 0; r < 6; r++)
-      for (int c = r; c < 6; c++) {
-        const float v = (float)sums[q++];
-        st.H[r * 6 + c] = v;
-        st.H[c * 6 + r] = v;
-      }
-    float Hinv[36];
-    lu_inverse6(st.H, Hinv);
-    for (int i = 0; i < 36; i++) st.Hinv[i] = Hinv[i];
-    if (a.mode == 1) return;
+    float Hm[36];
+    {
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = r; c < 6; c++) {
+          const float v = (float)sums[q++];
+          Hm[r * 6 + c] = v;
+          Hm[c * 6 + r] = v;
+        }
+    }
+    float x[6];
+    lu_inverse6_lanes(Hm, lane < 6 ? lane : 0, x);
+    if (lane < 6) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) sHinv[i * 6 + lane] = x[i];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 36; i++) st.H[i] = Hm[i];
+    }
   }
-  float bb[6];
-  for (int i = 0; i < 6; i++) { bb[i] = (float)sums[21 + i]; st.b[i] = bb[i]; }
-  // delta = -(Hinv * b)  (cv::gemm f32: products accumulated in double, rounded once)
-  float delta[6];
-  for (int i = 0; i < 6; i++) {
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  if (a.mode != 2 && lane < 36) st.Hinv[lane] = sHinv[lane];
+  if (a.mode == 1) return;
+  // delta = -(Hinv * b): cv::gemm f32 accumulates the products in double and rounds once
+  if (lane < 36) {
+    const int i = lane / 6, k = lane - 6 * i;
+    sprod[lane] = (double)(float)sums[21 + k] * (double)sHinv[i * 6 + k];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  if (lane < 6) {
     double s = 0.0;
-    for (int k = 0; k < 6; k++) s += (double)bb[k] * (double)st.Hinv[i * 6 + k];
-    delta[i] = -(float)s;
-    st.delta[i] = delta[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) s += sprod[lane * 6 + k];
+    const float d = -(float)s;
+    sdelta[lane] = d;
+    st.delta[lane] = d;
+    st.b[lane] = (float)sums[21 + lane];
   }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  if (lane != 0) return;
+  float delta[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) delta[i] = sdelta[i];
   const float weighted = fabsf(delta[0] * 100000.0f) + fabsf(delta[1] * 100000.0f) + fabsf(delta[2] * 100000.0f) +
                          fabsf(delta[3] * 10000.0f) + fabsf(delta[4] * 10000.0f) + fabsf(delta[5] * 10000.0f);
-  st.weighted = weighted;
   // pose <- log(exp(delta) * exp(pose)); exp(pose) is the f32 matrix the pixel pass used
   float D[12], C[12], np[6], S[12];
   exp_se3_f32(delta, D);
+#pragma unroll
   for (int i = 0; i < 12; i++) S[i] = st.S[i];
   compose_f32(D, S, C);
   log_se3_f32(C, np);
   exp_se3_f32(np, S);
+#pragma unroll
   for (int i = 0; i < 6; i++) st.pose[i] = np[i];
+#pragma unroll
   for (int i = 0; i < 12; i++) st.S[i] = S[i];
+  st.weighted = weighted;
   st.iters[a.level] += 1;
   if (a.early_exit && weighted < 1.0f) st.level_done = a.level;   // ImageFunc.cpp:251-252
 }

@@ -82,12 +82,15 @@ __global__ void maxgrad_horizontal(const float* __restrict__ mag, const float* _
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= w || y >= h) return;
   float v = mag[(size_t)y * w + x];   // border pixels keep the raw magnitude
+  bool hit = false;
   if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
     const float g1 = fmaxf(tmp[(size_t)y * w + x - 1], tmp[(size_t)y * w + x]);
     v = fmaxf(g1, tmp[(size_t)y * w + x + 1]);
-    if (v >= 5.0f) atomicAdd(count, 1);   // MIN_ABS_GRAD_DECREASE
+    if (v >= 5.0f) hit = true;   // MIN_ABS_GRAD_DECREASE
   }
   out[(size_t)y * w + x] = v;
+  const unsigned long long m = __ballot(hit);   // active lanes only
+  if (m && ((int)__lane_id() == __ffsll((long long)m) - 1)) atomicAdd(count, __popcll(m));
 }
 
 // depthMap::buildInvVarDepth, one level (DepthPropagation.cpp:1637-1719); the reference's source stride

@@ -157,6 +157,8 @@ def make_depth_state(w, h, seed, kf_image, idepth_true=None, fill=0.9):
     valid[:3, :] = False; valid[-3:, :] = False; valid[:, :3] = False; valid[:, -3:] = False
     idm = (idepth_true * (1.0 + 0.03 * rng.normal(size=(h, w)))).astype(np.float32)
     var = (0.01 * rng.uniform(0.5, 2.0, size=(h, w))).astype(np.float32)
+    outlier = rng.random((h, w)) < 0.03          # gross outliers: exercised by the regulariser / occlusion logic
+    idm = np.where(outlier, idm * rng.uniform(1.6, 2.5, size=(h, w)), idm).astype(np.float32)
     st = dict(invDepth=np.where(valid, idm, 0).astype(np.float32),
               invDepthSmoothed=np.where(valid, idm, 0).astype(np.float32),
               variance=np.where(valid, var, 0).astype(np.float32),
