@@ -4,6 +4,8 @@
 #include <string>
 #include <vector>
 #include <array>
+#include <map>
+#include <tuple>
 #include "../../include/ellc_abi.h"
 #include "ellc_device.hpp"
 
@@ -50,6 +52,10 @@ struct ellc_ctx {
   int tile_begin[ELLC_MAX_LEVELS + 1];
   int cap[ELLC_MAX_LEVELS];                            // compact capacity per level (= n)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // captured launch sequences of ellc_align, keyed by (B, unique keyframes, mode, save_weights)
+  std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
+  bool use_graph = true;
+  int resident_blocks = 1280;   // 256-thread blocks of the accumulate kernel resident on the device at once
   // depth map (one per context)
   ellc::DepthSoA dm_cur, dm_oth;
   int dm_kf_slot = -1;

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 
 using namespace ellc;
 
@@ -35,11 +36,16 @@ static ellc_status host_alloc(ellc_ctx* c, T** p, size_t count) {
   return ELLC_OK;
 }
 
+// Blocks per alignment for the accumulate kernels. Enough blocks to give every thread about one pixel at the
+// coarse levels (those launches are latency-bound), and at the fine levels a whole number of "rounds" of the
+// blocks the device holds at once (a 1.6-round grid runs as long as a 2-round one).
 int choose_nblk(const ellc_ctx* c, int level, int B) {
   const int n = c->geom_h[level].n;
   const int by_px = std::max(1, n / 1024);
-  const int target = std::max(1, 2048 / std::max(1, B));
-  return std::min(ELLC_NBLK_MAX, std::min(by_px, target));
+  B = std::max(1, B);
+  int per = std::max(1, c->resident_blocks / B);          // one round
+  if (by_px >= 3 * per) per = std::max(1, (2 * c->resident_blocks) / B);   // plenty of work: two rounds
+  return std::min(ELLC_NBLK_MAX, std::min(by_px, per));
 }
 
 static dim3 grid2d(int w, int h, dim3 blk) { return dim3((w + blk.x - 1) / blk.x, (h + blk.y - 1) / blk.y); }
@@ -350,6 +356,13 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
 #undef S
   }
   if (hipStreamSynchronize(c->stream) != hipSuccess) { *out = c; return fail(c, ELLC_ERR_HIP, "initial sync failed"); }
+  {
+    const char* ng = getenv("ELLC_NO_GRAPH");
+    c->use_graph = !(ng && ng[0] == '1');
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0)
+      c->resident_blocks = cus * 5;   // accumulate kernel: 89 VGPRs -> 5 waves/SIMD -> five 256-thread blocks per CU
+  }
 #undef TRY
   *out = c;
   return ELLC_OK;
@@ -358,6 +371,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
 ellc_status ellc_ctx_destroy(ellc_ctx* c) {
   if (!c) return ELLC_ERR_BAD_ARG;
   hipStreamSynchronize(c->stream);
+  for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->host_allocs) hipHostFree(p);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -520,17 +534,41 @@ ellc_status ellc_keyframe_finalise_weights(ellc_ctx* c, int slot) {
 }
 
 // ---- alignment -------------------------------------------------------------------------------------
+// prep + init + the whole level/iteration schedule; captured once per (B, unique keyframes, mode, save_weights)
+// into a hipGraph and replayed afterwards (the launches are too short to be issued one by one from the host)
+static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int save_weights) {
+  ellc_status s = run_prep(c, nu);   // mask / count per level: updationOnPyrChange, ImageFunc.cpp:158
+  if (s != ELLC_OK) return s;
+  hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
+  return enqueue_schedule(c, B, mode, save_weights);
+}
+
 ellc_status ellc_align_enqueue(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int save_weights) {
   if (!c) return ELLC_ERR_BAD_ARG;
   if (mode != ELLC_MODE_FCA && mode != ELLC_MODE_ICA) return fail(c, ELLC_ERR_BAD_ARG, "unknown mode");
   int nu = 0;
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
   if (s != ELLC_OK) return s;
-  s = run_prep(c, nu);   // mask / count per level: updationOnPyrChange, ImageFunc.cpp:158
-  if (s != ELLC_OK) return s;
-  hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
-  s = enqueue_schedule(c, B, mode, save_weights);
-  if (s != ELLC_OK) return s;
+  if (c->use_graph) {
+    const auto key = std::make_tuple(B, nu, mode, save_weights ? 1 : 0);
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      ELLC_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      s = enqueue_align_body(c, B, nu, mode, save_weights);
+      hipError_t e = hipStreamEndCapture(c->stream, &graph);
+      if (s != ELLC_OK) return s;
+      if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+      ELLC_HIP(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      hipGraphDestroy(graph);
+      it = c->graphs.emplace(key, exec).first;
+    }
+    ELLC_HIP(c, hipGraphLaunch(it->second, c->stream));
+  } else {
+    s = enqueue_align_body(c, B, nu, mode, save_weights);
+    if (s != ELLC_OK) return s;
+  }
   if (save_weights && mode == ELLC_MODE_FCA)
     for (int b = 0; b < B; b++)
       for (int l = 0; l < c->L; l++) c->kf_num_weights[kf_slots[b]][l]++;

@@ -14,20 +14,33 @@
 namespace ellc {
 
 // ---------------------------------------------------------------------------------------------------
-// wave-wide sum (64 lanes) with DPP row operations; total lands in lane 63 and is broadcast.
+// wave-wide sums (64 lanes) with DPP row operations; the total lands in lane 63.
+template <int CTRL, int RMASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false);
+  return v + __builtin_bit_cast(float, x);
+}
+// NV independent reductions, one DPP stage at a time across all values so the two wait states a DPP
+// read needs after the producing VALU are filled with the other values' adds instead of s_nop.
+template <int NV>
+__device__ __forceinline__ void wave_sum_all(float (&v)[NV]) {
+#pragma unroll
+  for (int j = 0; j < NV; j++) v[j] = dpp_add<0xB1, 0xf>(v[j]);    // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int j = 0; j < NV; j++) v[j] = dpp_add<0x4E, 0xf>(v[j]);    // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int j = 0; j < NV; j++) v[j] = dpp_add<0x141, 0xf>(v[j]);   // row_half_mirror
+#pragma unroll
+  for (int j = 0; j < NV; j++) v[j] = dpp_add<0x140, 0xf>(v[j]);   // row_mirror
+#pragma unroll
+  for (int j = 0; j < NV; j++) v[j] = dpp_add<0x142, 0xa>(v[j]);   // row_bcast:15 into rows 1,3
+#pragma unroll
+  for (int j = 0; j < NV; j++) v[j] = dpp_add<0x143, 0xc>(v[j]);   // row_bcast:31 into rows 2,3
+}
 __device__ __forceinline__ float wave_sum(float v) {
-  int x;
-#define ELLC_DPP_ADD(ctrl, rmask)                                                                         \
-  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false);                \
-  v += __builtin_bit_cast(float, x);
-  ELLC_DPP_ADD(0xB1, 0xf)   // quad_perm [1,0,3,2]
-  ELLC_DPP_ADD(0x4E, 0xf)   // quad_perm [2,3,0,1]
-  ELLC_DPP_ADD(0x141, 0xf)  // row_half_mirror
-  ELLC_DPP_ADD(0x140, 0xf)  // row_mirror
-  ELLC_DPP_ADD(0x142, 0xa)  // row_bcast:15 into rows 1,3
-  ELLC_DPP_ADD(0x143, 0xc)  // row_bcast:31 into rows 2,3
-#undef ELLC_DPP_ADD
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  float a[1] = {v};
+  wave_sum_all<1>(a);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[0]), 63));
 }
 
 // ExternVariable.h:232
@@ -184,10 +197,10 @@ template <int NV>
 __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float* __restrict__ out) {
   __shared__ float red[ELLC_GN_THREADS / 64][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wave_sum_all<NV>(acc);
+  if (lane == 63) {
 #pragma unroll
-  for (int j = 0; j < NV; j++) {
-    const float s = wave_sum(acc[j]);
-    if (lane == 0) red[wave][j] = s;
+    for (int j = 0; j < NV; j++) red[wave][j] = acc[j];
   }
   __syncthreads();
   if (threadIdx.x < NV) {

@@ -1,0 +1,59 @@
+"""Multi-GPU layer: independent keyframe<->frame alignments are sharded across ranks (one process per GPU);
+the only data-path collective is ONE gather of the resulting se(3) poses per batch.
+
+The reference has no distributed code; alignment b of a loop-closure batch (GlobalOptimize.cpp:566) is
+independent of every other, so ranks never exchange pixels — only 8 floats per alignment at the end:
+[pose(6), weightedPose, iterations]. Backend "nccl" (= RCCL over xGMI on MI355X) on GPUs, "gloo" in CPU tests.
+"""
+import numpy as np
+
+RECORD = 8  # floats per alignment in the gathered table
+
+
+def shard_range(total, world, rank):
+    """Contiguous block partition: alignment b lives on rank b // ceil(total / world)."""
+    per = (total + world - 1) // world
+    lo = min(total, rank * per)
+    hi = min(total, lo + per)
+    return lo, hi
+
+
+def pack_results(pose, iters, weighted):
+    pose = np.asarray(pose, np.float32).reshape(-1, 6)
+    out = np.zeros((pose.shape[0], RECORD), np.float32)
+    out[:, :6] = pose
+    out[:, 6] = np.asarray(weighted, np.float32).reshape(-1)
+    if pose.shape[0]:
+        out[:, 7] = np.asarray(iters).reshape(pose.shape[0], -1).sum(axis=1)
+    return out
+
+
+def gather_results(local, total, device=None, group=None):
+    """All ranks contribute their (n_local, 8) table; every rank gets the (total, 8) table in global order.
+
+    One all_gather of fixed-size (padded) blocks: 32 alignments x 32 B = 1 KiB per rank — latency-bound, so the
+    choice of ring vs direct and the xGMI link budget are irrelevant.
+    """
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return np.asarray(local, np.float32).reshape(-1, RECORD)[:total]
+    world = dist.get_world_size(group)
+    per = (total + world - 1) // world
+    buf = torch.zeros((per, RECORD), dtype=torch.float32)
+    loc = torch.from_numpy(np.ascontiguousarray(local, np.float32).reshape(-1, RECORD))
+    buf[: loc.shape[0]] = loc
+    if device is not None:
+        buf = buf.to(device)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    table = torch.cat(parts, dim=0)[:total]
+    return table.cpu().numpy()
+
+
+def align_sharded(ctx, total, local_kf_slots, local_frame_slots, init_pose=None, mode=0, device=None, group=None):
+    """Run this rank's share of `total` alignments on its GPU and gather all poses.
+
+    local_*_slots index THIS rank's resident slots, in the order of the rank's global range."""
+    pose, iters, wgt = ctx.align(local_kf_slots, local_frame_slots, init_pose=init_pose, mode=mode)
+    return gather_results(pack_results(pose, iters, wgt), total, device=device, group=group)

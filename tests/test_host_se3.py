@@ -1,0 +1,40 @@
+"""Host-side se(3) helpers of the product library (ellc_concatenate_*_pose, ellc_se3_exp/log) — pure host code,
+so they run here without a GPU — against scipy and the oracle."""
+import numpy as np
+import scipy.linalg as sl
+from test_oracle_algebra import hat, vee
+
+
+def test_exp_log_vs_scipy(ellc):
+    rng = np.random.default_rng(5)
+    for scale in (1e-6, 0.02, 0.3, 2.0):
+        for _ in range(10):
+            xi = (rng.normal(size=6) * scale).astype(np.float32)
+            T = ellc.se3_exp(xi)
+            Tref = sl.expm(hat(xi.astype(np.float64)))
+            assert np.abs(T - Tref).max() < 1.3e-7 * max(1.0, np.abs(Tref).max())
+            back = ellc.se3_log(Tref.astype(np.float32))
+            ref = vee(np.real(sl.logm(Tref.astype(np.float32).astype(np.float64))))
+            assert np.abs(back - ref).max() < 3e-7 * max(1.0, np.abs(ref).max())
+
+
+def test_concatenate_matches_oracle(ellc, oracle):
+    rng = np.random.default_rng(6)
+    worst = 0.0
+    for _ in range(200):
+        a = (rng.normal(size=6) * [0.03, 0.03, 0.03, 0.1, 0.1, 0.1]).astype(np.float32)
+        b = (rng.normal(size=6) * [0.03, 0.03, 0.03, 0.1, 0.1, 0.1]).astype(np.float32)
+        worst = max(worst, np.abs(ellc.concatenate_relative_pose(a, b) - oracle.concat_relative(a, b)).max(),
+                    np.abs(ellc.concatenate_origin_pose(a, b) - oracle.concat_origin(a, b)).max())
+    # two independent double-precision evaluations rounded to f32: at most an ulp apart
+    assert worst < 1.5e-8
+
+
+def test_near_pi_rotation(ellc):
+    for ax in ([1, 0, 0], [0, 1, 0], [0.6, 0.0, 0.8], [-0.48, 0.6, 0.64]):
+        ax = np.array(ax, float) / np.linalg.norm(ax)
+        for ang in (3.0, 3.14, 3.1415):
+            xi = np.concatenate([ax * ang, [0.1, -0.2, 0.3]]).astype(np.float32)
+            T = sl.expm(hat(xi.astype(np.float64))).astype(np.float32)
+            back = ellc.se3_log(T)
+            assert np.abs(sl.expm(hat(back.astype(np.float64))) - T).max() < 5e-6

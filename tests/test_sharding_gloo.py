@@ -1,0 +1,68 @@
+"""N>1 path on CPU: two gloo ranks shard a batch of alignments and gather the result table.
+The alignments themselves are produced by a stand-in context (the HIP library needs a GPU); what is under
+test is the partition, the padding of uneven shards and the order of the gathered poses."""
+import os
+import subprocess
+import sys
+import textwrap
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch.distributed as dist
+    from egomotion_with_local_loop_closures_amd import sharding
+
+    class FakeCtx:
+        def __init__(self, lo): self.lo = lo
+        def align(self, kf, fr, init_pose=None, mode=0):
+            g = self.lo + np.arange(len(kf))
+            pose = np.stack([g * 0.5 + k for k in range(6)], axis=1).astype(np.float32)
+            iters = np.tile(np.array([[4, 7, 9, 12]]), (len(kf), 1)) + (g[:, None] %% 2)
+            return pose, iters, (g * 0.25).astype(np.float32)
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    for total in (8, 7, 1, 5):
+        lo, hi = sharding.shard_range(total, world, rank)
+        slots = np.arange(hi - lo)
+        table = sharding.align_sharded(FakeCtx(lo), total, slots, slots)
+        g = np.arange(total)
+        assert table.shape == (total, 8), table.shape
+        assert np.array_equal(table[:, 0], (g * 0.5).astype(np.float32))
+        assert np.array_equal(table[:, 5], (g * 0.5 + 5).astype(np.float32))
+        assert np.array_equal(table[:, 6], (g * 0.25).astype(np.float32))
+        assert np.array_equal(table[:, 7], (32 + 4 * (g %% 2)).astype(np.float32))
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_shard_range_partitions():
+    from egomotion_with_local_loop_closures_amd import sharding
+    for total in (0, 1, 7, 32, 256, 257):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = sharding.shard_range(total, world, r)
+                assert 0 <= lo <= hi <= total
+                seen += list(range(lo, hi))
+            assert seen == list(range(total))
+    assert sharding.shard_range(256, 8, 3) == (96, 128)     # C3: 32 per GPU, contiguous blocks
+
+
+def test_two_rank_gloo_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+        assert "ok" in o
