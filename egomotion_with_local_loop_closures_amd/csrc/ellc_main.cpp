@@ -1,0 +1,79 @@
+// ellc_main — a main.cpp-shaped driver over the facade (reference: src/main.cpp:199-505): tracks a sequence of
+// grey frames against the active keyframe, refines / propagates the semi-dense depth map, switches keyframe every
+// KEYFRAME_PROPAGATE_INTERVAL frames and writes the reference's result files:
+//   poses_orig.txt   frameId kfId wx wy wz vx vy vz(poseWrtWorld) rescaleFactor seeds%        (main.cpp:373)
+//   matchframes.txt  frameId kfId pose6(poseWrtOrigin) rescaleFactor seeds% 0 0 0               (main.cpp:382)
+// Input is a header-less file of W*H u8 frames (decode / undistort / resize stay outside, Frame.cpp:45-75).
+// Loop-closure candidate search (GlobalOptimize.cpp) and the MATLAB rotation averaging are not part of this path.
+#include "../../include/ellc_facade.hpp"
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <memory>
+
+using namespace ellc;
+
+int main(int argc, char** argv) {
+  if (argc < 6) {
+    std::fprintf(stderr, "usage: %s frames.raw W H num_frames out_dir [LC] [levels]\n", argv[0]);
+    return -1;
+  }
+  const std::string in = argv[1], outdir = argv[5];
+  const int W = std::atoi(argv[2]), H = std::atoi(argv[3]), max_frame_counter = std::atoi(argv[4]);
+  const bool lc = argc > 6 && std::string(argv[6]) == "LC";
+  const int levels = argc > 7 ? std::atoi(argv[7]) : 4;
+  const int KEYFRAME_PROPAGATE_INTERVAL = 8;   // ExternVariable.h:39
+  std::ifstream f(in, std::ios::binary);
+  if (!f) { std::fprintf(stderr, "cannot open %s\n", in.c_str()); return -1; }
+  std::ofstream pose_file_orig(outdir + "/poses_orig.txt"), match_file(outdir + "/matchframes.txt");
+  if (!pose_file_orig || !match_file) { std::fprintf(stderr, "cannot open output files in %s\n", outdir.c_str()); return -1; }
+  try {
+    ellc_config cfg;
+    ellc_default_config(&cfg, W, H, levels);
+    Runtime rt(cfg);
+    rt.FLAG_DO_LOOP_CLOSURE = lc;
+    depthMap currentDepthMap(rt);
+    std::vector<std::unique_ptr<frame>> frameptr_vector;
+    frame* activeKeyFrame = nullptr;
+    std::vector<uint8_t> buf((size_t)W * H);
+    float initial_pose[6] = {0, 0, 0, 0, 0, 0};
+    for (int frame_counter = 1; frame_counter <= max_frame_counter; frame_counter++) {
+      if (!f.read((char*)buf.data(), buf.size())) { std::fprintf(stderr, "short read at frame %d\n", frame_counter); return -1; }
+      frameptr_vector.emplace_back(new frame(rt, buf.data()));
+      frame* cur = frameptr_vector.back().get();
+      if (frame_counter == 1) {   // main.cpp:228-236
+        activeKeyFrame = cur;
+        currentDepthMap.formDepthMap(cur);
+        currentDepthMap.updateDepthImage();
+        continue;
+      }
+      frame* tminus1 = frameptr_vector[frameptr_vector.size() - 2].get();
+      GetImagePoseEstimate(activeKeyFrame, cur, frame_counter, &currentDepthMap, tminus1, initial_pose);   // main.cpp:330
+      const float seeds_num = currentDepthMap.calculate_no_of_Seeds();
+      const int id = cur->frameId + rt.BATCH_START_ID - 1, kid = activeKeyFrame->frameId + rt.BATCH_START_ID - 1;
+      pose_file_orig << id << " " << kid << " " << cur->poseWrtWorld[0] << " " << cur->poseWrtWorld[1] << " " << cur->poseWrtWorld[2] << " "
+                     << cur->poseWrtWorld[3] << " " << cur->poseWrtWorld[4] << " " << cur->poseWrtWorld[5] << " " << activeKeyFrame->rescaleFactor
+                     << " " << seeds_num << "\n";
+      match_file << id << " " << kid << " " << cur->poseWrtOrigin[0] << " " << cur->poseWrtOrigin[1] << " " << cur->poseWrtOrigin[2] << " "
+                 << cur->poseWrtOrigin[3] << " " << cur->poseWrtOrigin[4] << " " << cur->poseWrtOrigin[5] << " " << activeKeyFrame->rescaleFactor
+                 << " " << seeds_num << " " << "0" << " " << "0" << " " << "0" << "\n";
+      currentDepthMap.formDepthMap(cur);   // main.cpp:391
+      if ((frame_counter % KEYFRAME_PROPAGATE_INTERVAL == 0) || (frame_counter == max_frame_counter)) {   // main.cpp:404
+        if (lc) activeKeyFrame->finaliseWeights();
+        currentDepthMap.finaliseKeyframe();
+        currentDepthMap.createKeyFrame(cur);
+        activeKeyFrame = cur;
+        frameptr_vector.erase(frameptr_vector.begin(), frameptr_vector.end() - 1);   // keep only the most recent frame
+        continue;
+      }
+      currentDepthMap.updateKeyFrame();   // main.cpp:499-502
+      currentDepthMap.observeDepthRowParallel();
+      currentDepthMap.doRegularization();
+      currentDepthMap.updateDepthImage();
+    }
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "ellc_main: %s\n", e.what());
+    return -2;
+  }
+  return 0;
+}

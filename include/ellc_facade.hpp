@@ -1,0 +1,217 @@
+// ellc_facade.hpp — the reference's object API (frame / PixelWisePyramid / depthMap / GetImagePoseEstimate)
+// re-expressed over the C ABI of libellc_hip.so, so a main.cpp-shaped driver keeps its structure.
+// Header-only, host C++11; every numeric operation is a call into include/ellc_abi.h (no CPU fallback).
+//
+// Reference members mirrored (file:line under the reference's src/):
+//   frame                     Frame.h:35-397, Frame.cpp:34-124 (constructor after decode/undistort/resize), :503-562, :678-695
+//   PixelWisePyramid          PixelWisePyramid.h:89-101, PixelWisePyramid.cpp:14-51, :416-491, :500-552, :917-974
+//   depthMap                  DepthPropagation.h:82-132, DepthPropagation.cpp:44-66, :83-184, :1254-1315, :1627-1635,
+//                             :1749-1802, :1804-1830, :1932-1958
+//   GetImagePoseEstimate      ImageFunc.h:31, ImageFunc.cpp:49-315
+// Differences that are deliberate: image decode / undistort / VideoCapture stay with the caller (frame takes
+// the grey W x H image); the process-wide globals of the reference (numberOfInstances, util::K*, GLOABL_DEPTH_SCALE)
+// live in ellc::Runtime; failures throw std::runtime_error carrying ellc_last_error() instead of being ignored.
+#ifndef ELLC_FACADE_HPP
+#define ELLC_FACADE_HPP
+
+#include "ellc_abi.h"
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace ellc {
+
+// Owner of the context and of the slot bookkeeping (keyframe slots: active + incoming; frame slots: ring).
+class Runtime {
+ public:
+  ellc_config cfg;
+  ellc_ctx* ctx = nullptr;
+  int numberOfInstances = 0;      // Frame.cpp:24
+  bool FLAG_DO_LOOP_CLOSURE = false;           // "LC" mode: save / average the tracking weights (ExternVariable.h:203,211)
+  int BATCH_START_ID = 1;
+  explicit Runtime(const ellc_config& c) : cfg(c) {
+    if (cfg.max_frames < 3) cfg.max_frames = 3;
+    if (cfg.max_keyframes < 2) cfg.max_keyframes = 2;
+    if (cfg.max_batch < 1) cfg.max_batch = 1;
+    check(ellc_ctx_create(&cfg, &ctx), "ellc_ctx_create");
+  }
+  ~Runtime() { if (ctx) ellc_ctx_destroy(ctx); }
+  Runtime(const Runtime&) = delete;
+  Runtime& operator=(const Runtime&) = delete;
+  void check(int st, const char* what) const {
+    if (st != ELLC_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(st) + "): " + (ctx ? ellc_last_error(ctx) : "no context"));
+  }
+  int next_frame_slot() { int s = frame_cursor_; frame_cursor_ = (frame_cursor_ + 1) % cfg.max_frames; return s; }
+  int other_keyframe_slot(int current) const { return (current + 1) % cfg.max_keyframes; }
+ private:
+  int frame_cursor_ = 0;
+};
+
+class frame {
+ public:
+  Runtime* rt;
+  int frameId;
+  int parentKeyframeId = 0;
+  bool isKeyframe = false;
+  int width, height;
+  int slot;                 // frame slot holding the u8 pyramid on the device
+  int kf_slot = -1;         // keyframe slot once this frame has become a keyframe
+  float poseWrtOrigin[6];   // w.r.t. the keyframe
+  float poseWrtWorld[6];    // w.r.t. the first frame
+  float rescaleFactor = 1.0f;
+  int numWeightsAdded[ELLC_MAX_LEVELS];
+
+  // Frame.cpp:34-124 from "width=image.cols" on: ids, zero poses, pyramids (constructImagePyramids on device)
+  frame(Runtime& r, const uint8_t* gray) : rt(&r) {
+    frameId = ++r.numberOfInstances;
+    width = r.cfg.width;
+    height = r.cfg.height;
+    for (int i = 0; i < 6; i++) poseWrtOrigin[i] = poseWrtWorld[i] = 0.0f;
+    for (int i = 0; i < ELLC_MAX_LEVELS; i++) numWeightsAdded[i] = 0;
+    slot = r.next_frame_slot();
+    r.check(ellc_frame_upload(r.ctx, slot, gray), "ellc_frame_upload");
+  }
+  void concatenateRelativePose(const float* src_1wrt2, const float* src_2wrt3, float* dest_1wrt3) const {
+    ellc_concatenate_relative_pose(src_1wrt2, src_2wrt3, dest_1wrt3);
+  }
+  void concatenateOriginPose(const float* src_1wrt0, const float* src_2wrt0, float* dest_1wrt2) const {
+    ellc_concatenate_origin_pose(src_1wrt0, src_2wrt0, dest_1wrt2);
+  }
+  void calculatePoseWrtOrigin(frame* prev_image, const float* poseChange) { concatenateRelativePose(poseChange, prev_image->poseWrtOrigin, poseWrtOrigin); }
+  void calculatePoseWrtWorld(frame* prev_image, const float* poseChange) { concatenateRelativePose(poseChange, prev_image->poseWrtWorld, poseWrtWorld); }
+  void finaliseWeights() {   // Frame.cpp:678-695
+    if (kf_slot < 0) throw std::runtime_error("finaliseWeights: frame is not a keyframe");
+    rt->check(ellc_keyframe_finalise_weights(rt->ctx, kf_slot), "ellc_keyframe_finalise_weights");
+  }
+};
+
+class depthMap {
+ public:
+  Runtime* rt;
+  frame* keyFrame = nullptr;
+  frame* currentFrame = nullptr;
+  float depthScale = 1.0f;
+  explicit depthMap(Runtime& r) : rt(&r) {}
+
+  // DepthPropagation.cpp:44-66
+  void formDepthMap(frame* image_frame) {
+    currentFrame = image_frame;
+    currentFrame->isKeyframe = false;
+    if (image_frame->frameId == 1) {
+      keyFrame = image_frame;
+      keyFrame->isKeyframe = true;
+      keyFrame->rescaleFactor = 1.0f;
+      keyFrame->kf_slot = 0;
+      rt->check(ellc_keyframe_from_frame(rt->ctx, 0, image_frame->slot), "ellc_keyframe_from_frame");
+      rt->check(ellc_depth_set_keyframe(rt->ctx, 0), "ellc_depth_set_keyframe");
+      initializeRandomly();
+    }
+    currentFrame->parentKeyframeId = keyFrame->frameId;
+    currentFrame->rescaleFactor = keyFrame->rescaleFactor;
+  }
+  // DepthPropagation.cpp:83-184 (random branch): glibc rand(), unseeded, raster order over the interior
+  void initializeRandomly() {
+    const int W = rt->cfg.width, H = rt->cfg.height;
+    const size_t n = (size_t)W * H;
+    std::vector<float> mg(n), id(n, 0.f), ids(n, 0.f), var(n, 0.f), vars(n, 0.f);
+    std::vector<int32_t> val(n, 0), bl(n, 0);
+    std::vector<uint8_t> ok(n, 0);
+    rt->check(ellc_get_max_gradient(rt->ctx, 1, keyFrame->kf_slot, mg.data(), nullptr), "ellc_get_max_gradient");
+    // The reference never seeds rand(), i.e. it consumes glibc's default sequence (seed 1) from its start. The GPU
+    // runtime may draw from rand() while it initialises, so the default sequence is re-established explicitly.
+    srand(1);
+    for (int y = 1; y < H - 1; y++)
+      for (int x = 1; x < W - 1; x++) {
+        const size_t i = (size_t)x + (size_t)W * y;
+        if (mg[i] > 1.0 * 1.0f) {   // MIN_ABS_GRAD_CREATE
+          id[i] = 0.5f + 1.0f * ((rand() % 100001) / 100000.0f);
+          var[i] = 0.125f;          // VAR_RANDOM_INIT_INITIAL
+          vars[i] = 0.125f;
+          ids[i] = id[i];
+          val[i] = 20;
+          ok[i] = 1;
+        }
+      }
+    ellc_hypotheses h = {id.data(), ids.data(), var.data(), vars.data(), val.data(), bl.data(), ok.data()};
+    rt->check(ellc_depth_set_state(rt->ctx, &h), "ellc_depth_set_state");
+  }
+  void updateDepthImage(bool = false) { rt->check(ellc_depth_update_depth_image(rt->ctx), "ellc_depth_update_depth_image"); }
+  void doRegularization(bool removeOcclusions = false) {   // :1627-1635
+    rt->check(ellc_depth_fill_holes(rt->ctx), "ellc_depth_fill_holes");
+    rt->check(ellc_depth_regularize(rt->ctx, removeOcclusions ? 1 : 0), "ellc_depth_regularize");
+  }
+  void finaliseKeyframe() { doRegularization(); updateDepthImage(); }   // :1749-1755
+  void updateKeyFrame() {}   // :1796-1802: the Sim3-scaled pose it computes is overwritten before use (:1935)
+  void observeDepthRowParallel() {   // :1932-1958
+    rt->check(ellc_depth_observe(rt->ctx, currentFrame->slot, currentFrame->poseWrtOrigin), "ellc_depth_observe");
+  }
+  void createKeyFrame(frame* new_keyframe) {   // :1758-1794
+    const int ns = rt->other_keyframe_slot(keyFrame->kf_slot);
+    rt->check(ellc_keyframe_from_frame(rt->ctx, ns, new_keyframe->slot), "ellc_keyframe_from_frame");
+    float f = 1.0f;
+    rt->check(ellc_depth_create_keyframe(rt->ctx, ns, new_keyframe->poseWrtOrigin, &f), "ellc_depth_create_keyframe");
+    new_keyframe->kf_slot = ns;
+    keyFrame = new_keyframe;
+    keyFrame->isKeyframe = true;
+    keyFrame->rescaleFactor = f;
+    depthScale = f;
+    for (int i = 0; i < 6; i++) keyFrame->poseWrtOrigin[i] = 0.0f;
+  }
+  float calculate_no_of_Seeds(bool = true) {   // :1804-1830
+    float p = 0;
+    rt->check(ellc_depth_seeds(rt->ctx, &p), "ellc_depth_seeds");
+    return p;
+  }
+};
+
+// One pyramid level of the Gauss-Newton loop, one iteration per call (PixelWisePyramid.cpp:416-491, :917-974).
+// The batched fast path is GetImagePoseEstimate below; this class exists for callers that drive single steps.
+class PixelWisePyramid {
+ public:
+  Runtime* rt;
+  frame* prev_frame;
+  frame* current_frame;
+  depthMap* currentDepthMap;
+  float* pose;            // caller-owned 6-vector, updated in place (ImageFunc.cpp:183)
+  int pyrlevel;
+  float weightedPose = 0;
+  float hessian[36], sd_param[6], deltapose[6];
+  float prevPose[6];
+  PixelWisePyramid(frame* prev, frame* cur, float* pose_, depthMap* dm, int level)
+      : rt(prev->rt), prev_frame(prev), current_frame(cur), currentDepthMap(dm), pose(pose_), pyrlevel(level) {}
+  void putPreviousPose(frame* tminus1) { tminus1->concatenateOriginPose(tminus1->poseWrtWorld, prev_frame->poseWrtWorld, prevPose); }
+  void calculatePixelWiseParallel() { step(ELLC_MODE_FCA, 0); }
+  void calculatePixelWiseParallelInvCompositional(int iter) { step(ELLC_MODE_ICA, iter); }
+ private:
+  void step(int mode, int iter) {
+    float np[6];
+    rt->check(ellc_gn_iterate(rt->ctx, prev_frame->kf_slot, current_frame->slot, pyrlevel, mode, iter, pose, hessian, sd_param, deltapose, np,
+                              &weightedPose, nullptr), "ellc_gn_iterate");
+    std::memcpy(pose, np, sizeof(np));
+  }
+};
+
+// ImageFunc.cpp:49-315. The level / iteration loops run on the device (ellc_align); weights of the last executed
+// iteration of every level are saved into the keyframe when the runtime is in LC mode and the call does not come
+// from loop closure (ImageFunc.cpp:280-288).
+inline std::vector<float> GetImagePoseEstimate(frame* prev_frame, frame* current_frame, int /*frame_num*/, depthMap* /*currDepthMap*/,
+                                               frame* tminus1_prev_frame, float* /*initial_pose_estimate*/, bool fromLoopClosure = false,
+                                               bool /*homo*/ = false) {
+  Runtime* rt = prev_frame->rt;
+  if (prev_frame->kf_slot < 0) throw std::runtime_error("GetImagePoseEstimate: prev_frame is not a keyframe");
+  float pose[6];
+  prev_frame->concatenateOriginPose(tminus1_prev_frame->poseWrtWorld, prev_frame->poseWrtWorld, pose);   // :106
+  const int save = (rt->FLAG_DO_LOOP_CLOSURE && !fromLoopClosure) ? 1 : 0;
+  float out[6];
+  rt->check(ellc_align(rt->ctx, 1, &prev_frame->kf_slot, &current_frame->slot, pose, fromLoopClosure ? ELLC_MODE_ICA : ELLC_MODE_FCA, save, out,
+                       nullptr, nullptr), "ellc_align");
+  if (save) for (int l = 0; l < rt->cfg.levels; l++) prev_frame->numWeightsAdded[l]++;
+  current_frame->calculatePoseWrtOrigin(prev_frame, out);   // :305
+  current_frame->calculatePoseWrtWorld(prev_frame, out);    // :306
+  return std::vector<float>(out, out + 6);
+}
+
+}  // namespace ellc
+#endif

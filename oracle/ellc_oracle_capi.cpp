@@ -123,6 +123,7 @@ void orc_frame_get_pose(Frame* f, float* origin6, float* world6) {
   std::memcpy(origin6, f->poseWrtOrigin, 24);
   std::memcpy(world6, f->poseWrtWorld, 24);
 }
+float orc_frame_get_rescale(Frame* f) { return f->rescaleFactor; }
 void orc_frame_update_level(Frame* f, int level, int is_prev) { f->updationOnPyrChange(level, is_prev != 0); }
 void orc_frame_get_gradient(Frame* f, float* gx, float* gy) {
   std::memcpy(gx, f->gradientx.d.data(), f->gradientx.d.size() * 4);

@@ -41,6 +41,7 @@ def lib():
         _lib.orc_dm_make_inv_depth_one.restype = C.c_float
         _lib.orc_dm_seeds.restype = C.c_float
         _lib.orc_dm_line_stereo.restype = C.c_float
+        _lib.orc_frame_get_rescale.restype = C.c_float
     return _lib
 
 
@@ -234,6 +235,9 @@ class Frame:
         o = np.zeros(6, np.float32); w = np.zeros(6, np.float32)
         lib().orc_frame_get_pose(self.h, _p(o), _p(w))
         return o, w
+
+    def rescale_factor(self):
+        return lib().orc_frame_get_rescale(self.h)
 
     def set_early_exit(self, e):
         lib().orc_frame_set_early_exit(self.h, int(e))
