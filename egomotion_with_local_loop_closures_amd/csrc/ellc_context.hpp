@@ -55,6 +55,8 @@ struct ellc_ctx {
   // captured launch sequences of ellc_align, keyed by (B, unique keyframes, mode, save_weights)
   std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
   bool use_graph = true;
+  int gn_ilp = 1;               // pixels in flight per thread in the FCA accumulate kernel (ELLC_GN_ILP)
+  int nblk_override[ELLC_MAX_LEVELS] = {0};
   int resident_blocks = 1280;   // 256-thread blocks of the accumulate kernel resident on the device at once
   // depth map (one per context)
   ellc::DepthSoA dm_cur, dm_oth;

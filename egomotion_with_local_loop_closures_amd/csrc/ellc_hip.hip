@@ -37,14 +37,14 @@ static ellc_status host_alloc(ellc_ctx* c, T** p, size_t count) {
 }
 
 // Blocks per alignment for the accumulate kernels. Enough blocks to give every thread about one pixel at the
-// coarse levels (those launches are latency-bound), and at the fine levels a whole number of "rounds" of the
-// blocks the device holds at once (a 1.6-round grid runs as long as a 2-round one).
+// coarse levels (those launches are latency-bound); at the fine levels exactly the number of blocks the device
+// holds at once, so every CU gets the same share and each block pays the 27-value reduction once.
 int choose_nblk(const ellc_ctx* c, int level, int B) {
+  if (c->nblk_override[level] > 0) return std::min(ELLC_NBLK_MAX, c->nblk_override[level]);   // tuning knob (ELLC_NBLK=l0,l1,..)
   const int n = c->geom_h[level].n;
   const int by_px = std::max(1, n / 1024);
   B = std::max(1, B);
-  int per = std::max(1, c->resident_blocks / B);          // one round
-  if (by_px >= 3 * per) per = std::max(1, (2 * c->resident_blocks) / B);   // plenty of work: two rounds
+  const int per = std::max(1, c->resident_blocks / B);    // one round of resident blocks (measured best: r01 sweep)
   return std::min(ELLC_NBLK_MAX, std::min(by_px, per));
 }
 
@@ -74,7 +74,7 @@ ellc_status build_maxgrad(ellc_ctx* c, bool is_kf, int slot) {
   ELLC_HIP(c, hipMemsetAsync(cnt, 0, sizeof(int), c->stream));
   hipLaunchKernelGGL(maxgrad_magnitude, grd, blk, 0, c->stream, img, g.sw, g.cols, g.rows, c->scratch_a);
   hipLaunchKernelGGL(maxgrad_vertical, grd, blk, 0, c->stream, c->scratch_a, g.cols, g.rows, c->scratch_b);
-  hipLaunchKernelGGL(maxgrad_horizontal, grd, blk, 0, c->stream, c->scratch_a, c->scratch_b, g.cols, g.rows, out, cnt);
+  hipLaunchKernelGGL(maxgrad_horizontal, dim3(128), dim3(256), 0, c->stream, c->scratch_a, c->scratch_b, g.cols, g.rows, out, cnt);
   ELLC_HIP(c, hipGetLastError());
   (is_kf ? c->kf_maxgrad_valid : c->fr_maxgrad_valid)[slot] = 1;
   return ELLC_OK;
@@ -128,6 +128,11 @@ static GnArgs make_gn_args(ellc_ctx* c, int level, int B, int save_w, float* pla
   return a;
 }
 
+static void launch_fca(ellc_ctx* c, dim3 grd, dim3 blk, const GnArgs& a) {
+  if (c->gn_ilp == 2) hipLaunchKernelGGL((gn_fca_accumulate<false, 2>), grd, blk, 0, c->stream, a);
+  else hipLaunchKernelGGL((gn_fca_accumulate<false, 1>), grd, blk, 0, c->stream, a);
+}
+
 static void launch_solve(ellc_ctx* c, int level, int B, int nblk, int mode, int early_exit) {
   SolveArgs s;
   s.state = c->state_d;
@@ -171,7 +176,7 @@ static ellc_status enqueue_schedule(ellc_ctx* c, int B, int mode, int save_weigh
     const dim3 grd(a.nblk, B), blk(ELLC_GN_THREADS);
     for (int it = 0; it < c->cfg.max_iter[level]; it++) {
       if (mode == ELLC_MODE_FCA) {
-        hipLaunchKernelGGL(gn_fca_accumulate<false>, grd, blk, 0, c->stream, a);
+        launch_fca(c, grd, blk, a);
         launch_solve(c, level, B, a.nblk, 0, c->cfg.early_exit);
       } else {
         if (it == 0) {
@@ -359,6 +364,16 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   {
     const char* ng = getenv("ELLC_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
+    if (const char* ilp = getenv("ELLC_GN_ILP")) c->gn_ilp = atoi(ilp) == 2 ? 2 : 1;
+    for (int l = 0; l < ELLC_MAX_LEVELS; l++) c->nblk_override[l] = 0;
+    if (const char* nb = getenv("ELLC_NBLK")) {
+      int l = 0;
+      for (const char* q = nb; *q && l < ELLC_MAX_LEVELS; l++) {
+        c->nblk_override[l] = atoi(q);
+        while (*q && *q != ',') q++;
+        if (*q == ',') q++;
+      }
+    }
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0)
       c->resident_blocks = cus * 5;   // accumulate kernel: 89 VGPRs -> 5 waves/SIMD -> five 256-thread blocks per CU
@@ -618,8 +633,8 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   GnArgs a = make_gn_args(c, level, 1, 0, planes ? c->planes_d : nullptr);
   const dim3 grd(a.nblk, 1), blk(ELLC_GN_THREADS);
   if (mode == ELLC_MODE_FCA) {
-    if (planes) hipLaunchKernelGGL(gn_fca_accumulate<true>, grd, blk, 0, c->stream, a);
-    else hipLaunchKernelGGL(gn_fca_accumulate<false>, grd, blk, 0, c->stream, a);
+    if (planes) hipLaunchKernelGGL((gn_fca_accumulate<true, 1>), grd, blk, 0, c->stream, a);
+    else launch_fca(c, grd, blk, a);
     launch_solve(c, level, 1, a.nblk, 0, 0);
   } else {
     if (iter == 0) {
@@ -681,9 +696,9 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
   GnArgs a = make_gn_args(c, level, B, 0, nullptr);
   const dim3 grd(a.nblk, B), blk(ELLC_GN_THREADS);
-  for (int i = 0; i < 3; i++) hipLaunchKernelGGL(gn_fca_accumulate<false>, grd, blk, 0, c->stream, a);
+  for (int i = 0; i < 3; i++) launch_fca(c, grd, blk, a);
   ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
-  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(gn_fca_accumulate<false>, grd, blk, 0, c->stream, a);
+  for (int i = 0; i < reps; i++) launch_fca(c, grd, blk, a);
   ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
   ELLC_HIP(c, hipEventSynchronize(c->ev1));
   float ms = 0;
@@ -715,6 +730,30 @@ ellc_status ellc_profile_align(ellc_ctx* c, int B, const int* kf_slots, const in
   float ms = 0;
   ELLC_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   if (avg_ms) *avg_ms = ms / reps;
+  return ELLC_OK;
+}
+
+__global__ __launch_bounds__(256) void calib_read_f32(const float* __restrict__ p, size_t n, float* __restrict__ sink) {
+  float acc = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += p[i];
+  if (acc == 1.2345e-30f) sink[0] = acc;   // keeps the loads alive
+}
+
+ellc_status ellc_profile_calibrate_read(ellc_ctx* c, size_t bytes, int reps, float* avg_ms) {
+  if (!c || reps < 1 || bytes < 1024) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  float* buf = nullptr;
+  ELLC_HIP(c, hipMalloc((void**)&buf, bytes));
+  ELLC_HIP(c, hipMemsetAsync(buf, 0, bytes, c->stream));
+  const size_t n = bytes / 4;
+  hipLaunchKernelGGL(calib_read_f32, dim3(2048), dim3(256), 0, c->stream, buf, n, c->scratch_a);
+  ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(calib_read_f32, dim3(2048), dim3(256), 0, c->stream, buf, n, c->scratch_a);
+  ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
+  ELLC_HIP(c, hipEventSynchronize(c->ev1));
+  float ms = 0;
+  ELLC_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  if (avg_ms) *avg_ms = ms / reps;
+  hipFree(buf);
   return ELLC_OK;
 }
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ void hyp_store(const DepthSoA& s, int i, const Hyp& h
 
 // u8 tap without the out-of-bounds sentinel (Frame.h:181, checkOutfBound = 0)
 __device__ __forceinline__ float tap_plain(const uint8_t* img, int sw, int cols, int rows, float x, float y) {
-  const Taps t = tap_point<false>(img, sw, cols, rows, x, y);
+  const Taps t = tap_point<false>(as_global(img), sw, cols, rows, x, y);
   return (t.I == -1.0f) ? 0.0f : t.I;   // four zero samples interpolate to 0 (NaN coordinates: reference UB)
 }
 
@@ -560,7 +560,7 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
   if (idnew_best_match < 0) return -2.0f;
   const float photoDispError = 4.0f * (float)DM_CAMERA_PIXEL_NOISE / (gradAlongLine + DM_DIVISION_EPS);
   const float trackingErrorFac = 0.25f * 1.0f;
-  const Taps gt = tap_point<true>(a.kfImg, a.sw, W, H, u, v);
+  const Taps gt = tap_point<true>(as_global(a.kfImg), a.sw, W, H, u, v);
   const float g0 = gt.gx, g1 = gt.gy;
   float geoDispError = (g0 * epxn + g1 * epyn) + DM_DIVISION_EPS;
   geoDispError = trackingErrorFac * trackingErrorFac * (g0 * g0 + g1 * g1) / (geoDispError * geoDispError);

@@ -13,6 +13,18 @@
 
 namespace ellc {
 
+// Pointers read out of device-resident tables are "flat" to the compiler (it emits flat_load and 64-bit address
+// arithmetic per lane). Everything this library indexes lives in global memory, so the hot kernels say so.
+#define ELLC_GLOBAL __attribute__((address_space(1)))
+typedef const ELLC_GLOBAL uint8_t* g_u8;
+typedef const ELLC_GLOBAL float* g_f32;
+typedef const ELLC_GLOBAL double* g_f64;
+typedef const ELLC_GLOBAL uint32_t* g_u32;
+template <class T>
+__device__ __forceinline__ const ELLC_GLOBAL T* as_global(const T* p) { return (const ELLC_GLOBAL T*)p; }
+template <class T>
+__device__ __forceinline__ ELLC_GLOBAL T* as_global_rw(T* p) { return (ELLC_GLOBAL T*)p; }
+
 // ---------------------------------------------------------------------------------------------------
 // wave-wide sums (64 lanes) with DPP row operations; the total lands in lane 63.
 template <int CTRL, int RMASK>
@@ -61,7 +73,7 @@ struct Taps {
 // gradient samples are rebuilt from the u8 image with the reference's border rules (interior central
 // difference x0.5, one-sided without 0.5 on the border), which is exact in f32.
 template <bool WANT_GRAD>
-__device__ __forceinline__ Taps tap_point(const uint8_t* __restrict__ img, int sw, int cols, int rows, float x1, float y1) {
+__device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, float x1, float y1) {
   Taps o;
   if (x1 != x1 || y1 != y1) {  // NaN: reference behaviour undefined; treated as out of bounds
     o.I = -1.0f; o.gx = 0.0f; o.gy = 0.0f;
@@ -83,9 +95,10 @@ __device__ __forceinline__ Taps tap_point(const uint8_t* __restrict__ img, int s
   const int y0 = (int)fminf(fmaxf(fy0, -4.0f), nR + 4.0f);
   const int xb = clampi(x0, 0, cols - 1), xc = clampi(x0 + 1, 0, cols - 1);
   const int yb = clampi(y0, 0, rows - 1), yc = clampi(y0 + 1, 0, rows - 1);
-  const uint8_t* rb = img + (size_t)yb * sw;
-  const uint8_t* rc = img + (size_t)yc * sw;
-  const float Pbb = (float)rb[xb], Pbc = (float)rb[xc], Pcb = (float)rc[xb], Pcc = (float)rc[xc];
+  // uniform base pointer + unsigned 32-bit lane offsets (SGPR-base global loads, no 64-bit lane arithmetic)
+  const unsigned rb = (unsigned)(yb * sw), rc = (unsigned)(yc * sw);
+  const float Pbb = (float)img[rb + (unsigned)xb], Pbc = (float)img[rb + (unsigned)xc];
+  const float Pcb = (float)img[rc + (unsigned)xb], Pcc = (float)img[rc + (unsigned)xc];
   const float omx = 1.0f - wx, omy = 1.0f - wy;
   {
     const float p00 = v00 ? Pbb : 0.0f, p01 = v01 ? Pbc : 0.0f, p10 = v10 ? Pcb : 0.0f, p11 = v11 ? Pcc : 0.0f;
@@ -96,10 +109,11 @@ __device__ __forceinline__ Taps tap_point(const uint8_t* __restrict__ img, int s
   if (WANT_GRAD) {
     const int xa = clampi(x0 - 1, 0, cols - 1), xd = clampi(x0 + 2, 0, cols - 1);
     const int ya = clampi(y0 - 1, 0, rows - 1), yd = clampi(y0 + 2, 0, rows - 1);
-    const uint8_t* ra = img + (size_t)ya * sw;
-    const uint8_t* rd = img + (size_t)yd * sw;
-    const float Pba = (float)rb[xa], Pbd = (float)rb[xd], Pca = (float)rc[xa], Pcd = (float)rc[xd];
-    const float Pab = (float)ra[xb], Pac = (float)ra[xc], Pdb = (float)rd[xb], Pdc = (float)rd[xc];
+    const unsigned ra = (unsigned)(ya * sw), rd = (unsigned)(yd * sw);
+    const float Pba = (float)img[rb + (unsigned)xa], Pbd = (float)img[rb + (unsigned)xd];
+    const float Pca = (float)img[rc + (unsigned)xa], Pcd = (float)img[rc + (unsigned)xd];
+    const float Pab = (float)img[ra + (unsigned)xb], Pac = (float)img[ra + (unsigned)xc];
+    const float Pdb = (float)img[rd + (unsigned)xb], Pdc = (float)img[rd + (unsigned)xc];
     // scale 1 on the border column/row of the tap itself, 0.5 inside
     const float sx0 = (x0 <= 0 || x0 >= cols - 1) ? 1.0f : 0.5f;
     const float sx1 = (x0 + 1 <= 0 || x0 + 1 >= cols - 1) ? 1.0f : 0.5f;
@@ -144,12 +158,12 @@ __device__ __forceinline__ void jacobian_row(float gradx, float grady, int x, in
   const float u = -g.cx + (float)x;
   const float v = -g.cy + (float)y;
   const float vu = v * u;
-  const float jb0 = (float)((double)grady * g.rowA[y]);
+  const float jb0 = (float)((double)grady * as_global(g.rowA)[y]);
   const float jt0 = gradx * (-vu / g.fy);
   const float jb1 = grady * (vu / g.fx);
-  const float jt1 = (float)((double)gradx * g.colA[x]);
-  const float jb2 = grady * g.colB[x];
-  const float jt2 = gradx * g.rowB[y];
+  const float jt1 = (float)((double)gradx * as_global(g.colA)[x]);
+  const float jb2 = grady * as_global(g.colB)[x];
+  const float jt2 = gradx * as_global(g.rowB)[y];
   const double invZ = 1.0 / (double)Z;
   const float jt3 = (float)((double)gradx * ((double)g.fx * invZ));
   const float jb4 = (float)((double)grady * ((double)g.fy * invZ));
@@ -212,9 +226,55 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------
-// FCA accumulate: grid (nblk, B). Each block owns a contiguous chunk of the alignment's compact pixel
-// list and writes one 27-float partial record.
+// One pixel of the FCA pass (PixelWisePyramid.cpp:236-361): J, residual, weight.
+struct FcaPix { float J[6]; float residual, wgt; };
+
 template <bool DEBUG>
+__device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
+                                            const float* S, unsigned i) {
+  const uint32_t xy = as_global(K.cxy)[i];
+  const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+  const float Z = as_global(K.cZ)[i];
+  const float var = as_global(K.cVar)[i];
+  const float Ikf = as_global(K.cI)[i];
+  const Warp w = warp_pixel(x, y, Z, g, S);
+  const Taps t = tap_point<true>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
+  FcaPix o;
+  jacobian_row(t.gx, t.gy, x, y, Z, g, o.J);
+  const bool oob = (t.I == -1.0f);
+  o.residual = oob ? 0.0f : (t.I - Ikf);
+  o.wgt = oob ? 0.0f : fca_weight(w, Z, o.residual, t.gx, t.gy, 1.0f * var, g, S[3], S[7], S[11]);
+  if (a.save_w) as_global_rw(K.wlast)[i] = o.wgt;
+  if (DEBUG) {
+    const size_t n = (size_t)g.n, p = (size_t)y * g.cols + x;
+    a.planes[0 * n + p] = o.residual;
+    a.planes[1 * n + p] = o.wgt;
+    a.planes[2 * n + p] = oob ? -1.0f : w.wx;
+    a.planes[3 * n + p] = oob ? -1.0f : w.wy;
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.planes[(4 + k) * n + p] = o.J[k];
+  }
+  return o;
+}
+
+// H += (w J)^T J (upper triangle), b += J (r w)   (PixelWisePyramid.cpp:364-374)
+__device__ __forceinline__ void fca_accumulate_pixel(float (&acc)[27], const FcaPix& p) {
+  const float rw = p.residual * p.wgt;
+  int q = 0;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const float wJ = p.J[r] * p.wgt;
+#pragma unroll
+    for (int c = r; c < 6; c++) { acc[q] = __builtin_fmaf(wJ, p.J[c], acc[q]); q++; }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; r++) acc[21 + r] = __builtin_fmaf(p.J[r], rw, acc[21 + r]);
+}
+
+// FCA accumulate: grid (nblk, B). Each block owns a contiguous chunk of the alignment's compact pixel
+// list and writes one 27-float partial record. ILP = pixels a thread keeps in flight per loop trip (the
+// per-pixel code is one long dependent chain of IEEE divisions; a second independent pixel fills its stalls).
+template <bool DEBUG, int ILP>
 __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   const int b = blockIdx.y;
   const AlignState& st = a.state[b];
@@ -229,47 +289,30 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = st.S[i];
-  const float tx = S[3], ty = S[7], tz = S[11];
-  const uint8_t* __restrict__ cur = F.img;
+  g_u8 cur = as_global(F.img);
 
   float acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0.0f;
 
-  for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
-    const uint32_t xy = K.cxy[i];
-    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-    const float Z = K.cZ[i];
-    const float var = K.cVar[i];
-    const float Ikf = K.cI[i];
-    const Warp w = warp_pixel(x, y, Z, g, S);
-    const Taps t = tap_point<true>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
-    float J[6];
-    jacobian_row(t.gx, t.gy, x, y, Z, g, J);
-    const bool oob = (t.I == -1.0f);
-    const float residual = oob ? 0.0f : (t.I - Ikf);
-    const float wgt = oob ? 0.0f : fca_weight(w, Z, residual, t.gx, t.gy, 1.0f * var, g, tx, ty, tz);
-    if (a.save_w) K.wlast[i] = wgt;
-    if (DEBUG) {
-      const size_t n = (size_t)g.n, p = (size_t)y * g.cols + x;
-      a.planes[0 * n + p] = residual;
-      a.planes[1 * n + p] = wgt;
-      a.planes[2 * n + p] = oob ? -1.0f : w.wx;
-      a.planes[3 * n + p] = oob ? -1.0f : w.wy;
-#pragma unroll
-      for (int k = 0; k < 6; k++) a.planes[(4 + k) * n + p] = J[k];
+  if (ILP == 1) {
+    for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
+      const FcaPix p = fca_pixel<DEBUG>(a, K, g, cur, S, i);
+      fca_accumulate_pixel(acc, p);
     }
-    // H += (w J)^T J (upper triangle), b += J (r w)   (PixelWisePyramid.cpp:364-374)
-    const float rw = residual * wgt;
-    int q = 0;
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-      const float wJ = J[r] * wgt;
-#pragma unroll
-      for (int c = r; c < 6; c++) { acc[q] = __builtin_fmaf(wJ, J[c], acc[q]); q++; }
+  } else {
+    for (int i = begin + (int)threadIdx.x; i < end; i += 2 * ELLC_GN_THREADS) {
+      const int i1 = i + ELLC_GN_THREADS;
+      const bool has1 = i1 < end;
+      const FcaPix p0 = fca_pixel<DEBUG>(a, K, g, cur, S, i);
+      if (has1) {
+        const FcaPix p1 = fca_pixel<DEBUG>(a, K, g, cur, S, i1);
+        fca_accumulate_pixel(acc, p0);   // same order as ILP == 1: pixel i, then pixel i + 256
+        fca_accumulate_pixel(acc, p1);
+      } else {
+        fca_accumulate_pixel(acc, p0);
+      }
     }
-#pragma unroll
-    for (int r = 0; r < 6; r++) acc[21 + r] = __builtin_fmaf(J[r], rw, acc[21 + r]);
   }
   block_reduce_store<27>(acc, a.partials + ((size_t)b * ELLC_NBLK_MAX + blockIdx.x) * ELLC_PART_STRIDE);
 }
@@ -287,28 +330,28 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_precompute(GnArgs a, i
   const int chunk = (V + a.nblk - 1) / a.nblk;
   const int begin = blockIdx.x * chunk;
   const int end = min(V, begin + chunk);
-  const uint8_t* __restrict__ img = K.img;
+  g_u8 img = as_global(K.img);
   float acc[21];
 #pragma unroll
   for (int i = 0; i < 21; i++) acc[i] = 0.0f;
   for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
-    const uint32_t xy = K.cxy[i];
+    const uint32_t xy = as_global(K.cxy)[i];
     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-    const float Z = K.cZ[i];
+    const float Z = as_global(K.cZ)[i];
     // frame::calculateGradient of the keyframe level image at (y,x)  (Frame.cpp:185-285)
     const int xm = clampi(x - 1, 0, g.cols - 1), xp = clampi(x + 1, 0, g.cols - 1);
     const int ym = clampi(y - 1, 0, g.rows - 1), yp = clampi(y + 1, 0, g.rows - 1);
     const float sx = (x == 0 || x == g.cols - 1) ? 1.0f : 0.5f;
     const float sy = (y == 0 || y == g.rows - 1) ? 1.0f : 0.5f;
-    const float gradx = sx * ((float)img[(size_t)y * g.sw + xp] - (float)img[(size_t)y * g.sw + xm]);
-    const float grady = sy * ((float)img[(size_t)yp * g.sw + x] - (float)img[(size_t)ym * g.sw + x]);
+    const float gradx = sx * ((float)img[(unsigned)(y * g.sw + xp)] - (float)img[(unsigned)(y * g.sw + xm)]);
+    const float grady = sy * ((float)img[(unsigned)(yp * g.sw + x)] - (float)img[(unsigned)(ym * g.sw + x)]);
     float J[6];
     jacobian_row(gradx, grady, x, y, Z, g, J);
-    const float wgt = K.cW[i];
+    const float wgt = as_global(K.cW)[i];
     int q = 0;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-      K.sd[(size_t)r * cap + i] = J[r];
+      as_global_rw(K.sd)[(size_t)r * cap + i] = J[r];
       const float wJ = J[r] * wgt;   // weightedSteepestDescent (:664-669)
 #pragma unroll
       for (int c = r; c < 6; c++) { acc[q] = __builtin_fmaf(wJ, J[c], acc[q]); q++; }
@@ -338,19 +381,20 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = st.S[i];
-  const uint8_t* __restrict__ cur = F.img;
+  g_u8 cur = as_global(F.img);
+  g_f32 sd = as_global(K.sd);
   float acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0.0f;
   for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
-    const uint32_t xy = K.cxy[i];
+    const uint32_t xy = as_global(K.cxy)[i];
     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-    const float Z = K.cZ[i];
+    const float Z = as_global(K.cZ)[i];
     const Warp w = warp_pixel(x, y, Z, g, S);
     const Taps t = tap_point<false>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
     const bool oob = (t.I == -1.0f);
-    const float residual = oob ? 0.0f : (t.I - K.cI[i]);
-    const float wgt = K.cW[i];
+    const float residual = oob ? 0.0f : (t.I - as_global(K.cI)[i]);
+    const float wgt = as_global(K.cW)[i];
     const float rw = residual * wgt;
     if (DEBUG) {
       const size_t n = (size_t)g.n, p = (size_t)y * g.cols + x;
@@ -359,10 +403,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
       a.planes[2 * n + p] = oob ? -1.0f : w.wx;
       a.planes[3 * n + p] = oob ? -1.0f : w.wy;
 #pragma unroll
-      for (int k = 0; k < 6; k++) a.planes[(4 + k) * n + p] = K.sd[(size_t)k * cap + i];
+      for (int k = 0; k < 6; k++) a.planes[(4 + k) * n + p] = sd[(size_t)k * cap + i];
     }
 #pragma unroll
-    for (int r = 0; r < 6; r++) acc[21 + r] = __builtin_fmaf(K.sd[(size_t)r * cap + i], rw, acc[21 + r]);
+    for (int r = 0; r < 6; r++) acc[21 + r] = __builtin_fmaf(sd[(size_t)r * cap + i], rw, acc[21 + r]);
   }
   block_reduce_store<27>(acc, a.partials + ((size_t)b * ELLC_NBLK_MAX + blockIdx.x) * ELLC_PART_STRIDE);
 }

@@ -77,20 +77,27 @@ __global__ void maxgrad_vertical(const float* __restrict__ mag, int w, int h, fl
   }
   tmp[(size_t)y * w + x] = v;
 }
-__global__ void maxgrad_horizontal(const float* __restrict__ mag, const float* __restrict__ tmp, int w, int h, float* __restrict__ out, int* count) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= w || y >= h) return;
-  float v = mag[(size_t)y * w + x];   // border pixels keep the raw magnitude
-  bool hit = false;
-  if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
-    const float g1 = fmaxf(tmp[(size_t)y * w + x - 1], tmp[(size_t)y * w + x]);
-    v = fmaxf(g1, tmp[(size_t)y * w + x + 1]);
-    if (v >= 5.0f) hit = true;   // MIN_ABS_GRAD_DECREASE
+__global__ __launch_bounds__(256) void maxgrad_horizontal(const float* __restrict__ mag, const float* __restrict__ tmp, int w, int h, float* __restrict__ out, int* count) {
+  int hits = 0;
+  const int n = w * h;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int y = i / w, x = i - y * w;
+    float v = mag[i];   // border pixels keep the raw magnitude
+    if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
+      const float g1 = fmaxf(tmp[i - 1], tmp[i]);
+      v = fmaxf(g1, tmp[i + 1]);
+      if (v >= 5.0f) hits++;   // MIN_ABS_GRAD_DECREASE
+    }
+    out[i] = v;
   }
-  out[(size_t)y * w + x] = v;
-  const unsigned long long m = __ballot(hit);   // active lanes only
-  if (m && ((int)__lane_id() == __ffsll((long long)m) - 1)) atomicAdd(count, __popcll(m));
+  __shared__ int sh[256];
+  sh[threadIdx.x] = hits;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && sh[0]) atomicAdd(count, sh[0]);
 }
 
 // depthMap::buildInvVarDepth, one level (DepthPropagation.cpp:1637-1719); the reference's source stride

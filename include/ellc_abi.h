@@ -173,6 +173,11 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* ctx, int B, const int* kf_slots, co
 ellc_status ellc_profile_align(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, const float* init_pose,
                                int mode, int reps, float* avg_ms);
 
+/* Counter calibration: stream `bytes` of device memory once per launch with 4-byte-per-lane loads (the access
+ * width of the compacted pixel arrays), `reps` launches, so FETCH_SIZE can be scaled against a known byte count
+ * (MI355X_MICROARCH.md, HBM section). Returns average milliseconds per launch. */
+ellc_status ellc_profile_calibrate_read(ellc_ctx* ctx, size_t bytes, int reps, float* avg_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Runs only the dominant kernel (gn_fca_accumulate, level 0) over a resident batch, plus the counter-calibration
+kernel — the process rocprofv3 wraps when collecting --kernel-trace / --pmc summaries for profiles/."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from egomotion_with_local_loop_closures_amd import api, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--width", type=int, default=640)
+ap.add_argument("--height", type=int, default=480)
+ap.add_argument("--levels", type=int, default=4)
+ap.add_argument("--level", type=int, default=0)
+ap.add_argument("--dense", action="store_true")
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--calib-mb", type=int, default=512)
+a = ap.parse_args()
+W, H, L, B = a.width, a.height, a.levels, a.batch
+fx, fy, cx, cy = synth.default_intrinsics(W, H)
+pairs = [synth.make_pair(W, H, seed=0x5EED + i, dense=a.dense) for i in range(min(8, B))]
+ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_keyframes=B, max_frames=B, max_batch=B))
+for b in range(B):
+    p = pairs[b % len(pairs)]
+    ctx.keyframe_upload(b, p["kf_image"]); ctx.keyframe_set_depth(b, p["depth0"], p["var0"]); ctx.frame_upload(b, p["cur_image"])
+slots = np.arange(B, dtype=np.int32)
+ms, alg, V = ctx.profile_gn_kernel(slots, slots, a.level, reps=a.reps)
+cal_bytes = a.calib_mb << 20
+cms = ctx.profile_calibrate_read(cal_bytes, reps=5)
+print(json.dumps({"kernel": "gn_fca_accumulate", "level": a.level, "batch": B, "avg_ms": ms, "algorithmic_bytes": alg, "valid_pixels": V,
+                  "achieved_GBps": alg / ms / 1e6, "launches": a.reps + 3, "calib_bytes_per_launch": cal_bytes, "calib_avg_ms": cms,
+                  "calib_GBps": cal_bytes / cms / 1e6, "calib_launches": 6}))
+ctx.close()
