@@ -118,7 +118,7 @@ def main():
         ms, alg_bytes, V = ctx.profile_gn_kernel(slots, slots, 0, reps=50)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "gn_fca_accumulate (level 0, batch %d)" % B, "achieved": achieved, "peak": 8000.0,
-                           "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "avg_launch_ms": ms,
+                           "unit": "GB/s", "frac": achieved / 8000.0, "traffic": pmc_traffic(a, B), "avg_launch_ms": ms,
                            "algorithmic_bytes_per_launch": alg_bytes, "valid_pixels_per_launch": V,
                            "valid_pixel_rate_Gpx_s": V / (ms * 1e-3) / 1e9}
         # ---- C1: the same path at B = 1 (latency-bound single alignment), for reference
@@ -137,6 +137,24 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(a, B):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE and
+    WRITE_SIZE passes over tools/profile_kernel.py, FETCH_SIZE scaled by the calibration kernel: profiles/*_pmc_summary.json).
+    Only valid for the workload the summary was taken on; otherwise null."""
+    import glob
+    if a.dense or a.mode != "fca" or (a.width, a.height, a.levels) != (640, 480, 4):
+        return None
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+            if d["profile_kernel_run"]["batch"] == B and d["profile_kernel_run"]["level"] == 0:
+                best = d["hbm_traffic"]["traffic_bytes_per_launch"]
+        except Exception:
+            pass
+    return best
 
 
 def cpu_baseline(a, pair, sched, gpu_value):
