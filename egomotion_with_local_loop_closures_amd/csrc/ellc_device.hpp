@@ -16,6 +16,8 @@ struct LevelGeom {
   int cols, rows, sw, sh;
   int n;                      // cols*rows
   float fx, fy, cx, cy;       // GetIntrinsic(level), UserDefinedFunc.cpp:34-50
+  float rfx, rfy;             // RN(1/fx), RN(1/fy): for the exact division-by-constant sequence (div_const)
+  int divc_ok;                // 1 when div_const was verified exhaustively for this fx, fy (all 2^23 mantissas)
   // per-level Jacobian tables (values that depend on the column or the row only; double where the
   // reference's pow() promotes the sub-expression to double, PixelWisePyramid.cpp:296-303)
   const double* colA;         // fx + u^2/fx              [cols]

@@ -129,8 +129,43 @@ static GnArgs make_gn_args(ellc_ctx* c, int level, int B, int save_w, float* pla
 }
 
 static void launch_fca(ellc_ctx* c, dim3 grd, dim3 blk, const GnArgs& a) {
-  if (c->gn_ilp == 2) hipLaunchKernelGGL((gn_fca_accumulate<false, 2>), grd, blk, 0, c->stream, a);
-  else hipLaunchKernelGGL((gn_fca_accumulate<false, 1>), grd, blk, 0, c->stream, a);
+  const bool divc = c->geom_h[0].divc_ok != 0;
+  if (c->gn_ilp == 2) {
+    if (divc) hipLaunchKernelGGL((gn_fca_accumulate<false, 2, true>), grd, blk, 0, c->stream, a);
+    else hipLaunchKernelGGL((gn_fca_accumulate<false, 2, false>), grd, blk, 0, c->stream, a);
+  } else {
+    if (divc) hipLaunchKernelGGL((gn_fca_accumulate<false, 1, true>), grd, blk, 0, c->stream, a);
+    else hipLaunchKernelGGL((gn_fca_accumulate<false, 1, false>), grd, blk, 0, c->stream, a);
+  }
+}
+
+// Exhaustive check of div_const(a, b, RN(1/b)) == a / b for every f32 mantissa of a (division commutes with the
+// power-of-two scaling of a and of b, so one binade of a covers all normal inputs and every pyramid level).
+__attribute__((target("fma"))) static bool verify_div_const_fma(float b) {
+  const float rb = (float)(1.0 / (double)b);
+  for (uint32_t m = 0; m < (1u << 23); m++) {
+    uint32_t bits = 0x3f800000u | m;
+    float a;
+    std::memcpy(&a, &bits, 4);
+    const float q = a * rb;
+    const float e = __builtin_fmaf(-b, q, a);
+    const float r = __builtin_fmaf(e, rb, q);
+    if (r != a / b) return false;
+  }
+  return true;
+}
+static bool verify_div_const(float b) {
+  static std::map<uint32_t, bool> cache;
+  if (!(b > 0.0f) || !std::isfinite(b)) return false;
+  if (!__builtin_cpu_supports("fma")) return false;   // no hardware fma on this host: keep the plain divisions
+  uint32_t bits;
+  std::memcpy(&bits, &b, 4);
+  bits &= 0x007fffffu;   // mantissa only
+  auto it = cache.find(bits);
+  if (it != cache.end()) return it->second;
+  const bool ok = verify_div_const_fma(b);
+  cache[bits] = ok;
+  return ok;
 }
 
 static void launch_solve(ellc_ctx* c, int level, int B, int nblk, int mode, int early_exit) {
@@ -264,6 +299,12 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     g.fy = (float)((double)cfg->fy / s);
     g.cx = (float)((double)cfg->cx / s);
     g.cy = (float)((double)cfg->cy / s);
+    g.rfx = (float)(1.0 / (double)g.fx);
+    g.rfy = (float)(1.0 / (double)g.fy);
+    {
+      const char* nd = getenv("ELLC_NO_DIVC");
+      g.divc_ok = (!(nd && nd[0] == '1') && verify_div_const(cfg->fx) && verify_div_const(cfg->fy)) ? 1 : 0;
+    }
     std::vector<double> colA(g.cols), rowA(g.rows);
     std::vector<float> colB(g.cols), rowB(g.rows);
     for (int x = 0; x < g.cols; x++) {
@@ -633,7 +674,8 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   GnArgs a = make_gn_args(c, level, 1, 0, planes ? c->planes_d : nullptr);
   const dim3 grd(a.nblk, 1), blk(ELLC_GN_THREADS);
   if (mode == ELLC_MODE_FCA) {
-    if (planes) hipLaunchKernelGGL((gn_fca_accumulate<true, 1>), grd, blk, 0, c->stream, a);
+    if (planes && c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_accumulate<true, 1, true>), grd, blk, 0, c->stream, a);
+    else if (planes) hipLaunchKernelGGL((gn_fca_accumulate<true, 1, false>), grd, blk, 0, c->stream, a);
     else launch_fca(c, grd, blk, a);
     launch_solve(c, level, 1, a.nblk, 0, 0);
   } else {

@@ -72,15 +72,47 @@ struct Taps {
 // The three bilinear taps of one warped point. The gradient planes are never materialised: the four
 // gradient samples are rebuilt from the u8 image with the reference's border rules (interior central
 // difference x0.5, one-sided without 0.5 on the border), which is exact in f32.
+// Fast path: when every active lane of the wave samples the interior (all 16 neighbours in range, none of the
+// four taps on a border column/row) the validity selects, clamps and border scales drop out; the arithmetic
+// that remains is the same expression, so the results are bit-identical to the general path.
 template <bool WANT_GRAD>
 __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, float x1, float y1) {
   Taps o;
+  const float fx0 = floorf(x1), fy0 = floorf(y1);
+  const float wx = x1 - fx0, wy = y1 - fy0;
+  const float omx = 1.0f - wx, omy = 1.0f - wy;
+  const bool interior = (fx0 >= 1.0f) && (fx0 <= (float)(cols - 3)) && (fy0 >= 1.0f) && (fy0 <= (float)(rows - 3));   // false for NaN
+  if (__builtin_amdgcn_ballot_w64(!interior) == 0ull) {
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const unsigned rb = (unsigned)(y0 * sw + x0), rc = rb + (unsigned)sw;
+    const float Pbb = (float)img[rb], Pbc = (float)img[rb + 1u], Pcb = (float)img[rc], Pcc = (float)img[rc + 1u];
+    {
+      const float top = (omx * Pbb) + (wx * Pbc);
+      const float btm = (omx * Pcb) + (wx * Pcc);
+      o.I = (omy * top) + (wy * btm);
+    }
+    if (WANT_GRAD) {
+      const unsigned ra = rb - (unsigned)sw, rd = rc + (unsigned)sw;
+      const float Pba = (float)img[rb - 1u], Pbd = (float)img[rb + 2u], Pca = (float)img[rc - 1u], Pcd = (float)img[rc + 2u];
+      const float Pab = (float)img[ra], Pac = (float)img[ra + 1u], Pdb = (float)img[rd], Pdc = (float)img[rd + 1u];
+      const float g00 = 0.5f * (Pbc - Pba), g01 = 0.5f * (Pbd - Pbb), g10 = 0.5f * (Pcc - Pca), g11 = 0.5f * (Pcd - Pcb);
+      float top = (omx * g00) + (wx * g01);
+      float btm = (omx * g10) + (wx * g11);
+      o.gx = (omy * top) + (wy * btm);
+      const float h00 = 0.5f * (Pcb - Pab), h01 = 0.5f * (Pcc - Pac), h10 = 0.5f * (Pdb - Pbb), h11 = 0.5f * (Pdc - Pbc);
+      top = (omx * h00) + (wx * h01);
+      btm = (omx * h10) + (wx * h11);
+      o.gy = (omy * top) + (wy * btm);
+    } else {
+      o.gx = 0.0f; o.gy = 0.0f;
+    }
+    return o;
+  }
+  // ---- general path: per-tap bounds tests of the reference (Frame.h:211-275)
   if (x1 != x1 || y1 != y1) {  // NaN: reference behaviour undefined; treated as out of bounds
     o.I = -1.0f; o.gx = 0.0f; o.gy = 0.0f;
     return o;
   }
-  const float fx0 = floorf(x1), fy0 = floorf(y1);
-  const float wx = x1 - fx0, wy = y1 - fy0;
   const float nC = (float)(cols - 1), nR = (float)(rows - 1);
   const bool xf_bad = (fx0 < 0.0f) || (fx0 > nC);
   const bool xc_bad = (x1 < 0.0f) || (x1 > nC);
@@ -99,7 +131,6 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
   const unsigned rb = (unsigned)(yb * sw), rc = (unsigned)(yc * sw);
   const float Pbb = (float)img[rb + (unsigned)xb], Pbc = (float)img[rb + (unsigned)xc];
   const float Pcb = (float)img[rc + (unsigned)xb], Pcc = (float)img[rc + (unsigned)xc];
-  const float omx = 1.0f - wx, omy = 1.0f - wy;
   {
     const float p00 = v00 ? Pbb : 0.0f, p01 = v01 ? Pbc : 0.0f, p10 = v10 ? Pcb : 0.0f, p11 = v11 ? Pcc : 0.0f;
     const float top = (omx * p00) + (wx * p01);
@@ -137,12 +168,23 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
   return o;
 }
 
+// a / b for a per-level constant b with rb = RN(1/b): q = RN(a rb), e = a - b q (exact, fma), RN(q + e rb).
+// Correctly rounded (Markstein's final-step theorem); verified exhaustively on the host for the context's fx, fy
+// over all 2^23 mantissas of a before LevelGeom::divc_ok is set (ellc_hip.hip: verify_div_const).
+__device__ __forceinline__ float div_const(float a, float b, float rb) {
+  const float q = a * rb;
+  const float e = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(e, rb, q);
+}
+
 struct Warp { float px, py, pz, wx, wy; };
 
 // PixelWisePyramid.cpp:236-262
+template <bool DIVC>
 __device__ __forceinline__ Warp warp_pixel(int x, int y, float Z, const LevelGeom& g, const float* S) {
-  const float X = ((float)x - g.cx) * Z / g.fx;
-  const float Y = ((float)y - g.cy) * Z / g.fy;
+  const float aX = ((float)x - g.cx) * Z, aY = ((float)y - g.cy) * Z;
+  const float X = DIVC ? div_const(aX, g.fx, g.rfx) : aX / g.fx;
+  const float Y = DIVC ? div_const(aY, g.fy, g.rfy) : aY / g.fy;
   Warp o;
   o.px = (S[0] * X) + (S[1] * Y) + (S[2] * Z) + (S[3]);
   o.py = (S[4] * X) + (S[5] * Y) + (S[6] * Z) + (S[7]);
@@ -153,18 +195,19 @@ __device__ __forceinline__ Warp warp_pixel(int x, int y, float Z, const LevelGeo
   return o;
 }
 
-// PixelWisePyramid.cpp:296-320: 1x6 steepest-descent row at the reference pixel / reference depth
-__device__ __forceinline__ void jacobian_row(float gradx, float grady, int x, int y, float Z, const LevelGeom& g, float J[6]) {
+// PixelWisePyramid.cpp:296-320: 1x6 steepest-descent row at the reference pixel / reference depth.
+// invZ = pow(depth,-1) evaluated in double (the reference's promotion), shared with the weight term.
+template <bool DIVC>
+__device__ __forceinline__ void jacobian_row(float gradx, float grady, int x, int y, double invZ, const LevelGeom& g, float J[6]) {
   const float u = -g.cx + (float)x;
   const float v = -g.cy + (float)y;
   const float vu = v * u;
   const float jb0 = (float)((double)grady * as_global(g.rowA)[y]);
-  const float jt0 = gradx * (-vu / g.fy);
-  const float jb1 = grady * (vu / g.fx);
+  const float jt0 = gradx * (DIVC ? div_const(-vu, g.fy, g.rfy) : (-vu / g.fy));
+  const float jb1 = grady * (DIVC ? div_const(vu, g.fx, g.rfx) : (vu / g.fx));
   const float jt1 = (float)((double)gradx * as_global(g.colA)[x]);
   const float jb2 = grady * as_global(g.colB)[x];
   const float jt2 = gradx * as_global(g.rowB)[y];
-  const double invZ = 1.0 / (double)Z;
   const float jt3 = (float)((double)gradx * ((double)g.fx * invZ));
   const float jb4 = (float)((double)grady * ((double)g.fy * invZ));
   const float jb5 = (float)((double)grady * ((double)(-v) * invZ));
@@ -178,9 +221,10 @@ __device__ __forceinline__ void jacobian_row(float gradx, float grady, int x, in
 }
 
 // PixelWisePyramid.cpp:341-358
-__device__ __forceinline__ float fca_weight(const Warp& w, float Z, float residual, float gradx, float grady, float s,
+// d = 1.0f / Z is passed in: it equals (float)(1.0 / (double)Z) exactly (the reciprocal of a 24-bit number cannot sit
+// within 2^-54 of a 25-bit midpoint unless it is itself representable, so the double rounding is innocuous).
+__device__ __forceinline__ float fca_weight(const Warp& w, float d, float residual, float gradx, float grady, float s,
                                             const LevelGeom& g, float tx, float ty, float tz) {
-  const float d = 1.0f / Z;
   const float gx = g.fx * gradx;
   const float gy = g.fy * grady;
   const float den = (w.pz * w.pz) * d;
@@ -229,7 +273,7 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float* __re
 // One pixel of the FCA pass (PixelWisePyramid.cpp:236-361): J, residual, weight.
 struct FcaPix { float J[6]; float residual, wgt; };
 
-template <bool DEBUG>
+template <bool DEBUG, bool DIVC>
 __device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
                                             const float* S, unsigned i) {
   const uint32_t xy = as_global(K.cxy)[i];
@@ -237,13 +281,14 @@ __device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K
   const float Z = as_global(K.cZ)[i];
   const float var = as_global(K.cVar)[i];
   const float Ikf = as_global(K.cI)[i];
-  const Warp w = warp_pixel(x, y, Z, g, S);
+  const Warp w = warp_pixel<DIVC>(x, y, Z, g, S);
   const Taps t = tap_point<true>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
   FcaPix o;
-  jacobian_row(t.gx, t.gy, x, y, Z, g, o.J);
+  const double invZ = 1.0 / (double)Z;
+  jacobian_row<DIVC>(t.gx, t.gy, x, y, invZ, g, o.J);
   const bool oob = (t.I == -1.0f);
   o.residual = oob ? 0.0f : (t.I - Ikf);
-  o.wgt = oob ? 0.0f : fca_weight(w, Z, o.residual, t.gx, t.gy, 1.0f * var, g, S[3], S[7], S[11]);
+  o.wgt = oob ? 0.0f : fca_weight(w, (float)invZ, o.residual, t.gx, t.gy, 1.0f * var, g, S[3], S[7], S[11]);
   if (a.save_w) as_global_rw(K.wlast)[i] = o.wgt;
   if (DEBUG) {
     const size_t n = (size_t)g.n, p = (size_t)y * g.cols + x;
@@ -274,7 +319,7 @@ __device__ __forceinline__ void fca_accumulate_pixel(float (&acc)[27], const Fca
 // FCA accumulate: grid (nblk, B). Each block owns a contiguous chunk of the alignment's compact pixel
 // list and writes one 27-float partial record. ILP = pixels a thread keeps in flight per loop trip (the
 // per-pixel code is one long dependent chain of IEEE divisions; a second independent pixel fills its stalls).
-template <bool DEBUG, int ILP>
+template <bool DEBUG, int ILP, bool DIVC>
 __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   const int b = blockIdx.y;
   const AlignState& st = a.state[b];
@@ -297,16 +342,16 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
 
   if (ILP == 1) {
     for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
-      const FcaPix p = fca_pixel<DEBUG>(a, K, g, cur, S, i);
+      const FcaPix p = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
       fca_accumulate_pixel(acc, p);
     }
   } else {
     for (int i = begin + (int)threadIdx.x; i < end; i += 2 * ELLC_GN_THREADS) {
       const int i1 = i + ELLC_GN_THREADS;
       const bool has1 = i1 < end;
-      const FcaPix p0 = fca_pixel<DEBUG>(a, K, g, cur, S, i);
+      const FcaPix p0 = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
       if (has1) {
-        const FcaPix p1 = fca_pixel<DEBUG>(a, K, g, cur, S, i1);
+        const FcaPix p1 = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i1);
         fca_accumulate_pixel(acc, p0);   // same order as ILP == 1: pixel i, then pixel i + 256
         fca_accumulate_pixel(acc, p1);
       } else {
@@ -346,7 +391,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_precompute(GnArgs a, i
     const float gradx = sx * ((float)img[(unsigned)(y * g.sw + xp)] - (float)img[(unsigned)(y * g.sw + xm)]);
     const float grady = sy * ((float)img[(unsigned)(yp * g.sw + x)] - (float)img[(unsigned)(ym * g.sw + x)]);
     float J[6];
-    jacobian_row(gradx, grady, x, y, Z, g, J);
+    jacobian_row<false>(gradx, grady, x, y, 1.0 / (double)Z, g, J);
     const float wgt = as_global(K.cW)[i];
     int q = 0;
 #pragma unroll
@@ -390,7 +435,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
     const uint32_t xy = as_global(K.cxy)[i];
     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
     const float Z = as_global(K.cZ)[i];
-    const Warp w = warp_pixel(x, y, Z, g, S);
+    const Warp w = warp_pixel<false>(x, y, Z, g, S);
     const Taps t = tap_point<false>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
     const bool oob = (t.I == -1.0f);
     const float residual = oob ? 0.0f : (t.I - as_global(K.cI)[i]);
