@@ -55,6 +55,7 @@ struct ellc_ctx {
   // captured launch sequences of ellc_align, keyed by (B, unique keyframes, mode, save_weights)
   std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
   bool use_graph = true;
+  bool use_fused = true;        // FCA: solve folded into the next accumulate launch (ELLC_NO_FUSE=1 disables)
   int gn_ilp = 1;               // pixels in flight per thread in the FCA accumulate kernel (ELLC_GN_ILP)
   int nblk_override[ELLC_MAX_LEVELS] = {0};
   int resident_blocks = 1280;   // 256-thread blocks of the accumulate kernel resident on the device at once
@@ -80,7 +81,7 @@ ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg);
   } while (0)
 
 int choose_nblk(const ellc_ctx* c, int level, int B);
-ellc_status run_prep(ellc_ctx* c, int n_unique);
+ellc_status run_prep(ellc_ctx* c, int n_unique, int need_w);
 ellc_status build_depth_pyramid(ellc_ctx* c, int slot);
 ellc_status build_maxgrad(ellc_ctx* c, bool is_kf, int slot);
 }  // namespace ellc

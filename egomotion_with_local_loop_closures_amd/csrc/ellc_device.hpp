@@ -55,6 +55,7 @@ struct AlignState {
   float delta[6];
   float weighted;
   int level_done;             // level terminated by weightedPose < 1 (-1: none)
+  int pending;                // fused schedule: the previous launch left partial sums that are not solved yet
   int iters[ELLC_MAX_LEVELS];
   float H[36];
   float b[6];

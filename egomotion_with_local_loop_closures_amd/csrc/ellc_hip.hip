@@ -42,10 +42,18 @@ static ellc_status host_alloc(ellc_ctx* c, T** p, size_t count) {
 int choose_nblk(const ellc_ctx* c, int level, int B) {
   if (c->nblk_override[level] > 0) return std::min(ELLC_NBLK_MAX, c->nblk_override[level]);   // tuning knob (ELLC_NBLK=l0,l1,..)
   const int n = c->geom_h[level].n;
-  const int by_px = std::max(1, n / 1024);
+  const int by_px = std::max(1, n / 640);   // semi-dense maps are ~30 % valid: about one valid pixel per thread
   B = std::max(1, B);
   const int per = std::max(1, c->resident_blocks / B);    // one round of resident blocks (measured best: r01 sweep)
-  return std::min(ELLC_NBLK_MAX, std::min(by_px, per));
+  int nblk = std::min(ELLC_NBLK_MAX, std::min(by_px, per));
+  // small levels: one block per CU runs the (serial) solve prologue and the short pixel pass fastest, as long as a
+  // thread does not get more than ~4 pixels (r01 sweep: level 2 at B=32, 8 blocks beat 30; level 1 keeps 32)
+  const int cus = std::max(1, c->resident_blocks / (c->use_fused ? 4 : 5));
+  if (nblk * B > cus) {
+    const int one_per_cu = std::max(1, cus / B);
+    if (0.3 * n / (256.0 * one_per_cu) <= 4.0) nblk = std::min(nblk, one_per_cu);
+  }
+  return nblk;
 }
 
 static dim3 grid2d(int w, int h, dim3 blk) { return dim3((w + blk.x - 1) / blk.x, (h + blk.y - 1) / blk.y); }
@@ -92,8 +100,9 @@ ellc_status build_depth_pyramid(ellc_ctx* c, int slot) {
   return ELLC_OK;
 }
 
-ellc_status run_prep(ellc_ctx* c, int n_unique) {
+ellc_status run_prep(ellc_ctx* c, int n_unique, int need_w) {
   PrepArgs a;
+  a.need_w = need_w;
   a.geom = c->geom_d;
   a.kf_tab = c->kf_tab_d;
   a.slots = c->uniq_slot_d;
@@ -204,8 +213,38 @@ static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const in
   return ELLC_OK;
 }
 
+// FCA schedule with the solve of iteration n folded into the prologue of launch n+1 (gn_fca_fused): one launch per
+// Gauss-Newton iteration plus one final solve.
+static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) {
+  FusedArgs fa;
+  fa.seq = 0;
+  fa.prev_level = -1;
+  fa.prev_nblk = 0;
+  fa.early_exit = c->cfg.early_exit;
+  fa.stride_state = c->cfg.max_batch;
+  fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+  const bool divc = c->geom_h[0].divc_ok != 0;
+  for (int level = c->L - 1; level >= 0; level--) {
+    fa.g = make_gn_args(c, level, B, save_weights ? 1 : 0, nullptr);
+    const dim3 grd(fa.g.nblk, B), blk(ELLC_GN_THREADS);
+    for (int it = 0; it < c->cfg.max_iter[level]; it++) {
+      if (divc) hipLaunchKernelGGL((gn_fca_fused<true>), grd, blk, 0, c->stream, fa);
+      else hipLaunchKernelGGL((gn_fca_fused<false>), grd, blk, 0, c->stream, fa);
+      fa.prev_level = level;
+      fa.prev_nblk = fa.g.nblk;
+      fa.seq++;
+    }
+    if (save_weights)
+      hipLaunchKernelGGL(gn_add_saved_weights, dim3(64, B), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, level, c->cfg.max_keyframes);
+  }
+  hipLaunchKernelGGL(gn_fused_finish, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
+  ELLC_HIP(c, hipGetLastError());
+  return ELLC_OK;
+}
+
 // the level / iteration schedule of GetImagePoseEstimate (ImageFunc.cpp:150-292) as a launch sequence
 static ellc_status enqueue_schedule(ellc_ctx* c, int B, int mode, int save_weights) {
+  if (mode == ELLC_MODE_FCA && c->use_fused) return enqueue_schedule_fused(c, B, save_weights);
   for (int level = c->L - 1; level >= 0; level--) {
     GnArgs a = make_gn_args(c, level, B, (save_weights && mode == ELLC_MODE_FCA) ? 1 : 0, nullptr);
     const dim3 grd(a.nblk, B), blk(ELLC_GN_THREADS);
@@ -367,8 +406,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   TRY(dev_alloc(c, &c->kf_slot_d, MB)); TRY(dev_alloc(c, &c->fr_slot_d, MB)); TRY(dev_alloc(c, &c->uniq_slot_d, MB));
   TRY(host_alloc(c, &c->kf_slot_h, MB)); TRY(host_alloc(c, &c->fr_slot_h, MB)); TRY(host_alloc(c, &c->uniq_slot_h, MB));
   TRY(dev_alloc(c, &c->init_pose_d, MB * 6)); TRY(host_alloc(c, &c->init_pose_h, MB * 6));
-  TRY(dev_alloc(c, &c->state_d, MB)); TRY(host_alloc(c, &c->state_h, MB));
-  TRY(dev_alloc(c, &c->partials_d, (size_t)MB * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
+  TRY(dev_alloc(c, &c->state_d, 2 * (size_t)MB)); TRY(host_alloc(c, &c->state_h, MB));          // two launch-parity buffers
+  TRY(dev_alloc(c, &c->partials_d, 2 * (size_t)MB * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
   TRY(dev_alloc(c, &c->planes_d, 10 * n0));
   TRY(dev_alloc(c, &c->scratch_a, n0)); TRY(dev_alloc(c, &c->scratch_b, n0));
   // ---- depth map state
@@ -403,6 +442,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   }
   if (hipStreamSynchronize(c->stream) != hipSuccess) { *out = c; return fail(c, ELLC_ERR_HIP, "initial sync failed"); }
   {
+    if (const char* nf = getenv("ELLC_NO_FUSE")) c->use_fused = !(nf[0] == '1');
     const char* ng = getenv("ELLC_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
     if (const char* ilp = getenv("ELLC_GN_ILP")) c->gn_ilp = atoi(ilp) == 2 ? 2 : 1;
@@ -417,7 +457,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     }
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0)
-      c->resident_blocks = cus * 5;   // accumulate kernel: 89 VGPRs -> 5 waves/SIMD -> five 256-thread blocks per CU
+      c->resident_blocks = cus * (c->use_fused ? 4 : 5);   // 256-thread blocks per CU: 126 VGPRs (fused) -> 4 waves/SIMD, 92 -> 5
   }
 #undef TRY
   *out = c;
@@ -593,7 +633,7 @@ ellc_status ellc_keyframe_finalise_weights(ellc_ctx* c, int slot) {
 // prep + init + the whole level/iteration schedule; captured once per (B, unique keyframes, mode, save_weights)
 // into a hipGraph and replayed afterwards (the launches are too short to be issued one by one from the host)
 static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int save_weights) {
-  ellc_status s = run_prep(c, nu);   // mask / count per level: updationOnPyrChange, ImageFunc.cpp:158
+  ellc_status s = run_prep(c, nu, mode == ELLC_MODE_ICA ? 1 : 0);   // mask / count per level: updationOnPyrChange, ImageFunc.cpp:158
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
   return enqueue_schedule(c, B, mode, save_weights);
@@ -666,7 +706,7 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   int nu = 0;
   ellc_status s = stage_batch(c, 1, &kf_slot, &frame_slot, pose, &nu);
   if (s != ELLC_OK) return s;
-  s = run_prep(c, nu);
+  s = run_prep(c, nu, 1);
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_set_pose0, dim3(1), dim3(1), 0, c->stream, c->state_d, c->init_pose_d);
   const size_t n = (size_t)c->geom_h[level].n;
@@ -733,7 +773,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   int nu = 0;
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, nullptr, &nu);
   if (s != ELLC_OK) return s;
-  s = run_prep(c, nu);
+  s = run_prep(c, nu, 1);
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
   GnArgs a = make_gn_args(c, level, B, 0, nullptr);

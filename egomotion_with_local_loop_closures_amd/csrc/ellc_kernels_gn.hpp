@@ -524,104 +524,242 @@ struct SolveArgs {
 
 #define ELLC_SOLVE_THREADS 256
 
-// One block per alignment: fixed-order f64 combine of the block partials (all 256 threads load in parallel),
-// 6x6 LU inverse across six lanes, weightedPose and pose <- log(exp(delta^) exp(pose^)) on one lane
-// (PixelWisePyramid.cpp:441-491). Everything between the loads and the final stores lives in registers / LDS.
+struct SolveShared {
+  double part[ELLC_SOLVE_THREADS / 32][32];
+  double sums[32];
+  double prod[36];
+  float Hinv[36];
+  float delta[6];
+  float newpose[6];
+  float newS[12];
+  float weighted;
+  int level_done;
+};
+
+// The solve of one Gauss-Newton iteration for one alignment, executed by a whole 256-thread block
+// (PixelWisePyramid.cpp:441-491): fixed-order f64 combine of the nblk block partials (all threads load in
+// parallel), 6x6 LU inverse across six lanes, delta, weightedPose, pose <- log(exp(delta^) exp(pose^)) on one lane.
+// Results are left in `sh` (new pose, exp(new pose), weightedPose, level_done) for every thread; when `dst` is
+// non-null the state record is written too. src may alias dst. Ends with a block barrier.
+__device__ __forceinline__ void solve_step(SolveShared& sh, const float* __restrict__ partials, int nblk, int mode, int level, int early_exit,
+                                           const AlignState& src, AlignState* dst) {
+  const int t = threadIdx.x;
+  const int comp = t & 31, grp = t >> 5;
+  {
+    g_f32 p = as_global(partials) + comp;
+    double s = 0.0;
+    for (int k = grp; k < nblk; k += ELLC_SOLVE_THREADS / 32) s += (double)p[(size_t)k * ELLC_PART_STRIDE];
+    sh.part[grp][comp] = s;
+  }
+  if (mode == 2 && t < 36) sh.Hinv[t] = src.Hinv[t];   // ICA iterate: the level's precomputed inverse
+  __syncthreads();
+  if (t < 27) {
+    double s = sh.part[0][t];
+#pragma unroll
+    for (int g = 1; g < ELLC_SOLVE_THREADS / 32; g++) s += sh.part[g][t];
+    sh.sums[t] = s;
+  }
+  __syncthreads();
+  if (t < 64) {   // wave 0 finishes the job; wave-level barriers only inside
+    const int lane = t;
+    if (mode != 2) {
+      float Hm[36];
+      {
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int c = r; c < 6; c++) {
+            const float v = (float)sh.sums[q++];
+            Hm[r * 6 + c] = v;
+            Hm[c * 6 + r] = v;
+          }
+      }
+      float x[6];
+      lu_inverse6_lanes(Hm, lane < 6 ? lane : 0, x);
+      if (lane < 6) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) sh.Hinv[i * 6 + lane] = x[i];
+      }
+      if (lane == 0 && dst) {
+#pragma unroll
+        for (int i = 0; i < 36; i++) dst->H[i] = Hm[i];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (dst && lane < 36) dst->Hinv[lane] = sh.Hinv[lane];
+    if (mode == 1) {
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) sh.newpose[i] = src.pose[i];
+#pragma unroll
+        for (int i = 0; i < 12; i++) sh.newS[i] = src.S[i];
+        sh.weighted = src.weighted;
+        sh.level_done = src.level_done;
+      }
+    } else {
+      // delta = -(Hinv * b): cv::gemm f32 accumulates the products in double and rounds once
+      if (lane < 36) {
+        const int i = lane / 6, k = lane - 6 * i;
+        sh.prod[lane] = (double)(float)sh.sums[21 + k] * (double)sh.Hinv[i * 6 + k];
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      if (lane < 6) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += sh.prod[lane * 6 + k];
+        const float d = -(float)s;
+        sh.delta[lane] = d;
+        if (dst) {
+          dst->delta[lane] = d;
+          dst->b[lane] = (float)sh.sums[21 + lane];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      if (lane == 0) {
+        float delta[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) delta[i] = sh.delta[i];
+        const float weighted = fabsf(delta[0] * 100000.0f) + fabsf(delta[1] * 100000.0f) + fabsf(delta[2] * 100000.0f) +
+                               fabsf(delta[3] * 10000.0f) + fabsf(delta[4] * 10000.0f) + fabsf(delta[5] * 10000.0f);
+        // pose <- log(exp(delta) * exp(pose)); exp(pose) is the f32 matrix the pixel pass used
+        float D[12], C[12], np[6], S[12];
+        exp_se3_f32(delta, D);
+#pragma unroll
+        for (int i = 0; i < 12; i++) S[i] = src.S[i];
+        compose_f32(D, S, C);
+        log_se3_f32(C, np);
+        exp_se3_f32(np, S);
+#pragma unroll
+        for (int i = 0; i < 6; i++) sh.newpose[i] = np[i];
+#pragma unroll
+        for (int i = 0; i < 12; i++) sh.newS[i] = S[i];
+        sh.weighted = weighted;
+        sh.level_done = (early_exit && weighted < 1.0f) ? level : src.level_done;   // ImageFunc.cpp:251-252
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// One block per alignment (used by the ICA path, the single-step API and as the final solve of a fused schedule).
 __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_solve(SolveArgs a) {
   const int b = blockIdx.x;
   AlignState& st = a.state[b];
   if (st.level_done == a.level) return;
-  __shared__ double part[ELLC_SOLVE_THREADS / 32][32];
-  __shared__ double sums[32];
-  __shared__ float sHinv[36];
-  __shared__ double sprod[36];
-  __shared__ float sdelta[6];
-  const int t = threadIdx.x;
-  const int comp = t & 31, grp = t >> 5;
-  {
-    const float* p = a.partials + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE + comp;
-    double s = 0.0;
-    for (int k = grp; k < a.nblk; k += ELLC_SOLVE_THREADS / 32) s += (double)p[(size_t)k * ELLC_PART_STRIDE];
-    part[grp][comp] = s;
-  }
-  if (a.mode == 2 && t < 36) sHinv[t] = st.Hinv[t];   // ICA iterate: the level's precomputed inverse
-  __syncthreads();
-  if (t < 27) {
-    double s = part[0][t];
-#pragma unroll
-    for (int g = 1; g < ELLC_SOLVE_THREADS / 32; g++) s += part[g][t];
-    sums[t] = s;
-  }
-  __syncthreads();
-  if (t >= 64) return;   // wave 0 finishes the job (no block-wide barrier below this line)
-  const int lane = t;
-  if (a.mode != 2) {
-    float Hm[36];
-    {
-      int q = 0;
-#pragma unroll
-      for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int c = r; c < 6; c++) {
-          const float v = (float)sums[q++];
-          Hm[r * 6 + c] = v;
-          Hm[c * 6 + r] = v;
-        }
-    }
-    float x[6];
-    lu_inverse6_lanes(Hm, lane < 6 ? lane : 0, x);
-    if (lane < 6) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) sHinv[i * 6 + lane] = x[i];
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < 36; i++) st.H[i] = Hm[i];
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  if (a.mode != 2 && lane < 36) st.Hinv[lane] = sHinv[lane];
+  __shared__ SolveShared sh;
+  solve_step(sh, a.partials + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, a.nblk, a.mode, a.level, a.early_exit, st, &st);
   if (a.mode == 1) return;
-  // delta = -(Hinv * b): cv::gemm f32 accumulates the products in double and rounds once
-  if (lane < 36) {
-    const int i = lane / 6, k = lane - 6 * i;
-    sprod[lane] = (double)(float)sums[21 + k] * (double)sHinv[i * 6 + k];
+  const int t = threadIdx.x;
+  if (t < 6) st.pose[t] = sh.newpose[t];
+  if (t < 12) st.S[t] = sh.newS[t];
+  if (t == 0) {
+    st.weighted = sh.weighted;
+    st.iters[a.level] += 1;
+    st.level_done = sh.level_done;
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  if (lane < 6) {
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) s += sprod[lane * 6 + k];
-    const float d = -(float)s;
-    sdelta[lane] = d;
-    st.delta[lane] = d;
-    st.b[lane] = (float)sums[21 + lane];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused schedule for the FCA path: launch n first *consumes* the partial sums launch n-1 left behind (every
+// block of the alignment redoes the tiny solve, so no extra launch and no cross-block synchronisation is needed),
+// then runs its own pixel pass with the fresh pose. State and partials are double-buffered by launch parity:
+// launch n reads state[n&1] / partials[(n+1)&1] and writes state[(n+1)&1] / partials[n&1].
+struct FusedArgs {
+  GnArgs g;
+  int seq;          // launch index inside the schedule
+  int prev_level;   // level / block count of the launch whose partials are pending
+  int prev_nblk;
+  int early_exit;
+  int stride_state;     // elements between the two AlignState buffers
+  size_t stride_part;   // floats between the two partial buffers
+};
+
+template <bool DIVC>
+__global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_fused(FusedArgs fa) {
+  const GnArgs& a = fa.g;
+  const int b = blockIdx.y;
+  const AlignState& src = a.state[(size_t)(fa.seq & 1) * fa.stride_state + b];
+  AlignState* dst = a.state + (size_t)((fa.seq + 1) & 1) * fa.stride_state + b;
+  __shared__ SolveShared sh;
+  const int t = threadIdx.x;
+  const bool writer = (blockIdx.x == 0);
+  const int pending = src.pending;
+  if (pending) {
+    const float* prev = a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+    solve_step(sh, prev, fa.prev_nblk, 0, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr);
+  } else {
+    if (t < 6) sh.newpose[t] = src.pose[t];
+    if (t < 12) sh.newS[t] = src.S[t];
+    if (t == 0) { sh.weighted = src.weighted; sh.level_done = src.level_done; }
+    __syncthreads();
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  if (lane != 0) return;
-  float delta[6];
+  const int level_done = sh.level_done;
+  const bool skip = (level_done == a.level);
+  if (writer) {
+    if (t < 6) dst->pose[t] = sh.newpose[t];
+    if (t < 12) dst->S[t] = sh.newS[t];
+    if (t < ELLC_MAX_LEVELS) dst->iters[t] = src.iters[t] + ((pending && t == fa.prev_level) ? 1 : 0);
+    if (t == 0) {
+      dst->weighted = sh.weighted;
+      dst->level_done = level_done;
+      dst->pending = skip ? 0 : 1;
+    }
+  }
+  if (skip) return;
+  const LevelGeom g = a.geom[a.level];
+  const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
+  const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
+  const int V = *K.count;
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = blockIdx.x * chunk;
+  const int end = min(V, begin + chunk);
+  float S[12];
 #pragma unroll
-  for (int i = 0; i < 6; i++) delta[i] = sdelta[i];
-  const float weighted = fabsf(delta[0] * 100000.0f) + fabsf(delta[1] * 100000.0f) + fabsf(delta[2] * 100000.0f) +
-                         fabsf(delta[3] * 10000.0f) + fabsf(delta[4] * 10000.0f) + fabsf(delta[5] * 10000.0f);
-  // pose <- log(exp(delta) * exp(pose)); exp(pose) is the f32 matrix the pixel pass used
-  float D[12], C[12], np[6], S[12];
-  exp_se3_f32(delta, D);
+  for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
+  g_u8 cur = as_global(F.img);
+  float acc[27];
 #pragma unroll
-  for (int i = 0; i < 12; i++) S[i] = st.S[i];
-  compose_f32(D, S, C);
-  log_se3_f32(C, np);
-  exp_se3_f32(np, S);
-#pragma unroll
-  for (int i = 0; i < 6; i++) st.pose[i] = np[i];
-#pragma unroll
-  for (int i = 0; i < 12; i++) st.S[i] = S[i];
-  st.weighted = weighted;
-  st.iters[a.level] += 1;
-  if (a.early_exit && weighted < 1.0f) st.level_done = a.level;   // ImageFunc.cpp:251-252
+  for (int i = 0; i < 27; i++) acc[i] = 0.0f;
+  for (int i = begin + t; i < end; i += ELLC_GN_THREADS) {
+    const FcaPix p = fca_pixel<false, DIVC>(a, K, g, cur, S, i);
+    fca_accumulate_pixel(acc, p);
+  }
+  float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + blockIdx.x) * ELLC_PART_STRIDE;
+  block_reduce_store<27>(acc, out);
+}
+
+// Final solve of a fused schedule: consumes the last pending partials; result always lands in state buffer 0.
+__global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs fa) {
+  const GnArgs& a = fa.g;
+  const int b = blockIdx.x;
+  const AlignState& src = a.state[(size_t)(fa.seq & 1) * fa.stride_state + b];
+  AlignState* dst = a.state + b;
+  __shared__ SolveShared sh;
+  const int t = threadIdx.x;
+  const int pending = src.pending;
+  __shared__ int it_copy[ELLC_MAX_LEVELS];
+  if (t < ELLC_MAX_LEVELS) it_copy[t] = src.iters[t];
+  if (pending) {
+    const float* prev = a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+    solve_step(sh, prev, fa.prev_nblk, 0, fa.prev_level, fa.early_exit, src, dst);
+  } else {
+    if (t < 6) sh.newpose[t] = src.pose[t];
+    if (t < 12) sh.newS[t] = src.S[t];
+    if (t == 0) { sh.weighted = src.weighted; sh.level_done = src.level_done; }
+    __syncthreads();
+  }
+  if (t < 6) dst->pose[t] = sh.newpose[t];
+  if (t < 12) dst->S[t] = sh.newS[t];
+  if (t < ELLC_MAX_LEVELS) dst->iters[t] = it_copy[t] + ((pending && t == fa.prev_level) ? 1 : 0);
+  if (t == 0) {
+    dst->weighted = sh.weighted;
+    dst->level_done = sh.level_done;
+    dst->pending = 0;
+  }
 }
 
 // initial state from the caller's initial relative pose
@@ -636,6 +774,7 @@ __global__ void gn_init_state(AlignState* state, const float* init_pose, int B) 
   for (int i = 0; i < 12; i++) st.S[i] = S[i];
   st.weighted = 0.0f;
   st.level_done = -1;
+  st.pending = 0;
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) st.iters[l] = 0;
   for (int i = 0; i < 36; i++) { st.H[i] = 0.0f; st.Hinv[i] = 0.0f; }
   for (int i = 0; i < 6; i++) st.b[i] = 0.0f;

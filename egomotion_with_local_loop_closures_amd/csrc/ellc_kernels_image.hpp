@@ -5,6 +5,14 @@
 
 namespace ellc {
 
+#ifndef ELLC_GLOBAL
+#define ELLC_GLOBAL __attribute__((address_space(1)))
+#endif
+template <class T>
+__device__ __forceinline__ const ELLC_GLOBAL T* gptr(const T* p) { return (const ELLC_GLOBAL T*)p; }
+template <class T>
+__device__ __forceinline__ ELLC_GLOBAL T* gptr_rw(T* p) { return (ELLC_GLOBAL T*)p; }
+
 __device__ __forceinline__ int reflect101(int p, int len) {
   if (len == 1) return 0;
   while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
@@ -135,13 +143,14 @@ __global__ void depth_pyr_level(const float* __restrict__ sd, const float* __res
 // ---------------------------------------------------------------------------------------------------
 // Compaction of the keyframe's valid pixels (mask = depth_pyramid[l] > 0, Frame.cpp:295-301), raster
 // order preserved. Three launches cover all levels of all listed keyframe slots.
-#define ELLC_TILE 1024
+#define ELLC_TILE 2048          // pixels per block: 256 threads x 8 consecutive pixels (two float4 loads)
 
 struct PrepArgs {
   const LevelGeom* geom;
   const KfLevelDev* kf_tab;
   const int* slots;            // unique keyframe slots
   int levels, max_kf;
+  int need_w;                  // also gather the saved weights (ICA); the FCA path never reads them
   int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
 };
 
@@ -152,25 +161,45 @@ __device__ __forceinline__ int prep_level_of(const PrepArgs& a, int tile, int& l
   return l;
 }
 
+// eight consecutive depths of this thread (zeros past the end of the plane)
+__device__ __forceinline__ void prep_load8(const float* __restrict__ depth, int i0, int n, float (&d)[8]) {
+  if (i0 + 7 < n) {
+    const float4 a = *reinterpret_cast<const float4*>(depth + i0);
+    const float4 b = *reinterpret_cast<const float4*>(depth + i0 + 4);
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) d[j] = (i0 + j < n) ? depth[i0 + j] : 0.0f;
+  }
+}
+
+// inclusive scan inside a wave; returns the wave total through `total`
+__device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  total = __shfl(v, 63, 64);
+  return v;
+}
+
 __global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
   int local;
   const int level = prep_level_of(a, blockIdx.x, local);
   const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
   const int n = a.geom[level].n;
-  const int base = local * ELLC_TILE + threadIdx.x * 4;
+  const int i0 = local * ELLC_TILE + threadIdx.x * 8;
+  float d[8];
+  prep_load8(K.depth, i0, n, d);
   int c = 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int i = base + j;
-    if (i < n && K.depth[i] > 0.0f) c++;
-  }
+  for (int j = 0; j < 8; j++) c += (d[j] > 0.0f) ? 1 : 0;
   __shared__ int ws[4];
-  const unsigned long long m0 = 0;
-  (void)m0;
-  // wave totals through LDS
-  int v = c;
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  int tot;
+  wave_inclusive_scan(c, tot);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = tot;
   __syncthreads();
   if (threadIdx.x == 0) K.tile_count[local] = ws[0] + ws[1] + ws[2] + ws[3];
 }
@@ -184,61 +213,75 @@ __global__ __launch_bounds__(256) void prep_scan(PrepArgs a) {
   const int t0 = threadIdx.x * per;
   int s = 0;
   for (int i = t0; i < min(T, t0 + per); i++) s += K.tile_count[i];
-  __shared__ int sc[256];
-  sc[threadIdx.x] = s;
+  __shared__ int ws[4];
+  int tot;
+  const int inc = wave_inclusive_scan(s, tot);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = tot;
   __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const int v = (threadIdx.x >= off) ? sc[threadIdx.x - off] : 0;
-    __syncthreads();
-    sc[threadIdx.x] += v;
-    __syncthreads();
-  }
-  int run = sc[threadIdx.x] - s;   // exclusive prefix of this thread's span
+  int wbase = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wbase += ws[w];
+  int run = wbase + inc - s;   // exclusive prefix of this thread's span
   for (int i = t0; i < min(T, t0 + per); i++) {
     const int c = K.tile_count[i];
     K.tile_count[i] = run;
     run += c;
   }
-  if (threadIdx.x == 255) *K.count = sc[255];
+  if (threadIdx.x == 255) *K.count = wbase + inc;
 }
 
+// Scatter: thread t of the block owns pixels base + j*256 + t (j = 0..7), so every load and — through the
+// ballot ranks — every store of a wave is contiguous. Raster order = (j, wave, lane).
 __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   int local;
   const int level = prep_level_of(a, blockIdx.x, local);
   const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
   const LevelGeom& g = a.geom[level];
   const int n = g.n;
-  const int base = local * ELLC_TILE + threadIdx.x * 4;
-  float d[4];
-  int c = 0;
+  const int base = local * ELLC_TILE + (int)threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int cnt[32];   // [j][wave]
+  float d[8];
+  unsigned long long m[8];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int i = base + j;
-    d[j] = (i < n) ? K.depth[i] : 0.0f;
-    if (d[j] > 0.0f) c++;
+  for (int j = 0; j < 8; j++) {
+    const int i = base + j * 256;
+    d[j] = (i < n) ? gptr(K.depth)[(unsigned)i] : 0.0f;
+    m[j] = __ballot(d[j] > 0.0f);
+    if (lane == 0) cnt[j * 4 + wave] = __popcll(m[j]);
   }
-  // block exclusive scan of c
-  __shared__ int sc[256];
-  sc[threadIdx.x] = c;
   __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const int v = (threadIdx.x >= off) ? sc[threadIdx.x - off] : 0;
-    __syncthreads();
-    sc[threadIdx.x] += v;
-    __syncthreads();
+  if (threadIdx.x < 64) {   // exclusive scan of the 32 (j, wave) counts
+    int v = (lane < 32) ? cnt[lane] : 0, tot;
+    const int inc = wave_inclusive_scan(v, tot);
+    if (lane < 32) cnt[lane] = inc - v;
   }
-  int pos = K.tile_count[local] + sc[threadIdx.x] - c;
+  __syncthreads();
+  const int tile_off = K.tile_count[local];
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const float inv_cols = 1.0f / (float)g.cols;
+  const ELLC_GLOBAL float* var = gptr(K.var);
+  const ELLC_GLOBAL float* wgt = gptr(K.weight);
+  const ELLC_GLOBAL uint8_t* img = gptr(K.img);
+  ELLC_GLOBAL uint32_t* cxy = gptr_rw(K.cxy);
+  ELLC_GLOBAL float* cZ = gptr_rw(K.cZ);
+  ELLC_GLOBAL float* cVar = gptr_rw(K.cVar);
+  ELLC_GLOBAL float* cI = gptr_rw(K.cI);
+  ELLC_GLOBAL float* cW = gptr_rw(K.cW);
+  const int cols = g.cols, sw = g.sw, need_w = a.need_w;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < 8; j++) {
     if (d[j] > 0.0f) {
-      const int i = base + j;
-      const int y = i / g.cols, x = i - y * g.cols;
-      K.cxy[pos] = ((uint32_t)y << 16) | (uint32_t)x;
-      K.cZ[pos] = d[j];
-      K.cVar[pos] = K.var[i];
-      K.cI[pos] = (float)K.img[(size_t)y * g.sw + x];
-      K.cW[pos] = K.weight[i];
-      pos++;
+      const int i = base + j * 256;
+      const unsigned pos = (unsigned)(tile_off + cnt[j * 4 + wave] + __popcll(m[j] & lt));
+      int y = (int)(((float)i + 0.5f) * inv_cols);   // i < 2^24: exact conversion; corrected below
+      if (y * cols > i) y--;
+      if ((y + 1) * cols <= i) y++;
+      const int x = i - y * cols;
+      cxy[pos] = ((uint32_t)y << 16) | (uint32_t)x;
+      cZ[pos] = d[j];
+      cVar[pos] = var[(unsigned)i];
+      cI[pos] = (float)img[(unsigned)(y * sw + x)];
+      if (need_w) cW[pos] = wgt[(unsigned)i];
     }
   }
 }
