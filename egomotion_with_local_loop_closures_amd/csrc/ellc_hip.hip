@@ -778,10 +778,32 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
   GnArgs a = make_gn_args(c, level, B, 0, nullptr);
   const dim3 grd(a.nblk, B), blk(ELLC_GN_THREADS);
-  for (int i = 0; i < 3; i++) launch_fca(c, grd, blk, a);
-  ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
-  for (int i = 0; i < reps; i++) launch_fca(c, grd, blk, a);
-  ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
+  if (c->use_fused) {
+    // the production kernel of the FCA path: every launch first solves the previous launch's partial sums
+    FusedArgs fa;
+    fa.g = a;
+    fa.seq = 0;
+    fa.prev_level = level;
+    fa.prev_nblk = a.nblk;
+    fa.early_exit = 0;
+    fa.stride_state = c->cfg.max_batch;
+    fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+    const bool divc = c->geom_h[0].divc_ok != 0;
+    auto launch = [&]() {
+      if (divc) hipLaunchKernelGGL((gn_fca_fused<true>), grd, blk, 0, c->stream, fa);
+      else hipLaunchKernelGGL((gn_fca_fused<false>), grd, blk, 0, c->stream, fa);
+      fa.seq++;
+    };
+    for (int i = 0; i < 3; i++) launch();
+    ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < reps; i++) launch();
+    ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
+  } else {
+    for (int i = 0; i < 3; i++) launch_fca(c, grd, blk, a);
+    ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < reps; i++) launch_fca(c, grd, blk, a);
+    ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
+  }
   ELLC_HIP(c, hipEventSynchronize(c->ev1));
   float ms = 0;
   ELLC_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));

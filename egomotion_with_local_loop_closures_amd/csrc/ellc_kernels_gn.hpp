@@ -462,10 +462,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
 // Lane j (0..5) of a wave carries right-hand-side column j; every lane eliminates its own copy of A, so
 // the rounding sequence per entry is the scalar algorithm's. All indices are compile-time (registers only).
 // On return x[i] = Hinv[i][lane].
-__device__ __forceinline__ void lu_inverse6_lanes(const float (&Hin)[36], int lane, float (&x)[6]) {
-  float A[36];
-#pragma unroll
-  for (int i = 0; i < 36; i++) A[i] = Hin[i];
+__device__ __forceinline__ void lu_inverse6_lanes(float (&A)[36], int lane, float (&x)[6]) {   // A is destroyed
 #pragma unroll
   for (int i = 0; i < 6; i++) x[i] = (i == lane) ? 1.0f : 0.0f;
   bool singular = false;
@@ -575,15 +572,15 @@ __device__ __forceinline__ void solve_step(SolveShared& sh, const float* __restr
             Hm[c * 6 + r] = v;
           }
       }
+      if (lane == 0 && dst) {
+#pragma unroll
+        for (int i = 0; i < 36; i++) dst->H[i] = Hm[i];
+      }
       float x[6];
       lu_inverse6_lanes(Hm, lane < 6 ? lane : 0, x);
       if (lane < 6) {
 #pragma unroll
         for (int i = 0; i < 6; i++) sh.Hinv[i * 6 + lane] = x[i];
-      }
-      if (lane == 0 && dst) {
-#pragma unroll
-        for (int i = 0; i < 36; i++) dst->H[i] = Hm[i];
       }
     }
     __builtin_amdgcn_wave_barrier();

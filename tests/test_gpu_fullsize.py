@@ -1,0 +1,116 @@
+"""Parity at BASELINE.json's full sizes (C1, C2, C4) plus size-independent properties of the batched path."""
+import numpy as np
+import pytest
+from egomotion_with_local_loop_closures_amd import synth
+from helpers import oracle_problem, gpu_problem, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c1_640x480_single_alignment_and_planes(oracle, ellc):
+    """configs[1]: one keyframe vs one frame, 640x480, 4 levels — per-pixel planes bit-exact at level 0, pose <= 1e-5."""
+    W, H, L = 640, 480, 4
+    pair = synth.make_pair(W, H, seed=0x5EED)
+    _, kf, cur, dm = oracle_problem(oracle, W, H, L, pair)
+    ctx = gpu_problem(ellc, W, H, L, [pair])
+    pose = np.array([0.002, -0.001, 0.0015, 0.005, -0.004, 0.003], np.float32)
+    st = oracle.GNStepper(kf, cur, dm.depth_pyr(), 0, pose, planes=True)
+    ref = st.step(0)
+    pl = st.get_planes()
+    got = ctx.gn_iterate(0, 0, 0, pose, planes=True)
+    mask = kf.depth(0) > 0
+    assert 0.15 < mask.mean() < 0.4                      # semi-dense
+    for name in ("residual", "weight", "warpedX", "warpedY"):
+        assert bits_equal(got[name][mask], pl[name][mask]), name
+    for k in range(6):
+        assert bits_equal(got["J"][k][mask], pl["J"][k][mask])
+    Hs = 0.5 * (ref["Hd"] + ref["Hd"].T)
+    assert np.allclose(got["H"], Hs, rtol=2e-6)
+    st.close()
+    p_ref, it_ref, _ = oracle.align(kf, cur, dm.depth_pyr())
+    p, it, _ = ctx.align([0], [0])
+    assert list(it[0]) == list(it_ref)
+    err = np.linalg.norm(p[0] - p_ref)
+    print("C1 pose error vs oracle: %.2e" % err)
+    assert err <= 1e-5
+    ctx.close()
+
+
+def test_c2_batch32_matches_singles_and_oracle(oracle, ellc):
+    """configs[2]: 32 alignments in one launch sequence. Properties: each result equals the single-alignment run
+    (independence), is invariant under permutation of the batch, and (spot check) matches the oracle."""
+    W, H, L, B = 640, 480, 4, 32
+    pairs = [synth.make_pair(W, H, seed=900 + i) for i in range(4)]
+    ctx = gpu_problem(ellc, W, H, L, [pairs[b % 4] for b in range(B)])
+    slots = np.arange(B)
+    p_all, it_all, _ = ctx.align(slots, slots)
+    assert it_all.sum() == B * 32
+    perm = np.random.default_rng(0).permutation(B)
+    p_perm, _, _ = ctx.align(slots[perm], slots[perm])
+    assert np.array_equal(p_perm, p_all[perm])           # block decomposition does not depend on the position in the batch
+    for b in (0, 1, 2, 3, 17, 31):
+        p1, _, _ = ctx.align([b], [b])
+        assert np.linalg.norm(p1[0] - p_all[b]) < 2e-6
+    for b in range(4):                                   # slots b, b+4, ... hold the same scene
+        assert np.array_equal(p_all[b], p_all[b + 4])
+        _, kf, cur, dm = oracle_problem(oracle, W, H, L, pairs[b])
+        p_ref, _, _ = oracle.align(kf, cur, dm.depth_pyr())
+        assert np.linalg.norm(p_all[b] - p_ref) <= 1e-5
+    ctx.close()
+
+
+def test_c4_1280x960_dense_five_levels(oracle, ellc):
+    """configs[4] shape: 1280x960, 5 levels {4,7,9,12,12}, dense (all-pixel) residuals."""
+    W, H, L = 1280, 960, 5
+    mi = (4, 7, 9, 12, 12)
+    pair = synth.make_pair(W, H, seed=77, dense=True)
+    _, kf, cur, dm = oracle_problem(oracle, W, H, L, pair, max_iter=mi)
+    ctx = gpu_problem(ellc, W, H, L, [pair], max_iter=mi)
+    assert (kf.depth(0) > 0).mean() > 0.98
+    p_ref, it_ref, _ = oracle.align(kf, cur, dm.depth_pyr())
+    p, it, _ = ctx.align([0], [0])
+    assert list(it[0]) == list(it_ref) == list(mi)
+    err = np.linalg.norm(p[0] - p_ref)
+    print("C4 pose error vs oracle: %.2e" % err)
+    assert err <= 1e-5
+    ctx.close()
+
+
+def test_normal_equations_properties(ellc):
+    """H is symmetric positive semi-definite; scaling all weights by c scales H and b by c and leaves delta unchanged (ICA)."""
+    W, H, L = 320, 240, 4
+    pair = synth.make_pair(W, H, seed=44)
+    ctx = gpu_problem(ellc, W, H, L, [pair])
+    pose = np.zeros(6, np.float32)
+    g = ctx.gn_iterate(0, 0, 1, pose)
+    assert np.array_equal(g["H"], g["H"].T)
+    assert np.linalg.eigvalsh(g["H"].astype(np.float64)).min() > -1e-3 * np.abs(g["H"]).max()
+    shp = (H >> 1, W >> 1)
+    w1 = np.full(shp, 0.02, np.float32)
+    ctx.keyframe_set_weights(0, 1, w1, 1)
+    a = ctx.gn_iterate(0, 0, 1, pose, mode=1, it=0)
+    ctx.keyframe_set_weights(0, 1, 4.0 * w1, 1)          # power-of-two scale: exact in f32
+    b = ctx.gn_iterate(0, 0, 1, pose, mode=1, it=0)
+    assert np.array_equal(b["H"], 4.0 * a["H"]) and np.array_equal(b["b"], 4.0 * a["b"])
+    assert np.allclose(b["delta"], a["delta"], rtol=1e-4, atol=1e-9)
+    ctx.close()
+
+
+def test_ica_batch_against_oracle(oracle, ellc):
+    """Loop-closure mode (constant weights) as a batch, 640x480."""
+    W, H, L, B = 640, 480, 4, 3
+    pairs = [synth.make_pair(W, H, seed=300 + i) for i in range(B)]
+    ctx = gpu_problem(ellc, W, H, L, pairs)
+    refs = []
+    rng = np.random.default_rng(1)
+    for b, p in enumerate(pairs):
+        _, kf, cur, dm = oracle_problem(oracle, W, H, L, p)
+        for l in range(L):
+            w = rng.uniform(0.01, 0.0625, size=(H >> l, W >> l)).astype(np.float32)
+            kf.set_weights(l, w, 1)
+            ctx.keyframe_set_weights(b, l, w, 1)
+        refs.append(oracle.align(kf, cur, dm.depth_pyr(), loop_closure=True)[0])
+    p, it, _ = ctx.align(np.arange(B), np.arange(B), mode=1)
+    for b in range(B):
+        assert np.linalg.norm(p[b] - refs[b]) <= 1e-5, (b, p[b], refs[b])
+    ctx.close()

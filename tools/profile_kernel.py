@@ -32,7 +32,7 @@ slots = np.arange(B, dtype=np.int32)
 ms, alg, V = ctx.profile_gn_kernel(slots, slots, a.level, reps=a.reps)
 cal_bytes = a.calib_mb << 20
 cms = ctx.profile_calibrate_read(cal_bytes, reps=5)
-print(json.dumps({"kernel": "gn_fca_accumulate", "level": a.level, "batch": B, "avg_ms": ms, "algorithmic_bytes": alg, "valid_pixels": V,
+print(json.dumps({"kernel": "gn_fca_fused", "level": a.level, "batch": B, "avg_ms": ms, "algorithmic_bytes": alg, "valid_pixels": V,
                   "achieved_GBps": alg / ms / 1e6, "launches": a.reps + 3, "calib_bytes_per_launch": cal_bytes, "calib_avg_ms": cms,
                   "calib_GBps": cal_bytes / cms / 1e6, "calib_launches": 6}))
 ctx.close()

@@ -25,8 +25,8 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):
-        if "gn_fca_accumulate" in r["Kernel_Name"] or "calib_read" in r["Kernel_Name"]:
-            k = "gn_fca_accumulate" if "gn_fca" in r["Kernel_Name"] else "calib_read_f32"
+        if "gn_fca_" in r["Kernel_Name"] or "calib_read" in r["Kernel_Name"]:
+            k = "gn_fca_level0" if "gn_fca" in r["Kernel_Name"] else "calib_read_f32"
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg[k]["duration_us_" + name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     for k, v in agg.items():
@@ -38,7 +38,7 @@ for line in open(log):
     if line.startswith("{"):
         run = json.loads(line)
 summary["profile_kernel_run"] = run
-k = summary["kernels"].get("gn_fca_accumulate", {})
+k = summary["kernels"].get("gn_fca_level0", {})
 c = summary["kernels"].get("calib_read_f32", {})
 if run and "FETCH_SIZE" in k and "FETCH_SIZE" in c:
     factor = run["calib_bytes_per_launch"] / (c["FETCH_SIZE"] * 1024.0)   # known bytes / reported bytes (gfx950: 2.0)
