@@ -8,7 +8,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libellc_hip.so")
+SO_PATH = os.environ.get("ELLC_LIB_PATH") or os.path.join(CSRC, "libellc_hip.so")   # override: diagnostic builds only
 MAX_LEVELS = 8
 
 # every symbol include/ellc_abi.h declares (checked by tests/test_abi_symbols.py against the header text)

@@ -205,12 +205,23 @@ static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const in
     if (!seen) c->uniq_slot_h[nu++] = kf_slots[b];
     for (int i = 0; i < 6; i++) c->init_pose_h[b * 6 + i] = init_pose ? init_pose[b * 6 + i] : 0.0f;
   }
-  ELLC_HIP(c, hipMemcpyAsync(c->kf_slot_d, c->kf_slot_h, B * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  ELLC_HIP(c, hipMemcpyAsync(c->fr_slot_d, c->fr_slot_h, B * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  ELLC_HIP(c, hipMemcpyAsync(c->uniq_slot_d, c->uniq_slot_h, nu * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  ELLC_HIP(c, hipMemcpyAsync(c->init_pose_d, c->init_pose_h, B * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  // the pinned staging record may still be in flight from the previous call only if the caller skipped the fetch;
+  // ellc_align always fetches (synchronises), ellc_align_enqueue callers must fetch before enqueueing again
+  ELLC_HIP(c, hipMemcpyAsync(c->kf_slot_d, c->kf_slot_h, (size_t)9 * c->cfg.max_batch * sizeof(int), hipMemcpyHostToDevice, c->stream));
   *n_unique = nu;
   return ELLC_OK;
+}
+
+// big launches are throughput-bound: ask the register allocator for 5 waves/SIMD; small ones are latency-bound
+static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, bool big) {
+  const bool divc = c->geom_h[0].divc_ok != 0;
+  if (big) {
+    if (divc) hipLaunchKernelGGL((gn_fca_fused<true, 5>), grd, blk, 0, c->stream, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, 5>), grd, blk, 0, c->stream, fa);
+  } else {
+    if (divc) hipLaunchKernelGGL((gn_fca_fused<true, 1>), grd, blk, 0, c->stream, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, 1>), grd, blk, 0, c->stream, fa);
+  }
 }
 
 // FCA schedule with the solve of iteration n folded into the prologue of launch n+1 (gn_fca_fused): one launch per
@@ -228,8 +239,7 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
     fa.g = make_gn_args(c, level, B, save_weights ? 1 : 0, nullptr);
     const dim3 grd(fa.g.nblk, B), blk(ELLC_GN_THREADS);
     for (int it = 0; it < c->cfg.max_iter[level]; it++) {
-      if (divc) hipLaunchKernelGGL((gn_fca_fused<true>), grd, blk, 0, c->stream, fa);
-      else hipLaunchKernelGGL((gn_fca_fused<false>), grd, blk, 0, c->stream, fa);
+      launch_fused(c, grd, blk, fa, c->geom_h[level].n * B >= c->occ5_min_pixels);
       fa.prev_level = level;
       fa.prev_nblk = fa.g.nblk;
       fa.seq++;
@@ -403,9 +413,12 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   for (int s = 0; s < MF; s++) { TRY(dev_alloc(c, &c->fr_maxgrad[s], n0)); TRY(dev_alloc(c, &c->fr_maxgrad_count[s], 4)); }
   // ---- alignment work buffers
   const int MB = cfg->max_batch;
-  TRY(dev_alloc(c, &c->kf_slot_d, MB)); TRY(dev_alloc(c, &c->fr_slot_d, MB)); TRY(dev_alloc(c, &c->uniq_slot_d, MB));
-  TRY(host_alloc(c, &c->kf_slot_h, MB)); TRY(host_alloc(c, &c->fr_slot_h, MB)); TRY(host_alloc(c, &c->uniq_slot_h, MB));
-  TRY(dev_alloc(c, &c->init_pose_d, MB * 6)); TRY(host_alloc(c, &c->init_pose_h, MB * 6));
+  {  // one staging record per call: [kf_slot MB][fr_slot MB][unique MB][init_pose 6*MB], moved with a single copy
+    int *sd = nullptr, *shh = nullptr;
+    TRY(dev_alloc(c, &sd, (size_t)9 * MB)); TRY(host_alloc(c, &shh, (size_t)9 * MB));
+    c->kf_slot_d = sd; c->fr_slot_d = sd + MB; c->uniq_slot_d = sd + 2 * MB; c->init_pose_d = (float*)(sd + 3 * MB);
+    c->kf_slot_h = shh; c->fr_slot_h = shh + MB; c->uniq_slot_h = shh + 2 * MB; c->init_pose_h = (float*)(shh + 3 * MB);
+  }
   TRY(dev_alloc(c, &c->state_d, 2 * (size_t)MB)); TRY(host_alloc(c, &c->state_h, MB));          // two launch-parity buffers
   TRY(dev_alloc(c, &c->partials_d, 2 * (size_t)MB * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
   TRY(dev_alloc(c, &c->planes_d, 10 * n0));
@@ -443,6 +456,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   if (hipStreamSynchronize(c->stream) != hipSuccess) { *out = c; return fail(c, ELLC_ERR_HIP, "initial sync failed"); }
   {
     if (const char* nf = getenv("ELLC_NO_FUSE")) c->use_fused = !(nf[0] == '1');
+    if (const char* o5 = getenv("ELLC_OCC5_MIN_PIXELS")) c->occ5_min_pixels = atoll(o5);
     const char* ng = getenv("ELLC_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
     if (const char* ilp = getenv("ELLC_GN_ILP")) c->gn_ilp = atoi(ilp) == 2 ? 2 : 1;
@@ -786,12 +800,11 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     fa.prev_level = level;
     fa.prev_nblk = a.nblk;
     fa.early_exit = 0;
-    fa.stride_state = c->cfg.max_batch;
+      fa.stride_state = c->cfg.max_batch;
     fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
     const bool divc = c->geom_h[0].divc_ok != 0;
     auto launch = [&]() {
-      if (divc) hipLaunchKernelGGL((gn_fca_fused<true>), grd, blk, 0, c->stream, fa);
-      else hipLaunchKernelGGL((gn_fca_fused<false>), grd, blk, 0, c->stream, fa);
+      launch_fused(c, grd, blk, fa, c->geom_h[level].n * B >= c->occ5_min_pixels);
       fa.seq++;
     };
     for (int i = 0; i < 3; i++) launch();
@@ -842,6 +855,20 @@ __global__ __launch_bounds__(256) void calib_read_f32(const float* __restrict__ 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += p[i];
   if (acc == 1.2345e-30f) sink[0] = acc;   // keeps the loads alive
 }
+
+#ifdef ELLC_STAMPS
+// diagnostic build only: copies the cycle stamps of block (0,0) of the last fused launch
+ellc_status ellc_debug_stamps(ellc_ctx* c, unsigned long long* out64) {
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  ELLC_HIP(c, hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_stamps), 64 * sizeof(unsigned long long)));
+  return ELLC_OK;
+}
+ellc_status ellc_debug_block_stamps(ellc_ctx* c, unsigned long long* out, int nblocks) {
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  ELLC_HIP(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_stamps), (size_t)nblocks * 4 * sizeof(unsigned long long)));
+  return ELLC_OK;
+}
+#endif
 
 ellc_status ellc_profile_calibrate_read(ellc_ctx* c, size_t bytes, int reps, float* avg_ms) {
   if (!c || reps < 1 || bytes < 1024) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");

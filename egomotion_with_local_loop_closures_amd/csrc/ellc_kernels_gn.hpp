@@ -13,6 +13,32 @@
 
 namespace ellc {
 
+// In-kernel cycle stamps: diagnostic builds only (make STAMPS=1); the stamp buffer is read by nothing else.
+#ifdef ELLC_STAMPS
+__device__ unsigned long long g_stamps[64];
+__device__ unsigned long long g_block_stamps[4 * 8192];   // per block: start, prologue end, pixels done, end
+#define ELLC_BSTAMP(slot)                                                                                    \
+  do {                                                                                                       \
+    if (threadIdx.x == 0) {                                                                                  \
+      unsigned long long t__;                                                                                \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                        \
+      const unsigned bid__ = blockIdx.y * gridDim.x + blockIdx.x;                                            \
+      if (bid__ < 8192) g_block_stamps[bid__ * 4 + slot] = t__;                                              \
+    }                                                                                                        \
+  } while (0)
+#define ELLC_STAMP(id)                                                                                       \
+  do {                                                                                                       \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                                            \
+      unsigned long long t__;                                                                                \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                            \
+      g_stamps[id] = t__;                                                                                    \
+    }                                                                                                        \
+  } while (0)
+#else
+#define ELLC_STAMP(id) do { } while (0)
+#define ELLC_BSTAMP(slot) do { } while (0)
+#endif
+
 // Pointers read out of device-resident tables are "flat" to the compiler (it emits flat_load and 64-bit address
 // arithmetic per lane). Everything this library indexes lives in global memory, so the hot kernels say so.
 #define ELLC_GLOBAL __attribute__((address_space(1)))
@@ -273,14 +299,25 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float* __re
 // One pixel of the FCA pass (PixelWisePyramid.cpp:236-361): J, residual, weight.
 struct FcaPix { float J[6]; float residual, wgt; };
 
+struct FcaIn { uint32_t xy; float Z, var, Ikf; };   // one entry of the keyframe's compact pixel list
+
+__device__ __forceinline__ FcaIn fca_load(const KfLevelDev& K, unsigned i) {
+  FcaIn in;
+  in.xy = as_global(K.cxy)[i];
+  in.Z = as_global(K.cZ)[i];
+  in.var = as_global(K.cVar)[i];
+  in.Ikf = as_global(K.cI)[i];
+  return in;
+}
+
 template <bool DEBUG, bool DIVC>
-__device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
-                                            const float* S, unsigned i) {
-  const uint32_t xy = as_global(K.cxy)[i];
+__device__ __forceinline__ FcaPix fca_pixel_in(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
+                                               const float* S, unsigned i, const FcaIn& in) {
+  const uint32_t xy = in.xy;
   const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-  const float Z = as_global(K.cZ)[i];
-  const float var = as_global(K.cVar)[i];
-  const float Ikf = as_global(K.cI)[i];
+  const float Z = in.Z;
+  const float var = in.var;
+  const float Ikf = in.Ikf;
   const Warp w = warp_pixel<DIVC>(x, y, Z, g, S);
   const Taps t = tap_point<true>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
   FcaPix o;
@@ -302,6 +339,12 @@ __device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K
   return o;
 }
 
+template <bool DEBUG, bool DIVC>
+__device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
+                                            const float* S, unsigned i) {
+  return fca_pixel_in<DEBUG, DIVC>(a, K, g, cur, S, i, fca_load(K, i));
+}
+
 // H += (w J)^T J (upper triangle), b += J (r w)   (PixelWisePyramid.cpp:364-374)
 __device__ __forceinline__ void fca_accumulate_pixel(float (&acc)[27], const FcaPix& p) {
   const float rw = p.residual * p.wgt;
@@ -316,7 +359,7 @@ __device__ __forceinline__ void fca_accumulate_pixel(float (&acc)[27], const Fca
   for (int r = 0; r < 6; r++) acc[21 + r] = __builtin_fmaf(p.J[r], rw, acc[21 + r]);
 }
 
-// FCA accumulate: grid (nblk, B). Each block owns a contiguous chunk of the alignment's compact pixel
+// FCA accumulate: grid (nblk, B). Each block owns every nblk-th 256-pixel tile of the alignment's compact pixel
 // list and writes one 27-float partial record. ILP = pixels a thread keeps in flight per loop trip (the
 // per-pixel code is one long dependent chain of IEEE divisions; a second independent pixel fills its stalls).
 template <bool DEBUG, int ILP, bool DIVC>
@@ -328,9 +371,11 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int V = *K.count;
-  const int chunk = (V + a.nblk - 1) / a.nblk;
-  const int begin = blockIdx.x * chunk;
-  const int end = min(V, begin + chunk);
+  // tile-cyclic split of the compact list: block k takes the 256-pixel tiles k, k+nblk, k+2nblk, ... so every block
+  // samples the whole image (a contiguous split left blocks 2x apart in run time: border / cache-unfriendly regions)
+  const int begin = blockIdx.x * ELLC_GN_THREADS;
+  const int end = V;
+  const int stride = a.nblk * ELLC_GN_THREADS;
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = st.S[i];
@@ -341,13 +386,13 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   for (int i = 0; i < 27; i++) acc[i] = 0.0f;
 
   if (ILP == 1) {
-    for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
+    for (int i = begin + (int)threadIdx.x; i < end; i += stride) {
       const FcaPix p = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
       fca_accumulate_pixel(acc, p);
     }
   } else {
-    for (int i = begin + (int)threadIdx.x; i < end; i += 2 * ELLC_GN_THREADS) {
-      const int i1 = i + ELLC_GN_THREADS;
+    for (int i = begin + (int)threadIdx.x; i < end; i += 2 * stride) {
+      const int i1 = i + stride;
       const bool has1 = i1 < end;
       const FcaPix p0 = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
       if (has1) {
@@ -372,14 +417,16 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_precompute(GnArgs a, i
   const LevelGeom g = a.geom[a.level];
   const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
   const int V = *K.count;
-  const int chunk = (V + a.nblk - 1) / a.nblk;
-  const int begin = blockIdx.x * chunk;
-  const int end = min(V, begin + chunk);
+  // tile-cyclic split of the compact list: block k takes the 256-pixel tiles k, k+nblk, k+2nblk, ... so every block
+  // samples the whole image (a contiguous split left blocks 2x apart in run time: border / cache-unfriendly regions)
+  const int begin = blockIdx.x * ELLC_GN_THREADS;
+  const int end = V;
+  const int stride = a.nblk * ELLC_GN_THREADS;
   g_u8 img = as_global(K.img);
   float acc[21];
 #pragma unroll
   for (int i = 0; i < 21; i++) acc[i] = 0.0f;
-  for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
+  for (int i = begin + (int)threadIdx.x; i < end; i += stride) {
     const uint32_t xy = as_global(K.cxy)[i];
     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
     const float Z = as_global(K.cZ)[i];
@@ -420,9 +467,11 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
   const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int V = *K.count;
-  const int chunk = (V + a.nblk - 1) / a.nblk;
-  const int begin = blockIdx.x * chunk;
-  const int end = min(V, begin + chunk);
+  // tile-cyclic split of the compact list: block k takes the 256-pixel tiles k, k+nblk, k+2nblk, ... so every block
+  // samples the whole image (a contiguous split left blocks 2x apart in run time: border / cache-unfriendly regions)
+  const int begin = blockIdx.x * ELLC_GN_THREADS;
+  const int end = V;
+  const int stride = a.nblk * ELLC_GN_THREADS;
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = st.S[i];
@@ -431,7 +480,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
   float acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0.0f;
-  for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
+  for (int i = begin + (int)threadIdx.x; i < end; i += stride) {
     const uint32_t xy = as_global(K.cxy)[i];
     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
     const float Z = as_global(K.cZ)[i];
@@ -548,6 +597,7 @@ __device__ __forceinline__ void solve_step(SolveShared& sh, const float* __restr
     for (int k = grp; k < nblk; k += ELLC_SOLVE_THREADS / 32) s += (double)p[(size_t)k * ELLC_PART_STRIDE];
     sh.part[grp][comp] = s;
   }
+  ELLC_STAMP(1);
   if (mode == 2 && t < 36) sh.Hinv[t] = src.Hinv[t];   // ICA iterate: the level's precomputed inverse
   __syncthreads();
   if (t < 27) {
@@ -557,6 +607,7 @@ __device__ __forceinline__ void solve_step(SolveShared& sh, const float* __restr
     sh.sums[t] = s;
   }
   __syncthreads();
+  ELLC_STAMP(2);
   if (t < 64) {   // wave 0 finishes the job; wave-level barriers only inside
     const int lane = t;
     if (mode != 2) {
@@ -585,6 +636,7 @@ __device__ __forceinline__ void solve_step(SolveShared& sh, const float* __restr
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    ELLC_STAMP(3);
     if (dst && lane < 36) dst->Hinv[lane] = sh.Hinv[lane];
     if (mode == 1) {
       if (lane == 0) {
@@ -616,6 +668,7 @@ __device__ __forceinline__ void solve_step(SolveShared& sh, const float* __restr
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      ELLC_STAMP(4);
       if (lane == 0) {
         float delta[6];
 #pragma unroll
@@ -637,6 +690,7 @@ __device__ __forceinline__ void solve_step(SolveShared& sh, const float* __restr
         sh.weighted = weighted;
         sh.level_done = (early_exit && weighted < 1.0f) ? level : src.level_done;   // ImageFunc.cpp:251-252
       }
+      ELLC_STAMP(5);
     }
   }
   __syncthreads();
@@ -675,8 +729,8 @@ struct FusedArgs {
   size_t stride_part;   // floats between the two partial buffers
 };
 
-template <bool DIVC>
-__global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_fused(FusedArgs fa) {
+template <bool DIVC, int MINW>   // MINW: minimum waves per SIMD the register allocator must leave room for
+__global__ __launch_bounds__(ELLC_GN_THREADS, MINW) void gn_fca_fused(FusedArgs fa) {
   const GnArgs& a = fa.g;
   const int b = blockIdx.y;
   const AlignState& src = a.state[(size_t)(fa.seq & 1) * fa.stride_state + b];
@@ -684,7 +738,24 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_fused(FusedArgs fa) {
   __shared__ SolveShared sh;
   const int t = threadIdx.x;
   const bool writer = (blockIdx.x == 0);
+  ELLC_STAMP(0);
+  ELLC_BSTAMP(0);
   const int pending = src.pending;
+  // Issued before the solve: the dependent table loads (slot -> table entry -> count) and this thread's first
+  // compact pixel are in flight while the solve runs; none of them depends on the pose.
+  const LevelGeom g = a.geom[a.level];
+  const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
+  const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
+  const int V = *K.count;
+  // tile-cyclic split of the compact list: block k takes the 256-pixel tiles k, k+nblk, k+2nblk, ... so every block
+  // samples the whole image (a contiguous split left blocks 2x apart in run time: border / cache-unfriendly regions)
+  const int begin = blockIdx.x * ELLC_GN_THREADS;
+  const int end = V;
+  const int stride = a.nblk * ELLC_GN_THREADS;
+  g_u8 cur = as_global(F.img);
+  FcaIn first;
+  first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f;
+  if (begin + t < end) first = fca_load(K, (unsigned)(begin + t));
   if (pending) {
     const float* prev = a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
     solve_step(sh, prev, fa.prev_nblk, 0, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr);
@@ -694,6 +765,8 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_fused(FusedArgs fa) {
     if (t == 0) { sh.weighted = src.weighted; sh.level_done = src.level_done; }
     __syncthreads();
   }
+  ELLC_STAMP(6);
+  ELLC_BSTAMP(1);
   const int level_done = sh.level_done;
   const bool skip = (level_done == a.level);
   if (writer) {
@@ -707,26 +780,27 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_fused(FusedArgs fa) {
     }
   }
   if (skip) return;
-  const LevelGeom g = a.geom[a.level];
-  const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
-  const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
-  const int V = *K.count;
-  const int chunk = (V + a.nblk - 1) / a.nblk;
-  const int begin = blockIdx.x * chunk;
-  const int end = min(V, begin + chunk);
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
-  g_u8 cur = as_global(F.img);
   float acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0.0f;
-  for (int i = begin + t; i < end; i += ELLC_GN_THREADS) {
-    const FcaPix p = fca_pixel<false, DIVC>(a, K, g, cur, S, i);
+  int i = begin + t;
+  if (i < end) {
+    const FcaPix p = fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, first);
     fca_accumulate_pixel(acc, p);
+    for (i += stride; i < end; i += stride) {
+      const FcaPix q = fca_pixel<false, DIVC>(a, K, g, cur, S, (unsigned)i);
+      fca_accumulate_pixel(acc, q);
+    }
   }
+  ELLC_STAMP(7);
+  ELLC_BSTAMP(2);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + blockIdx.x) * ELLC_PART_STRIDE;
   block_reduce_store<27>(acc, out);
+  ELLC_STAMP(8);
+  ELLC_BSTAMP(3);
 }
 
 // Final solve of a fused schedule: consumes the last pending partials; result always lands in state buffer 0.

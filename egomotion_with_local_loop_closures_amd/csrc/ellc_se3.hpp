@@ -57,15 +57,22 @@ ELLC_HD void log_se3(const Rt& m, double xi[6]) {
   const double* R = m.R;
   const double cs = 0.5 * (R[0] + R[4] + R[8] - 1.0);
   const double hx = 0.5 * (R[7] - R[5]), hy = 0.5 * (R[2] - R[6]), hz = 0.5 * (R[3] - R[1]);
-  const double sn = sqrt(hx * hx + hy * hy + hz * hz);
-  const double ang = atan2(sn, cs);
+  const double s2 = hx * hx + hy * hy + hz * hz;   // sin^2 of the rotation angle
   double a, b, c;
-  if (cs > -0.99) {
-    double k;
-    if (sn < 1e-4) { const double s2 = sn * sn; k = 1.0 + s2 * (1.0 / 6.0) + s2 * s2 * (3.0 / 40.0); }
-    else k = ang / sn;
+  if (cs > 0.9 && s2 < 1e-2) {
+    // small rotation (the Gauss-Newton regime): angle/sin = asin(s)/s as a series in s^2 — no sqrt, no atan2.
+    // Truncation < 2e-16 relative for s^2 < 0.01.
+    const double k = 1.0 + s2 * (1.0 / 6.0 + s2 * (3.0 / 40.0 + s2 * (15.0 / 336.0 + s2 * (105.0 / 3456.0 + s2 * (945.0 / 42240.0 +
+                     s2 * (10395.0 / 599040.0 + s2 * (135135.0 / 9676800.0)))))));
+    a = hx * k; b = hy * k; c = hz * k;
+  } else if (cs > -0.99) {
+    const double sn = sqrt(s2);
+    const double ang = atan2(sn, cs);
+    const double k = (sn < 1e-8) ? 1.0 : ang / sn;
     a = hx * k; b = hy * k; c = hz * k;
   } else {
+    const double sn = sqrt(s2);
+    const double ang = atan2(sn, cs);
     // rotation close to pi: magnitude of the axis from the diagonal, signs from the skew / symmetric parts
     const double d = 1.0 - cs;
     double ux = sqrt(fmax(0.0, (R[0] - cs) / d)), uy = sqrt(fmax(0.0, (R[4] - cs) / d)), uz = sqrt(fmax(0.0, (R[8] - cs) / d));

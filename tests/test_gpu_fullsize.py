@@ -25,7 +25,7 @@ def test_c1_640x480_single_alignment_and_planes(oracle, ellc):
     for k in range(6):
         assert bits_equal(got["J"][k][mask], pl["J"][k][mask])
     Hs = 0.5 * (ref["Hd"] + ref["Hd"].T)
-    assert np.allclose(got["H"], Hs, rtol=2e-6)
+    assert np.allclose(got["H"], Hs, rtol=2e-6, atol=2e-7 * np.abs(Hs).max())   # small off-diagonals are cancelling sums
     st.close()
     p_ref, it_ref, _ = oracle.align(kf, cur, dm.depth_pyr())
     p, it, _ = ctx.align([0], [0])

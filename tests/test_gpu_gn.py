@@ -38,7 +38,7 @@ def test_fca_per_pixel_planes_bit_exact(problem, oracle, level):
     # reduction: different summation order only -> tight relative tolerance against the f64-summed oracle terms
     Hd = ref["Hd"]; bd = ref["bd"]
     Hs = 0.5 * (Hd + Hd.T)
-    assert np.allclose(got["H"], Hs, rtol=2e-6, atol=0), np.abs(got["H"] / Hs - 1).max()
+    assert np.allclose(got["H"], Hs, rtol=2e-6, atol=2e-7 * np.abs(Hs).max()), np.abs(got["H"] / Hs - 1).max()
     scale_b = np.abs(bd).max()
     assert np.allclose(got["b"], bd, rtol=1e-5, atol=1e-6 * scale_b)
     # solve + update against the oracle's own f32 path
@@ -97,7 +97,7 @@ def test_ica_constant_weight_path(problem, oracle):
         assert bits_equal(got["J"][k][mask], sd[k][mask])
     assert bits_equal(got["residual"][mask], pl["residual"][mask])
     Hs = 0.5 * (ref["Hd"] + ref["Hd"].T)
-    assert np.allclose(got["H"], Hs, rtol=2e-6)
+    assert np.allclose(got["H"], Hs, rtol=2e-6, atol=2e-7 * np.abs(Hs).max())   # small off-diagonals are cancelling sums
     assert np.allclose(got["b"], ref["bd"], rtol=1e-5, atol=1e-6 * np.abs(ref["bd"]).max())
     assert np.abs(got["pose"] - ref["pose"]).max() < 1e-6
     st.close()
