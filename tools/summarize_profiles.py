@@ -15,12 +15,12 @@ src = os.path.join(ROOT, "gpurun_out", "profiles_" + rnd)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 for name in ("bench_trace", "kernel_trace"):
-    f = glob.glob(os.path.join(src, name, "*", "*_kernel_stats.csv"))
+    f = sorted(glob.glob(os.path.join(src, name, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if f:
-        shutil.copy(f[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, name)))
+        shutil.copy(f[-1], os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, name)))
 summary = {"round": rnd, "source": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python3 tools/profile_kernel.py", "kernels": {}}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    f = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]
     if not f:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
