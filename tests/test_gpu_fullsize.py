@@ -114,3 +114,66 @@ def test_ica_batch_against_oracle(oracle, ellc):
     for b in range(B):
         assert np.linalg.norm(p[b] - refs[b]) <= 1e-5, (b, p[b], refs[b])
     ctx.close()
+
+
+def test_reference_default_size_480x270_odd_pyramid(oracle, ellc):
+    """The reference's shipped configuration (ExternVariable.h:50-59): 480x270, fx=410.6014, fy=409.0370. The pyramid has odd
+    sizes: stored 270,135,68,34 rows vs iterated 270,135,67,33 (Q13) — planes bit-exact on every level, pose <= 1e-5."""
+    W, H, L = 480, 270, 4
+    pair = synth.make_pair(W, H, seed=2017)
+    pair["intrinsics"] = (410.601403, 409.037007, 240.0, 135.0)
+    _, kf, cur, dm = oracle_problem(oracle, W, H, L, pair)
+    ctx = gpu_problem(ellc, W, H, L, [pair])
+    pose = np.array([0.003, -0.002, 0.001, 0.006, -0.003, 0.004], np.float32)
+    for level in (3, 2, 1, 0):
+        st = oracle.GNStepper(kf, cur, dm.depth_pyr(), level, pose, planes=True)
+        ref = st.step(0)
+        pl = st.get_planes()
+        got = ctx.gn_iterate(0, 0, level, pose, planes=True)
+        assert got["residual"].shape == (H >> level, W >> level)
+        mask = kf.depth(level) > 0
+        for name in ("residual", "weight", "warpedX", "warpedY"):
+            assert bits_equal(got[name][mask], pl[name][mask]), (level, name)
+        for k in range(6):
+            assert bits_equal(got["J"][k][mask], pl["J"][k][mask]), (level, k)
+        assert np.abs(got["pose"] - ref["pose"]).max() < 1e-6
+        st.close()
+    p_ref, it_ref, _ = oracle.align(kf, cur, dm.depth_pyr())
+    p, it, _ = ctx.align([0], [0])
+    assert list(it[0]) == list(it_ref)
+    assert np.linalg.norm(p[0] - p_ref) <= 1e-5
+    ctx.close()
+
+
+def test_depth_path_at_reference_default_size(oracle, ellc):
+    """observe + regularise + propagate at 480x270 with the reference intrinsics (fx != fy exercises the FX_INV quirk Q19)."""
+    W, H, L = 480, 270, 4
+    pair = synth.make_pair(W, H, seed=99, rot=0.005, trans=0.03)
+    fx, fy, cx, cy = 410.601403, 409.037007, 240.0, 135.0
+    ocfg = oracle.make_config(W, H, L, fx, fy, cx, cy)
+    kf = oracle.Frame(ocfg, pair["kf_image"], 1)
+    cur = oracle.Frame(ocfg, pair["cur_image"], 2)
+    cur.set_pose(origin=pair["xi_true"])
+    st = synth.make_depth_state(W, H, 5, pair["kf_image"], pair["idepth_true"])
+    dm = oracle.DepthMap(ocfg)
+    dm.set_keyframe(kf); dm.set_current(cur); dm.set_state(st)
+    ctx = ellc.Context(ellc.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, max_keyframes=2, max_frames=1))
+    ctx.keyframe_upload(0, pair["kf_image"]); ctx.frame_upload(0, pair["cur_image"]); ctx.keyframe_from_frame(1, 0)
+    ctx.depth_set_keyframe(0); ctx.depth_set_state(st)
+    dm.regularize(False); ctx.depth_regularize(False)
+    dm.observe(); ctx.depth_observe(0, pair["xi_true"])
+    dm.fill_holes(); ctx.depth_fill_holes()
+    dm.regularize(False); ctx.depth_regularize(False)
+    ref, got = dm.get_state(), ctx.depth_get_state()
+    assert np.array_equal(got["valid"], ref["valid"]) and np.array_equal(got["blacklisted"], ref["blacklisted"])
+    m = ref["valid"] != 0
+    for f in ("invDepth", "invDepthSmoothed", "variance", "varianceSmoothed", "validity"):
+        assert bits_equal(got[f][m], ref[f][m]), f
+    nk = oracle.Frame(ocfg, pair["cur_image"], 3); nk.set_pose(origin=pair["xi_true"])
+    dm.propagate(nk); ctx.depth_propagate(1, pair["xi_true"])
+    ref, got = dm.get_state(), ctx.depth_get_state()
+    assert np.array_equal(got["valid"], ref["valid"])
+    m = ref["valid"] != 0
+    for f in ("invDepth", "variance", "validity"):
+        assert bits_equal(got[f][m], ref[f][m]), f
+    ctx.close()
