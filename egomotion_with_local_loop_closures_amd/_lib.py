@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "ellc_se3_log", "ellc_depth_set_state", "ellc_depth_get_state", "ellc_depth_set_keyframe", "ellc_depth_propagate",
     "ellc_depth_observe", "ellc_depth_fill_holes", "ellc_depth_regularize", "ellc_depth_make_inv_depth_one",
     "ellc_depth_update_depth_image", "ellc_depth_create_keyframe", "ellc_depth_seeds", "ellc_profile_gn_kernel", "ellc_profile_align",
-    "ellc_profile_calibrate_read",
+    "ellc_profile_calibrate_read", "ellc_histogram", "ellc_kl_divergence", "ellc_copy_slot",
 ]
 
 
@@ -61,6 +61,7 @@ def lib():
         _lib = C.CDLL(SO_PATH)
         _lib.ellc_last_error.restype = C.c_char_p
         _lib.ellc_stream.restype = C.c_void_p
+        _lib.ellc_kl_divergence.restype = C.c_double
         for name in ABI_SYMBOLS:
             getattr(_lib, name)  # raises AttributeError if the library does not export it
     return _lib

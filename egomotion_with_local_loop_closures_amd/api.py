@@ -222,6 +222,15 @@ class Context:
         self._ck(self._l.ellc_depth_seeds(self.h, C.byref(f)), "ellc_depth_seeds")
         return f.value
 
+    # ---- loop-closure support
+    def histogram(self, is_kf, slot):
+        h = np.zeros(256, np.float32)
+        self._ck(self._l.ellc_histogram(self.h, int(is_kf), slot, _p(h)), "ellc_histogram")
+        return h
+
+    def copy_slot(self, dst_is_kf, dst, src_is_kf, src):
+        self._ck(self._l.ellc_copy_slot(self.h, int(dst_is_kf), dst, int(src_is_kf), src), "ellc_copy_slot")
+
     # ---- measurement hooks
     def profile_gn_kernel(self, kf_slots, frame_slots, level, reps=20):
         B, kf, fr, _ = self._batch(kf_slots, frame_slots, None)
@@ -268,3 +277,8 @@ def se3_log(T):
     p = np.zeros(6, np.float32)
     _lib.lib().ellc_se3_log(_p(T), _p(p))
     return p
+
+
+def kl_divergence(p, q):
+    p = np.ascontiguousarray(p, np.float32); q = np.ascontiguousarray(q, np.float32)
+    return float(_lib.lib().ellc_kl_divergence(_p(p), _p(q), p.size))

@@ -643,6 +643,80 @@ ellc_status ellc_keyframe_finalise_weights(ellc_ctx* c, int slot) {
   return ELLC_OK;
 }
 
+// ---- loop-closure support ----------------------------------------------------------------------------
+ellc_status ellc_histogram(ellc_ctx* c, int is_kf, int slot, float* hist256) {
+  if (!c || !hist256 || !slot_ok(slot, is_kf ? c->cfg.max_keyframes : c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (!(is_kf ? c->kf_has_image[slot] : c->fr_has_image[slot])) return fail(c, ELLC_ERR_NOT_READY, "slot empty");
+  const LevelGeom& g = c->geom_h[0];
+  const uint8_t* img = is_kf ? c->kf_tab_h[slot].img : c->fr_tab_h[slot].img;
+  unsigned* bins = (unsigned*)c->scratch_a;
+  ELLC_HIP(c, hipMemsetAsync(bins, 0, 256 * sizeof(unsigned), c->stream));
+  hipLaunchKernelGGL(hist256_u8, dim3(128), dim3(256), 0, c->stream, img, g.sw, g.cols, g.rows, bins);
+  ELLC_HIP(c, hipGetLastError());
+  unsigned counts[256];
+  ELLC_HIP(c, hipMemcpyAsync(counts, bins, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  float sum = 0;   // GlobalOptimize.cpp:79-89: f32 sum of the (integer-valued) bin counts, then bin /= sum
+  for (int i = 0; i < 256; i++) sum += (float)counts[i];
+  for (int i = 0; i < 256; i++) hist256[i] = (float)counts[i] / sum;
+  return ELLC_OK;
+}
+
+double ellc_kl_divergence(const float* p, const float* q, int n) {
+  double result = 0;
+  for (int j = 0; j < n; j++) {
+    const double a = p[j];
+    double b = q[j];
+    if (std::fabs(a) <= 2.220446049250313e-16) continue;
+    if (std::fabs(b) <= 2.220446049250313e-16) b = 1e-10;
+    result += a * std::log(a / b);
+  }
+  return result;
+}
+
+ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, int src) {
+  if (!c || !slot_ok(dst, dst_is_kf ? c->cfg.max_keyframes : c->cfg.max_frames) || !slot_ok(src, src_is_kf ? c->cfg.max_keyframes : c->cfg.max_frames))
+    return fail(c, ELLC_ERR_BAD_ARG, "bad slot");
+  if (!(src_is_kf ? c->kf_has_image[src] : c->fr_has_image[src])) return fail(c, ELLC_ERR_NOT_READY, "source slot empty");
+  if (dst_is_kf == src_is_kf && dst == src) return ELLC_OK;
+  const int MK = c->cfg.max_keyframes, MF = c->cfg.max_frames;
+  for (int l = 0; l < c->L; l++) {
+    const LevelGeom& g = c->geom_h[l];
+    const uint8_t* s_img = src_is_kf ? c->kf_tab_h[(size_t)l * MK + src].img : c->fr_tab_h[(size_t)l * MF + src].img;
+    uint8_t* d_img = dst_is_kf ? c->kf_tab_h[(size_t)l * MK + dst].img : c->fr_tab_h[(size_t)l * MF + dst].img;
+    ELLC_HIP(c, hipMemcpyAsync(d_img, s_img, (size_t)g.sw * g.sh, hipMemcpyDeviceToDevice, c->stream));
+    if (dst_is_kf) {
+      KfLevelDev& d = c->kf_tab_h[(size_t)l * MK + dst];
+      if (src_is_kf) {
+        const KfLevelDev& k = c->kf_tab_h[(size_t)l * MK + src];
+        ELLC_HIP(c, hipMemcpyAsync(d.depth, k.depth, (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream));
+        ELLC_HIP(c, hipMemcpyAsync(d.var, k.var, (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream));
+        ELLC_HIP(c, hipMemcpyAsync(d.weight, k.weight, (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream));
+        c->kf_num_weights[dst][l] = c->kf_num_weights[src][l];
+      } else {
+        ELLC_HIP(c, hipMemsetAsync(d.weight, 0, (size_t)g.n * 4, c->stream));
+        c->kf_num_weights[dst][l] = 0;
+      }
+    }
+  }
+  if (dst_is_kf) {
+    c->kf_has_image[dst] = 1;
+    c->kf_has_depth[dst] = src_is_kf ? c->kf_has_depth[src] : 0;
+    if (src_is_kf && c->kf_maxgrad_valid[src]) {
+      const size_t n0 = (size_t)c->cfg.width * c->cfg.height;
+      ELLC_HIP(c, hipMemcpyAsync(c->kf_maxgrad[dst], c->kf_maxgrad[src], n0 * 4, hipMemcpyDeviceToDevice, c->stream));
+      ELLC_HIP(c, hipMemcpyAsync(c->kf_maxgrad_count[dst], c->kf_maxgrad_count[src], 4, hipMemcpyDeviceToDevice, c->stream));
+      c->kf_maxgrad_valid[dst] = 1;
+    } else {
+      return build_maxgrad(c, true, dst);
+    }
+  } else {
+    c->fr_has_image[dst] = 1;
+    c->fr_maxgrad_valid[dst] = 0;
+  }
+  return ELLC_OK;
+}
+
 // ---- alignment -------------------------------------------------------------------------------------
 // prep + init + the whole level/iteration schedule; captured once per (B, unique keyframes, mode, save_weights)
 // into a hipGraph and replayed afterwards (the launches are too short to be issued one by one from the host)

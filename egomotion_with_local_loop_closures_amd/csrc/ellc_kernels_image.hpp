@@ -286,6 +286,21 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   }
 }
 
+// globalOptimize::calculateImageHistogram (GlobalOptimize.cpp:68): cv::calcHist, 256 uniform bins over [0,256).
+// Integer counts (LDS-privatised, then one integer atomic per bin and block) => order-independent, deterministic.
+__global__ __launch_bounds__(256) void hist256_u8(const uint8_t* __restrict__ img, int sw, int cols, int rows, unsigned* __restrict__ bins) {
+  __shared__ unsigned sh[256];
+  sh[threadIdx.x] = 0;
+  __syncthreads();
+  const int n = cols * rows;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int y = i / cols, x = i - y * cols;
+    atomicAdd(&sh[img[(size_t)y * sw + x]], 1u);
+  }
+  __syncthreads();
+  if (sh[threadIdx.x]) atomicAdd(&bins[threadIdx.x], sh[threadIdx.x]);
+}
+
 // frame::finaliseWeights (Frame.cpp:678-695): weight_pyramid[l] /= numWeightsAdded[l] — cv evaluates
 // Mat / int as a*(1/n) through convertTo (32f -> 32f, f32 work type): v * (float)(1.0/n) + 0.
 __global__ void scale_plane(float* p, int n, float s) {

@@ -3,8 +3,10 @@
 // KEYFRAME_PROPAGATE_INTERVAL frames and writes the reference's result files:
 //   poses_orig.txt   frameId kfId wx wy wz vx vy vz(poseWrtWorld) rescaleFactor seeds%        (main.cpp:373)
 //   matchframes.txt  frameId kfId pose6(poseWrtOrigin) rescaleFactor seeds% 0 0 0               (main.cpp:382)
+//   matchframes_globalopt.txt (LC mode)  testId matchId pose6 rescale seeds matchValue rms_error view_angle   (GlobalOptimize.cpp:580)
 // Input is a header-less file of W*H u8 frames (decode / undistort / resize stay outside, Frame.cpp:45-75).
-// Loop-closure candidate search (GlobalOptimize.cpp) and the MATLAB rotation averaging are not part of this path.
+// In LC mode finished keyframes go through the loop-closure ring (facade class globalOptimize); tracking-loss recovery
+// (findConnection) and the MATLAB rotation averaging are not part of this path.
 #include "../../include/ellc_facade.hpp"
 #include <cstdio>
 #include <fstream>
@@ -30,9 +32,16 @@ int main(int argc, char** argv) {
   try {
     ellc_config cfg;
     ellc_default_config(&cfg, W, H, levels);
+    if (lc) {   // keyframe slots 0,1: active / incoming; 2..44: the loop-closure ring; frame slot 3: the ring's test frame
+      cfg.max_keyframes = 2 + globalOptimize::MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
+      cfg.max_frames = 4;
+      cfg.max_batch = globalOptimize::MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
+    }
     Runtime rt(cfg);
     rt.FLAG_DO_LOOP_CLOSURE = lc;
     depthMap currentDepthMap(rt);
+    std::unique_ptr<globalOptimize> globalOptimizeLoop;
+    if (lc) globalOptimizeLoop.reset(new globalOptimize(rt, outdir + "/matchframes_globalopt.txt", 2, 3));
     std::vector<std::unique_ptr<frame>> frameptr_vector;
     frame* activeKeyFrame = nullptr;
     std::vector<uint8_t> buf((size_t)W * H);
@@ -61,6 +70,7 @@ int main(int argc, char** argv) {
       if ((frame_counter % KEYFRAME_PROPAGATE_INTERVAL == 0) || (frame_counter == max_frame_counter)) {   // main.cpp:404
         if (lc) activeKeyFrame->finaliseWeights();
         currentDepthMap.finaliseKeyframe();
+        if (lc) globalOptimizeLoop->pushToArray(activeKeyFrame, &currentDepthMap);   // main.cpp:462
         currentDepthMap.createKeyFrame(cur);
         activeKeyFrame = cur;
         frameptr_vector.erase(frameptr_vector.begin(), frameptr_vector.end() - 1);   // keep only the most recent frame

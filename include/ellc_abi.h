@@ -133,6 +133,16 @@ void ellc_concatenate_origin_pose(const float* src_1wrt0, const float* src_2wrt0
 void ellc_se3_exp(const float* pose6, float* T16);
 void ellc_se3_log(const float* T16, float* pose6);
 
+/* ---- loop-closure candidate selection support (globalOptimize, GlobalOptimize.cpp) -------------------------
+ * calculateImageHistogram (:40-100): 256-bin histogram of the level-0 image, counts as f32 divided by their f32 sum. */
+ellc_status ellc_histogram(ellc_ctx* ctx, int is_keyframe, int slot, float* hist256);
+/* compareImageHistogram (:116-122) = cv::compareHist(H1, H2, CV_COMP_KL_DIV): sum p*log(p/q) over bins with |p| > DBL_EPSILON,
+ * q replaced by 1e-10 when |q| <= DBL_EPSILON. Host-side. */
+double ellc_kl_divergence(const float* p, const float* q, int n);
+/* pushToArray deep-copies the finished keyframe and its depth map into a ring slot (:185-223): device-to-device copy of a
+ * slot's pyramids (keyframe -> keyframe also copies depth / variance / weight pyramids, maxAbsGradient and weight counts). */
+ellc_status ellc_copy_slot(ellc_ctx* ctx, int dst_is_keyframe, int dst_slot, int src_is_keyframe, int src_slot);
+
 /* ---- semi-dense depth map: class depthMap (DepthPropagation.cpp) -----------------------------------
  * One depth map per context (the reference's currentDepthMap). State is SoA on device:
  * invDepth, invDepthSmoothed, variance, varianceSmoothed f32; validity_counter, blacklisted i32; isValid u8

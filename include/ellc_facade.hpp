@@ -15,8 +15,10 @@
 #define ELLC_FACADE_HPP
 
 #include "ellc_abi.h"
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -43,8 +45,9 @@ class Runtime {
   void check(int st, const char* what) const {
     if (st != ELLC_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(st) + "): " + (ctx ? ellc_last_error(ctx) : "no context"));
   }
-  int next_frame_slot() { int s = frame_cursor_; frame_cursor_ = (frame_cursor_ + 1) % cfg.max_frames; return s; }
-  int other_keyframe_slot(int current) const { return (current + 1) % cfg.max_keyframes; }
+  int frame_ring = 3;             // tracking uses frame slots [0, frame_ring): current, t-1 and one spare
+  int next_frame_slot() { int s = frame_cursor_; frame_cursor_ = (frame_cursor_ + 1) % frame_ring; return s; }
+  int other_keyframe_slot(int current) const { return (current + 1) % 2; }   // keyframe slots 0 / 1: active and incoming
  private:
   int frame_cursor_ = 0;
 };
@@ -212,6 +215,181 @@ inline std::vector<float> GetImagePoseEstimate(frame* prev_frame, frame* current
   current_frame->calculatePoseWrtWorld(prev_frame, out);    // :306
   return std::vector<float>(out, out + 6);
 }
+
+// Local loop-closure detection (GlobalOptimize.h:39-97, GlobalOptimize.cpp). Keeps a ring of finished keyframes
+// (image, depth pyramid, averaged tracking weights) resident on the device, selects candidates for a test keyframe by
+// intensity-histogram KL divergence, frame gap and view angle (findMatch :274-416), and aligns the test keyframe against
+// ALL selected candidates with ONE batched constant-weight alignment (the reference runs them one by one, :566).
+// The candidate sequence does not depend on the alignment results (the reference restores the test frame's poses after
+// every match, :591-606), so collecting first and aligning once is equivalent.
+class globalOptimize {
+ public:
+  static const int MAX_LOOP_ARRAY_LENGTH = 20;                                   // ExternVariable.h:161
+  static const int MAX_LOOP_ARRAY_LENGTH_SCALE_AVG = MAX_LOOP_ARRAY_LENGTH * 2 + 3;   // :162
+  struct loopFrame {   // LoopFrame.h:24-39
+    float image_histogram[256];
+    int frameId = -1;
+    float poseWrtWorld[6];
+    float poseWrtOrigin[6];
+    bool isValid = false;
+    float rescaleFactor = 1.0f;   // this_frame->rescaleFactor
+    float seeds = 0.0f;           // this_currentDepthMap->calculate_no_of_Seeds()
+    int kf_slot = -1;             // device slot holding this_frame / this_currentDepthMap
+  };
+  Runtime* rt;
+  loopFrame loopFrameArray[MAX_LOOP_ARRAY_LENGTH_SCALE_AVG];
+  loopFrame currentLoopFrame;
+  std::ofstream match_file;
+  bool isloopClosureDetected = false;
+  bool connectionLost = false;
+  int loopClosureArrayId = -1, lastTestedLoopClosureArrayId = -1, firstTestedLoopClosureArrayId = -1;
+  int currentArrayId = 0, nextArrayId = 1;
+  int match_window_beg = 0, match_window_end = MAX_LOOP_ARRAY_LENGTH - 1;
+  float matchValue = 0, rms_error = 0, relative_view_angle = 0;
+  int ring_slot_base;   // keyframe slots [ring_slot_base, ring_slot_base + 43) belong to the ring
+  int test_frame_slot;  // frame slot that holds the test keyframe's pyramid during the batched alignment
+
+  // The runtime must have been created with max_keyframes >= ring_slot_base + 43, max_frames > test_frame_slot and
+  // max_batch >= MAX_LOOP_ARRAY_LENGTH_SCALE_AVG.
+  globalOptimize(Runtime& r, const std::string& matchfilepath, int ring_base, int test_slot)
+      : rt(&r), ring_slot_base(ring_base), test_frame_slot(test_slot) {
+    match_file.open(matchfilepath.c_str());
+  }
+
+  // GlobalOptimize.cpp:151-272 (FLAG_USE_LOOP_CLOSURE_TRIGGER off: every finished keyframe is tested)
+  void pushToArray(frame* currentframe, depthMap* currentDepthMap) {
+    loopFrame& slot = loopFrameArray[currentArrayId];
+    slot.kf_slot = ring_slot_base + currentArrayId;
+    calculateImageHistogram(currentframe);
+    rt->check(ellc_copy_slot(rt->ctx, 1, slot.kf_slot, 1, currentframe->kf_slot), "ellc_copy_slot");   // :185-186 deep copies
+    slot.frameId = currentLoopFrame.frameId;
+    slot.isValid = currentLoopFrame.isValid;
+    std::memcpy(slot.image_histogram, currentLoopFrame.image_histogram, sizeof(slot.image_histogram));
+    std::memcpy(slot.poseWrtWorld, currentframe->poseWrtWorld, 24);
+    std::memcpy(slot.poseWrtOrigin, currentframe->poseWrtOrigin, 24);
+    slot.rescaleFactor = currentframe->rescaleFactor;
+    slot.seeds = currentDepthMap->calculate_no_of_Seeds();
+    findMatchParallel(currentframe);
+  }
+
+ private:
+  // :40-100
+  void calculateImageHistogram(frame* currentframe) {
+    isloopClosureDetected = false;
+    loopClosureArrayId = -1;
+    currentLoopFrame.isValid = true;
+    currentLoopFrame.frameId = currentframe->frameId;
+    std::memcpy(currentLoopFrame.poseWrtWorld, currentframe->poseWrtWorld, 24);
+    std::memcpy(currentLoopFrame.poseWrtOrigin, currentframe->poseWrtOrigin, 24);
+    rt->check(ellc_histogram(rt->ctx, 1, currentframe->kf_slot, currentLoopFrame.image_histogram), "ellc_histogram");
+  }
+  // :436-452  third row of the rotation of exp(pose)
+  static void calculateViewVec(const float* pose, float* view_vec) {
+    float T[16];
+    ellc_se3_exp(pose, T);
+    view_vec[0] = T[8]; view_vec[1] = T[9]; view_vec[2] = T[10];
+  }
+  // :419-434
+  void calculateRotationStats(const float* p1, const float* p2) {
+    rms_error = (float)std::pow(std::pow(p1[0] - p2[0], 2) + std::pow(p1[1] - p2[1], 2) + std::pow(p1[2] - p2[2], 2), 0.5);
+    float v1[3], v2[3];
+    calculateViewVec(p1, v1);
+    calculateViewVec(p2, v2);
+    const float mag1 = (float)std::pow(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2], 0.5);
+    const float mag2 = (float)std::pow(v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2], 0.5);
+    relative_view_angle = std::acos((v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2]) / (mag1 * mag2));
+    relative_view_angle = (relative_view_angle * 180) / 3.14f;   // sic: 3.14
+  }
+  // :274-416 (strayFlag = false)
+  bool findMatch(frame* currentframe) {
+    const int RING = MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
+    calculateImageHistogram(currentframe);
+    int i;
+    if (lastTestedLoopClosureArrayId == -1) i = currentArrayId - 1;
+    else if (lastTestedLoopClosureArrayId != 0) i = lastTestedLoopClosureArrayId - 1;
+    else i = RING - 1;
+    if (i < 0) i = RING - 1;
+    int conditionToTerminateLoop = 0;
+    while (1) {
+      lastTestedLoopClosureArrayId = i;
+      if (match_window_end > match_window_beg) {
+        if (!((i >= match_window_beg) && (i <= match_window_end))) conditionToTerminateLoop = 1;
+      } else if (match_window_end < match_window_beg) {
+        if (!((i >= match_window_beg) || (i <= match_window_end))) conditionToTerminateLoop = 1;
+      } else if (loopFrameArray[i].isValid == false) conditionToTerminateLoop = 1;
+      if (conditionToTerminateLoop == 1) { lastTestedLoopClosureArrayId = -1; break; }
+      if (loopFrameArray[i].isValid == 0) { lastTestedLoopClosureArrayId = -1; return false; }
+      if (currentframe->frameId - loopFrameArray[i].frameId > 8) {   // MIN_MATCH_DIFFERENCE = KEYFRAME_PROPAGATE_INTERVAL
+        matchValue = (float)ellc_kl_divergence(loopFrameArray[i].image_histogram, currentLoopFrame.image_histogram, 256);
+        calculateRotationStats(loopFrameArray[i].poseWrtWorld, currentLoopFrame.poseWrtWorld);
+        if (matchValue <= 0.1f) {                       // MATCH_THRESHOLD
+          if (relative_view_angle <= 10.0f) {           // MAX_REL_VIEW_ANGLE
+            isloopClosureDetected = true;
+            loopClosureArrayId = i;
+            break;
+          }
+        }
+      }
+      i--;
+      if (i < 0) i = RING - 1;
+    }
+    return isloopClosureDetected;
+  }
+  // :454-646
+  void findMatchParallel(frame* testFrame) {
+    const int RING = MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
+    struct Match { int arrayId; float matchValue, rms, angle; };
+    std::vector<Match> matches;
+    loopFrameArray[nextArrayId].frameId = testFrame->frameId;
+    lastTestedLoopClosureArrayId = -1;
+    firstTestedLoopClosureArrayId = -1;
+    int num_matches = 0;
+    do {
+      const bool matchFound = findMatch(testFrame);
+      if (num_matches > 0 && lastTestedLoopClosureArrayId == firstTestedLoopClosureArrayId) break;
+      if (matchFound) {
+        if (num_matches == 0) firstTestedLoopClosureArrayId = lastTestedLoopClosureArrayId;
+        num_matches++;
+        matches.push_back(Match{loopClosureArrayId, matchValue, rms_error, relative_view_angle});
+      }
+    } while (lastTestedLoopClosureArrayId != -1);
+    if (!matches.empty()) {
+      // one batched constant-weight alignment for all candidates (GetImagePoseEstimate(..., fromLoopClosure = true), :566)
+      const int B = (int)matches.size();
+      std::vector<int> kf(B), fr(B, test_frame_slot);
+      std::vector<float> init((size_t)B * 6), out((size_t)B * 6);
+      rt->check(ellc_copy_slot(rt->ctx, 0, test_frame_slot, 1, testFrame->kf_slot), "ellc_copy_slot");
+      for (int b = 0; b < B; b++) {
+        const loopFrame& m = loopFrameArray[matches[b].arrayId];
+        kf[b] = m.kf_slot;
+        ellc_concatenate_origin_pose(testFrame->poseWrtWorld, m.poseWrtWorld, &init[(size_t)b * 6]);   // ImageFunc.cpp:106
+      }
+      rt->check(ellc_align(rt->ctx, B, kf.data(), fr.data(), init.data(), ELLC_MODE_ICA, 0, out.data(), nullptr, nullptr), "ellc_align");
+      for (int b = 0; b < B; b++) {
+        const loopFrame& m = loopFrameArray[matches[b].arrayId];
+        float poseWrtOrigin[6];
+        ellc_concatenate_relative_pose(&out[(size_t)b * 6], m.poseWrtOrigin, poseWrtOrigin);   // ImageFunc.cpp:305
+        const int seeds_num = (int)m.seeds;   // `int seeds_num` in the reference (:466)
+        if (match_file.is_open()) {           // :580
+          match_file << (testFrame->frameId + rt->BATCH_START_ID - 1) << " " << (m.frameId + rt->BATCH_START_ID - 1) << " " << poseWrtOrigin[0] << " "
+                     << poseWrtOrigin[1] << " " << poseWrtOrigin[2] << " " << poseWrtOrigin[3] << " " << poseWrtOrigin[4] << " " << poseWrtOrigin[5]
+                     << " " << m.rescaleFactor << " " << seeds_num << " " << matches[b].matchValue << " " << matches[b].rms << " "
+                     << matches[b].angle << "\n";
+        }
+      }
+      match_file.flush();
+    }
+    // :614-641
+    currentArrayId++;
+    nextArrayId++;
+    if (currentArrayId == match_window_end + 2) { match_window_beg++; match_window_end++; }
+    if (currentArrayId == 1 && match_window_end == RING - 1) { match_window_beg++; match_window_end = 0; }
+    if (currentArrayId == RING) currentArrayId = 0;
+    if (nextArrayId == RING) nextArrayId = 0;
+    if (match_window_end == RING) match_window_end = 0;
+    if (match_window_beg == RING) match_window_beg = 0;
+  }
+};
 
 }  // namespace ellc
 #endif

@@ -69,3 +69,33 @@ def test_keyframe_from_frame_copies_pyramid(ellc):
         b, _ = ctx.image_level(1, 2, l)
         assert np.array_equal(a, b)
     ctx.close()
+
+
+def test_histogram_and_slot_copy(ellc):
+    """calculateImageHistogram (GlobalOptimize.cpp:40-100) and the ring's deep copy (pushToArray :185-223)."""
+    w, h, levels = 320, 240, 4
+    pair = synth.make_pair(w, h, seed=8)
+    ctx = ellc.Context(ellc.default_config(w, h, levels, max_keyframes=3, max_frames=2))
+    ctx.keyframe_upload(0, pair["kf_image"])
+    ctx.keyframe_set_depth(0, pair["depth0"], pair["var0"])
+    ctx.frame_upload(1, pair["cur_image"])
+    c = np.bincount(pair["kf_image"].ravel(), minlength=256).astype(np.float32)
+    ref = c / np.float32(c.sum(dtype=np.float64))
+    assert np.array_equal(ctx.histogram(1, 0), ref)
+    c2 = np.bincount(pair["cur_image"].ravel(), minlength=256).astype(np.float32)
+    assert np.array_equal(ctx.histogram(0, 1), c2 / np.float32(c2.sum(dtype=np.float64)))
+    wgt = np.random.default_rng(0).random((h, w)).astype(np.float32)
+    ctx.keyframe_set_weights(0, 0, wgt, 3)
+    ctx.copy_slot(1, 2, 1, 0)
+    for l in range(levels):
+        assert np.array_equal(ctx.image_level(1, 2, l)[0], ctx.image_level(1, 0, l)[0])
+        d0, v0 = ctx.keyframe_depth_level(0, l); d2, v2 = ctx.keyframe_depth_level(2, l)
+        assert bits_equal(d0, d2) and bits_equal(v0, v2)
+    w2, n2 = ctx.keyframe_weights(2, 0)
+    assert n2 == 3 and np.array_equal(w2, wgt)
+    assert bits_equal(ctx.max_gradient(1, 2)[0], ctx.max_gradient(1, 0)[0])
+    p0, _, _ = ctx.align([0], [1]); p2, _, _ = ctx.align([2], [1])
+    assert np.array_equal(p0, p2)                      # the copy aligns exactly like the original
+    ctx.copy_slot(0, 0, 1, 0)                          # keyframe -> frame slot (the ring's test frame)
+    assert np.array_equal(ctx.image_level(0, 0, 2)[0], ctx.image_level(1, 0, 2)[0])
+    ctx.close()

@@ -38,3 +38,18 @@ def test_near_pi_rotation(ellc):
             T = sl.expm(hat(xi.astype(np.float64))).astype(np.float32)
             back = ellc.se3_log(T)
             assert np.abs(sl.expm(hat(back.astype(np.float64))) - T).max() < 5e-6
+
+
+def test_kl_divergence_matches_opencv_definition(ellc):
+    """cv::compareHist(H1, H2, CV_COMP_KL_DIV): sum p log(p/q), bins with p ~ 0 skipped, q ~ 0 replaced by 1e-10 (host-only)."""
+    rng = np.random.default_rng(0)
+    p = rng.random(256).astype(np.float32); p /= p.sum()
+    q = rng.random(256).astype(np.float32); q /= q.sum()
+    ref = float(np.sum(p.astype(np.float64) * np.log(p.astype(np.float64) / q.astype(np.float64))))
+    assert abs(ellc.kl_divergence(p, q) - ref) < 1e-12
+    assert ellc.kl_divergence(p, p) == 0.0
+    p2 = p.copy(); p2[:10] = 0
+    q2 = q.copy(); q2[5:20] = 0
+    ref2 = sum(float(a) * np.log(float(a) / (float(b) if abs(b) > 2.220446049250313e-16 else 1e-10))
+               for a, b in zip(p2.astype(np.float64), q2.astype(np.float64)) if abs(a) > 2.220446049250313e-16)
+    assert abs(ellc.kl_divergence(p2, q2) - ref2) < 1e-10
