@@ -83,7 +83,7 @@ ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg);
   } while (0)
 
 int choose_nblk(const ellc_ctx* c, int level, int B);
-ellc_status run_prep(ellc_ctx* c, int n_unique, int need_w);
+ellc_status run_prep(ellc_ctx* c, int n_unique, int need);
 ellc_status build_depth_pyramid(ellc_ctx* c, int slot);
 ellc_status build_maxgrad(ellc_ctx* c, bool is_kf, int slot);
 }  // namespace ellc

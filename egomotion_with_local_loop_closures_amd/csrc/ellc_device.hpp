@@ -26,6 +26,15 @@ struct LevelGeom {
   const float* rowB;          // -((fx*v)/fy)             [rows]
 };
 
+// One valid (depth > 0) keyframe pixel as the FCA pixel pass reads it: 24 bytes, written by prep_scatter.
+// invZ = 1.0 / (double)Z is the reference's pow(depth, -1) (PixelWisePyramid.cpp:296), an IEEE division that does
+// not depend on the pose — computed once per keyframe update instead of once per pixel and iteration.
+struct __attribute__((aligned(8))) FcaRec {
+  uint32_t xy;                // y<<16 | x
+  float Z, var, Ikf;          // depth, variance, keyframe intensity (as f32)
+  double invZ;
+};
+
 // One keyframe (template) slot at one level: dense planes + the compacted list of pixels with depth > 0
 // (frame::calculateNonZeroDepthPts, Frame.cpp:295-301) in raster order.
 struct KfLevelDev {
@@ -34,9 +43,9 @@ struct KfLevelDev {
   float* var;                 // n   (depthMap::depthvararrptr[l])
   float* weight;              // n   (frame::weight_pyramid[l])
   uint32_t* cxy;              // compact: y<<16 | x
-  float* cZ;                  // compact depth
-  float* cVar;                // compact variance
-  float* cI;                  // compact keyframe intensity (as f32)
+  float* cZ;                  // compact depth (ICA)
+  float* cI;                  // compact keyframe intensity as f32 (ICA)
+  FcaRec* crec;               // compact FCA records (same order as cxy)
   float* cW;                  // compact saved weight (ICA)
   float* wlast;               // compact weight of the most recent iteration (for saveWeights)
   float* sd;                  // ICA steepest-descent planes, 6 x cap (plane k at sd + k*cap)

@@ -100,9 +100,9 @@ ellc_status build_depth_pyramid(ellc_ctx* c, int slot) {
   return ELLC_OK;
 }
 
-ellc_status run_prep(ellc_ctx* c, int n_unique, int need_w) {
+ellc_status run_prep(ellc_ctx* c, int n_unique, int need) {
   PrepArgs a;
-  a.need_w = need_w;
+  a.need = need;
   a.geom = c->geom_d;
   a.kf_tab = c->kf_tab_d;
   a.slots = c->uniq_slot_d;
@@ -393,8 +393,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       KfLevelDev& k = c->kf_tab_h[(size_t)l * MK + s];
       TRY(dev_alloc(c, &k.img, ni));
       TRY(dev_alloc(c, &k.depth, n)); TRY(dev_alloc(c, &k.var, n)); TRY(dev_alloc(c, &k.weight, n));
-      TRY(dev_alloc(c, &k.cxy, n)); TRY(dev_alloc(c, &k.cZ, n)); TRY(dev_alloc(c, &k.cVar, n)); TRY(dev_alloc(c, &k.cI, n));
-      TRY(dev_alloc(c, &k.cW, n)); TRY(dev_alloc(c, &k.wlast, n)); TRY(dev_alloc(c, &k.sd, 6 * n));
+      TRY(dev_alloc(c, &k.cxy, n)); TRY(dev_alloc(c, &k.cZ, n)); TRY(dev_alloc(c, &k.cI, n));
+      TRY(dev_alloc(c, &k.crec, n)); TRY(dev_alloc(c, &k.cW, n)); TRY(dev_alloc(c, &k.wlast, n)); TRY(dev_alloc(c, &k.sd, 6 * n));
       TRY(dev_alloc(c, &k.count, 4)); TRY(dev_alloc(c, &k.tile_count, tiles + 1));
     }
     for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni));
@@ -721,7 +721,7 @@ ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, i
 // prep + init + the whole level/iteration schedule; captured once per (B, unique keyframes, mode, save_weights)
 // into a hipGraph and replayed afterwards (the launches are too short to be issued one by one from the host)
 static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int save_weights) {
-  ellc_status s = run_prep(c, nu, mode == ELLC_MODE_ICA ? 1 : 0);   // mask / count per level: updationOnPyrChange, ImageFunc.cpp:158
+  ellc_status s = run_prep(c, nu, mode == ELLC_MODE_ICA ? 1 : 2);   // mask / count per level: updationOnPyrChange, ImageFunc.cpp:158
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
   return enqueue_schedule(c, B, mode, save_weights);
@@ -794,7 +794,7 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   int nu = 0;
   ellc_status s = stage_batch(c, 1, &kf_slot, &frame_slot, pose, &nu);
   if (s != ELLC_OK) return s;
-  s = run_prep(c, nu, 1);
+  s = run_prep(c, nu, mode == ELLC_MODE_ICA ? 1 : 2);
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_set_pose0, dim3(1), dim3(1), 0, c->stream, c->state_d, c->init_pose_d);
   const size_t n = (size_t)c->geom_h[level].n;
@@ -861,7 +861,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   int nu = 0;
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, nullptr, &nu);
   if (s != ELLC_OK) return s;
-  s = run_prep(c, nu, 1);
+  s = run_prep(c, nu, 2);
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
   GnArgs a = make_gn_args(c, level, B, 0, nullptr);

@@ -81,14 +81,24 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[0]), 63));
 }
 
-// ExternVariable.h:232
+// ExternVariable.h:232 clamps (double)v away from zero at +-1e-10 and rounds back to f32. For an f32 argument that is
+// a pure f32 select: with C = RN_f32(1e-10) = 0x1.b7cdfep-34 > 1e-10 and its predecessor below 1e-10,
+// "(double)v < 1e-10" <=> "v < C" and the clamped result (float)1e-10 is C (negative side mirrored; NaN passes).
 __device__ __forceinline__ float unzero_f(float v) {
-  const double d = (double)v;
-  const double r = (d < 0.0) ? ((d > -1e-10) ? -1e-10 : d) : ((d < 1e-10) ? 1e-10 : d);
-  return (float)r;
+  const float C = 0x1.b7cdfep-34f;
+  return (v < 0.0f) ? ((v > -C) ? -C : v) : ((v < C) ? C : v);
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// 32-bit load at any byte address of a global buffer (gfx9+ global memory accepts unaligned dword accesses; the
+// align-1 type lets the compiler choose the instruction, so this stays correct if a target did not)
+typedef uint32_t u32_align1 __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t load_u32_unaligned(g_u8 base, unsigned byte_off) {
+  return *(const ELLC_GLOBAL u32_align1*)(base + byte_off);
+}
+template <int N>
+__device__ __forceinline__ float byte_f32(uint32_t w) { return (float)((w >> (8 * N)) & 0xffu); }   // v_cvt_f32_ubyteN
 
 struct Taps {
   float I;      // u8 tap (Frame.h:181-279), -1 when all four taps are out of bounds
@@ -109,18 +119,20 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
   const float omx = 1.0f - wx, omy = 1.0f - wy;
   const bool interior = (fx0 >= 1.0f) && (fx0 <= (float)(cols - 3)) && (fy0 >= 1.0f) && (fy0 <= (float)(rows - 3));   // false for NaN
   if (__builtin_amdgcn_ballot_w64(!interior) == 0ull) {
+    // The 4x4 neighbourhood is fetched as one (byte-unaligned) 32-bit word per image row: columns x0-1 .. x0+2.
     const int x0 = (int)fx0, y0 = (int)fy0;
-    const unsigned rb = (unsigned)(y0 * sw + x0), rc = rb + (unsigned)sw;
-    const float Pbb = (float)img[rb], Pbc = (float)img[rb + 1u], Pcb = (float)img[rc], Pcc = (float)img[rc + 1u];
+    const unsigned ob = (unsigned)(y0 * sw + x0) - 1u, oc = ob + (unsigned)sw;
+    const uint32_t wb = load_u32_unaligned(img, ob), wc = load_u32_unaligned(img, oc);
+    const float Pbb = byte_f32<1>(wb), Pbc = byte_f32<2>(wb), Pcb = byte_f32<1>(wc), Pcc = byte_f32<2>(wc);
     {
       const float top = (omx * Pbb) + (wx * Pbc);
       const float btm = (omx * Pcb) + (wx * Pcc);
       o.I = (omy * top) + (wy * btm);
     }
     if (WANT_GRAD) {
-      const unsigned ra = rb - (unsigned)sw, rd = rc + (unsigned)sw;
-      const float Pba = (float)img[rb - 1u], Pbd = (float)img[rb + 2u], Pca = (float)img[rc - 1u], Pcd = (float)img[rc + 2u];
-      const float Pab = (float)img[ra], Pac = (float)img[ra + 1u], Pdb = (float)img[rd], Pdc = (float)img[rd + 1u];
+      const uint32_t wa = load_u32_unaligned(img, ob - (unsigned)sw), wd = load_u32_unaligned(img, oc + (unsigned)sw);
+      const float Pba = byte_f32<0>(wb), Pbd = byte_f32<3>(wb), Pca = byte_f32<0>(wc), Pcd = byte_f32<3>(wc);
+      const float Pab = byte_f32<1>(wa), Pac = byte_f32<2>(wa), Pdb = byte_f32<1>(wd), Pdc = byte_f32<2>(wd);
       const float g00 = 0.5f * (Pbc - Pba), g01 = 0.5f * (Pbd - Pbb), g10 = 0.5f * (Pcc - Pca), g11 = 0.5f * (Pcd - Pcb);
       float top = (omx * g00) + (wx * g01);
       float btm = (omx * g10) + (wx * g11);
@@ -299,14 +311,13 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float* __re
 // One pixel of the FCA pass (PixelWisePyramid.cpp:236-361): J, residual, weight.
 struct FcaPix { float J[6]; float residual, wgt; };
 
-struct FcaIn { uint32_t xy; float Z, var, Ikf; };   // one entry of the keyframe's compact pixel list
+typedef FcaRec FcaIn;   // one entry of the keyframe's compact pixel list
 
 __device__ __forceinline__ FcaIn fca_load(const KfLevelDev& K, unsigned i) {
+  // uniform base + 32-bit byte offset (24 * i < 2^32 for any image this library accepts): SGPR-base addressing
+  const ELLC_GLOBAL FcaRec* r = (const ELLC_GLOBAL FcaRec*)((const ELLC_GLOBAL char*)K.crec + i * (unsigned)sizeof(FcaRec));
   FcaIn in;
-  in.xy = as_global(K.cxy)[i];
-  in.Z = as_global(K.cZ)[i];
-  in.var = as_global(K.cVar)[i];
-  in.Ikf = as_global(K.cI)[i];
+  in.xy = r->xy; in.Z = r->Z; in.var = r->var; in.Ikf = r->Ikf; in.invZ = r->invZ;
   return in;
 }
 
@@ -321,12 +332,12 @@ __device__ __forceinline__ FcaPix fca_pixel_in(const GnArgs& a, const KfLevelDev
   const Warp w = warp_pixel<DIVC>(x, y, Z, g, S);
   const Taps t = tap_point<true>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
   FcaPix o;
-  const double invZ = 1.0 / (double)Z;
+  const double invZ = in.invZ;
   jacobian_row<DIVC>(t.gx, t.gy, x, y, invZ, g, o.J);
   const bool oob = (t.I == -1.0f);
   o.residual = oob ? 0.0f : (t.I - Ikf);
   o.wgt = oob ? 0.0f : fca_weight(w, (float)invZ, o.residual, t.gx, t.gy, 1.0f * var, g, S[3], S[7], S[11]);
-  if (a.save_w) as_global_rw(K.wlast)[i] = o.wgt;
+  if (a.save_w) *(ELLC_GLOBAL float*)((ELLC_GLOBAL char*)K.wlast + i * 4u) = o.wgt;
   if (DEBUG) {
     const size_t n = (size_t)g.n, p = (size_t)y * g.cols + x;
     a.planes[0 * n + p] = o.residual;
@@ -531,18 +542,20 @@ __device__ __forceinline__ void lu_inverse6_lanes(float (&A)[36], int lane, floa
       if (v > best) { best = v; k = j; }
     }
     if (best < 1.1920928955078125e-07f) singular = true;
+    if (k != i) {   // every lane eliminates the same matrix, so the branch is wave-uniform; most pivots sit on the diagonal
 #pragma unroll
-    for (int j = i + 1; j < 6; j++) {
-      const bool sw = (k == j);
+      for (int j = i + 1; j < 6; j++) {
+        const bool sw = (k == j);
 #pragma unroll
-      for (int q = i; q < 6; q++) {
-        const float a = A[i * 6 + q], b = A[j * 6 + q];
-        A[i * 6 + q] = sw ? b : a;
-        A[j * 6 + q] = sw ? a : b;
+        for (int q = i; q < 6; q++) {
+          const float a = A[i * 6 + q], b = A[j * 6 + q];
+          A[i * 6 + q] = sw ? b : a;
+          A[j * 6 + q] = sw ? a : b;
+        }
+        const float a = x[i], b = x[j];
+        x[i] = sw ? b : a;
+        x[j] = sw ? a : b;
       }
-      const float a = x[i], b = x[j];
-      x[i] = sw ? b : a;
-      x[j] = sw ? a : b;
     }
     const float d = -1.0f / A[i * 6 + i];
 #pragma unroll
@@ -593,16 +606,34 @@ struct SolveShared {
 // parallel), 6x6 LU inverse across six lanes, delta, weightedPose, pose <- log(exp(delta^) exp(pose^)) on one lane.
 // Results are left in `sh` (new pose, exp(new pose), weightedPose, level_done) for every thread; when `dst` is
 // non-null the state record is written too. src may alias dst. Ends with a block barrier.
-__device__ __forceinline__ void solve_step(SolveShared& sh, const float* __restrict__ partials, int nblk, int mode, int level, int early_exit,
+// Thread t's share of the fixed-order combine: component t&31 over the block records k = t>>5, t>>5 + 8, ... < nblk,
+// summed in double in ascending k. The loads depend on nothing but the kernel arguments, so they are issued eight at
+// a time (missing records read as +0.0, which leaves the sum unchanged bit for bit) instead of one round trip each.
+__device__ __forceinline__ double partial_group_sum(const float* __restrict__ partials, int nblk) {
+  const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  g_f32 p = as_global(partials) + comp;
+  double s = 0.0;
+  for (int base = 0; base < nblk; base += 8 * (ELLC_SOLVE_THREADS / 32)) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {   // unconditional loads (index clamped to the last record), so that all eight are in flight
+      const int k = base + grp + j * (ELLC_SOLVE_THREADS / 32);
+      v[j] = p[(unsigned)min(k, nblk - 1) * ELLC_PART_STRIDE];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = base + grp + j * (ELLC_SOLVE_THREADS / 32);
+      s += (k < nblk) ? (double)v[j] : 0.0;
+    }
+  }
+  return s;
+}
+
+__device__ __forceinline__ void solve_step(SolveShared& sh, double group_sum, int mode, int level, int early_exit,
                                            const AlignState& src, AlignState* dst) {
   const int t = threadIdx.x;
   const int comp = t & 31, grp = t >> 5;
-  {
-    g_f32 p = as_global(partials) + comp;
-    double s = 0.0;
-    for (int k = grp; k < nblk; k += ELLC_SOLVE_THREADS / 32) s += (double)p[(size_t)k * ELLC_PART_STRIDE];
-    sh.part[grp][comp] = s;
-  }
+  sh.part[grp][comp] = group_sum;
   ELLC_STAMP(1);
   if (mode == 2 && t < 36) sh.Hinv[t] = src.Hinv[t];   // ICA iterate: the level's precomputed inverse
   __syncthreads();
@@ -708,7 +739,7 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_solve(SolveArgs a) {
   AlignState& st = a.state[b];
   if (st.level_done == a.level) return;
   __shared__ SolveShared sh;
-  solve_step(sh, a.partials + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, a.nblk, a.mode, a.level, a.early_exit, st, &st);
+  solve_step(sh, partial_group_sum(a.partials + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, a.nblk), a.mode, a.level, a.early_exit, st, &st);
   if (a.mode == 1) return;
   const int t = threadIdx.x;
   if (t < 6) st.pose[t] = sh.newpose[t];
@@ -746,13 +777,18 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, MINW) void gn_fca_fused(FusedArgs 
   const bool writer = (blockIdx.x == 0);
   ELLC_STAMP(0);
   ELLC_BSTAMP(0);
-  const int pending = src.pending;
-  // Issued before the solve: the dependent table loads (slot -> table entry -> count) and this thread's first
-  // compact pixel are in flight while the solve runs; none of them depends on the pose.
+  // Load order of the prologue (everything below depends on the kernel arguments only, or on the uniform table
+  // entries): the scalar chain slot -> table entry -> count is started first, the pending partial sums are read
+  // unconditionally next (prev_nblk is 0 on the first launch of a schedule) so that they share one memory round trip
+  // with the chain and the state record, and this thread's first compact pixel is requested last, to arrive while
+  // the solve runs. None of it depends on the pose.
   const LevelGeom g = a.geom[a.level];
   const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
-  const int V = *K.count;
+  const int pending = src.pending;
+  const int V = *as_global(K.count);
+  const double group_sum = partial_group_sum(
+      a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, fa.prev_nblk);
   // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
   // split, which was tried in r01 and did not change the run time — co-resident blocks finish staggered because the
   // SIMD arbiter serves the oldest wave first, not because their pixels differ)
@@ -762,11 +798,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, MINW) void gn_fca_fused(FusedArgs 
   const int stride = ELLC_GN_THREADS;
   g_u8 cur = as_global(F.img);
   FcaIn first;
-  first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f;
+  first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.invZ = 1.0;
   if (begin + t < end) first = fca_load(K, (unsigned)(begin + t));
   if (pending) {
-    const float* prev = a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
-    solve_step(sh, prev, fa.prev_nblk, 0, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr);
+    solve_step(sh, group_sum, 0, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr);
   } else {
     if (t < 6) sh.newpose[t] = src.pose[t];
     if (t < 12) sh.newS[t] = src.S[t];
@@ -824,7 +859,7 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
   if (t < ELLC_MAX_LEVELS) it_copy[t] = src.iters[t];
   if (pending) {
     const float* prev = a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
-    solve_step(sh, prev, fa.prev_nblk, 0, fa.prev_level, fa.early_exit, src, dst);
+    solve_step(sh, partial_group_sum(prev, fa.prev_nblk), 0, fa.prev_level, fa.early_exit, src, dst);
   } else {
     if (t < 6) sh.newpose[t] = src.pose[t];
     if (t < 12) sh.newS[t] = src.S[t];

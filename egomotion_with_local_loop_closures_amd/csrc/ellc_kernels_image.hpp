@@ -150,7 +150,7 @@ struct PrepArgs {
   const KfLevelDev* kf_tab;
   const int* slots;            // unique keyframe slots
   int levels, max_kf;
-  int need_w;                  // also gather the saved weights (ICA); the FCA path never reads them
+  int need;                    // bit 0: planes Z / I / saved weight for the ICA path; bit 1: FcaRec records for the FCA path
   int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
 };
 
@@ -264,10 +264,10 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   const ELLC_GLOBAL uint8_t* img = gptr(K.img);
   ELLC_GLOBAL uint32_t* cxy = gptr_rw(K.cxy);
   ELLC_GLOBAL float* cZ = gptr_rw(K.cZ);
-  ELLC_GLOBAL float* cVar = gptr_rw(K.cVar);
+  ELLC_GLOBAL FcaRec* crec = gptr_rw(K.crec);
   ELLC_GLOBAL float* cI = gptr_rw(K.cI);
   ELLC_GLOBAL float* cW = gptr_rw(K.cW);
-  const int cols = g.cols, sw = g.sw, need_w = a.need_w;
+  const int cols = g.cols, sw = g.sw, need = a.need;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     if (d[j] > 0.0f) {
@@ -277,11 +277,19 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
       if (y * cols > i) y--;
       if ((y + 1) * cols <= i) y++;
       const int x = i - y * cols;
-      cxy[pos] = ((uint32_t)y << 16) | (uint32_t)x;
-      cZ[pos] = d[j];
-      cVar[pos] = var[(unsigned)i];
-      cI[pos] = (float)img[(unsigned)(y * sw + x)];
-      if (need_w) cW[pos] = wgt[(unsigned)i];
+      const uint32_t xy = ((uint32_t)y << 16) | (uint32_t)x;
+      const float Ikf = (float)img[(unsigned)(y * sw + x)];
+      cxy[pos] = xy;
+      if (need & 1) {   // ICA reads planes
+        cZ[pos] = d[j];
+        cI[pos] = Ikf;
+        cW[pos] = wgt[(unsigned)i];
+      }
+      if (need & 2) {   // FCA reads one record per pixel
+        ELLC_GLOBAL FcaRec* r = crec + pos;
+        r->xy = xy; r->Z = d[j]; r->var = var[(unsigned)i]; r->Ikf = Ikf;
+        r->invZ = 1.0 / (double)d[j];
+      }
     }
   }
 }
