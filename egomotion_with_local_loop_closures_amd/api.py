@@ -239,6 +239,12 @@ class Context:
                  "ellc_profile_gn_kernel")
         return ms.value, by.value, v.value
 
+    def selftest_div_pair(self, a, b):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        qp = np.zeros_like(a); qr = np.zeros_like(a)
+        self._ck(self._l.ellc_selftest_div_pair(self.h, int(a.size), _p(a), _p(b), _p(qp), _p(qr)), "ellc_selftest_div_pair")
+        return qp, qr
+
     def profile_calibrate_read(self, nbytes, reps=10):
         ms = C.c_float(0)
         self._ck(self._l.ellc_profile_calibrate_read(self.h, C.c_size_t(nbytes), reps, C.byref(ms)), "ellc_profile_calibrate_read")

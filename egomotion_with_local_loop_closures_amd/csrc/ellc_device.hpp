@@ -26,12 +26,14 @@ struct LevelGeom {
   const float* rowB;          // -((fx*v)/fy)             [rows]
 };
 
-// One valid (depth > 0) keyframe pixel as the FCA pixel pass reads it: 24 bytes, written by prep_scatter.
-// invZ = 1.0 / (double)Z is the reference's pow(depth, -1) (PixelWisePyramid.cpp:296), an IEEE division that does
-// not depend on the pose — computed once per keyframe update instead of once per pixel and iteration.
-struct __attribute__((aligned(8))) FcaRec {
+// One valid (depth > 0) keyframe pixel as the FCA pixel pass reads it: 32 bytes, written by prep_scatter. Besides the
+// inputs it carries the two pose-independent results that are IEEE divisions in the reference, computed once per
+// keyframe update instead of once per pixel and iteration: the back-projection X = ((x - cx) Z) / fx, Y likewise
+// (PixelWisePyramid.cpp:236-240) and invZ = 1.0 / (double)Z, the reference's pow(depth, -1) (:296).
+struct __attribute__((aligned(16))) FcaRec {
   uint32_t xy;                // y<<16 | x
   float Z, var, Ikf;          // depth, variance, keyframe intensity (as f32)
+  float X, Y;
   double invZ;
 };
 

@@ -944,6 +944,35 @@ ellc_status ellc_debug_block_stamps(ellc_ctx* c, unsigned long long* out, int nb
 }
 #endif
 
+// device self-test of div_pair_ieee against the compiler's `/` (both quotient arrays are returned)
+__global__ void selftest_div_pair(const float* a, const float* b, float* q_pair, float* q_ref, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (2 * i + 1 >= n) return;
+  float q0, q1;
+  ellc::div_pair_ieee(a[2 * i], b[2 * i], a[2 * i + 1], b[2 * i + 1], q0, q1);
+  q_pair[2 * i] = q0;
+  q_pair[2 * i + 1] = q1;
+  q_ref[2 * i] = a[2 * i] / b[2 * i];
+  q_ref[2 * i + 1] = a[2 * i + 1] / b[2 * i + 1];
+}
+ellc_status ellc_selftest_div_pair(ellc_ctx* c, int n, const float* a, const float* b, float* q_pair, float* q_ref) {
+  if (!c || n < 2 || (n & 1) || !a || !b || !q_pair || !q_ref) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  float* d = nullptr;
+  ELLC_HIP(c, hipMalloc(&d, (size_t)4 * n * sizeof(float)));
+  hipError_t e = hipMemcpyAsync(d, a, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d + n, b, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(selftest_div_pair, dim3((n / 2 + 255) / 256), dim3(256), 0, c->stream, d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(q_pair, d + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(q_ref, d + 3 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d);
+  if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("selftest_div_pair: ") + hipGetErrorString(e));
+  return ELLC_OK;
+}
+
 ellc_status ellc_profile_calibrate_read(ellc_ctx* c, size_t bytes, int reps, float* avg_ms) {
   if (!c || reps < 1 || bytes < 1024) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   float* buf = nullptr;

@@ -215,22 +215,52 @@ __device__ __forceinline__ float div_const(float a, float b, float rb) {
   return __builtin_fmaf(e, rb, q);
 }
 
+// Two IEEE f32 divisions a0/b0, a1/b1 with the refinement arithmetic of both packed (v_pk_fma_f32). Operation for
+// operation this is the sequence the compiler emits for `/` on gfx9 with f32 denormals enabled (div_scale x2, rcp,
+// three-step Newton refinement, div_fmas, div_fixup), so the quotients are the correctly rounded ones `/` gives;
+// checked against `/` on the device over special values and random bit patterns (tests/test_gpu_gn.py).
+__device__ __forceinline__ void div_pair_ieee(float a0, float b0, float a1, float b1, float& q0, float& q1) {
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  bool vd0, vd1, vn0, vn1;
+  const v2 ds = {__builtin_amdgcn_div_scalef(a0, b0, false, &vd0), __builtin_amdgcn_div_scalef(a1, b1, false, &vd1)};
+  const v2 ns = {__builtin_amdgcn_div_scalef(a0, b0, true, &vn0), __builtin_amdgcn_div_scalef(a1, b1, true, &vn1)};
+  const v2 r = {__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y)};
+  const v2 nds = -ds;
+  const v2 f0 = __builtin_elementwise_fma(nds, r, (v2)(1.0f));
+  const v2 f1 = __builtin_elementwise_fma(f0, r, r);
+  const v2 mul = ns * f1;
+  const v2 f2 = __builtin_elementwise_fma(nds, mul, ns);
+  const v2 f3 = __builtin_elementwise_fma(f2, f1, mul);
+  const v2 f4 = __builtin_elementwise_fma(nds, f3, ns);
+  q0 = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(f4.x, f1.x, f3.x, vn0), b0, a0);
+  q1 = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(f4.y, f1.y, f3.y, vn1), b1, a1);
+}
+
 struct Warp { float px, py, pz, wx, wy; };
 
-// PixelWisePyramid.cpp:236-262
-template <bool DIVC>
-__device__ __forceinline__ Warp warp_pixel(int x, int y, float Z, const LevelGeom& g, const float* S) {
-  const float aX = ((float)x - g.cx) * Z, aY = ((float)y - g.cy) * Z;
-  const float X = DIVC ? div_const(aX, g.fx, g.rfx) : aX / g.fx;
-  const float Y = DIVC ? div_const(aY, g.fy, g.rfy) : aY / g.fy;
+// PixelWisePyramid.cpp:241-262: rigid transform of the back-projected pixel (X, Y, Z) and projection
+template <bool PAIR>
+__device__ __forceinline__ Warp warp_point(float X, float Y, float Z, const LevelGeom& g, const float* S) {
   Warp o;
   o.px = (S[0] * X) + (S[1] * Y) + (S[2] * Z) + (S[3]);
   o.py = (S[4] * X) + (S[5] * Y) + (S[6] * Z) + (S[7]);
   o.pz = (S[8] * X) + (S[9] * Y) + (S[10] * Z) + (S[11]);
   o.pz = unzero_f(o.pz);
-  o.wx = ((o.px / o.pz) * g.fx) + g.cx;
-  o.wy = ((o.py / o.pz) * g.fy) + g.cy;
+  float qx, qy;
+  if (PAIR) div_pair_ieee(o.px, o.pz, o.py, o.pz, qx, qy);
+  else { qx = o.px / o.pz; qy = o.py / o.pz; }
+  o.wx = (qx * g.fx) + g.cx;
+  o.wy = (qy * g.fy) + g.cy;
   return o;
+}
+
+// PixelWisePyramid.cpp:236-240: back-projection of pixel (x, y) at depth Z, then the warp
+template <bool DIVC>
+__device__ __forceinline__ Warp warp_pixel(int x, int y, float Z, const LevelGeom& g, const float* S) {
+  const float aX = ((float)x - g.cx) * Z, aY = ((float)y - g.cy) * Z;
+  const float X = DIVC ? div_const(aX, g.fx, g.rfx) : aX / g.fx;
+  const float Y = DIVC ? div_const(aY, g.fy, g.rfy) : aY / g.fy;
+  return warp_point<false>(X, Y, Z, g, S);
 }
 
 // PixelWisePyramid.cpp:296-320: 1x6 steepest-descent row at the reference pixel / reference depth.
@@ -266,8 +296,8 @@ __device__ __forceinline__ float fca_weight(const Warp& w, float d, float residu
   const float gx = g.fx * gradx;
   const float gy = g.fy * grady;
   const float den = (w.pz * w.pz) * d;
-  const float g0 = (tx * w.pz - tz * w.px) / den;
-  const float g1 = (ty * w.pz - tz * w.py) / den;
+  float g0, g1;
+  div_pair_ieee(tx * w.pz - tz * w.px, den, ty * w.pz - tz * w.py, den, g0, g1);
   const float drpdd = gx * g0 + gy * g1;
   const float w_p = 1.0f / (16.0f + (s * drpdd) * drpdd);
   const float weighted_rp = fabsf(residual * sqrtf(w_p));
@@ -317,7 +347,7 @@ __device__ __forceinline__ FcaIn fca_load(const KfLevelDev& K, unsigned i) {
   // uniform base + 32-bit byte offset (24 * i < 2^32 for any image this library accepts): SGPR-base addressing
   const ELLC_GLOBAL FcaRec* r = (const ELLC_GLOBAL FcaRec*)((const ELLC_GLOBAL char*)K.crec + i * (unsigned)sizeof(FcaRec));
   FcaIn in;
-  in.xy = r->xy; in.Z = r->Z; in.var = r->var; in.Ikf = r->Ikf; in.invZ = r->invZ;
+  in.xy = r->xy; in.Z = r->Z; in.var = r->var; in.Ikf = r->Ikf; in.X = r->X; in.Y = r->Y; in.invZ = r->invZ;
   return in;
 }
 
@@ -329,7 +359,7 @@ __device__ __forceinline__ FcaPix fca_pixel_in(const GnArgs& a, const KfLevelDev
   const float Z = in.Z;
   const float var = in.var;
   const float Ikf = in.Ikf;
-  const Warp w = warp_pixel<DIVC>(x, y, Z, g, S);
+  const Warp w = warp_point<true>(in.X, in.Y, Z, g, S);
   const Taps t = tap_point<true>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
   FcaPix o;
   const double invZ = in.invZ;
@@ -357,17 +387,51 @@ __device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K
 }
 
 // H += (w J)^T J (upper triangle), b += J (r w)   (PixelWisePyramid.cpp:364-374)
-__device__ __forceinline__ void fca_accumulate_pixel(float (&acc)[27], const FcaPix& p) {
-  const float rw = p.residual * p.wgt;
-  int q = 0;
+// The accumulators are kept as register pairs so that every update is one packed fma (v_pk_fma_f32) of a J pair with a
+// broadcast (w J[r]): rows 1, 3 and 5 carry one unused lane each (the element left of the diagonal) to keep the J pairs
+// aligned. Each of the 27 used lanes still performs exactly acc = fma(J[r] * w, J[c], acc) per pixel.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct FcaAcc {
+  f32x2 h[12];   // (00,01)(02,03)(04,05) (10*,11)(12,13)(14,15) (22,23)(24,25) (32*,33)(34,35) (44,45) (54*,55)
+  f32x2 b[3];
+};
+__device__ __forceinline__ void fca_acc_zero(FcaAcc& A) {
 #pragma unroll
-  for (int r = 0; r < 6; r++) {
-    const float wJ = p.J[r] * p.wgt;
+  for (int i = 0; i < 12; i++) A.h[i] = (f32x2)(0.0f);
 #pragma unroll
-    for (int c = r; c < 6; c++) { acc[q] = __builtin_fmaf(wJ, p.J[c], acc[q]); q++; }
-  }
-#pragma unroll
-  for (int r = 0; r < 6; r++) acc[21 + r] = __builtin_fmaf(p.J[r], rw, acc[21 + r]);
+  for (int i = 0; i < 3; i++) A.b[i] = (f32x2)(0.0f);
+}
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void fca_accumulate_pixel(FcaAcc& A, const FcaPix& p) {
+  const f32x2 J01 = {p.J[0], p.J[1]}, J23 = {p.J[2], p.J[3]}, J45 = {p.J[4], p.J[5]};
+  const f32x2 w2 = (f32x2)(p.wgt);
+  const f32x2 wJ01 = J01 * w2, wJ23 = J23 * w2, wJ45 = J45 * w2;
+  A.h[0] = fma2((f32x2)(wJ01.x), J01, A.h[0]);
+  A.h[1] = fma2((f32x2)(wJ01.x), J23, A.h[1]);
+  A.h[2] = fma2((f32x2)(wJ01.x), J45, A.h[2]);
+  A.h[3] = fma2((f32x2)(wJ01.y), J01, A.h[3]);
+  A.h[4] = fma2((f32x2)(wJ01.y), J23, A.h[4]);
+  A.h[5] = fma2((f32x2)(wJ01.y), J45, A.h[5]);
+  A.h[6] = fma2((f32x2)(wJ23.x), J23, A.h[6]);
+  A.h[7] = fma2((f32x2)(wJ23.x), J45, A.h[7]);
+  A.h[8] = fma2((f32x2)(wJ23.y), J23, A.h[8]);
+  A.h[9] = fma2((f32x2)(wJ23.y), J45, A.h[9]);
+  A.h[10] = fma2((f32x2)(wJ45.x), J45, A.h[10]);
+  A.h[11] = fma2((f32x2)(wJ45.y), J45, A.h[11]);
+  const f32x2 rw = (f32x2)(p.residual * p.wgt);
+  A.b[0] = fma2(J01, rw, A.b[0]);
+  A.b[1] = fma2(J23, rw, A.b[1]);
+  A.b[2] = fma2(J45, rw, A.b[2]);
+}
+// the 27 sums in the order of the partial record: upper triangle by rows, then b
+__device__ __forceinline__ void fca_acc_unpack(const FcaAcc& A, float (&o)[27]) {
+  o[0] = A.h[0].x; o[1] = A.h[0].y; o[2] = A.h[1].x; o[3] = A.h[1].y; o[4] = A.h[2].x; o[5] = A.h[2].y;
+  o[6] = A.h[3].y; o[7] = A.h[4].x; o[8] = A.h[4].y; o[9] = A.h[5].x; o[10] = A.h[5].y;
+  o[11] = A.h[6].x; o[12] = A.h[6].y; o[13] = A.h[7].x; o[14] = A.h[7].y;
+  o[15] = A.h[8].y; o[16] = A.h[9].x; o[17] = A.h[9].y;
+  o[18] = A.h[10].x; o[19] = A.h[10].y;
+  o[20] = A.h[11].y;
+  o[21] = A.b[0].x; o[22] = A.b[0].y; o[23] = A.b[1].x; o[24] = A.b[1].y; o[25] = A.b[2].x; o[26] = A.b[2].y;
 }
 
 // FCA accumulate: grid (nblk, B). Each block owns a contiguous chunk of the alignment's compact pixel
@@ -379,7 +443,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   const AlignState& st = a.state[b];
   if (st.level_done == a.level) return;
   const LevelGeom g = a.geom[a.level];
-  const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
+  const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int V = *K.count;
   // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
@@ -394,9 +458,8 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   for (int i = 0; i < 12; i++) S[i] = st.S[i];
   g_u8 cur = as_global(F.img);
 
-  float acc[27];
-#pragma unroll
-  for (int i = 0; i < 27; i++) acc[i] = 0.0f;
+  FcaAcc acc;
+  fca_acc_zero(acc);
 
   if (ILP == 1) {
     for (int i = begin + (int)threadIdx.x; i < end; i += stride) {
@@ -417,7 +480,9 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
       }
     }
   }
-  block_reduce_store<27>(acc, a.partials + ((size_t)b * ELLC_NBLK_MAX + blockIdx.x) * ELLC_PART_STRIDE);
+  float sums[27];
+  fca_acc_unpack(acc, sums);
+  block_reduce_store<27>(sums, a.partials + ((size_t)b * ELLC_NBLK_MAX + blockIdx.x) * ELLC_PART_STRIDE);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -428,7 +493,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_precompute(GnArgs a, i
   const AlignState& st = a.state[b];
   if (st.level_done == a.level) return;
   const LevelGeom g = a.geom[a.level];
-  const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
+  const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const int V = *K.count;
   // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
   // split, which was tried in r01 and did not change the run time — co-resident blocks finish staggered because the
@@ -479,7 +544,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
   const AlignState& st = a.state[b];
   if (st.level_done == a.level) return;
   const LevelGeom g = a.geom[a.level];
-  const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
+  const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int V = *K.count;
   // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
@@ -783,7 +848,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, MINW) void gn_fca_fused(FusedArgs 
   // with the chain and the state record, and this thread's first compact pixel is requested last, to arrive while
   // the solve runs. None of it depends on the pose.
   const LevelGeom g = a.geom[a.level];
-  const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
+  const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int pending = src.pending;
   const int V = *as_global(K.count);
@@ -798,7 +863,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, MINW) void gn_fca_fused(FusedArgs 
   const int stride = ELLC_GN_THREADS;
   g_u8 cur = as_global(F.img);
   FcaIn first;
-  first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.invZ = 1.0;
+  first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.X = 0.0f; first.Y = 0.0f; first.invZ = 1.0;
   if (begin + t < end) first = fca_load(K, (unsigned)(begin + t));
   if (pending) {
     solve_step(sh, group_sum, 0, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr);
@@ -826,9 +891,8 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, MINW) void gn_fca_fused(FusedArgs 
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
-  float acc[27];
-#pragma unroll
-  for (int i = 0; i < 27; i++) acc[i] = 0.0f;
+  FcaAcc acc;
+  fca_acc_zero(acc);
   int i = begin + t;
   if (i < end) {
     const FcaPix p = fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, first);
@@ -841,7 +905,9 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, MINW) void gn_fca_fused(FusedArgs 
   ELLC_STAMP(7);
   ELLC_BSTAMP(2);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + blockIdx.x) * ELLC_PART_STRIDE;
-  block_reduce_store<27>(acc, out);
+  float sums[27];
+  fca_acc_unpack(acc, sums);
+  block_reduce_store<27>(sums, out);
   ELLC_STAMP(8);
   ELLC_BSTAMP(3);
 }

@@ -229,17 +229,23 @@ __global__ __launch_bounds__(256) void prep_scan(PrepArgs a) {
   if (threadIdx.x == 255) *K.count = wbase + inc;
 }
 
-// Scatter: thread t of the block owns pixels base + j*256 + t (j = 0..7), so every load and — through the
-// ballot ranks — every store of a wave is contiguous. Raster order = (j, wave, lane).
+// Scatter, two phases per tile of ELLC_TILE pixels. Phase 1: thread t owns pixels base + j*256 + t (j = 0..7), so the
+// depth loads of a wave are contiguous; ballot ranks give every valid pixel its raster-order rank inside the tile
+// (order = (j, wave, lane)), and (pixel index, depth) are parked in LDS at that rank. Phase 2 runs densely over the
+// parked entries — every lane has a valid pixel — computes the record (three IEEE divisions) and stores it; consecutive
+// lanes write consecutive records. Without the LDS step the divisions would run for every wave that holds at least one
+// valid pixel, i.e. about four times as often on a semi-dense map.
 __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   int local;
   const int level = prep_level_of(a, blockIdx.x, local);
-  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const KfLevelDev K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
   const LevelGeom& g = a.geom[level];
   const int n = g.n;
   const int base = local * ELLC_TILE + (int)threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ int cnt[32];   // [j][wave]
+  __shared__ int cnt[33];   // [j][wave] exclusive offsets, [32] = tile total
+  __shared__ uint32_t s_idx[ELLC_TILE];
+  __shared__ float s_Z[ELLC_TILE];
   float d[8];
   unsigned long long m[8];
 #pragma unroll
@@ -254,42 +260,58 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
     int v = (lane < 32) ? cnt[lane] : 0, tot;
     const int inc = wave_inclusive_scan(v, tot);
     if (lane < 32) cnt[lane] = inc - v;
+    if (lane == 0) cnt[32] = tot;
   }
   __syncthreads();
-  const int tile_off = K.tile_count[local];
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if (d[j] > 0.0f) {
+      const int r = cnt[j * 4 + wave] + __popcll(m[j] & lt);
+      s_idx[r] = (uint32_t)(base + j * 256);
+      s_Z[r] = d[j];
+    }
+  }
+  __syncthreads();
+  const int nvalid = cnt[32];
+  const unsigned tile_off = (unsigned)K.tile_count[local];
   const float inv_cols = 1.0f / (float)g.cols;
   const ELLC_GLOBAL float* var = gptr(K.var);
   const ELLC_GLOBAL float* wgt = gptr(K.weight);
   const ELLC_GLOBAL uint8_t* img = gptr(K.img);
   ELLC_GLOBAL uint32_t* cxy = gptr_rw(K.cxy);
   ELLC_GLOBAL float* cZ = gptr_rw(K.cZ);
-  ELLC_GLOBAL FcaRec* crec = gptr_rw(K.crec);
   ELLC_GLOBAL float* cI = gptr_rw(K.cI);
   ELLC_GLOBAL float* cW = gptr_rw(K.cW);
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  ELLC_GLOBAL u32x4* crec = (ELLC_GLOBAL u32x4*)K.crec;
   const int cols = g.cols, sw = g.sw, need = a.need;
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    if (d[j] > 0.0f) {
-      const int i = base + j * 256;
-      const unsigned pos = (unsigned)(tile_off + cnt[j * 4 + wave] + __popcll(m[j] & lt));
-      int y = (int)(((float)i + 0.5f) * inv_cols);   // i < 2^24: exact conversion; corrected below
-      if (y * cols > i) y--;
-      if ((y + 1) * cols <= i) y++;
-      const int x = i - y * cols;
-      const uint32_t xy = ((uint32_t)y << 16) | (uint32_t)x;
-      const float Ikf = (float)img[(unsigned)(y * sw + x)];
-      cxy[pos] = xy;
-      if (need & 1) {   // ICA reads planes
-        cZ[pos] = d[j];
-        cI[pos] = Ikf;
-        cW[pos] = wgt[(unsigned)i];
-      }
-      if (need & 2) {   // FCA reads one record per pixel
-        ELLC_GLOBAL FcaRec* r = crec + pos;
-        r->xy = xy; r->Z = d[j]; r->var = var[(unsigned)i]; r->Ikf = Ikf;
-        r->invZ = 1.0 / (double)d[j];
-      }
+  const float fx = g.fx, fy = g.fy, cx = g.cx, cy = g.cy;
+  for (int r = (int)threadIdx.x; r < nvalid; r += 256) {
+    const int i = (int)s_idx[r];
+    const float Z = s_Z[r];
+    const unsigned pos = tile_off + (unsigned)r;
+    int y = (int)(((float)i + 0.5f) * inv_cols);   // i < 2^24: exact conversion; corrected below
+    if (y * cols > i) y--;
+    if ((y + 1) * cols <= i) y++;
+    const int x = i - y * cols;
+    const uint32_t xy = ((uint32_t)y << 16) | (uint32_t)x;
+    const float Ikf = (float)img[(unsigned)(y * sw + x)];
+    cxy[pos] = xy;
+    if (need & 1) {   // ICA reads planes
+      cZ[pos] = Z;
+      cI[pos] = Ikf;
+      cW[pos] = wgt[(unsigned)i];
+    }
+    if (need & 2) {   // FCA reads one 32-byte record per pixel (FcaRec), stored as two 16-byte words
+      const float X = (((float)x - cx) * Z) / fx;
+      const float Y = (((float)y - cy) * Z) / fy;
+      const double invZ = 1.0 / (double)Z;
+      const unsigned long long zb = __builtin_bit_cast(unsigned long long, invZ);
+      const u32x4 lo = {xy, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, Ikf)};
+      const u32x4 hi = {__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), (uint32_t)zb, (uint32_t)(zb >> 32)};
+      crec[2u * pos] = lo;
+      crec[2u * pos + 1u] = hi;
     }
   }
 }

@@ -188,6 +188,10 @@ ellc_status ellc_profile_align(ellc_ctx* ctx, int B, const int* kf_slots, const 
  * (MI355X_MICROARCH.md, HBM section). Returns average milliseconds per launch. */
 ellc_status ellc_profile_calibrate_read(ellc_ctx* ctx, size_t bytes, int reps, float* avg_ms);
 
+/* Device self-test: q_pair[i] from the kernels' packed two-at-a-time IEEE division, q_ref[i] = a[i] / b[i] as the
+ * compiler emits it; n even. The per-pixel code relies on the two being bit-identical (tests/test_gpu_gn.py). */
+ellc_status ellc_selftest_div_pair(ellc_ctx* ctx, int n, const float* a, const float* b, float* q_pair, float* q_ref);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,12 @@ import statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
-from egomotion_with_local_loop_closures_amd import api, synth  # noqa: E402
+from egomotion_with_local_loop_closures_amd import api, synth, _lib  # noqa: E402
+import ctypes  # noqa: E402
+
+# an older library build (ELLC_LIB_PATH) may lack entry points added since; the timing hooks used here are old
+_so = ctypes.CDLL(_lib.SO_PATH)
+_lib.ABI_SYMBOLS = [s for s in _lib.ABI_SYMBOLS if hasattr(_so, s)]
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--variants", nargs="+", default=["ELLC_GN_ILP=1", "ELLC_GN_ILP=2"])

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Build the library as of a git revision into build/libellc_hip_<name>.so (for A/B timing against the working tree).
+# usage: tools/build_variant.sh <git-rev> <name>
+set -e
+REV=$1; NAME=$2
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+TMP=$(mktemp -d)
+git -C "$ROOT" archive "$REV" egomotion_with_local_loop_closures_amd/csrc include | tar -x -C "$TMP"
+cd "$TMP/egomotion_with_local_loop_closures_amd/csrc"
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -w -shared -o "$ROOT/build/libellc_hip_$NAME.so" ellc_hip.hip
+rm -rf "$TMP"
+ls -la "$ROOT/build/libellc_hip_$NAME.so"
