@@ -219,8 +219,8 @@ static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, b
     if (divc) hipLaunchKernelGGL((gn_fca_fused<true, 5>), grd, blk, 0, c->stream, fa);
     else hipLaunchKernelGGL((gn_fca_fused<false, 5>), grd, blk, 0, c->stream, fa);
   } else {
-    if (divc) hipLaunchKernelGGL((gn_fca_fused<true, 1>), grd, blk, 0, c->stream, fa);
-    else hipLaunchKernelGGL((gn_fca_fused<false, 1>), grd, blk, 0, c->stream, fa);
+    if (divc) hipLaunchKernelGGL((gn_fca_fused<true, 4>), grd, blk, 0, c->stream, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, 4>), grd, blk, 0, c->stream, fa);
   }
 }
 
@@ -235,7 +235,29 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
   fa.stride_state = c->cfg.max_batch;
   fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
   const bool divc = c->geom_h[0].divc_ok != 0;
-  for (int level = c->L - 1; level >= 0; level--) {
+  fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);   // the finish kernel reads state / partials from here even if no fused launch runs
+  // coarse levels (contiguous from the top of the pyramid): every iteration inside one launch, one block per alignment
+  int first_fused = c->L - 1;
+  while (first_fused >= 0 && c->geom_h[first_fused].n <= c->resident_max_pixels) first_fused--;
+  if (first_fused < c->L - 1) {
+    ResidentArgs ra;
+    ra.g = make_gn_args(c, c->L - 1, B, save_weights ? 1 : 0, nullptr);
+    ra.level_hi = c->L - 1;
+    ra.level_lo = first_fused + 1;
+    for (int l = 0; l < ELLC_MAX_LEVELS; l++) ra.max_iter[l] = c->cfg.max_iter[l];
+    ra.early_exit = c->cfg.early_exit;
+    if (c->resident_threads == 512) {
+      if (divc) hipLaunchKernelGGL((gn_fca_resident<true, 512>), dim3(B), dim3(512), 0, c->stream, ra);
+      else hipLaunchKernelGGL((gn_fca_resident<false, 512>), dim3(B), dim3(512), 0, c->stream, ra);
+    } else {
+      if (divc) hipLaunchKernelGGL((gn_fca_resident<true, 1024>), dim3(B), dim3(1024), 0, c->stream, ra);
+      else hipLaunchKernelGGL((gn_fca_resident<false, 1024>), dim3(B), dim3(1024), 0, c->stream, ra);
+    }
+    if (save_weights)
+      for (int level = c->L - 1; level > first_fused; level--)
+        hipLaunchKernelGGL(gn_add_saved_weights, dim3(64, B), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, level, c->cfg.max_keyframes);
+  }
+  for (int level = first_fused; level >= 0; level--) {
     fa.g = make_gn_args(c, level, B, save_weights ? 1 : 0, nullptr);
     const dim3 grd(fa.g.nblk, B), blk(ELLC_GN_THREADS);
     for (int it = 0; it < c->cfg.max_iter[level]; it++) {
@@ -457,6 +479,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   {
     if (const char* nf = getenv("ELLC_NO_FUSE")) c->use_fused = !(nf[0] == '1');
     if (const char* o5 = getenv("ELLC_OCC5_MIN_PIXELS")) c->occ5_min_pixels = atoll(o5);
+    if (const char* rm = getenv("ELLC_RESIDENT_MAXPX")) c->resident_max_pixels = atoi(rm);
+    if (const char* rt = getenv("ELLC_RES_THREADS")) c->resident_threads = atoi(rt) == 512 ? 512 : 1024;
     const char* ng = getenv("ELLC_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
     if (const char* ilp = getenv("ELLC_GN_ILP")) c->gn_ilp = atoi(ilp) == 2 ? 2 : 1;

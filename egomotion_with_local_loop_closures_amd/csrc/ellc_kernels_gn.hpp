@@ -351,24 +351,68 @@ __device__ __forceinline__ FcaIn fca_load(const KfLevelDev& K, unsigned i) {
   return in;
 }
 
-template <bool DEBUG, bool DIVC>
-__device__ __forceinline__ FcaPix fca_pixel_in(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
-                                               const float* S, unsigned i, const FcaIn& in) {
-  const uint32_t xy = in.xy;
-  const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-  const float Z = in.Z;
-  const float var = in.var;
-  const float Ikf = in.Ikf;
-  const Warp w = warp_point<true>(in.X, in.Y, Z, g, S);
+// Everything the Jacobian and the weight need from the keyframe pixel alone (no pose, no tap): the per-column /
+// per-row table entries and the products with 1/Z of PixelWisePyramid.cpp:296-303. The fused kernel evaluates this
+// for a thread's first pixel while the solve of the previous iteration is still running.
+struct FcaPre {
+  float c_t0, c_b1, colB, rowB, d;
+  double colA, rowA, fxz, fyz, nvz, nuz;
+};
+
+template <bool DIVC>
+__device__ __forceinline__ FcaPre fca_prepare(const LevelGeom& g, const FcaIn& in) {
+  const int x = (int)(in.xy & 0xffffu), y = (int)(in.xy >> 16);
+  const float u = -g.cx + (float)x;
+  const float v = -g.cy + (float)y;
+  const float vu = v * u;
+  FcaPre p;
+  p.c_t0 = DIVC ? div_const(-vu, g.fy, g.rfy) : (-vu / g.fy);
+  p.c_b1 = DIVC ? div_const(vu, g.fx, g.rfx) : (vu / g.fx);
+  p.colA = as_global(g.colA)[x];
+  p.colB = as_global(g.colB)[x];
+  p.rowA = as_global(g.rowA)[y];
+  p.rowB = as_global(g.rowB)[y];
+  p.fxz = (double)g.fx * in.invZ;
+  p.fyz = (double)g.fy * in.invZ;
+  p.nvz = (double)(-v) * in.invZ;
+  p.nuz = (double)(-u) * in.invZ;
+  p.d = (float)in.invZ;
+  return p;
+}
+
+// PixelWisePyramid.cpp:296-320 with the pose-independent factors of fca_prepare (same expressions as jacobian_row)
+__device__ __forceinline__ void jacobian_row_pre(float gradx, float grady, const FcaPre& p, float J[6]) {
+  const float jb0 = (float)((double)grady * p.rowA);
+  const float jt0 = gradx * p.c_t0;
+  const float jb1 = grady * p.c_b1;
+  const float jt1 = (float)((double)gradx * p.colA);
+  const float jb2 = grady * p.colB;
+  const float jt2 = gradx * p.rowB;
+  const float jt3 = (float)((double)gradx * p.fxz);
+  const float jb4 = (float)((double)grady * p.fyz);
+  const float jb5 = (float)((double)grady * p.nvz);
+  const float jt5 = (float)((double)gradx * p.nuz);
+  J[0] = jt0 + jb0;
+  J[1] = jt1 + jb1;
+  J[2] = jt2 + jb2;
+  J[3] = jt3 + 0.0f;
+  J[4] = 0.0f + jb4;
+  J[5] = jt5 + jb5;
+}
+
+template <bool DEBUG>
+__device__ __forceinline__ FcaPix fca_pixel_pre(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
+                                                const float* S, unsigned i, const FcaIn& in, const FcaPre& pre) {
+  const Warp w = warp_point<true>(in.X, in.Y, in.Z, g, S);
   const Taps t = tap_point<true>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
   FcaPix o;
-  const double invZ = in.invZ;
-  jacobian_row<DIVC>(t.gx, t.gy, x, y, invZ, g, o.J);
+  jacobian_row_pre(t.gx, t.gy, pre, o.J);
   const bool oob = (t.I == -1.0f);
-  o.residual = oob ? 0.0f : (t.I - Ikf);
-  o.wgt = oob ? 0.0f : fca_weight(w, (float)invZ, o.residual, t.gx, t.gy, 1.0f * var, g, S[3], S[7], S[11]);
+  o.residual = oob ? 0.0f : (t.I - in.Ikf);
+  o.wgt = oob ? 0.0f : fca_weight(w, pre.d, o.residual, t.gx, t.gy, 1.0f * in.var, g, S[3], S[7], S[11]);
   if (a.save_w) *(ELLC_GLOBAL float*)((ELLC_GLOBAL char*)K.wlast + i * 4u) = o.wgt;
   if (DEBUG) {
+    const int x = (int)(in.xy & 0xffffu), y = (int)(in.xy >> 16);
     const size_t n = (size_t)g.n, p = (size_t)y * g.cols + x;
     a.planes[0 * n + p] = o.residual;
     a.planes[1 * n + p] = o.wgt;
@@ -378,6 +422,12 @@ __device__ __forceinline__ FcaPix fca_pixel_in(const GnArgs& a, const KfLevelDev
     for (int k = 0; k < 6; k++) a.planes[(4 + k) * n + p] = o.J[k];
   }
   return o;
+}
+
+template <bool DEBUG, bool DIVC>
+__device__ __forceinline__ FcaPix fca_pixel_in(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
+                                               const float* S, unsigned i, const FcaIn& in) {
+  return fca_pixel_pre<DEBUG>(a, K, g, cur, S, i, in, fca_prepare<DIVC>(g, in));
 }
 
 template <bool DEBUG, bool DIVC>
@@ -694,24 +744,14 @@ __device__ __forceinline__ double partial_group_sum(const float* __restrict__ pa
   return s;
 }
 
-__device__ __forceinline__ void solve_step(SolveShared& sh, double group_sum, int mode, int level, int early_exit,
-                                           const AlignState& src, AlignState* dst) {
+// Second half of the solve: from the 27 combined sums in sh.sums to the new pose. S_cur / level_done_cur are the
+// current exp(pose) and level_done (state record or LDS copy). Ends with a block barrier.
+__device__ __forceinline__ void solve_finish(SolveShared& sh, int mode, int level, int early_exit, const AlignState& src,
+                                             const float* S_cur, int level_done_cur, AlignState* dst) {
   const int t = threadIdx.x;
-  const int comp = t & 31, grp = t >> 5;
-  sh.part[grp][comp] = group_sum;
-  ELLC_STAMP(1);
-  if (mode == 2 && t < 36) sh.Hinv[t] = src.Hinv[t];   // ICA iterate: the level's precomputed inverse
-  __syncthreads();
-  if (t < 27) {
-    double s = sh.part[0][t];
-#pragma unroll
-    for (int g = 1; g < ELLC_SOLVE_THREADS / 32; g++) s += sh.part[g][t];
-    sh.sums[t] = s;
-  }
-  __syncthreads();
-  ELLC_STAMP(2);
   if (t < 64) {   // wave 0 finishes the job; wave-level barriers only inside
     const int lane = t;
+    const float S_lane = S_cur[min(lane, 11)];   // entry `lane` of the current exp(pose); consumed after the LU
     if (mode != 2) {
       float Hm[36];
       {
@@ -771,31 +811,72 @@ __device__ __forceinline__ void solve_step(SolveShared& sh, double group_sum, in
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       ELLC_STAMP(4);
-      if (lane == 0) {
+      {
+        // pose <- log(exp(delta) * exp(pose)); exp(pose) is the f32 matrix the pixel pass used. The 64 lanes of the wave
+        // share the work: lane 3r+k evaluates entry (r,k) of each exp (ellc_se3.hpp: exp_se3 is the same nine entry
+        // evaluations in a loop), lane 4r+c entry (r,c) of the product; the log (series, a handful of terms) is evaluated
+        // redundantly by every lane on broadcast inputs. Same operations per value as the scalar host functions.
         float delta[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) delta[i] = sh.delta[i];
         const float weighted = fabsf(delta[0] * 100000.0f) + fabsf(delta[1] * 100000.0f) + fabsf(delta[2] * 100000.0f) +
                                fabsf(delta[3] * 10000.0f) + fabsf(delta[4] * 10000.0f) + fabsf(delta[5] * 10000.0f);
-        // pose <- log(exp(delta) * exp(pose)); exp(pose) is the f32 matrix the pixel pass used
-        float D[12], C[12], np[6], S[12];
-        exp_se3_f32(delta, D);
+        const int l9 = min(lane, 8);
+        const int r3 = l9 / 3, k3 = l9 - 3 * r3;
+        double Rrk, Vv;
+        exp_se3_entry((double)delta[0], (double)delta[1], (double)delta[2], (double)delta[3], (double)delta[4], (double)delta[5], r3, k3, Rrk, Vv);
+        const double trow = (Vv + __shfl_down(Vv, 1)) + __shfl_down(Vv, 2);   // t[r] in lanes 0, 3, 6
+        const float Df = (float)Rrk, Dt = (float)trow;
+        const int e = min(lane, 11), r = e >> 2, c = e & 3;
+        const float d0 = __shfl(Df, 3 * r), d1 = __shfl(Df, 3 * r + 1), d2 = __shfl(Df, 3 * r + 2), d3 = __shfl(Dt, 3 * r);
+        const float b0 = __shfl(S_lane, c), b1 = __shfl(S_lane, 4 + c), b2 = __shfl(S_lane, 8 + c);
+        double cs = 0.0;   // compose_f32: products summed in double, rounded once
+        cs += (double)d0 * (double)b0;
+        cs += (double)d1 * (double)b1;
+        cs += (double)d2 * (double)b2;
+        if (c == 3) cs += (double)d3;
+        const float Cf = (float)cs;
+        float C[12], np[6];
 #pragma unroll
-        for (int i = 0; i < 12; i++) S[i] = src.S[i];
-        compose_f32(D, S, C);
+        for (int i = 0; i < 12; i++) C[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Cf), i));
         log_se3_f32(C, np);
-        exp_se3_f32(np, S);
+        double R2, V2;
+        exp_se3_entry((double)np[0], (double)np[1], (double)np[2], (double)np[3], (double)np[4], (double)np[5], r3, k3, R2, V2);
+        const double t2 = (V2 + __shfl_down(V2, 1)) + __shfl_down(V2, 2);
+        if (lane < 9) {
+          sh.newS[r3 * 4 + k3] = (float)R2;
+          if (k3 == 0) sh.newS[r3 * 4 + 3] = (float)t2;
+        }
+        if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) sh.newpose[i] = np[i];
-#pragma unroll
-        for (int i = 0; i < 12; i++) sh.newS[i] = S[i];
-        sh.weighted = weighted;
-        sh.level_done = (early_exit && weighted < 1.0f) ? level : src.level_done;   // ImageFunc.cpp:251-252
+          for (int i = 0; i < 6; i++) sh.newpose[i] = np[i];
+          sh.weighted = weighted;
+          sh.level_done = (early_exit && weighted < 1.0f) ? level : level_done_cur;   // ImageFunc.cpp:251-252
+        }
       }
       ELLC_STAMP(5);
     }
   }
   __syncthreads();
+}
+
+__device__ __forceinline__ void solve_step(SolveShared& sh, double group_sum, int mode, int level, int early_exit,
+                                           const AlignState& src, AlignState* dst) {
+  const int t = threadIdx.x;
+  const int comp = t & 31, grp = t >> 5;
+  sh.part[grp][comp] = group_sum;
+  ELLC_STAMP(1);
+  if (mode == 2 && t < 36) sh.Hinv[t] = src.Hinv[t];   // ICA iterate: the level's precomputed inverse
+  __syncthreads();
+  if (t < 27) {
+    double s = sh.part[0][t];
+#pragma unroll
+    for (int g = 1; g < ELLC_SOLVE_THREADS / 32; g++) s += sh.part[g][t];
+    sh.sums[t] = s;
+  }
+  __syncthreads();
+  ELLC_STAMP(2);
+  solve_finish(sh, mode, level, early_exit, src, src.S, src.level_done, dst);
 }
 
 // One block per alignment (used by the ICA path, the single-step API and as the final solve of a fused schedule).
@@ -865,6 +946,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, MINW) void gn_fca_fused(FusedArgs 
   FcaIn first;
   first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.X = 0.0f; first.Y = 0.0f; first.invZ = 1.0;
   if (begin + t < end) first = fca_load(K, (unsigned)(begin + t));
+  const FcaPre first_pre = fca_prepare<DIVC>(g, first);
+  // pin the arithmetic here (the compiler would otherwise sink it below the solve, onto the critical path)
+  asm volatile("" ::"v"(first_pre.c_t0), "v"(first_pre.c_b1), "v"(first_pre.d), "v"(first_pre.fxz), "v"(first_pre.fyz),
+               "v"(first_pre.nvz), "v"(first_pre.nuz));
   if (pending) {
     solve_step(sh, group_sum, 0, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr);
   } else {
@@ -895,7 +980,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, MINW) void gn_fca_fused(FusedArgs 
   fca_acc_zero(acc);
   int i = begin + t;
   if (i < end) {
-    const FcaPix p = fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, first);
+    const FcaPix p = fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre);
     fca_accumulate_pixel(acc, p);
     for (i += stride; i < end; i += stride) {
       const FcaPix q = fca_pixel<false, DIVC>(a, K, g, cur, S, (unsigned)i);
@@ -939,6 +1024,87 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
     dst->weighted = sh.weighted;
     dst->level_done = sh.level_done;
     dst->pending = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Resident schedule for the coarse levels: one 1024-thread block per alignment runs ALL iterations of the levels
+// level_hi .. level_lo inside one launch. A coarse level has so few valid pixels (about one per thread) that a launch
+// per iteration is pure latency (dispatch, cold loads, cross-block partial sums); here the pixel pass, the reduction
+// (wave DPP tree, then a fixed-order f64 combine of the 16 wave partials) and the solve stay inside the block, the
+// thread's first pixel record and its pose-independent factors stay in registers across iterations, and the taps hit
+// the CU's L1 after the first iteration. Arithmetic per pixel and per solve is the fused kernel's, function for function.
+struct ResidentArgs {
+  GnArgs g;                       // g.level / g.nblk unused
+  int level_hi, level_lo;
+  int max_iter[ELLC_MAX_LEVELS];
+  int early_exit;
+};
+template <bool DIVC, int ELLC_RES_THREADS>
+__global__ __launch_bounds__(ELLC_RES_THREADS) void gn_fca_resident(ResidentArgs ra) {
+  const GnArgs& a = ra.g;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  AlignState* st = a.state + b;
+  __shared__ SolveShared sh;
+  __shared__ float wpart[ELLC_RES_THREADS / 64][32];
+  __shared__ int iters_sh[ELLC_MAX_LEVELS];
+  if (t < 6) sh.newpose[t] = st->pose[t];
+  if (t < 12) sh.newS[t] = st->S[t];
+  if (t < ELLC_MAX_LEVELS) iters_sh[t] = st->iters[t];
+  if (t == 0) { sh.weighted = st->weighted; sh.level_done = st->level_done; }
+  __syncthreads();
+  for (int level = ra.level_hi; level >= ra.level_lo; level--) {
+    const LevelGeom g = a.geom[level];
+    const KfLevelDev K = a.kf_tab[level * a.max_kf + a.kf_slot[b]];
+    const FrLevelDev F = a.fr_tab[level * a.max_fr + a.fr_slot[b]];
+    const int V = *as_global(K.count);
+    g_u8 cur = as_global(F.img);
+    FcaIn in0;
+    in0.xy = 0; in0.Z = 1.0f; in0.var = 0.0f; in0.Ikf = 0.0f; in0.X = 0.0f; in0.Y = 0.0f; in0.invZ = 1.0;
+    if (t < V) in0 = fca_load(K, (unsigned)t);
+    const FcaPre pre0 = fca_prepare<DIVC>(g, in0);
+    for (int it = 0; it < ra.max_iter[level]; it++) {
+      if (sh.level_done == level) break;   // block-uniform: written before the barrier that ended the previous solve
+      float S[12];
+#pragma unroll
+      for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
+      FcaAcc acc;
+      fca_acc_zero(acc);
+      if (t < V) {
+        const FcaPix p = fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)t, in0, pre0);
+        fca_accumulate_pixel(acc, p);
+        for (int i = t + ELLC_RES_THREADS; i < V; i += ELLC_RES_THREADS) {
+          const FcaPix q = fca_pixel<false, DIVC>(a, K, g, cur, S, (unsigned)i);
+          fca_accumulate_pixel(acc, q);
+        }
+      }
+      float sums[27];
+      fca_acc_unpack(acc, sums);
+      wave_sum_all<27>(sums);
+      if (lane == 63) {
+#pragma unroll
+        for (int j = 0; j < 27; j++) wpart[wave][j] = sums[j];
+      }
+      __syncthreads();
+      if (t < 27) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < ELLC_RES_THREADS / 64; w++) s += (double)wpart[w][t];
+        sh.sums[t] = s;
+      }
+      __syncthreads();
+      solve_finish(sh, 0, level, ra.early_exit, *st, sh.newS, sh.level_done, st);
+      if (t == 0) iters_sh[level] += 1;
+    }
+  }
+  __syncthreads();
+  if (t < 6) st->pose[t] = sh.newpose[t];
+  if (t < 12) st->S[t] = sh.newS[t];
+  if (t < ELLC_MAX_LEVELS) st->iters[t] = iters_sh[t];
+  if (t == 0) {
+    st->weighted = sh.weighted;
+    st->level_done = sh.level_done;
+    st->pending = 0;
   }
 }
 

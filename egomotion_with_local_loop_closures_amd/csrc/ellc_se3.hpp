@@ -35,21 +35,43 @@ ELLC_HD void sinc_family(double q, double& s1, double& s2, double& s3) {
   }
 }
 
-// exp: twist [w v] -> (R, t)
-ELLC_HD void exp_se3(const double xi[6], Rt& o) {
-  const double a = xi[0], b = xi[1], c = xi[2];
+// One entry of exp: R[r][k] and the product V[r][k] * v[k] (so that t[r] = (p_r0 + p_r1) + p_r2), written so that each
+// value is produced by exactly the operations exp_se3 uses for it — the solve kernel spreads the nine entries over
+// nine lanes (r = lane / 3, k = lane % 3) instead of evaluating all of them on one.
+ELLC_HD void exp_se3_entry(double a, double b, double c, double vx, double vy, double vz, int r, int k, double& Rrk, double& Vv) {
   const double q = a * a + b * b + c * c;
   double s1, s2, s3;
   sinc_family(q, s1, s2, s3);
-  // R = I + s1 [w]x + s2 [w]x^2,  V = I + s2 [w]x + s3 [w]x^2, with [w]x^2 = w w^T - q I
-  const double aa = a * a - q, bb = b * b - q, cc = c * c - q, ab = a * b, ac = a * c, bc = b * c;
-  o.R[0] = 1.0 + s2 * aa;      o.R[1] = -s1 * c + s2 * ab;  o.R[2] = s1 * b + s2 * ac;
-  o.R[3] = s1 * c + s2 * ab;   o.R[4] = 1.0 + s2 * bb;      o.R[5] = -s1 * a + s2 * bc;
-  o.R[6] = -s1 * b + s2 * ac;  o.R[7] = s1 * a + s2 * bc;   o.R[8] = 1.0 + s2 * cc;
-  const double vx = xi[3], vy = xi[4], vz = xi[5];
-  o.t[0] = (1.0 + s3 * aa) * vx + (-s2 * c + s3 * ab) * vy + (s2 * b + s3 * ac) * vz;
-  o.t[1] = (s2 * c + s3 * ab) * vx + (1.0 + s3 * bb) * vy + (-s2 * a + s3 * bc) * vz;
-  o.t[2] = (-s2 * b + s3 * ac) * vx + (s2 * a + s3 * bc) * vy + (1.0 + s3 * cc) * vz;
+  const double wr = (r == 0) ? a : ((r == 1) ? b : c);
+  const double wk = (k == 0) ? a : ((k == 1) ? b : c);
+  const bool diag = (r == k);
+  const int idx = 3 - r - k;                          // the remaining axis of an off-diagonal entry
+  const double wi = (idx == 0) ? a : ((idx == 1) ? b : c);
+  const bool pos = ((k - r + 3) % 3) == 2;            // sign of the skew part: (0,2) (1,0) (2,1) positive
+  const double sw = pos ? wi : -wi;
+  const double mm = wr * wk;
+  const double m = diag ? (mm - q) : mm;              // [w]x^2 = w w^T - q I
+  const double TR = diag ? 1.0 : (s1 * sw);
+  Rrk = TR + s2 * m;
+  const double TV = diag ? 1.0 : (s2 * sw);
+  const double Vrk = TV + s3 * m;
+  const double vk = (k == 0) ? vx : ((k == 1) ? vy : vz);
+  Vv = Vrk * vk;
+}
+
+// exp: twist [w v] -> (R, t):  R = I + s1 [w]x + s2 [w]x^2,  t = V v with V = I + s2 [w]x + s3 [w]x^2
+ELLC_HD void exp_se3(const double xi[6], Rt& o) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int r = 0; r < 3; r++) {
+    double p[3];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 3; k++) exp_se3_entry(xi[0], xi[1], xi[2], xi[3], xi[4], xi[5], r, k, o.R[r * 3 + k], p[k]);
+    o.t[r] = (p[0] + p[1]) + p[2];
+  }
 }
 
 // log: (R, t) -> twist (principal branch, angle in [0, pi])
