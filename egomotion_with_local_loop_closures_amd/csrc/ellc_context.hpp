@@ -55,14 +55,8 @@ struct ellc_ctx {
   // captured launch sequences of ellc_align, keyed by (B, unique keyframes, mode, save_weights)
   std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
   bool use_graph = true;
-  long long occ5_min_pixels = 1LL << 60;   // tuning knob (ELLC_OCC5_MIN_PIXELS): launches covering at least this many pixels use the
-                                           // 5-waves/SIMD build of the fused kernel; r01 A/B: the spills it needs cost more than the occupancy gives
   bool use_fused = true;        // FCA: solve folded into the next accumulate launch (ELLC_NO_FUSE=1 disables)
-  int gn_ilp = 1;               // pixels in flight per thread in the FCA accumulate kernel (ELLC_GN_ILP)
   int nblk_override[ELLC_MAX_LEVELS] = {0};
-  int resident_max_pixels = 20000;   // tuning knob (ELLC_RESIDENT_MAXPX): pyramid levels with at most this many pixels run all their
-                                     // iterations inside one block per alignment (gn_fca_resident); 0 disables
-  int resident_threads = 1024;       // threads per block of gn_fca_resident (ELLC_RES_THREADS: 512 or 1024)
   int resident_blocks = 1280;   // 256-thread blocks of the accumulate kernel resident on the device at once
   // depth map (one per context)
   ellc::DepthSoA dm_cur, dm_oth;

@@ -100,7 +100,9 @@ ellc_status build_depth_pyramid(ellc_ctx* c, int slot) {
   return ELLC_OK;
 }
 
-ellc_status run_prep(ellc_ctx* c, int n_unique, int need) {
+// compaction for pyramid levels lvl_lo .. lvl_hi of the listed keyframes, on stream `st`
+ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int lvl_hi, hipStream_t st) {
+  if (lvl_lo > lvl_hi) return ELLC_OK;
   PrepArgs a;
   a.need = need;
   a.geom = c->geom_d;
@@ -109,13 +111,17 @@ ellc_status run_prep(ellc_ctx* c, int n_unique, int need) {
   a.levels = c->L;
   a.max_kf = c->cfg.max_keyframes;
   for (int l = 0; l <= ELLC_MAX_LEVELS; l++) a.tile_begin[l] = c->tile_begin[std::min(l, c->L)];
-  const int tiles = c->tile_begin[c->L];
-  hipLaunchKernelGGL(prep_count, dim3(tiles, n_unique), dim3(256), 0, c->stream, a);
-  hipLaunchKernelGGL(prep_scan, dim3(c->L, n_unique), dim3(256), 0, c->stream, a);
-  hipLaunchKernelGGL(prep_scatter, dim3(tiles, n_unique), dim3(256), 0, c->stream, a);
+  a.tile0 = c->tile_begin[lvl_lo];
+  a.level0 = lvl_lo;
+  const int tiles = c->tile_begin[lvl_hi + 1] - c->tile_begin[lvl_lo];
+  hipLaunchKernelGGL(prep_count, dim3(tiles, n_unique), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(prep_scan, dim3(lvl_hi - lvl_lo + 1, n_unique), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(prep_scatter, dim3(tiles, n_unique), dim3(256), 0, st, a);
   ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
 }
+
+ellc_status run_prep(ellc_ctx* c, int n_unique, int need) { return run_prep_levels(c, n_unique, need, 0, c->L - 1, c->stream); }
 
 static bool slot_ok(int s, int n) { return s >= 0 && s < n; }
 
@@ -138,14 +144,8 @@ static GnArgs make_gn_args(ellc_ctx* c, int level, int B, int save_w, float* pla
 }
 
 static void launch_fca(ellc_ctx* c, dim3 grd, dim3 blk, const GnArgs& a) {
-  const bool divc = c->geom_h[0].divc_ok != 0;
-  if (c->gn_ilp == 2) {
-    if (divc) hipLaunchKernelGGL((gn_fca_accumulate<false, 2, true>), grd, blk, 0, c->stream, a);
-    else hipLaunchKernelGGL((gn_fca_accumulate<false, 2, false>), grd, blk, 0, c->stream, a);
-  } else {
-    if (divc) hipLaunchKernelGGL((gn_fca_accumulate<false, 1, true>), grd, blk, 0, c->stream, a);
-    else hipLaunchKernelGGL((gn_fca_accumulate<false, 1, false>), grd, blk, 0, c->stream, a);
-  }
+  if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_accumulate<false, true>), grd, blk, 0, c->stream, a);
+  else hipLaunchKernelGGL((gn_fca_accumulate<false, false>), grd, blk, 0, c->stream, a);
 }
 
 // Exhaustive check of div_const(a, b, RN(1/b)) == a / b for every f32 mantissa of a (division commutes with the
@@ -212,20 +212,16 @@ static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const in
   return ELLC_OK;
 }
 
-// big launches are throughput-bound: ask the register allocator for 5 waves/SIMD; small ones are latency-bound
-static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, bool big) {
-  const bool divc = c->geom_h[0].divc_ok != 0;
-  if (big) {
-    if (divc) hipLaunchKernelGGL((gn_fca_fused<true, 5>), grd, blk, 0, c->stream, fa);
-    else hipLaunchKernelGGL((gn_fca_fused<false, 5>), grd, blk, 0, c->stream, fa);
-  } else {
-    if (divc) hipLaunchKernelGGL((gn_fca_fused<true, 4>), grd, blk, 0, c->stream, fa);
-    else hipLaunchKernelGGL((gn_fca_fused<false, 4>), grd, blk, 0, c->stream, fa);
-  }
+static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
+  if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true>), grd, blk, 0, st, fa);
+  else hipLaunchKernelGGL((gn_fca_fused<false>), grd, blk, 0, st, fa);
 }
 
-// FCA schedule with the solve of iteration n folded into the prologue of launch n+1 (gn_fca_fused): one launch per
-// Gauss-Newton iteration plus one final solve.
+// FCA schedule: the solve of iteration n is folded into the prologue of launch n+1 (gn_fca_fused): one launch per
+// Gauss-Newton iteration plus one final solve. (r01 experiments that did not pay and were removed: cutting the batch
+// into independent chains on parallel graph branches — the queues interleave poorly and the per-node submission cost
+// dominates; compacting the fine levels on a second stream beside the coarse iterations — fork/join cost more than the
+// overlap gave; a one-block-per-alignment kernel running all coarse iterations — one CU is VALU-bound on a level.)
 static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) {
   FusedArgs fa;
   fa.seq = 0;
@@ -234,34 +230,12 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
   fa.early_exit = c->cfg.early_exit;
   fa.stride_state = c->cfg.max_batch;
   fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
-  const bool divc = c->geom_h[0].divc_ok != 0;
-  fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);   // the finish kernel reads state / partials from here even if no fused launch runs
-  // coarse levels (contiguous from the top of the pyramid): every iteration inside one launch, one block per alignment
-  int first_fused = c->L - 1;
-  while (first_fused >= 0 && c->geom_h[first_fused].n <= c->resident_max_pixels) first_fused--;
-  if (first_fused < c->L - 1) {
-    ResidentArgs ra;
-    ra.g = make_gn_args(c, c->L - 1, B, save_weights ? 1 : 0, nullptr);
-    ra.level_hi = c->L - 1;
-    ra.level_lo = first_fused + 1;
-    for (int l = 0; l < ELLC_MAX_LEVELS; l++) ra.max_iter[l] = c->cfg.max_iter[l];
-    ra.early_exit = c->cfg.early_exit;
-    if (c->resident_threads == 512) {
-      if (divc) hipLaunchKernelGGL((gn_fca_resident<true, 512>), dim3(B), dim3(512), 0, c->stream, ra);
-      else hipLaunchKernelGGL((gn_fca_resident<false, 512>), dim3(B), dim3(512), 0, c->stream, ra);
-    } else {
-      if (divc) hipLaunchKernelGGL((gn_fca_resident<true, 1024>), dim3(B), dim3(1024), 0, c->stream, ra);
-      else hipLaunchKernelGGL((gn_fca_resident<false, 1024>), dim3(B), dim3(1024), 0, c->stream, ra);
-    }
-    if (save_weights)
-      for (int level = c->L - 1; level > first_fused; level--)
-        hipLaunchKernelGGL(gn_add_saved_weights, dim3(64, B), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, level, c->cfg.max_keyframes);
-  }
-  for (int level = first_fused; level >= 0; level--) {
+  fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);
+  for (int level = c->L - 1; level >= 0; level--) {
     fa.g = make_gn_args(c, level, B, save_weights ? 1 : 0, nullptr);
     const dim3 grd(fa.g.nblk, B), blk(ELLC_GN_THREADS);
     for (int it = 0; it < c->cfg.max_iter[level]; it++) {
-      launch_fused(c, grd, blk, fa, c->geom_h[level].n * B >= c->occ5_min_pixels);
+      launch_fused(c, grd, blk, fa, c->stream);
       fa.prev_level = level;
       fa.prev_nblk = fa.g.nblk;
       fa.seq++;
@@ -478,12 +452,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   if (hipStreamSynchronize(c->stream) != hipSuccess) { *out = c; return fail(c, ELLC_ERR_HIP, "initial sync failed"); }
   {
     if (const char* nf = getenv("ELLC_NO_FUSE")) c->use_fused = !(nf[0] == '1');
-    if (const char* o5 = getenv("ELLC_OCC5_MIN_PIXELS")) c->occ5_min_pixels = atoll(o5);
-    if (const char* rm = getenv("ELLC_RESIDENT_MAXPX")) c->resident_max_pixels = atoi(rm);
-    if (const char* rt = getenv("ELLC_RES_THREADS")) c->resident_threads = atoi(rt) == 512 ? 512 : 1024;
     const char* ng = getenv("ELLC_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
-    if (const char* ilp = getenv("ELLC_GN_ILP")) c->gn_ilp = atoi(ilp) == 2 ? 2 : 1;
     for (int l = 0; l < ELLC_MAX_LEVELS; l++) c->nblk_override[l] = 0;
     if (const char* nb = getenv("ELLC_NBLK")) {
       int l = 0;
@@ -826,8 +796,8 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   GnArgs a = make_gn_args(c, level, 1, 0, planes ? c->planes_d : nullptr);
   const dim3 grd(a.nblk, 1), blk(ELLC_GN_THREADS);
   if (mode == ELLC_MODE_FCA) {
-    if (planes && c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_accumulate<true, 1, true>), grd, blk, 0, c->stream, a);
-    else if (planes) hipLaunchKernelGGL((gn_fca_accumulate<true, 1, false>), grd, blk, 0, c->stream, a);
+    if (planes && c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_accumulate<true, true>), grd, blk, 0, c->stream, a);
+    else if (planes) hipLaunchKernelGGL((gn_fca_accumulate<true, false>), grd, blk, 0, c->stream, a);
     else launch_fca(c, grd, blk, a);
     launch_solve(c, level, 1, a.nblk, 0, 0);
   } else {
@@ -902,7 +872,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
     const bool divc = c->geom_h[0].divc_ok != 0;
     auto launch = [&]() {
-      launch_fused(c, grd, blk, fa, c->geom_h[level].n * B >= c->occ5_min_pixels);
+      launch_fused(c, grd, blk, fa, c->stream);
       fa.seq++;
     };
     for (int i = 0; i < 3; i++) launch();

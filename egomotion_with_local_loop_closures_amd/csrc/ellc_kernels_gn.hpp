@@ -484,10 +484,9 @@ __device__ __forceinline__ void fca_acc_unpack(const FcaAcc& A, float (&o)[27]) 
   o[21] = A.b[0].x; o[22] = A.b[0].y; o[23] = A.b[1].x; o[24] = A.b[1].y; o[25] = A.b[2].x; o[26] = A.b[2].y;
 }
 
-// FCA accumulate: grid (nblk, B). Each block owns a contiguous chunk of the alignment's compact pixel
-// list and writes one 27-float partial record. ILP = pixels a thread keeps in flight per loop trip (the
-// per-pixel code is one long dependent chain of IEEE divisions; a second independent pixel fills its stalls).
-template <bool DEBUG, int ILP, bool DIVC>
+// FCA accumulate without the folded solve (single-step API, debug planes, ELLC_NO_FUSE): grid (nblk, B). Each block
+// owns a contiguous chunk of the alignment's compact pixel list and writes one 27-float partial record.
+template <bool DEBUG, bool DIVC>
 __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   const int b = blockIdx.y;
   const AlignState& st = a.state[b];
@@ -496,39 +495,18 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int V = *K.count;
-  // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
-  // split, which was tried in r01 and did not change the run time — co-resident blocks finish staggered because the
-  // SIMD arbiter serves the oldest wave first, not because their pixels differ)
   const int chunk = (V + a.nblk - 1) / a.nblk;
   const int begin = blockIdx.x * chunk;
   const int end = min(V, begin + chunk);
-  const int stride = ELLC_GN_THREADS;
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = st.S[i];
   g_u8 cur = as_global(F.img);
-
   FcaAcc acc;
   fca_acc_zero(acc);
-
-  if (ILP == 1) {
-    for (int i = begin + (int)threadIdx.x; i < end; i += stride) {
-      const FcaPix p = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
-      fca_accumulate_pixel(acc, p);
-    }
-  } else {
-    for (int i = begin + (int)threadIdx.x; i < end; i += 2 * stride) {
-      const int i1 = i + stride;
-      const bool has1 = i1 < end;
-      const FcaPix p0 = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
-      if (has1) {
-        const FcaPix p1 = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i1);
-        fca_accumulate_pixel(acc, p0);   // same order as ILP == 1: pixel i, then pixel i + 256
-        fca_accumulate_pixel(acc, p1);
-      } else {
-        fca_accumulate_pixel(acc, p0);
-      }
-    }
+  for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
+    const FcaPix p = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
+    fca_accumulate_pixel(acc, p);
   }
   float sums[27];
   fca_acc_unpack(acc, sums);
@@ -912,8 +890,8 @@ struct FusedArgs {
   size_t stride_part;   // floats between the two partial buffers
 };
 
-template <bool DIVC, int MINW>   // MINW: minimum waves per SIMD the register allocator must leave room for
-__global__ __launch_bounds__(ELLC_GN_THREADS, MINW) void gn_fca_fused(FusedArgs fa) {
+template <bool DIVC>
+__global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(FusedArgs fa) {   // 4 waves per SIMD: at most 128 VGPRs
   const GnArgs& a = fa.g;
   const int b = blockIdx.y;
   const AlignState& src = a.state[(size_t)(fa.seq & 1) * fa.stride_state + b];
@@ -1024,87 +1002,6 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
     dst->weighted = sh.weighted;
     dst->level_done = sh.level_done;
     dst->pending = 0;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Resident schedule for the coarse levels: one 1024-thread block per alignment runs ALL iterations of the levels
-// level_hi .. level_lo inside one launch. A coarse level has so few valid pixels (about one per thread) that a launch
-// per iteration is pure latency (dispatch, cold loads, cross-block partial sums); here the pixel pass, the reduction
-// (wave DPP tree, then a fixed-order f64 combine of the 16 wave partials) and the solve stay inside the block, the
-// thread's first pixel record and its pose-independent factors stay in registers across iterations, and the taps hit
-// the CU's L1 after the first iteration. Arithmetic per pixel and per solve is the fused kernel's, function for function.
-struct ResidentArgs {
-  GnArgs g;                       // g.level / g.nblk unused
-  int level_hi, level_lo;
-  int max_iter[ELLC_MAX_LEVELS];
-  int early_exit;
-};
-template <bool DIVC, int ELLC_RES_THREADS>
-__global__ __launch_bounds__(ELLC_RES_THREADS) void gn_fca_resident(ResidentArgs ra) {
-  const GnArgs& a = ra.g;
-  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  AlignState* st = a.state + b;
-  __shared__ SolveShared sh;
-  __shared__ float wpart[ELLC_RES_THREADS / 64][32];
-  __shared__ int iters_sh[ELLC_MAX_LEVELS];
-  if (t < 6) sh.newpose[t] = st->pose[t];
-  if (t < 12) sh.newS[t] = st->S[t];
-  if (t < ELLC_MAX_LEVELS) iters_sh[t] = st->iters[t];
-  if (t == 0) { sh.weighted = st->weighted; sh.level_done = st->level_done; }
-  __syncthreads();
-  for (int level = ra.level_hi; level >= ra.level_lo; level--) {
-    const LevelGeom g = a.geom[level];
-    const KfLevelDev K = a.kf_tab[level * a.max_kf + a.kf_slot[b]];
-    const FrLevelDev F = a.fr_tab[level * a.max_fr + a.fr_slot[b]];
-    const int V = *as_global(K.count);
-    g_u8 cur = as_global(F.img);
-    FcaIn in0;
-    in0.xy = 0; in0.Z = 1.0f; in0.var = 0.0f; in0.Ikf = 0.0f; in0.X = 0.0f; in0.Y = 0.0f; in0.invZ = 1.0;
-    if (t < V) in0 = fca_load(K, (unsigned)t);
-    const FcaPre pre0 = fca_prepare<DIVC>(g, in0);
-    for (int it = 0; it < ra.max_iter[level]; it++) {
-      if (sh.level_done == level) break;   // block-uniform: written before the barrier that ended the previous solve
-      float S[12];
-#pragma unroll
-      for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
-      FcaAcc acc;
-      fca_acc_zero(acc);
-      if (t < V) {
-        const FcaPix p = fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)t, in0, pre0);
-        fca_accumulate_pixel(acc, p);
-        for (int i = t + ELLC_RES_THREADS; i < V; i += ELLC_RES_THREADS) {
-          const FcaPix q = fca_pixel<false, DIVC>(a, K, g, cur, S, (unsigned)i);
-          fca_accumulate_pixel(acc, q);
-        }
-      }
-      float sums[27];
-      fca_acc_unpack(acc, sums);
-      wave_sum_all<27>(sums);
-      if (lane == 63) {
-#pragma unroll
-        for (int j = 0; j < 27; j++) wpart[wave][j] = sums[j];
-      }
-      __syncthreads();
-      if (t < 27) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < ELLC_RES_THREADS / 64; w++) s += (double)wpart[w][t];
-        sh.sums[t] = s;
-      }
-      __syncthreads();
-      solve_finish(sh, 0, level, ra.early_exit, *st, sh.newS, sh.level_done, st);
-      if (t == 0) iters_sh[level] += 1;
-    }
-  }
-  __syncthreads();
-  if (t < 6) st->pose[t] = sh.newpose[t];
-  if (t < 12) st->S[t] = sh.newS[t];
-  if (t < ELLC_MAX_LEVELS) st->iters[t] = iters_sh[t];
-  if (t == 0) {
-    st->weighted = sh.weighted;
-    st->level_done = sh.level_done;
-    st->pending = 0;
   }
 }
 

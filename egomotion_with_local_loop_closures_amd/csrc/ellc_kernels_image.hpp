@@ -152,6 +152,7 @@ struct PrepArgs {
   int levels, max_kf;
   int need;                    // bit 0: planes Z / I / saved weight for the ICA path; bit 1: FcaRec records for the FCA path
   int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
+  int tile0, level0;           // this launch covers tiles tile0 + blockIdx.x (count / scatter), levels level0 + blockIdx.x (scan)
 };
 
 __device__ __forceinline__ int prep_level_of(const PrepArgs& a, int tile, int& local) {
@@ -187,7 +188,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
 
 __global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
   int local;
-  const int level = prep_level_of(a, blockIdx.x, local);
+  const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
   const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
   const int n = a.geom[level].n;
   const int i0 = local * ELLC_TILE + threadIdx.x * 8;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
 
 // one block per (level, slot): exclusive scan of the tile counts in place, total -> count
 __global__ __launch_bounds__(256) void prep_scan(PrepArgs a) {
-  const int level = blockIdx.x;
+  const int level = a.level0 + (int)blockIdx.x;
   const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
   const int T = a.tile_begin[level + 1] - a.tile_begin[level];
   const int per = (T + 255) / 256;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void prep_scan(PrepArgs a) {
 // valid pixel, i.e. about four times as often on a semi-dense map.
 __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   int local;
-  const int level = prep_level_of(a, blockIdx.x, local);
+  const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
   const KfLevelDev K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
   const LevelGeom& g = a.geom[level];
   const int n = g.n;
