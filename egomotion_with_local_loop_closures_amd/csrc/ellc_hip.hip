@@ -212,6 +212,28 @@ static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const in
   return ELLC_OK;
 }
 
+// fills the age-balanced split of a launch (FusedArgs::age_rounds): on when the grid is 2..4 full rounds of one block per CU-slot
+static void set_age_split(ellc_ctx* c, FusedArgs& fa, int B) {
+  fa.age_rounds = 0;
+  for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
+  const int per_round = std::max(1, c->resident_blocks / 4);   // one block per CU
+  const int total = fa.g.nblk * B;
+  if (!c->age_balance || total % per_round != 0) return;
+  const int R = total / per_round;
+  if (R < 2 || R > 4 || fa.g.nblk % R != 0) return;
+  // only throughput-bound launches gain (several pixels per thread); a light level finishes before the arbitration matters
+  if (0.3 * c->geom_h[fa.g.level].n / (256.0 * fa.g.nblk) < c->age_min_px_per_thread) return;
+  double sum = 0;
+  for (int q = 0; q < R; q++) sum += c->age_weight[R][q];
+  double cum = 0;
+  for (int q = 0; q < R; q++) {
+    fa.age_cum[q] = (int)(65536.0 * cum / sum + 0.5);
+    cum += c->age_weight[R][q];
+  }
+  fa.age_cum[R] = 65536;
+  fa.age_rounds = R;
+}
+
 static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
   if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true>), grd, blk, 0, st, fa);
   else hipLaunchKernelGGL((gn_fca_fused<false>), grd, blk, 0, st, fa);
@@ -231,8 +253,10 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
   fa.stride_state = c->cfg.max_batch;
   fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
   fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);
+  set_age_split(c, fa, B);
   for (int level = c->L - 1; level >= 0; level--) {
     fa.g = make_gn_args(c, level, B, save_weights ? 1 : 0, nullptr);
+    set_age_split(c, fa, B);
     const dim3 grd(fa.g.nblk, B), blk(ELLC_GN_THREADS);
     for (int it = 0; it < c->cfg.max_iter[level]; it++) {
       launch_fused(c, grd, blk, fa, c->stream);
@@ -452,6 +476,19 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   if (hipStreamSynchronize(c->stream) != hipSuccess) { *out = c; return fail(c, ELLC_ERR_HIP, "initial sync failed"); }
   {
     if (const char* nf = getenv("ELLC_NO_FUSE")) c->use_fused = !(nf[0] == '1');
+    if (const char* ab = getenv("ELLC_NO_AGE_BALANCE")) c->age_balance = !(ab[0] == '1');
+    if (const char* am = getenv("ELLC_AGE_MIN_PX")) c->age_min_px_per_thread = atof(am);
+    if (const char* aw = getenv("ELLC_AGE_W")) {   // "R:w0,w1,..": weights for grids of R rounds
+      int R = 0, pos = 0;
+      if (sscanf(aw, "%d:%n", &R, &pos) == 1 && R >= 2 && R <= 4) {
+        const char* p = aw + pos;
+        for (int q = 0; q < R && *p; q++) {
+          c->age_weight[R][q] = atof(p);
+          while (*p && *p != ',') p++;
+          if (*p == ',') p++;
+        }
+      }
+    }
     const char* ng = getenv("ELLC_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
     for (int l = 0; l < ELLC_MAX_LEVELS; l++) c->nblk_override[l] = 0;
@@ -864,6 +901,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     // the production kernel of the FCA path: every launch first solves the previous launch's partial sums
     FusedArgs fa;
     fa.g = a;
+    set_age_split(c, fa, B);
     fa.seq = 0;
     fa.prev_level = level;
     fa.prev_nblk = a.nblk;

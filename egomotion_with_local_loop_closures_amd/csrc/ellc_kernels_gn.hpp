@@ -888,17 +888,34 @@ struct FusedArgs {
   int early_exit;
   int stride_state;     // elements between the two AlignState buffers
   size_t stride_part;   // floats between the two partial buffers
+  // Age-balanced split (0 = off). When the grid is R full rounds of resident blocks, the blocks dispatched first share
+  // their SIMDs with younger ones and are served first (oldest-wave-first arbitration), so with equal chunks the launch
+  // waits for the youngest round (measured: pixel phases of 15 / 17 / 20 / 23 us for rounds 0..3 of an equal split).
+  // With age_rounds = R every alignment gets nblk / R blocks in each round and round q is given the share
+  // (age_cum[q+1] - age_cum[q]) / 65536 of the alignment's pixels. The mapping only assumes that blocks are dispatched
+  // in linear order; if that were not so the result is unchanged (the split is static) and only the balance is lost.
+  int age_rounds;
+  int age_cum[5];
 };
 
 template <bool DIVC>
 __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(FusedArgs fa) {   // 4 waves per SIMD: at most 128 VGPRs
   const GnArgs& a = fa.g;
-  const int b = blockIdx.y;
+  int b = blockIdx.y, sub = blockIdx.x, age = 0, per_age = a.nblk;
+  if (fa.age_rounds > 1) {
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int per_round = (int)(gridDim.x * gridDim.y) / fa.age_rounds;
+    per_age = a.nblk / fa.age_rounds;          // blocks of one alignment in each round
+    age = lin / per_round;
+    const int j = lin - age * per_round;
+    b = j / per_age;
+    sub = age * per_age + (j - b * per_age);
+  }
   const AlignState& src = a.state[(size_t)(fa.seq & 1) * fa.stride_state + b];
   AlignState* dst = a.state + (size_t)((fa.seq + 1) & 1) * fa.stride_state + b;
   __shared__ SolveShared sh;
   const int t = threadIdx.x;
-  const bool writer = (blockIdx.x == 0);
+  const bool writer = (sub == 0);
   ELLC_STAMP(0);
   ELLC_BSTAMP(0);
   // Load order of the prologue (everything below depends on the kernel arguments only, or on the uniform table
@@ -916,9 +933,17 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(FusedArgs fa)
   // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
   // split, which was tried in r01 and did not change the run time — co-resident blocks finish staggered because the
   // SIMD arbiter serves the oldest wave first, not because their pixels differ)
-  const int chunk = (V + a.nblk - 1) / a.nblk;
-  const int begin = blockIdx.x * chunk;
-  const int end = min(V, begin + chunk);
+  int begin, end;
+  if (fa.age_rounds > 1) {
+    const int gb = (int)(((long long)V * fa.age_cum[age]) >> 16), ge = (int)(((long long)V * fa.age_cum[age + 1]) >> 16);
+    const int chunk = (ge - gb + per_age - 1) / per_age;
+    begin = gb + (sub - age * per_age) * chunk;
+    end = min(ge, begin + chunk);
+  } else {
+    const int chunk = (V + a.nblk - 1) / a.nblk;
+    begin = sub * chunk;
+    end = min(V, begin + chunk);
+  }
   const int stride = ELLC_GN_THREADS;
   g_u8 cur = as_global(F.img);
   FcaIn first;
@@ -967,7 +992,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(FusedArgs fa)
   }
   ELLC_STAMP(7);
   ELLC_BSTAMP(2);
-  float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + blockIdx.x) * ELLC_PART_STRIDE;
+  float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
   float sums[27];
   fca_acc_unpack(acc, sums);
   block_reduce_store<27>(sums, out);

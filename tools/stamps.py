@@ -48,6 +48,8 @@ print("  pixel phase per block: min %.2f med %.2f max %.2f" % (dur.min(), np.med
 bid = np.arange(nb)
 print("  by blockIdx.x (tile phase) :", np.round([dur[(bid % 32) == k].mean() for k in range(0, 32, 4)], 1))
 print("  by blockIdx.y (alignment)  :", np.round([dur[(bid // 32) == k].mean() for k in range(0, 32, 4)], 1))
+print("  by bid // 256 (dispatch round): pixel phase", np.round([dur[(bid // 256) == k].mean() for k in range(nb // 256)], 1),
+      "| pixels-done time", np.round([(t[(bid // 256) == k, 2] - t0).mean() for k in range(nb // 256)], 1))
 print("  by bid %% 8 (XCD group)     :", np.round([dur[(bid % 8) == k].mean() for k in range(8)], 1))
 order = np.argsort(dur)
 print("  slowest 12 blocks:", order[-12:], np.round(dur[order[-12:]], 1))
