@@ -46,6 +46,9 @@ struct ellc_ctx {
   int *kf_slot_h = nullptr, *fr_slot_h = nullptr, *uniq_slot_h = nullptr;   // pinned
   float *init_pose_d = nullptr, *init_pose_h = nullptr;
   ellc::AlignState *state_d = nullptr, *state_h = nullptr;
+  ellc::AlignResult* result_h = nullptr;            // pinned; written by the last kernel of a schedule through result_dev_alias
+  ellc::AlignResult* result_dev_alias = nullptr;
+  const int* stage_dev_alias = nullptr;             // device-side address of the pinned staging record (kf_slot_h ...)
   float* partials_d = nullptr;
   float* planes_d = nullptr;
   float *scratch_a = nullptr, *scratch_b = nullptr;   // W*H f32 each

@@ -73,4 +73,13 @@ struct AlignState {
   float Hinv[36];
 };
 
+// What ellc_align returns per alignment; lives in pinned host memory and is written by the last kernel of a schedule
+// (zero-copy), so fetching a result is a stream synchronisation, not a device-to-host copy.
+struct AlignResult {
+  float pose[6];
+  float weighted;
+  int iters[ELLC_MAX_LEVELS];
+  int pad;
+};
+
 }  // namespace ellc

@@ -205,11 +205,17 @@ static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const in
     if (!seen) c->uniq_slot_h[nu++] = kf_slots[b];
     for (int i = 0; i < 6; i++) c->init_pose_h[b * 6 + i] = init_pose ? init_pose[b * 6 + i] : 0.0f;
   }
-  // the pinned staging record may still be in flight from the previous call only if the caller skipped the fetch;
-  // ellc_align always fetches (synchronises), ellc_align_enqueue callers must fetch before enqueueing again
-  ELLC_HIP(c, hipMemcpyAsync(c->kf_slot_d, c->kf_slot_h, (size_t)9 * c->cfg.max_batch * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  // The pinned staging record is read by the first kernel of the schedule (enqueue_stage_in); it may still be in flight
+  // from the previous call only if the caller skipped the fetch: ellc_align always fetches (synchronises),
+  // ellc_align_enqueue callers must fetch before enqueueing again.
   *n_unique = nu;
   return ELLC_OK;
+}
+
+// device copy of the staged batch description, as a kernel reading the pinned record (part of the captured graph)
+static void enqueue_stage_in(ellc_ctx* c) {
+  const int n = 9 * c->cfg.max_batch;
+  hipLaunchKernelGGL(stage_in, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->kf_slot_d, c->stage_dev_alias, n);
 }
 
 // fills the age-balanced split of a launch (FusedArgs::age_rounds): on when the grid is 2..4 full rounds of one block per CU-slot
@@ -253,6 +259,7 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
   fa.stride_state = c->cfg.max_batch;
   fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
   fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);
+  fa.res = c->result_dev_alias;
   set_age_split(c, fa, B);
   for (int level = c->L - 1; level >= 0; level--) {
     fa.g = make_gn_args(c, level, B, save_weights ? 1 : 0, nullptr);
@@ -438,6 +445,14 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     TRY(dev_alloc(c, &sd, (size_t)9 * MB)); TRY(host_alloc(c, &shh, (size_t)9 * MB));
     c->kf_slot_d = sd; c->fr_slot_d = sd + MB; c->uniq_slot_d = sd + 2 * MB; c->init_pose_d = (float*)(sd + 3 * MB);
     c->kf_slot_h = shh; c->fr_slot_h = shh + MB; c->uniq_slot_h = shh + 2 * MB; c->init_pose_h = (float*)(shh + 3 * MB);
+    TRY(host_alloc(c, &c->result_h, MB));
+    void *da = nullptr, *db = nullptr;
+    if (hipHostGetDevicePointer(&da, shh, 0) != hipSuccess || hipHostGetDevicePointer(&db, c->result_h, 0) != hipSuccess) {
+      *out = c;
+      return fail(c, ELLC_ERR_HIP, "pinned host memory is not device-visible");
+    }
+    c->stage_dev_alias = (const int*)da;
+    c->result_dev_alias = (AlignResult*)db;
   }
   TRY(dev_alloc(c, &c->state_d, 2 * (size_t)MB)); TRY(host_alloc(c, &c->state_h, MB));          // two launch-parity buffers
   TRY(dev_alloc(c, &c->partials_d, 2 * (size_t)MB * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
@@ -752,10 +767,15 @@ ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, i
 // prep + init + the whole level/iteration schedule; captured once per (B, unique keyframes, mode, save_weights)
 // into a hipGraph and replayed afterwards (the launches are too short to be issued one by one from the host)
 static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int save_weights) {
+  enqueue_stage_in(c);
   ellc_status s = run_prep(c, nu, mode == ELLC_MODE_ICA ? 1 : 2);   // mask / count per level: updationOnPyrChange, ImageFunc.cpp:158
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
-  return enqueue_schedule(c, B, mode, save_weights);
+  s = enqueue_schedule(c, B, mode, save_weights);
+  if (s != ELLC_OK) return s;
+  if (!(mode == ELLC_MODE_FCA && c->use_fused))   // the fused schedule exports from its finish kernel
+    hipLaunchKernelGGL(gn_export_results, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->result_dev_alias, B);
+  return ELLC_OK;
 }
 
 ellc_status ellc_align_enqueue(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int save_weights) {
@@ -792,12 +812,11 @@ ellc_status ellc_align_enqueue(ellc_ctx* c, int B, const int* kf_slots, const in
 
 ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters, float* out_weighted) {
   if (!c || B < 1 || B > c->cfg.max_batch) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
-  ELLC_HIP(c, hipMemcpyAsync(c->state_h, c->state_d, sizeof(AlignState) * B, hipMemcpyDeviceToHost, c->stream));
-  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));   // the last kernel of the schedule wrote c->result_h (pinned, zero-copy)
   for (int b = 0; b < B; b++) {
-    if (out_pose) std::memcpy(out_pose + b * 6, c->state_h[b].pose, 24);
-    if (out_iters) for (int l = 0; l < c->L; l++) out_iters[b * c->L + l] = c->state_h[b].iters[l];
-    if (out_weighted) out_weighted[b] = c->state_h[b].weighted;
+    if (out_pose) std::memcpy(out_pose + b * 6, c->result_h[b].pose, 24);
+    if (out_iters) for (int l = 0; l < c->L; l++) out_iters[b * c->L + l] = c->result_h[b].iters[l];
+    if (out_weighted) out_weighted[b] = c->result_h[b].weighted;
   }
   return ELLC_OK;
 }
@@ -825,6 +844,7 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   int nu = 0;
   ellc_status s = stage_batch(c, 1, &kf_slot, &frame_slot, pose, &nu);
   if (s != ELLC_OK) return s;
+  enqueue_stage_in(c);
   s = run_prep(c, nu, mode == ELLC_MODE_ICA ? 1 : 2);
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_set_pose0, dim3(1), dim3(1), 0, c->stream, c->state_d, c->init_pose_d);
@@ -892,6 +912,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   int nu = 0;
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, nullptr, &nu);
   if (s != ELLC_OK) return s;
+  enqueue_stage_in(c);
   s = run_prep(c, nu, 2);
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
@@ -901,6 +922,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     // the production kernel of the FCA path: every launch first solves the previous launch's partial sums
     FusedArgs fa;
     fa.g = a;
+    fa.res = nullptr;
     set_age_split(c, fa, B);
     fa.seq = 0;
     fa.prev_level = level;

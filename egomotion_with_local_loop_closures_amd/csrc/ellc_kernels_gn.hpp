@@ -896,6 +896,7 @@ struct FusedArgs {
   // in linear order; if that were not so the result is unchanged (the split is static) and only the balance is lost.
   int age_rounds;
   int age_cum[5];
+  AlignResult* res;     // gn_fused_finish: host-visible result records (null: none)
 };
 
 template <bool DIVC>
@@ -1028,6 +1029,29 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
     dst->level_done = sh.level_done;
     dst->pending = 0;
   }
+  if (fa.res) {
+    AlignResult* r = fa.res + b;
+    if (t < 6) r->pose[t] = sh.newpose[t];
+    if (t < ELLC_MAX_LEVELS) r->iters[t] = it_copy[t] + ((pending && t == fa.prev_level) ? 1 : 0);
+    if (t == 0) r->weighted = sh.weighted;
+  }
+}
+
+// result export for schedules that do not end in gn_fused_finish
+__global__ void gn_export_results(const AlignState* state, AlignResult* res, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const AlignState& st = state[b];
+  AlignResult& r = res[b];
+  for (int i = 0; i < 6; i++) r.pose[i] = st.pose[i];
+  r.weighted = st.weighted;
+  for (int l = 0; l < ELLC_MAX_LEVELS; l++) r.iters[l] = st.iters[l];
+}
+
+// first kernel of a schedule: the staged batch description (slots, unique slots, initial poses) from pinned host memory
+__global__ void stage_in(int* __restrict__ dst, const int* __restrict__ src_host, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src_host[i];
 }
 
 // initial state from the caller's initial relative pose
