@@ -936,9 +936,27 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
       fa.seq++;
     };
     for (int i = 0; i < 3; i++) launch();
-    ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < reps; i++) launch();
-    ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
+    if (c->use_graph) {
+      // as in production: the launches are replayed from a captured graph (kernel arguments resident on the device)
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      ELLC_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      for (int i = 0; i < reps; i++) launch();
+      ELLC_HIP(c, hipStreamEndCapture(c->stream, &graph));
+      ELLC_HIP(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      hipGraphDestroy(graph);
+      hipError_t e = hipGraphLaunch(exec, c->stream);   // warm
+      if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
+      if (e == hipSuccess) e = hipGraphLaunch(exec, c->stream);
+      if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
+      if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
+      hipGraphExecDestroy(exec);
+      if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("profile graph: ") + hipGetErrorString(e));
+    } else {
+      ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
+      for (int i = 0; i < reps; i++) launch();
+      ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
+    }
   } else {
     for (int i = 0; i < 3; i++) launch_fca(c, grd, blk, a);
     ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));

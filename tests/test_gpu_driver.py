@@ -283,9 +283,6 @@ def test_loop_closure_candidates_and_batched_alignment(oracle, tmp_path):
     got = np.array([[float(c) for c in line.split(" ")] for line in txt.split("\n")]) if txt else np.zeros((0, 13))
     ref = np.array(oracle_track_lc(oracle, frames, (fx, fy, cx, cy), n_frames), np.float64)
     print("loop-closure matches (test, match):", [(int(a), int(b)) for a, b in got[:, :2]])
-    np.set_printoptions(precision=5, suppress=True, linewidth=250)
-    print("GOT\n", got)
-    print("REF\n", ref)
     assert got.shape[0] >= 3 and got.shape[1] == 13          # testId matchId pose6 rescale seeds matchValue rms angle
     assert got.shape == ref.shape
     assert np.array_equal(got[:, :2], ref[:, :2])            # same candidates in the same order
