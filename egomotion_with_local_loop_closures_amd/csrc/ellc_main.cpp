@@ -4,6 +4,10 @@
 //   poses_orig.txt   frameId kfId wx wy wz vx vy vz(poseWrtWorld) rescaleFactor seeds%        (main.cpp:373)
 //   matchframes.txt  frameId kfId pose6(poseWrtOrigin) rescaleFactor seeds% 0 0 0               (main.cpp:382)
 //   matchframes_globalopt.txt (LC mode)  testId matchId pose6 rescale seeds matchValue rms_error view_angle   (GlobalOptimize.cpp:580)
+//   <id>_{Depth,Depth_pyr0,DepthVarArr_pyr0}.txt (--save-mats DIR)  text checkpoints of the active keyframe at every
+//                    keyframe switch (ImageFunc.cpp:73-87, Frame.cpp:697-871); --replicate DIR reads them back (:58-66)
+// --init-poses FILE  FLAG_INITIALIZE_NONZERO_POSE (main.cpp:207-225): one line "frameNo wx wy wz vx vy vz" (world pose,
+//                    the so3poses7.txt of the rotation-averaging step) per tracked frame; supplies the initial rotation
 // Input is a header-less file of W*H u8 frames (decode / undistort / resize stay outside, Frame.cpp:45-75).
 // In LC mode finished keyframes go through the loop-closure ring (facade class globalOptimize); tracking-loss recovery
 // (findConnection) and the MATLAB rotation averaging are not part of this path.
@@ -17,13 +21,23 @@ using namespace ellc;
 
 int main(int argc, char** argv) {
   if (argc < 6) {
-    std::fprintf(stderr, "usage: %s frames.raw W H num_frames out_dir [LC] [levels]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s frames.raw W H num_frames out_dir [LC] [levels] [--save-mats DIR] [--replicate DIR] [--init-poses FILE]\n", argv[0]);
     return -1;
   }
   const std::string in = argv[1], outdir = argv[5];
   const int W = std::atoi(argv[2]), H = std::atoi(argv[3]), max_frame_counter = std::atoi(argv[4]);
-  const bool lc = argc > 6 && std::string(argv[6]) == "LC";
-  const int levels = argc > 7 ? std::atoi(argv[7]) : 4;
+  bool lc = false;
+  int levels = 4;
+  std::string save_mats, replicate, init_poses;
+  for (int i = 6; i < argc; i++) {
+    const std::string a = argv[i];
+    if (a == "LC") lc = true;
+    else if (a == "--save-mats" && i + 1 < argc) save_mats = argv[++i];
+    else if (a == "--replicate" && i + 1 < argc) replicate = argv[++i];
+    else if (a == "--init-poses" && i + 1 < argc) init_poses = argv[++i];
+    else if (!a.empty() && a[0] >= '0' && a[0] <= '9') levels = std::atoi(a.c_str());
+    else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return -1; }
+  }
   const int KEYFRAME_PROPAGATE_INTERVAL = 8;   // ExternVariable.h:39
   std::ifstream f(in, std::ios::binary);
   if (!f) { std::fprintf(stderr, "cannot open %s\n", in.c_str()); return -1; }
@@ -39,6 +53,14 @@ int main(int argc, char** argv) {
     }
     Runtime rt(cfg);
     rt.FLAG_DO_LOOP_CLOSURE = lc;
+    rt.KEYFRAME_PROPAGATE_INTERVAL = KEYFRAME_PROPAGATE_INTERVAL;
+    if (!save_mats.empty()) { rt.FLAG_SAVE_MATS = true; rt.SAVED_MATS_PATH = save_mats; }
+    if (!replicate.empty()) { rt.FLAG_REPLICATE_POSE_ESTIMATION = true; rt.SAVED_MATS_PATH = replicate; }
+    std::ifstream initialize_pose_file;
+    if (!init_poses.empty()) {
+      initialize_pose_file.open(init_poses.c_str());
+      if (!initialize_pose_file) { std::fprintf(stderr, "cannot open %s\n", init_poses.c_str()); return -1; }
+    }
     depthMap currentDepthMap(rt);
     std::unique_ptr<globalOptimize> globalOptimizeLoop;
     if (lc) globalOptimizeLoop.reset(new globalOptimize(rt, outdir + "/matchframes_globalopt.txt", 2, 3));
@@ -57,7 +79,13 @@ int main(int argc, char** argv) {
         continue;
       }
       frame* tminus1 = frameptr_vector[frameptr_vector.size() - 2].get();
-      GetImagePoseEstimate(activeKeyFrame, cur, frame_counter, &currentDepthMap, tminus1, initial_pose);   // main.cpp:330
+      const bool have_init = initialize_pose_file.is_open();
+      if (have_init) {   // main.cpp:207-211
+        int temp_frame_no;
+        initialize_pose_file >> temp_frame_no >> initial_pose[0] >> initial_pose[1] >> initial_pose[2] >> initial_pose[3] >> initial_pose[4] >> initial_pose[5];
+        if (!initialize_pose_file) { std::fprintf(stderr, "initial-pose file ends before frame %d\n", frame_counter); return -1; }
+      }
+      GetImagePoseEstimate(activeKeyFrame, cur, frame_counter, &currentDepthMap, tminus1, have_init ? initial_pose : nullptr);   // main.cpp:330
       const float seeds_num = currentDepthMap.calculate_no_of_Seeds();
       const int id = cur->frameId + rt.BATCH_START_ID - 1, kid = activeKeyFrame->frameId + rt.BATCH_START_ID - 1;
       pose_file_orig << id << " " << kid << " " << cur->poseWrtWorld[0] << " " << cur->poseWrtWorld[1] << " " << cur->poseWrtWorld[2] << " "

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -33,6 +34,12 @@ class Runtime {
   int numberOfInstances = 0;      // Frame.cpp:24
   bool FLAG_DO_LOOP_CLOSURE = false;           // "LC" mode: save / average the tracking weights (ExternVariable.h:203,211)
   int BATCH_START_ID = 1;
+  // text checkpoints of the active keyframe for the alternate Gauss-Newton <-> rotation-averaging loop (ToggleFlags.h:108-203)
+  bool FLAG_ALTERNATE_GN_RA = false;           // file ids become frameId + BATCH_START_ID - 1 (Frame.cpp:700-704)
+  bool FLAG_SAVE_MATS = false;                 // write <id>_{Depth,Depth_pyr0,DepthVarArr_pyr0}.txt at keyframe switches (ImageFunc.cpp:73-87)
+  bool FLAG_REPLICATE_POSE_ESTIMATION = false; // read them back instead (ImageFunc.cpp:58-66)
+  int KEYFRAME_PROPAGATE_INTERVAL = 8;         // ExternVariable.h:39
+  std::string SAVED_MATS_PATH = ".";
   explicit Runtime(const ellc_config& c) : cfg(c) {
     if (cfg.max_frames < 3) cfg.max_frames = 3;
     if (cfg.max_keyframes < 2) cfg.max_keyframes = 2;
@@ -84,6 +91,57 @@ class frame {
   }
   void calculatePoseWrtOrigin(frame* prev_image, const float* poseChange) { concatenateRelativePose(poseChange, prev_image->poseWrtOrigin, poseWrtOrigin); }
   void calculatePoseWrtWorld(frame* prev_image, const float* poseChange) { concatenateRelativePose(poseChange, prev_image->poseWrtWorld, poseWrtWorld); }
+  // ---- text checkpoints (Frame.cpp:697-871). `depth` and `depth_pyramid[0]` are one plane here (level 0 of the keyframe
+  // slot); the variance array is depthMap::depthvararrpyr0 (DepthPropagation.cpp:1637-1746), the slot's level-0 variance.
+  // Format: default ostream formatting of float (6 significant digits), one blank after every value; a Mat ends each
+  // row with '\n', an array is a single line.
+  std::string matFileName(const std::string& name, const std::string& dir) const {
+    const int id = rt->FLAG_ALTERNATE_GN_RA ? (frameId + rt->BATCH_START_ID - 1) : frameId;
+    std::stringstream ss;
+    ss << dir << "/" << id << "_" << name << ".txt";
+    return ss.str();
+  }
+  void level0(std::vector<float>& depth, std::vector<float>& var) const {
+    if (kf_slot < 0) throw std::runtime_error("text checkpoint: frame is not a keyframe");
+    depth.assign((size_t)width * height, 0.f);
+    var.assign((size_t)width * height, 0.f);
+    rt->check(ellc_keyframe_get_depth_level(rt->ctx, kf_slot, 0, depth.data(), var.data()), "ellc_keyframe_get_depth_level");
+  }
+  void saveMatAsText(const std::string& name, const std::string& save_mat_path) const {   // name: "Depth" | "Depth_pyr0"
+    std::vector<float> d, v;
+    level0(d, v);
+    std::ofstream f(matFileName(name, save_mat_path).c_str());
+    if (!f) throw std::runtime_error("saveMatAsText: cannot open " + matFileName(name, save_mat_path));
+    for (int y = 0; y < height; y++) {
+      for (int x = 0; x < width; x++) f << d[(size_t)y * width + x] << " ";
+      f << "\n";
+    }
+  }
+  void saveArrayAsText(const std::string& name, const std::string& save_arr_path, int pyr_level) const {   // "DepthVarArr_pyr0"
+    if (pyr_level != 0) throw std::runtime_error("saveArrayAsText: only level 0 is checkpointed (ImageFunc.cpp:84)");
+    std::vector<float> d, v;
+    level0(d, v);
+    std::ofstream f(matFileName(name, save_arr_path).c_str());
+    if (!f) throw std::runtime_error("saveArrayAsText: cannot open " + matFileName(name, save_arr_path));
+    for (size_t i = 0; i < v.size(); i++) f << v[i] << " ";
+  }
+  void makeMatFromText(const std::string& name, const std::string& read_txt_path) {
+    std::vector<float> d, v;
+    level0(d, v);
+    std::ifstream f(matFileName(name, read_txt_path).c_str());
+    if (!f) throw std::runtime_error("makeMatFromText: cannot open " + matFileName(name, read_txt_path));
+    for (size_t i = 0; i < d.size(); i++) f >> d[i];
+    rt->check(ellc_keyframe_set_depth_level(rt->ctx, kf_slot, 0, d.data(), v.data()), "ellc_keyframe_set_depth_level");
+  }
+  void makeArrayFromText(const std::string& name, const std::string& read_txt_path, int pyr_level) {
+    if (pyr_level != 0) throw std::runtime_error("makeArrayFromText: only level 0 is checkpointed (ImageFunc.cpp:65)");
+    std::vector<float> d, v;
+    level0(d, v);
+    std::ifstream f(matFileName(name, read_txt_path).c_str());
+    if (!f) throw std::runtime_error("makeArrayFromText: cannot open " + matFileName(name, read_txt_path));
+    for (size_t i = 0; i < v.size(); i++) f >> v[i];
+    rt->check(ellc_keyframe_set_depth_level(rt->ctx, kf_slot, 0, d.data(), v.data()), "ellc_keyframe_set_depth_level");
+  }
   void finaliseWeights() {   // Frame.cpp:678-695
     if (kf_slot < 0) throw std::runtime_error("finaliseWeights: frame is not a keyframe");
     rt->check(ellc_keyframe_finalise_weights(rt->ctx, kf_slot), "ellc_keyframe_finalise_weights");
@@ -200,12 +258,32 @@ class PixelWisePyramid {
 // iteration of every level are saved into the keyframe when the runtime is in LC mode and the call does not come
 // from loop closure (ImageFunc.cpp:280-288).
 inline std::vector<float> GetImagePoseEstimate(frame* prev_frame, frame* current_frame, int /*frame_num*/, depthMap* /*currDepthMap*/,
-                                               frame* tminus1_prev_frame, float* /*initial_pose_estimate*/, bool fromLoopClosure = false,
+                                               frame* tminus1_prev_frame, float* initial_pose_estimate, bool fromLoopClosure = false,
                                                bool /*homo*/ = false) {
   Runtime* rt = prev_frame->rt;
   if (prev_frame->kf_slot < 0) throw std::runtime_error("GetImagePoseEstimate: prev_frame is not a keyframe");
+  const bool kf_switch = !fromLoopClosure && (current_frame->frameId % rt->KEYFRAME_PROPAGATE_INTERVAL == 0);
+  if (rt->FLAG_REPLICATE_POSE_ESTIMATION && kf_switch) {   // :58-66 revive the keyframe's level-0 depth / variance
+    prev_frame->makeMatFromText("Depth", rt->SAVED_MATS_PATH);
+    prev_frame->makeMatFromText("Depth_pyr0", rt->SAVED_MATS_PATH);
+    prev_frame->makeArrayFromText("DepthVarArr_pyr0", rt->SAVED_MATS_PATH, 0);
+  }
+  if (rt->FLAG_SAVE_MATS && kf_switch && (rt->FLAG_ALTERNATE_GN_RA || current_frame->frameId < 50)) {   // :73-87
+    prev_frame->saveMatAsText("Depth", rt->SAVED_MATS_PATH);
+    prev_frame->saveMatAsText("Depth_pyr0", rt->SAVED_MATS_PATH);
+    prev_frame->saveArrayAsText("DepthVarArr_pyr0", rt->SAVED_MATS_PATH, 0);
+  }
   float pose[6];
   prev_frame->concatenateOriginPose(tminus1_prev_frame->poseWrtWorld, prev_frame->poseWrtWorld, pose);   // :106
+  if (initial_pose_estimate) {
+    // FLAG_INITIALIZE_NONZERO_POSE (:109-131): the given world pose (so3poses7.txt) is converted to a pose w.r.t. the
+    // keyframe and supplies the rotation; the translation stays the one predicted from frame t-1
+    float from_file[6];
+    prev_frame->concatenateOriginPose(initial_pose_estimate, prev_frame->poseWrtWorld, from_file);
+    pose[0] = from_file[0];
+    pose[1] = from_file[1];
+    pose[2] = from_file[2];
+  }
   const int save = (rt->FLAG_DO_LOOP_CLOSURE && !fromLoopClosure) ? 1 : 0;
   float out[6];
   rt->check(ellc_align(rt->ctx, 1, &prev_frame->kf_slot, &current_frame->slot, pose, fromLoopClosure ? ELLC_MODE_ICA : ELLC_MODE_FCA, save, out,

@@ -25,7 +25,12 @@ def make_sequence():
     return frames, (fx, fy, cx, cy)
 
 
-def oracle_track(O, frames, intr, lc):
+def oracle_keyframe_state_before(O, frames, intr, n_stop):
+    """Level-0 depth / variance of the active keyframe as they stand right before frame n_stop is tracked."""
+    return oracle_track(O, frames, intr, False, stop_before=n_stop)
+
+
+def oracle_track(O, frames, intr, lc, stop_before=None):
     libc = ctypes.CDLL("libc.so.6")
     libc.srand(1)   # the driver process starts with the default seed (unseeded rand(), DepthPropagation.cpp:160)
     fx, fy, cx, cy = intr
@@ -50,6 +55,8 @@ def oracle_track(O, frames, intr, lc):
     dm.update_depth_image()
     active, prev, lines = f1, f1, []
     for n in range(2, N + 1):
+        if stop_before == n:
+            return dm.pyr_level(0)
         cur = O.Frame(cfg, frames[n - 1], n)
         init = O.concat_origin(prev.pose()[1], active.pose()[1])
         O.align(active, cur, dm.depth_pyr(), init_pose=init, save_weights=lc)
@@ -292,3 +299,56 @@ def test_loop_closure_candidates_and_batched_alignment(oracle, tmp_path):
     assert np.array_equal(got[:, 9], ref[:, 9])              # int(seeds %)
     assert np.allclose(got[:, 10], ref[:, 10], rtol=1e-4, atol=1e-7) and np.all(got[:, 10] <= 0.1)
     assert np.allclose(got[:, 11:], ref[:, 11:], rtol=1e-3, atol=1e-5) and np.all(got[:, 12] <= 10.0)
+
+
+def test_text_checkpoints_and_initial_pose_file(oracle, tmp_path):
+    """<id>_{Depth,Depth_pyr0,DepthVarArr_pyr0}.txt written at the keyframe switch (ImageFunc.cpp:73-87,
+    Frame.cpp:697-871: default ostream float formatting, Mat rows end in newline, arrays are one line), read back with
+    --replicate, and the so3poses7-style initial-pose file (main.cpp:207-211) feeding the initial rotation."""
+    frames, intr = make_sequence()
+    raw = tmp_path / "frames.raw"
+    raw.write_bytes(b"".join(np.ascontiguousarray(f, np.uint8).tobytes() for f in frames))
+    exe = os.path.join(ROOT, "egomotion_with_local_loop_closures_amd", "csrc", "ellc_main")
+    mats = tmp_path / "Saved_mats"; mats.mkdir()
+    out1 = tmp_path / "run1"; out1.mkdir()
+    r = subprocess.run([exe, str(raw), str(W), str(H), str(N), str(out1), "--save-mats", str(mats)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()
+    # frame 8 is the first keyframe switch: the active keyframe (frame 1) is dumped before frame 8 is tracked
+    names = sorted(p.name for p in mats.iterdir())
+    assert names == ["1_Depth.txt", "1_DepthVarArr_pyr0.txt", "1_Depth_pyr0.txt"]
+    txt = (mats / "1_Depth.txt").read_text()
+    rows = txt.split("\n")
+    assert len(rows) == H + 1 and rows[-1] == "" and all(r_.endswith(" ") for r_ in rows[:-1])
+    depth = np.array([[float(v) for v in r_.split()] for r_ in rows[:-1]], np.float32)
+    assert depth.shape == (H, W)
+    assert (mats / "1_Depth_pyr0.txt").read_text() == txt
+    var_txt = (mats / "1_DepthVarArr_pyr0.txt").read_text()
+    assert "\n" not in var_txt and var_txt.endswith(" ")
+    var = np.array([float(v) for v in var_txt.split()], np.float32).reshape(H, W)
+    # the same state from the oracle-driven loop (keyframe 1 after 6 observe/regularise cycles = before frame 8 is tracked)
+    ref_depth, ref_var = oracle_keyframe_state_before(oracle, frames, intr, 8)
+    ref_depth = np.where(ref_depth > 0, ref_depth, 0).astype(np.float32)   # array form holds -1, the Mat 0 (Q20)
+    assert ((depth > 0) == (ref_depth > 0)).all() and ((var > 0) == (ref_var > 0)).all()
+    assert np.allclose(depth, ref_depth, rtol=2e-5, atol=1e-6)     # 6 significant digits in the file
+    assert np.allclose(var, ref_var, rtol=2e-5, atol=1e-9)
+    # --replicate reads them back at the switch: same trajectory (the files hold the state to 6 digits)
+    out2 = tmp_path / "run2"; out2.mkdir()
+    r = subprocess.run([exe, str(raw), str(W), str(H), str(N), str(out2), "--replicate", str(mats)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()
+    p1 = np.loadtxt(out1 / "poses_orig.txt"); p2 = np.loadtxt(out2 / "poses_orig.txt")
+    assert np.abs(p1[:, 2:8] - p2[:, 2:8]).max() < 5e-5
+    # initial-pose file: feeding the tracked world poses back as initial rotations converges to the same trajectory
+    init = tmp_path / "so3poses7.txt"
+    init.write_text("".join("%d %s\n" % (int(row[0]), " ".join("%.7g" % v for v in row[2:8])) for row in p1))
+    out3 = tmp_path / "run3"; out3.mkdir()
+    r = subprocess.run([exe, str(raw), str(W), str(H), str(N), str(out3), "--init-poses", str(init)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()
+    p3 = np.loadtxt(out3 / "poses_orig.txt")
+    assert np.abs(p1[:, 2:8] - p3[:, 2:8]).max() < 2e-4
+    short = tmp_path / "short.txt"; short.write_text("2 0 0 0 0 0 0\n")
+    r = subprocess.run([exe, str(raw), str(W), str(H), str(N), str(out3), "--init-poses", str(short)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode != 0 and b"initial-pose file ends" in r.stdout
