@@ -37,6 +37,15 @@ struct __attribute__((aligned(16))) FcaRec {
   double invZ;
 };
 
+// One valid keyframe pixel as the constant-weight (ICA) pixel pass reads it: 48 bytes. Everything here is independent
+// of the pose and of the current frame: back-projection, keyframe intensity, the saved weight and the template-gradient
+// steepest-descent row (PixelWisePyramid.cpp:561-680), so the compaction writes it once per ellc_align.
+struct __attribute__((aligned(16))) IcaRec {
+  float X, Y, Z, Ikf;
+  float W, sd0, sd1, sd2;
+  float sd3, sd4, sd5, pad;
+};
+
 // One keyframe (template) slot at one level: dense planes + the compacted list of pixels with depth > 0
 // (frame::calculateNonZeroDepthPts, Frame.cpp:295-301) in raster order.
 struct KfLevelDev {
@@ -48,6 +57,9 @@ struct KfLevelDev {
   float* cZ;                  // compact depth (ICA)
   float* cI;                  // compact keyframe intensity as f32 (ICA)
   FcaRec* crec;               // compact FCA records (same order as cxy)
+  IcaRec* irec;               // compact ICA records (same order as cxy)
+  float* hpart;               // ICA: per-tile partial sums of H = sum W J^T J, 32 floats per tile (21 used)
+  float* hinv;                // ICA: inverse of the level's H (36 floats), one per keyframe slot and level
   float* cW;                  // compact saved weight (ICA)
   float* wlast;               // compact weight of the most recent iteration (for saveWeights)
   float* sd;                  // ICA steepest-descent planes, 6 x cap (plane k at sd + k*cap)

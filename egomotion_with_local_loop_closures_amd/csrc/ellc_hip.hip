@@ -3,6 +3,7 @@
 #include "ellc_context.hpp"
 #include "ellc_kernels_image.hpp"
 #include "ellc_kernels_gn.hpp"
+#include "ellc_kernels_prep.hpp"
 #include <cstring>
 #include <cmath>
 #include <algorithm>
@@ -122,6 +123,21 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
 }
 
 ellc_status run_prep(ellc_ctx* c, int n_unique, int need) { return run_prep_levels(c, n_unique, need, 0, c->L - 1, c->stream); }
+
+// ICA: H^-1 of every (unique keyframe, level) from the per-tile sums the compaction (need bit 2) left behind
+static void enqueue_ica_hinv(ellc_ctx* c, int n_unique) {
+  PrepArgs a;
+  a.need = 4;
+  a.geom = c->geom_d;
+  a.kf_tab = c->kf_tab_d;
+  a.slots = c->uniq_slot_d;
+  a.levels = c->L;
+  a.max_kf = c->cfg.max_keyframes;
+  for (int l = 0; l <= ELLC_MAX_LEVELS; l++) a.tile_begin[l] = c->tile_begin[std::min(l, c->L)];
+  a.tile0 = 0;
+  a.level0 = 0;
+  hipLaunchKernelGGL(ica_hinv, dim3(c->L, n_unique), dim3(ELLC_SOLVE_THREADS), 0, c->stream, a);
+}
 
 static bool slot_ok(int s, int n) { return s >= 0 && s < n; }
 
@@ -260,6 +276,7 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
   fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
   fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);
   fa.res = c->result_dev_alias;
+  fa.ica = 0;
   set_age_split(c, fa, B);
   for (int level = c->L - 1; level >= 0; level--) {
     fa.g = make_gn_args(c, level, B, save_weights ? 1 : 0, nullptr);
@@ -279,9 +296,40 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
   return ELLC_OK;
 }
 
+// Constant-weight (ICA) schedule in the fused form: H^-1 per (keyframe, level) comes from the compaction (ica_hinv), every
+// launch solves the previous launch's b sums in its prologue: one launch per iteration plus the final solve.
+static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
+  FusedArgs fa;
+  fa.seq = 0;
+  fa.prev_level = -1;
+  fa.prev_nblk = 0;
+  fa.early_exit = c->cfg.early_exit;
+  fa.stride_state = c->cfg.max_batch;
+  fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+  fa.res = c->result_dev_alias;
+  fa.ica = 1;
+  fa.age_rounds = 0;
+  for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
+  fa.g = make_gn_args(c, 0, B, 0, nullptr);
+  for (int level = c->L - 1; level >= 0; level--) {
+    fa.g = make_gn_args(c, level, B, 0, nullptr);
+    const dim3 grd(fa.g.nblk, B), blk(ELLC_GN_THREADS);
+    for (int it = 0; it < c->cfg.max_iter[level]; it++) {
+      hipLaunchKernelGGL(gn_ica_fused, grd, blk, 0, c->stream, fa);
+      fa.prev_level = level;
+      fa.prev_nblk = fa.g.nblk;
+      fa.seq++;
+    }
+  }
+  hipLaunchKernelGGL(gn_fused_finish, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
+  ELLC_HIP(c, hipGetLastError());
+  return ELLC_OK;
+}
+
 // the level / iteration schedule of GetImagePoseEstimate (ImageFunc.cpp:150-292) as a launch sequence
 static ellc_status enqueue_schedule(ellc_ctx* c, int B, int mode, int save_weights) {
   if (mode == ELLC_MODE_FCA && c->use_fused) return enqueue_schedule_fused(c, B, save_weights);
+  if (mode == ELLC_MODE_ICA && c->use_fused) return enqueue_schedule_ica_fused(c, B);
   for (int level = c->L - 1; level >= 0; level--) {
     GnArgs a = make_gn_args(c, level, B, (save_weights && mode == ELLC_MODE_FCA) ? 1 : 0, nullptr);
     const dim3 grd(a.nblk, B), blk(ELLC_GN_THREADS);
@@ -423,6 +471,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       TRY(dev_alloc(c, &k.cxy, n)); TRY(dev_alloc(c, &k.cZ, n)); TRY(dev_alloc(c, &k.cI, n));
       TRY(dev_alloc(c, &k.crec, n)); TRY(dev_alloc(c, &k.cW, n)); TRY(dev_alloc(c, &k.wlast, n)); TRY(dev_alloc(c, &k.sd, 6 * n));
       TRY(dev_alloc(c, &k.count, 4)); TRY(dev_alloc(c, &k.tile_count, tiles + 1));
+      TRY(dev_alloc(c, &k.irec, n)); TRY(dev_alloc(c, &k.hpart, (size_t)(tiles + 1) * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
     }
     for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni));
   }
@@ -768,12 +817,15 @@ ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, i
 // into a hipGraph and replayed afterwards (the launches are too short to be issued one by one from the host)
 static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int save_weights) {
   enqueue_stage_in(c);
-  ellc_status s = run_prep(c, nu, mode == ELLC_MODE_ICA ? 1 : 2);   // mask / count per level: updationOnPyrChange, ImageFunc.cpp:158
+  // mask / count per level (updationOnPyrChange, ImageFunc.cpp:158) and the pose-independent per-pixel records
+  const int need = mode == ELLC_MODE_ICA ? (c->use_fused ? 4 : 1) : 2;
+  ellc_status s = run_prep(c, nu, need);
   if (s != ELLC_OK) return s;
+  if (need == 4) enqueue_ica_hinv(c, nu);
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
   s = enqueue_schedule(c, B, mode, save_weights);
   if (s != ELLC_OK) return s;
-  if (!(mode == ELLC_MODE_FCA && c->use_fused))   // the fused schedule exports from its finish kernel
+  if (!c->use_fused)   // the fused schedules export from their finish kernel
     hipLaunchKernelGGL(gn_export_results, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->result_dev_alias, B);
   return ELLC_OK;
 }
@@ -923,6 +975,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     FusedArgs fa;
     fa.g = a;
     fa.res = nullptr;
+    fa.ica = 0;
     set_age_split(c, fa, B);
     fa.seq = 0;
     fa.prev_level = level;

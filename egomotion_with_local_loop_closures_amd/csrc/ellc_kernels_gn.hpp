@@ -839,12 +839,12 @@ __device__ __forceinline__ void solve_finish(SolveShared& sh, int mode, int leve
 }
 
 __device__ __forceinline__ void solve_step(SolveShared& sh, double group_sum, int mode, int level, int early_exit,
-                                           const AlignState& src, AlignState* dst) {
+                                           const AlignState& src, AlignState* dst, const float* hinv_src = nullptr) {
   const int t = threadIdx.x;
   const int comp = t & 31, grp = t >> 5;
   sh.part[grp][comp] = group_sum;
   ELLC_STAMP(1);
-  if (mode == 2 && t < 36) sh.Hinv[t] = src.Hinv[t];   // ICA iterate: the level's precomputed inverse
+  if (mode == 2 && t < 36) sh.Hinv[t] = hinv_src ? hinv_src[t] : src.Hinv[t];   // ICA iterate: the level's precomputed inverse
   __syncthreads();
   if (t < 27) {
     double s = sh.part[0][t];
@@ -897,6 +897,7 @@ struct FusedArgs {
   int age_rounds;
   int age_cum[5];
   AlignResult* res;     // gn_fused_finish: host-visible result records (null: none)
+  int ica;              // 1: constant-weight schedule (gn_ica_fused): the pending sums are b only, H^-1 comes from the keyframe slot
 };
 
 template <bool DIVC>
@@ -1001,6 +1002,94 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(FusedArgs fa)
   ELLC_BSTAMP(3);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused schedule of the constant-weight path (PixelWisePyramid.cpp:687-913 + :941-974): the same launch structure as
+// gn_fca_fused — launch n first solves the sums launch n-1 left behind, then runs its own pixel pass — with the light
+// ICA pixel pass: warp, one u8 tap, residual, b += SD (r w). H^-1 of the level was computed once per keyframe by the
+// compaction (IcaRec, ica_hinv), so the pending sums are b only and no launch is spent on the precompute.
+struct IcaIn { float X, Y, Z, Ikf, W, sd[6]; };
+__device__ __forceinline__ IcaIn ica_load(const IcaRec* irec, unsigned i) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const ELLC_GLOBAL f32x4* r = (const ELLC_GLOBAL f32x4*)((const ELLC_GLOBAL char*)irec + i * (unsigned)sizeof(IcaRec));
+  const f32x4 a = r[0], b = r[1], c = r[2];
+  IcaIn in;
+  in.X = a.x; in.Y = a.y; in.Z = a.z; in.Ikf = a.w;
+  in.W = b.x; in.sd[0] = b.y; in.sd[1] = b.z; in.sd[2] = b.w;
+  in.sd[3] = c.x; in.sd[4] = c.y; in.sd[5] = c.z;
+  return in;
+}
+__device__ __forceinline__ void ica_accumulate_pixel(float (&acc)[6], const IcaIn& in, const LevelGeom& g, g_u8 cur, const float* S) {
+  const Warp w = warp_point<true>(in.X, in.Y, in.Z, g, S);
+  const Taps t = tap_point<false>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
+  const bool oob = (t.I == -1.0f);
+  const float residual = oob ? 0.0f : (t.I - in.Ikf);
+  const float rw = residual * in.W;
+#pragma unroll
+  for (int r = 0; r < 6; r++) acc[r] = __builtin_fmaf(in.sd[r], rw, acc[r]);
+}
+
+__global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(FusedArgs fa) {
+  const GnArgs& a = fa.g;
+  const int b = blockIdx.y, sub = blockIdx.x;
+  const AlignState& src = a.state[(size_t)(fa.seq & 1) * fa.stride_state + b];
+  AlignState* dst = a.state + (size_t)((fa.seq + 1) & 1) * fa.stride_state + b;
+  __shared__ SolveShared sh;
+  const int t = threadIdx.x;
+  const bool writer = (sub == 0);
+  const LevelGeom g = a.geom[a.level];
+  const int slot = a.kf_slot[b];
+  const KfLevelDev K = a.kf_tab[a.level * a.max_kf + slot];   // by value: uniform, lives in SGPRs
+  const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
+  const int pending = src.pending;
+  const int V = *as_global(K.count);
+  const double group_sum = partial_group_sum(
+      a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, fa.prev_nblk);
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = sub * chunk;
+  const int end = min(V, begin + chunk);
+  g_u8 cur = as_global(F.img);
+  IcaIn first;
+  first.X = 0.0f; first.Y = 0.0f; first.Z = 1.0f; first.Ikf = 0.0f; first.W = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 6; r++) first.sd[r] = 0.0f;
+  if (begin + t < end) first = ica_load(K.irec, (unsigned)(begin + t));
+  if (pending) {
+    const float* hinv = a.kf_tab[fa.prev_level * a.max_kf + slot].hinv;
+    solve_step(sh, group_sum, 2, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr, hinv);
+  } else {
+    if (t < 6) sh.newpose[t] = src.pose[t];
+    if (t < 12) sh.newS[t] = src.S[t];
+    if (t == 0) { sh.weighted = src.weighted; sh.level_done = src.level_done; }
+    __syncthreads();
+  }
+  const int level_done = sh.level_done;
+  const bool skip = (level_done == a.level);
+  if (writer) {
+    if (t < 6) dst->pose[t] = sh.newpose[t];
+    if (t < 12) dst->S[t] = sh.newS[t];
+    if (t < ELLC_MAX_LEVELS) dst->iters[t] = src.iters[t] + ((pending && t == fa.prev_level) ? 1 : 0);
+    if (t == 0) {
+      dst->weighted = sh.weighted;
+      dst->level_done = level_done;
+      dst->pending = skip ? 0 : 1;
+    }
+  }
+  if (skip) return;
+  float S[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
+  float acc[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) acc[i] = 0.0f;
+  int i = begin + t;
+  if (i < end) {
+    ica_accumulate_pixel(acc, first, g, cur, S);
+    for (i += ELLC_GN_THREADS; i < end; i += ELLC_GN_THREADS) ica_accumulate_pixel(acc, ica_load(K.irec, (unsigned)i), g, cur, S);
+  }
+  float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
+  block_reduce_store<6>(acc, out + 21);   // the b slots of the partial record; the H slots are not read by a mode-2 solve
+}
+
 // Final solve of a fused schedule: consumes the last pending partials; result always lands in state buffer 0.
 __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs fa) {
   const GnArgs& a = fa.g;
@@ -1014,7 +1103,8 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
   if (t < ELLC_MAX_LEVELS) it_copy[t] = src.iters[t];
   if (pending) {
     const float* prev = a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
-    solve_step(sh, partial_group_sum(prev, fa.prev_nblk), 0, fa.prev_level, fa.early_exit, src, dst);
+    const float* hinv = fa.ica ? a.kf_tab[fa.prev_level * a.max_kf + a.kf_slot[b]].hinv : nullptr;
+    solve_step(sh, partial_group_sum(prev, fa.prev_nblk), fa.ica ? 2 : 0, fa.prev_level, fa.early_exit, src, dst, hinv);
   } else {
     if (t < 6) sh.newpose[t] = src.pose[t];
     if (t < 12) sh.newS[t] = src.S[t];

@@ -1,0 +1,255 @@
+// Compaction of a keyframe's valid pixels into the per-level lists the Gauss-Newton kernels iterate (reference: the
+// mask / count of frame::calculateNonZeroDepthPts + updationOnPyrChange, Frame.cpp:295-327), plus everything about a
+// pixel that does not depend on the pose: the FCA records (FcaRec) and, for the constant-weight path, the ICA records
+// with the template-gradient Jacobian and the per-tile sums of H (PixelWisePyramid.cpp:561-680, :938).
+#pragma once
+#include "ellc_kernels_image.hpp"
+#include "ellc_kernels_gn.hpp"
+
+namespace ellc {
+
+// ---------------------------------------------------------------------------------------------------
+// Compaction of the keyframe's valid pixels (mask = depth_pyramid[l] > 0, Frame.cpp:295-301), raster
+// order preserved. Three launches cover all levels of all listed keyframe slots.
+#define ELLC_TILE 2048          // pixels per block: 256 threads x 8 consecutive pixels (two float4 loads)
+
+struct PrepArgs {
+  const LevelGeom* geom;
+  const KfLevelDev* kf_tab;
+  const int* slots;            // unique keyframe slots
+  int levels, max_kf;
+  int need;                    // bit 0: planes Z / I / saved weight (unfused ICA kernels); bit 1: FcaRec records (FCA);
+                               // bit 2: IcaRec records + per-tile sums of H (fused ICA schedule)
+  int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
+  int tile0, level0;           // this launch covers tiles tile0 + blockIdx.x (count / scatter), levels level0 + blockIdx.x (scan)
+};
+
+__device__ __forceinline__ int prep_level_of(const PrepArgs& a, int tile, int& local) {
+  int l = 0;
+  while (l + 1 < a.levels && tile >= a.tile_begin[l + 1]) l++;
+  local = tile - a.tile_begin[l];
+  return l;
+}
+
+// eight consecutive depths of this thread (zeros past the end of the plane)
+__device__ __forceinline__ void prep_load8(const float* __restrict__ depth, int i0, int n, float (&d)[8]) {
+  if (i0 + 7 < n) {
+    const float4 a = *reinterpret_cast<const float4*>(depth + i0);
+    const float4 b = *reinterpret_cast<const float4*>(depth + i0 + 4);
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) d[j] = (i0 + j < n) ? depth[i0 + j] : 0.0f;
+  }
+}
+
+// inclusive scan inside a wave; returns the wave total through `total`
+__device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  total = __shfl(v, 63, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
+  int local;
+  const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
+  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const int n = a.geom[level].n;
+  const int i0 = local * ELLC_TILE + threadIdx.x * 8;
+  float d[8];
+  prep_load8(K.depth, i0, n, d);
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) c += (d[j] > 0.0f) ? 1 : 0;
+  __shared__ int ws[4];
+  int tot;
+  wave_inclusive_scan(c, tot);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) K.tile_count[local] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// one block per (level, slot): exclusive scan of the tile counts in place, total -> count
+__global__ __launch_bounds__(256) void prep_scan(PrepArgs a) {
+  const int level = a.level0 + (int)blockIdx.x;
+  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const int T = a.tile_begin[level + 1] - a.tile_begin[level];
+  const int per = (T + 255) / 256;
+  const int t0 = threadIdx.x * per;
+  int s = 0;
+  for (int i = t0; i < min(T, t0 + per); i++) s += K.tile_count[i];
+  __shared__ int ws[4];
+  int tot;
+  const int inc = wave_inclusive_scan(s, tot);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  int wbase = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wbase += ws[w];
+  int run = wbase + inc - s;   // exclusive prefix of this thread's span
+  for (int i = t0; i < min(T, t0 + per); i++) {
+    const int c = K.tile_count[i];
+    K.tile_count[i] = run;
+    run += c;
+  }
+  if (threadIdx.x == 255) *K.count = wbase + inc;
+}
+
+// Scatter, two phases per tile of ELLC_TILE pixels. Phase 1: thread t owns pixels base + j*256 + t (j = 0..7), so the
+// depth loads of a wave are contiguous; ballot ranks give every valid pixel its raster-order rank inside the tile
+// (order = (j, wave, lane)), and (pixel index, depth) are parked in LDS at that rank. Phase 2 runs densely over the
+// parked entries — every lane has a valid pixel — computes the record (three IEEE divisions) and stores it; consecutive
+// lanes write consecutive records. Without the LDS step the divisions would run for every wave that holds at least one
+// valid pixel, i.e. about four times as often on a semi-dense map.
+__global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
+  int local;
+  const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
+  const KfLevelDev K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const LevelGeom& g = a.geom[level];
+  const int n = g.n;
+  const int base = local * ELLC_TILE + (int)threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int cnt[33];   // [j][wave] exclusive offsets, [32] = tile total
+  __shared__ uint32_t s_idx[ELLC_TILE];
+  __shared__ float s_Z[ELLC_TILE];
+  float d[8];
+  unsigned long long m[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int i = base + j * 256;
+    d[j] = (i < n) ? gptr(K.depth)[(unsigned)i] : 0.0f;
+    m[j] = __ballot(d[j] > 0.0f);
+    if (lane == 0) cnt[j * 4 + wave] = __popcll(m[j]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {   // exclusive scan of the 32 (j, wave) counts
+    int v = (lane < 32) ? cnt[lane] : 0, tot;
+    const int inc = wave_inclusive_scan(v, tot);
+    if (lane < 32) cnt[lane] = inc - v;
+    if (lane == 0) cnt[32] = tot;
+  }
+  __syncthreads();
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if (d[j] > 0.0f) {
+      const int r = cnt[j * 4 + wave] + __popcll(m[j] & lt);
+      s_idx[r] = (uint32_t)(base + j * 256);
+      s_Z[r] = d[j];
+    }
+  }
+  __syncthreads();
+  const int nvalid = cnt[32];
+  const unsigned tile_off = (unsigned)K.tile_count[local];
+  const float inv_cols = 1.0f / (float)g.cols;
+  const ELLC_GLOBAL float* var = gptr(K.var);
+  const ELLC_GLOBAL float* wgt = gptr(K.weight);
+  const ELLC_GLOBAL uint8_t* img = gptr(K.img);
+  ELLC_GLOBAL uint32_t* cxy = gptr_rw(K.cxy);
+  ELLC_GLOBAL float* cZ = gptr_rw(K.cZ);
+  ELLC_GLOBAL float* cI = gptr_rw(K.cI);
+  ELLC_GLOBAL float* cW = gptr_rw(K.cW);
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  ELLC_GLOBAL u32x4* crec = (ELLC_GLOBAL u32x4*)K.crec;
+  const int cols = g.cols, sw = g.sw, need = a.need;
+  const float fx = g.fx, fy = g.fy, cx = g.cx, cy = g.cy;
+  float hacc[27];
+#pragma unroll
+  for (int q = 0; q < 27; q++) hacc[q] = 0.0f;
+  for (int r = (int)threadIdx.x; r < nvalid; r += 256) {
+    const int i = (int)s_idx[r];
+    const float Z = s_Z[r];
+    const unsigned pos = tile_off + (unsigned)r;
+    int y = (int)(((float)i + 0.5f) * inv_cols);   // i < 2^24: exact conversion; corrected below
+    if (y * cols > i) y--;
+    if ((y + 1) * cols <= i) y++;
+    const int x = i - y * cols;
+    const uint32_t xy = ((uint32_t)y << 16) | (uint32_t)x;
+    const float Ikf = (float)img[(unsigned)(y * sw + x)];
+    cxy[pos] = xy;
+    if (need & 1) {   // ICA reads planes
+      cZ[pos] = Z;
+      cI[pos] = Ikf;
+      cW[pos] = wgt[(unsigned)i];
+    }
+    if (need & 4) {   // ICA record: template-gradient Jacobian at the integer pixel (PixelWisePyramid.cpp:561-680)
+      // frame::calculateGradient of the keyframe level image at (y,x)  (Frame.cpp:185-285)
+      const int xm = max(x - 1, 0), xp = min(x + 1, cols - 1), ym = max(y - 1, 0), yp = min(y + 1, g.rows - 1);
+      const float sx = (x == 0 || x == cols - 1) ? 1.0f : 0.5f;
+      const float sy = (y == 0 || y == g.rows - 1) ? 1.0f : 0.5f;
+      const float gradx = sx * ((float)img[(unsigned)(y * sw + xp)] - (float)img[(unsigned)(y * sw + xm)]);
+      const float grady = sy * ((float)img[(unsigned)(yp * sw + x)] - (float)img[(unsigned)(ym * sw + x)]);
+      float J[6];
+      jacobian_row<false>(gradx, grady, x, y, 1.0 / (double)Z, g, J);
+      const float wsave = wgt[(unsigned)i];
+      const float X = (((float)x - cx) * Z) / fx;
+      const float Y = (((float)y - cy) * Z) / fy;
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      ELLC_GLOBAL f32x4* ir = (ELLC_GLOBAL f32x4*)K.irec + 3u * pos;
+      ir[0] = (f32x4){X, Y, Z, Ikf};
+      ir[1] = (f32x4){wsave, J[0], J[1], J[2]};
+      ir[2] = (f32x4){J[3], J[4], J[5], 0.0f};
+      int q = 0;
+#pragma unroll
+      for (int rr = 0; rr < 6; rr++) {
+        const float wJ = J[rr] * wsave;   // weightedSteepestDescent (:664-669); H = WSD * SD^T (:938)
+#pragma unroll
+        for (int cc = rr; cc < 6; cc++) { hacc[q] = __builtin_fmaf(wJ, J[cc], hacc[q]); q++; }
+      }
+    }
+    if (need & 2) {   // FCA reads one 32-byte record per pixel (FcaRec), stored as two 16-byte words
+      const float X = (((float)x - cx) * Z) / fx;
+      const float Y = (((float)y - cy) * Z) / fy;
+      const double invZ = 1.0 / (double)Z;
+      const unsigned long long zb = __builtin_bit_cast(unsigned long long, invZ);
+      const u32x4 lo = {xy, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, Ikf)};
+      const u32x4 hi = {__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), (uint32_t)zb, (uint32_t)(zb >> 32)};
+      crec[2u * pos] = lo;
+      crec[2u * pos + 1u] = hi;
+    }
+  }
+  if (need & 4) block_reduce_store<27>(hacc, K.hpart + (size_t)local * ELLC_PART_STRIDE);   // block-uniform condition
+}
+
+// ICA: H of one (keyframe slot, level) from the per-tile sums (fixed-order f64 combine), then cv::Mat::inv(DECOMP_LU)
+// (PixelWisePyramid.cpp:938-939). One block per (level, unique slot); the level's inverse is kept with the slot.
+__global__ __launch_bounds__(ELLC_SOLVE_THREADS) void ica_hinv(PrepArgs a) {
+  const int level = a.level0 + (int)blockIdx.x;
+  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const int T = a.tile_begin[level + 1] - a.tile_begin[level];
+  __shared__ SolveShared sh;
+  const int t = threadIdx.x;
+  sh.part[t >> 5][t & 31] = partial_group_sum(K.hpart, T);
+  __syncthreads();
+  if (t < 27) {
+    double s = sh.part[0][t];
+#pragma unroll
+    for (int g = 1; g < ELLC_SOLVE_THREADS / 32; g++) s += sh.part[g][t];
+    sh.sums[t] = s;
+  }
+  __syncthreads();
+  if (t < 64) {
+    float Hm[36];
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = r; c < 6; c++) {
+        const float v = (float)sh.sums[q++];
+        Hm[r * 6 + c] = v;
+        Hm[c * 6 + r] = v;
+      }
+    float x[6];
+    lu_inverse6_lanes(Hm, t < 6 ? t : 0, x);
+    if (t < 6) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) K.hinv[i * 6 + t] = x[i];
+    }
+  }
+}
+
+}  // namespace ellc
