@@ -61,6 +61,8 @@ struct ellc_ctx {
   bool age_balance = true;      // age-balanced split of full-round grids (FusedArgs::age_rounds); ELLC_NO_AGE_BALANCE=1 disables
   double age_weight[5][4] = {{1, 1, 1, 1}, {1, 1, 1, 1}, {1.15, 0.85, 1, 1}, {1.2, 1.0, 0.8, 1}, {1.35, 1.15, 0.9, 0.6}};   // [rounds][round], ELLC_AGE_W (r01 sweep at 640x480, batch 32)
   double age_min_px_per_thread = 5.0;   // ELLC_AGE_MIN_PX
+  bool pipe = true;             // software-pipelined record loads in the fused FCA kernel (ELLC_PIPE=0 disables; r01: -10 % per launch at
+                                // 1280x960 dense where the records stream from HBM, neutral at 640x480 semi-dense)
   bool use_fused = true;        // FCA: solve folded into the next accumulate launch (ELLC_NO_FUSE=1 disables)
   int nblk_override[ELLC_MAX_LEVELS] = {0};
   int resident_blocks = 1280;   // 256-thread blocks of the accumulate kernel resident on the device at once

@@ -257,8 +257,13 @@ static void set_age_split(ellc_ctx* c, FusedArgs& fa, int B) {
 }
 
 static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
-  if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true>), grd, blk, 0, st, fa);
-  else hipLaunchKernelGGL((gn_fca_fused<false>), grd, blk, 0, st, fa);
+  if (c->pipe) {
+    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, true>), grd, blk, 0, st, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, true>), grd, blk, 0, st, fa);
+  } else {
+    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, false>), grd, blk, 0, st, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, false>), grd, blk, 0, st, fa);
+  }
 }
 
 // FCA schedule: the solve of iteration n is folded into the prologue of launch n+1 (gn_fca_fused): one launch per
@@ -541,6 +546,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   {
     if (const char* nf = getenv("ELLC_NO_FUSE")) c->use_fused = !(nf[0] == '1');
     if (const char* ab = getenv("ELLC_NO_AGE_BALANCE")) c->age_balance = !(ab[0] == '1');
+    if (const char* pp = getenv("ELLC_PIPE")) c->pipe = (pp[0] == '1');
     if (const char* am = getenv("ELLC_AGE_MIN_PX")) c->age_min_px_per_thread = atof(am);
     if (const char* aw = getenv("ELLC_AGE_W")) {   // "R:w0,w1,..": weights for grids of R rounds
       int R = 0, pos = 0;

@@ -900,7 +900,7 @@ struct FusedArgs {
   int ica;              // 1: constant-weight schedule (gn_ica_fused): the pending sums are b only, H^-1 comes from the keyframe slot
 };
 
-template <bool DIVC>
+template <bool DIVC, bool PIPE>
 __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(FusedArgs fa) {   // 4 waves per SIMD: at most 128 VGPRs
   const GnArgs& a = fa.g;
   int b = blockIdx.y, sub = blockIdx.x, age = 0, per_age = a.nblk;
@@ -987,9 +987,27 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(FusedArgs fa)
   if (i < end) {
     const FcaPix p = fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre);
     fca_accumulate_pixel(acc, p);
-    for (i += stride; i < end; i += stride) {
-      const FcaPix q = fca_pixel<false, DIVC>(a, K, g, cur, S, (unsigned)i);
-      fca_accumulate_pixel(acc, q);
+    if (PIPE) {
+      // software pipeline: the record of pixel i + 256 is requested before pixel i is processed (index clamped, so the
+      // load is unconditional), which takes the record's memory latency off the per-pixel dependency chain
+      i += stride;
+      if (i < end) {
+        FcaIn nxt = fca_load(K, (unsigned)i);
+        for (;;) {
+          const FcaIn in = nxt;
+          const int inext = i + stride;
+          nxt = fca_load(K, (unsigned)min(inext, end - 1));
+          const FcaPix q = fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, in);
+          fca_accumulate_pixel(acc, q);
+          i = inext;
+          if (i >= end) break;
+        }
+      }
+    } else {
+      for (i += stride; i < end; i += stride) {
+        const FcaPix q = fca_pixel<false, DIVC>(a, K, g, cur, S, (unsigned)i);
+        fca_accumulate_pixel(acc, q);
+      }
     }
   }
   ELLC_STAMP(7);
