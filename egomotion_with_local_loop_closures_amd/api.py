@@ -222,6 +222,23 @@ class Context:
         self._ck(self._l.ellc_depth_seeds(self.h, C.byref(f)), "ellc_depth_seeds")
         return f.value
 
+    # ---- frame ingest (Frame.cpp:45-75 after the decode)
+    def ingest_configure(self, orig_w, orig_h, fx, fy, cx, cy, dist5=None, do_undistort=True):
+        d = np.ascontiguousarray(dist5 if dist5 is not None else np.zeros(5), np.float32)
+        kn = np.zeros(4, np.float32)
+        self._ck(self._l.ellc_ingest_configure(self.h, int(orig_w), int(orig_h), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                                               _p(d), int(bool(do_undistort)), _p(kn)), "ellc_ingest_configure")
+        return kn
+
+    def frame_ingest_bgr(self, slot, bgr, probes=False):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        W, H = self.cfg.width, self.cfg.height
+        if probes:
+            g = np.zeros((H, W), np.uint8); u = np.zeros((H, W, 4), np.uint8)
+            self._ck(self._l.ellc_frame_ingest_bgr(self.h, slot, _p(bgr), _p(g), _p(u)), "ellc_frame_ingest_bgr")
+            return g, u
+        self._ck(self._l.ellc_frame_ingest_bgr(self.h, slot, _p(bgr), None, None), "ellc_frame_ingest_bgr")
+
     # ---- loop-closure support
     def histogram(self, is_kf, slot):
         h = np.zeros(256, np.float32)

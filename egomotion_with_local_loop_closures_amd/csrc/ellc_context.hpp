@@ -66,6 +66,10 @@ struct ellc_ctx {
   bool use_fused = true;        // FCA: solve folded into the next accumulate launch (ELLC_NO_FUSE=1 disables)
   int nblk_override[ELLC_MAX_LEVELS] = {0};
   int resident_blocks = 1280;   // 256-thread blocks of the accumulate kernel resident on the device at once
+  // frame ingest (ellc_ingest_configure): fixed-point undistortion map of the 2x2 source pixels of every output pixel
+  void* ingest_map = nullptr;
+  uint8_t* ingest_bgr = nullptr;    // staging for one full-size BGR frame
+  int ingest_w = 0, ingest_h = 0;
   // depth map (one per context)
   ellc::DepthSoA dm_cur, dm_oth;
   int dm_kf_slot = -1;

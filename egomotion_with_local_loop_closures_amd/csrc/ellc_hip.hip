@@ -585,6 +585,8 @@ ellc_status ellc_ctx_destroy(ellc_ctx* c) {
   for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
   for (void* p : c->allocs) hipFree(p);
   for (void* p : c->host_allocs) hipHostFree(p);
+  if (c->ingest_map) hipFree(c->ingest_map);
+  if (c->ingest_bgr) hipFree(c->ingest_bgr);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   hipStreamDestroy(c->stream);
@@ -1125,3 +1127,4 @@ ellc_status ellc_profile_calibrate_read(ellc_ctx* c, size_t bytes, int reps, flo
 }  // extern "C"
 
 #include "ellc_depth_impl.hpp"
+#include "ellc_ingest_impl.hpp"

@@ -8,7 +8,10 @@
 //                    keyframe switch (ImageFunc.cpp:73-87, Frame.cpp:697-871); --replicate DIR reads them back (:58-66)
 // --init-poses FILE  FLAG_INITIALIZE_NONZERO_POSE (main.cpp:207-225): one line "frameNo wx wy wz vx vy vz" (world pose,
 //                    the so3poses7.txt of the rotation-averaging step) per tracked frame; supplies the initial rotation
-// Input is a header-less file of W*H u8 frames (decode / undistort / resize stay outside, Frame.cpp:45-75).
+// --bgr              the input holds decoded full-size BGR frames (4W x 4H x 3 bytes each): grey conversion, undistortion with
+//                    the reference's hard-coded camera (ExternVariable.h:53-62, scaled to the input size) and the 1/4
+//                    resize run on the device (Frame.cpp:45-75); --no-undistort = FLAG_DO_UNDISTORTION off
+// Input is otherwise a header-less file of W*H u8 grey frames (the decode itself always stays outside).
 // In LC mode finished keyframes go through the loop-closure ring (facade class globalOptimize); tracking-loss recovery
 // (findConnection) and the MATLAB rotation averaging are not part of this path.
 #include "../../include/ellc_facade.hpp"
@@ -21,7 +24,7 @@ using namespace ellc;
 
 int main(int argc, char** argv) {
   if (argc < 6) {
-    std::fprintf(stderr, "usage: %s frames.raw W H num_frames out_dir [LC] [levels] [--save-mats DIR] [--replicate DIR] [--init-poses FILE]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s frames.raw W H num_frames out_dir [LC] [levels] [--save-mats DIR] [--replicate DIR] [--init-poses FILE] [--bgr] [--no-undistort]\n", argv[0]);
     return -1;
   }
   const std::string in = argv[1], outdir = argv[5];
@@ -29,12 +32,15 @@ int main(int argc, char** argv) {
   bool lc = false;
   int levels = 4;
   std::string save_mats, replicate, init_poses;
+  bool bgr = false, undistort = true;
   for (int i = 6; i < argc; i++) {
     const std::string a = argv[i];
     if (a == "LC") lc = true;
     else if (a == "--save-mats" && i + 1 < argc) save_mats = argv[++i];
     else if (a == "--replicate" && i + 1 < argc) replicate = argv[++i];
     else if (a == "--init-poses" && i + 1 < argc) init_poses = argv[++i];
+    else if (a == "--bgr") bgr = true;
+    else if (a == "--no-undistort") undistort = false;
     else if (!a.empty() && a[0] >= '0' && a[0] <= '9') levels = std::atoi(a.c_str());
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return -1; }
   }
@@ -66,11 +72,16 @@ int main(int argc, char** argv) {
     if (lc) globalOptimizeLoop.reset(new globalOptimize(rt, outdir + "/matchframes_globalopt.txt", 2, 3));
     std::vector<std::unique_ptr<frame>> frameptr_vector;
     frame* activeKeyFrame = nullptr;
-    std::vector<uint8_t> buf((size_t)W * H);
+    std::vector<uint8_t> buf(bgr ? (size_t)W * H * 48 : (size_t)W * H);
+    if (bgr) {   // the reference's camera is given for 1920 x 1080 (ExternVariable.h:53-62): scale with the input width
+      const float sc = (4.0f * W) / 1920.0f;
+      const float dist[5] = {-0.288283f, 0.146546f, 0.003800f, -0.001690f, -0.132134f};
+      rt.configureIngest(4 * W, 4 * H, 1642.405612f * sc, 1636.148027f * sc, 2.0f * W, 2.0f * H, dist, undistort);
+    }
     float initial_pose[6] = {0, 0, 0, 0, 0, 0};
     for (int frame_counter = 1; frame_counter <= max_frame_counter; frame_counter++) {
       if (!f.read((char*)buf.data(), buf.size())) { std::fprintf(stderr, "short read at frame %d\n", frame_counter); return -1; }
-      frameptr_vector.emplace_back(new frame(rt, buf.data()));
+      frameptr_vector.emplace_back(new frame(rt, buf.data(), bgr));
       frame* cur = frameptr_vector.back().get();
       if (frame_counter == 1) {   // main.cpp:228-236
         activeKeyFrame = cur;

@@ -72,6 +72,16 @@ void* ellc_stream(ellc_ctx* ctx);                   /* the context's hipStream_t
  *      (Frame.cpp:78-124, 170-182, 185-285, 618-674) -------------------------------------------------- */
 /* Upload a W x H u8 image into a current-frame slot; builds the u8 pyramid on device (cv::pyrDown). */
 ellc_status ellc_frame_upload(ellc_ctx* ctx, int slot, const uint8_t* image);
+/* Frame ingest as a device pre-pass (frame::frame(VideoCapture), Frame.cpp:45-75, after the decode): BGR 8-bit frame of
+ * orig_w x orig_h (= 4 x the context size: DIM_FACTOR, ExternVariable.h:41-43) -> cvtColor BGR2GRAY -> undistort with the
+ * 5-coefficient model {k1,k2,p1,p2,k3} and the alpha=0 getOptimalNewCameraMatrix (FLAG_DO_UNDISTORTION, :58-72) -> resize by
+ * 1/4 (INTER_LINEAR) -> level 0 of frame slot `slot` + pyramid. fx..cy are the FULL-size intrinsics the reference builds
+ * cam_K from (ORIG_FX*INTRINSIC_FACTOR ..., :61). configure builds the fixed-point map once; new_camera4 (optional)
+ * receives {fx,fy,cx,cy} of the new camera matrix. The probes (optional, tests) receive the grey value of source pixel
+ * (4x+1, 4y+1) [W*H] and the four undistorted source pixels of every output pixel [W*H*4]. */
+ellc_status ellc_ingest_configure(ellc_ctx* ctx, int orig_w, int orig_h, float fx, float fy, float cx, float cy,
+                                  const float* dist5, int do_undistort, float* new_camera4);
+ellc_status ellc_frame_ingest_bgr(ellc_ctx* ctx, int slot, const uint8_t* bgr, uint8_t* gray_probe, uint8_t* undistorted_probe);
 /* Same for a keyframe slot (the reference-side / template frame of an alignment). Also builds
  * maxAbsGradient (level 0). */
 ellc_status ellc_keyframe_upload(ellc_ctx* ctx, int slot, const uint8_t* image);

@@ -52,6 +52,13 @@ class Runtime {
   void check(int st, const char* what) const {
     if (st != ELLC_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(st) + "): " + (ctx ? ellc_last_error(ctx) : "no context"));
   }
+  // Frame.cpp:45-75 after the decode: BGR -> grey -> undistort -> 1/4 resize as a device pre-pass. fx..cy are the full-size
+  // intrinsics of cam_K (util::ORIG_FX*INTRINSIC_FACTOR ...), dist5 = util::distortion_parameters.
+  bool ingest_configured = false;
+  void configureIngest(int orig_w, int orig_h, float fx, float fy, float cx, float cy, const float* dist5, bool FLAG_DO_UNDISTORTION = true) {
+    check(ellc_ingest_configure(ctx, orig_w, orig_h, fx, fy, cx, cy, dist5, FLAG_DO_UNDISTORTION ? 1 : 0, nullptr), "ellc_ingest_configure");
+    ingest_configured = true;
+  }
   int frame_ring = 3;             // tracking uses frame slots [0, frame_ring): current, t-1 and one spare
   int next_frame_slot() { int s = frame_cursor_; frame_cursor_ = (frame_cursor_ + 1) % frame_ring; return s; }
   int other_keyframe_slot(int current) const { return (current + 1) % 2; }   // keyframe slots 0 / 1: active and incoming
@@ -74,14 +81,16 @@ class frame {
   int numWeightsAdded[ELLC_MAX_LEVELS];
 
   // Frame.cpp:34-124 from "width=image.cols" on: ids, zero poses, pyramids (constructImagePyramids on device)
-  frame(Runtime& r, const uint8_t* gray) : rt(&r) {
+  // `pixels` is the grey W x H image, or — with from_bgr — the decoded full-size BGR frame (Runtime::configureIngest first)
+  frame(Runtime& r, const uint8_t* pixels, bool from_bgr = false) : rt(&r) {
     frameId = ++r.numberOfInstances;
     width = r.cfg.width;
     height = r.cfg.height;
     for (int i = 0; i < 6; i++) poseWrtOrigin[i] = poseWrtWorld[i] = 0.0f;
     for (int i = 0; i < ELLC_MAX_LEVELS; i++) numWeightsAdded[i] = 0;
     slot = r.next_frame_slot();
-    r.check(ellc_frame_upload(r.ctx, slot, gray), "ellc_frame_upload");
+    if (from_bgr) r.check(ellc_frame_ingest_bgr(r.ctx, slot, pixels, nullptr, nullptr), "ellc_frame_ingest_bgr");
+    else r.check(ellc_frame_upload(r.ctx, slot, pixels), "ellc_frame_upload");
   }
   void concatenateRelativePose(const float* src_1wrt2, const float* src_2wrt3, float* dest_1wrt3) const {
     ellc_concatenate_relative_pose(src_1wrt2, src_2wrt3, dest_1wrt3);
