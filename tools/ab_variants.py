@@ -17,7 +17,7 @@ _so = ctypes.CDLL(_lib.SO_PATH)
 _lib.ABI_SYMBOLS = [s for s in _lib.ABI_SYMBOLS if hasattr(_so, s)]
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--variants", nargs="+", default=["ELLC_GN_ILP=1", "ELLC_GN_ILP=2"])
+ap.add_argument("--variants", nargs="+", default=["X=1"], help="environment settings, one context each: \"A=1;B=2\"")
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--level", type=int, default=0)

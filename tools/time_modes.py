@@ -1,7 +1,12 @@
-import sys, os, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import numpy as np
-from egomotion_with_local_loop_closures_amd import api, synth
+#!/usr/bin/env python3
+"""Device time of one full ellc_align (HIP events, graph replay) for both schedules — FCA (tracking) and ICA (loop-closure
+batch) — at B = 32 and B = 1, 640x480 semi-dense."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+from egomotion_with_local_loop_closures_amd import api, synth  # noqa: E402
 W, H, L, B = 640, 480, 4, 32
 fx, fy, cx, cy = synth.default_intrinsics(W, H)
 pairs = [synth.make_pair(W, H, seed=0x5EED + i) for i in range(4)]
