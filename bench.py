@@ -81,21 +81,31 @@ def main():
     from egomotion_with_local_loop_closures_amd import sharding
     dev = coll_dev if world > 1 else None
 
-    def step():
-        pose, iters, wgt = ctx.align(slots, slots, mode=mode)
-        if world > 1:   # the single RCCL gather of the resulting se(3) poses (8 floats per alignment)
-            table = sharding.gather_results(sharding.pack_results(pose, iters, wgt), B * world, device=dev)
-            assert table.shape == (B * world, sharding.RECORD)
+    gatherer = sharding.ResultGatherer(B * world, device=dev)
+
+    def run(nsteps):
+        """nsteps steps; step = one batch through ellc_align + (N>1) the one gather of its poses. The batches are software-
+        pipelined: batch s+1 is enqueued on the library's stream before batch s is fetched, so the device runs back to
+        back and the exchange of batch s (torch's stream) and the host work overlap batch s+1's kernels. Every batch is
+        fetched and gathered; all enqueued work is complete before the clock stops."""
+        pose = iters = None
+        ctx.align_enqueue(slots, slots, mode=mode)
+        for s in range(nsteps):
+            if s + 1 < nsteps:   # two batches in flight: the device runs batch s+1 right behind batch s
+                ctx.align_enqueue(slots, slots, mode=mode)
+            pose, iters, wgt = ctx.align_fetch(B)
+            if world > 1:   # the single RCCL gather of the resulting se(3) poses (8 floats per alignment)
+                table = gatherer.gather(sharding.pack_results(pose, iters, wgt))
+                assert table.shape == (B * world, sharding.RECORD)
         return pose, iters
 
-    for _ in range(a.warmup):
-        pose, iters = step()
+    if a.warmup > 0:
+        pose, iters = run(a.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        pose, iters = step()
+    pose, iters = run(a.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -115,7 +125,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C2/C3: %d independent keyframe<->frame alignments per GPU, %dx%d, %d-level pyramid, %s Gauss-Newton, "
                                "fixed schedule %s (early exit off), per-call mask compaction included%s"
-                               % (B, W, H, L, a.mode.upper(), sched, ", RCCL all_gather of poses per step" if world > 1 else ""),
+                               % (B, W, H, L, a.mode.upper(), sched, ", RCCL all_gather of poses per step (overlapped with the next batch)" if world > 1 else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "gn_iterations_per_alignment": iters_per_alignment,
                    "alignments_per_s": world * B * a.steps / dt, "pixels": "dense" if a.dense else "semi-dense (maxAbsGradient>=5)"},
     }

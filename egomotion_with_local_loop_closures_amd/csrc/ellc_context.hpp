@@ -49,6 +49,19 @@ struct ellc_ctx {
   ellc::AlignResult* result_h = nullptr;            // pinned; written by the last kernel of a schedule through result_dev_alias
   ellc::AlignResult* result_dev_alias = nullptr;
   const int* stage_dev_alias = nullptr;             // device-side address of the pinned staging record (kf_slot_h ...)
+  // Two batches may be in flight (ellc_align_enqueue twice before ellc_align_fetch): the pinned staging and result records
+  // exist twice; the members above point at the set of the batch being enqueued. Device state is shared — the stream
+  // runs the batches in order.
+  struct BatchSet {
+    int* stage_h = nullptr;                         // 9 * max_batch ints: kf slots, frame slots, unique slots, initial poses
+    const int* stage_dev_alias = nullptr;
+    ellc::AlignResult* result_h = nullptr;
+    ellc::AlignResult* result_dev_alias = nullptr;
+    hipEvent_t done = nullptr;
+  } batch_set[2];
+  int next_set = 0;
+  int inflight[2] = {0, 0};
+  int n_inflight = 0;
   float* partials_d = nullptr;
   float* planes_d = nullptr;
   float *scratch_a = nullptr, *scratch_b = nullptr;   // W*H f32 each

@@ -204,6 +204,19 @@ static void launch_solve(ellc_ctx* c, int level, int B, int nblk, int mode, int 
   hipLaunchKernelGGL(gn_solve, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, s);
 }
 
+// points the staging / result members at batch set p
+static void select_batch_set(ellc_ctx* c, int p) {
+  const int MB = c->cfg.max_batch;
+  ellc_ctx::BatchSet& bs = c->batch_set[p];
+  c->kf_slot_h = bs.stage_h;
+  c->fr_slot_h = bs.stage_h + MB;
+  c->uniq_slot_h = bs.stage_h + 2 * MB;
+  c->init_pose_h = (float*)(bs.stage_h + 3 * MB);
+  c->stage_dev_alias = bs.stage_dev_alias;
+  c->result_h = bs.result_h;
+  c->result_dev_alias = bs.result_dev_alias;
+}
+
 // stage slots / initial poses on the device and list the unique keyframe slots
 static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int* n_unique) {
   if (B < 1 || B > c->cfg.max_batch) return fail(c, ELLC_ERR_BAD_ARG, "B out of range");
@@ -496,17 +509,22 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   const int MB = cfg->max_batch;
   {  // one staging record per call: [kf_slot MB][fr_slot MB][unique MB][init_pose 6*MB], moved with a single copy
     int *sd = nullptr, *shh = nullptr;
-    TRY(dev_alloc(c, &sd, (size_t)9 * MB)); TRY(host_alloc(c, &shh, (size_t)9 * MB));
+    TRY(dev_alloc(c, &sd, (size_t)9 * MB));
     c->kf_slot_d = sd; c->fr_slot_d = sd + MB; c->uniq_slot_d = sd + 2 * MB; c->init_pose_d = (float*)(sd + 3 * MB);
-    c->kf_slot_h = shh; c->fr_slot_h = shh + MB; c->uniq_slot_h = shh + 2 * MB; c->init_pose_h = (float*)(shh + 3 * MB);
-    TRY(host_alloc(c, &c->result_h, MB));
-    void *da = nullptr, *db = nullptr;
-    if (hipHostGetDevicePointer(&da, shh, 0) != hipSuccess || hipHostGetDevicePointer(&db, c->result_h, 0) != hipSuccess) {
-      *out = c;
-      return fail(c, ELLC_ERR_HIP, "pinned host memory is not device-visible");
+    for (int p = 0; p < 2; p++) {
+      ellc_ctx::BatchSet& bs = c->batch_set[p];
+      TRY(host_alloc(c, &bs.stage_h, (size_t)9 * MB));
+      TRY(host_alloc(c, &bs.result_h, MB));
+      void *da = nullptr, *db = nullptr;
+      if (hipHostGetDevicePointer(&da, bs.stage_h, 0) != hipSuccess || hipHostGetDevicePointer(&db, bs.result_h, 0) != hipSuccess ||
+          hipEventCreateWithFlags(&bs.done, hipEventDisableTiming) != hipSuccess) {
+        *out = c;
+        return fail(c, ELLC_ERR_HIP, "pinned host memory is not device-visible");
+      }
+      bs.stage_dev_alias = (const int*)da;
+      bs.result_dev_alias = (AlignResult*)db;
     }
-    c->stage_dev_alias = (const int*)da;
-    c->result_dev_alias = (AlignResult*)db;
+    select_batch_set(c, 0);
   }
   TRY(dev_alloc(c, &c->state_d, 2 * (size_t)MB)); TRY(host_alloc(c, &c->state_h, MB));          // two launch-parity buffers
   TRY(dev_alloc(c, &c->partials_d, 2 * (size_t)MB * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
@@ -587,6 +605,7 @@ ellc_status ellc_ctx_destroy(ellc_ctx* c) {
   for (void* p : c->host_allocs) hipHostFree(p);
   if (c->ingest_map) hipFree(c->ingest_map);
   if (c->ingest_bgr) hipFree(c->ingest_bgr);
+  for (int p = 0; p < 2; p++) if (c->batch_set[p].done) hipEventDestroy(c->batch_set[p].done);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   hipStreamDestroy(c->stream);
@@ -838,14 +857,19 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
   return ELLC_OK;
 }
 
-ellc_status ellc_align_enqueue(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int save_weights) {
+// track: the batch joins the in-flight queue ellc_align_fetch drains (at most two); untracked use is for the timing hook
+static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode,
+                                      int save_weights, bool track) {
   if (!c) return ELLC_ERR_BAD_ARG;
   if (mode != ELLC_MODE_FCA && mode != ELLC_MODE_ICA) return fail(c, ELLC_ERR_BAD_ARG, "unknown mode");
+  if (c->n_inflight >= 2) return fail(c, ELLC_ERR_NOT_READY, "two batches are in flight: call ellc_align_fetch first");
+  const int set = c->next_set;
+  select_batch_set(c, set);
   int nu = 0;
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
   if (s != ELLC_OK) return s;
   if (c->use_graph) {
-    const auto key = std::make_tuple(B, nu, mode, save_weights ? 1 : 0);
+    const auto key = std::make_tuple(B, nu, mode, (save_weights ? 1 : 0) | (set << 1));
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
       hipGraph_t graph = nullptr;
@@ -867,22 +891,36 @@ ellc_status ellc_align_enqueue(ellc_ctx* c, int B, const int* kf_slots, const in
   if (save_weights && mode == ELLC_MODE_FCA)
     for (int b = 0; b < B; b++)
       for (int l = 0; l < c->L; l++) c->kf_num_weights[kf_slots[b]][l]++;
+  if (track) {
+    ELLC_HIP(c, hipEventRecord(c->batch_set[set].done, c->stream));
+    c->inflight[c->n_inflight++] = set;
+    c->next_set = set ^ 1;
+  }
   return ELLC_OK;
+}
+
+ellc_status ellc_align_enqueue(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int save_weights) {
+  return align_enqueue_impl(c, B, kf_slots, frame_slots, init_pose, mode, save_weights, true);
 }
 
 ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters, float* out_weighted) {
   if (!c || B < 1 || B > c->cfg.max_batch) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
-  ELLC_HIP(c, hipStreamSynchronize(c->stream));   // the last kernel of the schedule wrote c->result_h (pinned, zero-copy)
+  if (c->n_inflight < 1) return fail(c, ELLC_ERR_NOT_READY, "ellc_align_fetch: no batch in flight");
+  const ellc_ctx::BatchSet& bs = c->batch_set[c->inflight[0]];   // the oldest batch
+  ELLC_HIP(c, hipEventSynchronize(bs.done));   // its last kernel wrote bs.result_h (pinned, zero-copy)
+  c->inflight[0] = c->inflight[1];
+  c->n_inflight--;
   for (int b = 0; b < B; b++) {
-    if (out_pose) std::memcpy(out_pose + b * 6, c->result_h[b].pose, 24);
-    if (out_iters) for (int l = 0; l < c->L; l++) out_iters[b * c->L + l] = c->result_h[b].iters[l];
-    if (out_weighted) out_weighted[b] = c->result_h[b].weighted;
+    if (out_pose) std::memcpy(out_pose + b * 6, bs.result_h[b].pose, 24);
+    if (out_iters) for (int l = 0; l < c->L; l++) out_iters[b * c->L + l] = bs.result_h[b].iters[l];
+    if (out_weighted) out_weighted[b] = bs.result_h[b].weighted;
   }
   return ELLC_OK;
 }
 
 ellc_status ellc_align(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int save_weights,
                        float* out_pose, int* out_iters, float* out_weighted) {
+  if (c && c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_align: fetch the enqueued batches first");
   ellc_status s = ellc_align_enqueue(c, B, kf_slots, frame_slots, init_pose, mode, save_weights);
   if (s != ELLC_OK) return s;
   return ellc_align_fetch(c, B, out_pose, out_iters, out_weighted);
@@ -901,6 +939,7 @@ __global__ void gn_set_pose0(AlignState* state, const float* pose) {
 ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level, int mode, int iter, const float* pose, float* H36, float* b6,
                             float* delta6, float* new_pose6, float* weighted, float* planes) {
   if (!c || !pose || level < 0 || level >= c->L) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_gn_iterate: fetch the enqueued batches first");
   int nu = 0;
   ellc_status s = stage_batch(c, 1, &kf_slot, &frame_slot, pose, &nu);
   if (s != ELLC_OK) return s;
@@ -969,6 +1008,7 @@ void ellc_se3_log(const float* T16, float* pose6) {
 ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, int level, int reps, float* avg_ms,
                                    double* algorithmic_bytes, long long* valid_pixels) {
   if (!c || level < 0 || level >= c->L || reps < 1) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_profile_gn_kernel: fetch the enqueued batches first");
   int nu = 0;
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, nullptr, &nu);
   if (s != ELLC_OK) return s;
@@ -1041,12 +1081,13 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
 
 ellc_status ellc_profile_align(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int reps, float* avg_ms) {
   if (!c || reps < 1) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
-  ellc_status s = ellc_align_enqueue(c, B, kf_slots, frame_slots, init_pose, mode, 0);
+  if (c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_profile_align: fetch the enqueued batches first");
+  ellc_status s = align_enqueue_impl(c, B, kf_slots, frame_slots, init_pose, mode, 0, false);
   if (s != ELLC_OK) return s;
   ELLC_HIP(c, hipStreamSynchronize(c->stream));
   ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < reps; i++) {
-    s = ellc_align_enqueue(c, B, kf_slots, frame_slots, init_pose, mode, 0);
+    s = align_enqueue_impl(c, B, kf_slots, frame_slots, init_pose, mode, 0, false);
     if (s != ELLC_OK) return s;
   }
   ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));

@@ -51,6 +51,53 @@ def gather_results(local, total, device=None, group=None):
     return table.cpu().numpy()
 
 
+class ResultGatherer:
+    """The per-batch gather with everything allocated once: a (per, 8) input block and a (world*per, 8) output table on
+    the collective's device (GPU for nccl = RCCL, CPU for gloo) and a pinned host copy of the table. gather() costs one
+    small H2D, one all_gather_into_tensor and one D2H; it runs on torch's stream, so a caller that has already enqueued
+    its next batch on the library's stream (ellc_align_enqueue) overlaps the exchange with that batch's kernels."""
+
+    def __init__(self, total, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.total, self.group = total, group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if not self.active:
+            return
+        self.world = dist.get_world_size(group)
+        self.per = (total + self.world - 1) // self.world
+        self.on_gpu = device is not None and torch.device(device).type == "cuda"
+        dev = torch.device(device) if device is not None else torch.device("cpu")
+        self.host_in = torch.zeros((self.per, RECORD), dtype=torch.float32)
+        self.host_out = torch.zeros((self.world * self.per, RECORD), dtype=torch.float32)
+        if self.on_gpu:
+            self.host_in = self.host_in.pin_memory()
+            self.host_out = self.host_out.pin_memory()
+        self.dev_in = torch.zeros((self.per, RECORD), dtype=torch.float32, device=dev)
+        self.dev_out = torch.zeros((self.world * self.per, RECORD), dtype=torch.float32, device=dev)
+        self.into_tensor = dist.get_backend(group) != "gloo"   # gloo: list form
+
+    def gather(self, local):
+        """local: (n_local, 8) table of this rank; returns the (total, 8) table in global order (numpy view of a reused buffer)."""
+        if not self.active:
+            return np.asarray(local, np.float32).reshape(-1, RECORD)[: self.total]
+        import torch
+        import torch.distributed as dist
+        loc = np.asarray(local, np.float32).reshape(-1, RECORD)
+        self.host_in.zero_()
+        self.host_in[: loc.shape[0]] = torch.from_numpy(loc)
+        self.dev_in.copy_(self.host_in, non_blocking=True)
+        if self.into_tensor:
+            dist.all_gather_into_tensor(self.dev_out, self.dev_in, group=self.group)
+        else:
+            parts = list(self.dev_out.view(self.world, self.per, RECORD).unbind(0))
+            dist.all_gather(parts, self.dev_in, group=self.group)
+        self.host_out.copy_(self.dev_out, non_blocking=True)
+        if self.on_gpu:
+            torch.cuda.current_stream().synchronize()
+        return self.host_out.numpy()[: self.total]
+
+
 def align_sharded(ctx, total, local_kf_slots, local_frame_slots, init_pose=None, mode=0, device=None, group=None):
     """Run this rank's share of `total` alignments on its GPU and gather all poses.
 

@@ -123,7 +123,11 @@ ellc_status ellc_keyframe_finalise_weights(ellc_ctx* ctx, int slot);
  */
 ellc_status ellc_align(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, const float* init_pose,
                        int mode, int save_weights, float* out_pose, int* out_iters, float* out_weighted);
-/* Asynchronous form: enqueue only; results stay on device until ellc_align_fetch. */
+/* Asynchronous form: enqueue only. Up to TWO batches may be in flight (staging and result records exist twice), so a
+ * caller can enqueue batch n+1 before fetching batch n and keep the device busy back to back; a third enqueue returns
+ * ELLC_ERR_NOT_READY. ellc_align_fetch waits for the OLDEST batch in flight only (an event, not the whole stream) and
+ * returns its results; with nothing in flight it returns ELLC_ERR_NOT_READY. The slots a batch reads must not be
+ * modified (upload / set_depth ...) while it is in flight; those calls are stream-ordered after it anyway. */
 ellc_status ellc_align_enqueue(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, const float* init_pose,
                                int mode, int save_weights);
 ellc_status ellc_align_fetch(ellc_ctx* ctx, int B, float* out_pose, int* out_iters, float* out_weighted);

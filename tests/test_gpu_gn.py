@@ -191,3 +191,29 @@ def test_packed_division_matches_ieee_division(ellc):
     ctx.close()
     same = (qp.view(np.uint32) == qr.view(np.uint32)) | (np.isnan(qp) & np.isnan(qr))
     assert same.all(), "first mismatch: a=%r b=%r pair=%r ref=%r" % (a[~same][0], b[~same][0], qp[~same][0], qr[~same][0])
+
+
+def test_two_batches_in_flight(ellc, oracle):
+    """ellc_align_enqueue twice, then fetch twice: results come back oldest first and equal the synchronous ones; a third
+    enqueue and a fetch with nothing in flight are refused loudly."""
+    pairs = [synth.make_pair(W, H, seed=40 + i) for i in range(3)]
+    ctx = gpu_problem(ellc, W, H, L, pairs, early_exit=0)
+    ref0 = ctx.align([0, 1], [0, 1])[0]
+    ref1 = ctx.align([2], [2])[0]
+    ctx.align_enqueue([0, 1], [0, 1])
+    ctx.align_enqueue([2], [2])
+    with pytest.raises(ellc.EllcError):
+        ctx.align_enqueue([1], [1])
+    with pytest.raises(ellc.EllcError):
+        ctx.align([1], [1])
+    p0, it0, _ = ctx.align_fetch(2)
+    p1, it1, _ = ctx.align_fetch(1)
+    assert np.array_equal(p0, ref0) and np.array_equal(p1, ref1)
+    assert it0.sum() == 2 * 32 and it1.sum() == 32
+    with pytest.raises(ellc.EllcError):
+        ctx.align_fetch(1)
+    # alternating sets keep working
+    for _ in range(3):
+        ctx.align_enqueue([2], [2]); ctx.align_enqueue([0, 1], [0, 1])
+        assert np.array_equal(ctx.align_fetch(1)[0], ref1) and np.array_equal(ctx.align_fetch(2)[0], ref0)
+    ctx.close()

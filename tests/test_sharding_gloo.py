@@ -37,6 +37,13 @@ WORKER = textwrap.dedent("""
         assert np.array_equal(table[:, 5], (g * 0.5 + 5).astype(np.float32))
         assert np.array_equal(table[:, 6], (g * 0.25).astype(np.float32))
         assert np.array_equal(table[:, 7], (32 + 4 * (g %% 2)).astype(np.float32))
+        # the preallocated gatherer bench.py uses (reused buffers over several batches, enqueue/fetch pipelining)
+        gat = sharding.ResultGatherer(total)
+        for rep in range(3):
+            pose, iters, wgt = FakeCtx(lo).align(slots, slots)
+            t2 = gat.gather(sharding.pack_results(pose + rep, iters, wgt))
+            assert t2.shape == (total, 8) and np.array_equal(t2[:, 0], (g * 0.5 + rep).astype(np.float32))
+            assert np.array_equal(t2[:, 7], (32 + 4 * (g %% 2)).astype(np.float32))
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
