@@ -217,3 +217,27 @@ def test_two_batches_in_flight(ellc, oracle):
         ctx.align_enqueue([2], [2]); ctx.align_enqueue([0, 1], [0, 1])
         assert np.array_equal(ctx.align_fetch(1)[0], ref1) and np.array_equal(ctx.align_fetch(2)[0], ref0)
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_batch_sharing_one_keyframe(ellc, mode):
+    """BASELINE configs[2]: a batch of alignments against ONE keyframe (one compaction, one H^-1 per level in ICA mode),
+    each with its own current frame: every result equals the single-alignment result of the same pair."""
+    pairs = [synth.make_pair(W, H, seed=70, rot=0.004 + 0.002 * i, trans=0.02 + 0.01 * i) for i in range(4)]
+    cfg = ellc.default_config(W, H, L, early_exit=1, max_keyframes=1, max_frames=4, max_batch=4)
+    fx, fy, cx, cy = pairs[0]["intrinsics"]
+    cfg.fx, cfg.fy, cfg.cx, cfg.cy = fx, fy, cx, cy
+    ctx = ellc.Context(cfg)
+    ctx.keyframe_upload(0, pairs[0]["kf_image"]); ctx.keyframe_set_depth(0, pairs[0]["depth0"], pairs[0]["var0"])
+    rng = np.random.default_rng(5)
+    for l in range(L):
+        ctx.keyframe_set_weights(0, l, rng.uniform(0.01, 0.0625, size=(H >> l, W >> l)).astype(np.float32), 1)
+    for i, p in enumerate(pairs):
+        ctx.frame_upload(i, p["cur_image"])
+    singles = [ctx.align([0], [i], mode=mode) for i in range(4)]
+    pb, itb, wb = ctx.align([0, 0, 0, 0], [0, 1, 2, 3], mode=mode)
+    for i in range(4):
+        assert list(itb[i]) == list(singles[i][1][0])
+        assert np.abs(pb[i] - singles[i][0][0]).max() < 2e-6     # block decomposition differs with B
+    assert np.abs(pb[0] - pb[3]).max() > 1e-3                     # the frames really differ
+    ctx.close()
