@@ -64,7 +64,7 @@ struct KfLevelDev {
   float* wlast;               // compact weight of the most recent iteration (for saveWeights)
   float* sd;                  // ICA steepest-descent planes, 6 x cap (plane k at sd + k*cap)
   int* count;                 // V = number of compact entries
-  int* tile_count;            // per-tile counts / offsets scratch (n/1024+1)
+  int* tile_count;            // per-tile (ELLC_TILE pixels) counts, then exclusive offsets
 };
 
 struct FrLevelDev {

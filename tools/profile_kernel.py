@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs only the dominant kernel (gn_fca_accumulate, level 0) over a resident batch, plus the counter-calibration
+"""Runs only the dominant kernel (gn_fca_fused, level 0; ellc_profile_gn_kernel) over a resident batch, plus the counter-calibration
 kernel — the process rocprofv3 wraps when collecting --kernel-trace / --pmc summaries for profiles/."""
 import argparse
 import json
