@@ -1187,7 +1187,7 @@ __global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slo
   const int V = *K.count;
   const int cols = geom[level].cols;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
-    const uint32_t xy = K.cxy[i];
+    const uint32_t xy = K.crec[i].xy;   // saved weights exist in the FCA schedule only: its records carry the pixel position
     const size_t p = (size_t)(xy >> 16) * cols + (xy & 0xffffu);
     K.weight[p] = K.weight[p] + K.wlast[i];
   }

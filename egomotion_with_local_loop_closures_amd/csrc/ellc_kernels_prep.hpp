@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
     const int x = i - y * cols;
     const uint32_t xy = ((uint32_t)y << 16) | (uint32_t)x;
     const float Ikf = (float)img[(unsigned)(y * sw + x)];
-    cxy[pos] = xy;
-    if (need & 1) {   // ICA reads planes
+    if (need & 1) {   // unfused ICA kernels read planes
+      cxy[pos] = xy;
       cZ[pos] = Z;
       cI[pos] = Ikf;
       cW[pos] = wgt[(unsigned)i];
