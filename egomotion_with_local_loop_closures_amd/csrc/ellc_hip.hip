@@ -117,7 +117,12 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
   const int tiles = c->tile_begin[lvl_hi + 1] - c->tile_begin[lvl_lo];
   hipLaunchKernelGGL(prep_count, dim3(tiles, n_unique), dim3(256), 0, st, a);
   hipLaunchKernelGGL(prep_scan, dim3(lvl_hi - lvl_lo + 1, n_unique), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(prep_scatter, dim3(tiles, n_unique), dim3(256), 0, st, a);
+  switch (need) {
+    case 1: hipLaunchKernelGGL(prep_scatter<1>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(prep_scatter<2>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(prep_scatter<4>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
+    default: return fail(c, ELLC_ERR_BAD_ARG, "run_prep: unknown record set");
+  }
   ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
 }

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void prep_scan(PrepArgs a) {
 // parked entries — every lane has a valid pixel — computes the record (three IEEE divisions) and stores it; consecutive
 // lanes write consecutive records. Without the LDS step the divisions would run for every wave that holds at least one
 // valid pixel, i.e. about four times as often on a semi-dense map.
+template <int NEED>   // compile-time copy of PrepArgs::need: the FCA variant carries no Jacobian / H-sum code (and registers)
 __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   int local;
   const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
@@ -155,12 +156,22 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   ELLC_GLOBAL float* cW = gptr_rw(K.cW);
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   ELLC_GLOBAL u32x4* crec = (ELLC_GLOBAL u32x4*)K.crec;
-  const int cols = g.cols, sw = g.sw, need = a.need;
+  const int cols = g.cols, sw = g.sw;
+  constexpr int need = NEED;
   const float fx = g.fx, fy = g.fy, cx = g.cx, cy = g.cy;
   float hacc[27];
 #pragma unroll
   for (int q = 0; q < 27; q++) hacc[q] = 0.0f;
-  for (int r = (int)threadIdx.x; r < nvalid; r += 256) {
+  // The 48-byte ICA records leave through an LDS staging block of 256 records so that consecutive lanes store consecutive
+  // 16-byte words (lane-per-record, every store instruction would touch a third of each line): -5 % on the kernel. The
+  // 32-byte FCA records are stored directly (r01 A/B: the two extra barriers per 256 records cost more than the half-line
+  // stores).
+  constexpr int CH = 3;
+  __shared__ u32x4 s_rec[(NEED & 4) ? 256 * CH : 1];
+  ELLC_GLOBAL u32x4* rec_out = (ELLC_GLOBAL u32x4*)K.irec;
+  for (int r0 = 0; r0 < nvalid; r0 += 256) {   // block-uniform trip count
+    const int r = r0 + (int)threadIdx.x;
+    if (r < nvalid) {
     const int i = (int)s_idx[r];
     const float Z = s_Z[r];
     const unsigned pos = tile_off + (unsigned)r;
@@ -188,11 +199,10 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
       const float wsave = wgt[(unsigned)i];
       const float X = (((float)x - cx) * Z) / fx;
       const float Y = (((float)y - cy) * Z) / fy;
-      typedef float f32x4 __attribute__((ext_vector_type(4)));
-      ELLC_GLOBAL f32x4* ir = (ELLC_GLOBAL f32x4*)K.irec + 3u * pos;
-      ir[0] = (f32x4){X, Y, Z, Ikf};
-      ir[1] = (f32x4){wsave, J[0], J[1], J[2]};
-      ir[2] = (f32x4){J[3], J[4], J[5], 0.0f};
+      const unsigned t3 = 3u * threadIdx.x;
+      s_rec[t3] = (u32x4){__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, Ikf)};
+      s_rec[t3 + 1] = (u32x4){__builtin_bit_cast(uint32_t, wsave), __builtin_bit_cast(uint32_t, J[0]), __builtin_bit_cast(uint32_t, J[1]), __builtin_bit_cast(uint32_t, J[2])};
+      s_rec[t3 + 2] = (u32x4){__builtin_bit_cast(uint32_t, J[3]), __builtin_bit_cast(uint32_t, J[4]), __builtin_bit_cast(uint32_t, J[5]), 0u};
       int q = 0;
 #pragma unroll
       for (int rr = 0; rr < 6; rr++) {
@@ -210,6 +220,14 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
       const u32x4 hi = {__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), (uint32_t)zb, (uint32_t)(zb >> 32)};
       crec[2u * pos] = lo;
       crec[2u * pos + 1u] = hi;
+    }
+    }
+    if (NEED & 4) {
+      __syncthreads();
+      const int chunks = min(256, nvalid - r0) * CH;
+      const unsigned obase = (tile_off + (unsigned)r0) * CH;
+      for (int cidx = (int)threadIdx.x; cidx < chunks; cidx += 256) rec_out[obase + (unsigned)cidx] = s_rec[cidx];
+      __syncthreads();
     }
   }
   if (need & 4) block_reduce_store<27>(hacc, K.hpart + (size_t)local * ELLC_PART_STRIDE);   // block-uniform condition
