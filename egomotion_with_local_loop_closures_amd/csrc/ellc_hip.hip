@@ -116,7 +116,6 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
   a.level0 = lvl_lo;
   const int tiles = c->tile_begin[lvl_hi + 1] - c->tile_begin[lvl_lo];
   hipLaunchKernelGGL(prep_count, dim3(tiles, n_unique), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(prep_scan, dim3(lvl_hi - lvl_lo + 1, n_unique), dim3(256), 0, st, a);
   switch (need) {
     case 1: hipLaunchKernelGGL(prep_scatter<1>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL(prep_scatter<2>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;

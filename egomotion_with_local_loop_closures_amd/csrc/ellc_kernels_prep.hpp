@@ -10,7 +10,7 @@ namespace ellc {
 
 // ---------------------------------------------------------------------------------------------------
 // Compaction of the keyframe's valid pixels (mask = depth_pyramid[l] > 0, Frame.cpp:295-301), raster
-// order preserved. Three launches cover all levels of all listed keyframe slots.
+// order preserved. Two launches (count per tile, then scatter) cover all levels of all listed keyframe slots.
 #define ELLC_TILE 2048          // pixels per block: 256 threads x 8 consecutive pixels (two float4 loads)
 
 struct PrepArgs {
@@ -74,31 +74,6 @@ __global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
   if (threadIdx.x == 0) K.tile_count[local] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// one block per (level, slot): exclusive scan of the tile counts in place, total -> count
-__global__ __launch_bounds__(256) void prep_scan(PrepArgs a) {
-  const int level = a.level0 + (int)blockIdx.x;
-  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
-  const int T = a.tile_begin[level + 1] - a.tile_begin[level];
-  const int per = (T + 255) / 256;
-  const int t0 = threadIdx.x * per;
-  int s = 0;
-  for (int i = t0; i < min(T, t0 + per); i++) s += K.tile_count[i];
-  __shared__ int ws[4];
-  int tot;
-  const int inc = wave_inclusive_scan(s, tot);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = tot;
-  __syncthreads();
-  int wbase = 0;
-  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wbase += ws[w];
-  int run = wbase + inc - s;   // exclusive prefix of this thread's span
-  for (int i = t0; i < min(T, t0 + per); i++) {
-    const int c = K.tile_count[i];
-    K.tile_count[i] = run;
-    run += c;
-  }
-  if (threadIdx.x == 255) *K.count = wbase + inc;
-}
-
 // Scatter, two phases per tile of ELLC_TILE pixels. Phase 1: thread t owns pixels base + j*256 + t (j = 0..7), so the
 // depth loads of a wave are contiguous; ballot ranks give every valid pixel its raster-order rank inside the tile
 // (order = (j, wave, lane)), and (pixel index, depth) are parked in LDS at that rank. Phase 2 runs densely over the
@@ -115,8 +90,15 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   const int base = local * ELLC_TILE + (int)threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ int cnt[33];   // [j][wave] exclusive offsets, [32] = tile total
+  __shared__ int before[4]; // per wave: valid pixels in the tiles of this level that precede this one
   __shared__ uint32_t s_idx[ELLC_TILE];
   __shared__ float s_Z[ELLC_TILE];
+  {   // this tile's offset in the level's list = sum of the counts prep_count left for the tiles before it (at most a few hundred)
+    int part = 0, tot;
+    for (int i = (int)threadIdx.x; i < local; i += 256) part += K.tile_count[i];
+    wave_inclusive_scan(part, tot);
+    if (lane == 0) before[wave] = tot;
+  }
   float d[8];
   unsigned long long m[8];
 #pragma unroll
@@ -145,7 +127,8 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   }
   __syncthreads();
   const int nvalid = cnt[32];
-  const unsigned tile_off = (unsigned)K.tile_count[local];
+  const unsigned tile_off = (unsigned)(before[0] + before[1] + before[2] + before[3]);
+  if (threadIdx.x == 0 && local == a.tile_begin[level + 1] - a.tile_begin[level] - 1) *K.count = (int)tile_off + nvalid;   // last tile: the level's total
   const float inv_cols = 1.0f / (float)g.cols;
   const ELLC_GLOBAL float* var = gptr(K.var);
   const ELLC_GLOBAL float* wgt = gptr(K.weight);
