@@ -48,7 +48,7 @@ ellc_status need_map(ellc_ctx* c) {
 
 ellc_status do_regularize(ellc_ctx* c, int removeOcclusions) {
   const int W = c->cfg.width, H = c->cfg.height;
-  dim3 blk(32, 8);
+  dim3 blk(DM_TX, DM_TY);
   hipLaunchKernelGGL(dm_regularize, grid2(W, H, blk), blk, 0, c->stream, c->dm_cur, c->dm_oth, W, H, removeOcclusions);
   ELLC_HIP(c, hipGetLastError());
   swap_maps(c);
@@ -57,7 +57,7 @@ ellc_status do_regularize(ellc_ctx* c, int removeOcclusions) {
 
 ellc_status do_fill_holes(ellc_ctx* c) {
   const int W = c->cfg.width, H = c->cfg.height;
-  dim3 blk(32, 8);
+  dim3 blk(DM_TX, DM_TY);
   hipLaunchKernelGGL(dm_fill_holes, grid2(W, H, blk), blk, 0, c->stream, c->dm_cur, c->dm_oth, c->kf_maxgrad[c->dm_kf_slot], W, H);
   ELLC_HIP(c, hipGetLastError());
   swap_maps(c);
@@ -68,7 +68,7 @@ ellc_status do_rescale(ellc_ctx* c, float* factor_out) {
   const int n = c->cfg.width * c->cfg.height;
   const int nb = 256;
   hipLaunchKernelGGL(dm_sum_stage1, dim3(nb), dim3(256), 0, c->stream, c->dm_cur, n, c->red_scratch);
-  hipLaunchKernelGGL(dm_sum_stage2, dim3(1), dim3(64), 0, c->stream, c->red_scratch, nb, c->red_scratch + 2 * nb);
+  hipLaunchKernelGGL(dm_sum_stage2, dim3(1), dim3(256), 0, c->stream, c->red_scratch, nb, c->red_scratch + 2 * nb);
   const float* factor_d = (const float*)(c->red_scratch + 2 * nb + 2);
   hipLaunchKernelGGL(dm_rescale, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dm_cur, n, factor_d);
   ELLC_HIP(c, hipGetLastError());

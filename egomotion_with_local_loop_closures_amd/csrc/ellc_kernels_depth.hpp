@@ -63,27 +63,59 @@ __device__ __forceinline__ float tap_plain(const uint8_t* img, int sw, int cols,
 }
 
 // ------------------------------------------------------------------------------------------------
+// 5x5 / row-pair stencils over the hypothesis map. A block is DM_TX x DM_TY pixels; the four fields the stencils read
+// (invDepth, variance, validity, isValid) of the tile plus a halo of DM_HALO pixels are staged in LDS once — 25 (or up to
+// 35) neighbours per pixel straight from global memory made these kernels bound by the texture-address path, not by
+// HBM. Pixels outside the image read as invalid (they are never inside a stencil the reference evaluates).
+#define DM_TX 32
+#define DM_TY 8
+#define DM_HALO 3
+#define DM_TW (DM_TX + 2 * DM_HALO)
+#define DM_TH (DM_TY + 2 * DM_HALO)
+struct DmTile {
+  float id[DM_TH][DM_TW];
+  float var[DM_TH][DM_TW];
+  int validity[DM_TH][DM_TW];
+  uint8_t valid[DM_TH][DM_TW];
+};
+__device__ __forceinline__ void dm_tile_load(DmTile& t, const DepthSoA& in, int W, int H) {
+  const int x0 = blockIdx.x * DM_TX - DM_HALO, y0 = blockIdx.y * DM_TY - DM_HALO;
+  for (int k = threadIdx.y * DM_TX + threadIdx.x; k < DM_TW * DM_TH; k += DM_TX * DM_TY) {
+    const int ty = k / DM_TW, tx = k - ty * DM_TW;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool inside = (x >= 0 && x < W && y >= 0 && y < H);
+    const int j = inside ? (x + y * W) : 0;
+    t.valid[ty][tx] = inside ? in.isValid[j] : (uint8_t)0;
+    t.id[ty][tx] = inside ? in.invDepth[j] : 0.0f;
+    t.var[ty][tx] = inside ? in.variance[j] : 0.0f;
+    t.validity[ty][tx] = inside ? in.validity[j] : 0;
+  }
+  __syncthreads();
+}
+
 // depthMap::regularizeDepthMap (:1436-1543). Reads `in` (the memcpy snapshot), writes every pixel of `out`.
-__global__ void dm_regularize(DepthSoA in, DepthSoA out, int W, int H, int removeOcclusions) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+__global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA in, DepthSoA out, int W, int H, int removeOcclusions) {
+  __shared__ DmTile t;
+  dm_tile_load(t, in, W, H);
+  const int x = blockIdx.x * DM_TX + threadIdx.x;
+  const int y = blockIdx.y * DM_TY + threadIdx.y;
   if (x >= W || y >= H) return;
   const int i = x + y * W;
+  const int cx = threadIdx.x + DM_HALO, cy = threadIdx.y + DM_HALO;
   Hyp d = hyp_load(in, i);
   if (y >= 3 && y < H - 3 && x >= 2 && x < W - 2 && d.valid) {
     float sum = 0.0f, val_sum = 0.0f, sumIvar = 0.0f;
     int numOccluding = 0, numNotOccluding = 0;
     for (int dx = -2; dx <= 2; dx++)
       for (int dy = -2; dy <= 2; dy++) {
-        const int j = i + dx + dy * W;
-        if (!in.isValid[j]) continue;
-        const float sid = in.invDepth[j], svar = in.variance[j];
+        if (!t.valid[cy + dy][cx + dx]) continue;
+        const float sid = t.id[cy + dy][cx + dx], svar = t.var[cy + dy][cx + dx];
         const float diff = sid - d.id;
         if (1.0f * diff * diff > svar + d.var) {
           if (removeOcclusions && sid > d.id) numOccluding++;
           continue;
         }
-        val_sum += (float)in.validity[j];
+        val_sum += (float)t.validity[cy + dy][cx + dx];
         if (removeOcclusions) numNotOccluding++;
         const float distFac = (float)(dx * dx + dy * dy) * DM_REG_DIST_VAR;
         const float ivar = 1.0f / (svar + distFac);
@@ -108,27 +140,29 @@ __global__ void dm_regularize(DepthSoA in, DepthSoA out, int W, int H, int remov
 // indexes a per-row prefix sum as if it were a 2-D integral image, which evaluates to
 //   val = sum_{x-2..x+2} validity(row y+2) - sum_{x-2..x+2} validity(row y-3)
 // with rows outside [3, H-3) contributing 0 (never written, zero-initialised).
-__global__ void dm_fill_holes(DepthSoA in, DepthSoA out, const float* __restrict__ maxgrad, int W, int H) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+__global__ __launch_bounds__(DM_TX * DM_TY) void dm_fill_holes(DepthSoA in, DepthSoA out, const float* __restrict__ maxgrad, int W, int H) {
+  __shared__ DmTile t;
+  dm_tile_load(t, in, W, H);
+  const int x = blockIdx.x * DM_TX + threadIdx.x;
+  const int y = blockIdx.y * DM_TY + threadIdx.y;
   if (x >= W || y >= H) return;
   const int i = x + y * W;
+  const int cx = threadIdx.x + DM_HALO, cy = threadIdx.y + DM_HALO;
   Hyp d = hyp_load(in, i);
   if (y >= 3 && y < H - 3 && x >= 3 && x < W - 2 && !d.valid && !(maxgrad[i] < DM_MIN_ABS_GRAD_DECREASE)) {
     int val = 0;
     const int ya = y + 2, yb = y - 3;
     if (ya >= 3 && ya < H - 3)
-      for (int xx = x - 2; xx <= x + 2; xx++) { const int j = xx + ya * W; if (in.isValid[j]) val += in.validity[j]; }
+      for (int dx = -2; dx <= 2; dx++) { if (t.valid[cy + 2][cx + dx]) val += t.validity[cy + 2][cx + dx]; }
     if (yb >= 3 && yb < H - 3)
-      for (int xx = x - 2; xx <= x + 2; xx++) { const int j = xx + yb * W; if (in.isValid[j]) val -= in.validity[j]; }
+      for (int dx = -2; dx <= 2; dx++) { if (t.valid[cy - 3][cx + dx]) val -= t.validity[cy - 3][cx + dx]; }
     if ((d.bl >= DM_MIN_BLACKLIST && (float)val > DM_VAL_SUM_MIN_FOR_CREATE) || (float)val > DM_VAL_SUM_MIN_FOR_UNBLACKLIST) {
       float sumIdepthObs = 0.0f, sumIVarObs = 0.0f;
-      for (int yy = y - 2; yy < y + 3; yy++)
-        for (int xx = x - 2; xx < x + 3; xx++) {
-          const int j = xx + yy * W;
-          if (!in.isValid[j]) continue;
-          const float v = in.variance[j];
-          sumIdepthObs += in.invDepth[j] / v;
+      for (int dy = -2; dy < 3; dy++)
+        for (int dx = -2; dx < 3; dx++) {
+          if (!t.valid[cy + dy][cx + dx]) continue;
+          const float v = t.var[cy + dy][cx + dx];
+          sumIdepthObs += t.id[cy + dy][cx + dx] / v;
           sumIVarObs += 1.0f / v;
         }
       float idepthObs = sumIdepthObs / sumIVarObs;
@@ -166,7 +200,7 @@ __global__ void dm_export_level0(DepthSoA s, float* __restrict__ depthMat, float
 }
 
 // depthMap::makeInvDepthOne (:1546-1587): sum of invDepthSmoothed over valid pixels and their count.
-// Stage 1: per-block f64 partials (fixed order); stage 2: one block combines them in block order.
+// Stage 1: per-block f64 partials (fixed order); stage 2: one block combines them with the same fixed tree.
 __global__ __launch_bounds__(256) void dm_sum_stage1(DepthSoA s, int n, double* __restrict__ part) {
   double acc = 0.0, cnt = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
@@ -180,14 +214,22 @@ __global__ __launch_bounds__(256) void dm_sum_stage1(DepthSoA s, int n, double* 
   }
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = sa[0]; part[2 * blockIdx.x + 1] = sc[0]; }
 }
-__global__ void dm_sum_stage2(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double a = 0.0, c = 0.0;
-  for (int b = 0; b < nblocks; b++) { a += part[2 * b]; c += part[2 * b + 1]; }
-  out[0] = a;
-  out[1] = c;
-  const float num = (float)c, sum = (float)a;
-  ((float*)(out + 2))[0] = num / sum;   // rescaleFactor = numIdepth / sumIdepth (f32)
+__global__ __launch_bounds__(256) void dm_sum_stage2(const double* __restrict__ part, int nblocks, double* __restrict__ out) {   // one block, nblocks <= 256
+  __shared__ double sa[256], sc[256];
+  const int t = threadIdx.x;
+  sa[t] = (t < nblocks) ? part[2 * t] : 0.0;
+  sc[t] = (t < nblocks) ? part[2 * t + 1] : 0.0;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {   // the same fixed tree as stage 1
+    if (t < off) { sa[t] += sa[t + off]; sc[t] += sc[t + off]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    out[0] = sa[0];
+    out[1] = sc[0];
+    const float num = (float)sc[0], sum = (float)sa[0];
+    ((float*)(out + 2))[0] = num / sum;   // rescaleFactor = numIdepth / sumIdepth (f32)
+  }
 }
 __global__ void dm_rescale(DepthSoA s, int n, const float* __restrict__ factor) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
