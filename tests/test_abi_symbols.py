@@ -60,3 +60,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hpp", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle_py" not in txt and "ellc_oracle" not in txt and "libellc_oracle" not in txt, f
+
+
+def test_header_is_plain_c_and_facade_is_cxx11(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 without torch / HIP types; the facade as C++11."""
+    import subprocess
+    c = tmp_path / "abi.c"
+    c.write_text('#include "ellc_abi.h"\nint main(void) { ellc_config c; (void)c; return ELLC_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(c)])
+    cc = tmp_path / "facade.cpp"
+    cc.write_text('#include "ellc_facade.hpp"\nint main() { return 0; }\n')
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(cc)])
