@@ -274,12 +274,14 @@ static void set_age_split(ellc_ctx* c, FusedArgs& fa, int B) {
 }
 
 static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
+  const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
+  const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
   if (c->pipe) {
-    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, true>), grd, blk, 0, st, fa);
-    else hipLaunchKernelGGL((gn_fca_fused<false, true>), grd, blk, 0, st, fa);
+    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, true>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, true>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
   } else {
-    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, false>), grd, blk, 0, st, fa);
-    else hipLaunchKernelGGL((gn_fca_fused<false, false>), grd, blk, 0, st, fa);
+    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, false>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, false>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
   }
 }
 
@@ -337,7 +339,8 @@ static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
     fa.g = make_gn_args(c, level, B, 0, nullptr);
     const dim3 grd(fa.g.nblk, B), blk(ELLC_GN_THREADS);
     for (int it = 0; it < c->cfg.max_iter[level]; it++) {
-      hipLaunchKernelGGL(gn_ica_fused, grd, blk, 0, c->stream, fa);
+      hipLaunchKernelGGL(gn_ica_fused, grd, blk, 0, c->stream, (const AlignState*)(fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state),
+                         (const float*)(fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part), fa.prev_nblk, fa);
       fa.prev_level = level;
       fa.prev_nblk = fa.g.nblk;
       fa.seq++;

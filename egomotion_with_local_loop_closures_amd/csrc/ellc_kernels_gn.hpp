@@ -900,20 +900,25 @@ struct FusedArgs {
   int ica;              // 1: constant-weight schedule (gn_ica_fused): the pending sums are b only, H^-1 comes from the keyframe slot
 };
 
+// The leading scalar parameters repeat what the prologue's first loads need (addresses of the state record and of the
+// pending partial sums, block counts): the library is built with kernel-argument preloading, so they arrive in SGPRs with
+// the wave instead of through a scalar load from the argument buffer — one memory round trip less at the head of a
+// latency-bound kernel. Everything else stays in the by-value struct.
 template <bool DIVC, bool PIPE>
-__global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(FusedArgs fa) {   // 4 waves per SIMD: at most 128 VGPRs
+__global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignState* src_state, const float* prev_part, int prev_nblk,
+                                                                   int nblk, int age_rounds, FusedArgs fa) {   // 4 waves per SIMD: at most 128 VGPRs
   const GnArgs& a = fa.g;
-  int b = blockIdx.y, sub = blockIdx.x, age = 0, per_age = a.nblk;
-  if (fa.age_rounds > 1) {
+  int b = blockIdx.y, sub = blockIdx.x, age = 0, per_age = nblk;
+  if (age_rounds > 1) {
     const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
-    const int per_round = (int)(gridDim.x * gridDim.y) / fa.age_rounds;
-    per_age = a.nblk / fa.age_rounds;          // blocks of one alignment in each round
+    const int per_round = (int)(gridDim.x * gridDim.y) / age_rounds;
+    per_age = nblk / age_rounds;          // blocks of one alignment in each round
     age = lin / per_round;
     const int j = lin - age * per_round;
     b = j / per_age;
     sub = age * per_age + (j - b * per_age);
   }
-  const AlignState& src = a.state[(size_t)(fa.seq & 1) * fa.stride_state + b];
+  const AlignState& src = src_state[b];
   AlignState* dst = a.state + (size_t)((fa.seq + 1) & 1) * fa.stride_state + b;
   __shared__ SolveShared sh;
   const int t = threadIdx.x;
@@ -930,19 +935,18 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(FusedArgs fa)
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int pending = src.pending;
   const int V = *as_global(K.count);
-  const double group_sum = partial_group_sum(
-      a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, fa.prev_nblk);
+  const double group_sum = partial_group_sum(prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, prev_nblk);
   // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
   // split, which was tried in r01 and did not change the run time — co-resident blocks finish staggered because the
   // SIMD arbiter serves the oldest wave first, not because their pixels differ)
   int begin, end;
-  if (fa.age_rounds > 1) {
+  if (age_rounds > 1) {
     const int gb = (int)(((long long)V * fa.age_cum[age]) >> 16), ge = (int)(((long long)V * fa.age_cum[age + 1]) >> 16);
     const int chunk = (ge - gb + per_age - 1) / per_age;
     begin = gb + (sub - age * per_age) * chunk;
     end = min(ge, begin + chunk);
   } else {
-    const int chunk = (V + a.nblk - 1) / a.nblk;
+    const int chunk = (V + nblk - 1) / nblk;
     begin = sub * chunk;
     end = min(V, begin + chunk);
   }
@@ -1046,10 +1050,10 @@ __device__ __forceinline__ void ica_accumulate_pixel(float (&acc)[6], const IcaI
   for (int r = 0; r < 6; r++) acc[r] = __builtin_fmaf(in.sd[r], rw, acc[r]);
 }
 
-__global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(FusedArgs fa) {
-  const GnArgs& a = fa.g;
+__global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState* src_state, const float* prev_part, int prev_nblk, FusedArgs fa) {
+  const GnArgs& a = fa.g;   // leading scalars: preloaded kernel arguments, see gn_fca_fused
   const int b = blockIdx.y, sub = blockIdx.x;
-  const AlignState& src = a.state[(size_t)(fa.seq & 1) * fa.stride_state + b];
+  const AlignState& src = src_state[b];
   AlignState* dst = a.state + (size_t)((fa.seq + 1) & 1) * fa.stride_state + b;
   __shared__ SolveShared sh;
   const int t = threadIdx.x;
@@ -1060,8 +1064,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(FusedArgs fa) {
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int pending = src.pending;
   const int V = *as_global(K.count);
-  const double group_sum = partial_group_sum(
-      a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, fa.prev_nblk);
+  const double group_sum = partial_group_sum(prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, prev_nblk);
   const int chunk = (V + a.nblk - 1) / a.nblk;
   const int begin = sub * chunk;
   const int end = min(V, begin + chunk);
