@@ -7,6 +7,6 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TMP=$(mktemp -d)
 git -C "$ROOT" archive "$REV" egomotion_with_local_loop_closures_amd/csrc include | tar -x -C "$TMP"
 cd "$TMP/egomotion_with_local_loop_closures_amd/csrc"
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -w -shared -o "$ROOT/build/libellc_hip_$NAME.so" ellc_hip.hip
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -w -mllvm -amdgpu-kernarg-preload-count=16 -shared -o "$ROOT/build/libellc_hip_$NAME.so" ellc_hip.hip
 rm -rf "$TMP"
 ls -la "$ROOT/build/libellc_hip_$NAME.so"
