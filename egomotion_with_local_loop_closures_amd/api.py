@@ -262,6 +262,12 @@ class Context:
         self._ck(self._l.ellc_selftest_div_pair(self.h, int(a.size), _p(a), _p(b), _p(qp), _p(qr)), "ellc_selftest_div_pair")
         return qp, qr
 
+    def selftest_lu(self, tri21):
+        tri21 = np.ascontiguousarray(tri21, np.float64).reshape(-1, 21)
+        out = np.zeros((tri21.shape[0], 6, 6), np.float32)
+        self._ck(self._l.ellc_selftest_lu(self.h, int(tri21.shape[0]), _p(tri21), _p(out)), "ellc_selftest_lu")
+        return out
+
     def profile_calibrate_read(self, nbytes, reps=10):
         ms = C.c_float(0)
         self._ck(self._l.ellc_profile_calibrate_read(self.h, C.c_size_t(nbytes), reps, C.byref(ms)), "ellc_profile_calibrate_read")

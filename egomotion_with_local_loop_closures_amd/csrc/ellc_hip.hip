@@ -1154,6 +1154,42 @@ ellc_status ellc_selftest_div_pair(ellc_ctx* c, int n, const float* a, const flo
   return ELLC_OK;
 }
 
+// device self-test of the 6x6 LU inverse: n symmetric matrices given by their 21 upper-triangular entries (f64), one wave each
+__global__ void selftest_lu(const double* tri21, float* inv36, int n) {
+  const int m = blockIdx.x, lane = threadIdx.x;
+  if (m >= n) return;
+  float Hm[36];
+  int q = 0;
+  for (int r = 0; r < 6; r++)
+    for (int cc = r; cc < 6; cc++) {
+      const float v = (float)tri21[(size_t)m * 21 + q++];
+      Hm[r * 6 + cc] = v;
+      Hm[cc * 6 + r] = v;
+    }
+  float x[6];
+  ellc::lu_inverse6_lanes(Hm, lane < 6 ? lane : 0, x);
+  if (lane < 6)
+    for (int r = 0; r < 6; r++) inv36[(size_t)m * 36 + r * 6 + lane] = x[r];
+}
+ellc_status ellc_selftest_lu(ellc_ctx* c, int n, const double* tri21, float* inv36) {
+  if (!c || n < 1 || !tri21 || !inv36) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  double* d = nullptr;
+  float* o = nullptr;
+  ELLC_HIP(c, hipMalloc(&d, (size_t)n * 21 * sizeof(double)));
+  hipError_t e = hipMalloc(&o, (size_t)n * 36 * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpyAsync(d, tri21, (size_t)n * 21 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(selftest_lu, dim3(n), dim3(64), 0, c->stream, d, o, n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(inv36, o, (size_t)n * 36 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d);
+  if (o) hipFree(o);
+  if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("selftest_lu: ") + hipGetErrorString(e));
+  return ELLC_OK;
+}
+
 ellc_status ellc_profile_calibrate_read(ellc_ctx* c, size_t bytes, int reps, float* avg_ms) {
   if (!c || reps < 1 || bytes < 1024) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   float* buf = nullptr;

@@ -206,6 +206,11 @@ ellc_status ellc_profile_calibrate_read(ellc_ctx* ctx, size_t bytes, int reps, f
  * compiler emits it; n even. The per-pixel code relies on the two being bit-identical (tests/test_gpu_gn.py). */
 ellc_status ellc_selftest_div_pair(ellc_ctx* ctx, int n, const float* a, const float* b, float* q_pair, float* q_ref);
 
+/* Device self-test of the solve's 6x6 inverse (cv::Mat::inv(DECOMP_LU) restated, PixelWisePyramid.cpp:451): n symmetric
+ * matrices, each given by its 21 upper-triangular entries by rows (f64, rounded to f32 as the solve does); inv36 receives
+ * the row-major f32 inverses (all zeros for a singular matrix). */
+ellc_status ellc_selftest_lu(ellc_ctx* ctx, int n, const double* tri21, float* inv36);
+
 #ifdef __cplusplus
 }
 #endif

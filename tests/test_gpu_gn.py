@@ -241,3 +241,37 @@ def test_batch_sharing_one_keyframe(ellc, mode):
         assert np.abs(pb[i] - singles[i][0][0]).max() < 2e-6     # block decomposition differs with B
     assert np.abs(pb[0] - pb[3]).max() > 1e-3                     # the frames really differ
     ctx.close()
+
+
+def test_lu_inverse_matches_the_scalar_algorithm_bit_for_bit(ellc, oracle):
+    """The solve's wave-cooperative 6x6 inverse (one augmented-matrix column per lane) against the oracle's scalar restatement
+    of cv::Mat::inv(DECOMP_LU): well conditioned, badly scaled (pivoting needed), nearly and exactly singular matrices."""
+    rng = np.random.default_rng(11)
+    mats = []
+    for k in range(300):
+        J = rng.standard_normal((40, 6)) * 10.0 ** rng.uniform(-3, 3, size=6)     # GN-like: columns of very different scale
+        mats.append(J.T @ J)
+    for k in range(100):   # symmetric indefinite with small / zero diagonal entries: row exchanges at several steps
+        A = rng.standard_normal((6, 6)); A = A + A.T
+        A[np.diag_indices(6)] *= rng.choice([0.0, 1e-6, 1.0], size=6)
+        mats.append(A)
+    v = rng.standard_normal(6)
+    mats.append(np.outer(v, v))                       # rank 1: singular => zero matrix
+    mats.append(np.zeros((6, 6)))                     # no valid pixel
+    mats.append(np.eye(6) * 1e-8)                     # pivots below FLT_EPSILON
+    mats.append(np.eye(6))
+    iu = np.triu_indices(6)
+    tri = np.stack([m[iu] for m in mats])
+    ctx = ellc.Context(ellc.default_config(64, 48, 3))
+    got = ctx.selftest_lu(tri)
+    ctx.close()
+    nsing = 0
+    for m, g in zip(mats, got):
+        Hf = np.zeros((6, 6), np.float32)
+        Hf[iu] = m[iu].astype(np.float32)
+        Hf = np.triu(Hf) + np.triu(Hf, 1).T
+        _, ref = oracle.lu_inverse(Hf)
+        assert np.array_equal(np.asarray(ref, np.float32).view(np.uint32), g.view(np.uint32)) or \
+            (np.isnan(ref).any() and np.isnan(g).any()), (m, ref, g)
+        nsing += int(not np.any(g))
+    assert nsing >= 3
