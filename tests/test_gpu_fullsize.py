@@ -177,3 +177,42 @@ def test_depth_path_at_reference_default_size(oracle, ellc):
     for f in ("invDepth", "variance", "validity"):
         assert bits_equal(got[f][m], ref[f][m]), f
     ctx.close()
+
+
+def test_gpu_against_committed_golden_fixtures(ellc):
+    """The committed fixtures (tests/golden/*.npz, generator committed) checked directly against the device, without the
+    oracle in the loop: depth stages on 96x64 and the ingest pre-pass on a 128x96 BGR frame."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as G
+    gd = np.load(os.path.join(os.path.dirname(__file__), "golden", "depth_small.npz"))
+    w, h, L, pair, st = G.depth_small_scene()
+    fx, fy, cx, cy = pair["intrinsics"]
+    ctx = ellc.Context(ellc.default_config(w, h, L, fx=fx, fy=fy, cx=cx, cy=cy, max_keyframes=2, max_frames=1))
+    ctx.keyframe_upload(0, pair["kf_image"]); ctx.frame_upload(0, pair["cur_image"]); ctx.keyframe_from_frame(1, 0)
+
+    def fresh():
+        ctx.depth_set_keyframe(0); ctx.depth_set_state(st)
+
+    def check(tag):
+        got = ctx.depth_get_state()
+        m = gd[tag + "_valid"] != 0
+        assert np.array_equal(got["valid"] != 0, m), tag
+        assert np.array_equal(got["blacklisted"], gd[tag + "_blacklisted"]), tag
+        for f in ("invDepth", "invDepthSmoothed", "variance", "varianceSmoothed", "validity"):
+            assert np.array_equal(got[f][m], gd[tag + "_" + f][m]), (tag, f)
+    fresh(); ctx.depth_regularize(False); check("regularize")
+    ctx.depth_observe(0, pair["xi_true"]); check("regularize_observe")
+    fresh(); ctx.depth_fill_holes(); check("fill_holes")
+    fresh(); ctx.depth_regularize(False); ctx.depth_propagate(1, pair["xi_true"]); check("regularize_propagate")
+    ctx.close()
+    gi = np.load(os.path.join(os.path.dirname(__file__), "golden", "ingest_small.npz"))
+    bgr = G.ingest_small_frame()
+    ctx = ellc.Context(ellc.default_config(bgr.shape[1] // 4, bgr.shape[0] // 4, 3, max_frames=1))
+    kn = ctx.ingest_configure(bgr.shape[1], bgr.shape[0], G.INGEST_K[0], G.INGEST_K[1], G.INGEST_K[2], G.INGEST_K[3], G.INGEST_DIST, True)
+    assert np.array_equal(kn.view(np.uint32), gi["new_camera"].view(np.uint32))
+    ctx.frame_ingest_bgr(0, bgr)
+    lvl0, (rows, cols) = ctx.image_level(False, 0, 0)
+    assert np.array_equal(lvl0[:rows, :cols], gi["image"])
+    ctx.close()

@@ -53,3 +53,27 @@ def test_kl_divergence_matches_opencv_definition(ellc):
     ref2 = sum(float(a) * np.log(float(a) / (float(b) if abs(b) > 2.220446049250313e-16 else 1e-10))
                for a, b in zip(p2.astype(np.float64), q2.astype(np.float64)) if abs(a) > 2.220446049250313e-16)
     assert abs(ellc.kl_divergence(p2, q2) - ref2) < 1e-10
+
+
+def test_pose_algebra_agrees_with_the_oracle_bit_for_bit(oracle):
+    """Downstream per-pixel comparisons (depth observation / propagation) inherit the pose algebra: product and oracle must
+    round the same way. exp is well conditioned; log of an f32-rounded matrix is not (atan2(s, c) and asin(s) differ by an
+    ulp in a third of the cases), so both sides evaluate the same skew-part series for small rotations."""
+    import ctypes as C
+    from egomotion_with_local_loop_closures_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(8)
+
+    def p(a):
+        return a.ctypes.data_as(C.c_void_p)
+    for i in range(3000):
+        sc = (0.003, 0.02, 0.3, 1.5)[i % 4]
+        a = (rng.normal(size=6) * [sc, sc, sc, 0.05, 0.05, 0.05]).astype(np.float32)
+        b = (rng.normal(size=6) * [sc, sc, sc, 0.05, 0.05, 0.05]).astype(np.float32)
+        T = np.zeros(16, np.float32); L.ellc_se3_exp(p(a), p(T))
+        assert np.array_equal(T.view(np.uint32), oracle.se3_exp(a).reshape(-1).view(np.uint32))
+        lg = np.zeros(6, np.float32); L.ellc_se3_log(p(T), p(lg))
+        assert np.array_equal(lg.view(np.uint32), oracle.se3_log(T).view(np.uint32))
+        for fn, ofn in ((L.ellc_concatenate_relative_pose, oracle.concat_relative), (L.ellc_concatenate_origin_pose, oracle.concat_origin)):
+            o = np.zeros(6, np.float32); fn(p(a), p(b), p(o))
+            assert np.array_equal(o.view(np.uint32), np.asarray(ofn(a, b), np.float32).view(np.uint32)), (i, a, b)

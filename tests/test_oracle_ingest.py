@@ -66,3 +66,16 @@ def test_reference_camera_new_matrix_and_map_sanity():
     # the principal point of the new camera maps to the principal point of the old one (no distortion at r = 0)
     cxn, cyn = int(round(float(Kn[2]))), int(round(float(Kn[3])))
     assert abs(u[cyn, cxn] - 960) < 1.5 and abs(v[cyn, cxn] - 540) < 1.5
+
+
+def test_golden_ingest_small_regression():
+    """tests/golden/ingest_small.npz: pins the ingest restatement (generator: tests/golden/make_golden.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as G
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ingest_small.npz"))
+    img, gray, und, kn = I.ingest(G.ingest_small_frame(), G.INGEST_K, G.INGEST_DIST, True)
+    assert np.array_equal(img, g["image"]) and np.array_equal(gray, g["gray"]) and np.array_equal(und, g["undistorted"])
+    assert np.array_equal(kn.view(np.uint32), g["new_camera"].view(np.uint32))
+    assert und.min() < und.max() and (und == 0).mean() < 0.01     # alpha = 0: no black border
