@@ -1,0 +1,94 @@
+"""Randomised parity sweep: many small scenes (sizes incl. odd ones, seeds, poses far from the identity, custom
+intrinsics) through the per-pixel stages that are claimed bit-exact — FCA planes, ICA planes, and the four depth stages.
+Each case is tiny; the sweep exists to hit the rare branches a single scene does not (found in r01: a 1-ulp pose-algebra
+difference that only showed on a 96x64 scene)."""
+import numpy as np
+import pytest
+from egomotion_with_local_loop_closures_amd import synth
+from helpers import oracle_problem, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(96, 64, 3, 101), (101, 75, 3, 102), (64, 48, 3, 103), (160, 120, 4, 104), (128, 72, 3, 105), (90, 110, 3, 106),
+         (200, 64, 3, 107), (64, 200, 3, 108), (96, 64, 3, 109), (96, 64, 3, 110), (117, 83, 3, 111), (240, 136, 4, 112),
+         (72, 56, 3, 113), (150, 100, 3, 114), (96, 96, 3, 115), (320, 64, 3, 116)]
+FIELDS = ("invDepth", "invDepthSmoothed", "variance", "varianceSmoothed", "validity", "blacklisted")
+
+
+def states_equal(got, ref, what):
+    m = ref["valid"] != 0
+    assert np.array_equal(got["valid"] != 0, m), what + ": valid mask"
+    assert np.array_equal(got["blacklisted"], ref["blacklisted"]), what + ": blacklisted"
+    for f in FIELDS[:5]:
+        assert bits_equal(got[f][m], ref[f][m]), "%s: %s (%d px differ)" % (what, f, int((got[f][m] != ref[f][m]).sum()))
+
+
+@pytest.mark.parametrize("w,h,L,seed", CASES)
+def test_random_scene_per_pixel_parity(oracle, ellc, w, h, L, seed):
+    rng = np.random.default_rng(seed)
+    rot = float(rng.uniform(0.002, 0.03)); trans = float(rng.uniform(0.005, 0.06))
+    pair = synth.make_pair(w, h, seed=seed, rot=rot, trans=trans)
+    # intrinsics away from the defaults (non-square pixels, off-centre principal point)
+    fx, fy, cx, cy = pair["intrinsics"]
+    pair["intrinsics"] = (fx * float(rng.uniform(0.8, 1.3)), fy * float(rng.uniform(0.8, 1.3)), cx + float(rng.uniform(-4, 4)),
+                          cy + float(rng.uniform(-3, 3)))
+    fx, fy, cx, cy = pair["intrinsics"]
+    ocfg, kf, cur, dm = oracle_problem(oracle, w, h, L, pair)
+    ctx = ellc.Context(ellc.default_config(w, h, L, fx=fx, fy=fy, cx=cx, cy=cy, max_keyframes=2, max_frames=1))
+    ctx.keyframe_upload(0, pair["kf_image"]); ctx.keyframe_set_depth(0, pair["depth0"], pair["var0"]); ctx.frame_upload(0, pair["cur_image"])
+    # ---- Gauss-Newton planes at every level, poses up to ~0.1 rad / 0.2 units away from the identity
+    for level in reversed(range(L)):   # coarse to fine: tracking leaves both frames at level 0, which the depth code relies on (Q11)
+        pose = (rng.normal(size=6) * [0.03, 0.03, 0.03, 0.06, 0.06, 0.06]).astype(np.float32)
+        mask = kf.depth(level) > 0
+        if mask.sum() < 20:
+            continue
+        st = oracle.GNStepper(kf, cur, dm.depth_pyr(), level, pose, planes=True)
+        st.step(0)
+        pl = st.get_planes()
+        got = ctx.gn_iterate(0, 0, level, pose, planes=True)
+        for name in ("residual", "weight", "warpedX", "warpedY"):
+            assert bits_equal(got[name][mask], pl[name][mask]), (level, name)
+        for k in range(6):
+            assert bits_equal(got["J"][k][mask], pl["J"][k][mask]), (level, "J%d" % k)
+        st.close()
+    # ---- constant-weight path: template-gradient Jacobian and residual at one level
+    for l in range(L):
+        wplane = rng.uniform(0.01, 0.0625, size=(h >> l, w >> l)).astype(np.float32)
+        kf.set_weights(l, wplane, 1); ctx.keyframe_set_weights(0, l, wplane, 1)
+    lvl = int(rng.integers(0, L))
+    pose = (rng.normal(size=6) * [0.01, 0.01, 0.01, 0.03, 0.03, 0.03]).astype(np.float32)
+    mask = kf.depth(lvl) > 0
+    if mask.sum() >= 20:
+        st = oracle.GNStepper(kf, cur, dm.depth_pyr(), lvl, pose, planes=True)
+        st.step(1, 0)
+        sd, _ = st.get_sd()
+        pl = st.get_planes()
+        got = ctx.gn_iterate(0, 0, lvl, pose, mode=1, it=0, planes=True)
+        sd = sd.reshape(6, h >> lvl, w >> lvl)
+        for k in range(6):
+            assert bits_equal(got["J"][k][mask], sd[k][mask]), ("ica J%d" % k, lvl)
+        assert bits_equal(got["residual"][mask], pl["residual"][mask]), ("ica residual", lvl)
+        st.close()
+        if lvl != 0:   # leave the oracle frames at level 0 for the depth code (Q11)
+            st = oracle.GNStepper(kf, cur, dm.depth_pyr(), 0, pose, planes=False)
+            st.close()
+    # ---- depth stages on a hypothesis map of the same scene, pose = the scene's true motion plus noise
+    xi = (np.asarray(pair["xi_true"]) + rng.normal(size=6) * 1e-3).astype(np.float32)
+    stt = synth.make_depth_state(w, h, seed + 1, pair["kf_image"], pair["idepth_true"])
+    ocur = oracle.Frame(ocfg, pair["cur_image"], 2)
+    ocur.set_pose(origin=xi, world=xi)
+    ctx.keyframe_from_frame(1, 0)
+
+    def fresh():
+        d = oracle.DepthMap(ocfg)
+        d.set_keyframe(kf); d.set_current(ocur); d.set_state(stt)
+        ctx.depth_set_keyframe(0); ctx.depth_set_state(stt)
+        return d
+    d = fresh(); d.regularize(True); ctx.depth_regularize(True); states_equal(ctx.depth_get_state(), d.get_state(), "regularize(occl)")
+    d.observe(); ctx.depth_observe(0, xi); states_equal(ctx.depth_get_state(), d.get_state(), "observe")
+    d.fill_holes(); ctx.depth_fill_holes(); states_equal(ctx.depth_get_state(), d.get_state(), "fill_holes")
+    d = fresh(); d.regularize(False); ctx.depth_regularize(False)
+    nk = oracle.Frame(ocfg, pair["cur_image"], 3)
+    nk.set_pose(origin=xi)
+    d.propagate(nk); ctx.depth_propagate(1, xi); states_equal(ctx.depth_get_state(), d.get_state(), "propagate")
+    ctx.close()
