@@ -431,8 +431,10 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     return ELLC_ERR_HIP;
   }
 #define TRY(expr) do { ellc_status s__ = (expr); if (s__ != ELLC_OK) { *out = c; return s__; } } while (0)
-  hipEventCreate(&c->ev0);
-  hipEventCreate(&c->ev1);
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    *out = c;
+    return fail(c, ELLC_ERR_HIP, "cannot create the timing events");
+  }
   // ---- level geometry + Jacobian tables (UserDefinedFunc.cpp:34-50; PixelWisePyramid.cpp:296-303)
   int sw = cfg->width, sh = cfg->height;
   c->tile_begin[0] = 0;
@@ -469,10 +471,13 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     double *dA, *dR;
     float *dB, *dRB;
     TRY(dev_alloc(c, &dA, g.cols)); TRY(dev_alloc(c, &dR, g.rows)); TRY(dev_alloc(c, &dB, g.cols)); TRY(dev_alloc(c, &dRB, g.rows));
-    hipMemcpy(dA, colA.data(), g.cols * 8, hipMemcpyHostToDevice);
-    hipMemcpy(dR, rowA.data(), g.rows * 8, hipMemcpyHostToDevice);
-    hipMemcpy(dB, colB.data(), g.cols * 4, hipMemcpyHostToDevice);
-    hipMemcpy(dRB, rowB.data(), g.rows * 4, hipMemcpyHostToDevice);
+    if (hipMemcpy(dA, colA.data(), g.cols * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dR, rowA.data(), g.rows * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dB, colB.data(), g.cols * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dRB, rowB.data(), g.rows * 4, hipMemcpyHostToDevice) != hipSuccess) {
+      *out = c;
+      return fail(c, ELLC_ERR_HIP, "cannot upload the Jacobian tables");
+    }
     g.colA = dA; g.rowA = dR; g.colB = dB; g.rowB = dRB;
     c->cap[l] = g.n;
     c->tile_begin[l + 1] = c->tile_begin[l] + (g.n + ELLC_TILE - 1) / ELLC_TILE;
@@ -480,7 +485,10 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     sh = (sh + 1) / 2;
   }
   TRY(dev_alloc(c, &c->geom_d, ELLC_MAX_LEVELS));
-  hipMemcpy(c->geom_d, c->geom_h, sizeof(LevelGeom) * c->L, hipMemcpyHostToDevice);
+  if (hipMemcpy(c->geom_d, c->geom_h, sizeof(LevelGeom) * c->L, hipMemcpyHostToDevice) != hipSuccess) {
+    *out = c;
+    return fail(c, ELLC_ERR_HIP, "cannot upload the level geometry");
+  }
   // ---- slots
   const int MK = cfg->max_keyframes, MF = cfg->max_frames;
   c->kf_tab_h.assign((size_t)c->L * MK, KfLevelDev());
@@ -502,8 +510,11 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   }
   TRY(dev_alloc(c, &c->kf_tab_d, c->kf_tab_h.size()));
   TRY(dev_alloc(c, &c->fr_tab_d, c->fr_tab_h.size()));
-  hipMemcpy(c->kf_tab_d, c->kf_tab_h.data(), c->kf_tab_h.size() * sizeof(KfLevelDev), hipMemcpyHostToDevice);
-  hipMemcpy(c->fr_tab_d, c->fr_tab_h.data(), c->fr_tab_h.size() * sizeof(FrLevelDev), hipMemcpyHostToDevice);
+  if (hipMemcpy(c->kf_tab_d, c->kf_tab_h.data(), c->kf_tab_h.size() * sizeof(KfLevelDev), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->fr_tab_d, c->fr_tab_h.data(), c->fr_tab_h.size() * sizeof(FrLevelDev), hipMemcpyHostToDevice) != hipSuccess) {
+    *out = c;
+    return fail(c, ELLC_ERR_HIP, "cannot upload the slot tables");
+  }
   c->kf_has_image.assign(MK, 0); c->kf_has_depth.assign(MK, 0); c->fr_has_image.assign(MF, 0);
   c->kf_num_weights.assign(MK, std::array<int, ELLC_MAX_LEVELS>{});
   c->kf_maxgrad.assign(MK, nullptr); c->fr_maxgrad.assign(MF, nullptr);
@@ -515,7 +526,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   // ---- alignment work buffers
   const int MB = cfg->max_batch;
   {  // one staging record per call: [kf_slot MB][fr_slot MB][unique MB][init_pose 6*MB], moved with a single copy
-    int *sd = nullptr, *shh = nullptr;
+    int* sd = nullptr;
     TRY(dev_alloc(c, &sd, (size_t)9 * MB));
     c->kf_slot_d = sd; c->fr_slot_d = sd + MB; c->uniq_slot_d = sd + 2 * MB; c->init_pose_d = (float*)(sd + 3 * MB);
     for (int p = 0; p < 2; p++) {
@@ -606,16 +617,16 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
 
 ellc_status ellc_ctx_destroy(ellc_ctx* c) {
   if (!c) return ELLC_ERR_BAD_ARG;
-  hipStreamSynchronize(c->stream);
-  for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
-  for (void* p : c->allocs) hipFree(p);
-  for (void* p : c->host_allocs) hipHostFree(p);
-  if (c->ingest_map) hipFree(c->ingest_map);
-  if (c->ingest_bgr) hipFree(c->ingest_bgr);
-  for (int p = 0; p < 2; p++) if (c->batch_set[p].done) hipEventDestroy(c->batch_set[p].done);
-  if (c->ev0) hipEventDestroy(c->ev0);
-  if (c->ev1) hipEventDestroy(c->ev1);
-  hipStreamDestroy(c->stream);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
+  for (void* p : c->allocs) (void)hipFree(p);
+  for (void* p : c->host_allocs) (void)hipHostFree(p);
+  if (c->ingest_map) (void)hipFree(c->ingest_map);
+  if (c->ingest_bgr) (void)hipFree(c->ingest_bgr);
+  for (int p = 0; p < 2; p++) if (c->batch_set[p].done) (void)hipEventDestroy(c->batch_set[p].done);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
   delete c;
   return ELLC_OK;
 }
@@ -887,7 +898,7 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
       if (s != ELLC_OK) return s;
       if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
       ELLC_HIP(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      hipGraphDestroy(graph);
+      (void)hipGraphDestroy(graph);
       it = c->graphs.emplace(key, exec).first;
     }
     ELLC_HIP(c, hipGraphLaunch(it->second, c->stream));
@@ -1036,9 +1047,8 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     fa.prev_level = level;
     fa.prev_nblk = a.nblk;
     fa.early_exit = 0;
-      fa.stride_state = c->cfg.max_batch;
+    fa.stride_state = c->cfg.max_batch;
     fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
-    const bool divc = c->geom_h[0].divc_ok != 0;
     auto launch = [&]() {
       launch_fused(c, grd, blk, fa, c->stream);
       fa.seq++;
@@ -1052,13 +1062,13 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
       for (int i = 0; i < reps; i++) launch();
       ELLC_HIP(c, hipStreamEndCapture(c->stream, &graph));
       ELLC_HIP(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      hipGraphDestroy(graph);
+      (void)hipGraphDestroy(graph);
       hipError_t e = hipGraphLaunch(exec, c->stream);   // warm
       if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
       if (e == hipSuccess) e = hipGraphLaunch(exec, c->stream);
       if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
       if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
-      hipGraphExecDestroy(exec);
+      (void)hipGraphExecDestroy(exec);
       if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("profile graph: ") + hipGetErrorString(e));
     } else {
       ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
@@ -1149,7 +1159,7 @@ ellc_status ellc_selftest_div_pair(ellc_ctx* c, int n, const float* a, const flo
   if (e == hipSuccess) e = hipMemcpyAsync(q_pair, d + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(q_ref, d + 3 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(d);
+  (void)hipFree(d);
   if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("selftest_div_pair: ") + hipGetErrorString(e));
   return ELLC_OK;
 }
@@ -1184,8 +1194,8 @@ ellc_status ellc_selftest_lu(ellc_ctx* c, int n, const double* tri21, float* inv
   }
   if (e == hipSuccess) e = hipMemcpyAsync(inv36, o, (size_t)n * 36 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(d);
-  if (o) hipFree(o);
+  (void)hipFree(d);
+  if (o) (void)hipFree(o);
   if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("selftest_lu: ") + hipGetErrorString(e));
   return ELLC_OK;
 }
@@ -1204,7 +1214,7 @@ ellc_status ellc_profile_calibrate_read(ellc_ctx* c, size_t bytes, int reps, flo
   float ms = 0;
   ELLC_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   if (avg_ms) *avg_ms = ms / reps;
-  hipFree(buf);
+  (void)hipFree(buf);
   return ELLC_OK;
 }
 

@@ -170,8 +170,8 @@ ellc_status ellc_ingest_configure(ellc_ctx* c, int orig_w, int orig_h, float fx,
     for (int dx = 0; dx < ow; dx++)
       for (int q = 0; q < 4; q++)
         need[((size_t)dy * ow + dx) * 4 + q] = full[(size_t)(4 * dy + 1 + (q >> 1)) * orig_w + (4 * dx + 1 + (q & 1))];
-  if (c->ingest_map) hipFree(c->ingest_map);
-  if (c->ingest_bgr) hipFree(c->ingest_bgr);
+  if (c->ingest_map) (void)hipFree(c->ingest_map);
+  if (c->ingest_bgr) (void)hipFree(c->ingest_bgr);
   c->ingest_map = nullptr;
   c->ingest_bgr = nullptr;
   ELLC_HIP(c, hipMalloc(&c->ingest_map, need.size() * sizeof(IngestMapEntry)));
@@ -203,8 +203,8 @@ ellc_status ellc_frame_ingest_bgr(ellc_ctx* c, int slot, const uint8_t* bgr, uin
   if (e == hipSuccess && gd) e = hipMemcpyAsync(gray_probe, gd, (size_t)ow * oh, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess && ud) e = hipMemcpyAsync(undistorted_probe, ud, (size_t)ow * oh * 4, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the host frame buffer may be pageable
-  if (gd) hipFree(gd);
-  if (ud) hipFree(ud);
+  if (gd) (void)hipFree(gd);
+  if (ud) (void)hipFree(ud);
   if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("ellc_frame_ingest_bgr: ") + hipGetErrorString(e));
   c->fr_has_image[slot] = 1;
   c->fr_maxgrad_valid[slot] = 0;
