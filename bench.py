@@ -137,7 +137,8 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "gn_fca_fused (level 0, batch %d): solve of the previous iteration + residual/Jacobian/accumulate" % B, "achieved": achieved, "peak": 8000.0,
                            "unit": "GB/s", "frac": achieved / 8000.0, "traffic": pmc_traffic(a, B), "avg_launch_ms": ms,
                            "algorithmic_bytes_per_launch": alg_bytes, "valid_pixels_per_launch": V,
-                           "valid_pixel_rate_Gpx_s": V / (ms * 1e-3) / 1e9}
+                           "valid_pixel_rate_Gpx_s": V / (ms * 1e-3) / 1e9,
+                           "level0_gn_iterations_per_s": B / (ms * 1e-3)}
         # ---- C1: the same path at B = 1 (latency-bound single alignment), for reference
         pose1, it1, _ = ctx.align([0], [0], mode=mode)
         n1 = 20
@@ -147,6 +148,8 @@ def main():
         d1 = (time.perf_counter() - t1) / n1
         out["single_alignment"] = {"workload": "C1: one keyframe vs one frame, same sizes/schedule", "ms_per_alignment": 1e3 * d1,
                                    "gn_iterations_per_s": iters_per_alignment / d1}
+        if world == 1:
+            out["early_exit_on"] = early_exit_run(api, cfg, pairs, a, slots, mode)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a, pairs[0], sched, value)
         print(json.dumps(out), flush=True)
@@ -154,6 +157,37 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def early_exit_run(api, cfg, pairs, a, slots, mode):
+    """Informational (SURVEY.md §8d iii): the same batch with the reference's early exit on (a level stops once
+    weightedPose < 1, ImageFunc.cpp:251-252), so the iteration count is data dependent. Not part of `value`."""
+    B, L, W, H = a.batch, a.levels, a.width, a.height
+    ctx = None
+    try:
+        cfg2 = type(cfg).from_buffer_copy(cfg)
+        cfg2.early_exit = 1
+        ctx = api.Context(cfg2)
+        for b in range(B):
+            p = pairs[b % len(pairs)]
+            ctx.keyframe_upload(b, p["kf_image"])
+            ctx.keyframe_set_depth(b, p["depth0"], p["var0"])
+            ctx.frame_upload(b, p["cur_image"])
+            if a.mode == "ica":
+                for l in range(L):
+                    ctx.keyframe_set_weights(b, l, np.full((H >> l, W >> l), 0.03, np.float32), 1)
+        _, iters, _ = ctx.align(slots, slots, mode=mode)
+        n = 10
+        t = time.perf_counter()
+        for _ in range(n):
+            ctx.align(slots, slots, mode=mode)
+        d = (time.perf_counter() - t) / n
+        done = int(np.asarray(iters).sum())
+        return {"ms_per_batch": 1e3 * d, "alignments_per_s": B / d, "gn_iterations_per_s": done / d,
+                "mean_iterations_per_alignment": done / B}
+    finally:
+        if ctx is not None:
+            ctx.close()
 
 
 def pmc_traffic(a, B):
