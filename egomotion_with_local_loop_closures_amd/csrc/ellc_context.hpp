@@ -104,6 +104,17 @@ ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg);
     if (e__ != hipSuccess) return ellc::fail(ctx, ELLC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
   } while (0)
 
+// Every entry point makes the context's device current for the calling thread first: HIP's current device is per
+// thread, and the reference calls GetImagePoseEstimate from a second (loop-closure) thread (GlobalOptimize.cpp:241).
+ellc_status enter(ellc_ctx* c);
+#define ELLC_ENTER(ctx)                          \
+  do {                                           \
+    if (ctx) {                                   \
+      const ellc_status s__ = ellc::enter(ctx);  \
+      if (s__ != ELLC_OK) return s__;            \
+    }                                            \
+  } while (0)
+
 int choose_nblk(const ellc_ctx* c, int level, int B);
 ellc_status run_prep(ellc_ctx* c, int n_unique, int need);
 ellc_status build_depth_pyramid(ellc_ctx* c, int slot);

@@ -140,6 +140,7 @@ ellc_status do_propagate(ellc_ctx* c, int new_kf_slot, const float* pose_new_wrt
 extern "C" {
 
 ellc_status ellc_depth_set_state(ellc_ctx* c, const ellc_hypotheses* h) {
+  ELLC_ENTER(c);
   if (!c || !h || !h->invDepth || !h->invDepthSmoothed || !h->variance || !h->varianceSmoothed || !h->validity_counter || !h->blacklisted || !h->isValid)
     return fail(c, ELLC_ERR_BAD_ARG, "ellc_depth_set_state: null array");
   const size_t n = (size_t)c->cfg.width * c->cfg.height;
@@ -157,6 +158,7 @@ ellc_status ellc_depth_set_state(ellc_ctx* c, const ellc_hypotheses* h) {
 }
 
 ellc_status ellc_depth_get_state(ellc_ctx* c, const ellc_hypotheses* h) {
+  ELLC_ENTER(c);
   if (!c || !h) return fail(c, ELLC_ERR_BAD_ARG, "ellc_depth_get_state: null");
   const size_t n = (size_t)c->cfg.width * c->cfg.height;
   const DepthSoA& d = c->dm_cur;
@@ -172,6 +174,7 @@ ellc_status ellc_depth_get_state(ellc_ctx* c, const ellc_hypotheses* h) {
 }
 
 ellc_status ellc_depth_set_keyframe(ellc_ctx* c, int kf_slot) {
+  ELLC_ENTER(c);
   if (!c || kf_slot < 0 || kf_slot >= c->cfg.max_keyframes) return fail(c, ELLC_ERR_BAD_ARG, "bad keyframe slot");
   if (!c->kf_has_image[kf_slot]) return fail(c, ELLC_ERR_NOT_READY, "keyframe slot has no image");
   c->dm_kf_slot = kf_slot;
@@ -180,12 +183,14 @@ ellc_status ellc_depth_set_keyframe(ellc_ctx* c, int kf_slot) {
 }
 
 ellc_status ellc_depth_propagate(ellc_ctx* c, int new_kf_slot, const float* pose_new_wrt_old) {
+  ELLC_ENTER(c);
   ellc_status s = need_map(c);
   if (s != ELLC_OK) return s;
   return do_propagate(c, new_kf_slot, pose_new_wrt_old);
 }
 
 ellc_status ellc_depth_observe(ellc_ctx* c, int frame_slot, const float* pose_frame_wrt_kf) {
+  ELLC_ENTER(c);
   ellc_status s = need_map(c);
   if (s != ELLC_OK) return s;
   if (frame_slot < 0 || frame_slot >= c->cfg.max_frames || !pose_frame_wrt_kf) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
@@ -215,30 +220,35 @@ ellc_status ellc_depth_observe(ellc_ctx* c, int frame_slot, const float* pose_fr
 }
 
 ellc_status ellc_depth_fill_holes(ellc_ctx* c) {
+  ELLC_ENTER(c);
   ellc_status s = need_map(c);
   if (s != ELLC_OK) return s;
   return do_fill_holes(c);
 }
 
 ellc_status ellc_depth_regularize(ellc_ctx* c, int remove_occlusions) {
+  ELLC_ENTER(c);
   ellc_status s = need_map(c);
   if (s != ELLC_OK) return s;
   return do_regularize(c, remove_occlusions);
 }
 
 ellc_status ellc_depth_make_inv_depth_one(ellc_ctx* c, float* rescale_factor) {
+  ELLC_ENTER(c);
   ellc_status s = need_map(c);
   if (s != ELLC_OK) return s;
   return do_rescale(c, rescale_factor);
 }
 
 ellc_status ellc_depth_update_depth_image(ellc_ctx* c) {
+  ELLC_ENTER(c);
   ellc_status s = need_map(c);
   if (s != ELLC_OK) return s;
   return do_update_depth_image(c);
 }
 
 ellc_status ellc_depth_create_keyframe(ellc_ctx* c, int new_kf_slot, const float* pose_new_wrt_old, float* rescale_factor) {
+  ELLC_ENTER(c);
   ellc_status s = need_map(c);
   if (s != ELLC_OK) return s;
   if ((s = do_propagate(c, new_kf_slot, pose_new_wrt_old)) != ELLC_OK) return s;   // :1769
@@ -251,6 +261,7 @@ ellc_status ellc_depth_create_keyframe(ellc_ctx* c, int new_kf_slot, const float
 }
 
 ellc_status ellc_depth_seeds(ellc_ctx* c, float* percent) {
+  ELLC_ENTER(c);
   ellc_status s = need_map(c);
   if (s != ELLC_OK) return s;
   const int n = c->cfg.width * c->cfg.height;

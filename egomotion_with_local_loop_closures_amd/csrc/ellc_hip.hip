@@ -8,6 +8,8 @@
 #include <cmath>
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 using namespace ellc;
 
@@ -16,6 +18,13 @@ namespace ellc {
 ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg) {
   if (c) c->err = msg;
   return s;
+}
+
+ellc_status enter(ellc_ctx* c) {
+  int dev = -1;
+  if (hipGetDevice(&dev) == hipSuccess && dev == c->cfg.device) return ELLC_OK;
+  if (hipSetDevice(c->cfg.device) != hipSuccess) return fail(c, ELLC_ERR_HIP, "cannot make the context's device current");
+  return ELLC_OK;
 }
 
 template <class T>
@@ -185,6 +194,8 @@ __attribute__((target("fma"))) static bool verify_div_const_fma(float b) {
 }
 static bool verify_div_const(float b) {
   static std::map<uint32_t, bool> cache;
+  static std::mutex cache_mutex;   // contexts may be created from several threads
+  std::lock_guard<std::mutex> lock(cache_mutex);
   if (!(b > 0.0f) || !std::isfinite(b)) return false;
   if (!__builtin_cpu_supports("fma")) return false;   // no hardware fma on this host: keep the plain divisions
   uint32_t bits;
@@ -408,6 +419,7 @@ const char* ellc_last_error(const ellc_ctx* ctx) { return ctx ? ctx->err.c_str()
 void* ellc_stream(ellc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 ellc_status ellc_sync(ellc_ctx* c) {
+  ELLC_ENTER(c);
   if (!c) return ELLC_ERR_BAD_ARG;
   ELLC_HIP(c, hipStreamSynchronize(c->stream));
   return ELLC_OK;
@@ -616,6 +628,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
 }
 
 ellc_status ellc_ctx_destroy(ellc_ctx* c) {
+  ELLC_ENTER(c);
   if (!c) return ELLC_ERR_BAD_ARG;
   (void)hipStreamSynchronize(c->stream);
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
@@ -633,6 +646,7 @@ ellc_status ellc_ctx_destroy(ellc_ctx* c) {
 
 // ---- frame side ----------------------------------------------------------------------------------
 ellc_status ellc_frame_upload(ellc_ctx* c, int slot, const uint8_t* image) {
+  ELLC_ENTER(c);
   if (!c || !image || !slot_ok(slot, c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_frame_upload: bad argument");
   uint8_t* img[ELLC_MAX_LEVELS];
   for (int l = 0; l < c->L; l++) img[l] = c->fr_tab_h[(size_t)l * c->cfg.max_frames + slot].img;
@@ -644,6 +658,7 @@ ellc_status ellc_frame_upload(ellc_ctx* c, int slot, const uint8_t* image) {
 }
 
 ellc_status ellc_keyframe_upload(ellc_ctx* c, int slot, const uint8_t* image) {
+  ELLC_ENTER(c);
   if (!c || !image || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_keyframe_upload: bad argument");
   uint8_t* img[ELLC_MAX_LEVELS];
   for (int l = 0; l < c->L; l++) img[l] = c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + slot].img;
@@ -658,6 +673,7 @@ ellc_status ellc_keyframe_upload(ellc_ctx* c, int slot, const uint8_t* image) {
 }
 
 ellc_status ellc_keyframe_from_frame(ellc_ctx* c, int kf_slot, int frame_slot) {
+  ELLC_ENTER(c);
   if (!c || !slot_ok(kf_slot, c->cfg.max_keyframes) || !slot_ok(frame_slot, c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "bad slot");
   if (!c->fr_has_image[frame_slot]) return fail(c, ELLC_ERR_NOT_READY, "frame slot empty");
   for (int l = 0; l < c->L; l++) {
@@ -673,6 +689,7 @@ ellc_status ellc_keyframe_from_frame(ellc_ctx* c, int kf_slot, int frame_slot) {
 }
 
 ellc_status ellc_get_image_level(ellc_ctx* c, int is_kf, int slot, int level, uint8_t* out, int* stored_w, int* stored_h, int* cols, int* rows) {
+  ELLC_ENTER(c);
   if (!c || level < 0 || level >= c->L || !slot_ok(slot, is_kf ? c->cfg.max_keyframes : c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (!(is_kf ? c->kf_has_image[slot] : c->fr_has_image[slot])) return fail(c, ELLC_ERR_NOT_READY, "slot empty");
   const LevelGeom& g = c->geom_h[level];
@@ -689,6 +706,7 @@ ellc_status ellc_get_image_level(ellc_ctx* c, int is_kf, int slot, int level, ui
 }
 
 ellc_status ellc_get_gradient(ellc_ctx* c, int is_kf, int slot, int level, float* gx, float* gy) {
+  ELLC_ENTER(c);
   if (!c || !gx || !gy || level < 0 || level >= c->L || !slot_ok(slot, is_kf ? c->cfg.max_keyframes : c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (!(is_kf ? c->kf_has_image[slot] : c->fr_has_image[slot])) return fail(c, ELLC_ERR_NOT_READY, "slot empty");
   const LevelGeom& g = c->geom_h[level];
@@ -703,6 +721,7 @@ ellc_status ellc_get_gradient(ellc_ctx* c, int is_kf, int slot, int level, float
 }
 
 ellc_status ellc_get_max_gradient(ellc_ctx* c, int is_kf, int slot, float* out, int* n_substantial) {
+  ELLC_ENTER(c);
   if (!c || !slot_ok(slot, is_kf ? c->cfg.max_keyframes : c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (!(is_kf ? c->kf_has_image[slot] : c->fr_has_image[slot])) return fail(c, ELLC_ERR_NOT_READY, "slot empty");
   if (!(is_kf ? c->kf_maxgrad_valid[slot] : c->fr_maxgrad_valid[slot])) {
@@ -718,6 +737,7 @@ ellc_status ellc_get_max_gradient(ellc_ctx* c, int is_kf, int slot, float* out, 
 
 // ---- keyframe depth / variance / weights -----------------------------------------------------------
 ellc_status ellc_keyframe_set_depth(ellc_ctx* c, int slot, const float* depth0, const float* var0) {
+  ELLC_ENTER(c);
   if (!c || !depth0 || !var0 || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   const KfLevelDev& k = c->kf_tab_h[slot];
   const size_t n0 = (size_t)c->geom_h[0].n;
@@ -731,6 +751,7 @@ ellc_status ellc_keyframe_set_depth(ellc_ctx* c, int slot, const float* depth0, 
 }
 
 ellc_status ellc_keyframe_set_depth_level(ellc_ctx* c, int slot, int level, const float* depth, const float* var) {
+  ELLC_ENTER(c);
   if (!c || !depth || !var || level < 0 || level >= c->L || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   const KfLevelDev& k = c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + slot];
   ELLC_HIP(c, hipMemcpyAsync(k.depth, depth, (size_t)c->geom_h[level].n * 4, hipMemcpyHostToDevice, c->stream));
@@ -741,6 +762,7 @@ ellc_status ellc_keyframe_set_depth_level(ellc_ctx* c, int slot, int level, cons
 }
 
 ellc_status ellc_keyframe_get_depth_level(ellc_ctx* c, int slot, int level, float* depth, float* var) {
+  ELLC_ENTER(c);
   if (!c || level < 0 || level >= c->L || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   const KfLevelDev& k = c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + slot];
   if (depth) ELLC_HIP(c, hipMemcpyAsync(depth, k.depth, (size_t)c->geom_h[level].n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -750,6 +772,7 @@ ellc_status ellc_keyframe_get_depth_level(ellc_ctx* c, int slot, int level, floa
 }
 
 ellc_status ellc_keyframe_set_weights(ellc_ctx* c, int slot, int level, const float* w, int num_added) {
+  ELLC_ENTER(c);
   if (!c || !w || level < 0 || level >= c->L || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   const KfLevelDev& k = c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + slot];
   ELLC_HIP(c, hipMemcpyAsync(k.weight, w, (size_t)c->geom_h[level].n * 4, hipMemcpyHostToDevice, c->stream));
@@ -759,6 +782,7 @@ ellc_status ellc_keyframe_set_weights(ellc_ctx* c, int slot, int level, const fl
 }
 
 ellc_status ellc_keyframe_get_weights(ellc_ctx* c, int slot, int level, float* w, int* num_added) {
+  ELLC_ENTER(c);
   if (!c || level < 0 || level >= c->L || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   const KfLevelDev& k = c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + slot];
   if (w) {
@@ -770,6 +794,7 @@ ellc_status ellc_keyframe_get_weights(ellc_ctx* c, int slot, int level, float* w
 }
 
 ellc_status ellc_keyframe_finalise_weights(ellc_ctx* c, int slot) {
+  ELLC_ENTER(c);
   if (!c || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   for (int l = c->L - 1; l >= 0; l--) {
     const int na = c->kf_num_weights[slot][l];
@@ -785,6 +810,7 @@ ellc_status ellc_keyframe_finalise_weights(ellc_ctx* c, int slot) {
 
 // ---- loop-closure support ----------------------------------------------------------------------------
 ellc_status ellc_histogram(ellc_ctx* c, int is_kf, int slot, float* hist256) {
+  ELLC_ENTER(c);
   if (!c || !hist256 || !slot_ok(slot, is_kf ? c->cfg.max_keyframes : c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (!(is_kf ? c->kf_has_image[slot] : c->fr_has_image[slot])) return fail(c, ELLC_ERR_NOT_READY, "slot empty");
   const LevelGeom& g = c->geom_h[0];
@@ -815,6 +841,7 @@ double ellc_kl_divergence(const float* p, const float* q, int n) {
 }
 
 ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, int src) {
+  ELLC_ENTER(c);
   if (!c || !slot_ok(dst, dst_is_kf ? c->cfg.max_keyframes : c->cfg.max_frames) || !slot_ok(src, src_is_kf ? c->cfg.max_keyframes : c->cfg.max_frames))
     return fail(c, ELLC_ERR_BAD_ARG, "bad slot");
   if (!(src_is_kf ? c->kf_has_image[src] : c->fr_has_image[src])) return fail(c, ELLC_ERR_NOT_READY, "source slot empty");
@@ -918,10 +945,12 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
 }
 
 ellc_status ellc_align_enqueue(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int save_weights) {
+  ELLC_ENTER(c);
   return align_enqueue_impl(c, B, kf_slots, frame_slots, init_pose, mode, save_weights, true);
 }
 
 ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters, float* out_weighted) {
+  ELLC_ENTER(c);
   if (!c || B < 1 || B > c->cfg.max_batch) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (c->n_inflight < 1) return fail(c, ELLC_ERR_NOT_READY, "ellc_align_fetch: no batch in flight");
   const ellc_ctx::BatchSet& bs = c->batch_set[c->inflight[0]];   // the oldest batch
@@ -938,6 +967,7 @@ ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters
 
 ellc_status ellc_align(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int save_weights,
                        float* out_pose, int* out_iters, float* out_weighted) {
+  ELLC_ENTER(c);
   if (c && c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_align: fetch the enqueued batches first");
   ellc_status s = ellc_align_enqueue(c, B, kf_slots, frame_slots, init_pose, mode, save_weights);
   if (s != ELLC_OK) return s;
@@ -956,6 +986,7 @@ __global__ void gn_set_pose0(AlignState* state, const float* pose) {
 
 ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level, int mode, int iter, const float* pose, float* H36, float* b6,
                             float* delta6, float* new_pose6, float* weighted, float* planes) {
+  ELLC_ENTER(c);
   if (!c || !pose || level < 0 || level >= c->L) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_gn_iterate: fetch the enqueued batches first");
   int nu = 0;
@@ -1025,6 +1056,7 @@ void ellc_se3_log(const float* T16, float* pose6) {
 // ---- measurement hooks -------------------------------------------------------------------------------
 ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, int level, int reps, float* avg_ms,
                                    double* algorithmic_bytes, long long* valid_pixels) {
+  ELLC_ENTER(c);
   if (!c || level < 0 || level >= c->L || reps < 1) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_profile_gn_kernel: fetch the enqueued batches first");
   int nu = 0;
@@ -1097,6 +1129,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
 }
 
 ellc_status ellc_profile_align(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int reps, float* avg_ms) {
+  ELLC_ENTER(c);
   if (!c || reps < 1) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_profile_align: fetch the enqueued batches first");
   ellc_status s = align_enqueue_impl(c, B, kf_slots, frame_slots, init_pose, mode, 0, false);
@@ -1124,11 +1157,13 @@ __global__ __launch_bounds__(256) void calib_read_f32(const float* __restrict__ 
 #ifdef ELLC_STAMPS
 // diagnostic build only: copies the cycle stamps of block (0,0) of the last fused launch
 ellc_status ellc_debug_stamps(ellc_ctx* c, unsigned long long* out64) {
+  ELLC_ENTER(c);
   ELLC_HIP(c, hipStreamSynchronize(c->stream));
   ELLC_HIP(c, hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_stamps), 64 * sizeof(unsigned long long)));
   return ELLC_OK;
 }
 ellc_status ellc_debug_block_stamps(ellc_ctx* c, unsigned long long* out, int nblocks) {
+  ELLC_ENTER(c);
   ELLC_HIP(c, hipStreamSynchronize(c->stream));
   ELLC_HIP(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_stamps), (size_t)nblocks * 4 * sizeof(unsigned long long)));
   return ELLC_OK;
@@ -1147,6 +1182,7 @@ __global__ void selftest_div_pair(const float* a, const float* b, float* q_pair,
   q_ref[2 * i + 1] = a[2 * i + 1] / b[2 * i + 1];
 }
 ellc_status ellc_selftest_div_pair(ellc_ctx* c, int n, const float* a, const float* b, float* q_pair, float* q_ref) {
+  ELLC_ENTER(c);
   if (!c || n < 2 || (n & 1) || !a || !b || !q_pair || !q_ref) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   float* d = nullptr;
   ELLC_HIP(c, hipMalloc(&d, (size_t)4 * n * sizeof(float)));
@@ -1182,6 +1218,7 @@ __global__ void selftest_lu(const double* tri21, float* inv36, int n) {
     for (int r = 0; r < 6; r++) inv36[(size_t)m * 36 + r * 6 + lane] = x[r];
 }
 ellc_status ellc_selftest_lu(ellc_ctx* c, int n, const double* tri21, float* inv36) {
+  ELLC_ENTER(c);
   if (!c || n < 1 || !tri21 || !inv36) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   double* d = nullptr;
   float* o = nullptr;
@@ -1201,6 +1238,7 @@ ellc_status ellc_selftest_lu(ellc_ctx* c, int n, const double* tri21, float* inv
 }
 
 ellc_status ellc_profile_calibrate_read(ellc_ctx* c, size_t bytes, int reps, float* avg_ms) {
+  ELLC_ENTER(c);
   if (!c || reps < 1 || bytes < 1024) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   float* buf = nullptr;
   ELLC_HIP(c, hipMalloc((void**)&buf, bytes));

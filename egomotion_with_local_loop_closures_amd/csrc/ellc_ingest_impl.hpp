@@ -151,6 +151,7 @@ extern "C" {
 
 ellc_status ellc_ingest_configure(ellc_ctx* c, int orig_w, int orig_h, float fx, float fy, float cx, float cy, const float* dist5,
                                   int do_undistort, float* new_camera4) {
+  ELLC_ENTER(c);
   using namespace ellc;
   if (!c || orig_w < 8 || orig_h < 8 || (do_undistort && !dist5)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_ingest_configure: bad argument");
   if (orig_w != 4 * c->cfg.width || orig_h != 4 * c->cfg.height)
@@ -183,6 +184,7 @@ ellc_status ellc_ingest_configure(ellc_ctx* c, int orig_w, int orig_h, float fx,
 }
 
 ellc_status ellc_frame_ingest_bgr(ellc_ctx* c, int slot, const uint8_t* bgr, uint8_t* gray_probe, uint8_t* undistorted_probe) {
+  ELLC_ENTER(c);
   using namespace ellc;
   if (!c || !bgr || !slot_ok(slot, c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_frame_ingest_bgr: bad argument");
   if (!c->ingest_map) return fail(c, ELLC_ERR_NOT_READY, "ellc_frame_ingest_bgr: call ellc_ingest_configure first");

@@ -275,3 +275,33 @@ def test_lu_inverse_matches_the_scalar_algorithm_bit_for_bit(ellc, oracle):
             (np.isnan(ref).any() and np.isnan(g).any()), (m, ref, g)
         nsing += int(not np.any(g))
     assert nsing >= 3
+
+
+def test_two_contexts_on_two_threads(ellc):
+    """The reference tracks on the main thread while a loop-closure thread runs its own alignments (GlobalOptimize.cpp:241):
+    two contexts driven concurrently from two host threads (one of them not the creating thread) give, every time, the
+    bits each context gives when it runs alone."""
+    import threading
+    pairs_a = [synth.make_pair(W, H, seed=90 + i) for i in range(2)]
+    pairs_b = [synth.make_pair(W, H, seed=95 + i, rot=0.01) for i in range(3)]
+    ctx_a = gpu_problem(ellc, W, H, L, pairs_a, early_exit=1)
+    ctx_b = gpu_problem(ellc, W, H, L, pairs_b, early_exit=0)
+    ref_a = ctx_a.align([0, 1], [0, 1])
+    ref_b = ctx_b.align([0, 1, 2], [0, 1, 2], mode=0)
+    bad = []
+
+    def work(ctx, slots, ref, reps):
+        try:
+            for _ in range(reps):
+                pose, iters, wgt = ctx.align(slots, slots)
+                if not (np.array_equal(pose, ref[0]) and np.array_equal(iters, ref[1]) and np.array_equal(wgt, ref[2])):
+                    bad.append("result differs")
+        except Exception as e:   # noqa: BLE001
+            bad.append(repr(e))
+
+    ta = threading.Thread(target=work, args=(ctx_a, [0, 1], ref_a, 25))
+    tb = threading.Thread(target=work, args=(ctx_b, [0, 1, 2], ref_b, 25))
+    ta.start(); tb.start()
+    ta.join(); tb.join()
+    ctx_a.close(); ctx_b.close()
+    assert not bad, bad[:3]
