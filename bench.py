@@ -125,7 +125,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C2/C3: %d independent keyframe<->frame alignments per GPU, %dx%d, %d-level pyramid, %s Gauss-Newton, "
                                "fixed schedule %s (early exit off), per-call mask compaction included%s"
-                               % (B, W, H, L, a.mode.upper(), sched, ", RCCL all_gather of poses per step (overlapped with the next batch)" if world > 1 else ""),
+                               % (B, W, H, L, a.mode.upper(), sched, ", one all_gather of poses per step over %s (overlapped with the next batch)" % ("RCCL" if a.backend == "nccl" else a.backend) if world > 1 else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "gn_iterations_per_alignment": iters_per_alignment,
                    "alignments_per_s": world * B * a.steps / dt, "pixels": "dense" if a.dense else "semi-dense (maxAbsGradient>=5)"},
     }
