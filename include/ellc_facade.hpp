@@ -26,6 +26,31 @@
 
 namespace ellc {
 
+// Text checkpoint format of the reference (Frame.cpp:697-871): default ostream formatting of float (6 significant digits,
+// %g style), one blank after every value; a Mat ends each row with '\n', an array is a single line. Host-only helpers.
+namespace text {
+inline void writeMat(const std::string& path, const float* data, int width, int height) {
+  std::ofstream f(path.c_str());
+  if (!f) throw std::runtime_error("saveMatAsText: cannot open " + path);
+  for (int y = 0; y < height; y++) {
+    for (int x = 0; x < width; x++) f << data[(size_t)y * width + x] << " ";
+    f << "\n";
+  }
+}
+inline void writeArray(const std::string& path, const float* data, size_t n) {
+  std::ofstream f(path.c_str());
+  if (!f) throw std::runtime_error("saveArrayAsText: cannot open " + path);
+  for (size_t i = 0; i < n; i++) f << data[i] << " ";
+}
+// whitespace-separated values, rows and single lines alike (makeMatFromText / makeArrayFromText, Frame.cpp:738-810): the
+// same `stream >> element` per entry, so entries a short file does not hold are left as they were
+inline void readValues(const std::string& path, float* data, size_t n) {
+  std::ifstream f(path.c_str());
+  if (!f) throw std::runtime_error("makeMatFromText: cannot open " + path);
+  for (size_t i = 0; i < n; i++) f >> data[i];
+}
+}  // namespace text
+
 // Owner of the context and of the slot bookkeeping (keyframe slots: active + incoming; frame slots: ring).
 class Runtime {
  public:
@@ -119,36 +144,25 @@ class frame {
   void saveMatAsText(const std::string& name, const std::string& save_mat_path) const {   // name: "Depth" | "Depth_pyr0"
     std::vector<float> d, v;
     level0(d, v);
-    std::ofstream f(matFileName(name, save_mat_path).c_str());
-    if (!f) throw std::runtime_error("saveMatAsText: cannot open " + matFileName(name, save_mat_path));
-    for (int y = 0; y < height; y++) {
-      for (int x = 0; x < width; x++) f << d[(size_t)y * width + x] << " ";
-      f << "\n";
-    }
+    text::writeMat(matFileName(name, save_mat_path), d.data(), width, height);
   }
   void saveArrayAsText(const std::string& name, const std::string& save_arr_path, int pyr_level) const {   // "DepthVarArr_pyr0"
     if (pyr_level != 0) throw std::runtime_error("saveArrayAsText: only level 0 is checkpointed (ImageFunc.cpp:84)");
     std::vector<float> d, v;
     level0(d, v);
-    std::ofstream f(matFileName(name, save_arr_path).c_str());
-    if (!f) throw std::runtime_error("saveArrayAsText: cannot open " + matFileName(name, save_arr_path));
-    for (size_t i = 0; i < v.size(); i++) f << v[i] << " ";
+    text::writeArray(matFileName(name, save_arr_path), v.data(), v.size());
   }
   void makeMatFromText(const std::string& name, const std::string& read_txt_path) {
     std::vector<float> d, v;
     level0(d, v);
-    std::ifstream f(matFileName(name, read_txt_path).c_str());
-    if (!f) throw std::runtime_error("makeMatFromText: cannot open " + matFileName(name, read_txt_path));
-    for (size_t i = 0; i < d.size(); i++) f >> d[i];
+    text::readValues(matFileName(name, read_txt_path), d.data(), d.size());
     rt->check(ellc_keyframe_set_depth_level(rt->ctx, kf_slot, 0, d.data(), v.data()), "ellc_keyframe_set_depth_level");
   }
   void makeArrayFromText(const std::string& name, const std::string& read_txt_path, int pyr_level) {
     if (pyr_level != 0) throw std::runtime_error("makeArrayFromText: only level 0 is checkpointed (ImageFunc.cpp:65)");
     std::vector<float> d, v;
     level0(d, v);
-    std::ifstream f(matFileName(name, read_txt_path).c_str());
-    if (!f) throw std::runtime_error("makeArrayFromText: cannot open " + matFileName(name, read_txt_path));
-    for (size_t i = 0; i < v.size(); i++) f >> v[i];
+    text::readValues(matFileName(name, read_txt_path), v.data(), v.size());
     rt->check(ellc_keyframe_set_depth_level(rt->ctx, kf_slot, 0, d.data(), v.data()), "ellc_keyframe_set_depth_level");
   }
   void finaliseWeights() {   // Frame.cpp:678-695
