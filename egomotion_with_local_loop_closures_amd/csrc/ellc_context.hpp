@@ -49,18 +49,33 @@ struct ellc_ctx {
   ellc::AlignResult* result_h = nullptr;            // pinned; written by the last kernel of a schedule through result_dev_alias
   ellc::AlignResult* result_dev_alias = nullptr;
   const int* stage_dev_alias = nullptr;             // device-side address of the pinned staging record (kf_slot_h ...)
-  // Two batches may be in flight (ellc_align_enqueue twice before ellc_align_fetch): the pinned staging and result records
-  // exist twice; the members above point at the set of the batch being enqueued. Device state is shared — the stream
-  // runs the batches in order.
+  // Up to SETS batches may be in flight (ellc_align_enqueue several times before ellc_align_fetch). Every set has its own
+  // pinned staging / result records and device work buffers (staged slots, AlignState, block partials); set 0 runs on the
+  // context's main stream, sets 1 and 2 on streams of their own (created when first needed: a process holds few hardware
+  // queues, and streams that end up on the same one do not overlap), so the batches run CONCURRENTLY: the latency-bound coarse iterations of one batch overlap the throughput-bound fine
+  // iterations of another (r01: 0.55 -> 0.36 ms per batch of 32 with three in flight). Batches that share a keyframe
+  // slot are ordered one after the other (the compaction, H^-1 and the saved weights live in the keyframe slot). The
+  // members above point at the set of the batch being enqueued. All other entry points work on `stream` and first make
+  // it wait for the batches in flight, so a caller sees one in-order queue per context as before.
+  static constexpr int SETS = 3;
   struct BatchSet {
     int* stage_h = nullptr;                         // 9 * max_batch ints: kf slots, frame slots, unique slots, initial poses
     const int* stage_dev_alias = nullptr;
     ellc::AlignResult* result_h = nullptr;
     ellc::AlignResult* result_dev_alias = nullptr;
     hipEvent_t done = nullptr;
-  } batch_set[2];
-  int next_set = 0;
-  int inflight[2] = {0, 0};
+    hipStream_t stream = nullptr;                   // sets 1, 2 (set 0: the main stream)
+    int waited_mark = 0;                            // the main-stream mark this set's stream has been ordered after
+    int* stage_d = nullptr;                         // device copy of the staging record
+    ellc::AlignState* state_d = nullptr;            // two launch-parity buffers
+    float* partials_d = nullptr;
+    std::vector<int> kf_slots;                      // unique keyframe slots of the batch in flight
+    bool joined = true;                             // `stream` (the context's main stream) already waits for `done`
+  } batch_set[SETS];
+  hipEvent_t ev_main = nullptr;                     // marks the main stream behind the last non-batch call
+  bool main_dirty = false;                          // a non-batch entry point ran since ev_main was recorded
+  int main_mark = 0;
+  int inflight[SETS] = {0, 0, 0};
   int n_inflight = 0;
   float* partials_d = nullptr;
   float* planes_d = nullptr;
@@ -106,14 +121,16 @@ ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg);
 
 // Every entry point makes the context's device current for the calling thread first: HIP's current device is per
 // thread, and the reference calls GetImagePoseEstimate from a second (loop-closure) thread (GlobalOptimize.cpp:241).
-ellc_status enter(ellc_ctx* c);
-#define ELLC_ENTER(ctx)                          \
-  do {                                           \
-    if (ctx) {                                   \
-      const ellc_status s__ = ellc::enter(ctx);  \
-      if (s__ != ELLC_OK) return s__;            \
-    }                                            \
+ellc_status enter(ellc_ctx* c, bool join);
+#define ELLC_ENTER_IMPL(ctx, join)                      \
+  do {                                                  \
+    if (ctx) {                                          \
+      const ellc_status s__ = ellc::enter(ctx, join);   \
+      if (s__ != ELLC_OK) return s__;                   \
+    }                                                   \
   } while (0)
+#define ELLC_ENTER(ctx) ELLC_ENTER_IMPL(ctx, true)          // runs on the main stream, behind the batches in flight
+#define ELLC_ENTER_BATCH(ctx) ELLC_ENTER_IMPL(ctx, false)   // ellc_align_enqueue / ellc_align_fetch
 
 int choose_nblk(const ellc_ctx* c, int level, int B);
 ellc_status run_prep(ellc_ctx* c, int n_unique, int need);

@@ -20,10 +20,19 @@ ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg) {
   return s;
 }
 
-ellc_status enter(ellc_ctx* c) {
+ellc_status enter(ellc_ctx* c, bool join) {
   int dev = -1;
-  if (hipGetDevice(&dev) == hipSuccess && dev == c->cfg.device) return ELLC_OK;
-  if (hipSetDevice(c->cfg.device) != hipSuccess) return fail(c, ELLC_ERR_HIP, "cannot make the context's device current");
+  if (!(hipGetDevice(&dev) == hipSuccess && dev == c->cfg.device) && hipSetDevice(c->cfg.device) != hipSuccess)
+    return fail(c, ELLC_ERR_HIP, "cannot make the context's device current");
+  if (join) {   // everything but the batch entry points runs on the main stream, after the batches in flight
+    for (int i = 0; i < c->n_inflight; i++) {
+      ellc_ctx::BatchSet& bs = c->batch_set[c->inflight[i]];
+      if (bs.joined) continue;   // set 0 runs on the main stream itself
+      ELLC_HIP(c, hipStreamWaitEvent(c->stream, bs.done, 0));
+      bs.joined = true;
+    }
+    c->main_dirty = true;   // the next batch on another stream has to be ordered after what this call enqueues
+  }
   return ELLC_OK;
 }
 
@@ -219,7 +228,7 @@ static void launch_solve(ellc_ctx* c, int level, int B, int nblk, int mode, int 
   hipLaunchKernelGGL(gn_solve, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, s);
 }
 
-// points the staging / result members at batch set p
+// points the staging / result / work-buffer members at batch set p
 static void select_batch_set(ellc_ctx* c, int p) {
   const int MB = c->cfg.max_batch;
   ellc_ctx::BatchSet& bs = c->batch_set[p];
@@ -230,6 +239,12 @@ static void select_batch_set(ellc_ctx* c, int p) {
   c->stage_dev_alias = bs.stage_dev_alias;
   c->result_h = bs.result_h;
   c->result_dev_alias = bs.result_dev_alias;
+  c->kf_slot_d = bs.stage_d;
+  c->fr_slot_d = bs.stage_d + MB;
+  c->uniq_slot_d = bs.stage_d + 2 * MB;
+  c->init_pose_d = (float*)(bs.stage_d + 3 * MB);
+  c->state_d = bs.state_d;
+  c->partials_d = bs.partials_d;
 }
 
 // stage slots / initial poses on the device and list the unique keyframe slots
@@ -421,7 +436,7 @@ void* ellc_stream(ellc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 ellc_status ellc_sync(ellc_ctx* c) {
   ELLC_ENTER(c);
   if (!c) return ELLC_ERR_BAD_ARG;
-  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));   // ELLC_ENTER made it wait for every batch in flight
   return ELLC_OK;
 }
 
@@ -537,27 +552,30 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   for (int s = 0; s < MF; s++) { TRY(dev_alloc(c, &c->fr_maxgrad[s], n0)); TRY(dev_alloc(c, &c->fr_maxgrad_count[s], 4)); }
   // ---- alignment work buffers
   const int MB = cfg->max_batch;
-  {  // one staging record per call: [kf_slot MB][fr_slot MB][unique MB][init_pose 6*MB], moved with a single copy
-    int* sd = nullptr;
-    TRY(dev_alloc(c, &sd, (size_t)9 * MB));
-    c->kf_slot_d = sd; c->fr_slot_d = sd + MB; c->uniq_slot_d = sd + 2 * MB; c->init_pose_d = (float*)(sd + 3 * MB);
-    for (int p = 0; p < 2; p++) {
-      ellc_ctx::BatchSet& bs = c->batch_set[p];
-      TRY(host_alloc(c, &bs.stage_h, (size_t)9 * MB));
-      TRY(host_alloc(c, &bs.result_h, MB));
-      void *da = nullptr, *db = nullptr;
-      if (hipHostGetDevicePointer(&da, bs.stage_h, 0) != hipSuccess || hipHostGetDevicePointer(&db, bs.result_h, 0) != hipSuccess ||
-          hipEventCreateWithFlags(&bs.done, hipEventDisableTiming) != hipSuccess) {
-        *out = c;
-        return fail(c, ELLC_ERR_HIP, "pinned host memory is not device-visible");
-      }
-      bs.stage_dev_alias = (const int*)da;
-      bs.result_dev_alias = (AlignResult*)db;
+  // per batch set: one staging record [kf_slot MB][fr_slot MB][unique MB][init_pose 6*MB] (pinned, and its device copy),
+  // the result records (pinned), the alignment states (two launch-parity buffers), the block partials, a stream
+  for (int p = 0; p < ellc_ctx::SETS; p++) {
+    ellc_ctx::BatchSet& bs = c->batch_set[p];
+    TRY(dev_alloc(c, &bs.stage_d, (size_t)9 * MB));
+    TRY(host_alloc(c, &bs.stage_h, (size_t)9 * MB));
+    TRY(host_alloc(c, &bs.result_h, MB));
+    TRY(dev_alloc(c, &bs.state_d, 2 * (size_t)MB));
+    TRY(dev_alloc(c, &bs.partials_d, 2 * (size_t)MB * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
+    void *da = nullptr, *db = nullptr;
+    if (hipHostGetDevicePointer(&da, bs.stage_h, 0) != hipSuccess || hipHostGetDevicePointer(&db, bs.result_h, 0) != hipSuccess ||
+        hipEventCreateWithFlags(&bs.done, hipEventDisableTiming) != hipSuccess) {
+      *out = c;
+      return fail(c, ELLC_ERR_HIP, "pinned host memory is not device-visible, or no event for a batch set");
     }
-    select_batch_set(c, 0);
+    bs.stage_dev_alias = (const int*)da;
+    bs.result_dev_alias = (AlignResult*)db;
   }
-  TRY(dev_alloc(c, &c->state_d, 2 * (size_t)MB)); TRY(host_alloc(c, &c->state_h, MB));          // two launch-parity buffers
-  TRY(dev_alloc(c, &c->partials_d, 2 * (size_t)MB * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
+  if (hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess) {
+    *out = c;
+    return fail(c, ELLC_ERR_HIP, "cannot create the ordering event");
+  }
+  select_batch_set(c, 0);
+  TRY(host_alloc(c, &c->state_h, MB));
   TRY(dev_alloc(c, &c->planes_d, 10 * n0));
   TRY(dev_alloc(c, &c->scratch_a, n0)); TRY(dev_alloc(c, &c->scratch_b, n0));
   // ---- depth map state
@@ -630,13 +648,18 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
 ellc_status ellc_ctx_destroy(ellc_ctx* c) {
   ELLC_ENTER(c);
   if (!c) return ELLC_ERR_BAD_ARG;
+  for (int p = 0; p < ellc_ctx::SETS; p++) if (c->batch_set[p].stream) (void)hipStreamSynchronize(c->batch_set[p].stream);
   (void)hipStreamSynchronize(c->stream);
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
   for (void* p : c->allocs) (void)hipFree(p);
   for (void* p : c->host_allocs) (void)hipHostFree(p);
   if (c->ingest_map) (void)hipFree(c->ingest_map);
   if (c->ingest_bgr) (void)hipFree(c->ingest_bgr);
-  for (int p = 0; p < 2; p++) if (c->batch_set[p].done) (void)hipEventDestroy(c->batch_set[p].done);
+  for (int p = 0; p < ellc_ctx::SETS; p++) {
+    if (c->batch_set[p].done) (void)hipEventDestroy(c->batch_set[p].done);
+    if (c->batch_set[p].stream) (void)hipStreamDestroy(c->batch_set[p].stream);
+  }
+  if (c->ev_main) (void)hipEventDestroy(c->ev_main);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
@@ -902,60 +925,103 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
   return ELLC_OK;
 }
 
-// track: the batch joins the in-flight queue ellc_align_fetch drains (at most two); untracked use is for the timing hook
+// swaps the stream every launch helper uses (c->stream) for the duration of one enqueue
+struct StreamScope {
+  ellc_ctx* c;
+  hipStream_t saved;
+  StreamScope(ellc_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
+  ~StreamScope() { c->stream = saved; }
+};
+
+// track: the batch takes the next free set, runs on that set's stream and joins the in-flight queue ellc_align_fetch
+// drains; untracked use (the timing hook, nothing in flight) runs set 0's buffers on the main stream.
 static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode,
                                       int save_weights, bool track) {
   if (!c) return ELLC_ERR_BAD_ARG;
   if (mode != ELLC_MODE_FCA && mode != ELLC_MODE_ICA) return fail(c, ELLC_ERR_BAD_ARG, "unknown mode");
-  if (c->n_inflight >= 2) return fail(c, ELLC_ERR_NOT_READY, "two batches are in flight: call ellc_align_fetch first");
-  const int set = c->next_set;
+  if (c->n_inflight >= ellc_ctx::SETS) return fail(c, ELLC_ERR_NOT_READY, "three batches are in flight: call ellc_align_fetch first");
+  // the lowest free set: a caller with one batch at a time stays on set 0, i.e. on the main stream with no extra stream
+  int set = 0;
+  if (track) {
+    bool used[ellc_ctx::SETS] = {false, false, false};
+    for (int i = 0; i < c->n_inflight; i++) used[c->inflight[i]] = true;
+    while (used[set]) set++;
+  }
+  ellc_ctx::BatchSet& bs = c->batch_set[set];
+  if (set > 0 && !bs.stream) ELLC_HIP(c, hipStreamCreate(&bs.stream));   // created on first use
   select_batch_set(c, set);
   int nu = 0;
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
   if (s != ELLC_OK) return s;
-  if (c->use_graph) {
-    const auto key = std::make_tuple(B, nu, mode, (save_weights ? 1 : 0) | (set << 1));
-    auto it = c->graphs.find(key);
-    if (it == c->graphs.end()) {
-      hipGraph_t graph = nullptr;
-      hipGraphExec_t exec = nullptr;
-      ELLC_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      s = enqueue_align_body(c, B, nu, mode, save_weights);
-      hipError_t e = hipStreamEndCapture(c->stream, &graph);
-      if (s != ELLC_OK) return s;
-      if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-      ELLC_HIP(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(graph);
-      it = c->graphs.emplace(key, exec).first;
+  hipStream_t run_stream = set > 0 ? bs.stream : c->stream;
+  if (track) {
+    // A batch on another stream runs after everything the caller has put on the main stream through the other entry
+    // points (uploads, depth stages), but not after the batches that run there: the mark is recorded before them.
+    if (c->main_dirty) {
+      ELLC_HIP(c, hipEventRecord(c->ev_main, c->stream));
+      c->main_dirty = false;
+      c->main_mark++;
     }
-    ELLC_HIP(c, hipGraphLaunch(it->second, c->stream));
-  } else {
-    s = enqueue_align_body(c, B, nu, mode, save_weights);
-    if (s != ELLC_OK) return s;
+    if (set > 0 && bs.waited_mark != c->main_mark) {
+      ELLC_HIP(c, hipStreamWaitEvent(run_stream, c->ev_main, 0));
+      bs.waited_mark = c->main_mark;
+    }
+    // after the batches in flight that use one of its keyframe slots: compaction, H^-1 and saved weights are per slot
+    for (int i = 0; i < c->n_inflight; i++) {
+      const ellc_ctx::BatchSet& other = c->batch_set[c->inflight[i]];
+      bool shared = false;
+      for (int u = 0; u < nu && !shared; u++)
+        for (int v : other.kf_slots) shared = shared || (v == c->uniq_slot_h[u]);
+      if (shared) ELLC_HIP(c, hipStreamWaitEvent(run_stream, other.done, 0));
+    }
+  }
+  {
+    StreamScope scope(c, run_stream);
+    if (c->use_graph) {
+      const auto key = std::make_tuple(B, nu, mode, (save_weights ? 1 : 0) | (set << 1));
+      auto it = c->graphs.find(key);
+      if (it == c->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        ELLC_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        s = enqueue_align_body(c, B, nu, mode, save_weights);
+        hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (s != ELLC_OK) return s;
+        if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        ELLC_HIP(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        it = c->graphs.emplace(key, exec).first;
+      }
+      ELLC_HIP(c, hipGraphLaunch(it->second, c->stream));
+    } else {
+      s = enqueue_align_body(c, B, nu, mode, save_weights);
+      if (s != ELLC_OK) return s;
+    }
+    if (track) ELLC_HIP(c, hipEventRecord(bs.done, c->stream));
   }
   if (save_weights && mode == ELLC_MODE_FCA)
     for (int b = 0; b < B; b++)
       for (int l = 0; l < c->L; l++) c->kf_num_weights[kf_slots[b]][l]++;
   if (track) {
-    ELLC_HIP(c, hipEventRecord(c->batch_set[set].done, c->stream));
+    bs.kf_slots.assign(c->uniq_slot_h, c->uniq_slot_h + nu);
+    bs.joined = (set == 0);
     c->inflight[c->n_inflight++] = set;
-    c->next_set = set ^ 1;
   }
   return ELLC_OK;
 }
 
 ellc_status ellc_align_enqueue(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int save_weights) {
-  ELLC_ENTER(c);
+  ELLC_ENTER_BATCH(c);
   return align_enqueue_impl(c, B, kf_slots, frame_slots, init_pose, mode, save_weights, true);
 }
 
 ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters, float* out_weighted) {
-  ELLC_ENTER(c);
+  ELLC_ENTER_BATCH(c);
   if (!c || B < 1 || B > c->cfg.max_batch) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (c->n_inflight < 1) return fail(c, ELLC_ERR_NOT_READY, "ellc_align_fetch: no batch in flight");
   const ellc_ctx::BatchSet& bs = c->batch_set[c->inflight[0]];   // the oldest batch
   ELLC_HIP(c, hipEventSynchronize(bs.done));   // its last kernel wrote bs.result_h (pinned, zero-copy)
-  c->inflight[0] = c->inflight[1];
+  for (int i = 1; i < c->n_inflight; i++) c->inflight[i - 1] = c->inflight[i];
   c->n_inflight--;
   for (int b = 0; b < B; b++) {
     if (out_pose) std::memcpy(out_pose + b * 6, bs.result_h[b].pose, 24);

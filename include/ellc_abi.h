@@ -123,11 +123,14 @@ ellc_status ellc_keyframe_finalise_weights(ellc_ctx* ctx, int slot);
  */
 ellc_status ellc_align(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, const float* init_pose,
                        int mode, int save_weights, float* out_pose, int* out_iters, float* out_weighted);
-/* Asynchronous form: enqueue only. Up to TWO batches may be in flight (staging and result records exist twice), so a
- * caller can enqueue batch n+1 before fetching batch n and keep the device busy back to back; a third enqueue returns
- * ELLC_ERR_NOT_READY. ellc_align_fetch waits for the OLDEST batch in flight only (an event, not the whole stream) and
- * returns its results; with nothing in flight it returns ELLC_ERR_NOT_READY. The slots a batch reads must not be
- * modified (upload / set_depth ...) while it is in flight; those calls are stream-ordered after it anyway. */
+/* Asynchronous form: enqueue only. Up to THREE batches may be in flight; each runs on a stream of its own with its own
+ * staging, state and result records, so batches in flight execute CONCURRENTLY on the device (the latency-bound coarse
+ * iterations of one batch overlap the fine iterations of another) unless they share a keyframe slot, in which case the
+ * later one is ordered after the earlier one. A fourth enqueue returns ELLC_ERR_NOT_READY. ellc_align_fetch waits for
+ * the OLDEST batch in flight only (an event) and returns its results; with nothing in flight it returns
+ * ELLC_ERR_NOT_READY. Every other entry point is ordered after the batches in flight and before the batches enqueued
+ * later, exactly as if the context had a single in-order queue: an upload into a slot a batch in flight reads takes
+ * effect behind that batch. */
 ellc_status ellc_align_enqueue(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, const float* init_pose,
                                int mode, int save_weights);
 ellc_status ellc_align_fetch(ellc_ctx* ctx, int B, float* out_pose, int* out_iters, float* out_weighted);

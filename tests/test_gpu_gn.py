@@ -193,29 +193,44 @@ def test_packed_division_matches_ieee_division(ellc):
     assert same.all(), "first mismatch: a=%r b=%r pair=%r ref=%r" % (a[~same][0], b[~same][0], qp[~same][0], qr[~same][0])
 
 
-def test_two_batches_in_flight(ellc, oracle):
-    """ellc_align_enqueue twice, then fetch twice: results come back oldest first and equal the synchronous ones; a third
-    enqueue and a fetch with nothing in flight are refused loudly."""
-    pairs = [synth.make_pair(W, H, seed=40 + i) for i in range(3)]
+def test_batches_in_flight(ellc, oracle):
+    """ellc_align_enqueue up to three times, then fetch: the batches run concurrently on their own streams, results come
+    back oldest first and equal the synchronous ones — also when two batches in flight share a keyframe slot (they are
+    then ordered one after the other); a fourth enqueue and a fetch with nothing in flight are refused loudly."""
+    pairs = [synth.make_pair(W, H, seed=40 + i) for i in range(4)]
     ctx = gpu_problem(ellc, W, H, L, pairs, early_exit=0)
     ref0 = ctx.align([0, 1], [0, 1])[0]
     ref1 = ctx.align([2], [2])[0]
+    ref2 = ctx.align([3, 0], [3, 0])[0]    # shares keyframe slot 0 with the first batch
     ctx.align_enqueue([0, 1], [0, 1])
     ctx.align_enqueue([2], [2])
+    ctx.align_enqueue([3, 0], [3, 0])
     with pytest.raises(ellc.EllcError):
         ctx.align_enqueue([1], [1])
     with pytest.raises(ellc.EllcError):
         ctx.align([1], [1])
     p0, it0, _ = ctx.align_fetch(2)
     p1, it1, _ = ctx.align_fetch(1)
-    assert np.array_equal(p0, ref0) and np.array_equal(p1, ref1)
-    assert it0.sum() == 2 * 32 and it1.sum() == 32
+    p2, it2, _ = ctx.align_fetch(2)
+    assert np.array_equal(p0, ref0) and np.array_equal(p1, ref1) and np.array_equal(p2, ref2)
+    assert it0.sum() == 2 * 32 and it1.sum() == 32 and it2.sum() == 2 * 32
     with pytest.raises(ellc.EllcError):
         ctx.align_fetch(1)
-    # alternating sets keep working
-    for _ in range(3):
-        ctx.align_enqueue([2], [2]); ctx.align_enqueue([0, 1], [0, 1])
+    # a rolling window of three keeps working, and uploads between enqueues are ordered with the batches around them
+    for r in range(4):
+        ctx.align_enqueue([2], [2]); ctx.align_enqueue([0, 1], [0, 1]); ctx.align_enqueue([3, 0], [3, 0])
+        if r == 2:   # overwrite frame slot 2 while its batch is in flight, then restore it: both land behind that batch
+            ctx.frame_upload(2, pairs[0]["cur_image"])
+            ctx.frame_upload(2, pairs[2]["cur_image"])
         assert np.array_equal(ctx.align_fetch(1)[0], ref1) and np.array_equal(ctx.align_fetch(2)[0], ref0)
+        assert np.array_equal(ctx.align_fetch(2)[0], ref2)
+    # a different frame in the slot changes the result of the next batch only
+    ctx.align_enqueue([2], [2])
+    ctx.frame_upload(2, pairs[0]["cur_image"])
+    ctx.align_enqueue([2], [2])
+    a0 = ctx.align_fetch(1)[0]
+    a1 = ctx.align_fetch(1)[0]
+    assert np.array_equal(a0, ref1) and not np.array_equal(a1, ref1)
     ctx.close()
 
 
