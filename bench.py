@@ -70,7 +70,7 @@ def main():
     # the workload keeps G = --inflight groups of B keyframe / frame slots resident and step s works on group s % G.
     G = max(1, min(3, a.inflight))
     cfg = api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_iter=sched, max_keyframes=G * B, max_frames=G * B,
-                             max_batch=B, device=dev_index)
+                             max_batch=B, device=dev_index, concurrent_batches=G)
     ctx = api.Context(cfg)
     for b in range(G * B):
         p = pairs[b % nd]
@@ -156,7 +156,14 @@ def main():
         out["single_alignment"] = {"workload": "C1: one keyframe vs one frame, same sizes/schedule", "ms_per_alignment": 1e3 * d1,
                                    "gn_iterations_per_s": iters_per_alignment / d1}
         if world == 1:
-            out["early_exit_on"] = early_exit_run(api, cfg, pairs, a, slots, mode)
+            out["early_exit_on"], alone = early_exit_run(api, cfg, pairs, a, slots, mode)
+            if alone is not None and G > 1:
+                # the same kernel on the grid a context uses when its batches run one at a time (concurrent_batches = 1: one
+                # full round of resident blocks). With several batches in flight the library launches half-round grids: slower
+                # per launch in isolation (what `achieved` reports), faster as a pipeline (what `value` reports).
+                ms1, bytes1, _ = alone
+                out["roofline"]["one_batch_at_a_time_grid"] = {"avg_launch_ms": ms1, "achieved": bytes1 / (ms1 * 1e-3) / 1e9,
+                                                               "frac": bytes1 / (ms1 * 1e-3) / 1e9 / 8000.0}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a, pairs[0], sched, value)
         print(json.dumps(out), flush=True)
@@ -167,13 +174,15 @@ def main():
 
 
 def early_exit_run(api, cfg, pairs, a, slots, mode):
-    """Informational (SURVEY.md §8d iii): the same batch with the reference's early exit on (a level stops once
-    weightedPose < 1, ImageFunc.cpp:251-252), so the iteration count is data dependent. Not part of `value`."""
+    """Informational (SURVEY.md §8d iii): the same batch, one at a time, with the reference's early exit on (a level stops
+    once weightedPose < 1, ImageFunc.cpp:251-252), so the iteration count is data dependent. Not part of `value`. Also
+    returns the level-0 kernel timing of this one-batch-at-a-time context."""
     B, L, W, H = a.batch, a.levels, a.width, a.height
     ctx = None
     try:
         cfg2 = type(cfg).from_buffer_copy(cfg)
         cfg2.early_exit = 1
+        cfg2.concurrent_batches = 1
         ctx = api.Context(cfg2)
         for b in range(B):
             p = pairs[b % len(pairs)]
@@ -190,8 +199,9 @@ def early_exit_run(api, cfg, pairs, a, slots, mode):
             ctx.align(slots, slots, mode=mode)
         d = (time.perf_counter() - t) / n
         done = int(np.asarray(iters).sum())
+        alone = ctx.profile_gn_kernel(slots, slots, 0, reps=50) if a.mode == "fca" else None
         return {"ms_per_batch": 1e3 * d, "alignments_per_s": B / d, "gn_iterations_per_s": done / d,
-                "mean_iterations_per_alignment": done / B}
+                "mean_iterations_per_alignment": done / B, "batches_in_flight": 1}, alone
     finally:
         if ctx is not None:
             ctx.close()

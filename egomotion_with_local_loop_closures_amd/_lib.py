@@ -30,7 +30,8 @@ class EllcConfig(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("levels", C.c_int),
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("max_iter", C.c_int * MAX_LEVELS), ("early_exit", C.c_int),
-                ("max_keyframes", C.c_int), ("max_frames", C.c_int), ("max_batch", C.c_int), ("device", C.c_int)]
+                ("max_keyframes", C.c_int), ("max_frames", C.c_int), ("max_batch", C.c_int), ("device", C.c_int),
+                ("concurrent_batches", C.c_int)]
 
 
 class EllcHypotheses(C.Structure):

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define ELLC_MAX_LEVELS 8
-#define ELLC_ABI_VERSION 1
+#define ELLC_ABI_VERSION 2
 
 typedef enum {
   ELLC_OK = 0,
@@ -55,6 +55,9 @@ typedef struct {
   int max_frames;               /* current-frame slots resident in HBM */
   int max_batch;                /* largest B accepted by ellc_align */
   int device;                   /* HIP device ordinal */
+  int concurrent_batches;       /* 1..3: how many batches the caller keeps in flight (ellc_align_enqueue); > 1 sizes the
+                                 * fine-level grids for sharing the device. Fixed per context, so a batch's result does
+                                 * not depend on what else happens to be in flight (the grid fixes the summation order) */
 } ellc_config;
 
 typedef struct ellc_ctx ellc_ctx;

@@ -26,7 +26,9 @@ def test_library_builds_loads_and_exports_every_symbol():
     lib = _lib.lib()
     for name in header_functions():
         assert hasattr(lib, name), name
-    assert lib.ellc_abi_version() == 1
+    import re
+    header = open(os.path.join(ROOT, "include", "ellc_abi.h")).read()
+    assert lib.ellc_abi_version() == int(re.search(r"#define ELLC_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_code_object_is_gfx950():
@@ -36,11 +38,26 @@ def test_code_object_is_gfx950():
     assert b"gn_fca_accumulate" in data and b"dm_observe" in data and b"pyr_down_u8" in data
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof / offsetof of the ABI structs as the C compiler sees the header == the ctypes mirrors."""
+    import subprocess
     from egomotion_with_local_loop_closures_amd import _lib
-    # ellc_config: 3 ints, 4 floats, 8 ints, 5 ints
-    assert ctypes.sizeof(_lib.EllcConfig) == 4 * (3 + 4 + 8 + 5)
-    assert ctypes.sizeof(_lib.EllcHypotheses) == 7 * ctypes.sizeof(ctypes.c_void_p)
+    fields = {"ellc_config": [f[0] for f in _lib.EllcConfig._fields_], "ellc_hypotheses": [f[0] for f in _lib.EllcHypotheses._fields_]}
+    lines = ['#include "ellc_abi.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
+    for st, fs in fields.items():
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (st, st))
+        for f in fs:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (st, f, st, f))
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    seen = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for st, cls in (("ellc_config", _lib.EllcConfig), ("ellc_hypotheses", _lib.EllcHypotheses)):
+        assert int(seen[st]) == ctypes.sizeof(cls)
+        for f in fields[st]:
+            assert int(seen["%s.%s" % (st, f)]) == getattr(cls, f).offset, (st, f)
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
