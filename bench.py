@@ -86,7 +86,7 @@ def main():
     from egomotion_with_local_loop_closures_amd import sharding
     dev = coll_dev if world > 1 else None
 
-    gatherer = sharding.ResultGatherer(B * world, device=dev)
+    gatherer = sharding.ResultGatherer(B * world, device=dev, depth=G)
 
     def run(nsteps):
         """nsteps steps; step = one batch through ellc_align_enqueue / ellc_align_fetch + (N>1) the one gather of its poses.
@@ -101,9 +101,12 @@ def main():
             pose, iters, wgt = ctx.align_fetch(B)
             if s + G < nsteps:
                 ctx.align_enqueue(group[(s + G) % G], group[(s + G) % G], mode=mode)
-            if world > 1:   # the single RCCL gather of the resulting se(3) poses (8 floats per alignment)
-                table = gatherer.gather(sharding.pack_results(pose, iters, wgt))
-                assert table.shape == (B * world, sharding.RECORD)
+            if world > 1:   # the single RCCL gather of the resulting se(3) poses (8 floats per alignment): enqueued now,
+                if len(gatherer.pending) == G:   # collected up to G steps later, so the exchange never stalls this loop
+                    assert gatherer.finish().shape == (B * world, sharding.RECORD)
+                gatherer.start(sharding.pack_results(pose, iters, wgt))
+        while world > 1 and gatherer.pending:
+            assert gatherer.finish().shape == (B * world, sharding.RECORD)
         return pose, iters
 
     if a.warmup > 0:
