@@ -25,7 +25,7 @@ def gpu_problem(E, w, h, levels, pairs, early_exit=0, max_iter=(4, 7, 9, 12), **
     n = len(pairs)
     cfg = E.default_config(w, h, levels, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=early_exit, max_iter=max_iter,
                            max_keyframes=max(n, kw.pop("max_keyframes", 1)), max_frames=max(n, kw.pop("max_frames", 1)),
-                           max_batch=max(n, kw.pop("max_batch", 1)))
+                           max_batch=max(n, kw.pop("max_batch", 1)), **kw)
     ctx = E.Context(cfg)
     for i, p in enumerate(pairs):
         ctx.keyframe_upload(i, p["kf_image"])
