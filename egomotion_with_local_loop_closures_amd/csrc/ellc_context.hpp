@@ -57,7 +57,10 @@ struct ellc_ctx {
   // slot are ordered one after the other (the compaction, H^-1 and the saved weights live in the keyframe slot). The
   // members above point at the set of the batch being enqueued. All other entry points work on `stream` and first make
   // it wait for the batches in flight, so a caller sees one in-order queue per context as before.
-  static constexpr int SETS = 3;
+#ifndef ELLC_SETS
+#define ELLC_SETS 3
+#endif
+  static constexpr int SETS = ELLC_SETS;
   struct BatchSet {
     int* stage_h = nullptr;                         // 9 * max_batch ints: kf slots, frame slots, unique slots, initial poses
     const int* stage_dev_alias = nullptr;
@@ -75,7 +78,7 @@ struct ellc_ctx {
   hipEvent_t ev_main = nullptr;                     // marks the main stream behind the last non-batch call
   bool main_dirty = false;                          // a non-batch entry point ran since ev_main was recorded
   int main_mark = 0;
-  int inflight[SETS] = {0, 0, 0};
+  int inflight[SETS] = {0};
   int n_inflight = 0;
   float* partials_d = nullptr;
   float* planes_d = nullptr;

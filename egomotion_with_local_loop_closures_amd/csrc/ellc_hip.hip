@@ -948,7 +948,7 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
   // the lowest free set: a caller with one batch at a time stays on set 0, i.e. on the main stream with no extra stream
   int set = 0;
   if (track) {
-    bool used[ellc_ctx::SETS] = {false, false, false};
+    bool used[ellc_ctx::SETS] = {false};
     for (int i = 0; i < c->n_inflight; i++) used[c->inflight[i]] = true;
     while (used[set]) set++;
   }

@@ -22,9 +22,9 @@ pairs = [synth.make_pair(W, H, seed=0x5EED + i) for i in range(4)]
 slots = np.arange(B, dtype=np.int32)
 ctxs = []
 for k in range(NC):
-    ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_iter=sched, max_keyframes=B,
-                                         max_frames=B, max_batch=B))
-    for b in range(B):
+    ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_iter=sched, max_keyframes=NF * B,
+                                         max_frames=NF * B, max_batch=B, concurrent_batches=min(3, NC * NF)))
+    for b in range(NF * B):
         p = pairs[(b + k) % len(pairs)]
         ctx.keyframe_upload(b, p["kf_image"]); ctx.keyframe_set_depth(b, p["depth0"], p["var0"]); ctx.frame_upload(b, p["cur_image"])
     ctxs.append(ctx)
@@ -38,7 +38,8 @@ def run(steps):
     while min(done) < steps:
         for k, ctx in enumerate(ctxs):
             while pending[k] < NF and issued[k] < steps:
-                ctx.align_enqueue(slots, slots); pending[k] += 1; issued[k] += 1
+                g = slots + (issued[k] % NF) * B   # batches in flight on one context use their own slot group
+                ctx.align_enqueue(g, g); pending[k] += 1; issued[k] += 1
         for k, ctx in enumerate(ctxs):
             if pending[k] and (pending[k] == NF or issued[k] == steps):
                 ctx.align_fetch(B); pending[k] -= 1; done[k] += 1
