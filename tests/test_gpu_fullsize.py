@@ -36,15 +36,25 @@ def test_c1_640x480_single_alignment_and_planes(oracle, ellc):
     ctx.close()
 
 
-def test_c2_batch32_matches_singles_and_oracle(oracle, ellc):
-    """configs[2]: 32 alignments in one launch sequence. Properties: each result equals the single-alignment run
-    (independence), is invariant under permutation of the batch, and (spot check) matches the oracle."""
+@pytest.mark.parametrize("concurrent", [1, 3])
+def test_c2_batch32_matches_singles_and_oracle(oracle, ellc, concurrent):
+    """configs[2]: 32 alignments in one launch sequence, on the full-round grid (one batch at a time) and on the grid
+    bench.py runs (cfg.concurrent_batches = 3, with two more batches in flight on the same data). Properties: each result
+    equals the single-alignment run (independence), is invariant under permutation of the batch, does not depend on what
+    else is in flight, and (spot check) matches the oracle."""
     W, H, L, B = 640, 480, 4, 32
     pairs = [synth.make_pair(W, H, seed=900 + i) for i in range(4)]
-    ctx = gpu_problem(ellc, W, H, L, [pairs[b % 4] for b in range(B)])
+    ctx = gpu_problem(ellc, W, H, L, [pairs[b % 4] for b in range(B)], concurrent_batches=concurrent)
     slots = np.arange(B)
     p_all, it_all, _ = ctx.align(slots, slots)
     assert it_all.sum() == B * 32
+    if concurrent > 1:   # three batches over disjoint halves / quarters of the slots, concurrently
+        parts = [slots[:16], slots[16:24], slots[24:]]
+        alone = [ctx.align(q, q)[0] for q in parts]
+        for q in parts:
+            ctx.align_enqueue(q, q)
+        for q, ref in zip(parts, alone):
+            assert np.array_equal(ctx.align_fetch(len(q))[0], ref)
     perm = np.random.default_rng(0).permutation(B)
     p_perm, _, _ = ctx.align(slots[perm], slots[perm])
     assert np.array_equal(p_perm, p_all[perm])           # block decomposition does not depend on the position in the batch
