@@ -962,7 +962,8 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
   if (track) {
     // A batch on another stream runs after everything the caller has put on the main stream through the other entry
     // points (uploads, depth stages), but not after the batches that run there: the mark is recorded before them.
-    if (c->main_dirty) {
+    // (a context that has only ever had one batch in flight has no other stream and never records the mark)
+    if (c->main_dirty && (set > 0 || c->batch_set[1].stream)) {
       ELLC_HIP(c, hipEventRecord(c->ev_main, c->stream));
       c->main_dirty = false;
       c->main_mark++;
