@@ -154,6 +154,11 @@ def main():
                            "algorithmic_bytes_per_launch": alg_bytes, "valid_pixels_per_launch": V,
                            "valid_pixel_rate_Gpx_s": V / (ms * 1e-3) / 1e9,
                            "level0_gn_iterations_per_s": B / (ms * 1e-3)}
+        # what a kernel that only reads reaches on this box (2 GiB, 16-byte lanes, far larger than the 256 MB Infinity
+        # Cache): the practical ceiling behind the 8 TB/s the fraction is priced against
+        cal_bytes = 2 << 30
+        cal_ms = ctx.profile_stream_read(cal_bytes, reps=5)
+        out["roofline"]["measured_stream_read_GBps"] = cal_bytes / (cal_ms * 1e-3) / 1e9
         # ---- C1: the same path at B = 1 (latency-bound single alignment), for reference
         pose1, it1, _ = ctx.align([0], [0], mode=mode)
         n1 = 20

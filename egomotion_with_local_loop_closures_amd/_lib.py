@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "ellc_se3_log", "ellc_depth_set_state", "ellc_depth_get_state", "ellc_depth_set_keyframe", "ellc_depth_propagate",
     "ellc_depth_observe", "ellc_depth_fill_holes", "ellc_depth_regularize", "ellc_depth_make_inv_depth_one",
     "ellc_depth_update_depth_image", "ellc_depth_create_keyframe", "ellc_depth_seeds", "ellc_profile_gn_kernel", "ellc_profile_align",
-    "ellc_profile_calibrate_read", "ellc_histogram", "ellc_kl_divergence", "ellc_copy_slot", "ellc_selftest_div_pair",
+    "ellc_profile_calibrate_read", "ellc_profile_stream_read", "ellc_histogram", "ellc_kl_divergence", "ellc_copy_slot", "ellc_selftest_div_pair",
     "ellc_ingest_configure", "ellc_frame_ingest_bgr", "ellc_selftest_lu",
 ]
 

@@ -273,6 +273,11 @@ class Context:
         self._ck(self._l.ellc_profile_calibrate_read(self.h, C.c_size_t(nbytes), reps, C.byref(ms)), "ellc_profile_calibrate_read")
         return ms.value
 
+    def profile_stream_read(self, nbytes, reps=10):
+        ms = C.c_float(0)
+        self._ck(self._l.ellc_profile_stream_read(self.h, C.c_size_t(nbytes), reps, C.byref(ms)), "ellc_profile_stream_read")
+        return ms.value
+
     def profile_align(self, kf_slots, frame_slots, init_pose=None, mode=MODE_FCA, reps=5):
         B, kf, fr, ip = self._batch(kf_slots, frame_slots, init_pose)
         ms = C.c_float(0)

@@ -1328,6 +1328,41 @@ ellc_status ellc_profile_calibrate_read(ellc_ctx* c, size_t bytes, int reps, flo
   return ELLC_OK;
 }
 
+__global__ __launch_bounds__(256) void stream_read_f32x4(const float4* __restrict__ p, size_t n, float* __restrict__ sink) {
+  float acc = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float4 v = p[i];
+    acc += (v.x + v.y) + (v.z + v.w);
+  }
+  if (acc == 1.2345e-30f) sink[0] = acc;   // keeps the loads alive
+}
+
+// Streaming-read rate of this device with 16-byte lanes (the widest global load): what "HBM peak" amounts to in practice
+// for a kernel that does nothing but read. bench.py reports it beside the 8 TB/s the roofline is priced against.
+ellc_status ellc_profile_stream_read(ellc_ctx* c, size_t bytes, int reps, float* avg_ms) {
+  ELLC_ENTER(c);
+  if (!c || reps < 1 || bytes < 4096) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  float4* buf = nullptr;
+  ELLC_HIP(c, hipMalloc((void**)&buf, bytes));
+  hipError_t e = hipMemsetAsync(buf, 0, bytes, c->stream);
+  const size_t n = bytes / 16;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(stream_read_f32x4, dim3(4096), dim3(256), 0, c->stream, buf, n, c->scratch_a);
+    e = hipEventRecord(c->ev0, c->stream);
+  }
+  if (e == hipSuccess) {
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(stream_read_f32x4, dim3(4096), dim3(256), 0, c->stream, buf, n, c->scratch_a);
+    e = hipEventRecord(c->ev1, c->stream);
+  }
+  if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
+  float ms = 0;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("ellc_profile_stream_read: ") + hipGetErrorString(e));
+  if (avg_ms) *avg_ms = ms / reps;
+  return ELLC_OK;
+}
+
 }  // extern "C"
 
 #include "ellc_depth_impl.hpp"

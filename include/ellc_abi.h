@@ -207,6 +207,9 @@ ellc_status ellc_profile_align(ellc_ctx* ctx, int B, const int* kf_slots, const 
  * width of the compacted pixel arrays), `reps` launches, so FETCH_SIZE can be scaled against a known byte count
  * (MI355X_MICROARCH.md, HBM section). Returns average milliseconds per launch. */
 ellc_status ellc_profile_calibrate_read(ellc_ctx* ctx, size_t bytes, int reps, float* avg_ms);
+/* Streaming-read rate with 16-byte lanes over `bytes` of device memory: the practical ceiling behind the nominal HBM peak;
+ * bench.py reports it beside the roofline (SURVEY.md section 8d asks for the measured figure). */
+ellc_status ellc_profile_stream_read(ellc_ctx* ctx, size_t bytes, int reps, float* avg_ms);
 
 /* Device self-test: q_pair[i] from the kernels' packed two-at-a-time IEEE division, q_ref[i] = a[i] / b[i] as the
  * compiler emits it; n even. The per-pixel code relies on the two being bit-identical (tests/test_gpu_gn.py). */
