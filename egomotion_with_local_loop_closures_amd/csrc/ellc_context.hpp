@@ -73,6 +73,7 @@ struct ellc_ctx {
     ellc::AlignState* state_d = nullptr;            // two launch-parity buffers
     float* partials_d = nullptr;
     std::vector<int> kf_slots;                      // unique keyframe slots of the batch in flight
+    int B = 0;                                      // its size
     bool joined = true;                             // `stream` (the context's main stream) already waits for `done`
   } batch_set[SETS];
   hipEvent_t ev_main = nullptr;                     // marks the main stream behind the last non-batch call

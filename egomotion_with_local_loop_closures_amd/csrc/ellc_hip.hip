@@ -1010,6 +1010,7 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
       for (int l = 0; l < c->L; l++) c->kf_num_weights[kf_slots[b]][l]++;
   if (track) {
     bs.kf_slots.assign(c->uniq_slot_h, c->uniq_slot_h + nu);
+    bs.B = B;
     bs.joined = (set == 0);
     c->inflight[c->n_inflight++] = set;
   }
@@ -1026,6 +1027,7 @@ ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters
   if (!c || B < 1 || B > c->cfg.max_batch) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (c->n_inflight < 1) return fail(c, ELLC_ERR_NOT_READY, "ellc_align_fetch: no batch in flight");
   const ellc_ctx::BatchSet& bs = c->batch_set[c->inflight[0]];   // the oldest batch
+  if (B != bs.B) return fail(c, ELLC_ERR_BAD_ARG, "ellc_align_fetch: the oldest batch in flight has a different size");
   ELLC_HIP(c, hipEventSynchronize(bs.done));   // its last kernel wrote bs.result_h (pinned, zero-copy)
   for (int i = 1; i < c->n_inflight; i++) c->inflight[i - 1] = c->inflight[i];
   c->n_inflight--;

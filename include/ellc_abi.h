@@ -130,7 +130,8 @@ ellc_status ellc_align(ellc_ctx* ctx, int B, const int* kf_slots, const int* fra
  * staging, state and result records, so batches in flight execute CONCURRENTLY on the device (the latency-bound coarse
  * iterations of one batch overlap the fine iterations of another) unless they share a keyframe slot, in which case the
  * later one is ordered after the earlier one. A fourth enqueue returns ELLC_ERR_NOT_READY. ellc_align_fetch waits for
- * the OLDEST batch in flight only (an event) and returns its results; with nothing in flight it returns
+ * the OLDEST batch in flight only (an event) and returns its results (B must be that batch's size: ELLC_ERR_BAD_ARG
+ * otherwise, the batch stays in flight); with nothing in flight it returns
  * ELLC_ERR_NOT_READY. Every other entry point is ordered after the batches in flight and before the batches enqueued
  * later, exactly as if the context had a single in-order queue: an upload into a slot a batch in flight reads takes
  * effect behind that batch. */

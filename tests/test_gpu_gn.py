@@ -209,6 +209,8 @@ def test_batches_in_flight(ellc, oracle):
         ctx.align_enqueue([1], [1])
     with pytest.raises(ellc.EllcError):
         ctx.align([1], [1])
+    with pytest.raises(ellc.EllcError):
+        ctx.align_fetch(3)             # the oldest batch holds two alignments
     p0, it0, _ = ctx.align_fetch(2)
     p1, it1, _ = ctx.align_fetch(1)
     p2, it2, _ = ctx.align_fetch(2)
