@@ -275,9 +275,11 @@ static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const in
 }
 
 // device copy of the staged batch description, as a kernel reading the pinned record (part of the captured graph)
-static void enqueue_stage_in(ellc_ctx* c) {
+static void enqueue_stage_in(ellc_ctx* c, int B) {
   const int n = 9 * c->cfg.max_batch;
-  hipLaunchKernelGGL(stage_in, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->kf_slot_d, c->stage_dev_alias, n);
+  const int copy_blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(stage_in, dim3(copy_blocks + (B + 255) / 256), dim3(256), 0, c->stream, c->kf_slot_d, c->stage_dev_alias, n, copy_blocks,
+                     c->state_d, B, c->cfg.max_batch);
 }
 
 // fills the age-balanced split of a launch (FusedArgs::age_rounds): on when the grid is 2..4 full rounds of one block per CU-slot
@@ -916,13 +918,12 @@ ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, i
 // prep + init + the whole level/iteration schedule; captured once per (B, unique keyframes, mode, save_weights)
 // into a hipGraph and replayed afterwards (the launches are too short to be issued one by one from the host)
 static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int save_weights) {
-  enqueue_stage_in(c);
+  enqueue_stage_in(c, B);   // also initialises the B alignment states
   // mask / count per level (updationOnPyrChange, ImageFunc.cpp:158) and the pose-independent per-pixel records
   const int need = mode == ELLC_MODE_ICA ? (c->use_fused ? 4 : 1) : 2;
   ellc_status s = run_prep(c, nu, need);
   if (s != ELLC_OK) return s;
   if (need == 4) enqueue_ica_hinv(c, nu);
-  hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
   s = enqueue_schedule(c, B, mode, save_weights);
   if (s != ELLC_OK) return s;
   if (!c->use_fused)   // the fused schedules export from their finish kernel
@@ -1066,7 +1067,7 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   int nu = 0;
   ellc_status s = stage_batch(c, 1, &kf_slot, &frame_slot, pose, &nu);
   if (s != ELLC_OK) return s;
-  enqueue_stage_in(c);
+  enqueue_stage_in(c, 0);   // staging only: the state keeps the level's H^-1 (gn_set_pose0)
   s = run_prep(c, nu, mode == ELLC_MODE_ICA ? 1 : 2);
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_set_pose0, dim3(1), dim3(1), 0, c->stream, c->state_d, c->init_pose_d);
@@ -1136,7 +1137,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   int nu = 0;
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, nullptr, &nu);
   if (s != ELLC_OK) return s;
-  enqueue_stage_in(c);
+  enqueue_stage_in(c, 0);
   s = run_prep(c, nu, 2);
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);

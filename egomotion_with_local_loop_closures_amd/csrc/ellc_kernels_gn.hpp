@@ -1159,17 +1159,29 @@ __global__ void gn_export_results(const AlignState* state, AlignResult* res, int
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) r.iters[l] = st.iters[l];
 }
 
-// first kernel of a schedule: the staged batch description (slots, unique slots, initial poses) from pinned host memory
-__global__ void stage_in(int* __restrict__ dst, const int* __restrict__ src_host, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src_host[i];
+// initial state of alignment b from the caller's initial relative pose
+__device__ inline void init_state_record(AlignState& st, const float* init_pose, int b);
+
+// first kernel of a schedule: the staged batch description (slots, unique slots, initial poses: 9 * max_batch words) is
+// copied from pinned host memory by the first copy_blocks blocks; the remaining blocks initialise the alignment states
+// straight from the staged initial poses (same launch: one dependent kernel boundary less at the head of every batch)
+__global__ void stage_in(int* __restrict__ dst, const int* __restrict__ src_host, int n, int copy_blocks, AlignState* state, int B, int max_batch) {
+  if ((int)blockIdx.x < copy_blocks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src_host[i];
+    return;
+  }
+  const int b = ((int)blockIdx.x - copy_blocks) * blockDim.x + threadIdx.x;
+  if (b < B) init_state_record(state[b], (const float*)(src_host + 3 * max_batch), b);
 }
 
-// initial state from the caller's initial relative pose
 __global__ void gn_init_state(AlignState* state, const float* init_pose, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  AlignState& st = state[b];
+  init_state_record(state[b], init_pose, b);
+}
+
+__device__ inline void init_state_record(AlignState& st, const float* init_pose, int b) {
   float p[6];
   for (int i = 0; i < 6; i++) { p[i] = init_pose[b * 6 + i]; st.pose[i] = p[i]; st.delta[i] = 0.0f; }
   float S[12];
