@@ -20,6 +20,14 @@ ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg) {
   return s;
 }
 
+// blocking copy on the context's own stream: the legacy default stream would synchronise with every other stream of the
+// process (another context's batches in flight) and take a hardware queue of its own
+static hipError_t copy_blocking(ellc_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  return e;
+}
+
 ellc_status enter(ellc_ctx* c, bool join) {
   int dev = -1;
   if (!(hipGetDevice(&dev) == hipSuccess && dev == c->cfg.device) && hipSetDevice(c->cfg.device) != hipSuccess)
@@ -505,10 +513,10 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     double *dA, *dR;
     float *dB, *dRB;
     TRY(dev_alloc(c, &dA, g.cols)); TRY(dev_alloc(c, &dR, g.rows)); TRY(dev_alloc(c, &dB, g.cols)); TRY(dev_alloc(c, &dRB, g.rows));
-    if (hipMemcpy(dA, colA.data(), g.cols * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(dR, rowA.data(), g.rows * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(dB, colB.data(), g.cols * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(dRB, rowB.data(), g.rows * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    if (copy_blocking(c, dA, colA.data(), g.cols * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        copy_blocking(c, dR, rowA.data(), g.rows * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        copy_blocking(c, dB, colB.data(), g.cols * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        copy_blocking(c, dRB, rowB.data(), g.rows * 4, hipMemcpyHostToDevice) != hipSuccess) {
       *out = c;
       return fail(c, ELLC_ERR_HIP, "cannot upload the Jacobian tables");
     }
@@ -519,7 +527,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     sh = (sh + 1) / 2;
   }
   TRY(dev_alloc(c, &c->geom_d, ELLC_MAX_LEVELS));
-  if (hipMemcpy(c->geom_d, c->geom_h, sizeof(LevelGeom) * c->L, hipMemcpyHostToDevice) != hipSuccess) {
+  if (copy_blocking(c, c->geom_d, c->geom_h, sizeof(LevelGeom) * c->L, hipMemcpyHostToDevice) != hipSuccess) {
     *out = c;
     return fail(c, ELLC_ERR_HIP, "cannot upload the level geometry");
   }
@@ -544,8 +552,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   }
   TRY(dev_alloc(c, &c->kf_tab_d, c->kf_tab_h.size()));
   TRY(dev_alloc(c, &c->fr_tab_d, c->fr_tab_h.size()));
-  if (hipMemcpy(c->kf_tab_d, c->kf_tab_h.data(), c->kf_tab_h.size() * sizeof(KfLevelDev), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->fr_tab_d, c->fr_tab_h.data(), c->fr_tab_h.size() * sizeof(FrLevelDev), hipMemcpyHostToDevice) != hipSuccess) {
+  if (copy_blocking(c, c->kf_tab_d, c->kf_tab_h.data(), c->kf_tab_h.size() * sizeof(KfLevelDev), hipMemcpyHostToDevice) != hipSuccess ||
+      copy_blocking(c, c->fr_tab_d, c->fr_tab_h.data(), c->fr_tab_h.size() * sizeof(FrLevelDev), hipMemcpyHostToDevice) != hipSuccess) {
     *out = c;
     return fail(c, ELLC_ERR_HIP, "cannot upload the slot tables");
   }
@@ -1195,7 +1203,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   long long V = 0;
   for (int b = 0; b < B; b++) {
     int v = 0;
-    ELLC_HIP(c, hipMemcpy(&v, c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + kf_slots[b]].count, 4, hipMemcpyDeviceToHost));
+    ELLC_HIP(c, copy_blocking(c, &v, c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + kf_slots[b]].count, 4, hipMemcpyDeviceToHost));
     V += v;
   }
   if (valid_pixels) *valid_pixels = V;

@@ -177,7 +177,8 @@ ellc_status ellc_ingest_configure(ellc_ctx* c, int orig_w, int orig_h, float fx,
   c->ingest_bgr = nullptr;
   ELLC_HIP(c, hipMalloc(&c->ingest_map, need.size() * sizeof(IngestMapEntry)));
   ELLC_HIP(c, hipMalloc(&c->ingest_bgr, (size_t)orig_w * orig_h * 3));
-  ELLC_HIP(c, hipMemcpy(c->ingest_map, need.data(), need.size() * sizeof(IngestMapEntry), hipMemcpyHostToDevice));
+  ELLC_HIP(c, hipMemcpyAsync(c->ingest_map, need.data(), need.size() * sizeof(IngestMapEntry), hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
   c->ingest_w = orig_w;
   c->ingest_h = orig_h;
   return ELLC_OK;
