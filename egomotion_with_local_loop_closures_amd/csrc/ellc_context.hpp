@@ -53,7 +53,7 @@ struct ellc_ctx {
   // pinned staging / result records and device work buffers (staged slots, AlignState, block partials); set 0 runs on the
   // context's main stream, sets 1 and 2 on streams of their own (created when first needed: a process holds few hardware
   // queues, and streams that end up on the same one do not overlap), so the batches run CONCURRENTLY: the latency-bound coarse iterations of one batch overlap the throughput-bound fine
-  // iterations of another (r01: 0.55 -> 0.36 ms per batch of 32 with three in flight). Batches that share a keyframe
+  // iterations of another (r01: 0.56 -> 0.34 ms per batch of 32 with three in flight). Batches that share a keyframe
   // slot are ordered one after the other (the compaction, H^-1 and the saved weights live in the keyframe slot). The
   // members above point at the set of the batch being enqueued. All other entry points work on `stream` and first make
   // it wait for the batches in flight, so a caller sees one in-order queue per context as before.
