@@ -150,7 +150,7 @@ def main():
         ms, alg_bytes, V = ctx.profile_gn_kernel(slots, slots, 0, reps=50)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "gn_fca_fused (level 0, batch %d): solve of the previous iteration + residual/Jacobian/accumulate" % B, "achieved": achieved, "peak": 8000.0,
-                           "unit": "GB/s", "frac": achieved / 8000.0, "traffic": pmc_traffic(a, B), "avg_launch_ms": ms,
+                           "unit": "GB/s", "frac": achieved / 8000.0, "traffic": pmc_traffic(a, B, G), "avg_launch_ms": ms,
                            "algorithmic_bytes_per_launch": alg_bytes, "valid_pixels_per_launch": V,
                            "valid_pixel_rate_Gpx_s": V / (ms * 1e-3) / 1e9,
                            "level0_gn_iterations_per_s": B / (ms * 1e-3)}
@@ -220,7 +220,7 @@ def early_exit_run(api, cfg, pairs, a, slots, mode):
             ctx.close()
 
 
-def pmc_traffic(a, B):
+def pmc_traffic(a, B, G):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE and
     WRITE_SIZE passes over tools/profile_kernel.py, FETCH_SIZE scaled by the calibration kernel: profiles/*_pmc_summary.json).
     Only valid for the workload the summary was taken on; otherwise null."""
@@ -231,7 +231,8 @@ def pmc_traffic(a, B):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
         try:
             d = json.load(open(f))
-            if d["profile_kernel_run"]["batch"] == B and d["profile_kernel_run"]["level"] == 0:
+            run = d["profile_kernel_run"]
+            if run["batch"] == B and run["level"] == 0 and (run.get("concurrent_batches", 1) > 1) == (G > 1):   # same grid
                 best = d["hbm_traffic"]["traffic_bytes_per_launch"]
         except Exception:
             pass
