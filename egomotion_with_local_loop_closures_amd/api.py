@@ -27,7 +27,8 @@ def default_config(width, height, levels=4, **kw):
 
 
 class Context:
-    """One HIP stream + resident keyframe / frame slots + one depth map (ellc_ctx)."""
+    """Resident keyframe / frame slots, one depth map and an in-order queue of work on the GPU (ellc_ctx); up to three
+    alignment batches may be in flight at once (align_enqueue / align_fetch)."""
 
     def __init__(self, cfg):
         self.cfg = cfg

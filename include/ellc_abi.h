@@ -14,8 +14,9 @@
  *   - all pointers are HOST pointers unless the parameter name ends in _dev.
  *   - pose = 6 f32 [wx wy wz vx vy vz] (rotation first, PixelWisePyramid.cpp:153).
  *   - images are u8 row-major W x H; depth / variance / weights are f32 row-major.
- *   - a context owns one HIP stream; calls on one context are serialised by the caller, calls on
- *     different contexts are independent (the reference's loop-closure thread, GlobalOptimize.cpp:241).
+ *   - a context owns its HIP streams (one, plus one per extra batch in flight: ellc_align_enqueue) and behaves as one
+ *     in-order queue; calls on one context are serialised by the caller, calls on different contexts are independent
+ *     and may come from different threads (the reference's loop-closure thread, GlobalOptimize.cpp:241).
  */
 #ifndef ELLC_ABI_H
 #define ELLC_ABI_H
