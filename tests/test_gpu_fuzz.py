@@ -12,6 +12,12 @@ pytestmark = pytest.mark.gpu
 CASES = [(96, 64, 3, 101), (101, 75, 3, 102), (64, 48, 3, 103), (160, 120, 4, 104), (128, 72, 3, 105), (90, 110, 3, 106),
          (200, 64, 3, 107), (64, 200, 3, 108), (96, 64, 3, 109), (96, 64, 3, 110), (117, 83, 3, 111), (240, 136, 4, 112),
          (72, 56, 3, 113), (150, 100, 3, 114), (96, 96, 3, 115), (320, 64, 3, 116)]
+# ELLC_FUZZ_EXTRA=n appends n more random (size, seed) cases for a one-off wide sweep (r01: 300 extra cases, all green)
+import os   # noqa: E402
+_extra = int(os.environ.get("ELLC_FUZZ_EXTRA", "0"))
+if _extra:
+    _r = np.random.default_rng(12345)
+    CASES = CASES + [(int(_r.integers(48, 260)), int(_r.integers(48, 200)), 3, 1000 + i) for i in range(_extra)]
 FIELDS = ("invDepth", "invDepthSmoothed", "variance", "varianceSmoothed", "validity", "blacklisted")
 
 
