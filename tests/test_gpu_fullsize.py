@@ -106,11 +106,12 @@ def test_normal_equations_properties(ellc):
     ctx.close()
 
 
-def test_ica_batch_against_oracle(oracle, ellc):
-    """Loop-closure mode (constant weights) as a batch, 640x480."""
+@pytest.mark.parametrize("concurrent", [1, 3])
+def test_ica_batch_against_oracle(oracle, ellc, concurrent):
+    """Loop-closure mode (constant weights) as a batch, 640x480, on the grids of both context configurations."""
     W, H, L, B = 640, 480, 4, 3
     pairs = [synth.make_pair(W, H, seed=300 + i) for i in range(B)]
-    ctx = gpu_problem(ellc, W, H, L, pairs)
+    ctx = gpu_problem(ellc, W, H, L, pairs, concurrent_batches=concurrent)
     refs = []
     rng = np.random.default_rng(1)
     for b, p in enumerate(pairs):
