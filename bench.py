@@ -241,29 +241,44 @@ def pmc_traffic(a, B, G):
 
 def cpu_baseline(a, pair, sched, gpu_value):
     """The CPU restatement (oracle, kind 'port') timed on this box's host cores on a bounded sample of the same
-    workload: full-schedule alignments of one 640x480 pair, (a) 3 row-band threads created/joined per iteration as
-    the reference does (NUM_POSE_THREADS=3, PixelWisePyramid.cpp:424-436), (b) all hardware threads."""
+    workload: full-schedule alignments of one 640x480 pair. Variants: one thread; 3 row-band threads created / joined per
+    iteration exactly as the reference does (NUM_POSE_THREADS=3, PixelWisePyramid.cpp:424-436) — the headline `value`;
+    and a persistent worker pool with 8 / 16 / 32 / 64 row bands (capped at the host's hardware threads), best reported.
+    Every variant gets the same wall-time budget; each is run twice and the faster run is kept (host noise)."""
     from oracle import oracle_py as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_problem
     W, H, L = a.width, a.height, a.levels
     _, kf, cur, dm = oracle_problem(O, W, H, L, pair, early_exit=0, max_iter=sched)
     dp = dm.depth_pyr()
-    res = {}
-    ncores = O.hardware_threads()
-    for name, nt in (("3T", 3), ("allcores", max(1, ncores))):
-        sec, its = O.align_timed(kf, cur, dp, loop_closure=(a.mode == "ica"), spawn_threads=True, n_threads=nt, reps=1)
-        reps = int(max(1, min(200, a.cpu_seconds / max(sec, 1e-3))))
-        sec, its = O.align_timed(kf, cur, dp, loop_closure=(a.mode == "ica"), spawn_threads=True, n_threads=nt, reps=reps)
-        res[name] = {"value": its / sec, "cores": nt, "seconds": sec, "alignments": reps}
-    return {"value": res["3T"]["value"], "unit": "GN iterations/s", "cores": 3, "kind": "port",
-            "sample": "%d full-schedule alignments of one %dx%d semi-dense pair (same schedule/inputs as the GPU workload), faithful-f32 "
-                      "restatement, 3 row-band threads forked/joined per iteration as the reference does; host has %d hardware threads"
-                      % (res["3T"]["alignments"], W, H, ncores),
-            "allcores": res["allcores"], "gpu_over_cpu_3T": gpu_value / res["3T"]["value"],
-            "gpu_over_cpu_allcores": gpu_value / res["allcores"]["value"],
-            "note": "upper bound on the real reference's speed: the restatement has none of its per-pixel cv::Mat temporaries, "
-                    "string-dispatched taps or per-level 29 MB allocations"}
+    ncores = max(1, O.hardware_threads())
+    lc = (a.mode == "ica")
+
+    def timed(nt, **kw):
+        sec, its = O.align_timed(kf, cur, dp, loop_closure=lc, n_threads=nt, reps=1, **kw)   # warm (pool threads, page faults)
+        reps = int(max(1, min(200, 0.5 * a.cpu_seconds / max(sec, 1e-3))))
+        best = None
+        for _ in range(2):
+            sec, its = O.align_timed(kf, cur, dp, loop_closure=lc, n_threads=nt, reps=reps, **kw)
+            if best is None or its / sec > best["value"]:
+                best = {"value": its / sec, "cores": nt, "seconds": sec, "alignments": reps}
+        return best
+
+    one = timed(1, spawn_threads=False)
+    three = timed(3, spawn_threads=True)
+    pool = {}
+    for nt in (8, 16, 32, 64):
+        if nt <= ncores:
+            pool[nt] = timed(nt, pool=True)
+    best = max(pool.values(), key=lambda r: r["value"]) if pool else three
+    return {"value": three["value"], "unit": "GN iterations/s", "cores": 3, "kind": "port",
+            "sample": "%d full-schedule alignments (x2 runs, faster kept) of one %dx%d semi-dense pair (same schedule/inputs as the GPU "
+                      "workload), faithful-f32 restatement, 3 row-band threads created/joined per iteration as the reference does; host has "
+                      "%d hardware threads" % (three["alignments"], W, H, ncores),
+            "1T": one, "3T": three, "3T_over_1T": three["value"] / one["value"],
+            "best": dict(best, threading="persistent pool, %d row bands" % best["cores"]),
+            "pool_sweep": {str(k): v["value"] for k, v in pool.items()},
+            "gpu_over_cpu_3T": gpu_value / three["value"], "gpu_over_cpu_best": gpu_value / best["value"]}
 
 
 if __name__ == "__main__":

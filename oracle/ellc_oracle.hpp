@@ -153,7 +153,9 @@ struct PixelWisePyramid {
   float weightedPose = 0;
   SumMode sum_mode = SUM_F32_BANDS;
   int n_threads = 3;         // NUM_POSE_THREADS
-  bool spawn_threads = false;  // run bands on real std::threads (CPU baseline); results identical
+  int thread_mode = 0;       // 0: bands run one after the other on the caller's thread (tests); 1: std::threads created
+                             // and joined per iteration as the reference does (CPU baseline); 2: persistent worker pool
+                             // (CPU baseline variant). Results identical in all three.
   PlaneF display_weightimg, display_iterationres;
   PlaneF savedWarpedPointsX, savedWarpedPointsY;
   std::vector<float> steepestDescent, weightedSteepestDescent;  // 6 x N row-major (ICA)
@@ -177,7 +179,7 @@ struct AlignResult {
 // ImageFunc.cpp:49-315  (initial pose from tminus1/prev world poses unless init_pose given)
 AlignResult GetImagePoseEstimate(Frame* prev_frame, Frame* current_frame, const DepthPyr* dm,
                                  Frame* tminus1, const float* init_rel_pose, bool fromLoopClosure,
-                                 bool save_weights, SumMode mode, bool spawn_threads, int n_threads);
+                                 bool save_weights, SumMode mode, int thread_mode, int n_threads);
 
 // ---------------------------------------------------------------- depth map
 struct Hyp {  // DepthHypothesis.h:14-40 (live fields only)

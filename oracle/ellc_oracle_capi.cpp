@@ -204,11 +204,11 @@ void orc_gn_save_weights(orc_gn_handle* h) { h->p->saveWeights(true); }
 void orc_gn_end(orc_gn_handle* h) { delete h->p; delete h; }
 
 // ---- full alignment (GetImagePoseEstimate). flags: bit0 fromLoopClosure (ICA), bit1 save weights,
-// bit2 spawn real threads per iteration (CPU baseline behaviour), sum_mode as above.
+// bit2 spawn real threads per iteration (CPU baseline behaviour), bit3 persistent worker pool instead; sum_mode as above.
 void orc_align(Frame* kf, Frame* cur, DepthPyr* dp, const float* init_pose, int flags, int sum_mode, int n_threads,
                float* pose6, int* iters, float* last_weighted) {
   AlignResult r = GetImagePoseEstimate(kf, cur, dp, cur, init_pose, (flags & 1) != 0, (flags & 2) != 0, (SumMode)sum_mode,
-                                       (flags & 4) != 0, n_threads);
+                                       (flags & 8) ? 2 : ((flags & 4) ? 1 : 0), n_threads);
   std::memcpy(pose6, r.pose, 24);
   if (iters) for (int l = 0; l < kf->cfg.levels; l++) iters[l] = r.iters[l];
   if (last_weighted) *last_weighted = r.last_weighted;
@@ -220,8 +220,8 @@ double orc_align_timed(Frame* kf, Frame* cur, DepthPyr* dp, const float* init_po
   long long its = 0;
   auto t0 = std::chrono::steady_clock::now();
   for (int r = 0; r < reps; r++) {
-    AlignResult a = GetImagePoseEstimate(kf, cur, dp, cur, init_pose, (flags & 1) != 0, false, SUM_F32_BANDS, (flags & 4) != 0,
-                                         n_threads);
+    AlignResult a = GetImagePoseEstimate(kf, cur, dp, cur, init_pose, (flags & 1) != 0, false, SUM_F32_BANDS,
+                                         (flags & 8) ? 2 : ((flags & 4) ? 1 : 0), n_threads);
     for (int l = 0; l < kf->cfg.levels; l++) its += a.iters[l];
   }
   auto t1 = std::chrono::steady_clock::now();

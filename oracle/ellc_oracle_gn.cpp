@@ -6,7 +6,79 @@
 #include <thread>
 #include <algorithm>
 
+#include <condition_variable>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+
 namespace ellc_oracle {
+
+// CPU-baseline variant only (thread_mode 2): T worker threads that stay alive between iterations and run the row bands of
+// every iteration, instead of the reference's create/join of NUM_POSE_THREADS threads per iteration
+// (PixelWisePyramid.cpp:424-436). Same bands, same sums; only the thread management differs.
+namespace {
+class BandPool {
+ public:
+  explicit BandPool(int T) : T_(T) {
+    for (int t = 0; t < T; t++) workers_.emplace_back([this, t] { loop(t); });
+  }
+  ~BandPool() {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      stop_ = true;
+      gen_++;
+    }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  void run(const std::function<void(int)>& f) {
+    std::unique_lock<std::mutex> l(m_);
+    job_ = &f;
+    left_ = T_;
+    gen_++;
+    cv_.notify_all();
+    done_.wait(l, [this] { return left_ == 0; });
+    job_ = nullptr;
+  }
+  static BandPool& get(int T) {
+    static std::mutex pm;
+    static std::map<int, std::unique_ptr<BandPool>> pools;
+    std::lock_guard<std::mutex> l(pm);
+    auto& p = pools[T];
+    if (!p) p.reset(new BandPool(T));
+    return *p;
+  }
+
+ private:
+  void loop(int t) {
+    unsigned long long seen = 0;
+    for (;;) {
+      const std::function<void(int)>* job;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        job = job_;
+      }
+      (*job)(t);
+      {
+        std::lock_guard<std::mutex> l(m_);
+        if (--left_ == 0) done_.notify_one();
+      }
+    }
+  }
+  int T_;
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* job_ = nullptr;
+  int left_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
+}  // namespace
 
 PixelWisePyramid::PixelWisePyramid(Frame* prev, Frame* cur, float* pose_, const DepthPyr* dm)
     : prev_frame(prev), current_frame(cur), depthMap(dm), pose(pose_) {
@@ -65,8 +137,14 @@ inline WarpOut warp_point(int x, int y, float Z, const Intrin& k, const float* S
 
 // PixelWisePyramid.cpp:58-413 — one row band. H/b are the band's f32 partial sums (raster order);
 // Hd/bd the same terms summed in double (SUM_F64 mode, diagnostics only).
-void PixelWisePyramid::calculatePixelWise(int ymin, int ymax, float H[36], float b[6], double Hd[36], double bd[6]) {
+void PixelWisePyramid::calculatePixelWise(int ymin, int ymax, float H_out[36], float b_out[6], double Hd_out[36], double bd_out[6]) {
   const Intrin k = get_intrinsic(prev_frame->cfg, prev_frame->pyrLevel);
+  // The band's sums live on this thread's stack and are stored once at the end (same additions in the same order). The
+  // reference gives every band separately allocated cv::Mat accumulators (PixelWisePyramid.cpp:370-404); accumulating
+  // through pointers into one contiguous vector shared by the bands would put several bands' sums into one cache line
+  // (false sharing) and make the multithreaded CPU baseline slower than one thread.
+  float H[36], b[6];
+  double Hd[36], bd[6];
   for (int i = 0; i < 36; i++) { H[i] = 0; Hd[i] = 0; }
   for (int i = 0; i < 6; i++) { b[i] = 0; bd[i] = 0; }
   float SE3[16];
@@ -152,6 +230,10 @@ void PixelWisePyramid::calculatePixelWise(int ymin, int ymax, float H[36], float
       }
     }
   }
+  std::memcpy(H_out, H, sizeof(H));
+  std::memcpy(b_out, b, sizeof(b));
+  std::memcpy(Hd_out, Hd, sizeof(Hd));
+  std::memcpy(bd_out, bd, sizeof(bd));
 }
 
 // PixelWisePyramid.cpp:416-455
@@ -164,7 +246,9 @@ void PixelWisePyramid::calculatePixelWiseParallel() {
     int y0 = t * y_increment, y1 = (t == T - 1) ? nRows : (t + 1) * y_increment;
     calculatePixelWise(y0, y1, &Hs[(size_t)t * 36], &bs[(size_t)t * 6], &Hds[(size_t)t * 36], &bds[(size_t)t * 6]);
   };
-  if (spawn_threads) {
+  if (thread_mode == 2) {
+    BandPool::get(T).run(band);
+  } else if (thread_mode == 1) {
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++) th.emplace_back(band, t);
     for (auto& t : th) t.join();
@@ -241,9 +325,11 @@ void PixelWisePyramid::precomputePixelWiseInvCompositional(int ymin, int ymax) {
 }
 
 // PixelWisePyramid.cpp:687-913
-void PixelWisePyramid::iteratePixelWiseInvCompositional(int ymin, int ymax, float b[6], double bd[6]) {
+void PixelWisePyramid::iteratePixelWiseInvCompositional(int ymin, int ymax, float b_out[6], double bd_out[6]) {
   const Intrin k = get_intrinsic(prev_frame->cfg, prev_frame->pyrLevel);
   const size_t N = (size_t)nRows * nCols;
+  float b[6];      // band sums on this thread's stack, stored once (see calculatePixelWise)
+  double bd[6];
   for (int i = 0; i < 6; i++) { b[i] = 0; bd[i] = 0; }
   float SE3[16];
   se3_exp(pose, SE3);
@@ -272,6 +358,8 @@ void PixelWisePyramid::iteratePixelWiseInvCompositional(int ymin, int ymax, floa
         bd[i] += (double)t;
       }
     }
+  std::memcpy(b_out, b, sizeof(b));
+  std::memcpy(bd_out, bd, sizeof(bd));
 }
 
 // PixelWisePyramid.cpp:917-974 (FLAG_DO_PARALLEL_CONST_WEIGHT_POSE_EST branch: 3 bands precompute, 2 uneven bands iterate)
@@ -300,7 +388,9 @@ void PixelWisePyramid::calculatePixelWiseParallelInvCompositional(int iter) {
   double bd1[6], bd2[6];
   auto f1 = [&]() { iteratePixelWiseInvCompositional(0, y_increment, b1, bd1); };
   auto f2 = [&]() { iteratePixelWiseInvCompositional(y_increment, nRows, b2, bd2); };
-  if (spawn_threads) {
+  if (thread_mode == 2) {
+    BandPool::get(2).run([&](int t) { if (t == 0) f1(); else f2(); });
+  } else if (thread_mode == 1) {
     std::thread t1(f1), t2(f2);
     t1.join();
     t2.join();
@@ -319,7 +409,7 @@ void PixelWisePyramid::calculatePixelWiseParallelInvCompositional(int iter) {
 // ImageFunc.cpp:92-138, 150-307
 AlignResult GetImagePoseEstimate(Frame* prev_frame, Frame* current_frame, const DepthPyr* dm, Frame* tminus1,
                                  const float* init_rel_pose, bool fromLoopClosure, bool save_weights, SumMode mode,
-                                 bool spawn_threads, int n_threads) {
+                                 int thread_mode, int n_threads) {
   const Config& cfg = prev_frame->cfg;
   AlignResult res;
   std::memset(&res, 0, sizeof(res));
@@ -331,7 +421,7 @@ AlignResult GetImagePoseEstimate(Frame* prev_frame, Frame* current_frame, const 
     current_frame->updationOnPyrChange(level, false);  // :159
     PixelWisePyramid wp(prev_frame, current_frame, pose, dm);
     wp.sum_mode = mode;
-    wp.spawn_threads = spawn_threads;
+    wp.thread_mode = thread_mode;
     wp.n_threads = n_threads;
     int iter;
     int executed = 0;

@@ -331,10 +331,12 @@ def align(kf, cur, dpyr, init_pose=None, loop_closure=False, save_weights=False,
     return pose, iters[:kf.cfg.levels].copy(), w.value
 
 
-def align_timed(kf, cur, dpyr, init_pose=None, loop_closure=False, spawn_threads=True, n_threads=3, reps=1):
+def align_timed(kf, cur, dpyr, init_pose=None, loop_closure=False, spawn_threads=True, n_threads=3, reps=1, pool=False):
+    """CPU baseline timing. spawn_threads: bands on std::threads created / joined per iteration (the reference's way);
+    pool: a persistent worker pool instead; neither: bands one after the other on the calling thread."""
     ip = np.zeros(6, np.float32) if init_pose is None else np.ascontiguousarray(init_pose, np.float32)
     its = C.c_longlong(0)
-    flags = (1 if loop_closure else 0) | (4 if spawn_threads else 0)
+    flags = (1 if loop_closure else 0) | (8 if pool else (4 if spawn_threads else 0))
     sec = lib().orc_align_timed(kf.h, cur.h, dpyr.h, _p(ip), flags, n_threads, reps, C.byref(its))
     return sec, its.value
 
