@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--inflight", type=int, default=3, help="batches in flight per GPU (1..3), each on its own stream and slot group")
     ap.add_argument("--early-exit", action="store_true", help="informational: the reference's early exit on (data-dependent iteration counts; "
                     "value then counts the iterations actually executed)")
+    ap.add_argument("--arith", choices=["fast", "exact"], default="fast", help="arithmetic of the Gauss-Newton pixel pass and solve (cfg.arith): "
+                    "fast = tolerance mode (pose <= 1e-5 vs the oracle), exact = per-pixel bit-exact mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse ranks sharing one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="wall-time budget of each CPU baseline variant")
@@ -72,7 +74,8 @@ def main():
     # the workload keeps G = --inflight groups of B keyframe / frame slots resident and step s works on group s % G.
     G = max(1, min(3, a.inflight))
     cfg = api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=int(a.early_exit), max_iter=sched, max_keyframes=G * B, max_frames=G * B,
-                             max_batch=B, device=dev_index, concurrent_batches=G)
+                             max_batch=B, device=dev_index, concurrent_batches=G,
+                             arith=api.ARITH_FAST if a.arith == "fast" else api.ARITH_EXACT)
     ctx = api.Context(cfg)
     for b in range(G * B):
         p = pairs[b % nd]

@@ -6,6 +6,8 @@ from ._lib import EllcConfig, EllcHypotheses, EllcError, MAX_LEVELS
 
 MODE_FCA = 0
 MODE_ICA = 1
+ARITH_EXACT = 0
+ARITH_FAST = 1
 HYP_FIELDS = ("invDepth", "invDepthSmoothed", "variance", "varianceSmoothed", "validity", "blacklisted", "valid")
 
 

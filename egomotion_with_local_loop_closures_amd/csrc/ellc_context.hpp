@@ -30,7 +30,10 @@ struct ellc_ctx {
   int L = 0;
   ellc::LevelGeom geom_h[ELLC_MAX_LEVELS];
   ellc::LevelGeom* geom_d = nullptr;
-  std::vector<void*> allocs;                 // everything hipMalloc'ed (freed on destroy)
+  std::vector<void*> allocs;                 // the arena chunks (freed on destroy)
+  char* arena_base = nullptr;                // current chunk: device buffers are carved out of a few large allocations
+  size_t arena_size = 0, arena_used = 0;
+  bool fast = false;                         // cfg.arith == ELLC_ARITH_FAST
   std::vector<void*> host_allocs;            // hipHostMalloc'ed
   std::vector<ellc::KfLevelDev> kf_tab_h;    // [L][max_kf]
   std::vector<ellc::FrLevelDev> fr_tab_h;    // [L][max_fr]

@@ -44,15 +44,32 @@ ellc_status enter(ellc_ctx* c, bool join) {
   return ELLC_OK;
 }
 
+// Device memory of a context comes from a few large chunks (first 64 MiB, then doubling up to 4 GiB), each allocated and
+// zeroed once; buffers are carved out at 256-byte granularity. A 640x480 context with 96 keyframe slots is thousands of
+// buffers: one hipMalloc + fill launch each made context creation take seconds.
+static ellc_status dev_alloc_bytes(ellc_ctx* c, void** p, size_t bytes) {
+  bytes = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
+  if (c->arena_used + bytes > c->arena_size) {
+    const size_t next = std::min<size_t>(std::max<size_t>(c->arena_size * 2, (size_t)64 << 20), (size_t)4 << 30);
+    const size_t chunk = std::max(bytes, next);
+    void* q = nullptr;
+    ELLC_HIP(c, hipMalloc(&q, chunk));
+    c->allocs.push_back(q);
+    ELLC_HIP(c, hipMemsetAsync(q, 0, chunk, c->stream));
+    c->arena_base = (char*)q;
+    c->arena_size = chunk;
+    c->arena_used = 0;
+  }
+  *p = c->arena_base + c->arena_used;
+  c->arena_used += bytes;
+  return ELLC_OK;
+}
 template <class T>
 static ellc_status dev_alloc(ellc_ctx* c, T** p, size_t count) {
   void* q = nullptr;
-  size_t bytes = std::max<size_t>(count * sizeof(T), 16);
-  ELLC_HIP(c, hipMalloc(&q, bytes));
-  ELLC_HIP(c, hipMemsetAsync(q, 0, bytes, c->stream));
-  c->allocs.push_back(q);
+  const ellc_status s = dev_alloc_bytes(c, &q, count * sizeof(T));
   *p = (T*)q;
-  return ELLC_OK;
+  return s;
 }
 template <class T>
 static ellc_status host_alloc(ellc_ctx* c, T** p, size_t count) {
@@ -67,7 +84,9 @@ static ellc_status host_alloc(ellc_ctx* c, T** p, size_t count) {
 // coarse levels (those launches are latency-bound); at the fine levels exactly the number of blocks the device
 // holds at once, so every CU gets the same share and each block pays the 27-value reduction once.
 int choose_nblk(const ellc_ctx* c, int level, int B) {
+#ifdef ELLC_DIAG
   if (c->nblk_override[level] > 0) return std::min(ELLC_NBLK_MAX, c->nblk_override[level]);   // tuning knob (ELLC_NBLK=l0,l1,..)
+#endif
   const int n = c->geom_h[level].n;
   const int by_px = std::max(1, n / 640);   // semi-dense maps are ~30 % valid: about one valid pixel per thread
   B = std::max(1, B);
@@ -149,6 +168,7 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
     case 1: hipLaunchKernelGGL(prep_scatter<1>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL(prep_scatter<2>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL(prep_scatter<4>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(prep_scatter<8>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     default: return fail(c, ELLC_ERR_BAD_ARG, "run_prep: unknown record set");
   }
   ELLC_HIP(c, hipGetLastError());
@@ -193,13 +213,17 @@ static GnArgs make_gn_args(ellc_ctx* c, int level, int B, int save_w, float* pla
 }
 
 static void launch_fca(ellc_ctx* c, dim3 grd, dim3 blk, const GnArgs& a) {
-  if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_accumulate<false, true>), grd, blk, 0, c->stream, a);
+  if (c->fast) hipLaunchKernelGGL((gn_fca_accumulate<false, false, true>), grd, blk, 0, c->stream, a);
+  else if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_accumulate<false, true>), grd, blk, 0, c->stream, a);
   else hipLaunchKernelGGL((gn_fca_accumulate<false, false>), grd, blk, 0, c->stream, a);
 }
 
 // Exhaustive check of div_const(a, b, RN(1/b)) == a / b for every f32 mantissa of a (division commutes with the
 // power-of-two scaling of a and of b, so one binade of a covers all normal inputs and every pyramid level).
-__attribute__((target("fma"))) static bool verify_div_const_fma(float b) {
+#if defined(__x86_64__)
+__attribute__((target("fma")))
+#endif
+static bool verify_div_const_fma(float b) {
   const float rb = (float)(1.0 / (double)b);
   for (uint32_t m = 0; m < (1u << 23); m++) {
     uint32_t bits = 0x3f800000u | m;
@@ -217,7 +241,11 @@ static bool verify_div_const(float b) {
   static std::mutex cache_mutex;   // contexts may be created from several threads
   std::lock_guard<std::mutex> lock(cache_mutex);
   if (!(b > 0.0f) || !std::isfinite(b)) return false;
+#if defined(__x86_64__)
   if (!__builtin_cpu_supports("fma")) return false;   // no hardware fma on this host: keep the plain divisions
+#elif !defined(__FP_FAST_FMAF)
+  return false;                                       // host without a known-fused fmaf: keep the plain divisions
+#endif
   uint32_t bits;
   std::memcpy(&bits, &b, 4);
   bits &= 0x007fffffu;   // mantissa only
@@ -236,7 +264,8 @@ static void launch_solve(ellc_ctx* c, int level, int B, int nblk, int mode, int 
   s.nblk = nblk;
   s.mode = mode;
   s.early_exit = early_exit;
-  hipLaunchKernelGGL(gn_solve, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, s);
+  if (c->fast) hipLaunchKernelGGL(gn_solve<true>, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, s);
+  else hipLaunchKernelGGL(gn_solve<false>, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, s);
 }
 
 // points the staging / result / work-buffer members at batch set p
@@ -315,13 +344,20 @@ static void set_age_split(ellc_ctx* c, FusedArgs& fa, int B) {
 static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
   const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
   const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
-  if (c->pipe) {
+  if (c->fast) {
+    hipLaunchKernelGGL((gn_fca_fused<false, true, true>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+  } else if (c->pipe) {
     if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, true>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
     else hipLaunchKernelGGL((gn_fca_fused<false, true>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
   } else {
     if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, false>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
     else hipLaunchKernelGGL((gn_fca_fused<false, false>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
   }
+}
+
+static void launch_finish(ellc_ctx* c, int B, const FusedArgs& fa) {
+  if (c->fast) hipLaunchKernelGGL(gn_fused_finish<true>, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
+  else hipLaunchKernelGGL(gn_fused_finish<false>, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
 }
 
 // FCA schedule: the solve of iteration n is folded into the prologue of launch n+1 (gn_fca_fused): one launch per
@@ -352,9 +388,9 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
       fa.seq++;
     }
     if (save_weights)
-      hipLaunchKernelGGL(gn_add_saved_weights, dim3(64, B), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, level, c->cfg.max_keyframes);
+      hipLaunchKernelGGL(gn_add_saved_weights, dim3(64, B), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, level, c->cfg.max_keyframes, c->fast ? 1 : 0);
   }
-  hipLaunchKernelGGL(gn_fused_finish, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
+  launch_finish(c, B, fa);
   ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
 }
@@ -378,14 +414,16 @@ static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
     fa.g = make_gn_args(c, level, B, 0, nullptr);
     const dim3 grd(fa.g.nblk, B), blk(ELLC_GN_THREADS);
     for (int it = 0; it < c->cfg.max_iter[level]; it++) {
-      hipLaunchKernelGGL(gn_ica_fused, grd, blk, 0, c->stream, (const AlignState*)(fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state),
-                         (const float*)(fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part), fa.prev_nblk, fa);
+      const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
+      const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
+      if (c->fast) hipLaunchKernelGGL(gn_ica_fused<true>, grd, blk, 0, c->stream, src_state, prev_part, fa.prev_nblk, fa);
+      else hipLaunchKernelGGL(gn_ica_fused<false>, grd, blk, 0, c->stream, src_state, prev_part, fa.prev_nblk, fa);
       fa.prev_level = level;
       fa.prev_nblk = fa.g.nblk;
       fa.seq++;
     }
   }
-  hipLaunchKernelGGL(gn_fused_finish, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
+  launch_finish(c, B, fa);
   ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
 }
@@ -412,7 +450,7 @@ static ellc_status enqueue_schedule(ellc_ctx* c, int B, int mode, int save_weigh
     }
     if (save_weights && mode == ELLC_MODE_FCA) {
       hipLaunchKernelGGL(gn_add_saved_weights, dim3(64, B), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, level,
-                         c->cfg.max_keyframes);
+                         c->cfg.max_keyframes, c->fast ? 1 : 0);
     }
   }
   ELLC_HIP(c, hipGetLastError());
@@ -458,6 +496,11 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   if (!cfg || !out) return ELLC_ERR_BAD_ARG;
   *out = nullptr;
   if (cfg->width < 16 || cfg->height < 16 || cfg->width > 65535 || cfg->height > 65535) return ELLC_ERR_BAD_ARG;
+  // the kernels index a plane with 32-bit offsets (24 * i and 48 * i byte offsets into the record lists) and the compaction
+  // converts a pixel index to f32 exactly: planes of at most 2^24 pixels
+  if ((long long)cfg->width * cfg->height > (1ll << 24)) return ELLC_ERR_BAD_ARG;
+  if (cfg->arith != ELLC_ARITH_EXACT && cfg->arith != ELLC_ARITH_FAST) return ELLC_ERR_BAD_ARG;
+  if (cfg->arith == ELLC_ARITH_FAST && (cfg->width > 4096 || cfg->height > 4096)) return ELLC_ERR_BAD_ARG;   // 12-bit x / y in FcaRecF
   if (cfg->levels < 1 || cfg->levels > ELLC_MAX_LEVELS) return ELLC_ERR_BAD_ARG;
   if ((cfg->width >> (cfg->levels - 1)) < 4 || (cfg->height >> (cfg->levels - 1)) < 4) return ELLC_ERR_BAD_ARG;
   if (cfg->max_keyframes < 1 || cfg->max_frames < 1 || cfg->max_batch < 1) return ELLC_ERR_BAD_ARG;
@@ -468,6 +511,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   ellc_ctx* c = new ellc_ctx();
   c->cfg = *cfg;
   c->L = cfg->levels;
+  c->fast = (cfg->arith == ELLC_ARITH_FAST);
   if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
     delete c;
     return ELLC_ERR_HIP;
@@ -494,10 +538,10 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     g.cy = (float)((double)cfg->cy / s);
     g.rfx = (float)(1.0 / (double)g.fx);
     g.rfy = (float)(1.0 / (double)g.fy);
-    {
-      const char* nd = getenv("ELLC_NO_DIVC");
-      g.divc_ok = (!(nd && nd[0] == '1') && verify_div_const(cfg->fx) && verify_div_const(cfg->fy)) ? 1 : 0;
-    }
+    g.divc_ok = (!c->fast && verify_div_const(cfg->fx) && verify_div_const(cfg->fy)) ? 1 : 0;   // the tolerance mode multiplies by rfx, rfy
+#ifdef ELLC_DIAG
+    if (const char* nd = getenv("ELLC_NO_DIVC")) if (nd[0] == '1') g.divc_ok = 0;
+#endif
     std::vector<double> colA(g.cols), rowA(g.rows);
     std::vector<float> colB(g.cols), rowB(g.rows);
     for (int x = 0; x < g.cols; x++) {
@@ -625,6 +669,10 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   }
   if (hipStreamSynchronize(c->stream) != hipSuccess) { *out = c; return fail(c, ELLC_ERR_HIP, "initial sync failed"); }
   {
+    for (int l = 0; l < ELLC_MAX_LEVELS; l++) c->nblk_override[l] = 0;
+#ifdef ELLC_DIAG
+    // Diagnostic builds only (make diag -> build/libellc_hip_diag.so, loaded through ELLC_LIB_PATH by the tools): the
+    // shipping library reads nothing from the environment.
     if (const char* nf = getenv("ELLC_NO_FUSE")) c->use_fused = !(nf[0] == '1');
     if (const char* ab = getenv("ELLC_NO_AGE_BALANCE")) c->age_balance = !(ab[0] == '1');
     if (const char* pp = getenv("ELLC_PIPE")) c->pipe = (pp[0] == '1');
@@ -640,9 +688,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
         }
       }
     }
-    const char* ng = getenv("ELLC_NO_GRAPH");
-    c->use_graph = !(ng && ng[0] == '1');
-    for (int l = 0; l < ELLC_MAX_LEVELS; l++) c->nblk_override[l] = 0;
+    if (const char* ng = getenv("ELLC_NO_GRAPH")) c->use_graph = !(ng[0] == '1');
     if (const char* nb = getenv("ELLC_NBLK")) {
       int l = 0;
       for (const char* q = nb; *q && l < ELLC_MAX_LEVELS; l++) {
@@ -651,6 +697,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
         if (*q == ',') q++;
       }
     }
+#endif
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0)
       c->resident_blocks = cus * (c->use_fused ? 4 : 5);   // 256-thread blocks per CU: 126 VGPRs (fused) -> 4 waves/SIMD, 92 -> 5
@@ -703,6 +750,7 @@ ellc_status ellc_keyframe_upload(ellc_ctx* c, int slot, const uint8_t* image) {
   ellc_status s = upload_pyramid(c, img, image);
   if (s != ELLC_OK) return s;
   c->kf_has_image[slot] = 1;
+  c->kf_has_depth[slot] = 0;         // a fresh frame has no depth yet (as ellc_keyframe_from_frame): set_depth / update_depth_image follow
   for (int l = 0; l < c->L; l++) {   // frame::frame zeroes weight_pyramid / numWeightsAdded (Frame.cpp:114-122)
     ELLC_HIP(c, hipMemsetAsync(c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + slot].weight, 0, (size_t)c->geom_h[l].n * 4, c->stream));
     c->kf_num_weights[slot][l] = 0;
@@ -928,7 +976,7 @@ ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, i
 static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int save_weights) {
   enqueue_stage_in(c, B);   // also initialises the B alignment states
   // mask / count per level (updationOnPyrChange, ImageFunc.cpp:158) and the pose-independent per-pixel records
-  const int need = mode == ELLC_MODE_ICA ? (c->use_fused ? 4 : 1) : 2;
+  const int need = mode == ELLC_MODE_ICA ? (c->use_fused ? 4 : 1) : (c->fast ? 8 : 2);
   ellc_status s = run_prep(c, nu, need);
   if (s != ELLC_OK) return s;
   if (need == 4) enqueue_ica_hinv(c, nu);
@@ -967,6 +1015,10 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
   int nu = 0;
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
   if (s != ELLC_OK) return s;
+  // saved weights are accumulated per keyframe slot (wlast, weight plane, numWeightsAdded): two alignments of one batch on the
+  // same slot would race on them
+  if (save_weights && mode == ELLC_MODE_FCA && nu < B)
+    return fail(c, ELLC_ERR_BAD_ARG, "save_weights needs a different keyframe slot for every alignment of the batch");
   hipStream_t run_stream = set > 0 ? bs.stream : c->stream;
   if (track) {
     // A batch on another stream runs after everything the caller has put on the main stream through the other entry
@@ -1001,10 +1053,14 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
         ELLC_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         s = enqueue_align_body(c, B, nu, mode, save_weights);
         hipError_t e = hipStreamEndCapture(c->stream, &graph);
-        if (s != ELLC_OK) return s;
-        if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        ELLC_HIP(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        if (s != ELLC_OK || e != hipSuccess) {
+          if (graph) (void)hipGraphDestroy(graph);
+          if (s != ELLC_OK) return s;
+          return fail(c, ELLC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        }
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
         it = c->graphs.emplace(key, exec).first;
       }
       ELLC_HIP(c, hipGraphLaunch(it->second, c->stream));
@@ -1037,9 +1093,10 @@ ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters
   if (c->n_inflight < 1) return fail(c, ELLC_ERR_NOT_READY, "ellc_align_fetch: no batch in flight");
   const ellc_ctx::BatchSet& bs = c->batch_set[c->inflight[0]];   // the oldest batch
   if (B != bs.B) return fail(c, ELLC_ERR_BAD_ARG, "ellc_align_fetch: the oldest batch in flight has a different size");
-  ELLC_HIP(c, hipEventSynchronize(bs.done));   // its last kernel wrote bs.result_h (pinned, zero-copy)
-  for (int i = 1; i < c->n_inflight; i++) c->inflight[i - 1] = c->inflight[i];
+  const hipError_t ev = hipEventSynchronize(bs.done);   // its last kernel wrote bs.result_h (pinned, zero-copy)
+  for (int i = 1; i < c->n_inflight; i++) c->inflight[i - 1] = c->inflight[i];   // the batch leaves the queue either way
   c->n_inflight--;
+  if (ev != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("ellc_align_fetch: the batch failed on the device: ") + hipGetErrorString(ev));
   for (int b = 0; b < B; b++) {
     if (out_pose) std::memcpy(out_pose + b * 6, bs.result_h[b].pose, 24);
     if (out_iters) for (int l = 0; l < c->L; l++) out_iters[b * c->L + l] = bs.result_h[b].iters[l];
@@ -1076,7 +1133,7 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   ellc_status s = stage_batch(c, 1, &kf_slot, &frame_slot, pose, &nu);
   if (s != ELLC_OK) return s;
   enqueue_stage_in(c, 0);   // staging only: the state keeps the level's H^-1 (gn_set_pose0)
-  s = run_prep(c, nu, mode == ELLC_MODE_ICA ? 1 : 2);
+  s = run_prep(c, nu, mode == ELLC_MODE_ICA ? 1 : (c->fast ? 8 : 2));
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_set_pose0, dim3(1), dim3(1), 0, c->stream, c->state_d, c->init_pose_d);
   const size_t n = (size_t)c->geom_h[level].n;
@@ -1084,7 +1141,8 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   GnArgs a = make_gn_args(c, level, 1, 0, planes ? c->planes_d : nullptr);
   const dim3 grd(a.nblk, 1), blk(ELLC_GN_THREADS);
   if (mode == ELLC_MODE_FCA) {
-    if (planes && c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_accumulate<true, true>), grd, blk, 0, c->stream, a);
+    if (planes && c->fast) hipLaunchKernelGGL((gn_fca_accumulate<true, false, true>), grd, blk, 0, c->stream, a);
+    else if (planes && c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_accumulate<true, true>), grd, blk, 0, c->stream, a);
     else if (planes) hipLaunchKernelGGL((gn_fca_accumulate<true, false>), grd, blk, 0, c->stream, a);
     else launch_fca(c, grd, blk, a);
     launch_solve(c, level, 1, a.nblk, 0, 0);
@@ -1146,7 +1204,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, nullptr, &nu);
   if (s != ELLC_OK) return s;
   enqueue_stage_in(c, 0);
-  s = run_prep(c, nu, 2);
+  s = run_prep(c, nu, c->fast ? 8 : 2);
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
   GnArgs a = make_gn_args(c, level, B, 0, nullptr);

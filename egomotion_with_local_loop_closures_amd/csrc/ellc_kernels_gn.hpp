@@ -111,8 +111,15 @@ struct Taps {
 // Fast path: when every active lane of the wave samples the interior (all 16 neighbours in range, none of the
 // four taps on a border column/row) the validity selects, clamps and border scales drop out; the arithmetic
 // that remains is the same expression, so the results are bit-identical to the general path.
-template <bool WANT_GRAD>
-__device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, float x1, float y1) {
+// FAST (cfg.arith = ELLC_ARITH_FAST): the interior path interpolates in the fused form a + w (b - a) and applies the 0.5 of
+// the central differences once to the interpolated gradient: same values to within a few ulp, 19 instructions fewer.
+// after_issue() is called exactly once, on the interior path right after the tap loads have been issued: the pixel loops
+// request the next pixel's record there. Vector loads return in order, so a record load issued BEFORE the taps would have
+// to come back from HBM before the (cache-resident) taps count as complete; issued behind them it stays in flight while
+// this pixel's arithmetic runs.
+struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+template <bool WANT_GRAD, bool FAST = false, class AfterIssue = NoPrefetch>
+__device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, float x1, float y1, AfterIssue after_issue = AfterIssue()) {
   Taps o;
   const float fx0 = floorf(x1), fy0 = floorf(y1);
   const float wx = x1 - fx0, wy = y1 - fy0;
@@ -123,14 +130,38 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
     const int x0 = (int)fx0, y0 = (int)fy0;
     const unsigned ob = (unsigned)(y0 * sw + x0) - 1u, oc = ob + (unsigned)sw;
     const uint32_t wb = load_u32_unaligned(img, ob), wc = load_u32_unaligned(img, oc);
+    uint32_t wa = 0, wd = 0;
+    if (WANT_GRAD) { wa = load_u32_unaligned(img, ob - (unsigned)sw); wd = load_u32_unaligned(img, oc + (unsigned)sw); }
+    __builtin_amdgcn_sched_barrier(0);
+    after_issue();
+    __builtin_amdgcn_sched_barrier(0);
     const float Pbb = byte_f32<1>(wb), Pbc = byte_f32<2>(wb), Pcb = byte_f32<1>(wc), Pcc = byte_f32<2>(wc);
+    if (FAST) {
+      const float top = __builtin_fmaf(wx, Pbc - Pbb, Pbb);
+      const float btm = __builtin_fmaf(wx, Pcc - Pcb, Pcb);
+      o.I = __builtin_fmaf(wy, btm - top, top);
+      if (WANT_GRAD) {
+        const float Pba = byte_f32<0>(wb), Pbd = byte_f32<3>(wb), Pca = byte_f32<0>(wc), Pcd = byte_f32<3>(wc);
+        const float Pab = byte_f32<1>(wa), Pac = byte_f32<2>(wa), Pdb = byte_f32<1>(wd), Pdc = byte_f32<2>(wd);
+        const float g00 = Pbc - Pba, g01 = Pbd - Pbb, g10 = Pcc - Pca, g11 = Pcd - Pcb;   // twice the central differences
+        float t2 = __builtin_fmaf(wx, g01 - g00, g00);
+        float b2 = __builtin_fmaf(wx, g11 - g10, g10);
+        o.gx = 0.5f * __builtin_fmaf(wy, b2 - t2, t2);
+        const float h00 = Pcb - Pab, h01 = Pcc - Pac, h10 = Pdb - Pbb, h11 = Pdc - Pbc;
+        t2 = __builtin_fmaf(wx, h01 - h00, h00);
+        b2 = __builtin_fmaf(wx, h11 - h10, h10);
+        o.gy = 0.5f * __builtin_fmaf(wy, b2 - t2, t2);
+      } else {
+        o.gx = 0.0f; o.gy = 0.0f;
+      }
+      return o;
+    }
     {
       const float top = (omx * Pbb) + (wx * Pbc);
       const float btm = (omx * Pcb) + (wx * Pcc);
       o.I = (omy * top) + (wy * btm);
     }
     if (WANT_GRAD) {
-      const uint32_t wa = load_u32_unaligned(img, ob - (unsigned)sw), wd = load_u32_unaligned(img, oc + (unsigned)sw);
       const float Pba = byte_f32<0>(wb), Pbd = byte_f32<3>(wb), Pca = byte_f32<0>(wc), Pcd = byte_f32<3>(wc);
       const float Pab = byte_f32<1>(wa), Pac = byte_f32<2>(wa), Pdb = byte_f32<1>(wd), Pdc = byte_f32<2>(wd);
       const float g00 = 0.5f * (Pbc - Pba), g01 = 0.5f * (Pbd - Pbb), g10 = 0.5f * (Pcc - Pca), g11 = 0.5f * (Pcd - Pcb);
@@ -147,6 +178,7 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
     return o;
   }
   // ---- general path: per-tap bounds tests of the reference (Frame.h:211-275)
+  after_issue();
   if (x1 != x1 || y1 != y1) {  // NaN: reference behaviour undefined; treated as out of bounds
     o.I = -1.0f; o.gx = 0.0f; o.gy = 0.0f;
     return o;
@@ -400,11 +432,11 @@ __device__ __forceinline__ void jacobian_row_pre(float gradx, float grady, const
   J[5] = jt5 + jb5;
 }
 
-template <bool DEBUG>
+template <bool DEBUG, class PF = NoPrefetch>
 __device__ __forceinline__ FcaPix fca_pixel_pre(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
-                                                const float* S, unsigned i, const FcaIn& in, const FcaPre& pre) {
+                                                const float* S, unsigned i, const FcaIn& in, const FcaPre& pre, PF pf = PF()) {
   const Warp w = warp_point<true>(in.X, in.Y, in.Z, g, S);
-  const Taps t = tap_point<true>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
+  const Taps t = tap_point<true, false, PF>(cur, g.sw, g.cols, g.rows, w.wx, w.wy, pf);
   FcaPix o;
   jacobian_row_pre(t.gx, t.gy, pre, o.J);
   const bool oob = (t.I == -1.0f);
@@ -424,16 +456,86 @@ __device__ __forceinline__ FcaPix fca_pixel_pre(const GnArgs& a, const KfLevelDe
   return o;
 }
 
-template <bool DEBUG, bool DIVC>
+template <bool DEBUG, bool DIVC, class PF = NoPrefetch>
 __device__ __forceinline__ FcaPix fca_pixel_in(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
-                                               const float* S, unsigned i, const FcaIn& in) {
-  return fca_pixel_pre<DEBUG>(a, K, g, cur, S, i, in, fca_prepare<DIVC>(g, in));
+                                               const float* S, unsigned i, const FcaIn& in, PF pf = PF()) {
+  return fca_pixel_pre<DEBUG, PF>(a, K, g, cur, S, i, in, fca_prepare<DIVC>(g, in), pf);
 }
 
 template <bool DEBUG, bool DIVC>
 __device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
                                             const float* S, unsigned i) {
   return fca_pixel_in<DEBUG, DIVC>(a, K, g, cur, S, i, fca_load(K, i));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Tolerance-mode pixel pass (cfg.arith = ELLC_ARITH_FAST). Same formulas as PixelWisePyramid.cpp:236-361, evaluated in f32
+// with fused multiply-adds and the hardware reciprocal / reciprocal square root (1 ulp) in place of the IEEE division and
+// sqrt sequences, and f32 products where the reference's pow() promotes to double. Per-pixel values agree with the
+// exact path to a few 1e-7 relative (tests/test_gpu_fast.py states the bounds); the final pose to well below the 1e-5 bar.
+// About 130 VALU instructions per pixel instead of 285, 16-byte records instead of 32.
+struct FcaInF { uint32_t xyI; float Z, var, d; };
+
+__device__ __forceinline__ FcaInF fcaf_load(const KfLevelDev& K, unsigned i) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = *(const ELLC_GLOBAL u32x4*)((const ELLC_GLOBAL char*)K.crec + i * 16u);
+  FcaInF in;
+  // (elements are copied to scalars first: __builtin_bit_cast applied to a vector element expression reads element 0)
+  const uint32_t w1 = v.y, w2 = v.z, w3 = v.w;
+  in.xyI = v.x; in.Z = __builtin_bit_cast(float, w1); in.var = __builtin_bit_cast(float, w2); in.d = __builtin_bit_cast(float, w3);
+  return in;
+}
+
+template <bool DEBUG, class PF = NoPrefetch>
+__device__ __forceinline__ FcaPix fcaf_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const float* S, unsigned i,
+                                             const FcaInF& in, PF pf = PF()) {
+  const int x = (int)(in.xyI & 0xfffu), y = (int)((in.xyI >> 12) & 0xfffu);
+  const float Ikf = byte_f32<3>(in.xyI);
+  const float p = ((float)x - g.cx) * g.rfx, q = ((float)y - g.cy) * g.rfy;   // u / fx, v / fy
+  const float Z = in.Z;
+  const float X = p * Z, Y = q * Z;
+  const float px = __builtin_fmaf(S[0], X, __builtin_fmaf(S[1], Y, __builtin_fmaf(S[2], Z, S[3])));
+  const float py = __builtin_fmaf(S[4], X, __builtin_fmaf(S[5], Y, __builtin_fmaf(S[6], Z, S[7])));
+  const float pz = __builtin_fmaf(S[8], X, __builtin_fmaf(S[9], Y, __builtin_fmaf(S[10], Z, S[11])));
+  // no clamp of pz away from zero (ExternVariable.h:232): 1/0 = inf sends the point out of bounds, as the clamped value does
+  const float rz = __builtin_amdgcn_rcpf(pz);
+  const float wx = __builtin_fmaf(px * rz, g.fx, g.cx);
+  const float wy = __builtin_fmaf(py * rz, g.fy, g.cy);
+  const Taps t = tap_point<true, true, PF>(cur, g.sw, g.cols, g.rows, wx, wy, pf);
+  FcaPix o;
+  // 1x6 row (:296-320) with A = fx gradx, B = fy grady, T = A p + B q:
+  //   J = [-(q T + B), p T + A, B p - A q, A d, B d, -d T]
+  const float A = g.fx * t.gx, B = g.fy * t.gy;
+  const float T = __builtin_fmaf(A, p, B * q);
+  o.J[0] = -__builtin_fmaf(q, T, B);
+  o.J[1] = __builtin_fmaf(p, T, A);
+  o.J[2] = __builtin_fmaf(B, p, -(A * q));
+  o.J[3] = A * in.d;
+  o.J[4] = B * in.d;
+  o.J[5] = -(in.d * T);
+  const bool oob = (t.I == -1.0f);
+  const float res = t.I - Ikf;
+  // weight (:341-358): 1 / (pz^2 d) = Z rz^2;  w_p = 1 / D, sqrt(w_p) = rsq(D);  Huber: w_p below the knee, 1.5 sqrt(w_p) / |r| above
+  const float tx = S[3], ty = S[7], tz = S[11];
+  const float n0 = __builtin_fmaf(tx, pz, -(tz * px)), n1 = __builtin_fmaf(ty, pz, -(tz * py));
+  const float drpdd = __builtin_fmaf(A, n0, B * n1) * (Z * (rz * rz));
+  const float D = __builtin_fmaf(in.var * drpdd, drpdd, 16.0f);
+  const float r = __builtin_amdgcn_rsqf(D);
+  const float ares = fabsf(res);
+  const float wgt = r * ((ares * r < 1.5f) ? r : 1.5f * __builtin_amdgcn_rcpf(ares));
+  o.residual = oob ? 0.0f : res;
+  o.wgt = oob ? 0.0f : wgt;
+  if (a.save_w) *(ELLC_GLOBAL float*)((ELLC_GLOBAL char*)K.wlast + i * 4u) = o.wgt;
+  if (DEBUG) {
+    const size_t n = (size_t)g.n, pp = (size_t)y * g.cols + x;
+    a.planes[0 * n + pp] = o.residual;
+    a.planes[1 * n + pp] = o.wgt;
+    a.planes[2 * n + pp] = oob ? -1.0f : wx;
+    a.planes[3 * n + pp] = oob ? -1.0f : wy;
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.planes[(4 + k) * n + pp] = o.J[k];
+  }
+  return o;
 }
 
 // H += (w J)^T J (upper triangle), b += J (r w)   (PixelWisePyramid.cpp:364-374)
@@ -486,7 +588,7 @@ __device__ __forceinline__ void fca_acc_unpack(const FcaAcc& A, float (&o)[27]) 
 
 // FCA accumulate without the folded solve (single-step API, debug planes, ELLC_NO_FUSE): grid (nblk, B). Each block
 // owns a contiguous chunk of the alignment's compact pixel list and writes one 27-float partial record.
-template <bool DEBUG, bool DIVC>
+template <bool DEBUG, bool DIVC, bool FAST = false>
 __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   const int b = blockIdx.y;
   const AlignState& st = a.state[b];
@@ -505,7 +607,9 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   FcaAcc acc;
   fca_acc_zero(acc);
   for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
-    const FcaPix p = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
+    FcaPix p;
+    if constexpr (FAST) p = fcaf_pixel<DEBUG>(a, K, g, cur, S, (unsigned)i, fcaf_load(K, (unsigned)i));
+    else p = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
     fca_accumulate_pixel(acc, p);
   }
   float sums[27];
@@ -669,6 +773,63 @@ __device__ __forceinline__ void lu_inverse6_lanes(float (&A)[36], int lane, floa
   if (singular) {
 #pragma unroll
     for (int i = 0; i < 6; i++) x[i] = 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Tolerance-mode solve (cfg.arith = ELLC_ARITH_FAST). The normal equations H delta = -b are solved directly by an
+// L D L^T factorisation in double (H is a sum of w J^T J, symmetric positive semi-definite) instead of forming
+// cv::Mat::inv(DECOMP_LU) in f32 and multiplying: more accurate than the reference's own update and a much shorter
+// dependent chain (every lane runs the whole 6x6 factorisation redundantly on registers; no cross-lane step). A pivot
+// below FLT_EPSILON gives the zero update, as the reference's singular inverse does (PixelWisePyramid.cpp:451).
+// sums: 21 upper-triangular entries by rows, then b.
+__device__ __forceinline__ double rcp_f64(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ void ldlt_solve6(const double* sums, double (&x)[6]) {
+  double A[6][6];   // lower triangle used
+  {
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = r; c < 6; c++) A[c][r] = sums[q++];
+  }
+  double y[6], dinv[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] = -sums[21 + i];
+  bool singular = false;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const double dj = A[j][j];
+    if (!(dj >= 1.1920928955078125e-07)) singular = true;
+    const double inv = rcp_f64(dj);
+    dinv[j] = inv;
+    double col[6];   // column j below the diagonal, still scaled: L_ij d_j
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) col[i] = A[i][j];
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      const double l = col[i] * inv;
+      A[i][j] = l;
+#pragma unroll
+      for (int k = j + 1; k <= i; k++) A[i][k] = __builtin_fma(-l, col[k], A[i][k]);
+      y[i] = __builtin_fma(-l, y[j], y[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double v = y[i] * dinv[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) v = __builtin_fma(-A[k][i], x[k], v);
+    x[i] = v;
+  }
+  if (singular) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = 0.0;
   }
 }
 
@@ -838,6 +999,77 @@ __device__ __forceinline__ void solve_finish(SolveShared& sh, int mode, int leve
   __syncthreads();
 }
 
+// Second half of the solve in tolerance mode: delta from the L D L^T solve (mode 0) or from the level's H^-1 (mode 2), then
+// exp(pose) <- exp(delta) exp(pose) rounded to f32 — the same product the exact path forms — WITHOUT the round trip through
+// log and exp that follows it there (PixelWisePyramid.cpp:483-489 keeps the pose as a twist and re-exponentiates it every
+// iteration; mathematically the identity, a few 1e-8 per iteration in f32). The twist is recovered once, by the kernel that
+// ends the schedule (log of the final matrix). Ends with a block barrier.
+__device__ __forceinline__ void solve_finish_fast(SolveShared& sh, int mode, int level, int early_exit, const AlignState& src,
+                                                  const float* S_cur, int level_done_cur, AlignState* dst) {
+  const int t = threadIdx.x;
+  if (t < 64) {
+    const int lane = t;
+    const float S_lane = S_cur[min(lane, 11)];
+    double x[6];
+    if (mode == 0) {
+      double sums[27];
+#pragma unroll
+      for (int i = 0; i < 27; i++) sums[i] = sh.sums[i];
+      ldlt_solve6(sums, x);
+      if (lane == 0 && dst) {
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int c = r; c < 6; c++) {
+            const float v = (float)sums[q++];
+            dst->H[r * 6 + c] = v;
+            dst->H[c * 6 + r] = v;
+          }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc += (double)(float)sh.sums[21 + k] * (double)sh.Hinv[i * 6 + k];
+        x[i] = -acc;
+      }
+    }
+    float delta[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) delta[i] = (float)x[i];
+    if (lane == 0 && dst) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) { dst->delta[i] = delta[i]; dst->b[i] = (float)sh.sums[21 + i]; }
+    }
+    const float weighted = fabsf(delta[0] * 100000.0f) + fabsf(delta[1] * 100000.0f) + fabsf(delta[2] * 100000.0f) +
+                           fabsf(delta[3] * 10000.0f) + fabsf(delta[4] * 10000.0f) + fabsf(delta[5] * 10000.0f);
+    const int l9 = min(lane, 8);
+    const int r3 = l9 / 3, k3 = l9 - 3 * r3;
+    double Rrk, Vv;
+    exp_se3_entry(x[0], x[1], x[2], x[3], x[4], x[5], r3, k3, Rrk, Vv);
+    const double trow = (Vv + __shfl_down(Vv, 1)) + __shfl_down(Vv, 2);   // t[r] in lanes 0, 3, 6
+    const float Df = (float)Rrk, Dt = (float)trow;
+    const int e = min(lane, 11), r = e >> 2, c = e & 3;
+    const float d0 = __shfl(Df, 3 * r), d1 = __shfl(Df, 3 * r + 1), d2 = __shfl(Df, 3 * r + 2), d3 = __shfl(Dt, 3 * r);
+    const float b0 = __shfl(S_lane, c), b1 = __shfl(S_lane, 4 + c), b2 = __shfl(S_lane, 8 + c);
+    double cs = 0.0;
+    cs += (double)d0 * (double)b0;
+    cs += (double)d1 * (double)b1;
+    cs += (double)d2 * (double)b2;
+    if (c == 3) cs += (double)d3;
+    if (lane < 12) sh.newS[lane] = (float)cs;
+    if (lane < 6) sh.newpose[lane] = src.pose[lane];   // not maintained per iteration in this mode
+    if (lane == 0) {
+      sh.weighted = weighted;
+      sh.level_done = (early_exit && weighted < 1.0f) ? level : level_done_cur;   // ImageFunc.cpp:251-252
+    }
+  }
+  __syncthreads();
+}
+
+template <bool FAST = false>
 __device__ __forceinline__ void solve_step(SolveShared& sh, double group_sum, int mode, int level, int early_exit,
                                            const AlignState& src, AlignState* dst, const float* hinv_src = nullptr) {
   const int t = threadIdx.x;
@@ -854,18 +1086,29 @@ __device__ __forceinline__ void solve_step(SolveShared& sh, double group_sum, in
   }
   __syncthreads();
   ELLC_STAMP(2);
-  solve_finish(sh, mode, level, early_exit, src, src.S, src.level_done, dst);
+  if (FAST && mode != 1) solve_finish_fast(sh, mode, level, early_exit, src, src.S, src.level_done, dst);
+  else solve_finish(sh, mode, level, early_exit, src, src.S, src.level_done, dst);
 }
 
 // One block per alignment (used by the ICA path, the single-step API and as the final solve of a fused schedule).
+template <bool FAST>
 __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_solve(SolveArgs a) {
   const int b = blockIdx.x;
   AlignState& st = a.state[b];
   if (st.level_done == a.level) return;
   __shared__ SolveShared sh;
-  solve_step(sh, partial_group_sum(a.partials + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, a.nblk), a.mode, a.level, a.early_exit, st, &st);
+  solve_step<FAST>(sh, partial_group_sum(a.partials + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, a.nblk), a.mode, a.level, a.early_exit, st, &st);
   if (a.mode == 1) return;
   const int t = threadIdx.x;
+  if (FAST) {   // the twist of the updated matrix, for the callers of the single-step API
+    if (t == 0) {
+      float S[12], np[6];
+      for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
+      log_se3_f32(S, np);
+      for (int i = 0; i < 6; i++) sh.newpose[i] = np[i];
+    }
+    __syncthreads();
+  }
   if (t < 6) st.pose[t] = sh.newpose[t];
   if (t < 12) st.S[t] = sh.newS[t];
   if (t == 0) {
@@ -904,7 +1147,7 @@ struct FusedArgs {
 // pending partial sums, block counts): the library is built with kernel-argument preloading, so they arrive in SGPRs with
 // the wave instead of through a scalar load from the argument buffer — one memory round trip less at the head of a
 // latency-bound kernel. Everything else stays in the by-value struct.
-template <bool DIVC, bool PIPE>
+template <bool DIVC, bool PIPE, bool FAST = false>
 __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignState* src_state, const float* prev_part, int prev_nblk,
                                                                    int nblk, int age_rounds, FusedArgs fa) {   // 4 waves per SIMD: at most 128 VGPRs
   const GnArgs& a = fa.g;
@@ -950,17 +1193,27 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
     begin = sub * chunk;
     end = min(V, begin + chunk);
   }
-  const int stride = ELLC_GN_THREADS;
+  constexpr int stride = ELLC_GN_THREADS;
   g_u8 cur = as_global(F.img);
+  // this thread's first compact pixel, requested before the solve (exact mode: together with its pose-independent products)
   FcaIn first;
   first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.X = 0.0f; first.Y = 0.0f; first.invZ = 1.0;
-  if (begin + t < end) first = fca_load(K, (unsigned)(begin + t));
-  const FcaPre first_pre = fca_prepare<DIVC>(g, first);
-  // pin the arithmetic here (the compiler would otherwise sink it below the solve, onto the critical path)
-  asm volatile("" ::"v"(first_pre.c_t0), "v"(first_pre.c_b1), "v"(first_pre.d), "v"(first_pre.fxz), "v"(first_pre.fyz),
-               "v"(first_pre.nvz), "v"(first_pre.nuz));
+  FcaInF firstf;
+  firstf.xyI = 0; firstf.Z = 1.0f; firstf.var = 0.0f; firstf.d = 1.0f;
+  FcaPre first_pre;
+  if constexpr (FAST) {
+    if (begin + t < end) firstf = fcaf_load(K, (unsigned)(begin + t));
+  } else {
+    if (begin + t < end) {
+      first = fca_load(K, (unsigned)(begin + t));
+    }
+    first_pre = fca_prepare<DIVC>(g, first);
+    // pin the arithmetic here (the compiler would otherwise sink it below the solve, onto the critical path)
+    asm volatile("" ::"v"(first_pre.c_t0), "v"(first_pre.c_b1), "v"(first_pre.d), "v"(first_pre.fxz), "v"(first_pre.fyz),
+                 "v"(first_pre.nvz), "v"(first_pre.nuz));
+  }
   if (pending) {
-    solve_step(sh, group_sum, 0, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr);
+    solve_step<FAST>(sh, group_sum, 0, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr);
   } else {
     if (t < 6) sh.newpose[t] = src.pose[t];
     if (t < 12) sh.newS[t] = src.S[t];
@@ -988,26 +1241,48 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   FcaAcc acc;
   fca_acc_zero(acc);
   int i = begin + t;
-  if (i < end) {
-    const FcaPix p = fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre);
-    fca_accumulate_pixel(acc, p);
-    if (PIPE) {
-      // software pipeline: the record of pixel i + 256 is requested before pixel i is processed (index clamped, so the
-      // load is unconditional), which takes the record's memory latency off the per-pixel dependency chain
-      i += stride;
-      if (i < end) {
-        FcaIn nxt = fca_load(K, (unsigned)i);
-        for (;;) {
-          const FcaIn in = nxt;
-          const int inext = i + stride;
-          nxt = fca_load(K, (unsigned)min(inext, end - 1));
-          const FcaPix q = fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, in);
-          fca_accumulate_pixel(acc, q);
-          i = inext;
-          if (i >= end) break;
-        }
+  // Software pipeline of both loops: the record of pixel i + 256 is requested while pixel i is processed (index clamped, so
+  // the load is unconditional), behind pixel i's tap loads, see tap_point. The two record slots alternate through an
+  // explicitly unrolled loop body: a register copy of a slot would have to wait for the load that fills it. (Keeping two
+  // records in flight was measured no faster: with ~100 % VALU issue in the pixel phase the loop is not waiting for memory.)
+  if constexpr (FAST) {
+    if (i < end) {
+      FcaInF r0 = firstf, r1 = firstf;
+      auto step = [&](const FcaInF& in, FcaInF& fill) {
+        const int i1 = i + stride;
+        auto prefetch = [&]() { fill = fcaf_load(K, (unsigned)min(i1, end - 1)); };
+        fca_accumulate_pixel(acc, fcaf_pixel<false>(a, K, g, cur, S, (unsigned)i, in, prefetch));
+        i += stride;
+      };
+      for (;;) {
+        step(r0, r1);
+        if (i >= end) break;
+        step(r1, r0);
+        if (i >= end) break;
+      }
+    }
+  } else if (i < end) {
+    if (PIPE) {   // exact mode: one record ahead (two slots; a third costs registers this kernel does not have)
+      FcaIn r0 = first, r1 = first;
+      {
+        const int i1 = i + stride;
+        auto prefetch = [&]() { r1 = fca_load(K, (unsigned)min(i1, end - 1)); };
+        fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre, prefetch));
+        i += stride;
+      }
+      auto step = [&](const FcaIn& in, FcaIn& fill) {
+        const int i1 = i + stride;
+        auto prefetch = [&]() { fill = fca_load(K, (unsigned)min(i1, end - 1)); };
+        fca_accumulate_pixel(acc, fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, in, prefetch));
+        i += stride;
+      };
+      while (i < end) {
+        step(r1, r0);
+        if (i >= end) break;
+        step(r0, r1);
       }
     } else {
+      fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre));
       for (i += stride; i < end; i += stride) {
         const FcaPix q = fca_pixel<false, DIVC>(a, K, g, cur, S, (unsigned)i);
         fca_accumulate_pixel(acc, q);
@@ -1040,9 +1315,20 @@ __device__ __forceinline__ IcaIn ica_load(const IcaRec* irec, unsigned i) {
   in.sd[3] = c.x; in.sd[4] = c.y; in.sd[5] = c.z;
   return in;
 }
+template <bool FAST>
 __device__ __forceinline__ void ica_accumulate_pixel(float (&acc)[6], const IcaIn& in, const LevelGeom& g, g_u8 cur, const float* S) {
-  const Warp w = warp_point<true>(in.X, in.Y, in.Z, g, S);
-  const Taps t = tap_point<false>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
+  Warp w;
+  if constexpr (FAST) {   // tolerance mode: fused multiply-adds and the hardware reciprocal in the projection
+    w.px = __builtin_fmaf(S[0], in.X, __builtin_fmaf(S[1], in.Y, __builtin_fmaf(S[2], in.Z, S[3])));
+    w.py = __builtin_fmaf(S[4], in.X, __builtin_fmaf(S[5], in.Y, __builtin_fmaf(S[6], in.Z, S[7])));
+    w.pz = __builtin_fmaf(S[8], in.X, __builtin_fmaf(S[9], in.Y, __builtin_fmaf(S[10], in.Z, S[11])));
+    const float rz = __builtin_amdgcn_rcpf(w.pz);
+    w.wx = __builtin_fmaf(w.px * rz, g.fx, g.cx);
+    w.wy = __builtin_fmaf(w.py * rz, g.fy, g.cy);
+  } else {
+    w = warp_point<true>(in.X, in.Y, in.Z, g, S);
+  }
+  const Taps t = tap_point<false, FAST>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
   const bool oob = (t.I == -1.0f);
   const float residual = oob ? 0.0f : (t.I - in.Ikf);
   const float rw = residual * in.W;
@@ -1050,6 +1336,7 @@ __device__ __forceinline__ void ica_accumulate_pixel(float (&acc)[6], const IcaI
   for (int r = 0; r < 6; r++) acc[r] = __builtin_fmaf(in.sd[r], rw, acc[r]);
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState* src_state, const float* prev_part, int prev_nblk, FusedArgs fa) {
   const GnArgs& a = fa.g;   // leading scalars: preloaded kernel arguments, see gn_fca_fused
   const int b = blockIdx.y, sub = blockIdx.x;
@@ -1076,7 +1363,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
   if (begin + t < end) first = ica_load(K.irec, (unsigned)(begin + t));
   if (pending) {
     const float* hinv = a.kf_tab[fa.prev_level * a.max_kf + slot].hinv;
-    solve_step(sh, group_sum, 2, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr, hinv);
+    solve_step<FAST>(sh, group_sum, 2, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr, hinv);
   } else {
     if (t < 6) sh.newpose[t] = src.pose[t];
     if (t < 12) sh.newS[t] = src.S[t];
@@ -1104,14 +1391,15 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
   for (int i = 0; i < 6; i++) acc[i] = 0.0f;
   int i = begin + t;
   if (i < end) {
-    ica_accumulate_pixel(acc, first, g, cur, S);
-    for (i += ELLC_GN_THREADS; i < end; i += ELLC_GN_THREADS) ica_accumulate_pixel(acc, ica_load(K.irec, (unsigned)i), g, cur, S);
+    ica_accumulate_pixel<FAST>(acc, first, g, cur, S);
+    for (i += ELLC_GN_THREADS; i < end; i += ELLC_GN_THREADS) ica_accumulate_pixel<FAST>(acc, ica_load(K.irec, (unsigned)i), g, cur, S);
   }
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
   block_reduce_store<6>(acc, out + 21);   // the b slots of the partial record; the H slots are not read by a mode-2 solve
 }
 
 // Final solve of a fused schedule: consumes the last pending partials; result always lands in state buffer 0.
+template <bool FAST>
 __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs fa) {
   const GnArgs& a = fa.g;
   const int b = blockIdx.x;
@@ -1125,11 +1413,20 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
   if (pending) {
     const float* prev = a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
     const float* hinv = fa.ica ? a.kf_tab[fa.prev_level * a.max_kf + a.kf_slot[b]].hinv : nullptr;
-    solve_step(sh, partial_group_sum(prev, fa.prev_nblk), fa.ica ? 2 : 0, fa.prev_level, fa.early_exit, src, dst, hinv);
+    solve_step<FAST>(sh, partial_group_sum(prev, fa.prev_nblk), fa.ica ? 2 : 0, fa.prev_level, fa.early_exit, src, dst, hinv);
   } else {
     if (t < 6) sh.newpose[t] = src.pose[t];
     if (t < 12) sh.newS[t] = src.S[t];
     if (t == 0) { sh.weighted = src.weighted; sh.level_done = src.level_done; }
+    __syncthreads();
+  }
+  if (FAST) {   // tolerance mode carries exp(pose) through the schedule; the twist is its log, taken once here
+    if (t == 0) {
+      float S[12], np[6];
+      for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
+      log_se3_f32(S, np);
+      for (int i = 0; i < 6; i++) sh.newpose[i] = np[i];
+    }
     __syncthreads();
   }
   if (t < 6) dst->pose[t] = sh.newpose[t];
@@ -1196,14 +1493,21 @@ __device__ inline void init_state_record(AlignState& st, const float* init_pose,
 }
 
 // PixelWisePyramid::saveWeights(true) (:544-549): weight_pyramid[l] += display_weightimg (masked pixels add 0)
-__global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, int level, int max_kf) {
+__global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, int level, int max_kf, int fast_records) {
   const int b = blockIdx.y;
   const KfLevelDev& K = kf_tab[level * max_kf + kf_slot[b]];
   const int V = *K.count;
   const int cols = geom[level].cols;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
-    const uint32_t xy = K.crec[i].xy;   // saved weights exist in the FCA schedule only: its records carry the pixel position
-    const size_t p = (size_t)(xy >> 16) * cols + (xy & 0xffffu);
+    // saved weights exist in the FCA schedule only: its records carry the pixel position
+    size_t p;
+    if (fast_records) {
+      const uint32_t xyI = ((const FcaRecF*)K.crec)[i].xyI;
+      p = (size_t)((xyI >> 12) & 0xfffu) * cols + (xyI & 0xfffu);
+    } else {
+      const uint32_t xy = K.crec[i].xy;
+      p = (size_t)(xy >> 16) * cols + (xy & 0xffffu);
+    }
     K.weight[p] = K.weight[p] + K.wlast[i];
   }
 }

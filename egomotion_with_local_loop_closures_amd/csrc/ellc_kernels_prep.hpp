@@ -19,7 +19,8 @@ struct PrepArgs {
   const int* slots;            // unique keyframe slots
   int levels, max_kf;
   int need;                    // bit 0: planes Z / I / saved weight (unfused ICA kernels); bit 1: FcaRec records (FCA);
-                               // bit 2: IcaRec records + per-tile sums of H (fused ICA schedule)
+                               // bit 2: IcaRec records + per-tile sums of H (fused ICA schedule); bit 3: FcaRecF records
+                               // (FCA in tolerance mode, cfg.arith = ELLC_ARITH_FAST)
   int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
   int tile0, level0;           // this launch covers tiles tile0 + blockIdx.x (count / scatter), levels level0 + blockIdx.x (scan)
 };
@@ -193,6 +194,11 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
 #pragma unroll
         for (int cc = rr; cc < 6; cc++) { hacc[q] = __builtin_fmaf(wJ, J[cc], hacc[q]); q++; }
       }
+    }
+    if (need & 8) {   // FCA in tolerance mode: one 16-byte record per pixel (FcaRecF)
+      const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)img[(unsigned)(y * sw + x)] << 24);
+      const float d = __builtin_amdgcn_rcpf(Z);
+      crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, d)};
     }
     if (need & 2) {   // FCA reads one 32-byte record per pixel (FcaRec), stored as two 16-byte words
       const float X = (((float)x - cx) * Z) / fx;

@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define ELLC_MAX_LEVELS 8
-#define ELLC_ABI_VERSION 2
+#define ELLC_ABI_VERSION 3
 
 typedef enum {
   ELLC_OK = 0,
@@ -45,6 +45,16 @@ typedef enum {
   ELLC_MODE_ICA = 1   /* constant saved weights, template gradient: calculatePixelWiseParallelInvCompositional, :917-974 */
 } ellc_mode;
 
+typedef enum {
+  ELLC_ARITH_EXACT = 0, /* every per-pixel value is computed with the reference's expression order in IEEE f32 (f64 where its
+                         * pow() promotes): bit-identical to the CPU path per pixel; only the order of the 27 sums differs */
+  ELLC_ARITH_FAST = 1   /* tolerance mode: fused multiply-adds, hardware reciprocal / rsqrt (1 ulp) for the divisions and the
+                         * sqrt, f32 for the double-promoted Jacobian terms, the 6x6 system solved by L D L^T in double, the
+                         * pose carried as exp(pose) through the schedule. Per-pixel values agree with EXACT to a few 1e-7
+                         * relative, the final pose to <= 1e-5 (tests/test_gpu_fast.py); about half the instructions per pixel.
+                         * Requires width, height <= 4096. */
+} ellc_arith;
+
 /* Run-time form of the compile-time constants in ExternVariable.h:39-59 and main.cpp:34. */
 typedef struct {
   int width, height;            /* ORIG_COLS, ORIG_ROWS */
@@ -59,6 +69,7 @@ typedef struct {
   int concurrent_batches;       /* 1..3: how many batches the caller keeps in flight (ellc_align_enqueue); > 1 sizes the
                                  * fine-level grids for sharing the device. Fixed per context, so a batch's result does
                                  * not depend on what else happens to be in flight (the grid fixes the summation order) */
+  int arith;                    /* ELLC_ARITH_EXACT (default) or ELLC_ARITH_FAST: arithmetic of the Gauss-Newton pixel pass and solve */
 } ellc_config;
 
 typedef struct ellc_ctx ellc_ctx;
@@ -120,7 +131,10 @@ ellc_status ellc_keyframe_finalise_weights(ellc_ctx* ctx, int slot);
  * levels (levels-1 .. 0) with up to max_iter[level] Gauss-Newton iterations each.
  *   mode            ELLC_MODE_FCA or ELLC_MODE_ICA (fromLoopClosure with FLAG_DO_CONST_WEIGHT_POSE_ESTIMATION)
  *   save_weights    1: add the last executed iteration's weights of every level into the keyframe's
- *                   weight_pyramid (PixelWisePyramid::saveWeights(true), :544-549; ImageFunc.cpp:280-288)
+ *                   weight_pyramid (PixelWisePyramid::saveWeights(true), :544-549; ImageFunc.cpp:280-288). The weights
+ *                   are accumulated per keyframe slot, so with save_weights every alignment of the batch must use a
+ *                   different keyframe slot (ELLC_ERR_BAD_ARG otherwise): the reference saves weights on the tracking
+ *                   path only, one alignment at a time (ImageFunc.cpp:280)
  *   out_pose        B*6 f32 relative poses
  *   out_iters       B*levels ints: iterations executed per level (may be NULL)
  *   out_weighted    B f32: weightedPose of the last executed iteration (may be NULL)

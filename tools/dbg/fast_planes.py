@@ -1,0 +1,22 @@
+import sys, os
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,'tests'))
+import numpy as np
+from egomotion_with_local_loop_closures_amd import api, synth
+from helpers import gpu_problem
+W,H,L=320,240,4
+pair=synth.make_pair(W,H,seed=11)
+ce=gpu_problem(api,W,H,L,[pair])
+cf=gpu_problem(api,W,H,L,[pair],arith=api.ARITH_FAST)
+for pose in (np.array([0.004,-0.003,0.002,0.0,0.0,0.0],np.float32), np.array([0.004,-0.003,0.002,0.01,-0.005,0.008],np.float32)):
+  for level in (3,):
+    e=ce.gn_iterate(0,0,level,pose,planes=True)
+    f=cf.gn_iterate(0,0,level,pose,planes=True)
+    d,v=ce.keyframe_depth_level(0,level)
+    mask=d>0
+    ok=mask&(e["warpedX"]>=0)&(f["warpedX"]>=0)
+    print("pose",pose,"ok",ok.sum(),"max dwx",np.abs(e["warpedX"]-f["warpedX"])[ok].max())
+    ys,xs=np.nonzero(ok)
+    for y,x in list(zip(ys,xs))[:4]:
+        print(y,x,"Z",d[y,x],"var",v[y,x],"exact wx",e["warpedX"][y,x],"res",e["residual"][y,x],"w",e["weight"][y,x],"J",[float(e["J"][k][y,x]) for k in range(6)])
+        print("      fast wx",f["warpedX"][y,x],"res",f["residual"][y,x],"w",f["weight"][y,x],"J",[float(f["J"][k][y,x]) for k in range(6)])
