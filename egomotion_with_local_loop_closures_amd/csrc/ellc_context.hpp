@@ -11,6 +11,8 @@
 
 namespace ellc {
 
+struct RunSync;   // ellc_kernels_run.hpp
+
 struct DepthSoA {   // DepthHypothesis.h:14-40, live fields, structure of arrays
   float* invDepth = nullptr;
   float* invDepthSmoothed = nullptr;
@@ -75,6 +77,8 @@ struct ellc_ctx {
     int* stage_d = nullptr;                         // device copy of the staging record
     ellc::AlignState* state_d = nullptr;            // two launch-parity buffers
     float* partials_d = nullptr;
+    ellc::RunSync* sync_d = nullptr;                // per alignment: arrival / generation counters and the published state of a run
+    int run_reserved = 0;                           // blocks reserved in the device's run budget while the batch is in flight
     std::vector<int> kf_slots;                      // unique keyframe slots of the batch in flight
     int B = 0;                                      // its size
     bool joined = true;                             // `stream` (the context's main stream) already waits for `done`
@@ -85,6 +89,7 @@ struct ellc_ctx {
   int inflight[SETS] = {0};
   int n_inflight = 0;
   float* partials_d = nullptr;
+  ellc::RunSync* sync_d = nullptr;
   float* planes_d = nullptr;
   float *scratch_a = nullptr, *scratch_b = nullptr;   // W*H f32 each
   int tile_begin[ELLC_MAX_LEVELS + 1];
@@ -98,7 +103,12 @@ struct ellc_ctx {
   double age_min_px_per_thread = 5.0;   // ELLC_AGE_MIN_PX
   bool pipe = true;             // software-pipelined record loads in the fused FCA kernel (ELLC_PIPE=0 disables; r01: -10 % per launch at
                                 // 1280x960 dense where the records stream from HBM, neutral at 640x480 semi-dense)
-  bool use_fused = true;        // FCA: solve folded into the next accumulate launch (ELLC_NO_FUSE=1 disables)
+  bool use_fused = true;        // the production schedules (ELLC_NO_FUSE=1, diagnostic builds: one accumulate + one solve launch per iteration)
+  bool use_run = false;         // diagnostic builds, ELLC_RUN=1: the run kernels (ellc_kernels_run.hpp: last-arriving block solves, runs of
+                                // iterations inside one launch) instead of the fused kernels; measured slower, see DESIGN.md section 4
+  bool use_persist = true;      // runs may cover all iterations of a level (ELLC_NO_PERSIST=1, diagnostic builds: single-iteration launches only)
+  bool plan_persist = false;    // decision for the batch being enqueued (the reservation succeeded)
+  int untracked_reserved = 0;   // run budget held by untracked enqueues (measurement hooks)
   int nblk_override[ELLC_MAX_LEVELS] = {0};
   int resident_blocks = 1280;   // 256-thread blocks of the accumulate kernel resident on the device at once
   // frame ingest (ellc_ingest_configure): fixed-point undistortion map of the 2x2 source pixels of every output pixel

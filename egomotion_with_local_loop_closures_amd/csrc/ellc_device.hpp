@@ -88,6 +88,7 @@ struct AlignState {
   float weighted;
   int level_done;             // level terminated by weightedPose < 1 (-1: none)
   int pending;                // fused schedule: the previous launch left partial sums that are not solved yet
+  unsigned ticket_base, gen_base;   // run kernels: values of the alignment's arrival / generation counters when the next launch starts
   int iters[ELLC_MAX_LEVELS];
   float H[36];
   float b[6];

@@ -4,6 +4,10 @@
 #include "ellc_kernels_image.hpp"
 #include "ellc_kernels_gn.hpp"
 #include "ellc_kernels_prep.hpp"
+#ifdef ELLC_DIAG
+#include "ellc_kernels_run.hpp"   // measured alternative to the fused schedule ("Runs"): diagnostic builds only
+#include <atomic>
+#endif
 #include <cstring>
 #include <cmath>
 #include <algorithm>
@@ -285,6 +289,7 @@ static void select_batch_set(ellc_ctx* c, int p) {
   c->init_pose_d = (float*)(bs.stage_d + 3 * MB);
   c->state_d = bs.state_d;
   c->partials_d = bs.partials_d;
+  c->sync_d = bs.sync_d;
 }
 
 // stage slots / initial poses on the device and list the unique keyframe slots
@@ -303,6 +308,7 @@ static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const in
     for (int u = 0; u < nu; u++) seen = seen || (c->uniq_slot_h[u] == kf_slots[b]);
     if (!seen) c->uniq_slot_h[nu++] = kf_slots[b];
     for (int i = 0; i < 6; i++) c->init_pose_h[b * 6 + i] = init_pose ? init_pose[b * 6 + i] : 0.0f;
+    c->result_h[b].pad = -1;   // the kernel that exports the result clears it
   }
   // The pinned staging record is read by the first kernel of the schedule (enqueue_stage_in); it may still be in flight
   // from the previous call only if the caller skipped the fetch: ellc_align always fetches (synchronises),
@@ -316,7 +322,7 @@ static void enqueue_stage_in(ellc_ctx* c, int B) {
   const int n = 9 * c->cfg.max_batch;
   const int copy_blocks = (n + 255) / 256;
   hipLaunchKernelGGL(stage_in, dim3(copy_blocks + (B + 255) / 256), dim3(256), 0, c->stream, c->kf_slot_d, c->stage_dev_alias, n, copy_blocks,
-                     c->state_d, B, c->cfg.max_batch);
+                     c->state_d, B, c->cfg.max_batch, (unsigned*)c->sync_d);
 }
 
 // fills the age-balanced split of a launch (FusedArgs::age_rounds): on when the grid is 2..4 full rounds of one block per CU-slot
@@ -428,8 +434,106 @@ static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
   return ELLC_OK;
 }
 
+#ifdef ELLC_DIAG
+// ---- the schedule as run kernels (ellc_kernels_run.hpp) ----------------------------------------------------------------
+// Blocks of multi-iteration runs wait for each other, so all of them must be resident at once — together with those of
+// every other run in flight on the device, whichever context enqueued it. Each device has one budget (the blocks of a run
+// kernel the device holds at once: four 256-thread blocks per CU, guaranteed by the kernel's launch bounds); a batch
+// reserves its largest run when it is enqueued and gives it back when it is fetched. A batch that does not fit is enqueued
+// as single-iteration launches, which need no residency — same sums, same bits, only slower.
+static std::atomic<int> g_run_reserved[64];
+
+static bool run_reserve(ellc_ctx* c, int blocks) {
+  if (blocks <= 0) return true;
+  std::atomic<int>& r = g_run_reserved[c->cfg.device & 63];
+  int cur = r.load();
+  while (cur + blocks <= c->resident_blocks)
+    if (r.compare_exchange_weak(cur, cur + blocks)) return true;
+  return false;
+}
+static void run_release(ellc_ctx* c, int blocks) {
+  if (blocks > 0) g_run_reserved[c->cfg.device & 63].fetch_sub(blocks);
+}
+
+struct RunPlan {
+  struct Seg { int lvl_hi, lvl_lo, grid_x; bool single_iterations; };
+  std::vector<Seg> segs;
+  int nblk[ELLC_MAX_LEVELS];
+  int max_run_blocks = 0;   // blocks of the largest multi-iteration run (what has to be reserved)
+};
+
+// Levels whose blocks (B x nblk) fit a batch's share of the device become runs that cover all their iterations; consecutive
+// such levels merge into one run unless weights are saved (the saved-weights kernel follows each level). The others are
+// launched iteration by iteration. persist = false plans single iterations throughout.
+static RunPlan plan_runs(const ellc_ctx* c, int B, bool save_w, bool persist) {
+  RunPlan p;
+  const int share = std::max(1, c->resident_blocks / std::max(1, c->cfg.concurrent_batches));
+  for (int l = 0; l < ELLC_MAX_LEVELS; l++) p.nblk[l] = 1;
+  for (int l = 0; l < c->L; l++) p.nblk[l] = std::min(64, choose_nblk(c, l, B));
+  for (int level = c->L - 1; level >= 0; level--) {
+    const bool fits = persist && c->cfg.max_iter[level] > 1 && B * p.nblk[level] <= share;
+    if (fits && !p.segs.empty() && !p.segs.back().single_iterations && !save_w &&
+        B * std::max(p.segs.back().grid_x, p.nblk[level]) <= share) {
+      p.segs.back().lvl_lo = level;
+      p.segs.back().grid_x = std::max(p.segs.back().grid_x, p.nblk[level]);
+    } else {
+      p.segs.push_back({level, level, p.nblk[level], !fits});
+    }
+  }
+  for (const auto& sg : p.segs)
+    if (!sg.single_iterations) p.max_run_blocks = std::max(p.max_run_blocks, B * sg.grid_x);
+  return p;
+}
+
+template <bool ICA>
+static void launch_run(ellc_ctx* c, dim3 grd, const RunArgs& ra) {
+  const dim3 blk(ELLC_GN_THREADS);
+  if (c->fast) hipLaunchKernelGGL((gn_run<ICA, true, false>), grd, blk, 0, c->stream, ra);
+  else if (!ICA && c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_run<ICA, false, true>), grd, blk, 0, c->stream, ra);
+  else hipLaunchKernelGGL((gn_run<ICA, false, false>), grd, blk, 0, c->stream, ra);
+}
+
+static ellc_status enqueue_schedule_runs(ellc_ctx* c, int B, int mode, int save_weights, bool persist) {
+  const bool save_w = save_weights && mode == ELLC_MODE_FCA;
+  const RunPlan plan = plan_runs(c, B, save_w, persist);
+  RunArgs ra;
+  ra.geom = c->geom_d; ra.kf_tab = c->kf_tab_d; ra.fr_tab = c->fr_tab_d; ra.kf_slot = c->kf_slot_d; ra.fr_slot = c->fr_slot_d;
+  ra.state = c->state_d; ra.partials = c->partials_d; ra.sync = c->sync_d; ra.res = c->result_dev_alias;
+  ra.max_kf = c->cfg.max_keyframes; ra.max_fr = c->cfg.max_frames;
+  ra.early_exit = c->cfg.early_exit; ra.save_w = save_w ? 1 : 0;
+  for (int l = 0; l < ELLC_MAX_LEVELS; l++) { ra.iters[l] = 0; ra.nblk[l] = plan.nblk[l]; }
+  for (size_t si = 0; si < plan.segs.size(); si++) {
+    const RunPlan::Seg& sg = plan.segs[si];
+    const bool last_seg = (si + 1 == plan.segs.size());
+    ra.lvl_hi = sg.lvl_hi; ra.lvl_lo = sg.lvl_lo;
+    const dim3 grd(sg.grid_x, B);
+    if (sg.single_iterations) {
+      const int level = sg.lvl_hi;
+      for (int l = 0; l < ELLC_MAX_LEVELS; l++) ra.iters[l] = (l == level) ? 1 : 0;
+      for (int it = 0; it < c->cfg.max_iter[level]; it++) {
+        ra.final = (last_seg && it + 1 == c->cfg.max_iter[level]) ? 1 : 0;
+        if (mode == ELLC_MODE_ICA) launch_run<true>(c, grd, ra); else launch_run<false>(c, grd, ra);
+      }
+    } else {
+      for (int l = 0; l < ELLC_MAX_LEVELS; l++) ra.iters[l] = (l <= sg.lvl_hi && l >= sg.lvl_lo) ? c->cfg.max_iter[l] : 0;
+      ra.final = last_seg ? 1 : 0;
+      if (mode == ELLC_MODE_ICA) launch_run<true>(c, grd, ra); else launch_run<false>(c, grd, ra);
+    }
+    if (save_w)   // one level per segment when weights are saved
+      hipLaunchKernelGGL(gn_add_saved_weights, dim3(64, B), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, sg.lvl_hi, c->cfg.max_keyframes,
+                         c->fast ? 1 : 0);
+  }
+  ELLC_HIP(c, hipGetLastError());
+  return ELLC_OK;
+}
+
+#endif   // ELLC_DIAG
+
 // the level / iteration schedule of GetImagePoseEstimate (ImageFunc.cpp:150-292) as a launch sequence
 static ellc_status enqueue_schedule(ellc_ctx* c, int B, int mode, int save_weights) {
+#ifdef ELLC_DIAG
+  if (c->use_fused && c->use_run) return enqueue_schedule_runs(c, B, mode, save_weights, c->plan_persist);
+#endif
   if (mode == ELLC_MODE_FCA && c->use_fused) return enqueue_schedule_fused(c, B, save_weights);
   if (mode == ELLC_MODE_ICA && c->use_fused) return enqueue_schedule_ica_fused(c, B);
   for (int level = c->L - 1; level >= 0; level--) {
@@ -620,6 +724,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     TRY(host_alloc(c, &bs.result_h, MB));
     TRY(dev_alloc(c, &bs.state_d, 2 * (size_t)MB));
     TRY(dev_alloc(c, &bs.partials_d, 2 * (size_t)MB * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
+    TRY(dev_alloc(c, (char**)&bs.sync_d, 256 * (size_t)MB));   // RunSync records (diagnostic builds), 256 bytes each
     void *da = nullptr, *db = nullptr;
     if (hipHostGetDevicePointer(&da, bs.stage_h, 0) != hipSuccess || hipHostGetDevicePointer(&db, bs.result_h, 0) != hipSuccess ||
         hipEventCreateWithFlags(&bs.done, hipEventDisableTiming) != hipSuccess) {
@@ -689,6 +794,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       }
     }
     if (const char* ng = getenv("ELLC_NO_GRAPH")) c->use_graph = !(ng[0] == '1');
+    if (const char* nr = getenv("ELLC_RUN")) c->use_run = (nr[0] == '1');
+    if (const char* np = getenv("ELLC_NO_PERSIST")) c->use_persist = !(np[0] == '1');
     if (const char* nb = getenv("ELLC_NBLK")) {
       int l = 0;
       for (const char* q = nb; *q && l < ELLC_MAX_LEVELS; l++) {
@@ -1020,6 +1127,21 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
   if (save_weights && mode == ELLC_MODE_FCA && nu < B)
     return fail(c, ELLC_ERR_BAD_ARG, "save_weights needs a different keyframe slot for every alignment of the batch");
   hipStream_t run_stream = set > 0 ? bs.stream : c->stream;
+  int reserved = 0;
+#ifdef ELLC_DIAG
+  // run kernels (diagnostic builds, ELLC_RUN=1): multi-iteration runs need their blocks resident together with every other
+  // run in flight on the device: reserve, or fall back to single-iteration launches (same results)
+  c->plan_persist = false;
+  if (c->use_fused && c->use_run && c->use_persist) {
+    reserved = plan_runs(c, B, save_weights && mode == ELLC_MODE_FCA, true).max_run_blocks;
+    if (run_reserve(c, reserved)) c->plan_persist = true;
+    else reserved = 0;
+  }
+  struct ReserveGuard {   // gives the reservation back unless the batch was enqueued
+    ellc_ctx* c; int blocks; bool keep;
+    ~ReserveGuard() { if (!keep) run_release(c, blocks); }
+  } guard{c, reserved, false};
+#endif
   if (track) {
     // A batch on another stream runs after everything the caller has put on the main stream through the other entry
     // points (uploads, depth stages), but not after the batches that run there: the mark is recorded before them.
@@ -1045,7 +1167,7 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
   {
     StreamScope scope(c, run_stream);
     if (c->use_graph) {
-      const auto key = std::make_tuple(B, nu, mode, (save_weights ? 1 : 0) | (set << 1));
+      const auto key = std::make_tuple(B, nu, mode, (save_weights ? 1 : 0) | (set << 1) | (c->plan_persist ? 16 : 0) | (c->use_run ? 32 : 0));
       auto it = c->graphs.find(key);
       if (it == c->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -1073,11 +1195,17 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
   if (save_weights && mode == ELLC_MODE_FCA)
     for (int b = 0; b < B; b++)
       for (int l = 0; l < c->L; l++) c->kf_num_weights[kf_slots[b]][l]++;
+#ifdef ELLC_DIAG
+  guard.keep = true;
+#endif
   if (track) {
     bs.kf_slots.assign(c->uniq_slot_h, c->uniq_slot_h + nu);
     bs.B = B;
     bs.joined = (set == 0);
+    bs.run_reserved = reserved;
     c->inflight[c->n_inflight++] = set;
+  } else {
+    c->untracked_reserved += reserved;   // given back by the caller once the stream has drained (ellc_profile_align)
   }
   return ELLC_OK;
 }
@@ -1091,12 +1219,22 @@ ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters
   ELLC_ENTER_BATCH(c);
   if (!c || B < 1 || B > c->cfg.max_batch) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (c->n_inflight < 1) return fail(c, ELLC_ERR_NOT_READY, "ellc_align_fetch: no batch in flight");
-  const ellc_ctx::BatchSet& bs = c->batch_set[c->inflight[0]];   // the oldest batch
+  const int oldest = c->inflight[0];
+  const ellc_ctx::BatchSet& bs = c->batch_set[oldest];   // the oldest batch
   if (B != bs.B) return fail(c, ELLC_ERR_BAD_ARG, "ellc_align_fetch: the oldest batch in flight has a different size");
   const hipError_t ev = hipEventSynchronize(bs.done);   // its last kernel wrote bs.result_h (pinned, zero-copy)
   for (int i = 1; i < c->n_inflight; i++) c->inflight[i - 1] = c->inflight[i];   // the batch leaves the queue either way
   c->n_inflight--;
+#ifdef ELLC_DIAG
+  run_release(c, bs.run_reserved);
+#endif
+  c->batch_set[oldest].run_reserved = 0;
   if (ev != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("ellc_align_fetch: the batch failed on the device: ") + hipGetErrorString(ev));
+  for (int b = 0; b < B; b++)
+    if (bs.result_h[b].pad != 0) {   // a run gave up waiting for its other blocks (bounded spin): clear the error words, report
+      (void)hipMemsetAsync(bs.sync_d, 0, 256 * (size_t)c->cfg.max_batch, c->stream);
+      return fail(c, ELLC_ERR_HIP, "ellc_align_fetch: the schedule did not complete on the device (no result was exported)");
+    }
   for (int b = 0; b < B; b++) {
     if (out_pose) std::memcpy(out_pose + b * 6, bs.result_h[b].pose, 24);
     if (out_iters) for (int l = 0; l < c->L; l++) out_iters[b * c->L + l] = bs.result_h[b].iters[l];
@@ -1282,7 +1420,12 @@ ellc_status ellc_profile_align(ellc_ctx* c, int B, const int* kf_slots, const in
     if (s != ELLC_OK) return s;
   }
   ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
-  ELLC_HIP(c, hipEventSynchronize(c->ev1));
+  const hipError_t pe = hipEventSynchronize(c->ev1);
+#ifdef ELLC_DIAG
+  run_release(c, c->untracked_reserved);   // the untracked enqueues above have drained
+#endif
+  c->untracked_reserved = 0;
+  ELLC_HIP(c, pe);
   float ms = 0;
   ELLC_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   if (avg_ms) *avg_ms = ms / reps;

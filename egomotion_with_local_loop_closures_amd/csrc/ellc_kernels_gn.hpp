@@ -1036,6 +1036,7 @@ __device__ __forceinline__ void solve_finish_fast(SolveShared& sh, int mode, int
         x[i] = -acc;
       }
     }
+    ELLC_STAMP(3);
     float delta[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) delta[i] = (float)x[i];
@@ -1043,6 +1044,7 @@ __device__ __forceinline__ void solve_finish_fast(SolveShared& sh, int mode, int
 #pragma unroll
       for (int i = 0; i < 6; i++) { dst->delta[i] = delta[i]; dst->b[i] = (float)sh.sums[21 + i]; }
     }
+    ELLC_STAMP(4);
     const float weighted = fabsf(delta[0] * 100000.0f) + fabsf(delta[1] * 100000.0f) + fabsf(delta[2] * 100000.0f) +
                            fabsf(delta[3] * 10000.0f) + fabsf(delta[4] * 10000.0f) + fabsf(delta[5] * 10000.0f);
     const int l9 = min(lane, 8);
@@ -1065,6 +1067,7 @@ __device__ __forceinline__ void solve_finish_fast(SolveShared& sh, int mode, int
       sh.weighted = weighted;
       sh.level_done = (early_exit && weighted < 1.0f) ? level : level_done_cur;   // ImageFunc.cpp:251-252
     }
+    ELLC_STAMP(5);
   }
   __syncthreads();
 }
@@ -1213,7 +1216,8 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
                  "v"(first_pre.nvz), "v"(first_pre.nuz));
   }
   if (pending) {
-    solve_step<FAST>(sh, group_sum, 0, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr);
+    // (H, b, delta and H^-1 of the state record serve the single-step API only, which runs gn_solve: not stored here)
+    solve_step<FAST>(sh, group_sum, 0, fa.prev_level, fa.early_exit, src, nullptr);
   } else {
     if (t < 6) sh.newpose[t] = src.pose[t];
     if (t < 12) sh.newS[t] = src.S[t];
@@ -1363,7 +1367,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
   if (begin + t < end) first = ica_load(K.irec, (unsigned)(begin + t));
   if (pending) {
     const float* hinv = a.kf_tab[fa.prev_level * a.max_kf + slot].hinv;
-    solve_step<FAST>(sh, group_sum, 2, fa.prev_level, fa.early_exit, src, writer ? dst : nullptr, hinv);
+    solve_step<FAST>(sh, group_sum, 2, fa.prev_level, fa.early_exit, src, nullptr, hinv);
   } else {
     if (t < 6) sh.newpose[t] = src.pose[t];
     if (t < 12) sh.newS[t] = src.S[t];
@@ -1441,7 +1445,7 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
     AlignResult* r = fa.res + b;
     if (t < 6) r->pose[t] = sh.newpose[t];
     if (t < ELLC_MAX_LEVELS) r->iters[t] = it_copy[t] + ((pending && t == fa.prev_level) ? 1 : 0);
-    if (t == 0) r->weighted = sh.weighted;
+    if (t == 0) { r->weighted = sh.weighted; r->pad = 0; }
   }
 }
 
@@ -1453,6 +1457,7 @@ __global__ void gn_export_results(const AlignState* state, AlignResult* res, int
   AlignResult& r = res[b];
   for (int i = 0; i < 6; i++) r.pose[i] = st.pose[i];
   r.weighted = st.weighted;
+  r.pad = 0;
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) r.iters[l] = st.iters[l];
 }
 
@@ -1462,14 +1467,18 @@ __device__ inline void init_state_record(AlignState& st, const float* init_pose,
 // first kernel of a schedule: the staged batch description (slots, unique slots, initial poses: 9 * max_batch words) is
 // copied from pinned host memory by the first copy_blocks blocks; the remaining blocks initialise the alignment states
 // straight from the staged initial poses (same launch: one dependent kernel boundary less at the head of every batch)
-__global__ void stage_in(int* __restrict__ dst, const int* __restrict__ src_host, int n, int copy_blocks, AlignState* state, int B, int max_batch) {
+__global__ void stage_in(int* __restrict__ dst, const int* __restrict__ src_host, int n, int copy_blocks, AlignState* state, int B, int max_batch,
+                         unsigned* sync_words) {   // sync_words: the batch's RunSync records (64 words each); arrivals [0] and generation [16] start at 0
   if ((int)blockIdx.x < copy_blocks) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src_host[i];
     return;
   }
   const int b = ((int)blockIdx.x - copy_blocks) * blockDim.x + threadIdx.x;
-  if (b < B) init_state_record(state[b], (const float*)(src_host + 3 * max_batch), b);
+  if (b < B) {
+    init_state_record(state[b], (const float*)(src_host + 3 * max_batch), b);
+    if (sync_words) { sync_words[(size_t)b * 64] = 0u; sync_words[(size_t)b * 64 + 16] = 0u; }
+  }
 }
 
 __global__ void gn_init_state(AlignState* state, const float* init_pose, int B) {
@@ -1487,6 +1496,8 @@ __device__ inline void init_state_record(AlignState& st, const float* init_pose,
   st.weighted = 0.0f;
   st.level_done = -1;
   st.pending = 0;
+  st.ticket_base = 0;
+  st.gen_base = 0;
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) st.iters[l] = 0;
   for (int i = 0; i < 36; i++) { st.H[i] = 0.0f; st.Hinv[i] = 0.0f; }
   for (int i = 0; i < 6; i++) st.b[i] = 0.0f;

@@ -14,11 +14,13 @@ from egomotion_with_local_loop_closures_amd import api, synth, _lib  # noqa: E40
 ap = argparse.ArgumentParser()
 ap.add_argument("--level", type=int, default=3)
 ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--arith", choices=["fast", "exact"], default="fast")
 a = ap.parse_args()
 W, H, L, B = 640, 480, 4, a.batch
 fx, fy, cx, cy = synth.default_intrinsics(W, H)
 pairs = [synth.make_pair(W, H, seed=0x5EED + i) for i in range(4)]
-ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_keyframes=B, max_frames=B, max_batch=B))
+ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_keyframes=B, max_frames=B, max_batch=B,
+                                     arith=api.ARITH_FAST if a.arith == "fast" else api.ARITH_EXACT))
 for b in range(B):
     p = pairs[b % 4]
     ctx.keyframe_upload(b, p["kf_image"]); ctx.keyframe_set_depth(b, p["depth0"], p["var0"]); ctx.frame_upload(b, p["cur_image"])
