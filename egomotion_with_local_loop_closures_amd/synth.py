@@ -68,8 +68,9 @@ def _bilinear_sample(img, x, y):
     return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
 
 
-def render_current(tex, idepth_true, T, fx, fy, cx, cy, iters=8):
-    """Image seen after the camera motion T (P' = R P + t): inverse warp by fixed-point iteration."""
+def render_current(tex, idepth_true, T, fx, fy, cx, cy, iters=8, with_depth=False):
+    """Image seen after the camera motion T (P' = R P + t): inverse warp by fixed-point iteration.
+    with_depth: also return the inverse depth of the surface as seen from the new view (f64)."""
     h, w = tex.shape
     texf = tex.astype(np.float64)
     uu, vv = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
@@ -87,7 +88,14 @@ def render_current(tex, idepth_true, T, fx, fy, cx, cy, iters=8):
         x -= (uw - uu)
         y -= (vw - vv)
     out = _bilinear_sample(texf, x, y)
-    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    img = np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    if not with_depth:
+        return img
+    Z = 1.0 / _bilinear_sample(idepth_true, x, y)
+    X = (x - cx) * Z / fx
+    Y = (y - cy) * Z / fy
+    Zp = R[2, 0] * X + R[2, 1] * Y + R[2, 2] * Z + t[2]
+    return img, 1.0 / Zp
 
 
 def max_abs_gradient(img):
@@ -145,6 +153,55 @@ def make_loop_closure_batch(w, h, B, seed, dense=False, rot=0.01, trans=0.02):
     image, so each alignment carries its own current frame — same work per alignment.
     """
     return [make_pair(w, h, seed + 7919 * b, dense=dense, rot=rot, trans=trans) for b in range(B)]
+
+
+def make_shared_frame_batch(w, h, B, seed, dense=False, rot=0.01, trans=0.02, depth_noise=0.02, border=3):
+    """The loop-closure batch in the reference's shape (GlobalOptimize.cpp:566): B different keyframes of ONE scene, each
+    with its own semi-dense depth map, all aligned against ONE current frame. Every view is the scene texture re-rendered
+    under its own known camera motion; alignment b's true pose is that of the current view relative to keyframe b.
+    Returns a list of B dicts with make_pair's keys; every cur_image is the same array."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = default_intrinsics(w, h)
+    tex = value_noise_texture(w, h, rng)
+    idepth0 = smooth_field(w, h, rng)
+
+    def motion(scale_r, scale_t):
+        d = rng.normal(size=6)
+        return np.concatenate([scale_r * d[:3] / np.linalg.norm(d[:3]), scale_t * d[3:] / np.linalg.norm(d[3:])])
+    T_cur = se3_exp(motion(rot, trans))
+    cur = render_current(tex, idepth0, T_cur, fx, fy, cx, cy, iters=6)
+    out = []
+    for b in range(B):
+        T_kf = se3_exp(motion(rot, trans))
+        kf_img, idepth_kf = render_current(tex, idepth0, T_kf, fx, fy, cx, cy, iters=6, with_depth=True)
+        T_rel = T_cur @ np.linalg.inv(T_kf)          # keyframe b -> current view
+        idepth_meas = idepth_kf * (1.0 + depth_noise * rng.normal(size=(h, w)))
+        var = (0.125 * rng.uniform(0.5, 1.5, size=(h, w)) * 0.1).astype(np.float32)
+        valid = np.ones((h, w), bool) if dense else (max_abs_gradient(kf_img) >= 5.0)
+        valid[:border, :] = False; valid[-border:, :] = False; valid[:, :border] = False; valid[:, -border:] = False
+        out.append(dict(kf_image=kf_img, cur_image=cur, depth0=np.where(valid, 1.0 / idepth_meas, 0.0).astype(np.float32),
+                        var0=np.where(valid, var, -1.0).astype(np.float32), idepth_true=idepth_kf, xi_true=se3_log(T_rel).astype(np.float32),
+                        intrinsics=(fx, fy, cx, cy), valid=valid))
+    return out
+
+
+def se3_log(T):
+    """closed-form log of a 4x4 rigid transform (rotation angle < pi) -> [w, v] (float64)."""
+    R, t = T[:3, :3], T[:3, 3]
+    c = np.clip(0.5 * (np.trace(R) - 1.0), -1.0, 1.0)
+    th = np.arccos(c)
+    if th < 1e-8:
+        w = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    else:
+        w = th / (2.0 * np.sin(th)) * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    th2 = float(w @ w)
+    if th2 < 1e-12:
+        Vinv = np.eye(3) - 0.5 * W + (1.0 / 12.0) * W @ W
+    else:
+        th = np.sqrt(th2)
+        Vinv = np.eye(3) - 0.5 * W + (1.0 / th2) * (1.0 - (th * np.sin(th)) / (2.0 * (1.0 - np.cos(th)))) * W @ W
+    return np.concatenate([w, Vinv @ t])
 
 
 def make_depth_state(w, h, seed, kf_image, idepth_true=None, fill=0.9):

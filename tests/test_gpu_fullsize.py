@@ -86,6 +86,82 @@ def test_c4_1280x960_dense_five_levels(oracle, ellc):
     ctx.close()
 
 
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_c4_batch16_1280x960_dense(oracle, ellc, arith):
+    """configs[4] at its per-GPU batch: 16 alignments of 1280x960, 5 levels {4,7,9,12,12}, dense residuals, two distinct
+    scenes alternating over the batch, in both arithmetic modes. Every alignment within 1e-5 of the oracle's pose for its
+    scene; same scene => same bits wherever it sits in the batch; a permuted batch gives the permuted results; a batch in
+    flight beside two others gives the same bits as alone."""
+    W, H, L, B = 1280, 960, 5, 16
+    mi = (4, 7, 9, 12, 12)
+    pairs = [synth.make_pair(W, H, seed=770 + i, dense=True) for i in range(2)]
+    refs = []
+    for p in pairs:
+        _, kf, cur, dm = oracle_problem(oracle, W, H, L, p, max_iter=mi)
+        refs.append(oracle.align(kf, cur, dm.depth_pyr())[0])
+    ctx = gpu_problem(ellc, W, H, L, [pairs[b % 2] for b in range(B)], max_iter=mi, concurrent_batches=3,
+                      arith=ellc.ARITH_FAST if arith == "fast" else ellc.ARITH_EXACT)
+    slots = np.arange(B, dtype=np.int32)
+    p_all, it_all, _ = ctx.align(slots, slots)
+    worst = 0.0
+    for b in range(B):
+        assert list(it_all[b]) == list(mi)
+        assert np.array_equal(p_all[b], p_all[b % 2])
+        worst = max(worst, float(np.linalg.norm(p_all[b] - refs[b % 2])))
+    print("C4 B=16 (%s): worst pose error vs oracle %.2e" % (arith, worst))
+    assert worst <= 1e-5
+    perm = np.random.default_rng(4).permutation(B)
+    assert np.array_equal(ctx.align(slots[perm], slots[perm])[0], p_all[perm])
+    parts = [slots[:6], slots[6:11], slots[11:]]
+    alone = [ctx.align(q, q)[0] for q in parts]
+    for q in parts:
+        ctx.align_enqueue(q, q)
+    for q, ref in zip(parts, alone):
+        assert np.array_equal(ctx.align_fetch(len(q))[0], ref)
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def lc_batch():
+    """configs[2] in the reference's shape (GlobalOptimize.cpp:566): 32 keyframes of one scene, ONE current frame."""
+    return synth.make_shared_frame_batch(640, 480, 32, seed=4242)
+
+
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+@pytest.mark.parametrize("mode", ["fca", "ica"])
+def test_c2_32_keyframes_against_one_frame(oracle, ellc, lc_batch, arith, mode):
+    """The loop-closure batch as the reference runs it: 32 different keyframes (own image, own depth map) aligned against one
+    frame slot, 640x480, 4 levels, forward-compositional and constant-weight paths, both arithmetic modes: every one of the
+    32 poses within 1e-5 of the oracle's, iteration counts equal, and the alignment recovers the rendered motion."""
+    W, H, L, B = 640, 480, 4, 32
+    fx, fy, cx, cy = lc_batch[0]["intrinsics"]
+    cfg = ellc.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_keyframes=B, max_frames=1, max_batch=B,
+                              concurrent_batches=3, arith=ellc.ARITH_FAST if arith == "fast" else ellc.ARITH_EXACT)
+    ctx = ellc.Context(cfg)
+    ctx.frame_upload(0, lc_batch[0]["cur_image"])
+    rng = np.random.default_rng(8)
+    refs = []
+    for b, p in enumerate(lc_batch):
+        ctx.keyframe_upload(b, p["kf_image"])
+        ctx.keyframe_set_depth(b, p["depth0"], p["var0"])
+        _, kf, cur, dm = oracle_problem(oracle, W, H, L, p, early_exit=0)
+        if mode == "ica":
+            for l in range(L):
+                w = rng.uniform(0.02, 0.0625, size=(H >> l, W >> l)).astype(np.float32)
+                kf.set_weights(l, w, 1)
+                ctx.keyframe_set_weights(b, l, w, 1)
+        refs.append(oracle.align(kf, cur, dm.depth_pyr(), loop_closure=(mode == "ica")))
+    pose, iters, _ = ctx.align(np.arange(B), np.zeros(B, np.int32), mode=1 if mode == "ica" else 0)
+    worst = 0.0
+    for b in range(B):
+        assert list(iters[b]) == list(refs[b][1])
+        worst = max(worst, float(np.linalg.norm(pose[b] - refs[b][0])))
+        assert np.linalg.norm(pose[b] - lc_batch[b]["xi_true"]) < 3e-3
+    print("C2 shared frame (%s, %s): worst pose error vs oracle %.2e" % (mode, arith, worst))
+    assert worst <= 1e-5
+    ctx.close()
+
+
 def test_normal_equations_properties(ellc):
     """H is symmetric positive semi-definite; scaling all weights by c scales H and b by c and leaves delta unchanged (ICA)."""
     W, H, L = 320, 240, 4

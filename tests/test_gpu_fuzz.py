@@ -100,36 +100,44 @@ def test_random_scene_per_pixel_parity(oracle, ellc, w, h, L, seed):
     ctx.close()
 
 
+def _stable_case(oracle, w, h, L, seed, mi, ica):
+    """First random scene (and, for the constant-weight path, weight planes) on which the ORACLE is stable: its result moves
+    by <= 1e-6 when its three row-band f32 sums are replaced by f64 sums, and it converges to the scene's motion."""
+    for attempt in range(16):
+        sd = seed + 1000 * attempt + (500 if ica else 0)
+        rng = np.random.default_rng(sd)
+        pair = synth.make_pair(w, h, seed=sd, rot=float(rng.uniform(0.002, 0.012)), trans=float(rng.uniform(0.005, 0.03)))
+        ocfg, kf, cur, dm = oracle_problem(oracle, w, h, L, pair, early_exit=0, max_iter=mi)
+        init = (rng.normal(size=6) * [0.002, 0.002, 0.002, 0.005, 0.005, 0.005]).astype(np.float32)
+        planes = None
+        if ica:
+            planes = [rng.uniform(0.01, 0.0625, size=(h >> l, w >> l)).astype(np.float32) for l in range(L)]
+            for l in range(L):
+                kf.set_weights(l, planes[l], 1)
+        pr, itr, _ = oracle.align(kf, cur, dm.depth_pyr(), init_pose=init, loop_closure=ica)
+        pr64, _, _ = oracle.align(kf, cur, dm.depth_pyr(), init_pose=init, loop_closure=ica, sum_mode=1)
+        if np.linalg.norm(pr64 - pr) <= 1e-6 and np.linalg.norm(pr - np.asarray(pair["xi_true"], np.float32)) < 0.02:
+            return pair, init, planes, pr, itr
+    pytest.fail("no well-conditioned %s scene in 16 attempts" % ("ICA" if ica else "FCA"))
+
+
 @pytest.mark.parametrize("w,h,L,seed", [(96, 64, 3, 201), (101, 75, 3, 202), (160, 120, 4, 203), (128, 72, 3, 204), (240, 136, 4, 205),
                                         (64, 48, 3, 206)])
-def test_random_scene_full_alignment(oracle, ellc, w, h, L, seed):
-    """Full fixed-schedule alignments (FCA and ICA) of random scenes: final pose within 1e-5 of the oracle (measured ~1e-7)."""
-    rng = np.random.default_rng(seed)
-    pair = synth.make_pair(w, h, seed=seed, rot=float(rng.uniform(0.002, 0.012)), trans=float(rng.uniform(0.005, 0.03)))
+@pytest.mark.parametrize("ica", [False, True], ids=["fca", "ica"])
+def test_random_scene_full_alignment(oracle, ellc, w, h, L, seed, ica):
+    """Full fixed-schedule alignments of random scenes, FCA and ICA: final pose within 1e-5 of the oracle, no exceptions.
+    A tiny random scene can be ill-conditioned — the iteration does not contract and amplifies the rounding of the sums, the
+    one thing that legitimately differs between product and oracle. Such a case is not excused with a wider bar: it is
+    REGENERATED (_stable_case) until the oracle itself is stable; the first stable case is then held to 1e-5."""
     mi = (4, 7, 9, 12)[:L]
-    ocfg, kf, cur, dm = oracle_problem(oracle, w, h, L, pair, early_exit=0, max_iter=mi)
+    pair, init, planes, pr, itr = _stable_case(oracle, w, h, L, seed, mi, ica)
     fx, fy, cx, cy = pair["intrinsics"]
     ctx = ellc.Context(ellc.default_config(w, h, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_iter=mi))
     ctx.keyframe_upload(0, pair["kf_image"]); ctx.keyframe_set_depth(0, pair["depth0"], pair["var0"]); ctx.frame_upload(0, pair["cur_image"])
-    init = (rng.normal(size=6) * [0.002, 0.002, 0.002, 0.005, 0.005, 0.005]).astype(np.float32)
-    pr, itr, _ = oracle.align(kf, cur, dm.depth_pyr(), init_pose=init)
-    pg, itg, _ = ctx.align([0], [0], init_pose=init[None])
+    if ica:
+        for l in range(L):
+            ctx.keyframe_set_weights(0, l, planes[l], 1)
+    pg, itg, _ = ctx.align([0], [0], init_pose=init[None], mode=1 if ica else 0)
     assert list(itg[0]) == list(itr) == list(mi)
-    pr64, _, _ = oracle.align(kf, cur, dm.depth_pyr(), init_pose=init, sum_mode=1)
-    assert np.linalg.norm(pg[0] - pr) <= max(1e-5, 10.0 * float(np.linalg.norm(pr64 - pr))), (pg[0], pr)
-    for l in range(L):
-        wplane = rng.uniform(0.01, 0.0625, size=(h >> l, w >> l)).astype(np.float32)
-        kf.set_weights(l, wplane, 1); ctx.keyframe_set_weights(0, l, wplane, 1)
-    pr, itr, _ = oracle.align(kf, cur, dm.depth_pyr(), init_pose=init, loop_closure=True)
-    pg, itg, _ = ctx.align([0], [0], init_pose=init[None], mode=1)
-    assert list(itg[0]) == list(itr)
-    # A constant-weight alignment of a small image with random weights need not converge, and a non-contracting iteration
-    # amplifies the rounding of the sums (the only thing that differs): the oracle itself moves by `sens` when its three
-    # row-band f32 sums are replaced by f64 sums. The bar is 1e-5, widened to that sensitivity where it is larger.
-    pr64, _, _ = oracle.align(kf, cur, dm.depth_pyr(), init_pose=init, loop_closure=True, sum_mode=1)
-    sens = float(np.linalg.norm(pr64 - pr))
-    tol = max(1e-5, 10.0 * sens)
-    if np.linalg.norm(pr - np.asarray(pair["xi_true"], np.float32)) > 0.05:   # ran away from the solution: chaotic, 1 % of its size
-        tol = max(tol, 0.01 * float(np.linalg.norm(pr)))
-    assert np.linalg.norm(pg[0] - pr) <= tol, (pg[0], pr, sens)
+    assert np.linalg.norm(pg[0] - pr) <= 1e-5, (pg[0], pr)
     ctx.close()

@@ -389,3 +389,32 @@ def test_pipelined_calls_equal_the_same_calls_made_one_by_one(ellc, seed, concur
             wb, nb = b.keyframe_weights(s, l)
             assert na == nb and np.array_equal(wa, wb)
     a.close(); b.close()
+
+
+def test_save_weights_rejects_a_shared_keyframe_slot(ellc):
+    """Saved weights are accumulated per keyframe slot: a batch in which two alignments share one is refused, not raced."""
+    pair = synth.make_pair(160, 120, seed=1)
+    ctx = gpu_problem(ellc, 160, 120, 3, [pair, pair], max_iter=(4, 7, 9))
+    ctx.align([0, 1], [0, 1], save_weights=True)            # distinct slots: fine
+    with pytest.raises(ellc.EllcError):
+        ctx.align([0, 0], [0, 1], save_weights=True)
+    ctx.align([0, 0], [0, 1])                               # without saved weights sharing a keyframe is allowed
+    ctx.close()
+
+
+def test_image_upload_drops_the_previous_depth(ellc):
+    """A keyframe slot re-used for a new image must not be aligned against the previous occupant's depth pyramid."""
+    pair = synth.make_pair(160, 120, seed=2)
+    ctx = gpu_problem(ellc, 160, 120, 3, [pair], max_iter=(4, 7, 9))
+    ctx.align([0], [0])
+    ctx.keyframe_upload(0, pair["cur_image"])
+    with pytest.raises(ellc.EllcError):
+        ctx.align([0], [0])
+    ctx.keyframe_set_depth(0, pair["depth0"], pair["var0"])
+    ctx.align([0], [0])
+    ctx.close()
+
+
+def test_context_rejects_planes_the_kernels_cannot_index(ellc):
+    with pytest.raises(ellc.EllcError):
+        ellc.Context(ellc.default_config(8192, 4096, 1))   # 2^25 pixels > the 2^24 the 32-bit plane offsets are written for
