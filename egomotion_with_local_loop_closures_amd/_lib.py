@@ -22,7 +22,9 @@ ABI_SYMBOLS = [
     "ellc_depth_observe", "ellc_depth_fill_holes", "ellc_depth_regularize", "ellc_depth_make_inv_depth_one",
     "ellc_depth_update_depth_image", "ellc_depth_create_keyframe", "ellc_depth_seeds", "ellc_profile_gn_kernel", "ellc_profile_align",
     "ellc_profile_calibrate_read", "ellc_profile_stream_read", "ellc_histogram", "ellc_kl_divergence", "ellc_copy_slot", "ellc_selftest_div_pair",
-    "ellc_ingest_configure", "ellc_frame_ingest_bgr", "ellc_selftest_lu",
+    "ellc_ingest_configure", "ellc_frame_ingest_bgr", "ellc_selftest_lu", "ellc_profile_depth_stage",
+    "ellc_shard_range", "ellc_comm_unique_id", "ellc_comm_init_rccl", "ellc_comm_init_tcp", "ellc_comm_destroy", "ellc_comm_last_error",
+    "ellc_gather_start", "ellc_gather_finish", "ellc_gather_results",
 ]
 
 
@@ -51,6 +53,25 @@ def build(verbose=False):
     subprocess.check_call(args)
 
 
+COMM_SO_PATH = os.path.join(CSRC, "libellc_comm.so")   # csrc/ellc_comm.cpp alone (TCP transport): loads without a GPU
+COMM_SYMBOLS = ["ellc_shard_range", "ellc_comm_init_tcp", "ellc_comm_destroy", "ellc_comm_last_error", "ellc_gather_start", "ellc_gather_finish",
+                "ellc_gather_results"]
+_comm = None
+
+
+def comm_lib():
+    """The multi-GPU layer as a host-only library (no HIP, no RCCL): what the CPU tests of the sharded path drive."""
+    global _comm
+    if _comm is None:
+        if not os.path.exists(COMM_SO_PATH):
+            raise EllcError("libellc_comm.so is not built (%s). Run __graft_entry__.build() / make -C %s" % (COMM_SO_PATH, CSRC))
+        _comm = C.CDLL(COMM_SO_PATH)
+        _comm.ellc_comm_last_error.restype = C.c_char_p
+        for name in COMM_SYMBOLS:
+            getattr(_comm, name)
+    return _comm
+
+
 _lib = None
 
 
@@ -64,6 +85,7 @@ def lib():
         _lib.ellc_last_error.restype = C.c_char_p
         _lib.ellc_stream.restype = C.c_void_p
         _lib.ellc_kl_divergence.restype = C.c_double
+        _lib.ellc_comm_last_error.restype = C.c_char_p
         for name in ABI_SYMBOLS:
             getattr(_lib, name)  # raises AttributeError if the library does not export it
     return _lib

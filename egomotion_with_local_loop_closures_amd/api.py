@@ -276,6 +276,13 @@ class Context:
         self._ck(self._l.ellc_profile_calibrate_read(self.h, C.c_size_t(nbytes), reps, C.byref(ms)), "ellc_profile_calibrate_read")
         return ms.value
 
+    def profile_depth_stage(self, stage, frame_slot, pose, reps=20):
+        """ms per call of one depth-map stage (0 regularize, 1 fill holes, 2 observe, 3 update depth image), HIP events."""
+        pose = np.ascontiguousarray(pose, np.float32)
+        ms = C.c_float(0)
+        self._ck(self._l.ellc_profile_depth_stage(self.h, stage, frame_slot, _p(pose), reps, C.byref(ms)), "ellc_profile_depth_stage")
+        return ms.value
+
     def profile_stream_read(self, nbytes, reps=10):
         ms = C.c_float(0)
         self._ck(self._l.ellc_profile_stream_read(self.h, C.c_size_t(nbytes), reps, C.byref(ms)), "ellc_profile_stream_read")

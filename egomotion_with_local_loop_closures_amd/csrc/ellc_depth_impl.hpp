@@ -119,8 +119,8 @@ ellc_status do_propagate(ellc_ctx* c, int new_kf_slot, const float* pose_new_wrt
   dim3 blk(32, 8);
   hipLaunchKernelGGL(dm_prop_project, grid2(W, H, blk), blk, 0, c->stream, a);
   // rounds: at most as many as the deepest collision chain; checked every 4 rounds
-  for (int guard = 0; guard < 64; guard++) {
-    int remaining = 0;
+  int remaining = 1;
+  for (int guard = 0; guard < 64 && remaining != 0; guard++) {
     for (int r = 0; r < 4; r++) {
       ELLC_HIP(c, hipMemsetAsync(c->pr_remaining, 0, 4, c->stream));
       hipLaunchKernelGGL(dm_prop_select, dim3((n + 255) / 256), dim3(256), 0, c->stream, a, n);
@@ -129,8 +129,11 @@ ellc_status do_propagate(ellc_ctx* c, int new_kf_slot, const float* pose_new_wrt
     ELLC_HIP(c, hipGetLastError());
     ELLC_HIP(c, hipMemcpyAsync(&remaining, c->pr_remaining, 4, hipMemcpyDeviceToHost, c->stream));
     ELLC_HIP(c, hipStreamSynchronize(c->stream));
-    if (remaining == 0) break;
   }
+  // 256 rounds resolve every collision chain a map of <= 2^24 pixels can hold in practice; if sources were still unresolved the
+  // target map would differ from the reference's raster-order fold: report it instead of returning a wrong map (the current
+  // map is left untouched: no swap)
+  if (remaining != 0) return fail(c, ELLC_ERR_CAPACITY, "ellc_depth_propagate: collision chains deeper than 256 rounds");
   swap_maps(c);   // std::swap(currentDepthHypothesis, otherDepthHypothesis) (:1154)
   return ELLC_OK;
 }
@@ -251,13 +254,47 @@ ellc_status ellc_depth_create_keyframe(ellc_ctx* c, int new_kf_slot, const float
   ELLC_ENTER(c);
   ellc_status s = need_map(c);
   if (s != ELLC_OK) return s;
-  if ((s = do_propagate(c, new_kf_slot, pose_new_wrt_old)) != ELLC_OK) return s;   // :1769
+  if ((s = do_propagate(c, new_kf_slot, pose_new_wrt_old)) != ELLC_OK) return s;   // :1769 (on failure the map is unchanged)
+  const int old_slot = c->dm_kf_slot;
   c->dm_kf_slot = new_kf_slot;                                                     // :1772
-  if ((s = do_regularize(c, 1)) != ELLC_OK) return s;                              // :1775
-  if ((s = do_fill_holes(c)) != ELLC_OK) return s;                                 // :1777 doRegularization(false)
-  if ((s = do_regularize(c, 0)) != ELLC_OK) return s;
-  if ((s = do_rescale(c, rescale_factor)) != ELLC_OK) return s;                    // :1779
-  return do_update_depth_image(c);                                                 // :1781
+  if ((s = do_regularize(c, 1)) == ELLC_OK &&                                      // :1775
+      (s = do_fill_holes(c)) == ELLC_OK &&                                         // :1777 doRegularization(false)
+      (s = do_regularize(c, 0)) == ELLC_OK &&
+      (s = do_rescale(c, rescale_factor)) == ELLC_OK)                              // :1779
+    s = do_update_depth_image(c);                                                  // :1781
+  if (s != ELLC_OK) {   // a device error part-way: the map no longer matches either keyframe
+    c->dm_kf_slot = old_slot;
+    c->dm_ready = false;
+  }
+  return s;
+}
+
+// measurement hook (bench.py): `reps` enqueues of one depth-map stage between two HIP events on the context's stream.
+// stage 0: regularizeDepthMap(false), 1: fillDepthHoles, 2: observeDepthRow against frame_slot / pose, 3: updateDepthImage
+// (export + depth / variance pyramid). The map keeps evolving from call to call, as it does from frame to frame.
+ellc_status ellc_profile_depth_stage(ellc_ctx* c, int stage, int frame_slot, const float* pose_frame_wrt_kf, int reps, float* avg_ms) {
+  ELLC_ENTER(c);
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  if (reps < 1 || stage < 0 || stage > 3) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  auto once = [&]() -> ellc_status {
+    switch (stage) {
+      case 0: return do_regularize(c, 0);
+      case 1: return do_fill_holes(c);
+      case 2: return ellc_depth_observe(c, frame_slot, pose_frame_wrt_kf);
+      default: return do_update_depth_image(c);
+    }
+  };
+  if ((s = once()) != ELLC_OK) return s;
+  ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < reps; i++)
+    if ((s = once()) != ELLC_OK) return s;
+  ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
+  ELLC_HIP(c, hipEventSynchronize(c->ev1));
+  float ms = 0;
+  ELLC_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  if (avg_ms) *avg_ms = ms / reps;
+  return ELLC_OK;
 }
 
 ellc_status ellc_depth_seeds(ellc_ctx* c, float* percent) {

@@ -11,6 +11,11 @@
 // --bgr              the input holds decoded full-size BGR frames (4W x 4H x 3 bytes each): grey conversion, undistortion with
 //                    the reference's hard-coded camera (ExternVariable.h:53-62, scaled to the input size) and the 1/4
 //                    resize run on the device (Frame.cpp:45-75); --no-undistort = FLAG_DO_UNDISTORTION off
+// --world N --rank r [--device d] with --comm-id FILE (RCCL: rank 0 writes its 128-byte unique id there, the others read it)
+//                    or --comm-tcp PORT (TCP on 127.0.0.1 through rank 0): one process per GPU, every process tracks the whole
+//                    sequence, the loop-closure batch (GlobalOptimize.cpp:480-610) is sharded over the ranks by
+//                    ellc_shard_range and its poses are gathered once per batch (ellc_gather_results); every rank writes
+//                    the same files into its own out_dir
 // Input is otherwise a header-less file of W*H u8 grey frames (the decode itself always stays outside).
 // In LC mode finished keyframes go through the loop-closure ring (facade class globalOptimize); tracking-loss recovery
 // (findConnection) and the MATLAB rotation averaging are not part of this path.
@@ -19,6 +24,7 @@
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <unistd.h>
 
 using namespace ellc;
 
@@ -33,6 +39,8 @@ int main(int argc, char** argv) {
   int levels = 4;
   std::string save_mats, replicate, init_poses;
   bool bgr = false, undistort = true;
+  int world = 1, rank = 0, device = 0, comm_port = 0;
+  std::string comm_id_file;
   for (int i = 6; i < argc; i++) {
     const std::string a = argv[i];
     if (a == "LC") lc = true;
@@ -41,6 +49,11 @@ int main(int argc, char** argv) {
     else if (a == "--init-poses" && i + 1 < argc) init_poses = argv[++i];
     else if (a == "--bgr") bgr = true;
     else if (a == "--no-undistort") undistort = false;
+    else if (a == "--world" && i + 1 < argc) world = std::atoi(argv[++i]);
+    else if (a == "--rank" && i + 1 < argc) rank = std::atoi(argv[++i]);
+    else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+    else if (a == "--comm-id" && i + 1 < argc) comm_id_file = argv[++i];
+    else if (a == "--comm-tcp" && i + 1 < argc) comm_port = std::atoi(argv[++i]);
     else if (!a.empty() && a[0] >= '0' && a[0] <= '9') levels = std::atoi(a.c_str());
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return -1; }
   }
@@ -57,7 +70,39 @@ int main(int argc, char** argv) {
       cfg.max_frames = 4;
       cfg.max_batch = globalOptimize::MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
     }
+    cfg.device = device;
     Runtime rt(cfg);
+    struct CommOwner {   // destroyed after the loop, before the runtime
+      ellc_comm* c = nullptr;
+      ~CommOwner() { if (c) ellc_comm_destroy(c); }
+    } comm;
+    if (world > 1) {
+      if (rank < 0 || rank >= world || (comm_id_file.empty() && comm_port <= 0)) { std::fprintf(stderr, "--world needs --rank and --comm-id FILE or --comm-tcp PORT\n"); return -1; }
+      const int max_total = globalOptimize::MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
+      ellc_status st;
+      if (!comm_id_file.empty()) {
+        unsigned char id[128];
+        if (rank == 0) {
+          if (ellc_comm_unique_id(id) != ELLC_OK) { std::fprintf(stderr, "ellc_comm_unique_id failed\n"); return -2; }
+          std::ofstream o((comm_id_file + ".tmp").c_str(), std::ios::binary);
+          o.write((const char*)id, 128);
+          o.close();
+          std::rename((comm_id_file + ".tmp").c_str(), comm_id_file.c_str());
+        } else {
+          for (int attempt = 0;; attempt++) {
+            std::ifstream idf(comm_id_file.c_str(), std::ios::binary);
+            if (idf && idf.read((char*)id, 128)) break;
+            if (attempt > 600) { std::fprintf(stderr, "no unique id in %s after 60 s\n", comm_id_file.c_str()); return -2; }
+            usleep(100000);
+          }
+        }
+        st = ellc_comm_init_rccl(device, id, world, rank, max_total, &comm.c);
+      } else {
+        st = ellc_comm_init_tcp("127.0.0.1", comm_port, world, rank, max_total, &comm.c);
+      }
+      if (st != ELLC_OK) { std::fprintf(stderr, "communicator: %s\n", ellc_comm_last_error(comm.c)); return -2; }
+      rt.comm = comm.c; rt.world = world; rt.rank = rank;
+    }
     rt.FLAG_DO_LOOP_CLOSURE = lc;
     rt.KEYFRAME_PROPAGATE_INTERVAL = KEYFRAME_PROPAGATE_INTERVAL;
     if (!save_mats.empty()) { rt.FLAG_SAVE_MATS = true; rt.SAVED_MATS_PATH = save_mats; }

@@ -131,6 +131,81 @@ class ResultGatherer:
         return self.finish()
 
 
+class Comm:
+    """The C ABI's communicator (include/ellc_abi.h, multi-GPU section): the gather of a sharded batch's results as the
+    library implements it in C++ — ncclAllGather over xGMI (transport "rccl", libellc_hip.so) or a TCP star through rank 0
+    (transport "tcp", host memory only; `host_only` loads csrc/libellc_comm.so, which needs no GPU). torch.distributed is
+    not involved; a launcher only has to hand rank 0's 128-byte unique id to the other ranks (rccl) or name a port (tcp)."""
+
+    def __init__(self, world, rank, max_total, transport="tcp", device=0, unique_id=None, host="127.0.0.1", port=29611, host_only=False):
+        import ctypes as C
+        from . import _lib
+        self._C = C
+        self._l = _lib.comm_lib() if host_only else _lib.lib()
+        self.world, self.rank, self.max_total = world, rank, max_total
+        h = C.c_void_p()
+        if transport == "rccl":
+            assert unique_id is not None and len(unique_id) == 128
+            buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+            st = self._l.ellc_comm_init_rccl(device, buf, world, rank, max_total, C.byref(h))
+        else:
+            st = self._l.ellc_comm_init_tcp(host.encode(), port, world, rank, max_total, C.byref(h))
+        self.h = h
+        if st != 0:
+            msg = self._l.ellc_comm_last_error(h).decode() if h else "communicator creation failed"
+            self.close()
+            raise _lib.EllcError("ellc_comm_init_%s -> %d: %s" % (transport, st, msg))
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_ubyte * 128)()
+        st = _lib.lib().ellc_comm_unique_id(buf)
+        if st != 0:
+            raise _lib.EllcError("ellc_comm_unique_id -> %d" % st)
+        return bytes(buf)
+
+    def shard_range(self, total):
+        C = self._C
+        lo, hi = C.c_int(0), C.c_int(0)
+        self._l.ellc_shard_range(total, self.world, self.rank, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def _ck(self, st, what):
+        if st != 0:
+            from . import _lib
+            raise _lib.EllcError("%s -> %d: %s" % (what, st, self._l.ellc_comm_last_error(self.h).decode()))
+
+    def start(self, total, local):
+        loc = np.ascontiguousarray(local, np.float32).reshape(-1, RECORD)
+        self._total = total
+        self._ck(self._l.ellc_gather_start(self.h, total, loc.ctypes.data_as(self._C.c_void_p), loc.shape[0]), "ellc_gather_start")
+
+    def finish(self, total=None):
+        out = np.zeros((self._total if total is None else total, RECORD), np.float32)
+        self._ck(self._l.ellc_gather_finish(self.h, out.ctypes.data_as(self._C.c_void_p)), "ellc_gather_finish")
+        return out
+
+    def gather(self, total, local):
+        loc = np.ascontiguousarray(local, np.float32).reshape(-1, RECORD)
+        out = np.zeros((total, RECORD), np.float32)
+        self._ck(self._l.ellc_gather_results(self.h, total, loc.ctypes.data_as(self._C.c_void_p), loc.shape[0], out.ctypes.data_as(self._C.c_void_p)),
+                 "ellc_gather_results")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._l.ellc_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def align_sharded(ctx, total, local_kf_slots, local_frame_slots, init_pose=None, mode=0, device=None, group=None):
     """Run this rank's share of `total` alignments on its GPU and gather all poses.
 

@@ -209,6 +209,26 @@ ellc_status ellc_depth_update_depth_image(ellc_ctx* ctx);
 ellc_status ellc_depth_create_keyframe(ellc_ctx* ctx, int new_kf_slot, const float* pose_new_wrt_old, float* rescale_factor);
 ellc_status ellc_depth_seeds(ellc_ctx* ctx, float* percent);              /* calculate_no_of_Seeds :1804-1830 */
 
+/* ---- multi-GPU: the loop-closure batch sharded over the ranks of one node, one gather of the results ------
+ * The batch loop of globalOptimize::findMatchParallel (GlobalOptimize.cpp:480-610) runs B independent alignments; rank r of
+ * `world` (one process per GPU) aligns the contiguous block ellc_shard_range gives it on its own context and the ONLY
+ * exchange is one gather per batch of 8 floats per alignment: [pose(6), weightedPose, iterations executed]. A communicator
+ * is independent of any ellc_ctx. Transports: RCCL (ncclAllGather over xGMI on a stream of its own; libellc_hip.so) and TCP
+ * through rank 0 (host memory only: CPU tests of the sharded path, hosts without xGMI; also in libellc_comm.so, which is
+ * csrc/ellc_comm.cpp alone). Up to 4 gathers may be outstanding (start / finish), so the exchange of one batch overlaps the
+ * kernels of the next; ellc_gather_results = start + finish. Every rank passes the same `total`; n_local must be the size
+ * of the rank's block; out8 receives `total` records in global order on every rank. */
+typedef struct ellc_comm ellc_comm;
+void ellc_shard_range(int total, int world, int rank, int* lo, int* hi);
+ellc_status ellc_comm_unique_id(unsigned char* id128);   /* rank 0 creates it (ncclGetUniqueId); the host program hands the 128 bytes to the other ranks */
+ellc_status ellc_comm_init_rccl(int device, const unsigned char* id128, int world, int rank, int max_total, ellc_comm** out);
+ellc_status ellc_comm_init_tcp(const char* host_ipv4, int port, int world, int rank, int max_total, ellc_comm** out);
+ellc_status ellc_comm_destroy(ellc_comm* comm);
+const char* ellc_comm_last_error(const ellc_comm* comm);
+ellc_status ellc_gather_start(ellc_comm* comm, int total, const float* local8, int n_local);
+ellc_status ellc_gather_finish(ellc_comm* comm, float* out8);
+ellc_status ellc_gather_results(ellc_comm* comm, int total, const float* local8, int n_local, float* out8);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------- */
 /* Launch the dominant kernel (FCA residual/Jacobian/accumulate at `level` over a batch) `reps` times on
  * the context stream between two HIP events; returns the average milliseconds per launch and the
@@ -218,6 +238,10 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* ctx, int B, const int* kf_slots, co
 /* Time `reps` full ellc_align_enqueue passes with HIP events on the context stream (ms per pass). */
 ellc_status ellc_profile_align(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, const float* init_pose,
                                int mode, int reps, float* avg_ms);
+
+/* `reps` enqueues of one depth-map stage between two HIP events on the context stream (ms per call). stage 0:
+ * regularizeDepthMap(false), 1: fillDepthHoles, 2: observeDepthRow against frame_slot / pose, 3: updateDepthImage. */
+ellc_status ellc_profile_depth_stage(ellc_ctx* ctx, int stage, int frame_slot, const float* pose_frame_wrt_kf, int reps, float* avg_ms);
 
 /* Counter calibration: stream `bytes` of device memory once per launch with 4-byte-per-lane loads (the access
  * width of the compacted pixel arrays), `reps` launches, so FETCH_SIZE can be scaled against a known byte count

@@ -15,6 +15,7 @@
 #define ELLC_FACADE_HPP
 
 #include "ellc_abi.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -84,6 +85,10 @@ class Runtime {
     check(ellc_ingest_configure(ctx, orig_w, orig_h, fx, fy, cx, cy, dist5, FLAG_DO_UNDISTORTION ? 1 : 0, nullptr), "ellc_ingest_configure");
     ingest_configured = true;
   }
+  // Multi-GPU (one process per GPU, every process tracks the whole sequence): the loop-closure batch is sharded over the
+  // ranks and its results gathered once per batch (ellc_gather_results). comm == nullptr: single process.
+  ellc_comm* comm = nullptr;
+  int world = 1, rank = 0;
   int frame_ring = 3;             // tracking uses frame slots [0, frame_ring): current, t-1 and one spare
   int next_frame_slot() { int s = frame_cursor_; frame_cursor_ = (frame_cursor_ + 1) % frame_ring; return s; }
   int other_keyframe_slot(int current) const { return (current + 1) % 2; }   // keyframe slots 0 / 1: active and incoming
@@ -465,7 +470,31 @@ class globalOptimize {
         kf[b] = m.kf_slot;
         ellc_concatenate_origin_pose(testFrame->poseWrtWorld, m.poseWrtWorld, &init[(size_t)b * 6]);   // ImageFunc.cpp:106
       }
-      rt->check(ellc_align(rt->ctx, B, kf.data(), fr.data(), init.data(), ELLC_MODE_ICA, 0, out.data(), nullptr, nullptr), "ellc_align");
+      if (rt->comm && rt->world > 1) {
+        // this rank's contiguous block of the candidates on its own GPU, then the one exchange of the batch: 8 floats per
+        // alignment [pose6, weightedPose, iterations] from every rank, in global order on every rank
+        int lo = 0, hi = B;
+        ellc_shard_range(B, rt->world, rt->rank, &lo, &hi);
+        const int n = hi - lo;
+        std::vector<float> pose((size_t)std::max(n, 1) * 6), wgt((size_t)std::max(n, 1)), local((size_t)std::max(n, 1) * 8), table((size_t)B * 8);
+        std::vector<int> iters((size_t)std::max(n, 1) * rt->cfg.levels);
+        if (n > 0)
+          rt->check(ellc_align(rt->ctx, n, kf.data() + lo, fr.data() + lo, init.data() + (size_t)lo * 6, ELLC_MODE_ICA, 0, pose.data(), iters.data(), wgt.data()),
+                    "ellc_align");
+        for (int b = 0; b < n; b++) {
+          for (int k = 0; k < 6; k++) local[(size_t)b * 8 + k] = pose[(size_t)b * 6 + k];
+          local[(size_t)b * 8 + 6] = wgt[b];
+          int it = 0;
+          for (int l = 0; l < rt->cfg.levels; l++) it += iters[(size_t)b * rt->cfg.levels + l];
+          local[(size_t)b * 8 + 7] = (float)it;
+        }
+        if (ellc_gather_results(rt->comm, B, local.data(), n, table.data()) != ELLC_OK)
+          throw std::runtime_error(std::string("ellc_gather_results failed: ") + ellc_comm_last_error(rt->comm));
+        for (int b = 0; b < B; b++)
+          for (int k = 0; k < 6; k++) out[(size_t)b * 6 + k] = table[(size_t)b * 8 + k];
+      } else {
+        rt->check(ellc_align(rt->ctx, B, kf.data(), fr.data(), init.data(), ELLC_MODE_ICA, 0, out.data(), nullptr, nullptr), "ellc_align");
+      }
       for (int b = 0; b < B; b++) {
         const loopFrame& m = loopFrameArray[matches[b].arrayId];
         float poseWrtOrigin[6];

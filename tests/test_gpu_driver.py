@@ -380,3 +380,59 @@ def test_driver_ingests_bgr_frames(oracle, tmp_path):
         assert r.returncode == 0, r.stdout.decode()
         outs.append((out / "poses_orig.txt").read_text())
     assert outs[0] == outs[1] and len(outs[0].strip().split("\n")) == n - 1
+
+
+def test_gather_entry_points_over_rccl_single_rank(ellc):
+    """The RCCL transport of the C ABI's gather (ncclAllGather on the library's own stream) on the one GPU of this box: a
+    communicator of one rank, several gathers outstanding. (Two ranks need two GPUs; the two- and three-rank exchange is
+    covered on CPU over the TCP transport, tests/test_comm_tcp.py, which drives the same entry points.)"""
+    from egomotion_with_local_loop_closures_amd import sharding
+    comm = sharding.Comm(1, 0, max_total=64, transport="rccl", device=0, unique_id=sharding.Comm.unique_id())
+    rng = np.random.default_rng(0)
+    tabs = [rng.normal(size=(n, 8)).astype(np.float32) for n in (32, 1, 64, 7)]
+    for t in tabs:
+        assert np.array_equal(comm.gather(t.shape[0], t), t)
+    for t in tabs:
+        comm.start(t.shape[0], t)
+    for t in tabs:
+        assert np.array_equal(comm.finish(t.shape[0]), t)
+    with pytest.raises(ellc.EllcError):
+        comm.finish(1)
+    comm.close()
+
+
+def test_loop_closure_batch_sharded_over_two_processes(tmp_path):
+    """ellc_main --world 2: two processes (here both on the box's one GPU, the exchange over the TCP transport; on a node
+    with several GPUs --device / --comm-id select RCCL) each track the sequence, align their half of every loop-closure
+    batch and gather the poses through ellc_gather_results: both write the files the single process writes."""
+    n_frames = 33
+    rng = np.random.default_rng(7)
+    tex = synth.value_noise_texture(W, H, rng)
+    idepth = synth.smooth_field(W, H, rng, cell=64, lo=0.7, hi=1.3)
+    fx, fy, cx, cy = synth.default_intrinsics(W, H)
+    step = np.array([0.0004, -0.0003, 0.0002, 0.0015, 0.0006, -0.0004])
+    frames = [tex] + [synth.render_current(tex, idepth, synth.se3_exp(step * n), fx, fy, cx, cy) for n in range(1, n_frames)]
+    raw = tmp_path / "frames.raw"
+    raw.write_bytes(b"".join(np.ascontiguousarray(f, np.uint8).tobytes() for f in frames))
+    exe = os.path.join(ROOT, "egomotion_with_local_loop_closures_amd", "csrc", "ellc_main")
+    single = tmp_path / "single"; single.mkdir()
+    r = subprocess.run([exe, str(raw), str(W), str(H), str(n_frames), str(single), "LC"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()
+    port = 29700 + (os.getpid() % 200)
+    outs, procs = [], []
+    for rank in range(2):
+        d = tmp_path / ("rank%d" % rank); d.mkdir(); outs.append(d)
+        procs.append(subprocess.Popen([exe, str(raw), str(W), str(H), str(n_frames), str(d), "LC", "--world", "2", "--rank", str(rank), "--comm-tcp", str(port)],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o = p.communicate(timeout=600)[0]
+        assert p.returncode == 0, o.decode()
+    exp = np.loadtxt(single / "matchframes_globalopt.txt")
+    assert exp.shape[0] >= 3
+    for d in outs:
+        got = np.loadtxt(d / "matchframes_globalopt.txt")
+        assert got.shape == exp.shape and np.array_equal(got[:, :2], exp[:, :2])
+        # a shard runs on the grid of a smaller batch than the whole: the sums, and so the poses, differ by rounding only
+        assert np.abs(got[:, 2:8] - exp[:, 2:8]).max() < 2e-6
+        assert (d / "poses_orig.txt").read_text() == (single / "poses_orig.txt").read_text()
+    assert (outs[0] / "matchframes_globalopt.txt").read_text() == (outs[1] / "matchframes_globalopt.txt").read_text()
