@@ -111,6 +111,11 @@ struct ellc_ctx {
   int untracked_reserved = 0;   // run budget held by untracked enqueues (measurement hooks)
   int nblk_override[ELLC_MAX_LEVELS] = {0};
   int resident_blocks = 1280;   // 256-thread blocks of the accumulate kernel resident on the device at once
+  // image uploads: ring of pinned staging buffers, so an upload only enqueues (ellc_hip.hip: upload_pyramid)
+  static constexpr int UPLOAD_RING = 4;
+  uint8_t* upload_stage[UPLOAD_RING] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t upload_done[UPLOAD_RING] = {nullptr, nullptr, nullptr, nullptr};
+  int upload_cursor = 0;
   // frame ingest (ellc_ingest_configure): fixed-point undistortion map of the 2x2 source pixels of every output pixel
   void* ingest_map = nullptr;
   uint8_t* ingest_bgr = nullptr;    // staging for one full-size BGR frame
@@ -152,5 +157,7 @@ ellc_status enter(ellc_ctx* c, bool join);
 int choose_nblk(const ellc_ctx* c, int level, int B);
 ellc_status run_prep(ellc_ctx* c, int n_unique, int need);
 ellc_status build_depth_pyramid(ellc_ctx* c, int slot);
+ellc_status build_depth_pyramid_from(ellc_ctx* c, int slot, int first_level);
 ellc_status build_maxgrad(ellc_ctx* c, bool is_kf, int slot);
+ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img);
 }  // namespace ellc

@@ -84,10 +84,25 @@ ellc_status do_rescale(ellc_ctx* c, float* factor_out) {
 ellc_status do_update_depth_image(ellc_ctx* c) {
   const int W = c->cfg.width, H = c->cfg.height;
   const KfLevelDev& k = c->kf_tab_h[c->dm_kf_slot];
-  dim3 blk(32, 8);
-  hipLaunchKernelGGL(dm_export_level0, grid2(W, H, blk), blk, 0, c->stream, c->dm_cur, k.depth, k.var, W, H);
+  // levels that halve exactly go into the export's own launch (dm_export_pyramid); the rest take the per-level kernel
+  int steps = 0;
+  while (steps < 3 && steps + 1 < c->L && ((W >> steps) & 1) == 0 && ((H >> steps) & 1) == 0) steps++;
+  if (steps > 0 && (W % 32) == 0 && (H % 32) == 0) {   // tiles of 32 x 32 must align with every level's 2 x 2 cells: true when the size is a multiple of 32
+    ExportPyrArgs ea;
+    ea.W = W; ea.H = H; ea.steps = steps;
+    for (int l = 0; l < 4; l++) {
+      const KfLevelDev& kl = c->kf_tab_h[(size_t)std::min(l, c->L - 1) * c->cfg.max_keyframes + c->dm_kf_slot];
+      ea.depth[l] = kl.depth;
+      ea.var[l] = kl.var;
+    }
+    hipLaunchKernelGGL(dm_export_pyramid, dim3(W / 32, H / 32), dim3(256), 0, c->stream, c->dm_cur, ea);
+  } else {
+    steps = 0;
+    dim3 blk(32, 8);
+    hipLaunchKernelGGL(dm_export_level0, grid2(W, H, blk), blk, 0, c->stream, c->dm_cur, k.depth, k.var, W, H);
+  }
   ELLC_HIP(c, hipGetLastError());
-  ellc_status s = build_depth_pyramid(c, c->dm_kf_slot);   // buildInvVarDepth + mapDepthArr2Mat
+  ellc_status s = build_depth_pyramid_from(c, c->dm_kf_slot, steps + 1);   // buildInvVarDepth + mapDepthArr2Mat: the remaining levels
   if (s != ELLC_OK) return s;
   c->kf_has_depth[c->dm_kf_slot] = 1;
   return ELLC_OK;

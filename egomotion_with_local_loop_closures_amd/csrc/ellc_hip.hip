@@ -111,19 +111,44 @@ int choose_nblk(const ellc_ctx* c, int level, int B) {
 
 static dim3 grid2d(int w, int h, dim3 blk) { return dim3((w + blk.x - 1) / blk.x, (h + blk.y - 1) / blk.y); }
 
-// upload + build the u8 pyramid for the level table entries `img[l]`
-static ellc_status upload_pyramid(ellc_ctx* c, uint8_t* const* img, const uint8_t* host) {
+// the u8 pyramid below level 0 of `img[]`: one launch per three levels (pyr_down_chain_u8)
+ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img) {
   const LevelGeom* g = c->geom_h;
-  ELLC_HIP(c, hipMemcpyAsync(img[0], host, (size_t)g[0].sw * g[0].sh, hipMemcpyHostToDevice, c->stream));
-  for (int l = 1; l < c->L; l++) {
-    dim3 blk(32, 8);
-    hipLaunchKernelGGL(pyr_down_u8, grid2d(g[l].sw, g[l].sh, blk), blk, 0, c->stream, img[l - 1], g[l - 1].sw, g[l - 1].sh, img[l],
-                       g[l].sw, g[l].sh);
+  for (int l = 0; l + 1 < c->L; l += 3) {
+    PyrChainArgs a;
+    a.steps = std::min(3, c->L - 1 - l);
+    a.src = img[l];
+    for (int k = 0; k < 4; k++) {
+      const int q = std::min(l + k, c->L - 1);
+      a.w[k] = g[q].sw;
+      a.h[k] = g[q].sh;
+    }
+    for (int k = 0; k < 3; k++) a.dst[k] = img[std::min(l + 1 + k, c->L - 1)];
+    const int dw = g[l + a.steps].sw, dh = g[l + a.steps].sh;
+    hipLaunchKernelGGL(pyr_down_chain_u8, dim3((dw + ELLC_PT - 1) / ELLC_PT, (dh + ELLC_PT - 1) / ELLC_PT), dim3(256), 0, c->stream, a);
   }
   ELLC_HIP(c, hipGetLastError());
-  // the host buffer may be pageable: make the copy complete before returning to the caller
-  ELLC_HIP(c, hipStreamSynchronize(c->stream));
   return ELLC_OK;
+}
+
+// Upload + pyramid without stalling the caller: the image is copied into one of a ring of pinned staging buffers (so the
+// caller's buffer is free when this returns, as with the blocking copy it replaces), and the host-to-device copy and the
+// pyramid launch are only enqueued. A staging buffer is reused once the copy that read it has completed (event).
+static ellc_status upload_pyramid(ellc_ctx* c, uint8_t* const* img, const uint8_t* host) {
+  const LevelGeom* g = c->geom_h;
+  const size_t bytes = (size_t)g[0].sw * g[0].sh;
+  const int k = c->upload_cursor;
+  c->upload_cursor = (c->upload_cursor + 1) % ellc_ctx::UPLOAD_RING;
+  if (!c->upload_stage[k]) {
+    ELLC_HIP(c, hipHostMalloc((void**)&c->upload_stage[k], bytes, hipHostMallocDefault));
+    ELLC_HIP(c, hipEventCreateWithFlags(&c->upload_done[k], hipEventDisableTiming));
+  } else {
+    ELLC_HIP(c, hipEventSynchronize(c->upload_done[k]));
+  }
+  std::memcpy(c->upload_stage[k], host, bytes);
+  ELLC_HIP(c, hipMemcpyAsync(img[0], c->upload_stage[k], bytes, hipMemcpyHostToDevice, c->stream));
+  ELLC_HIP(c, hipEventRecord(c->upload_done[k], c->stream));
+  return build_image_pyramid(c, img);
 }
 
 ellc_status build_maxgrad(ellc_ctx* c, bool is_kf, int slot) {
@@ -131,18 +156,17 @@ ellc_status build_maxgrad(ellc_ctx* c, bool is_kf, int slot) {
   const uint8_t* img = is_kf ? c->kf_tab_h[slot].img : c->fr_tab_h[slot].img;
   float* out = is_kf ? c->kf_maxgrad[slot] : c->fr_maxgrad[slot];
   int* cnt = is_kf ? c->kf_maxgrad_count[slot] : c->fr_maxgrad_count[slot];
-  dim3 blk(32, 8), grd = grid2d(g.cols, g.rows, blk);
   ELLC_HIP(c, hipMemsetAsync(cnt, 0, sizeof(int), c->stream));
-  hipLaunchKernelGGL(maxgrad_magnitude, grd, blk, 0, c->stream, img, g.sw, g.cols, g.rows, c->scratch_a);
-  hipLaunchKernelGGL(maxgrad_vertical, grd, blk, 0, c->stream, c->scratch_a, g.cols, g.rows, c->scratch_b);
-  hipLaunchKernelGGL(maxgrad_horizontal, dim3(128), dim3(256), 0, c->stream, c->scratch_a, c->scratch_b, g.cols, g.rows, out, cnt);
+  hipLaunchKernelGGL(maxgrad_fused, dim3((g.cols + 31) / 32, (g.rows + 7) / 8), dim3(256), 0, c->stream, img, g.sw, g.cols, g.rows, out, cnt);
   ELLC_HIP(c, hipGetLastError());
   (is_kf ? c->kf_maxgrad_valid : c->fr_maxgrad_valid)[slot] = 1;
   return ELLC_OK;
 }
 
-ellc_status build_depth_pyramid(ellc_ctx* c, int slot) {
-  for (int l = 1; l < c->L; l++) {
+ellc_status build_depth_pyramid(ellc_ctx* c, int slot) { return build_depth_pyramid_from(c, slot, 1); }
+
+ellc_status build_depth_pyramid_from(ellc_ctx* c, int slot, int first_level) {
+  for (int l = std::max(1, first_level); l < c->L; l++) {
     const KfLevelDev& s = c->kf_tab_h[(l - 1) * c->cfg.max_keyframes + slot];
     const KfLevelDev& d = c->kf_tab_h[l * c->cfg.max_keyframes + slot];
     const int w = c->cfg.width >> l, h = c->cfg.height >> l;
@@ -153,8 +177,9 @@ ellc_status build_depth_pyramid(ellc_ctx* c, int slot) {
   return ELLC_OK;
 }
 
-// compaction for pyramid levels lvl_lo .. lvl_hi of the listed keyframes, on stream `st`
-ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int lvl_hi, hipStream_t st) {
+// compaction for pyramid levels lvl_lo .. lvl_hi of the listed keyframes, on stream `st`. stage_B >= 0: the count launch also
+// stages the batch description and initialises stage_B alignment states (PrepArgs; replaces a separate stage_in launch)
+ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int lvl_hi, hipStream_t st, int stage_B) {
   if (lvl_lo > lvl_hi) return ELLC_OK;
   PrepArgs a;
   a.need = need;
@@ -167,7 +192,27 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
   a.tile0 = c->tile_begin[lvl_lo];
   a.level0 = lvl_lo;
   const int tiles = c->tile_begin[lvl_hi + 1] - c->tile_begin[lvl_lo];
-  hipLaunchKernelGGL(prep_count, dim3(tiles, n_unique), dim3(256), 0, st, a);
+  a.count_tiles = tiles;
+  a.count_slots = a.slots;
+  a.stage_dst = nullptr;
+  a.stage_src = nullptr;
+  a.stage_n = a.stage_copy_blocks = a.stage_B = a.stage_max_batch = 0;
+  a.stage_state = nullptr;
+  a.stage_sync_words = nullptr;
+  int stage_blocks = 0;
+  if (stage_B >= 0) {
+    a.stage_dst = c->kf_slot_d;
+    a.stage_src = c->stage_dev_alias;
+    a.stage_n = 9 * c->cfg.max_batch;
+    a.stage_copy_blocks = (a.stage_n + 255) / 256;
+    a.stage_B = stage_B;
+    a.stage_max_batch = c->cfg.max_batch;
+    a.stage_state = c->state_d;
+    a.stage_sync_words = (unsigned*)c->sync_d;
+    a.count_slots = c->stage_dev_alias + 2 * c->cfg.max_batch;   // the unique slots in the pinned record
+    stage_blocks = a.stage_copy_blocks + (stage_B + 255) / 256;
+  }
+  hipLaunchKernelGGL(prep_count, dim3(tiles + stage_blocks, n_unique), dim3(256), 0, st, a);
   switch (need) {
     case 1: hipLaunchKernelGGL(prep_scatter<1>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL(prep_scatter<2>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
@@ -179,7 +224,7 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
   return ELLC_OK;
 }
 
-ellc_status run_prep(ellc_ctx* c, int n_unique, int need) { return run_prep_levels(c, n_unique, need, 0, c->L - 1, c->stream); }
+ellc_status run_prep(ellc_ctx* c, int n_unique, int need) { return run_prep_levels(c, n_unique, need, 0, c->L - 1, c->stream, -1); }
 
 // ICA: H^-1 of every (unique keyframe, level) from the per-tile sums the compaction (need bit 2) left behind
 static void enqueue_ica_hinv(ellc_ctx* c, int n_unique) {
@@ -822,6 +867,10 @@ ellc_status ellc_ctx_destroy(ellc_ctx* c) {
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
   for (void* p : c->allocs) (void)hipFree(p);
   for (void* p : c->host_allocs) (void)hipHostFree(p);
+  for (int k = 0; k < ellc_ctx::UPLOAD_RING; k++) {
+    if (c->upload_stage[k]) (void)hipHostFree(c->upload_stage[k]);
+    if (c->upload_done[k]) (void)hipEventDestroy(c->upload_done[k]);
+  }
   if (c->ingest_map) (void)hipFree(c->ingest_map);
   if (c->ingest_bgr) (void)hipFree(c->ingest_bgr);
   for (int p = 0; p < ellc_ctx::SETS; p++) {
@@ -1081,10 +1130,10 @@ ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, i
 // prep + init + the whole level/iteration schedule; captured once per (B, unique keyframes, mode, save_weights)
 // into a hipGraph and replayed afterwards (the launches are too short to be issued one by one from the host)
 static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int save_weights) {
-  enqueue_stage_in(c, B);   // also initialises the B alignment states
-  // mask / count per level (updationOnPyrChange, ImageFunc.cpp:158) and the pose-independent per-pixel records
+  // staging + state initialisation (folded into the first launch), mask / count per level (updationOnPyrChange,
+  // ImageFunc.cpp:158) and the pose-independent per-pixel records
   const int need = mode == ELLC_MODE_ICA ? (c->use_fused ? 4 : 1) : (c->fast ? 8 : 2);
-  ellc_status s = run_prep(c, nu, need);
+  ellc_status s = run_prep_levels(c, nu, need, 0, c->L - 1, c->stream, B);
   if (s != ELLC_OK) return s;
   if (need == 4) enqueue_ica_hinv(c, nu);
   s = enqueue_schedule(c, B, mode, save_weights);

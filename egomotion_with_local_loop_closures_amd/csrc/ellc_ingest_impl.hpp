@@ -106,8 +106,10 @@ static inline void ingest_build_maps(const float K[4], const float dist[5], cons
         const double v = fy * (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy) + v0;
         const int iu = (int)std::nearbyint(u * 32), iv = (int)std::nearbyint(v * 32);   // saturate_cast<int>: round half to even
         IngestMapEntry e;
-        e.ix = (short)(iu >> 5);
-        e.iy = (short)(iv >> 5);
+        // saturate_cast<short>, as cv::convertMaps stores the integer part (a distortion model evaluated far outside the image
+        // can leave the 16-bit range; such entries only have to stay out of bounds, not wrap around into the image)
+        e.ix = (short)std::max(-32768, std::min(32767, iu >> 5));
+        e.iy = (short)std::max(-32768, std::min(32767, iv >> 5));
         e.frac = (unsigned short)((iv & 31) * 32 + (iu & 31));
         e.pad = 0;
         map[(size_t)(y0 + i) * w + j] = e;
@@ -175,10 +177,17 @@ ellc_status ellc_ingest_configure(ellc_ctx* c, int orig_w, int orig_h, float fx,
   if (c->ingest_bgr) (void)hipFree(c->ingest_bgr);
   c->ingest_map = nullptr;
   c->ingest_bgr = nullptr;
-  ELLC_HIP(c, hipMalloc(&c->ingest_map, need.size() * sizeof(IngestMapEntry)));
-  ELLC_HIP(c, hipMalloc(&c->ingest_bgr, (size_t)orig_w * orig_h * 3));
-  ELLC_HIP(c, hipMemcpyAsync(c->ingest_map, need.data(), need.size() * sizeof(IngestMapEntry), hipMemcpyHostToDevice, c->stream));
-  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  hipError_t ie = hipMalloc(&c->ingest_map, need.size() * sizeof(IngestMapEntry));
+  if (ie == hipSuccess) ie = hipMalloc((void**)&c->ingest_bgr, (size_t)orig_w * orig_h * 3);
+  if (ie == hipSuccess) ie = hipMemcpyAsync(c->ingest_map, need.data(), need.size() * sizeof(IngestMapEntry), hipMemcpyHostToDevice, c->stream);
+  if (ie == hipSuccess) ie = hipStreamSynchronize(c->stream);
+  if (ie != hipSuccess) {   // all or nothing: a half-configured ingest would pass the "configured" check of ellc_frame_ingest_bgr
+    if (c->ingest_map) (void)hipFree(c->ingest_map);
+    if (c->ingest_bgr) (void)hipFree(c->ingest_bgr);
+    c->ingest_map = nullptr;
+    c->ingest_bgr = nullptr;
+    return fail(c, ELLC_ERR_HIP, std::string("ellc_ingest_configure: ") + hipGetErrorString(ie));
+  }
   c->ingest_w = orig_w;
   c->ingest_h = orig_h;
   return ELLC_OK;
@@ -193,16 +202,18 @@ ellc_status ellc_frame_ingest_bgr(ellc_ctx* c, int slot, const uint8_t* bgr, uin
   ELLC_HIP(c, hipMemcpyAsync(c->ingest_bgr, bgr, (size_t)w * h * 3, hipMemcpyHostToDevice, c->stream));
   uint8_t *gd = nullptr, *ud = nullptr;
   if (gray_probe) ELLC_HIP(c, hipMalloc(&gd, (size_t)ow * oh));
-  if (undistorted_probe) ELLC_HIP(c, hipMalloc(&ud, (size_t)ow * oh * 4));
+  if (undistorted_probe && hipMalloc(&ud, (size_t)ow * oh * 4) != hipSuccess) {
+    if (gd) (void)hipFree(gd);
+    return fail(c, ELLC_ERR_HIP, "ellc_frame_ingest_bgr: cannot allocate the probe buffer");
+  }
   uint8_t* img[ELLC_MAX_LEVELS];
   for (int l = 0; l < c->L; l++) img[l] = c->fr_tab_h[(size_t)l * c->cfg.max_frames + slot].img;
   const LevelGeom* g = c->geom_h;
   dim3 blk(32, 8);
   hipLaunchKernelGGL(ingest_frame, grid2d(ow, oh, blk), blk, 0, c->stream, c->ingest_bgr, w, h, (const IngestMapEntry*)c->ingest_map, img[0], ow, oh,
                      g[0].sw, gd, ud);
-  for (int l = 1; l < c->L; l++)
-    hipLaunchKernelGGL(pyr_down_u8, grid2d(g[l].sw, g[l].sh, blk), blk, 0, c->stream, img[l - 1], g[l - 1].sw, g[l - 1].sh, img[l], g[l].sw, g[l].sh);
   hipError_t e = hipGetLastError();
+  if (e == hipSuccess && build_image_pyramid(c, img) != ELLC_OK) e = hipErrorUnknown;
   if (e == hipSuccess && gd) e = hipMemcpyAsync(gray_probe, gd, (size_t)ow * oh, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess && ud) e = hipMemcpyAsync(undistorted_probe, ud, (size_t)ow * oh * 4, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the host frame buffer may be pageable

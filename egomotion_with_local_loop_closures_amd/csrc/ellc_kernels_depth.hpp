@@ -199,6 +199,89 @@ __global__ void dm_export_level0(DepthSoA s, float* __restrict__ depthMat, float
   }
 }
 
+// updateDepthImage's export (dm_export_level0) and up to three levels of buildInvVarDepth (depth_pyr_level,
+// ellc_kernels_image.hpp) in ONE launch: a block exports a 32 x 32 tile of level 0 and reduces it 2x2 -> 16x16 -> 8x8 -> 4x4
+// through LDS, writing every level. Only for level sizes that halve exactly (W >> l == 2 (W >> (l + 1)) for the levels
+// produced): the reference reads a source level with the stride 2 * (destination width), which is the source's own width
+// exactly then; other sizes take the per-level kernels. Same operations per value as the kernels it replaces.
+struct ExportPyrArgs {
+  float* depth[4];     // levels 0..3 of the keyframe's depth pyramid (frame::depth_pyramid)
+  float* var[4];       // depthMap::depthvararrptr
+  int W, H, steps;     // steps = pyramid levels produced below level 0 (0..3)
+};
+__device__ __forceinline__ void depth_pyr_merge(const float d[4], const float v[4], float& od, float& ov) {
+  float idepthSumsSum = 0.0f, ivarSumsSum = 0.0f;
+  int num = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    if (v[q] > 0.0f) {
+      const float ivar = 1.0f / v[q];
+      ivarSumsSum += ivar;
+      idepthSumsSum += ivar * 1.0f / d[q];
+      num++;
+    }
+  }
+  if (num > 0) {
+    od = ivarSumsSum / idepthSumsSum;
+    ov = (float)num / ivarSumsSum;
+  } else {
+    od = 0.0f;
+    ov = -1.0f;
+  }
+}
+__global__ __launch_bounds__(256) void dm_export_pyramid(DepthSoA s, ExportPyrArgs a) {
+  __shared__ float ld[2][32 * 32], lv[2][32 * 32];   // ping-pong: level l in [l & 1]
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int W = a.W, H = a.H;
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const int ty = i >> 5, tx = i & 31;
+    const int x = bx + tx, y = by + ty;
+    float d = 0.0f, v = -1.0f;
+    if (x < W && y < H) {
+      const int p = x + y * W;
+      bool valid = s.isValid[p] != 0;
+      if (y < 3 || y >= H - 3 || x < 3 || x >= W - 3) {
+        valid = false;
+        s.isValid[p] = 0;
+      }
+      const float ids = s.invDepthSmoothed[p];
+      if (valid && ids >= -0.05f) {
+        d = 1.0f / ids;
+        v = s.varianceSmoothed[p];
+      }
+      a.depth[0][p] = d;
+      a.var[0][p] = v;
+    }
+    ld[0][i] = d;
+    lv[0][i] = v;
+  }
+  __syncthreads();
+  int edge = 32;
+  for (int l = 1; l <= a.steps; l++) {
+    const int e2 = edge >> 1;             // tile edge at level l
+    const int wl = W >> l, hl = H >> l;
+    const float* sd = ld[(l - 1) & 1];
+    const float* sv = lv[(l - 1) & 1];
+    for (int i = threadIdx.x; i < e2 * e2; i += 256) {
+      const int ty = i / e2, tx = i - ty * e2;
+      const int x = (bx >> l) + tx, y = (by >> l) + ty;
+      const int q0 = (2 * ty) * edge + 2 * tx;
+      const float d4[4] = {sd[q0], sd[q0 + 1], sd[q0 + edge], sd[q0 + edge + 1]};
+      const float v4[4] = {sv[q0], sv[q0 + 1], sv[q0 + edge], sv[q0 + edge + 1]};
+      float od, ov;
+      depth_pyr_merge(d4, v4, od, ov);
+      if (x < wl && y < hl) {
+        a.depth[l][x + y * wl] = od;
+        a.var[l][x + y * wl] = ov;
+      }
+      ld[l & 1][ty * e2 + tx] = od;
+      lv[l & 1][ty * e2 + tx] = ov;
+    }
+    __syncthreads();
+    edge = e2;
+  }
+}
+
 // depthMap::makeInvDepthOne (:1546-1587): sum of invDepthSmoothed over valid pixels and their count.
 // Stage 1: per-block f64 partials (fixed order); stage 2: one block combines them with the same fixed tree.
 __global__ __launch_bounds__(256) void dm_sum_stage1(DepthSoA s, int n, double* __restrict__ part) {

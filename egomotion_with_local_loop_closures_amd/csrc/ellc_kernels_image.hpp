@@ -108,6 +108,139 @@ __global__ __launch_bounds__(256) void maxgrad_horizontal(const float* __restric
   if (threadIdx.x == 0 && sh[0]) atomicAdd(count, sh[0]);
 }
 
+// The whole u8 pyramid below one source level in ONE launch (up to three pyrDown steps): a block owns a PT x PT tile of the
+// deepest level it produces and computes, through LDS, everything above it that the tile depends on — the (2PT+3)^2 region of
+// the level above, the (4PT+9)^2 region two above, from the (8PT+21)^2 region of the source — writing the part of each level
+// it owns (a 2x / 4x larger tile; the halo is recomputed by the neighbours: 1.9x / 2.4x redundant arithmetic at PT = 4 on images
+// of a few hundred KB, against two kernel boundaries saved; PT = 8 gave 80 blocks at 640x480 and a 17 us launch). Same integer arithmetic as pyr_down_u8, so the same bytes.
+// Regions are kept in image coordinates clipped to the level (REFLECT_101 is applied to coordinates, and a reflected
+// coordinate of a position the tile needs lies inside the clipped region).
+#define ELLC_PT 4
+struct PyrChainArgs {
+  const uint8_t* src;            // level l
+  uint8_t* dst[3];               // levels l+1 .. l+3 (only the first `steps` are used)
+  int w[4], h[4];                // stored sizes of levels l .. l+3
+  int steps;                     // 1..3
+};
+__device__ __forceinline__ int pyr5(const uint8_t* t, int stride, int x0, int y0, int lox, int loy, int sw, int sh, int x, int y) {
+  // (sum over the 5x5 [1 4 6 4 1]^2 window centred at (2x, 2y) of the level above + 128) >> 8; t holds that level from (lox, loy)
+  const int wk[5] = {1, 4, 6, 4, 1};
+  int cx[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) cx[k] = reflect101(2 * x + k - 2, sw) - lox;
+  int v = 0;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const uint8_t* r = t + (reflect101(2 * y + j - 2, sh) - loy) * stride;
+    int hsum = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) hsum += wk[k] * (int)r[cx[k]];
+    v += wk[j] * hsum;
+  }
+  (void)x0; (void)y0;
+  return (v + 128) >> 8;
+}
+__global__ __launch_bounds__(256) void pyr_down_chain_u8(PyrChainArgs a) {
+  constexpr int R1 = 2 * ELLC_PT + 3, R2 = 2 * R1 + 3, R3 = 2 * R2 + 3;   // 11, 25, 53: region edge one, two, three levels above the tile
+  __shared__ uint8_t lds[R3 * R3 + R2 * R2 + R1 * R1];   // three regions: 53^2, 25^2, 11^2
+  const int S = a.steps;
+  // owned tile at the deepest produced level (level index S relative to the source)
+  int lox[4], loy[4], hix[4], hiy[4];   // needed region per level (relative index 0 = source), [lo, hi) clipped to the level
+  lox[S] = blockIdx.x * ELLC_PT; loy[S] = blockIdx.y * ELLC_PT;
+  hix[S] = min(a.w[S], lox[S] + ELLC_PT); hiy[S] = min(a.h[S], loy[S] + ELLC_PT);
+  for (int l = S - 1; l >= 0; l--) {
+    lox[l] = max(0, 2 * lox[l + 1] - 2); loy[l] = max(0, 2 * loy[l + 1] - 2);
+    hix[l] = min(a.w[l], 2 * (hix[l + 1] - 1) + 3); hiy[l] = min(a.h[l], 2 * (hiy[l + 1] - 1) + 3);
+  }
+  // the level with relative index l lives in region l + 3 - S (so the source of a 3-step chain is the 53^2 region, of a
+  // 1-step chain the 11^2 region)
+  auto buf = [&](int l) {
+    const int k = l + 3 - S;
+    return lds + (k == 0 ? 0 : (k == 1 ? R3 * R3 : R3 * R3 + R2 * R2));
+  };
+  auto stride = [&](int l) { return hix[l] - lox[l]; };
+  {   // source region
+    const int wdt = stride(0), hgt = hiy[0] - loy[0];
+    uint8_t* t = buf(0);
+    for (int i = threadIdx.x; i < wdt * hgt; i += 256) {
+      const int y = i / wdt, x = i - y * wdt;
+      t[i] = a.src[(size_t)(loy[0] + y) * a.w[0] + lox[0] + x];
+    }
+  }
+  __syncthreads();
+  for (int l = 1; l <= S; l++) {
+    const int wdt = stride(l), hgt = hiy[l] - loy[l];
+    const uint8_t* up = buf(l - 1);
+    const int ustride = stride(l - 1);
+    // what this block owns of level l: the 2^(S-l) times larger tile (the region beyond it is halo, recomputed by neighbours)
+    const int sc = ELLC_PT << (S - l);
+    const int ox0 = blockIdx.x * sc, oy0 = blockIdx.y * sc, ox1 = ox0 + sc, oy1 = oy0 + sc;
+    for (int i = threadIdx.x; i < wdt * hgt; i += 256) {
+      const int yy = i / wdt, xx = i - yy * wdt;
+      const int x = lox[l] + xx, y = loy[l] + yy;
+      const int v = pyr5(up, ustride, 0, 0, lox[l - 1], loy[l - 1], a.w[l - 1], a.h[l - 1], x, y);
+      if (l < S) buf(l)[i] = (uint8_t)v;
+      if (x >= ox0 && x < ox1 && y >= oy0 && y < oy1) a.dst[l - 1][(size_t)y * a.w[l] + x] = (uint8_t)v;
+    }
+    __syncthreads();
+  }
+}
+
+// frame::buildMaxGradients (Frame.cpp:618-674) in one launch: a 32 x 8 tile of outputs per block; the gradient magnitude of
+// the tile plus a one-pixel ring goes through LDS, then the vertical and the horizontal 3-maximum with the reference's
+// border rules (maxgrad_magnitude / _vertical / _horizontal above are the three-pass form it replaces: same operations per
+// value, same order of the two fmaxf). count += pixels >= MIN_ABS_GRAD_DECREASE (zeroed by the caller).
+__global__ __launch_bounds__(256) void maxgrad_fused(const uint8_t* __restrict__ img, int sw, int w, int h, float* __restrict__ out, int* count) {
+  constexpr int TW = 32, TH = 8;
+  __shared__ float mag[(TH + 2) * (TW + 2)];
+  __shared__ float tmp[TH * (TW + 2)];
+  __shared__ int hits_sh[4];
+  const int bx = blockIdx.x * TW, by = blockIdx.y * TH;
+  for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += 256) {
+    const int yy = i / (TW + 2), xx = i - yy * (TW + 2);
+    const int x = bx + xx - 1, y = by + yy - 1;
+    float m = 0.0f;
+    if (x >= 0 && x < w && y >= 0 && y < h) {
+      float gx, gy;
+      grad_at(img, sw, w, h, x, y, gx, gy);
+      const float p = gx * gx, q = gy * gy;
+      m = sqrtf(p + q);
+    }
+    mag[i] = m;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TH * (TW + 2); i += 256) {   // vertical 3-maximum for the tile's rows, all TW + 2 columns
+    const int yy = i / (TW + 2), xx = i - yy * (TW + 2);
+    const int y = by + yy;
+    float v = 0.0f;
+    if (y >= 1 && y < h - 1) {
+      const float g1 = fmaxf(mag[(yy + 1) * (TW + 2) + xx], mag[yy * (TW + 2) + xx]);
+      v = fmaxf(g1, mag[(yy + 2) * (TW + 2) + xx]);
+    }
+    tmp[i] = v;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int x = bx + tx, y = by + ty;
+  int hit = 0;
+  if (x < w && y < h) {
+    float v = mag[(ty + 1) * (TW + 2) + tx + 1];   // border pixels keep the raw magnitude
+    if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
+      const float g1 = fmaxf(tmp[ty * (TW + 2) + tx], tmp[ty * (TW + 2) + tx + 1]);
+      v = fmaxf(g1, tmp[ty * (TW + 2) + tx + 2]);
+      hit = (v >= 5.0f) ? 1 : 0;   // MIN_ABS_GRAD_DECREASE
+    }
+    out[(size_t)y * w + x] = v;
+  }
+  const unsigned long long m = __ballot(hit != 0);
+  if ((threadIdx.x & 63) == 0) hits_sh[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = hits_sh[0] + hits_sh[1] + hits_sh[2] + hits_sh[3];
+    if (tot) atomicAdd(count, tot);
+  }
+}
+
 // depthMap::buildInvVarDepth, one level (DepthPropagation.cpp:1637-1719); the reference's source stride
 // is 2*width of the destination. src_depth_is_mat: level-0 source holds keyFrame->depth (0 = invalid).
 __global__ void depth_pyr_level(const float* __restrict__ sd, const float* __restrict__ sv, float* __restrict__ dd, float* __restrict__ dv,
