@@ -62,16 +62,19 @@ def test_fca_full_alignment_fixed_schedule(problem, oracle):
     assert np.linalg.norm(pose[0] - problem["pair"]["xi_true"]) < 2e-3
 
 
-def test_fca_early_exit_matches_oracle(oracle, ellc):
-    pair = synth.make_pair(W, H, seed=5, rot=0.004, trans=0.008)
+@pytest.mark.parametrize("seed,rot,trans", [(5, 0.004, 0.008), (6, 0.006, 0.01), (7, 0.003, 0.02)])
+def test_fca_early_exit_matches_oracle(oracle, ellc, seed, rot, trans):
+    """The reference's early exit (a level ends once weightedPose < 1, ImageFunc.cpp:251-252): the exact mode takes the same
+    decisions as the oracle — same iteration counts per level — and lands within the 1e-5 bar."""
+    pair = synth.make_pair(W, H, seed=seed, rot=rot, trans=trans)
     ocfg, kf, cur, dm = oracle_problem(oracle, W, H, L, pair, early_exit=1)
     ctx = gpu_problem(ellc, W, H, L, [pair], early_exit=1)
     pose_ref, iters_ref, _ = oracle.align(kf, cur, dm.depth_pyr())
     pose, iters, w = ctx.align([0], [0])
     print("iters gpu", iters[0], "oracle", iters_ref)
-    # the termination test |delta|_w < 1 sits at the 1e-5 scale of the parity target; allow one iteration of slack per level
-    assert np.all(np.abs(iters[0] - iters_ref) <= 1)
-    assert np.linalg.norm(pose[0] - pose_ref) < 1e-4
+    assert list(iters[0]) == list(iters_ref)
+    assert int(np.sum(iters_ref)) < 32                       # the exit did trigger
+    assert np.linalg.norm(pose[0] - pose_ref) <= 1e-5
     ctx.close()
 
 
@@ -119,16 +122,16 @@ def test_save_weights_accumulates_last_iteration(oracle, ellc):
         wr, nr = kf.weights(l)
         wg, ng = ctx.keyframe_weights(0, l)
         assert nr == ng == 2
-        # weights of the last iteration are evaluated at poses that agree to ~1e-6 (not bitwise): the robust
-        # weight is sensitive to that at the 1e-4 level on a few pixels; identical poses give identical bits
-        # (test_fca_per_pixel_planes_bit_exact)
-        assert np.allclose(wg, wr, rtol=5e-3, atol=1e-4), (l, np.abs(wg - wr).max())
+        # The weights of the last iteration are evaluated at poses that agree to ~1e-7, not bitwise (identical poses give
+        # identical bits: test_fca_per_pixel_planes_bit_exact). Measured on this scene: 3.3e-4 relative at worst (a pixel near
+        # the Huber knee), 6e-6 at the 99.9th percentile, 2.4e-5 absolute; the zero pattern (out-of-bounds pixels) is identical.
+        assert np.array_equal(wg == 0, wr == 0), l
+        assert np.allclose(wg, wr, rtol=1e-3, atol=5e-6), (l, np.abs(wg - wr).max())
         assert np.abs(wg - wr).mean() < 2e-6
-        assert np.array_equal(wg == 0, wr == 0) or np.mean((wg == 0) != (wr == 0)) < 1e-4
     kf.finalise_weights()
     ctx.keyframe_finalise_weights(0)
     for l in range(L):
-        assert np.allclose(ctx.keyframe_weights(0, l)[0], kf.weights(l)[0], rtol=5e-3, atol=1e-4)
+        assert np.allclose(ctx.keyframe_weights(0, l)[0], kf.weights(l)[0], rtol=1e-3, atol=5e-6)
     ctx.close()
 
 

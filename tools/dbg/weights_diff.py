@@ -1,0 +1,28 @@
+import sys, os
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,'tests'))
+import numpy as np
+from egomotion_with_local_loop_closures_amd import api, synth
+from oracle import oracle_py as oracle
+from helpers import gpu_problem, oracle_problem
+W,H,L=320,240,4
+for arith in (0,1):
+    pair = synth.make_pair(W, H, seed=21)
+    ocfg, kf, cur, dm = oracle_problem(oracle, W, H, L, pair)
+    ctx = gpu_problem(api, W, H, L, [pair], arith=arith)
+    oracle.align(kf, cur, dm.depth_pyr(), save_weights=True); oracle.align(kf, cur, dm.depth_pyr(), save_weights=True)
+    ctx.align([0],[0],save_weights=True); ctx.align([0],[0],save_weights=True)
+    for l in range(L):
+        wr,nr=kf.weights(l); wg,ng=ctx.keyframe_weights(0,l)
+        m=(wr>1e-4)
+        rel=np.abs(wg-wr)[m]/wr[m]
+        print("arith",arith,"level",l,"max abs",np.abs(wg-wr).max(),"max rel",rel.max(),"99.9pct rel",np.quantile(rel,0.999),"zero mismatch",((wg==0)!=(wr==0)).sum())
+    for seed,rot,trans in ((5,0.004,0.008),(6,0.006,0.01),(7,0.003,0.02)):
+        pair = synth.make_pair(W, H, seed=seed, rot=rot, trans=trans)
+        ocfg, kf2, cur2, dm2 = oracle_problem(oracle, W, H, L, pair, early_exit=1)
+        c2 = gpu_problem(api, W, H, L, [pair], early_exit=1, arith=arith)
+        pr, itr, _ = oracle.align(kf2, cur2, dm2.depth_pyr())
+        pg, itg, _ = c2.align([0],[0])
+        print("  early exit seed",seed,"iters",itg[0],itr,"err",np.linalg.norm(pg[0]-pr))
+        c2.close()
+    ctx.close()
