@@ -150,11 +150,14 @@ def main():
     # ---- the single gather of the resulting se(3) poses (8 floats per alignment) per batch: enqueued when a batch is fetched,
     # collected up to G steps later, so the exchange never stalls the loop. Default: the library's own C++ path
     # (ellc_gather_start / ellc_gather_finish over RCCL); torch.distributed only carries rank 0's unique id to the others.
-    use_cabi = world > 1 and a.gather == "cabi" and a.backend == "nccl"
+    use_cabi = world > 1 and a.gather == "cabi"
     if use_cabi:
-        ids = [sharding.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        comm = sharding.Comm(world, rank, max_total=B * world, transport="rccl", device=dev_index, unique_id=ids[0])
+        if a.backend == "nccl":
+            ids = [sharding.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = sharding.Comm(world, rank, max_total=B * world, transport="rccl", device=dev_index, unique_id=ids[0])
+        else:   # rehearsal of several ranks on one GPU (RCCL refuses two ranks on one device): the same entry points over TCP
+            comm = sharding.Comm(world, rank, max_total=B * world, transport="tcp", port=int(os.environ.get("MASTER_PORT", "29500")) + 17)
         outstanding = [0]
 
         def on_fetch(pose, iters, wgt):
@@ -218,7 +221,7 @@ def main():
                                "compaction included, arithmetic mode '%s' (%s), %d batches in flight on %d streams%s"
                                % (shape, W, H, L, a.mode.upper(), sched, "ON: informational run" if a.early_exit else "off", a.arith,
                                   "pose <= 1e-5 vs the CPU path, tests/test_gpu_fast.py" if a.arith == "fast" else "per-pixel values bit-identical to the CPU path",
-                                  G, G, ", one all_gather of poses per step over %s (overlapped with the next batch)" % (("RCCL, issued by the library's C entry points" if use_cabi else "RCCL via torch.distributed") if a.backend == "nccl" else a.backend) if world > 1 else ""),
+                                  G, G, ", one all_gather of poses per step over %s (overlapped with the next batch)" % (("RCCL, issued by the library's C entry points" if use_cabi else "RCCL via torch.distributed") if a.backend == "nccl" else (a.backend + (" harness, gather through the library's C entry points over TCP" if use_cabi else ""))) if world > 1 else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "batches_in_flight": G, "gn_iterations_per_alignment": iters_per_alignment,
                    "alignments_per_s": world * B * a.steps / dt, "pixels": "dense" if a.dense else "semi-dense (maxAbsGradient>=5)", "arith": a.arith},
     }
