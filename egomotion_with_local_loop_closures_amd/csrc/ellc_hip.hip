@@ -427,6 +427,7 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
   fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);
   fa.res = c->result_dev_alias;
   fa.ica = 0;
+  fa.xcd_map = (B % 8 == 0) ? 1 : 0;
   set_age_split(c, fa, B);
   for (int level = c->L - 1; level >= 0; level--) {
     fa.g = make_gn_args(c, level, B, save_weights ? 1 : 0, nullptr);
@@ -458,6 +459,7 @@ static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
   fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
   fa.res = c->result_dev_alias;
   fa.ica = 1;
+  fa.xcd_map = 0;
   fa.age_rounds = 0;
   for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
   fa.g = make_gn_args(c, 0, B, 0, nullptr);
@@ -1402,6 +1404,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     fa.g = a;
     fa.res = nullptr;
     fa.ica = 0;
+    fa.xcd_map = (B % 8 == 0) ? 1 : 0;
     set_age_split(c, fa, B);
     fa.seq = 0;
     fa.prev_level = level;

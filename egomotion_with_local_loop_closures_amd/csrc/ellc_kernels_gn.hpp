@@ -1142,6 +1142,7 @@ struct FusedArgs {
   // in linear order; if that were not so the result is unchanged (the split is static) and only the balance is lost.
   int age_rounds;
   int age_cum[5];
+  int xcd_map;          // 1: blocks are renumbered so that all blocks of an alignment run on one XCD (see gn_fca_fused)
   AlignResult* res;     // gn_fused_finish: host-visible result records (null: none)
   int ica;              // 1: constant-weight schedule (gn_ica_fused): the pending sums are b only, H^-1 comes from the keyframe slot
 };
@@ -1163,6 +1164,15 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
     const int j = lin - age * per_round;
     b = j / per_age;
     sub = age * per_age + (j - b * per_age);
+  } else if (fa.xcd_map) {
+    // Workgroups are dealt round-robin over the 8 XCDs in dispatch order, each XCD with an L2 of its own. Renumbered so that
+    // alignment b's blocks are the linear ids congruent to b mod 8, all of an alignment's taps (and its record list) go
+    // through ONE L2: with a frame per alignment (1280x960: 1.2 MB each) every XCD otherwise pulls every image. Pure
+    // relabelling of (alignment, chunk): results unchanged; a different dispatch order would only lose the locality.
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int w = lin >> 3, bl = w / nblk;
+    sub = w - bl * nblk;
+    b = bl * 8 + (lin & 7);
   }
   const AlignState& src = src_state[b];
   AlignState* dst = a.state + (size_t)((fa.seq + 1) & 1) * fa.stride_state + b;
@@ -1247,8 +1257,9 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   int i = begin + t;
   // Software pipeline of both loops: the record of pixel i + 256 is requested while pixel i is processed (index clamped, so
   // the load is unconditional), behind pixel i's tap loads, see tap_point. The two record slots alternate through an
-  // explicitly unrolled loop body: a register copy of a slot would have to wait for the load that fills it. (Keeping two
-  // records in flight was measured no faster: with ~100 % VALU issue in the pixel phase the loop is not waiting for memory.)
+  // explicitly unrolled loop body: a register copy of a slot would have to wait for the load that fills it. (More records
+  // in flight were measured no faster, neither at 640x480 semi-dense, where the lists are cache resident, nor at 1280x960
+  // dense x 16, where they stream from HBM: the pixel phase is bound by VALU issue, not by the record loads.)
   if constexpr (FAST) {
     if (i < end) {
       FcaInF r0 = firstf, r1 = firstf;
