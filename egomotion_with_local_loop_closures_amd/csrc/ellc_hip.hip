@@ -177,9 +177,8 @@ ellc_status build_depth_pyramid_from(ellc_ctx* c, int slot, int first_level) {
   return ELLC_OK;
 }
 
-// compaction for pyramid levels lvl_lo .. lvl_hi of the listed keyframes, on stream `st`. stage_B >= 0: the count launch also
-// stages the batch description and initialises stage_B alignment states (PrepArgs; replaces a separate stage_in launch)
-ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int lvl_hi, hipStream_t st, int stage_B) {
+// compaction for pyramid levels lvl_lo .. lvl_hi of the listed keyframes, on stream `st`
+ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int lvl_hi, hipStream_t st) {
   if (lvl_lo > lvl_hi) return ELLC_OK;
   PrepArgs a;
   a.need = need;
@@ -192,27 +191,7 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
   a.tile0 = c->tile_begin[lvl_lo];
   a.level0 = lvl_lo;
   const int tiles = c->tile_begin[lvl_hi + 1] - c->tile_begin[lvl_lo];
-  a.count_tiles = tiles;
-  a.count_slots = a.slots;
-  a.stage_dst = nullptr;
-  a.stage_src = nullptr;
-  a.stage_n = a.stage_copy_blocks = a.stage_B = a.stage_max_batch = 0;
-  a.stage_state = nullptr;
-  a.stage_sync_words = nullptr;
-  int stage_blocks = 0;
-  if (stage_B >= 0) {
-    a.stage_dst = c->kf_slot_d;
-    a.stage_src = c->stage_dev_alias;
-    a.stage_n = 9 * c->cfg.max_batch;
-    a.stage_copy_blocks = (a.stage_n + 255) / 256;
-    a.stage_B = stage_B;
-    a.stage_max_batch = c->cfg.max_batch;
-    a.stage_state = c->state_d;
-    a.stage_sync_words = (unsigned*)c->sync_d;
-    a.count_slots = c->stage_dev_alias + 2 * c->cfg.max_batch;   // the unique slots in the pinned record
-    stage_blocks = a.stage_copy_blocks + (stage_B + 255) / 256;
-  }
-  hipLaunchKernelGGL(prep_count, dim3(tiles + stage_blocks, n_unique), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(prep_count, dim3(tiles, n_unique), dim3(256), 0, st, a);
   switch (need) {
     case 1: hipLaunchKernelGGL(prep_scatter<1>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL(prep_scatter<2>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
@@ -224,7 +203,7 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
   return ELLC_OK;
 }
 
-ellc_status run_prep(ellc_ctx* c, int n_unique, int need) { return run_prep_levels(c, n_unique, need, 0, c->L - 1, c->stream, -1); }
+ellc_status run_prep(ellc_ctx* c, int n_unique, int need) { return run_prep_levels(c, n_unique, need, 0, c->L - 1, c->stream); }
 
 // ICA: H^-1 of every (unique keyframe, level) from the per-tile sums the compaction (need bit 2) left behind
 static void enqueue_ica_hinv(ellc_ctx* c, int n_unique) {
@@ -1132,10 +1111,12 @@ ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, i
 // prep + init + the whole level/iteration schedule; captured once per (B, unique keyframes, mode, save_weights)
 // into a hipGraph and replayed afterwards (the launches are too short to be issued one by one from the host)
 static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int save_weights) {
-  // staging + state initialisation (folded into the first launch), mask / count per level (updationOnPyrChange,
-  // ImageFunc.cpp:158) and the pose-independent per-pixel records
+  enqueue_stage_in(c, B);   // also initialises the B alignment states
+  // mask / count per level (updationOnPyrChange, ImageFunc.cpp:158) and the pose-independent per-pixel records. (Folding the
+  // staging into the count launch — its tile blocks then read their keyframe slot from the pinned record, one PCIe round trip
+  // per block — was measured in r02: the count launch went from 10 to 29 us at 32 keyframes; the separate 8 us launch stays.)
   const int need = mode == ELLC_MODE_ICA ? (c->use_fused ? 4 : 1) : (c->fast ? 8 : 2);
-  ellc_status s = run_prep_levels(c, nu, need, 0, c->L - 1, c->stream, B);
+  ellc_status s = run_prep(c, nu, need);
   if (s != ELLC_OK) return s;
   if (need == 4) enqueue_ica_hinv(c, nu);
   s = enqueue_schedule(c, B, mode, save_weights);

@@ -23,17 +23,6 @@ struct PrepArgs {
                                // (FCA in tolerance mode, cfg.arith = ELLC_ARITH_FAST)
   int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
   int tile0, level0;           // this launch covers tiles tile0 + blockIdx.x (count / scatter), levels level0 + blockIdx.x (scan)
-  // The count launch of an alignment schedule also does the staging (what stage_in does alone for the single-step entry
-  // points): blocks past the tiles (blockIdx.y == 0) copy the staged batch description from pinned host memory and
-  // initialise the alignment states; the count blocks themselves read their keyframe slot from the pinned record
-  // (count_slots), since the device copy is only complete when this launch ends. One kernel boundary less per batch.
-  const int* count_slots;      // what prep_count reads its slots from (the pinned record when staging is folded in, else `slots`)
-  int count_tiles;             // tiles of this launch (blocks with blockIdx.x >= count_tiles are staging blocks)
-  int* stage_dst;              // null: no staging in this launch
-  const int* stage_src;
-  int stage_n, stage_copy_blocks, stage_B, stage_max_batch;
-  AlignState* stage_state;
-  unsigned* stage_sync_words;
 };
 
 __device__ __forceinline__ int prep_level_of(const PrepArgs& a, int tile, int& local) {
@@ -67,27 +56,10 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
   return v;
 }
 
-__device__ inline void init_state_record(AlignState& st, const float* init_pose, int b);   // ellc_kernels_gn.hpp
-
 __global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
-  if ((int)blockIdx.x >= a.count_tiles) {   // staging blocks (see PrepArgs)
-    if (blockIdx.y != 0 || !a.stage_dst) return;
-    const int sb = (int)blockIdx.x - a.count_tiles;
-    if (sb < a.stage_copy_blocks) {
-      const int i = sb * 256 + (int)threadIdx.x;
-      if (i < a.stage_n) a.stage_dst[i] = a.stage_src[i];
-      return;
-    }
-    const int b = (sb - a.stage_copy_blocks) * 256 + (int)threadIdx.x;
-    if (b < a.stage_B) {
-      init_state_record(a.stage_state[b], (const float*)(a.stage_src + 3 * a.stage_max_batch), b);
-      if (a.stage_sync_words) { a.stage_sync_words[(size_t)b * 64] = 0u; a.stage_sync_words[(size_t)b * 64 + 16] = 0u; }
-    }
-    return;
-  }
   int local;
   const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
-  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.count_slots[blockIdx.y]];
+  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
   const int n = a.geom[level].n;
   const int i0 = local * ELLC_TILE + threadIdx.x * 8;
   float d[8];
