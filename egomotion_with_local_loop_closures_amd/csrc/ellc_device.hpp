@@ -39,11 +39,11 @@ struct __attribute__((aligned(16))) FcaRec {
 
 // The same pixel as the tolerance-mode FCA pass reads it (cfg.arith = ELLC_ARITH_FAST): 16 bytes. Position and keyframe
 // intensity share one word (x: bits 0-11, y: bits 12-23, intensity: bits 24-31, hence width, height <= 4096 in this mode);
-// d = 1/Z in f32. The back-projection is recomputed per iteration (two multiplies each): the pass is then short enough
-// in instructions for the 16 bytes saved per pixel to matter.
+// p = (x - cx) / fx is stored (one conversion less per pixel and iteration; q comes from y with one fma), d = 1/Z in f32.
+// Z itself is not needed: the pass warps (p, q, 1) + t d, the point divided by Z (see fcaf_pixel).
 struct __attribute__((aligned(16))) FcaRecF {
   uint32_t xyI;
-  float Z, var, d;
+  float p, var, d;
 };
 
 // One valid keyframe pixel as the constant-weight (ICA) pixel pass reads it: 48 bytes. Everything here is independent

@@ -375,7 +375,8 @@ static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, h
   const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
   const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
   if (c->fast) {
-    hipLaunchKernelGGL((gn_fca_fused<false, true, true>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    if (fa.g.save_w) hipLaunchKernelGGL((gn_fca_fused<false, true, true, 1>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, true, true, 0>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
   } else if (c->pipe) {
     if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, true>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
     else hipLaunchKernelGGL((gn_fca_fused<false, true>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);

@@ -124,7 +124,8 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
   const float fx0 = floorf(x1), fy0 = floorf(y1);
   const float wx = x1 - fx0, wy = y1 - fy0;
   const float omx = 1.0f - wx, omy = 1.0f - wy;
-  const bool interior = (fx0 >= 1.0f) && (fx0 <= (float)(cols - 3)) && (fy0 >= 1.0f) && (fy0 <= (float)(rows - 3));   // false for NaN
+  // fx0 in [1, cols-3] and fy0 in [1, rows-3], false for NaN: a value equals its clamp (v_med3_f32) exactly when it is in range
+  const bool interior = (__builtin_amdgcn_fmed3f(fx0, 1.0f, (float)(cols - 3)) == fx0) & (__builtin_amdgcn_fmed3f(fy0, 1.0f, (float)(rows - 3)) == fy0);
   if (__builtin_amdgcn_ballot_w64(!interior) == 0ull) {
     // The 4x4 neighbourhood is fetched as one (byte-unaligned) 32-bit word per image row: columns x0-1 .. x0+2.
     const int x0 = (int)fx0, y0 = (int)fy0;
@@ -474,7 +475,7 @@ __device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K
 // sqrt sequences, and f32 products where the reference's pow() promotes to double. Per-pixel values agree with the
 // exact path to a few 1e-7 relative (tests/test_gpu_fast.py states the bounds); the final pose to well below the 1e-5 bar.
 // About 130 VALU instructions per pixel instead of 285, 16-byte records instead of 32.
-struct FcaInF { uint32_t xyI; float Z, var, d; };
+struct FcaInF { uint32_t xyI; float p, var, d; };   // FcaRecF: x | y << 12 | I << 24, p = (x - cx) / fx, variance, d = 1 / Z
 
 __device__ __forceinline__ FcaInF fcaf_load(const KfLevelDev& K, unsigned i) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -482,21 +483,23 @@ __device__ __forceinline__ FcaInF fcaf_load(const KfLevelDev& K, unsigned i) {
   FcaInF in;
   // (elements are copied to scalars first: __builtin_bit_cast applied to a vector element expression reads element 0)
   const uint32_t w1 = v.y, w2 = v.z, w3 = v.w;
-  in.xyI = v.x; in.Z = __builtin_bit_cast(float, w1); in.var = __builtin_bit_cast(float, w2); in.d = __builtin_bit_cast(float, w3);
+  in.xyI = v.x; in.p = __builtin_bit_cast(float, w1); in.var = __builtin_bit_cast(float, w2); in.d = __builtin_bit_cast(float, w3);
   return in;
 }
 
-template <bool DEBUG, class PF = NoPrefetch>
+// SAVEW: 1 = store the weights (saved-weights call), 0 = do not, -1 = a.save_w decides at run time
+template <bool DEBUG, class PF = NoPrefetch, int SAVEW = -1>
 __device__ __forceinline__ FcaPix fcaf_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const float* S, unsigned i,
                                              const FcaInF& in, PF pf = PF()) {
-  const int x = (int)(in.xyI & 0xfffu), y = (int)((in.xyI >> 12) & 0xfffu);
+  const int y = (int)((in.xyI >> 12) & 0xfffu);
   const float Ikf = byte_f32<3>(in.xyI);
-  const float p = ((float)x - g.cx) * g.rfx, q = ((float)y - g.cy) * g.rfy;   // u / fx, v / fy
-  const float Z = in.Z;
-  const float X = p * Z, Y = q * Z;
-  const float px = __builtin_fmaf(S[0], X, __builtin_fmaf(S[1], Y, __builtin_fmaf(S[2], Z, S[3])));
-  const float py = __builtin_fmaf(S[4], X, __builtin_fmaf(S[5], Y, __builtin_fmaf(S[6], Z, S[7])));
-  const float pz = __builtin_fmaf(S[8], X, __builtin_fmaf(S[9], Y, __builtin_fmaf(S[10], Z, S[11])));
+  const float p = in.p, q = __builtin_fmaf((float)y, g.rfy, -(g.cy * g.rfy));   // u / fx, v / fy
+  const float d = in.d;
+  // the warped point divided by Z — (p, q, 1) + t d — projects to the same pixel, and the factors of Z cancel in the
+  // weight below (1 / (pz^2 d) = Z rz^2 with the true pz; here pz is pz / Z): no product with Z is needed
+  const float px = __builtin_fmaf(S[0], p, __builtin_fmaf(S[1], q, __builtin_fmaf(S[3], d, S[2])));
+  const float py = __builtin_fmaf(S[4], p, __builtin_fmaf(S[5], q, __builtin_fmaf(S[7], d, S[6])));
+  const float pz = __builtin_fmaf(S[8], p, __builtin_fmaf(S[9], q, __builtin_fmaf(S[11], d, S[10])));
   // no clamp of pz away from zero (ExternVariable.h:232): 1/0 = inf sends the point out of bounds, as the clamped value does
   const float rz = __builtin_amdgcn_rcpf(pz);
   const float wx = __builtin_fmaf(px * rz, g.fx, g.cx);
@@ -510,23 +513,25 @@ __device__ __forceinline__ FcaPix fcaf_pixel(const GnArgs& a, const KfLevelDev& 
   o.J[0] = -__builtin_fmaf(q, T, B);
   o.J[1] = __builtin_fmaf(p, T, A);
   o.J[2] = __builtin_fmaf(B, p, -(A * q));
-  o.J[3] = A * in.d;
-  o.J[4] = B * in.d;
-  o.J[5] = -(in.d * T);
+  o.J[3] = A * d;
+  o.J[4] = B * d;
+  o.J[5] = -(d * T);
   const bool oob = (t.I == -1.0f);
   const float res = t.I - Ikf;
-  // weight (:341-358): 1 / (pz^2 d) = Z rz^2;  w_p = 1 / D, sqrt(w_p) = rsq(D);  Huber: w_p below the knee, 1.5 sqrt(w_p) / |r| above
+  // weight (:341-358): w_p = 1 / D, sqrt(w_p) = rsq(D);  Huber: w_p below the knee (|r| sqrt(w_p) < 1.5), 1.5 sqrt(w_p) / |r|
+  // above it — the smaller of the two
   const float tx = S[3], ty = S[7], tz = S[11];
   const float n0 = __builtin_fmaf(tx, pz, -(tz * px)), n1 = __builtin_fmaf(ty, pz, -(tz * py));
-  const float drpdd = __builtin_fmaf(A, n0, B * n1) * (Z * (rz * rz));
+  const float drpdd = __builtin_fmaf(A, n0, B * n1) * (rz * rz);
   const float D = __builtin_fmaf(in.var * drpdd, drpdd, 16.0f);
   const float r = __builtin_amdgcn_rsqf(D);
-  const float ares = fabsf(res);
-  const float wgt = r * ((ares * r < 1.5f) ? r : 1.5f * __builtin_amdgcn_rcpf(ares));
-  o.residual = oob ? 0.0f : res;
+  const float wgt = r * fminf(r, 1.5f * __builtin_amdgcn_rcpf(fabsf(res)));
+  // out of bounds: weight 0 (the gradients, hence J, are 0 and the residual is finite: every sum gets 0)
+  o.residual = DEBUG ? (oob ? 0.0f : res) : res;
   o.wgt = oob ? 0.0f : wgt;
-  if (a.save_w) *(ELLC_GLOBAL float*)((ELLC_GLOBAL char*)K.wlast + i * 4u) = o.wgt;
+  if (SAVEW > 0 || (SAVEW < 0 && a.save_w)) *(ELLC_GLOBAL float*)((ELLC_GLOBAL char*)K.wlast + i * 4u) = o.wgt;
   if (DEBUG) {
+    const int x = (int)(in.xyI & 0xfffu);
     const size_t n = (size_t)g.n, pp = (size_t)y * g.cols + x;
     a.planes[0 * n + pp] = o.residual;
     a.planes[1 * n + pp] = o.wgt;
@@ -1151,7 +1156,7 @@ struct FusedArgs {
 // pending partial sums, block counts): the library is built with kernel-argument preloading, so they arrive in SGPRs with
 // the wave instead of through a scalar load from the argument buffer — one memory round trip less at the head of a
 // latency-bound kernel. Everything else stays in the by-value struct.
-template <bool DIVC, bool PIPE, bool FAST = false>
+template <bool DIVC, bool PIPE, bool FAST = false, int SAVEW = -1>   // SAVEW: see fcaf_pixel (tolerance mode only)
 __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignState* src_state, const float* prev_part, int prev_nblk,
                                                                    int nblk, int age_rounds, FusedArgs fa) {   // 4 waves per SIMD: at most 128 VGPRs
   const GnArgs& a = fa.g;
@@ -1212,7 +1217,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   FcaIn first;
   first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.X = 0.0f; first.Y = 0.0f; first.invZ = 1.0;
   FcaInF firstf;
-  firstf.xyI = 0; firstf.Z = 1.0f; firstf.var = 0.0f; firstf.d = 1.0f;
+  firstf.xyI = 0; firstf.p = 0.0f; firstf.var = 0.0f; firstf.d = 1.0f;
   FcaPre first_pre;
   if constexpr (FAST) {
     if (begin + t < end) firstf = fcaf_load(K, (unsigned)(begin + t));
@@ -1266,7 +1271,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
       auto step = [&](const FcaInF& in, FcaInF& fill) {
         const int i1 = i + stride;
         auto prefetch = [&]() { fill = fcaf_load(K, (unsigned)min(i1, end - 1)); };
-        fca_accumulate_pixel(acc, fcaf_pixel<false>(a, K, g, cur, S, (unsigned)i, in, prefetch));
+        fca_accumulate_pixel(acc, fcaf_pixel<false, decltype(prefetch), SAVEW>(a, K, g, cur, S, (unsigned)i, in, prefetch));
         i += stride;
       };
       for (;;) {

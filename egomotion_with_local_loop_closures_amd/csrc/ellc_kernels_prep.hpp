@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
     if (need & 8) {   // FCA in tolerance mode: one 16-byte record per pixel (FcaRecF)
       const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)img[(unsigned)(y * sw + x)] << 24);
       const float d = __builtin_amdgcn_rcpf(Z);
-      crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, d)};
+      const float pn = ((float)x - g.cx) * g.rfx;   // u / fx (fcaf_pixel forms v / fy from y)
+      crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, d)};
     }
     if (need & 2) {   // FCA reads one 32-byte record per pixel (FcaRec), stored as two 16-byte words
       const float X = (((float)x - cx) * Z) / fx;
