@@ -129,7 +129,7 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
   if (__builtin_amdgcn_ballot_w64(!interior) == 0ull) {
     // The 4x4 neighbourhood is fetched as one (byte-unaligned) 32-bit word per image row: columns x0-1 .. x0+2.
     const int x0 = (int)fx0, y0 = (int)fy0;
-    const unsigned ob = (unsigned)(y0 * sw + x0) - 1u, oc = ob + (unsigned)sw;
+    const unsigned ob = __umul24((unsigned)y0, (unsigned)sw) + (unsigned)x0 - 1u, oc = ob + (unsigned)sw;   // y0 >= 1, sw < 2^24: full-rate v_mad_u32_u24
     const uint32_t wb = load_u32_unaligned(img, ob), wc = load_u32_unaligned(img, oc);
     uint32_t wa = 0, wd = 0;
     if (WANT_GRAD) { wa = load_u32_unaligned(img, ob - (unsigned)sw); wd = load_u32_unaligned(img, oc + (unsigned)sw); }
@@ -147,11 +147,11 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
         const float g00 = Pbc - Pba, g01 = Pbd - Pbb, g10 = Pcc - Pca, g11 = Pcd - Pcb;   // twice the central differences
         float t2 = __builtin_fmaf(wx, g01 - g00, g00);
         float b2 = __builtin_fmaf(wx, g11 - g10, g10);
-        o.gx = 0.5f * __builtin_fmaf(wy, b2 - t2, t2);
+        o.gx = __builtin_fmaf(wy, b2 - t2, t2);   // FAST: TWICE the gradient (the caller folds the 0.5 into fx, fy)
         const float h00 = Pcb - Pab, h01 = Pcc - Pac, h10 = Pdb - Pbb, h11 = Pdc - Pbc;
         t2 = __builtin_fmaf(wx, h01 - h00, h00);
         b2 = __builtin_fmaf(wx, h11 - h10, h10);
-        o.gy = 0.5f * __builtin_fmaf(wy, b2 - t2, t2);
+        o.gy = __builtin_fmaf(wy, b2 - t2, t2);
       } else {
         o.gx = 0.0f; o.gy = 0.0f;
       }
@@ -199,7 +199,7 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
   const int xb = clampi(x0, 0, cols - 1), xc = clampi(x0 + 1, 0, cols - 1);
   const int yb = clampi(y0, 0, rows - 1), yc = clampi(y0 + 1, 0, rows - 1);
   // uniform base pointer + unsigned 32-bit lane offsets (SGPR-base global loads, no 64-bit lane arithmetic)
-  const unsigned rb = (unsigned)(yb * sw), rc = (unsigned)(yc * sw);
+  const unsigned rb = __umul24((unsigned)yb, (unsigned)sw), rc = __umul24((unsigned)yc, (unsigned)sw);   // rows are clamped to >= 0
   const float Pbb = (float)img[rb + (unsigned)xb], Pbc = (float)img[rb + (unsigned)xc];
   const float Pcb = (float)img[rc + (unsigned)xb], Pcc = (float)img[rc + (unsigned)xc];
   {
@@ -211,7 +211,7 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
   if (WANT_GRAD) {
     const int xa = clampi(x0 - 1, 0, cols - 1), xd = clampi(x0 + 2, 0, cols - 1);
     const int ya = clampi(y0 - 1, 0, rows - 1), yd = clampi(y0 + 2, 0, rows - 1);
-    const unsigned ra = (unsigned)(ya * sw), rd = (unsigned)(yd * sw);
+    const unsigned ra = __umul24((unsigned)ya, (unsigned)sw), rd = __umul24((unsigned)yd, (unsigned)sw);
     const float Pba = (float)img[rb + (unsigned)xa], Pbd = (float)img[rb + (unsigned)xd];
     const float Pca = (float)img[rc + (unsigned)xa], Pcd = (float)img[rc + (unsigned)xd];
     const float Pab = (float)img[ra + (unsigned)xb], Pac = (float)img[ra + (unsigned)xc];
@@ -233,6 +233,7 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
     top = (omx * h00) + (wx * h01);
     btm = (omx * h10) + (wx * h11);
     o.gy = (omy * top) + (wy * btm);
+    if (FAST) { o.gx *= 2.0f; o.gy *= 2.0f; }   // as the interior branch of this mode returns them
   } else {
     o.gx = 0.0f; o.gy = 0.0f;
   }
@@ -508,14 +509,16 @@ __device__ __forceinline__ FcaPix fcaf_pixel(const GnArgs& a, const KfLevelDev& 
   FcaPix o;
   // 1x6 row (:296-320) with A = fx gradx, B = fy grady, T = A p + B q:
   //   J = [-(q T + B), p T + A, B p - A q, A d, B d, -d T]
-  const float A = g.fx * t.gx, B = g.fy * t.gy;
+  // (tap_point returns twice the gradients in this mode.) Entries 0 and 5 are carried with the opposite sign — the
+  // accumulators then hold sign-flipped sums, exactly (rounding is symmetric), and fca_acc_unpack<true> flips them back
+  const float A = (0.5f * g.fx) * t.gx, B = (0.5f * g.fy) * t.gy;
   const float T = __builtin_fmaf(A, p, B * q);
-  o.J[0] = -__builtin_fmaf(q, T, B);
+  o.J[0] = __builtin_fmaf(q, T, B);   // -J[0]
   o.J[1] = __builtin_fmaf(p, T, A);
   o.J[2] = __builtin_fmaf(B, p, -(A * q));
   o.J[3] = A * d;
   o.J[4] = B * d;
-  o.J[5] = -(d * T);
+  o.J[5] = d * T;                     // -J[5]
   const bool oob = (t.I == -1.0f);
   const float res = t.I - Ikf;
   // weight (:341-358): w_p = 1 / D, sqrt(w_p) = rsq(D);  Huber: w_p below the knee (|r| sqrt(w_p) < 1.5), 1.5 sqrt(w_p) / |r|
@@ -538,7 +541,7 @@ __device__ __forceinline__ FcaPix fcaf_pixel(const GnArgs& a, const KfLevelDev& 
     a.planes[2 * n + pp] = oob ? -1.0f : wx;
     a.planes[3 * n + pp] = oob ? -1.0f : wy;
 #pragma unroll
-    for (int k = 0; k < 6; k++) a.planes[(4 + k) * n + pp] = o.J[k];
+    for (int k = 0; k < 6; k++) a.planes[(4 + k) * n + pp] = (k == 0 || k == 5) ? -o.J[k] : o.J[k];
   }
   return o;
 }
@@ -581,6 +584,8 @@ __device__ __forceinline__ void fca_accumulate_pixel(FcaAcc& A, const FcaPix& p)
   A.b[2] = fma2(J45, rw, A.b[2]);
 }
 // the 27 sums in the order of the partial record: upper triangle by rows, then b
+// FLIP: the pixel pass carried J[0] and J[5] with the opposite sign (fcaf_pixel): H(0,1..4), H(1..4,5), b[0], b[5] change sign
+template <bool FLIP = false>
 __device__ __forceinline__ void fca_acc_unpack(const FcaAcc& A, float (&o)[27]) {
   o[0] = A.h[0].x; o[1] = A.h[0].y; o[2] = A.h[1].x; o[3] = A.h[1].y; o[4] = A.h[2].x; o[5] = A.h[2].y;
   o[6] = A.h[3].y; o[7] = A.h[4].x; o[8] = A.h[4].y; o[9] = A.h[5].x; o[10] = A.h[5].y;
@@ -589,6 +594,11 @@ __device__ __forceinline__ void fca_acc_unpack(const FcaAcc& A, float (&o)[27]) 
   o[18] = A.h[10].x; o[19] = A.h[10].y;
   o[20] = A.h[11].y;
   o[21] = A.b[0].x; o[22] = A.b[0].y; o[23] = A.b[1].x; o[24] = A.b[1].y; o[25] = A.b[2].x; o[26] = A.b[2].y;
+  if (FLIP) {
+    o[1] = -o[1]; o[2] = -o[2]; o[3] = -o[3]; o[4] = -o[4];
+    o[10] = -o[10]; o[14] = -o[14]; o[17] = -o[17]; o[19] = -o[19];
+    o[21] = -o[21]; o[26] = -o[26];
+  }
 }
 
 // FCA accumulate without the folded solve (single-step API, debug planes, ELLC_NO_FUSE): grid (nblk, B). Each block
@@ -618,7 +628,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
     fca_accumulate_pixel(acc, p);
   }
   float sums[27];
-  fca_acc_unpack(acc, sums);
+  fca_acc_unpack<FAST>(acc, sums);
   block_reduce_store<27>(sums, a.partials + ((size_t)b * ELLC_NBLK_MAX + blockIdx.x) * ELLC_PART_STRIDE);
 }
 
@@ -1313,7 +1323,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   ELLC_BSTAMP(2);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
   float sums[27];
-  fca_acc_unpack(acc, sums);
+  fca_acc_unpack<FAST>(acc, sums);
   block_reduce_store<27>(sums, out);
   ELLC_STAMP(8);
   ELLC_BSTAMP(3);

@@ -162,7 +162,7 @@ __device__ __forceinline__ void run_pixel_pass(const GnArgs& ga, const KfLevelDe
         }
       }
     }
-    fca_acc_unpack(acc, sums);
+    fca_acc_unpack<FAST>(acc, sums);
   }
 }
 
