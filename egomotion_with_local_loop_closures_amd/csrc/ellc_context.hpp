@@ -82,12 +82,16 @@ struct ellc_ctx {
     std::vector<int> kf_slots;                      // unique keyframe slots of the batch in flight
     int B = 0;                                      // its size
     bool joined = true;                             // `stream` (the context's main stream) already waits for `done`
+    int mode = 0, save_weights = 0;                 // of the batch in flight (a state-driven schedule may need its continuation)
+    bool adaptive = false;                          // the batch runs the state-driven schedule (gn_fca_adaptive)
+    bool resolved = true;                           // `done` has been waited for and the continuation, if one was needed, has run
   } batch_set[SETS];
   hipEvent_t ev_main = nullptr;                     // marks the main stream behind the last non-batch call
   bool main_dirty = false;                          // a non-batch entry point ran since ev_main was recorded
   int main_mark = 0;
   int inflight[SETS] = {0};
   int n_inflight = 0;
+  int cur_set = 0;                                  // the batch set the per-batch pointers below refer to (select_batch_set)
   float* partials_d = nullptr;
   ellc::RunSync* sync_d = nullptr;
   float* planes_d = nullptr;
@@ -101,6 +105,9 @@ struct ellc_ctx {
   bool age_balance = true;      // age-balanced split of full-round grids (FusedArgs::age_rounds); ELLC_NO_AGE_BALANCE=1 disables
   double age_weight[5][4] = {{1, 1, 1, 1}, {1, 1, 1, 1}, {1.15, 0.85, 1, 1}, {1.2, 1.0, 0.8, 1}, {1.35, 1.15, 0.9, 0.6}};   // [rounds][round], ELLC_AGE_W (r01 sweep at 640x480, batch 32)
   double age_min_px_per_thread = 5.0;   // ELLC_AGE_MIN_PX
+  bool use_adaptive = true;             // early-exit FCA schedules are state-driven (gn_fca_adaptive); ELLC_NO_ADAPTIVE=1 (diag) turns it off
+  int adaptive_max_batch = 2;           //   for batches of at most this many alignments; ELLC_ADAPTIVE_MAX_BATCH (diag)
+  int adaptive_first_override = 0;      //   launches of the first graph; ELLC_ADAPTIVE_FIRST (diag)
   bool pipe = true;             // software-pipelined record loads in the fused FCA kernel (ELLC_PIPE=0 disables; r01: -10 % per launch at
                                 // 1280x960 dense where the records stream from HBM, neutral at 640x480 semi-dense)
   bool use_fused = true;        // the production schedules (ELLC_NO_FUSE=1, diagnostic builds: one accumulate + one solve launch per iteration)

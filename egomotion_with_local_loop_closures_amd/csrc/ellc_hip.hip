@@ -17,6 +17,8 @@
 
 using namespace ellc;
 
+static ellc_status resolve_batch(ellc_ctx* c, int set);   // waits for a batch in flight (and runs its continuation), defined with ellc_align_fetch
+
 namespace ellc {
 
 ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg) {
@@ -39,6 +41,12 @@ ellc_status enter(ellc_ctx* c, bool join) {
   if (join) {   // everything but the batch entry points runs on the main stream, after the batches in flight
     for (int i = 0; i < c->n_inflight; i++) {
       ellc_ctx::BatchSet& bs = c->batch_set[c->inflight[i]];
+      if (bs.adaptive && !bs.resolved) {
+        // a state-driven batch may need a continuation that only the host can start, and this call may change what it
+        // reads (an upload into one of its slots, a depth stage): the host finishes the batch first
+        const ellc_status s = ::resolve_batch(c, c->inflight[i]);
+        if (s != ELLC_OK) return s;
+      }
       if (bs.joined) continue;   // set 0 runs on the main stream itself
       ELLC_HIP(c, hipStreamWaitEvent(c->stream, bs.done, 0));
       bs.joined = true;
@@ -299,6 +307,7 @@ static void launch_solve(ellc_ctx* c, int level, int B, int nblk, int mode, int 
 // points the staging / result / work-buffer members at batch set p
 static void select_batch_set(ellc_ctx* c, int p) {
   const int MB = c->cfg.max_batch;
+  c->cur_set = p;
   ellc_ctx::BatchSet& bs = c->batch_set[p];
   c->kf_slot_h = bs.stage_h;
   c->fr_slot_h = bs.stage_h + MB;
@@ -346,7 +355,7 @@ static void enqueue_stage_in(ellc_ctx* c, int B) {
   const int n = 9 * c->cfg.max_batch;
   const int copy_blocks = (n + 255) / 256;
   hipLaunchKernelGGL(stage_in, dim3(copy_blocks + (B + 255) / 256), dim3(256), 0, c->stream, c->kf_slot_d, c->stage_dev_alias, n, copy_blocks,
-                     c->state_d, B, c->cfg.max_batch, (unsigned*)c->sync_d);
+                     c->state_d, B, c->cfg.max_batch, (unsigned*)c->sync_d, c->L - 1);
 }
 
 // fills the age-balanced split of a launch (FusedArgs::age_rounds): on when the grid is 2..4 full rounds of one block per CU-slot
@@ -386,9 +395,87 @@ static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, h
   }
 }
 
-static void launch_finish(ellc_ctx* c, int B, const FusedArgs& fa) {
-  if (c->fast) hipLaunchKernelGGL(gn_fused_finish<true>, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
-  else hipLaunchKernelGGL(gn_fused_finish<false>, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
+static void launch_finish(ellc_ctx* c, int B, const FusedArgs& fa, bool adaptive = false) {
+  if (adaptive) {
+    if (c->fast) hipLaunchKernelGGL((gn_fused_finish<true, true>), dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
+    else hipLaunchKernelGGL((gn_fused_finish<false, true>), dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
+  } else {
+    if (c->fast) hipLaunchKernelGGL(gn_fused_finish<true>, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
+    else hipLaunchKernelGGL(gn_fused_finish<false>, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
+  }
+}
+
+// saved weights of every level, after the finish kernel (gn_add_saved_weights_all reads the record it wrote)
+static void launch_add_saved_weights(ellc_ctx* c, int B) {
+  hipLaunchKernelGGL(gn_add_saved_weights_all, dim3(32, B, c->L), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, c->state_d,
+                     c->cfg.max_keyframes, c->fast ? 1 : 0);
+}
+
+// The FCA schedule is state-driven (gn_fca_adaptive) for one or two alignments in contexts with early exit on — the tracking
+// call; level-bound launches otherwise. Measured (r02, 640x480, fast, ms per batch, state-driven / level-bound,
+// tools/dbg/early_exit_modes.py): B = 1 0.146 / 0.181, B = 2 0.158 / 0.195, B = 4 0.215 / 0.215, B = 8 0.237 / 0.241,
+// B = 32 0.371 / 0.334 — a batch ends with its slowest alignment, every launch carries the finest level's grid, and the
+// age-balanced split of the level-bound launches is lost.
+static bool schedule_is_adaptive(const ellc_ctx* c, int mode, int B) {
+  return c->use_fused && c->use_adaptive && c->cfg.early_exit && mode == ELLC_MODE_FCA && B <= c->adaptive_max_batch;
+}
+static int schedule_total_iters(const ellc_ctx* c) {
+  int total = 0;
+  for (int l = 0; l < c->L; l++) total += c->cfg.max_iter[l];
+  return total;
+}
+// launches of the first graph: five eighths of the iteration caps (20 of {4,7,9,12}; tracked frames run 13-17 iterations); the
+// continuation holds the rest
+static int adaptive_first_launches(const ellc_ctx* c, int B) {
+  const int total = schedule_total_iters(c);
+  int first = (total * 5 + 7) / 8;
+#ifdef ELLC_DIAG
+  if (c->adaptive_first_override > 0) first = c->adaptive_first_override;   // ELLC_ADAPTIVE_FIRST
+#endif
+  return std::min(total, std::max(c->L, first));
+}
+
+// State-driven FCA schedule: `launches` launches of gn_fca_adaptive and the finish kernel. continuation: the records were
+// left by an earlier graph of the same batch (buffer 0, nothing pending), otherwise by stage_in.
+static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weights, int launches) {
+  FusedArgs fa;
+  fa.seq = 0;
+  fa.prev_level = -1;
+  fa.prev_nblk = 0;
+  fa.early_exit = c->cfg.early_exit;
+  fa.stride_state = c->cfg.max_batch;
+  fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+  fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);
+  fa.res = c->result_dev_alias;
+  fa.ica = 0;
+  fa.xcd_map = (B % 8 == 0) ? 1 : 0;
+  fa.age_rounds = 0;
+  for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
+  int grid_x = 1;
+  for (int l = 0; l < ELLC_MAX_LEVELS; l++) {
+    fa.nblk_lv[l] = l < c->L ? choose_nblk(c, l, B) : 1;
+    fa.max_it[l] = l < c->L ? c->cfg.max_iter[l] : 0;
+    grid_x = std::max(grid_x, fa.nblk_lv[l]);
+  }
+  fa.nblk_grid = grid_x;
+  const dim3 grd(grid_x, B), blk(ELLC_GN_THREADS);
+  for (int i = 0; i < launches; i++) {
+    const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
+    const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
+    if (c->fast) {
+      if (save_weights) hipLaunchKernelGGL((gn_fca_adaptive<false, true, 1>), grd, blk, 0, c->stream, src_state, prev_part, grid_x, fa);
+      else hipLaunchKernelGGL((gn_fca_adaptive<false, true, 0>), grd, blk, 0, c->stream, src_state, prev_part, grid_x, fa);
+    } else if (c->geom_h[0].divc_ok) {
+      hipLaunchKernelGGL((gn_fca_adaptive<true, false, -1>), grd, blk, 0, c->stream, src_state, prev_part, grid_x, fa);
+    } else {
+      hipLaunchKernelGGL((gn_fca_adaptive<false, false, -1>), grd, blk, 0, c->stream, src_state, prev_part, grid_x, fa);
+    }
+    fa.seq++;
+  }
+  launch_finish(c, B, fa, true);
+  if (save_weights) launch_add_saved_weights(c, B);
+  ELLC_HIP(c, hipGetLastError());
+  return ELLC_OK;
 }
 
 // FCA schedule: the solve of iteration n is folded into the prologue of launch n+1 (gn_fca_fused): one launch per
@@ -419,10 +506,9 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
       fa.prev_nblk = fa.g.nblk;
       fa.seq++;
     }
-    if (save_weights)
-      hipLaunchKernelGGL(gn_add_saved_weights, dim3(64, B), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, level, c->cfg.max_keyframes, c->fast ? 1 : 0);
   }
   launch_finish(c, B, fa);
+  if (save_weights) launch_add_saved_weights(c, B);
   ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
 }
@@ -561,6 +647,7 @@ static ellc_status enqueue_schedule(ellc_ctx* c, int B, int mode, int save_weigh
 #ifdef ELLC_DIAG
   if (c->use_fused && c->use_run) return enqueue_schedule_runs(c, B, mode, save_weights, c->plan_persist);
 #endif
+  if (schedule_is_adaptive(c, mode, B)) return enqueue_schedule_adaptive(c, B, save_weights, adaptive_first_launches(c, B));
   if (mode == ELLC_MODE_FCA && c->use_fused) return enqueue_schedule_fused(c, B, save_weights);
   if (mode == ELLC_MODE_ICA && c->use_fused) return enqueue_schedule_ica_fused(c, B);
   for (int level = c->L - 1; level >= 0; level--) {
@@ -809,6 +896,9 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     if (const char* ab = getenv("ELLC_NO_AGE_BALANCE")) c->age_balance = !(ab[0] == '1');
     if (const char* pp = getenv("ELLC_PIPE")) c->pipe = (pp[0] == '1');
     if (const char* am = getenv("ELLC_AGE_MIN_PX")) c->age_min_px_per_thread = atof(am);
+    if (getenv("ELLC_NO_ADAPTIVE")) c->use_adaptive = false;
+    if (const char* ab = getenv("ELLC_ADAPTIVE_MAX_BATCH")) c->adaptive_max_batch = atoi(ab);
+    if (const char* af = getenv("ELLC_ADAPTIVE_FIRST")) c->adaptive_first_override = atoi(af);
     if (const char* aw = getenv("ELLC_AGE_W")) {   // "R:w0,w1,..": weights for grids of R rounds
       int R = 0, pos = 0;
       if (sscanf(aw, "%d:%n", &R, &pos) == 1 && R >= 2 && R <= 4) {
@@ -1127,6 +1217,38 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
   return ELLC_OK;
 }
 
+// Enqueues the launch sequence of one batch on c->stream — replayed from a hipGraph captured on first use, keyed by
+// (B, unique keyframes, mode, save_weights, batch set, part). continuation: the rest of a state-driven schedule whose first
+// graph ended before every alignment had (enqueue_schedule_adaptive), for the batch set selected in the context.
+static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int save_weights, int set, bool continuation) {
+  auto body = [&]() -> ellc_status {
+    if (continuation) return enqueue_schedule_adaptive(c, B, save_weights, schedule_total_iters(c) - adaptive_first_launches(c, B));
+    return enqueue_align_body(c, B, nu, mode, save_weights);
+  };
+  if (!c->use_graph) return body();
+  const auto key = std::make_tuple(B, continuation ? 0 : nu, mode,
+                                   (save_weights ? 1 : 0) | (set << 1) | (c->plan_persist ? 16 : 0) | (c->use_run ? 32 : 0) | (continuation ? 64 : 0));
+  auto it = c->graphs.find(key);
+  if (it == c->graphs.end()) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    ELLC_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    const ellc_status s = body();
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (s != ELLC_OK || e != hipSuccess) {
+      if (graph) (void)hipGraphDestroy(graph);
+      if (s != ELLC_OK) return s;
+      return fail(c, ELLC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    }
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    it = c->graphs.emplace(key, exec).first;
+  }
+  ELLC_HIP(c, hipGraphLaunch(it->second, c->stream));
+  return ELLC_OK;
+}
+
 // swaps the stream every launch helper uses (c->stream) for the duration of one enqueue
 struct StreamScope {
   ellc_ctx* c;
@@ -1134,6 +1256,33 @@ struct StreamScope {
   StreamScope(ellc_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
   ~StreamScope() { c->stream = saved; }
 };
+
+// Waits for a batch in flight and, when it ran the state-driven schedule and one of its alignments had not ended when the
+// first graph did (result pad = 1, gn_fused_finish), replays the continuation graph on the batch's stream and waits again.
+static ellc_status resolve_batch(ellc_ctx* c, int set) {
+  ellc_ctx::BatchSet& bs = c->batch_set[set];
+  if (bs.resolved) return ELLC_OK;
+  bs.resolved = true;
+  hipError_t ev = hipEventSynchronize(bs.done);   // the last kernel wrote bs.result_h (pinned, zero-copy)
+  if (ev != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("the batch failed on the device: ") + hipGetErrorString(ev));
+  if (!bs.adaptive) return ELLC_OK;
+  bool unfinished = false;
+  for (int b = 0; b < bs.B; b++) unfinished = unfinished || (bs.result_h[b].pad == 1);
+  if (!unfinished) return ELLC_OK;
+  const int selected = c->cur_set;
+  select_batch_set(c, set);
+  ellc_status s = ELLC_OK;
+  {
+    StreamScope scope(c, set > 0 ? bs.stream : c->stream);
+    s = launch_align_graph(c, bs.B, 0, bs.mode, bs.save_weights, set, true);
+    if (s == ELLC_OK && hipEventRecord(bs.done, c->stream) != hipSuccess) s = fail(c, ELLC_ERR_HIP, "hipEventRecord failed");
+  }
+  select_batch_set(c, selected);
+  if (s != ELLC_OK) return s;
+  ev = hipEventSynchronize(bs.done);
+  if (ev != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("the batch failed on the device: ") + hipGetErrorString(ev));
+  return ELLC_OK;
+}
 
 // track: the batch takes the next free set, runs on that set's stream and joins the in-flight queue ellc_align_fetch
 // drains; untracked use (the timing hook, nothing in flight) runs set 0's buffers on the main stream.
@@ -1194,35 +1343,20 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
       bool shared = false;
       for (int u = 0; u < nu && !shared; u++)
         for (int v : other.kf_slots) shared = shared || (v == c->uniq_slot_h[u]);
-      if (shared) ELLC_HIP(c, hipStreamWaitEvent(run_stream, other.done, 0));
+      if (!shared) continue;
+      if (other.adaptive && !other.resolved) {
+        // a state-driven batch may still need its continuation, which only the host can start: finish it first (the host
+        // waits here; batches on disjoint keyframes never do)
+        s = resolve_batch(c, c->inflight[i]);
+        if (s != ELLC_OK) return s;
+      }
+      ELLC_HIP(c, hipStreamWaitEvent(run_stream, other.done, 0));
     }
   }
   {
     StreamScope scope(c, run_stream);
-    if (c->use_graph) {
-      const auto key = std::make_tuple(B, nu, mode, (save_weights ? 1 : 0) | (set << 1) | (c->plan_persist ? 16 : 0) | (c->use_run ? 32 : 0));
-      auto it = c->graphs.find(key);
-      if (it == c->graphs.end()) {
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        ELLC_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        s = enqueue_align_body(c, B, nu, mode, save_weights);
-        hipError_t e = hipStreamEndCapture(c->stream, &graph);
-        if (s != ELLC_OK || e != hipSuccess) {
-          if (graph) (void)hipGraphDestroy(graph);
-          if (s != ELLC_OK) return s;
-          return fail(c, ELLC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        }
-        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-        it = c->graphs.emplace(key, exec).first;
-      }
-      ELLC_HIP(c, hipGraphLaunch(it->second, c->stream));
-    } else {
-      s = enqueue_align_body(c, B, nu, mode, save_weights);
-      if (s != ELLC_OK) return s;
-    }
+    s = launch_align_graph(c, B, nu, mode, save_weights, set, false);
+    if (s != ELLC_OK) return s;
     if (track) ELLC_HIP(c, hipEventRecord(bs.done, c->stream));
   }
   if (save_weights && mode == ELLC_MODE_FCA)
@@ -1234,6 +1368,10 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
   if (track) {
     bs.kf_slots.assign(c->uniq_slot_h, c->uniq_slot_h + nu);
     bs.B = B;
+    bs.mode = mode;
+    bs.save_weights = save_weights ? 1 : 0;
+    bs.adaptive = schedule_is_adaptive(c, mode, B);
+    bs.resolved = false;
     bs.joined = (set == 0);
     bs.run_reserved = reserved;
     c->inflight[c->n_inflight++] = set;
@@ -1255,14 +1393,14 @@ ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters
   const int oldest = c->inflight[0];
   const ellc_ctx::BatchSet& bs = c->batch_set[oldest];   // the oldest batch
   if (B != bs.B) return fail(c, ELLC_ERR_BAD_ARG, "ellc_align_fetch: the oldest batch in flight has a different size");
-  const hipError_t ev = hipEventSynchronize(bs.done);   // its last kernel wrote bs.result_h (pinned, zero-copy)
+  const ellc_status rs = resolve_batch(c, oldest);   // waits; runs the continuation of a state-driven schedule if one is needed
   for (int i = 1; i < c->n_inflight; i++) c->inflight[i - 1] = c->inflight[i];   // the batch leaves the queue either way
   c->n_inflight--;
 #ifdef ELLC_DIAG
   run_release(c, bs.run_reserved);
 #endif
   c->batch_set[oldest].run_reserved = 0;
-  if (ev != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("ellc_align_fetch: the batch failed on the device: ") + hipGetErrorString(ev));
+  if (rs != ELLC_OK) return rs;
   for (int b = 0; b < B; b++)
     if (bs.result_h[b].pad != 0) {   // a run gave up waiting for its other blocks (bounded spin): clear the error words, report
       (void)hipMemsetAsync(bs.sync_d, 0, 256 * (size_t)c->cfg.max_batch, c->stream);
@@ -1377,7 +1515,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   enqueue_stage_in(c, 0);
   s = run_prep(c, nu, c->fast ? 8 : 2);
   if (s != ELLC_OK) return s;
-  hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B);
+  hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B, c->L - 1);
   GnArgs a = make_gn_args(c, level, B, 0, nullptr);
   const dim3 grd(a.nblk, B), blk(ELLC_GN_THREADS);
   if (c->use_fused) {

@@ -898,6 +898,43 @@ __device__ __forceinline__ double partial_group_sum(const float* __restrict__ pa
   return s;
 }
 
+// partial_group_sum in two steps, for a launch that learns the number of pending records from the state record: the loads of
+// the first 64 records (8 per thread, as above) are issued at once against an upper bound nload of the count, the sum is
+// formed once the count nblk is known (records past it are ignored; past 64 they are loaded then). Same order, same bits.
+__device__ __forceinline__ void partial_preload(const float* __restrict__ partials, int nload, float (&v)[8]) {
+  const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  g_f32 p = as_global(partials) + comp;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int k = grp + j * (ELLC_SOLVE_THREADS / 32);
+    v[j] = p[(unsigned)min(k, nload - 1) * ELLC_PART_STRIDE];
+  }
+}
+__device__ __forceinline__ double partial_group_sum_from(const float* __restrict__ partials, const float (&v0)[8], int nblk) {
+  const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  g_f32 p = as_global(partials) + comp;
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int k = grp + j * (ELLC_SOLVE_THREADS / 32);
+    s += (k < nblk) ? (double)v0[j] : 0.0;
+  }
+  for (int base = 8 * (ELLC_SOLVE_THREADS / 32); base < nblk; base += 8 * (ELLC_SOLVE_THREADS / 32)) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = base + grp + j * (ELLC_SOLVE_THREADS / 32);
+      v[j] = p[(unsigned)min(k, nblk - 1) * ELLC_PART_STRIDE];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = base + grp + j * (ELLC_SOLVE_THREADS / 32);
+      s += (k < nblk) ? (double)v[j] : 0.0;
+    }
+  }
+  return s;
+}
+
 // Second half of the solve: from the 27 combined sums in sh.sums to the new pose. S_cur / level_done_cur are the
 // current exp(pose) and level_done (state record or LDS copy). Ends with a block barrier.
 __device__ __forceinline__ void solve_finish(SolveShared& sh, int mode, int level, int early_exit, const AlignState& src,
@@ -1160,7 +1197,77 @@ struct FusedArgs {
   int xcd_map;          // 1: blocks are renumbered so that all blocks of an alignment run on one XCD (see gn_fca_fused)
   AlignResult* res;     // gn_fused_finish: host-visible result records (null: none)
   int ica;              // 1: constant-weight schedule (gn_ica_fused): the pending sums are b only, H^-1 comes from the keyframe slot
+  // state-driven schedule (gn_fca_adaptive): blocks and iteration caps per level, the grid's x extent
+  int nblk_lv[ELLC_MAX_LEVELS];
+  int max_it[ELLC_MAX_LEVELS];
+  int nblk_grid;
 };
+
+// The pixel pass of one block of a fused launch over its chunk [begin, end) of the compact list, thread t taking the
+// entries begin + t, begin + t + 256, ...; the thread's first record (and, in the exact mode, its pose-independent products)
+// was requested by the caller before the solve. newS: exp(pose) of this iteration (LDS). Leaves the thread's 27 sums.
+template <bool DIVC, bool PIPE, bool FAST, int SAVEW>
+__device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const float* newS, int begin,
+                                               int end, const FcaIn& first, const FcaInF& firstf, const FcaPre& first_pre, float (&sums)[27]) {
+  constexpr int stride = ELLC_GN_THREADS;
+  const int t = threadIdx.x;
+  float S[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) S[i] = newS[i];
+  FcaAcc acc;
+  fca_acc_zero(acc);
+  int i = begin + t;
+  // Software pipeline of both loops: the record of pixel i + 256 is requested while pixel i is processed (index clamped, so
+  // the load is unconditional), behind pixel i's tap loads, see tap_point. The two record slots alternate through an
+  // explicitly unrolled loop body: a register copy of a slot would have to wait for the load that fills it. (More records
+  // in flight were measured no faster, neither at 640x480 semi-dense, where the lists are cache resident, nor at 1280x960
+  // dense x 16, where they stream from HBM: the pixel phase is bound by VALU issue, not by the record loads.)
+  if constexpr (FAST) {
+    if (i < end) {
+      FcaInF r0 = firstf, r1 = firstf;
+      auto step = [&](const FcaInF& in, FcaInF& fill) {
+        const int i1 = i + stride;
+        auto prefetch = [&]() { fill = fcaf_load(K, (unsigned)min(i1, end - 1)); };
+        fca_accumulate_pixel(acc, fcaf_pixel<false, decltype(prefetch), SAVEW>(a, K, g, cur, S, (unsigned)i, in, prefetch));
+        i += stride;
+      };
+      for (;;) {
+        step(r0, r1);
+        if (i >= end) break;
+        step(r1, r0);
+        if (i >= end) break;
+      }
+    }
+  } else if (i < end) {
+    if (PIPE) {   // exact mode: one record ahead (two slots; a third costs registers this kernel does not have)
+      FcaIn r0 = first, r1 = first;
+      {
+        const int i1 = i + stride;
+        auto prefetch = [&]() { r1 = fca_load(K, (unsigned)min(i1, end - 1)); };
+        fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre, prefetch));
+        i += stride;
+      }
+      auto step = [&](const FcaIn& in, FcaIn& fill) {
+        const int i1 = i + stride;
+        auto prefetch = [&]() { fill = fca_load(K, (unsigned)min(i1, end - 1)); };
+        fca_accumulate_pixel(acc, fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, in, prefetch));
+        i += stride;
+      };
+      while (i < end) {
+        step(r1, r0);
+        if (i >= end) break;
+        step(r0, r1);
+      }
+    } else {
+      fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre));
+      for (i += stride; i < end; i += stride) {
+        const FcaPix q = fca_pixel<false, DIVC>(a, K, g, cur, S, (unsigned)i);
+        fca_accumulate_pixel(acc, q);
+      }
+    }
+  }
+  fca_acc_unpack<FAST>(acc, sums);
+}
 
 // The leading scalar parameters repeat what the prologue's first loads need (addresses of the state record and of the
 // pending partial sums, block counts): the library is built with kernel-argument preloading, so they arrive in SGPRs with
@@ -1221,7 +1328,6 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
     begin = sub * chunk;
     end = min(V, begin + chunk);
   }
-  constexpr int stride = ELLC_GN_THREADS;
   g_u8 cur = as_global(F.img);
   // this thread's first compact pixel, requested before the solve (exact mode: together with its pose-independent products)
   FcaIn first;
@@ -1264,69 +1370,139 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
     }
   }
   if (skip) return;
-  float S[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
-  FcaAcc acc;
-  fca_acc_zero(acc);
-  int i = begin + t;
-  // Software pipeline of both loops: the record of pixel i + 256 is requested while pixel i is processed (index clamped, so
-  // the load is unconditional), behind pixel i's tap loads, see tap_point. The two record slots alternate through an
-  // explicitly unrolled loop body: a register copy of a slot would have to wait for the load that fills it. (More records
-  // in flight were measured no faster, neither at 640x480 semi-dense, where the lists are cache resident, nor at 1280x960
-  // dense x 16, where they stream from HBM: the pixel phase is bound by VALU issue, not by the record loads.)
-  if constexpr (FAST) {
-    if (i < end) {
-      FcaInF r0 = firstf, r1 = firstf;
-      auto step = [&](const FcaInF& in, FcaInF& fill) {
-        const int i1 = i + stride;
-        auto prefetch = [&]() { fill = fcaf_load(K, (unsigned)min(i1, end - 1)); };
-        fca_accumulate_pixel(acc, fcaf_pixel<false, decltype(prefetch), SAVEW>(a, K, g, cur, S, (unsigned)i, in, prefetch));
-        i += stride;
-      };
-      for (;;) {
-        step(r0, r1);
-        if (i >= end) break;
-        step(r1, r0);
-        if (i >= end) break;
-      }
-    }
-  } else if (i < end) {
-    if (PIPE) {   // exact mode: one record ahead (two slots; a third costs registers this kernel does not have)
-      FcaIn r0 = first, r1 = first;
-      {
-        const int i1 = i + stride;
-        auto prefetch = [&]() { r1 = fca_load(K, (unsigned)min(i1, end - 1)); };
-        fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre, prefetch));
-        i += stride;
-      }
-      auto step = [&](const FcaIn& in, FcaIn& fill) {
-        const int i1 = i + stride;
-        auto prefetch = [&]() { fill = fca_load(K, (unsigned)min(i1, end - 1)); };
-        fca_accumulate_pixel(acc, fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, in, prefetch));
-        i += stride;
-      };
-      while (i < end) {
-        step(r1, r0);
-        if (i >= end) break;
-        step(r0, r1);
-      }
-    } else {
-      fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre));
-      for (i += stride; i < end; i += stride) {
-        const FcaPix q = fca_pixel<false, DIVC>(a, K, g, cur, S, (unsigned)i);
-        fca_accumulate_pixel(acc, q);
-      }
-    }
-  }
+  float sums[27];
+  fca_chunk_pass<DIVC, PIPE, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
   ELLC_STAMP(7);
   ELLC_BSTAMP(2);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
-  float sums[27];
-  fca_acc_unpack<FAST>(acc, sums);
   block_reduce_store<27>(sums, out);
   ELLC_STAMP(8);
   ELLC_BSTAMP(3);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// State-driven form of the fused FCA schedule, for contexts with the reference's early exit on (ImageFunc.cpp:251-252). A
+// launch of gn_fca_fused is bound to a level when the schedule is captured: with early exit most of the 32 launches find
+// their level already ended and return at once, but each still costs a dependent launch (about 4.5 us; 17 of 32 for a
+// tracked frame). Here the LEVEL comes from the state record: launch n solves the pending sums of the record's level,
+// decides — level ended by weightedPose < 1 or by its iteration cap — whether the pixel pass that follows belongs to the same
+// level or the next finer one, and runs it; once the last level has ended the remaining launches only carry the record
+// forward. A captured graph is therefore as long as alignments usually need, not as long as the caps allow; the host looks
+// at the exported records and, if an alignment has not ended, replays a continuation graph (ellc_align_fetch). Per
+// alignment the sequence of pixel passes and solves — and so every bit of the result — is that of the level-bound schedule.
+//   The grid is (max over levels of the level's block count, B); a block stays if the record's level or the next finer one
+// needs it (the blocks of the finer level take part in the solve: only its result says whether they are needed). The
+// pending partial sums are requested before the level is known (partial_preload against the grid's block count); the level's
+// table entries start with the state record's arrival and are read again only at a level change.
+// (exact mode: three waves per SIMD — with the level change in the kernel the exact pixel loop needs a few registers more than
+// the 128 that four waves leave, and spills cost more than the fourth wave gives)
+template <bool DIVC, bool FAST, int SAVEW>
+__global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive(const AlignState* src_state, const float* prev_part, int nblk_grid,
+                                                                      FusedArgs fa) {
+  const GnArgs& a = fa.g;
+  int b = blockIdx.y, sub = blockIdx.x;
+  if (fa.xcd_map) {   // see gn_fca_fused
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int w = lin >> 3, bl = w / nblk_grid;
+    sub = w - bl * nblk_grid;
+    b = bl * 8 + (lin & 7);
+  }
+  const AlignState& src = src_state[b];
+  AlignState* dst = a.state + (size_t)((fa.seq + 1) & 1) * fa.stride_state + b;
+  __shared__ SolveShared sh;
+  const int t = threadIdx.x;
+  const bool writer = (sub == 0);
+  const float* pend = prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+  float pv[8];
+  partial_preload(pend, min(nblk_grid, 8 * (ELLC_SOLVE_THREADS / 32)), pv);
+  const int slot = a.kf_slot[b], frs = a.fr_slot[b];
+  const int lvl = src.cur_level;
+  const int pending = src.pending;
+  if (lvl < 0) {   // the schedule of this alignment has ended: the record moves to the other buffer unchanged
+    if (writer) {
+      if (t < 6) dst->pose[t] = src.pose[t];
+      if (t < 12) dst->S[t] = src.S[t];
+      if (t < ELLC_MAX_LEVELS) dst->iters[t] = src.iters[t];
+      if (t == 0) { dst->weighted = src.weighted; dst->level_done = src.level_done; dst->pending = 0; dst->cur_level = -1; dst->it_in_level = 0; }
+    }
+    return;
+  }
+  const int nb_l = fa.nblk_lv[lvl];
+  if (sub >= max(nb_l, lvl > 0 ? fa.nblk_lv[lvl - 1] : 0)) return;   // needed neither at this level nor at the next (block 0 always is)
+  // speculatively the tables of the record's level (the pixel pass stays there unless the solve ends the level)
+  LevelGeom g = a.geom[lvl];
+  KfLevelDev K = a.kf_tab[lvl * a.max_kf + slot];
+  const FrLevelDev* F = &a.fr_tab[lvl * a.max_fr + frs];
+  int V = *as_global(K.count);
+  const double group_sum = partial_group_sum_from(pend, pv, nb_l);
+  int begin, end;
+  {
+    const int chunk = (V + nb_l - 1) / nb_l;
+    begin = sub * chunk;
+    end = min(V, begin + chunk);
+  }
+  // this thread's first record (exact mode: and its pose-independent products), requested before the solve
+  FcaIn first;
+  first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.X = 0.0f; first.Y = 0.0f; first.invZ = 1.0;
+  FcaInF firstf;
+  firstf.xyI = 0; firstf.p = 0.0f; firstf.var = 0.0f; firstf.d = 1.0f;
+  FcaPre first_pre;
+  if constexpr (FAST) {
+    if (sub < nb_l && begin + t < end) firstf = fcaf_load(K, (unsigned)(begin + t));
+  } else {
+    if (sub < nb_l && begin + t < end) first = fca_load(K, (unsigned)(begin + t));
+    first_pre = fca_prepare<DIVC>(g, first);
+    asm volatile("" ::"v"(first_pre.c_t0), "v"(first_pre.c_b1), "v"(first_pre.d), "v"(first_pre.fxz), "v"(first_pre.fyz),
+                 "v"(first_pre.nvz), "v"(first_pre.nuz));   // pinned above the solve, see gn_fca_fused
+  }
+  if (pending) {
+    solve_step<FAST>(sh, group_sum, 0, lvl, fa.early_exit, src, nullptr);
+  } else {
+    if (t < 6) sh.newpose[t] = src.pose[t];
+    if (t < 12) sh.newS[t] = src.S[t];
+    if (t == 0) { sh.weighted = src.weighted; sh.level_done = src.level_done; }
+    __syncthreads();
+  }
+  const int it = src.it_in_level + (pending ? 1 : 0);
+  const bool over = pending && (sh.level_done == lvl || it >= fa.max_it[lvl]);   // the level has ended: early exit, or its cap
+  const int nl = over ? lvl - 1 : lvl;
+  if (writer) {
+    if (t < 6) dst->pose[t] = sh.newpose[t];
+    if (t < 12) dst->S[t] = sh.newS[t];
+    if (t < ELLC_MAX_LEVELS) dst->iters[t] = src.iters[t] + ((pending && t == lvl) ? 1 : 0);
+    if (t == 0) {
+      dst->weighted = sh.weighted;
+      dst->level_done = sh.level_done;
+      dst->pending = nl >= 0 ? 1 : 0;
+      dst->cur_level = nl;
+      dst->it_in_level = over ? 0 : it;
+    }
+  }
+  if (nl < 0) return;
+  if (over) {   // a level change (at most L - 1 per alignment): tables, chunk and first record of the finer level
+    const int nb_n = fa.nblk_lv[nl];
+    if (sub >= nb_n) return;
+    g = a.geom[nl];
+    K = a.kf_tab[nl * a.max_kf + slot];
+    F = &a.fr_tab[nl * a.max_fr + frs];
+    V = *as_global(K.count);
+    const int chunk = (V + nb_n - 1) / nb_n;
+    begin = sub * chunk;
+    end = min(V, begin + chunk);
+    if constexpr (FAST) {
+      if (begin + t < end) firstf = fcaf_load(K, (unsigned)(begin + t));
+    } else {
+      if (begin + t < end) first = fca_load(K, (unsigned)(begin + t));
+      first_pre = fca_prepare<DIVC>(g, first);
+    }
+  } else if (sub >= nb_l) {
+    return;
+  }
+  g_u8 cur = as_global(F->img);
+  float sums[27];
+  fca_chunk_pass<DIVC, true, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
+  float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
+  block_reduce_store<27>(sums, out);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1429,7 +1605,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
 }
 
 // Final solve of a fused schedule: consumes the last pending partials; result always lands in state buffer 0.
-template <bool FAST>
+template <bool FAST, bool ADAPT = false>
 __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs fa) {
   const GnArgs& a = fa.g;
   const int b = blockIdx.x;
@@ -1437,20 +1613,32 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
   AlignState* dst = a.state + b;
   __shared__ SolveShared sh;
   const int t = threadIdx.x;
-  const int pending = src.pending;
+  // state-driven schedule (ADAPT, gn_fca_adaptive): the level of the pending sums comes from the record, and the schedule
+  // may not have ended yet — the result record then says so (pad = 1) and the host replays a continuation
+  const int lvl = ADAPT ? src.cur_level : fa.prev_level;
+  const int pending = ADAPT ? (src.pending && lvl >= 0) : src.pending;
+  const int it_in = ADAPT ? src.it_in_level : 0;
   __shared__ int it_copy[ELLC_MAX_LEVELS];
   if (t < ELLC_MAX_LEVELS) it_copy[t] = src.iters[t];
   if (pending) {
     const float* prev = a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
-    const float* hinv = fa.ica ? a.kf_tab[fa.prev_level * a.max_kf + a.kf_slot[b]].hinv : nullptr;
-    solve_step<FAST>(sh, partial_group_sum(prev, fa.prev_nblk), fa.ica ? 2 : 0, fa.prev_level, fa.early_exit, src, dst, hinv);
+    const float* hinv = fa.ica ? a.kf_tab[lvl * a.max_kf + a.kf_slot[b]].hinv : nullptr;
+    solve_step<FAST>(sh, partial_group_sum(prev, ADAPT ? fa.nblk_lv[lvl] : fa.prev_nblk), fa.ica ? 2 : 0, lvl, fa.early_exit, src, dst, hinv);
   } else {
     if (t < 6) sh.newpose[t] = src.pose[t];
     if (t < 12) sh.newS[t] = src.S[t];
     if (t == 0) { sh.weighted = src.weighted; sh.level_done = src.level_done; }
     __syncthreads();
   }
-  if (FAST) {   // tolerance mode carries exp(pose) through the schedule; the twist is its log, taken once here
+  int nl = -1, nit = 0;
+  if (ADAPT && lvl >= 0) {
+    const int it = it_in + (pending ? 1 : 0);
+    const bool over = pending && (sh.level_done == lvl || it >= fa.max_it[lvl]);
+    nl = over ? lvl - 1 : lvl;
+    nit = over ? 0 : it;
+  }
+  const bool ended = nl < 0;
+  if (FAST && ended) {   // tolerance mode carries exp(pose) through the schedule; the twist is its log, taken once here
     if (t == 0) {
       float S[12], np[6];
       for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
@@ -1461,17 +1649,23 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
   }
   if (t < 6) dst->pose[t] = sh.newpose[t];
   if (t < 12) dst->S[t] = sh.newS[t];
-  if (t < ELLC_MAX_LEVELS) dst->iters[t] = it_copy[t] + ((pending && t == fa.prev_level) ? 1 : 0);
+  if (t < ELLC_MAX_LEVELS) dst->iters[t] = it_copy[t] + ((pending && t == lvl) ? 1 : 0);
   if (t == 0) {
     dst->weighted = sh.weighted;
     dst->level_done = sh.level_done;
     dst->pending = 0;
+    dst->cur_level = nl;
+    dst->it_in_level = nit;
   }
   if (fa.res) {
     AlignResult* r = fa.res + b;
-    if (t < 6) r->pose[t] = sh.newpose[t];
-    if (t < ELLC_MAX_LEVELS) r->iters[t] = it_copy[t] + ((pending && t == fa.prev_level) ? 1 : 0);
-    if (t == 0) { r->weighted = sh.weighted; r->pad = 0; }
+    if (ended) {
+      if (t < 6) r->pose[t] = sh.newpose[t];
+      if (t < ELLC_MAX_LEVELS) r->iters[t] = it_copy[t] + ((pending && t == lvl) ? 1 : 0);
+      if (t == 0) { r->weighted = sh.weighted; r->pad = 0; }
+    } else if (t == 0) {
+      r->pad = 1;
+    }
   }
 }
 
@@ -1488,13 +1682,13 @@ __global__ void gn_export_results(const AlignState* state, AlignResult* res, int
 }
 
 // initial state of alignment b from the caller's initial relative pose
-__device__ inline void init_state_record(AlignState& st, const float* init_pose, int b);
+__device__ inline void init_state_record(AlignState& st, const float* init_pose, int b, int top_level);
 
 // first kernel of a schedule: the staged batch description (slots, unique slots, initial poses: 9 * max_batch words) is
 // copied from pinned host memory by the first copy_blocks blocks; the remaining blocks initialise the alignment states
 // straight from the staged initial poses (same launch: one dependent kernel boundary less at the head of every batch)
 __global__ void stage_in(int* __restrict__ dst, const int* __restrict__ src_host, int n, int copy_blocks, AlignState* state, int B, int max_batch,
-                         unsigned* sync_words) {   // sync_words: the batch's RunSync records (64 words each); arrivals [0] and generation [16] start at 0
+                         unsigned* sync_words, int top_level) {   // sync_words: the batch's RunSync records (64 words each); arrivals [0] and generation [16] start at 0
   if ((int)blockIdx.x < copy_blocks) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src_host[i];
@@ -1502,18 +1696,18 @@ __global__ void stage_in(int* __restrict__ dst, const int* __restrict__ src_host
   }
   const int b = ((int)blockIdx.x - copy_blocks) * blockDim.x + threadIdx.x;
   if (b < B) {
-    init_state_record(state[b], (const float*)(src_host + 3 * max_batch), b);
+    init_state_record(state[b], (const float*)(src_host + 3 * max_batch), b, top_level);
     if (sync_words) { sync_words[(size_t)b * 64] = 0u; sync_words[(size_t)b * 64 + 16] = 0u; }
   }
 }
 
-__global__ void gn_init_state(AlignState* state, const float* init_pose, int B) {
+__global__ void gn_init_state(AlignState* state, const float* init_pose, int B, int top_level) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  init_state_record(state[b], init_pose, b);
+  init_state_record(state[b], init_pose, b, top_level);
 }
 
-__device__ inline void init_state_record(AlignState& st, const float* init_pose, int b) {
+__device__ inline void init_state_record(AlignState& st, const float* init_pose, int b, int top_level) {
   float p[6];
   for (int i = 0; i < 6; i++) { p[i] = init_pose[b * 6 + i]; st.pose[i] = p[i]; st.delta[i] = 0.0f; }
   float S[12];
@@ -1522,6 +1716,8 @@ __device__ inline void init_state_record(AlignState& st, const float* init_pose,
   st.weighted = 0.0f;
   st.level_done = -1;
   st.pending = 0;
+  st.cur_level = top_level;
+  st.it_in_level = 0;
   st.ticket_base = 0;
   st.gen_base = 0;
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) st.iters[l] = 0;
@@ -1537,6 +1733,29 @@ __global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slo
   const int cols = geom[level].cols;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
     // saved weights exist in the FCA schedule only: its records carry the pixel position
+    size_t p;
+    if (fast_records) {
+      const uint32_t xyI = ((const FcaRecF*)K.crec)[i].xyI;
+      p = (size_t)((xyI >> 12) & 0xfffu) * cols + (xyI & 0xfffu);
+    } else {
+      const uint32_t xy = K.crec[i].xy;
+      p = (size_t)(xy >> 16) * cols + (xy & 0xffffu);
+    }
+    K.weight[p] = K.weight[p] + K.wlast[i];
+  }
+}
+
+// The same for every level in ONE launch at the end of a fused schedule (grid (x, B, L)): each level's wlast holds the
+// weights of that level's last executed pixel pass. Only once the alignment's schedule has ended (the state-driven schedule
+// may stop short of it and be continued: cur_level of the record the finish kernel wrote is -1 at the end).
+__global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, const AlignState* state, int max_kf,
+                                         int fast_records) {
+  const int b = blockIdx.y, level = blockIdx.z;
+  if (state[b].cur_level >= 0) return;
+  const KfLevelDev& K = kf_tab[level * max_kf + kf_slot[b]];
+  const int V = *K.count;
+  const int cols = geom[level].cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
     size_t p;
     if (fast_records) {
       const uint32_t xyI = ((const FcaRecF*)K.crec)[i].xyI;

@@ -78,6 +78,47 @@ def test_fca_early_exit_matches_oracle(oracle, ellc, seed, rot, trans):
     ctx.close()
 
 
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_early_exit_schedule_is_state_driven_and_continues(oracle, ellc, arith):
+    """With early exit on, the FCA schedule of one or two alignments is state-driven (gn_fca_adaptive): the first graph holds
+    20 of the 32 possible launches and the library replays a continuation when an alignment needs more. Alignments that end
+    early (16 iterations), exactly with the first graph (20), in the continuation (29) and never (32: every cap reached),
+    in batches of two and alone. Per alignment: the oracle's iteration counts and pose; the same bits when the batch is
+    repeated; and, for the one that reaches every cap, the bits of the level-bound schedule (a context with early exit off)."""
+    cases = [(21, 0.02, 0.05), (22, 0.03, 0.08), (24, 0.015, 0.04), (25, 0.05, 0.15)]
+    pairs = [synth.make_pair(W, H, seed=s, rot=r, trans=t) for s, r, t in cases]
+    kw = dict(arith=ellc.ARITH_FAST) if arith == "fast" else {}
+    ctx = gpu_problem(ellc, W, H, L, pairs, early_exit=1, **kw)
+    pa, ia, wa = ctx.align([0, 1], [0, 1])
+    pb, ib, wb = ctx.align([2, 3], [2, 3])
+    pose, iters, wgt = np.concatenate([pa, pb]), np.concatenate([ia, ib]), np.concatenate([wa, wb])
+    totals = []
+    for i, pair in enumerate(pairs):
+        _, kf, cur, dm = oracle_problem(oracle, W, H, L, pair, early_exit=1)
+        pose_ref, iters_ref, _ = oracle.align(kf, cur, dm.depth_pyr())
+        totals.append(int(np.sum(iters_ref)))
+        if arith == "exact":
+            assert list(iters[i]) == list(iters_ref), (i, iters[i], iters_ref)
+            assert np.linalg.norm(pose[i] - pose_ref) <= 1e-5
+        elif i != 3 and list(iters[i]) == list(iters_ref):
+            # (a decision at the threshold may differ in the tolerance mode; alignment 3 does not converge — its motion is
+            # beyond the basin — and a diverging trajectory amplifies rounding differences: its bits are checked below)
+            assert np.linalg.norm(pose[i] - pose_ref) <= 1e-5
+        # alone: the library sizes its grids by the batch, so the sums are grouped differently (tolerance, not bits)
+        p1, i1, _ = ctx.align([i], [i])
+        if i != 3:
+            assert list(i1[0]) == list(iters[i]) and np.linalg.norm(p1[0] - pose[i]) <= 1e-6
+    assert totals == [16, 29, 20, 32]
+    assert list(iters[3]) == [4, 7, 9, 12]
+    again = ctx.align([0, 1], [0, 1])
+    assert np.array_equal(again[0], pa) and np.array_equal(again[1], ia) and np.array_equal(again[2], wa)
+    ctx.close()
+    ctx0 = gpu_problem(ellc, W, H, L, pairs, early_exit=0, **kw)   # same batch, level-bound schedule
+    p0, i0, w0 = ctx0.align([2, 3], [2, 3])
+    ctx0.close()
+    assert np.array_equal(p0[1], pose[3]) and w0[1] == wgt[3]
+
+
 def test_ica_constant_weight_path(problem, oracle):
     """Loop-closure mode: template-gradient Jacobian, saved weights, H once per level (A9-A11)."""
     rng = np.random.default_rng(3)
