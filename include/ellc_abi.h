@@ -149,7 +149,11 @@ ellc_status ellc_align(ellc_ctx* ctx, int B, const int* kf_slots, const int* fra
  * otherwise, the batch stays in flight); with nothing in flight it returns
  * ELLC_ERR_NOT_READY. Every other entry point is ordered after the batches in flight and before the batches enqueued
  * later, exactly as if the context had a single in-order queue: an upload into a slot a batch in flight reads takes
- * effect behind that batch. */
+ * effect behind that batch.
+ *   With cfg.early_exit on, an FCA call of one or two alignments (the tracking call) runs a schedule whose launch sequence is
+ * as long as alignments usually need; when one needs more, ellc_align_fetch replays the remainder before it returns. Only
+ * the host can start that remainder, so while such a batch is in flight a batch sharing one of its keyframe slots, and
+ * every non-batch entry point, first WAITS for it on the host (results and ordering are unchanged). */
 ellc_status ellc_align_enqueue(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, const float* init_pose,
                                int mode, int save_weights);
 ellc_status ellc_align_fetch(ellc_ctx* ctx, int B, float* out_pose, int* out_iters, float* out_weighted);
@@ -235,7 +239,8 @@ ellc_status ellc_gather_results(ellc_comm* comm, int total, const float* local8,
  * algorithmic bytes one launch covers (4*N + 14*V summed over the batch). */
 ellc_status ellc_profile_gn_kernel(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, int level, int reps,
                                    float* avg_ms, double* algorithmic_bytes, long long* valid_pixels);
-/* Time `reps` full ellc_align_enqueue passes with HIP events on the context stream (ms per pass). */
+/* Time `reps` full ellc_align_enqueue passes with HIP events on the context stream (ms per pass). (A call that runs the
+ * early-exit tracking schedule described above is timed without a remainder it might need.) */
 ellc_status ellc_profile_align(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, const float* init_pose,
                                int mode, int reps, float* avg_ms);
 
