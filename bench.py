@@ -285,6 +285,13 @@ def main():
             done = int(np.asarray(it3).sum())
             out["early_exit_on"] = {"ms_per_batch": 1e3 * d3, "alignments_per_s": B / d3, "gn_iterations_per_s": done / d3,
                                     "mean_iterations_per_alignment": done / B, "batches_in_flight": 1}
+            # the tracking call: ONE alignment with early exit (state-driven schedule)
+            _, it1, _ = w3.ctx.align(w3.kf[0][:1], w3.fr[0][:1], mode=w3.mode)
+            t4 = time.perf_counter()
+            for _ in range(30):
+                w3.ctx.align(w3.kf[0][:1], w3.fr[0][:1], mode=w3.mode)
+            d4 = (time.perf_counter() - t4) / 30
+            out["early_exit_on"]["single_alignment"] = {"ms_per_alignment": 1e3 * d4, "iterations": int(np.asarray(it1).sum())}
             if G > 1 and a.mode == "fca":
                 out["roofline"]["one_batch_at_a_time_grid"] = w3.level0_kernel()
             w3.close()

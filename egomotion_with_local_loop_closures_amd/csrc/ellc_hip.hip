@@ -417,7 +417,10 @@ static void launch_add_saved_weights(ellc_ctx* c, int B) {
 // B = 32 0.371 / 0.334 — a batch ends with its slowest alignment, every launch carries the finest level's grid, and the
 // age-balanced split of the level-bound launches is lost.
 static bool schedule_is_adaptive(const ellc_ctx* c, int mode, int B) {
-  return c->use_fused && c->use_adaptive && c->cfg.early_exit && mode == ELLC_MODE_FCA && B <= c->adaptive_max_batch;
+  if (!(c->use_fused && c->use_adaptive && c->cfg.early_exit && mode == ELLC_MODE_FCA && B <= c->adaptive_max_batch)) return false;
+  for (int l = 0; l < c->L; l++)
+    if (c->cfg.max_iter[l] < 1) return false;   // a level without iterations: the level-bound schedule simply has no launch for it
+  return true;
 }
 static int schedule_total_iters(const ellc_ctx* c) {
   int total = 0;

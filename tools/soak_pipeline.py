@@ -12,9 +12,10 @@ import numpy as np  # noqa: E402
 from egomotion_with_local_loop_closures_amd import api, synth  # noqa: E402
 
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-W, H, L, B, G = 640, 480, 4, 32, 3
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32   # 1 or 2: the state-driven early-exit schedule (continuations included)
+W, H, L, G = 640, 480, 4, 3
 fx, fy, cx, cy = synth.default_intrinsics(W, H)
-pairs = [synth.make_pair(W, H, seed=0x5EED + i) for i in range(6)]
+pairs = [synth.make_pair(W, H, seed=0x5EED + i) for i in range(5)] + [synth.make_pair(W, H, seed=22, rot=0.03, trans=0.08)]   # the last: > 20 iterations
 ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=G * B, max_frames=G * B,
                                      max_batch=B, concurrent_batches=G))
 for b in range(G * B):
