@@ -1,5 +1,5 @@
 #!/bin/bash
-# Interleaved A/B of library builds on one box: bench.py (contract fields only, 200 steps) under each ELLC_LIB_PATH,
+# Interleaved A/B of library builds on one box: bench.py (contract fields only; 200 warm-up steps put the HIP runtime's one-time pool growth, a 37 ms pause near the 120th graph launch when torch's runtime is loaded, before the timed 40) under each ELLC_LIB_PATH,
 # several rounds, so that box-to-box and warm-up differences cancel. usage: tools/ab_libs.sh OUT ROUNDS lib1.so lib2.so ... [-- bench flags]
 OUT=$1; ROUNDS=$2; shift 2
 LIBS=()
@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 for r in $(seq 1 "$ROUNDS"); do
   for lib in "${LIBS[@]}"; do
     name=$(basename "$lib" .so)
-    ELLC_LIB_PATH=$lib python bench.py --no-extras --no-cpu-baseline --steps 200 "$@" > "$OUT/${name}_r$r.json" 2>> "$OUT/err.log" || exit 1
+    ELLC_LIB_PATH=$lib python bench.py --no-extras --no-cpu-baseline --steps 40 --warmup 200 "$@" > "$OUT/${name}_r$r.json" 2>> "$OUT/err.log" || exit 1
   done
 done
 python - "$OUT" <<'PY'
