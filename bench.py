@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--mode", choices=["fca", "ica"], default="fca")
     ap.add_argument("--arith", choices=["fast", "exact"], default="fast", help="arithmetic of the Gauss-Newton pixel pass and solve (cfg.arith): "
                     "fast = tolerance mode (pose <= 1e-5 vs the oracle), exact = per-pixel bit-exact mode")
-    ap.add_argument("--inflight", type=int, default=3, help="batches in flight per GPU (1..3), each on its own stream and slot group")
+    ap.add_argument("--inflight", type=int, default=8, help="batches in flight per GPU (1 .. 4 x --coalesce; 1 .. 3 with --coalesce 1), each on its own slot group")
+    ap.add_argument("--coalesce", type=int, default=2, help="cfg.coalesce: full batches enqueued one after the other run side by side in one "
+                    "launch sequence, up to this many (1: every batch is launched by itself, at most three in flight)")
     ap.add_argument("--early-exit", action="store_true", help="informational: the reference's early exit on (data-dependent iteration counts; "
                     "value then counts the iterations actually executed)")
     ap.add_argument("--blocks", type=int, default=25, help="after the timed region: this many further blocks of --steps steps, for the spread (N=1)")
@@ -58,18 +60,20 @@ def parse():
 class Workload:
     """G slot groups of B keyframes + one frame each, resident on the device; step s works on group s % G."""
 
-    def __init__(self, api, a, scenes, arith, dev_index, W=None, H=None, L=None, B=None, sched=None, early_exit=None, G=None, shared_frame=True):
+    def __init__(self, api, a, scenes, arith, dev_index, W=None, H=None, L=None, B=None, sched=None, early_exit=None, G=None, shared_frame=True,
+                 coalesce=None, prime=None):
         self.api = api
         self.W, self.H, self.L = W or a.width, H or a.height, L or a.levels
         self.B = B or a.batch
-        self.G = G or max(1, min(3, a.inflight))
+        self.coalesce = max(1, min(3, a.coalesce if coalesce is None else coalesce))
+        self.G = G or max(1, min(4 * self.coalesce if self.coalesce > 1 else 3, a.inflight))
         self.sched = sched or [4, 7, 9, 12, 12, 12, 12, 12][:self.L]
         fx, fy, cx, cy = scenes[0]["intrinsics"]
         B, G = self.B, self.G
         self.shared = shared_frame
         self.cfg = api.default_config(self.W, self.H, self.L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=int(a.early_exit if early_exit is None else early_exit),
                                       max_iter=self.sched, max_keyframes=G * B, max_frames=(G if shared_frame else G * B), max_batch=B, device=dev_index,
-                                      concurrent_batches=G, arith=api.ARITH_FAST if arith == "fast" else api.ARITH_EXACT)
+                                      concurrent_batches=G, coalesce=self.coalesce, arith=api.ARITH_FAST if arith == "fast" else api.ARITH_EXACT)
         self.ctx = api.Context(self.cfg)
         self.mode = api.MODE_FCA if a.mode == "fca" else api.MODE_ICA
         for g in range(G):
@@ -86,7 +90,10 @@ class Workload:
                         self.ctx.keyframe_set_weights(g * B + b, l, np.full((self.H >> l, self.W >> l), 0.03, np.float32), 1)
         self.kf = [np.arange(B, dtype=np.int32) + g * B for g in range(G)]
         self.fr = [np.full(B, g, np.int32) if shared_frame else self.kf[g] for g in range(G)]
-        self.run(G)   # set-up, not warm-up: every slot group's launch sequence is captured into its hipGraph once (like the uploads above)
+        # set-up, not warm-up: launch sequences are captured into hipGraphs on first use, one per (buffer set, batches in the group);
+        # a rehearsal of the step counts that will be run captures every one the measured runs replay (like the uploads above)
+        for n in sorted(set([G] + [int(x) for x in (prime or []) if x > 0])):
+            self.run(n)
 
     def run(self, nsteps, on_fetch=None):
         """nsteps steps, software-pipelined through the asynchronous API: up to G batches in flight, each on its own stream and
@@ -111,10 +118,12 @@ class Workload:
         return time.perf_counter() - t0, pose, iters
 
     def level0_kernel(self, reps=50):
-        ms, alg, V = self.ctx.profile_gn_kernel(self.kf[0], self.fr[0], 0, reps=reps)
+        """The level-0 launch as the timed region issues it: over the alignments of one launch group (coalesce batches side by side)."""
+        k = min(self.coalesce, self.G)
+        ms, alg, V = self.ctx.profile_gn_kernel(np.concatenate(self.kf[:k]), np.concatenate(self.fr[:k]), 0, reps=reps)
         gbps = alg / (ms * 1e-3) / 1e9
-        return {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg, "valid_pixels_per_launch": V, "achieved": gbps, "frac": gbps / PEAK_GBPS,
-                "valid_pixel_rate_Gpx_s": V / (ms * 1e-3) / 1e9}
+        return {"avg_launch_ms": ms, "alignments_per_launch": int(k * self.B), "algorithmic_bytes_per_launch": alg, "valid_pixels_per_launch": V,
+                "achieved": gbps, "frac": gbps / PEAK_GBPS, "valid_pixel_rate_Gpx_s": V / (ms * 1e-3) / 1e9}
 
     def close(self):
         self.ctx.close()
@@ -144,7 +153,7 @@ def main():
         scenes = [synth.make_pair(W, H, seed=0x5EED + 1000 * rank + i, dense=True) for i in range(2)]
     else:
         scenes = synth.make_shared_frame_batch(W, H, B, seed=0x5EED + 1000 * rank)
-    wl = Workload(api, a, scenes, a.arith, dev_index, shared_frame=not a.dense)
+    wl = Workload(api, a, scenes, a.arith, dev_index, shared_frame=not a.dense, prime=[a.warmup, a.steps])
     G, sched = wl.G, wl.sched
     iters_per_alignment = sum(sched)
     # ---- the single gather of the resulting se(3) poses (8 floats per alignment) per batch: enqueued when a batch is fetched,
@@ -218,11 +227,11 @@ def main():
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C2 (N=1) / C3 (32 per GPU, N>1): %s, %dx%d, %d-level pyramid, %s Gauss-Newton, schedule %s (early exit %s), per-call mask "
-                               "compaction included, arithmetic mode '%s' (%s), %d batches in flight on %d streams%s"
+                               "compaction included, arithmetic mode '%s' (%s), %d batches in flight, launched in groups of up to %d side by side (cfg.coalesce) on up to 3 streams%s"
                                % (shape, W, H, L, a.mode.upper(), sched, "ON: informational run" if a.early_exit else "off", a.arith,
                                   "pose <= 1e-5 vs the CPU path, tests/test_gpu_fast.py" if a.arith == "fast" else "per-pixel values bit-identical to the CPU path",
-                                  G, G, ", one all_gather of poses per step over %s (overlapped with the next batch)" % (("RCCL, issued by the library's C entry points" if use_cabi else "RCCL via torch.distributed") if a.backend == "nccl" else (a.backend + (" harness, gather through the library's C entry points over TCP" if use_cabi else ""))) if world > 1 else ""),
-                   "batch_per_gpu": B, "global_batch": B * world, "batches_in_flight": G, "gn_iterations_per_alignment": iters_per_alignment,
+                                  G, wl.coalesce, ", one all_gather of poses per step over %s (overlapped with the next batch)" % (("RCCL, issued by the library's C entry points" if use_cabi else "RCCL via torch.distributed") if a.backend == "nccl" else (a.backend + (" harness, gather through the library's C entry points over TCP" if use_cabi else ""))) if world > 1 else ""),
+                   "batch_per_gpu": B, "global_batch": B * world, "batches_in_flight": G, "coalesce": wl.coalesce, "gn_iterations_per_alignment": iters_per_alignment,
                    "alignments_per_s": world * B * a.steps / dt, "pixels": "dense" if a.dense else "semi-dense (maxAbsGradient>=5)", "arith": a.arith},
     }
 
@@ -266,7 +275,7 @@ def main():
             wl = None
             # ---- the other arithmetic mode on the same workload
             other = "exact" if a.arith == "fast" else "fast"
-            w2 = Workload(api, a, scenes, other, dev_index, shared_frame=not a.dense)
+            w2 = Workload(api, a, scenes, other, dev_index, shared_frame=not a.dense, prime=[a.warmup, a.steps])
             w2.run(a.warmup)
             d2, p2, _ = w2.timed(a.steps, sync)
             k2 = w2.level0_kernel()
@@ -311,17 +320,17 @@ def main():
 
 def c4_dense(api, synth, a, dev_index, sync):
     """BASELINE configs[4] at its per-GPU batch (the honest HBM test — the working set streams from HBM):
-    1280x960, 5 levels {4,7,9,12,12}, dense residuals, 16 alignments per batch, three batches in flight; both arithmetic modes."""
+    1280x960, 5 levels {4,7,9,12,12}, dense residuals, 16 alignments per batch, pipelined as the main workload is; both arithmetic modes."""
     W, H, L, B = 1280, 960, 5, 16
     scenes = [synth.make_pair(W, H, seed=0xC4 + i, dense=True) for i in range(2)]
     ns = argparse.Namespace(**vars(a))
     ns.early_exit = False
-    rec = {"workload": "C4 shape: 1280x960, 5 levels [4,7,9,12,12], dense, 16 alignments per GPU per batch, 3 batches in flight",
-           "iterations_per_alignment": 44}
+    rec = {"workload": "C4 shape: 1280x960, 5 levels [4,7,9,12,12], dense, 16 alignments per GPU per batch, %d batches in flight in groups of %d"
+                       % (min(a.inflight, 4 * a.coalesce if a.coalesce > 1 else 3), a.coalesce), "iterations_per_alignment": 44}
     for arith in ("fast", "exact"):
-        w = Workload(api, ns, scenes, arith, dev_index, W=W, H=H, L=L, B=B, G=3, shared_frame=False)
-        w.run(3)
         steps = 12
+        w = Workload(api, ns, scenes, arith, dev_index, W=W, H=H, L=L, B=B, shared_frame=False, prime=[3, steps])
+        w.run(3)
         d, _, iters = w.timed(steps, sync)
         assert int(iters.sum()) == B * 44
         # algorithmic bytes of one full-schedule alignment: sum over levels of iters_l * (4 N_l + 14 V_l), V_l = N_l (dense): 144.8 MB

@@ -54,42 +54,61 @@ struct ellc_ctx {
   ellc::AlignResult* result_h = nullptr;            // pinned; written by the last kernel of a schedule through result_dev_alias
   ellc::AlignResult* result_dev_alias = nullptr;
   const int* stage_dev_alias = nullptr;             // device-side address of the pinned staging record (kf_slot_h ...)
-  // Up to SETS batches may be in flight (ellc_align_enqueue several times before ellc_align_fetch). Every set has its own
-  // pinned staging / result records and device work buffers (staged slots, AlignState, block partials); set 0 runs on the
-  // context's main stream, sets 1 and 2 on streams of their own (created when first needed: a process holds few hardware
-  // queues, and streams that end up on the same one do not overlap), so the batches run CONCURRENTLY: the latency-bound coarse iterations of one batch overlap the throughput-bound fine
-  // iterations of another (r01: 0.56 -> 0.34 ms per batch of 32 with three in flight). Batches that share a keyframe
-  // slot are ordered one after the other (the compaction, H^-1 and the saved weights live in the keyframe slot). The
-  // members above point at the set of the batch being enqueued. All other entry points work on `stream` and first make
-  // it wait for the batches in flight, so a caller sees one in-order queue per context as before.
-#ifndef ELLC_SETS
-#define ELLC_SETS 3
-#endif
-  static constexpr int SETS = ELLC_SETS;
+  // Batches in flight (ellc_align_enqueue several times before ellc_align_fetch). The unit that runs on the device is a GROUP:
+  // up to cfg.coalesce full batches (B == max_batch) staged side by side in one set of buffers and launched as ONE sequence
+  // over all their alignments — a launch over 96 alignments costs little more than one over 32 (the per-launch costs of the
+  // dependent chain: launch gap, cold loads, solve, reduction, and the latency-bound coarse levels that do not fill the
+  // device, are paid once), r02: 4.7 -> 6.5 M iterations/s at three groups of three in flight. With cfg.coalesce = 1 (default)
+  // a group is one batch and everything is as before. Every group has its own pinned staging / result records and device work
+  // buffers (staged slots, AlignState, block partials), sized for coalesce x max_batch alignments; launched groups take one of
+  // three streams (the main stream first: a caller with one batch at a time never leaves it; a process holds few hardware
+  // queues, and streams that end up on the same one do not overlap), so up to three groups run CONCURRENTLY: the latency-bound
+  // coarse iterations of one overlap the throughput-bound fine iterations of another. Groups that share a keyframe slot are
+  // ordered one after the other (the compaction, H^-1 and the saved weights live in the keyframe slot). There is one set more than
+  // batches may be in flight (max_inflight): it takes the batches that arrive while the oldest group is being fetched. The members above point at the set / slice of the batch being
+  // staged or the group being launched. All other entry points work on `stream`, launch a group that is still open and make
+  // the stream wait for the groups in flight, so a caller sees one in-order queue per context as before.
+  static constexpr int MAX_COALESCE = 3;
+  static constexpr int SETS = 4 * MAX_COALESCE + 1;   // of which max_inflight + 1 are used (n_sets): every batch in flight may be a group of its own
+  static constexpr int STREAMS = 3;
   struct BatchSet {
-    int* stage_h = nullptr;                         // 9 * max_batch ints: kf slots, frame slots, unique slots, initial poses
+    int* stage_h = nullptr;                         // 9 * cap ints: kf slots, frame slots, unique slots, initial poses (cap = coalesce * max_batch)
     const int* stage_dev_alias = nullptr;
     ellc::AlignResult* result_h = nullptr;
     ellc::AlignResult* result_dev_alias = nullptr;
     hipEvent_t done = nullptr;
-    hipStream_t stream = nullptr;                   // sets 1, 2 (set 0: the main stream)
-    int waited_mark = 0;                            // the main-stream mark this set's stream has been ordered after
     int* stage_d = nullptr;                         // device copy of the staging record
     ellc::AlignState* state_d = nullptr;            // two launch-parity buffers
     float* partials_d = nullptr;
     ellc::RunSync* sync_d = nullptr;                // per alignment: arrival / generation counters and the published state of a run
-    int run_reserved = 0;                           // blocks reserved in the device's run budget while the batch is in flight
-    std::vector<int> kf_slots;                      // unique keyframe slots of the batch in flight
-    int B = 0;                                      // its size
-    bool joined = true;                             // `stream` (the context's main stream) already waits for `done`
-    int mode = 0, save_weights = 0;                 // of the batch in flight (a state-driven schedule may need its continuation)
-    bool adaptive = false;                          // the batch runs the state-driven schedule (gn_fca_adaptive)
+    int run_reserved = 0;                           // blocks reserved in the device's run budget while the group is in flight
+    // the group staged / in flight in this set
+    int fill = 0;                                   // batches staged side by side: batch j = alignments [j * max_batch, ...)
+    int fetched = 0;                                // of which fetched (the set is free again when fetched == fill)
+    bool launched = false;
+    bool coalescable = false;                       // further full batches of the same mode may join until it is launched
+    int slice_B[MAX_COALESCE] = {0, 0, 0};          // size of each staged batch
+    int stream_idx = 0;                             // the batch stream it was launched on (0: the context's main stream)
+    std::vector<int> kf_slots;                      // unique keyframe slots of the group
+    int B = 0;                                      // alignments the launch covers
+    bool joined = true;                             // the main stream already waits for `done`
+    int mode = 0, save_weights = 0;
+    bool adaptive = false;                          // the group (one batch) runs the state-driven schedule (gn_fca_adaptive)
     bool resolved = true;                           // `done` has been waited for and the continuation, if one was needed, has run
   } batch_set[SETS];
+  hipStream_t batch_stream[STREAMS] = {nullptr, nullptr, nullptr};   // [0] = stream; the others are created when first needed
+  int stream_waited_mark[STREAMS] = {0, 0, 0};      // the main-stream mark each batch stream has been ordered after
+  int coalesce = 1;                                 // cfg.coalesce clamped to 1..MAX_COALESCE
+  int max_inflight = 3;                             // batches in flight: 3 with coalesce = 1; 4 x coalesce otherwise (three groups
+                                                    // running and a fourth queued behind the oldest, so that the device never waits
+                                                    // for the host to gather the next group)
+  int n_sets = 4;                                   // sets in use: max_inflight + 1
+  int group_cap = 0;                                // alignments per set: coalesce * max_batch
+  int open_set = -1;                                // the set whose group is staged but not launched yet (-1: none)
   hipEvent_t ev_main = nullptr;                     // marks the main stream behind the last non-batch call
   bool main_dirty = false;                          // a non-batch entry point ran since ev_main was recorded
   int main_mark = 0;
-  int inflight[SETS] = {0};
+  int inflight[SETS * MAX_COALESCE] = {0};         // FIFO of the batches in flight: set * MAX_COALESCE + slice
   int n_inflight = 0;
   int cur_set = 0;                                  // the batch set the per-batch pointers below refer to (select_batch_set)
   float* partials_d = nullptr;

@@ -17,7 +17,8 @@
 
 using namespace ellc;
 
-static ellc_status resolve_batch(ellc_ctx* c, int set);   // waits for a batch in flight (and runs its continuation), defined with ellc_align_fetch
+static ellc_status resolve_batch(ellc_ctx* c, int set);   // waits for a group in flight (and runs its continuation), defined with ellc_align_fetch
+static ellc_status launch_group(ellc_ctx* c, int set);    // launches the group staged in a set
 
 namespace ellc {
 
@@ -39,19 +40,24 @@ ellc_status enter(ellc_ctx* c, bool join) {
   if (!(hipGetDevice(&dev) == hipSuccess && dev == c->cfg.device) && hipSetDevice(c->cfg.device) != hipSuccess)
     return fail(c, ELLC_ERR_HIP, "cannot make the context's device current");
   if (join) {   // everything but the batch entry points runs on the main stream, after the batches in flight
-    for (int i = 0; i < c->n_inflight; i++) {
-      ellc_ctx::BatchSet& bs = c->batch_set[c->inflight[i]];
+    if (c->open_set >= 0) {   // a group still waiting for batches to join: this call comes after them in the caller's order
+      const ellc_status s = ::launch_group(c, c->open_set);
+      if (s != ELLC_OK) return s;
+    }
+    for (int p = 0; p < ellc_ctx::SETS; p++) {
+      ellc_ctx::BatchSet& bs = c->batch_set[p];
+      if (!bs.launched) continue;
       if (bs.adaptive && !bs.resolved) {
         // a state-driven batch may need a continuation that only the host can start, and this call may change what it
         // reads (an upload into one of its slots, a depth stage): the host finishes the batch first
-        const ellc_status s = ::resolve_batch(c, c->inflight[i]);
+        const ellc_status s = ::resolve_batch(c, p);
         if (s != ELLC_OK) return s;
       }
-      if (bs.joined) continue;   // set 0 runs on the main stream itself
+      if (bs.joined) continue;   // it runs on the main stream itself
       ELLC_HIP(c, hipStreamWaitEvent(c->stream, bs.done, 0));
       bs.joined = true;
     }
-    c->main_dirty = true;   // the next batch on another stream has to be ordered after what this call enqueues
+    c->main_dirty = true;   // the next group on another stream has to be ordered after what this call enqueues
   }
   return ELLC_OK;
 }
@@ -230,6 +236,13 @@ static void enqueue_ica_hinv(ellc_ctx* c, int n_unique) {
 
 static bool slot_ok(int s, int n) { return s >= 0 && s < n; }
 
+// The batch size the grids are chosen for. A full batch (B = max_batch) of a coalescing context may run alone or side by
+// side with others in one launch: its block counts — they fix the order of the sums, i.e. the bits of the result — are those
+// of a full group either way. B here is what a launch covers: one batch, or k full batches.
+static int grid_batch(const ellc_ctx* c, int B) {
+  return (c->coalesce > 1 && B % c->cfg.max_batch == 0) ? c->cfg.max_batch * c->coalesce : B;
+}
+
 static GnArgs make_gn_args(ellc_ctx* c, int level, int B, int save_w, float* planes) {
   GnArgs a;
   a.geom = c->geom_d;
@@ -243,7 +256,7 @@ static GnArgs make_gn_args(ellc_ctx* c, int level, int B, int save_w, float* pla
   a.level = level;
   a.max_kf = c->cfg.max_keyframes;
   a.max_fr = c->cfg.max_frames;
-  a.nblk = choose_nblk(c, level, B);
+  a.nblk = choose_nblk(c, level, grid_batch(c, B));
   a.save_w = save_w;
   return a;
 }
@@ -304,31 +317,44 @@ static void launch_solve(ellc_ctx* c, int level, int B, int nblk, int mode, int 
   else hipLaunchKernelGGL(gn_solve<false>, dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, s);
 }
 
-// points the staging / result / work-buffer members at batch set p
-static void select_batch_set(ellc_ctx* c, int p) {
-  const int MB = c->cfg.max_batch;
+// points the staging / result / work-buffer members at batch set p: the host-side ones at batch `slice` of the group (where a
+// batch is staged and its results are read), the device-side ones at the whole group (what a launch covers)
+static void select_batch_set(ellc_ctx* c, int p, int slice = 0) {
+  const int MB = c->cfg.max_batch, cap = c->group_cap;
   c->cur_set = p;
   ellc_ctx::BatchSet& bs = c->batch_set[p];
-  c->kf_slot_h = bs.stage_h;
-  c->fr_slot_h = bs.stage_h + MB;
-  c->uniq_slot_h = bs.stage_h + 2 * MB;
-  c->init_pose_h = (float*)(bs.stage_h + 3 * MB);
+  c->kf_slot_h = bs.stage_h + slice * MB;
+  c->fr_slot_h = bs.stage_h + cap + slice * MB;
+  c->uniq_slot_h = bs.stage_h + 2 * cap;
+  c->init_pose_h = (float*)(bs.stage_h + 3 * cap) + 6 * slice * MB;
   c->stage_dev_alias = bs.stage_dev_alias;
-  c->result_h = bs.result_h;
+  c->result_h = bs.result_h + slice * MB;
   c->result_dev_alias = bs.result_dev_alias;
   c->kf_slot_d = bs.stage_d;
-  c->fr_slot_d = bs.stage_d + MB;
-  c->uniq_slot_d = bs.stage_d + 2 * MB;
-  c->init_pose_d = (float*)(bs.stage_d + 3 * MB);
+  c->fr_slot_d = bs.stage_d + cap;
+  c->uniq_slot_d = bs.stage_d + 2 * cap;
+  c->init_pose_d = (float*)(bs.stage_d + 3 * cap);
   c->state_d = bs.state_d;
   c->partials_d = bs.partials_d;
   c->sync_d = bs.sync_d;
 }
 
 // stage slots / initial poses on the device and list the unique keyframe slots
-static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int* n_unique) {
-  if (B < 1 || B > c->cfg.max_batch) return fail(c, ELLC_ERR_BAD_ARG, "B out of range");
+// (the selected set / slice; the unique slots of the batch go to `uniq` when given, else to the set's list: a batch that is
+// launched by itself)
+static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int* n_unique,
+                               std::vector<int>* uniq = nullptr, bool whole_group = false) {
+  if (B < 1 || B > (whole_group ? c->group_cap : c->cfg.max_batch)) return fail(c, ELLC_ERR_BAD_ARG, "B out of range");
   if (!kf_slots || !frame_slots) return fail(c, ELLC_ERR_BAD_ARG, "null slot arrays");
+  for (int b = 0; b < B; b++) {   // validated first: a refused batch leaves the set as it was
+    if (!slot_ok(kf_slots[b], c->cfg.max_keyframes) || !slot_ok(frame_slots[b], c->cfg.max_frames))
+      return fail(c, ELLC_ERR_BAD_ARG, "slot index out of range");
+    if (!c->kf_has_image[kf_slots[b]] || !c->kf_has_depth[kf_slots[b]]) return fail(c, ELLC_ERR_NOT_READY, "keyframe slot lacks image or depth");
+    if (!c->fr_has_image[frame_slots[b]]) return fail(c, ELLC_ERR_NOT_READY, "frame slot lacks image");
+  }
+  std::vector<int> local_uniq;
+  std::vector<int>& un = uniq ? *uniq : local_uniq;
+  un.clear();
   int nu = 0;
   for (int b = 0; b < B; b++) {
     if (!slot_ok(kf_slots[b], c->cfg.max_keyframes) || !slot_ok(frame_slots[b], c->cfg.max_frames))
@@ -338,24 +364,26 @@ static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const in
     c->kf_slot_h[b] = kf_slots[b];
     c->fr_slot_h[b] = frame_slots[b];
     bool seen = false;
-    for (int u = 0; u < nu; u++) seen = seen || (c->uniq_slot_h[u] == kf_slots[b]);
-    if (!seen) c->uniq_slot_h[nu++] = kf_slots[b];
+    for (int u = 0; u < nu; u++) seen = seen || (un[u] == kf_slots[b]);
+    if (!seen) { un.push_back(kf_slots[b]); nu++; }
     for (int i = 0; i < 6; i++) c->init_pose_h[b * 6 + i] = init_pose ? init_pose[b * 6 + i] : 0.0f;
     c->result_h[b].pad = -1;   // the kernel that exports the result clears it
   }
   // The pinned staging record is read by the first kernel of the schedule (enqueue_stage_in); it may still be in flight
   // from the previous call only if the caller skipped the fetch: ellc_align always fetches (synchronises),
   // ellc_align_enqueue callers must fetch before enqueueing again.
+  if (!uniq)
+    for (int u = 0; u < nu; u++) c->uniq_slot_h[u] = un[u];
   *n_unique = nu;
   return ELLC_OK;
 }
 
 // device copy of the staged batch description, as a kernel reading the pinned record (part of the captured graph)
 static void enqueue_stage_in(ellc_ctx* c, int B) {
-  const int n = 9 * c->cfg.max_batch;
+  const int n = 9 * c->group_cap;
   const int copy_blocks = (n + 255) / 256;
   hipLaunchKernelGGL(stage_in, dim3(copy_blocks + (B + 255) / 256), dim3(256), 0, c->stream, c->kf_slot_d, c->stage_dev_alias, n, copy_blocks,
-                     c->state_d, B, c->cfg.max_batch, (unsigned*)c->sync_d, c->L - 1);
+                     c->state_d, B, c->group_cap, (unsigned*)c->sync_d, c->L - 1);
 }
 
 // fills the age-balanced split of a launch (FusedArgs::age_rounds): on when the grid is 2..4 full rounds of one block per CU-slot
@@ -446,8 +474,8 @@ static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weight
   fa.prev_level = -1;
   fa.prev_nblk = 0;
   fa.early_exit = c->cfg.early_exit;
-  fa.stride_state = c->cfg.max_batch;
-  fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+  fa.stride_state = c->group_cap;
+  fa.stride_part = (size_t)c->group_cap * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
   fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);
   fa.res = c->result_dev_alias;
   fa.ica = 0;
@@ -456,7 +484,7 @@ static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weight
   for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
   int grid_x = 1;
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) {
-    fa.nblk_lv[l] = l < c->L ? choose_nblk(c, l, B) : 1;
+    fa.nblk_lv[l] = l < c->L ? choose_nblk(c, l, grid_batch(c, B)) : 1;
     fa.max_it[l] = l < c->L ? c->cfg.max_iter[l] : 0;
     grid_x = std::max(grid_x, fa.nblk_lv[l]);
   }
@@ -492,8 +520,8 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
   fa.prev_level = -1;
   fa.prev_nblk = 0;
   fa.early_exit = c->cfg.early_exit;
-  fa.stride_state = c->cfg.max_batch;
-  fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+  fa.stride_state = c->group_cap;
+  fa.stride_part = (size_t)c->group_cap * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
   fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);
   fa.res = c->result_dev_alias;
   fa.ica = 0;
@@ -524,8 +552,8 @@ static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
   fa.prev_level = -1;
   fa.prev_nblk = 0;
   fa.early_exit = c->cfg.early_exit;
-  fa.stride_state = c->cfg.max_batch;
-  fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+  fa.stride_state = c->group_cap;
+  fa.stride_part = (size_t)c->group_cap * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
   fa.res = c->result_dev_alias;
   fa.ica = 1;
   fa.xcd_map = 0;
@@ -701,6 +729,7 @@ void ellc_default_config(ellc_config* cfg, int width, int height, int levels) {
   cfg->max_batch = 4;
   cfg->device = 0;
   cfg->concurrent_batches = 1;
+  cfg->coalesce = 1;
 }
 
 const char* ellc_last_error(const ellc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -725,7 +754,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   if (cfg->levels < 1 || cfg->levels > ELLC_MAX_LEVELS) return ELLC_ERR_BAD_ARG;
   if ((cfg->width >> (cfg->levels - 1)) < 4 || (cfg->height >> (cfg->levels - 1)) < 4) return ELLC_ERR_BAD_ARG;
   if (cfg->max_keyframes < 1 || cfg->max_frames < 1 || cfg->max_batch < 1) return ELLC_ERR_BAD_ARG;
-  if (cfg->concurrent_batches < 0 || cfg->concurrent_batches > ellc_ctx::SETS) return ELLC_ERR_BAD_ARG;   // 0: as 1
+  if (cfg->coalesce < 0 || cfg->coalesce > ellc_ctx::MAX_COALESCE) return ELLC_ERR_BAD_ARG;   // 0: as 1
+  if (cfg->concurrent_batches < 0 || cfg->concurrent_batches > 4 * ellc_ctx::MAX_COALESCE) return ELLC_ERR_BAD_ARG;   // 0: as 1
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ELLC_ERR_NO_DEVICE;
   if (cfg->device < 0 || cfg->device >= ndev) return ELLC_ERR_BAD_ARG;
@@ -832,16 +862,22 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   for (int s = 0; s < MF; s++) { TRY(dev_alloc(c, &c->fr_maxgrad[s], n0)); TRY(dev_alloc(c, &c->fr_maxgrad_count[s], 4)); }
   // ---- alignment work buffers
   const int MB = cfg->max_batch;
-  // per batch set: one staging record [kf_slot MB][fr_slot MB][unique MB][init_pose 6*MB] (pinned, and its device copy),
-  // the result records (pinned), the alignment states (two launch-parity buffers), the block partials, a stream
-  for (int p = 0; p < ellc_ctx::SETS; p++) {
+  c->coalesce = std::max(1, cfg->coalesce);
+  c->group_cap = c->coalesce * MB;
+  c->max_inflight = c->coalesce > 1 ? 4 * c->coalesce : 3;
+  c->n_sets = c->max_inflight + 1;
+  c->batch_stream[0] = c->stream;
+  const size_t CAP = (size_t)c->group_cap;
+  // per batch set (group): one staging record [kf_slot cap][fr_slot cap][unique cap][init_pose 6*cap] (pinned, and its device
+  // copy), the result records (pinned), the alignment states (two launch-parity buffers), the block partials
+  for (int p = 0; p < c->n_sets; p++) {
     ellc_ctx::BatchSet& bs = c->batch_set[p];
-    TRY(dev_alloc(c, &bs.stage_d, (size_t)9 * MB));
-    TRY(host_alloc(c, &bs.stage_h, (size_t)9 * MB));
-    TRY(host_alloc(c, &bs.result_h, MB));
-    TRY(dev_alloc(c, &bs.state_d, 2 * (size_t)MB));
-    TRY(dev_alloc(c, &bs.partials_d, 2 * (size_t)MB * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
-    TRY(dev_alloc(c, (char**)&bs.sync_d, 256 * (size_t)MB));   // RunSync records (diagnostic builds), 256 bytes each
+    TRY(dev_alloc(c, &bs.stage_d, 9 * CAP));
+    TRY(host_alloc(c, &bs.stage_h, 9 * CAP));
+    TRY(host_alloc(c, &bs.result_h, CAP));
+    TRY(dev_alloc(c, &bs.state_d, 2 * CAP));
+    TRY(dev_alloc(c, &bs.partials_d, 2 * CAP * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
+    TRY(dev_alloc(c, (char**)&bs.sync_d, 256 * CAP));   // RunSync records (diagnostic builds), 256 bytes each
     void *da = nullptr, *db = nullptr;
     if (hipHostGetDevicePointer(&da, bs.stage_h, 0) != hipSuccess || hipHostGetDevicePointer(&db, bs.result_h, 0) != hipSuccess ||
         hipEventCreateWithFlags(&bs.done, hipEventDisableTiming) != hipSuccess) {
@@ -937,7 +973,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
 ellc_status ellc_ctx_destroy(ellc_ctx* c) {
   ELLC_ENTER(c);
   if (!c) return ELLC_ERR_BAD_ARG;
-  for (int p = 0; p < ellc_ctx::SETS; p++) if (c->batch_set[p].stream) (void)hipStreamSynchronize(c->batch_set[p].stream);
+  for (int i = 1; i < ellc_ctx::STREAMS; i++) if (c->batch_stream[i]) (void)hipStreamSynchronize(c->batch_stream[i]);
   (void)hipStreamSynchronize(c->stream);
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
   for (void* p : c->allocs) (void)hipFree(p);
@@ -948,10 +984,10 @@ ellc_status ellc_ctx_destroy(ellc_ctx* c) {
   }
   if (c->ingest_map) (void)hipFree(c->ingest_map);
   if (c->ingest_bgr) (void)hipFree(c->ingest_bgr);
-  for (int p = 0; p < ellc_ctx::SETS; p++) {
+  for (int p = 0; p < ellc_ctx::SETS; p++)
     if (c->batch_set[p].done) (void)hipEventDestroy(c->batch_set[p].done);
-    if (c->batch_set[p].stream) (void)hipStreamDestroy(c->batch_set[p].stream);
-  }
+  for (int i = 1; i < ellc_ctx::STREAMS; i++)
+    if (c->batch_stream[i]) (void)hipStreamDestroy(c->batch_stream[i]);
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1260,8 +1296,8 @@ struct StreamScope {
   ~StreamScope() { c->stream = saved; }
 };
 
-// Waits for a batch in flight and, when it ran the state-driven schedule and one of its alignments had not ended when the
-// first graph did (result pad = 1, gn_fused_finish), replays the continuation graph on the batch's stream and waits again.
+// Waits for a launched group and, when it ran the state-driven schedule and one of its alignments had not ended when the
+// first graph did (result pad = 1, gn_fused_finish), replays the continuation graph on the group's stream and waits again.
 static ellc_status resolve_batch(ellc_ctx* c, int set) {
   ellc_ctx::BatchSet& bs = c->batch_set[set];
   if (bs.resolved) return ELLC_OK;
@@ -1276,7 +1312,7 @@ static ellc_status resolve_batch(ellc_ctx* c, int set) {
   select_batch_set(c, set);
   ellc_status s = ELLC_OK;
   {
-    StreamScope scope(c, set > 0 ? bs.stream : c->stream);
+    StreamScope scope(c, c->batch_stream[bs.stream_idx]);
     s = launch_align_graph(c, bs.B, 0, bs.mode, bs.save_weights, set, true);
     if (s == ELLC_OK && hipEventRecord(bs.done, c->stream) != hipSuccess) s = fail(c, ELLC_ERR_HIP, "hipEventRecord failed");
   }
@@ -1287,101 +1323,196 @@ static ellc_status resolve_batch(ellc_ctx* c, int set) {
   return ELLC_OK;
 }
 
-// track: the batch takes the next free set, runs on that set's stream and joins the in-flight queue ellc_align_fetch
-// drains; untracked use (the timing hook, nothing in flight) runs set 0's buffers on the main stream.
-static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode,
-                                      int save_weights, bool track) {
-  if (!c) return ELLC_ERR_BAD_ARG;
-  if (mode != ELLC_MODE_FCA && mode != ELLC_MODE_ICA) return fail(c, ELLC_ERR_BAD_ARG, "unknown mode");
-  if (c->n_inflight >= ellc_ctx::SETS) return fail(c, ELLC_ERR_NOT_READY, "three batches are in flight: call ellc_align_fetch first");
-  // the lowest free set: a caller with one batch at a time stays on set 0, i.e. on the main stream with no extra stream
-  int set = 0;
-  if (track) {
-    bool used[ellc_ctx::SETS] = {false};
-    for (int i = 0; i < c->n_inflight; i++) used[c->inflight[i]] = true;
-    while (used[set]) set++;
-  }
+// Launches the group staged in `set`: its batches lie side by side (batch j = alignments [j * max_batch, ...)), the launch
+// sequence covers all of them. The group takes the lowest batch stream no unfetched group occupies (a caller with one batch at
+// a time stays on the main stream), else the stream of the group launched longest ago.
+static ellc_status launch_group(ellc_ctx* c, int set) {
   ellc_ctx::BatchSet& bs = c->batch_set[set];
-  if (set > 0 && !bs.stream) ELLC_HIP(c, hipStreamCreate(&bs.stream));   // created on first use
+  if (c->open_set == set) c->open_set = -1;
+  if (bs.launched || bs.fill < 1) return ELLC_OK;
+  const int MB = c->cfg.max_batch;
+  const int k = bs.fill;
+  const int B = (k == 1) ? bs.slice_B[0] : k * MB;
   select_batch_set(c, set);
-  int nu = 0;
-  ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
-  if (s != ELLC_OK) return s;
-  // saved weights are accumulated per keyframe slot (wlast, weight plane, numWeightsAdded): two alignments of one batch on the
-  // same slot would race on them
-  if (save_weights && mode == ELLC_MODE_FCA && nu < B)
-    return fail(c, ELLC_ERR_BAD_ARG, "save_weights needs a different keyframe slot for every alignment of the batch");
-  hipStream_t run_stream = set > 0 ? bs.stream : c->stream;
+  // unique keyframe slots of the group (the compaction runs once per slot)
+  bs.kf_slots.clear();
+  for (int b = 0; b < B; b++) {
+    bool seen = false;
+    for (int v : bs.kf_slots) seen = seen || (v == c->kf_slot_h[b]);
+    if (!seen) bs.kf_slots.push_back(c->kf_slot_h[b]);
+  }
+  const int nu = (int)bs.kf_slots.size();
+  for (int u = 0; u < nu; u++) c->uniq_slot_h[u] = bs.kf_slots[u];
+  // stream
+  bool busy[ellc_ctx::STREAMS] = {false, false, false};
+  for (int p = 0; p < ellc_ctx::SETS; p++)
+    if (p != set && c->batch_set[p].launched) busy[c->batch_set[p].stream_idx] = true;
+  int si = 0;
+  while (si < ellc_ctx::STREAMS && busy[si]) si++;
+  if (si == ellc_ctx::STREAMS) {   // all three carry a group: behind the one launched longest ago (the head of the queue)
+    si = c->n_inflight > 0 ? c->batch_set[c->inflight[0] / ellc_ctx::MAX_COALESCE].stream_idx : 0;
+  }
+  if (si > 0 && !c->batch_stream[si]) ELLC_HIP(c, hipStreamCreate(&c->batch_stream[si]));   // created on first use
+  hipStream_t run_stream = c->batch_stream[si];
   int reserved = 0;
 #ifdef ELLC_DIAG
   // run kernels (diagnostic builds, ELLC_RUN=1): multi-iteration runs need their blocks resident together with every other
   // run in flight on the device: reserve, or fall back to single-iteration launches (same results)
   c->plan_persist = false;
   if (c->use_fused && c->use_run && c->use_persist) {
-    reserved = plan_runs(c, B, save_weights && mode == ELLC_MODE_FCA, true).max_run_blocks;
+    reserved = plan_runs(c, B, bs.save_weights && bs.mode == ELLC_MODE_FCA, true).max_run_blocks;
     if (run_reserve(c, reserved)) c->plan_persist = true;
     else reserved = 0;
   }
-  struct ReserveGuard {   // gives the reservation back unless the batch was enqueued
+  struct ReserveGuard {   // gives the reservation back unless the group was launched
     ellc_ctx* c; int blocks; bool keep;
     ~ReserveGuard() { if (!keep) run_release(c, blocks); }
   } guard{c, reserved, false};
 #endif
-  if (track) {
-    // A batch on another stream runs after everything the caller has put on the main stream through the other entry
-    // points (uploads, depth stages), but not after the batches that run there: the mark is recorded before them.
-    // (a context that has only ever had one batch in flight has no other stream and never records the mark)
-    if (c->main_dirty && (set > 0 || c->batch_set[1].stream)) {
-      ELLC_HIP(c, hipEventRecord(c->ev_main, c->stream));
-      c->main_dirty = false;
-      c->main_mark++;
+  // A group on another stream runs after everything the caller has put on the main stream through the other entry
+  // points (uploads, depth stages), but not after the groups that run there: the mark is recorded before them.
+  // (a context that has only ever had one batch in flight has no other stream and never records the mark)
+  if (c->main_dirty && (si > 0 || c->batch_stream[1])) {
+    ELLC_HIP(c, hipEventRecord(c->ev_main, c->stream));
+    c->main_dirty = false;
+    c->main_mark++;
+  }
+  if (si > 0 && c->stream_waited_mark[si] != c->main_mark) {
+    ELLC_HIP(c, hipStreamWaitEvent(run_stream, c->ev_main, 0));
+    c->stream_waited_mark[si] = c->main_mark;
+  }
+  // after the groups in flight that use one of its keyframe slots: compaction, H^-1 and saved weights are per slot
+  for (int p = 0; p < ellc_ctx::SETS; p++) {
+    ellc_ctx::BatchSet& other = c->batch_set[p];
+    if (p == set || !other.launched) continue;
+    bool shared = false;
+    for (int u = 0; u < nu && !shared; u++)
+      for (int v : other.kf_slots) shared = shared || (v == bs.kf_slots[u]);
+    if (!shared) continue;
+    if (other.adaptive && !other.resolved) {
+      // a state-driven batch may still need its continuation, which only the host can start: finish it first (the host
+      // waits here; batches on disjoint keyframes never do)
+      const ellc_status s = resolve_batch(c, p);
+      if (s != ELLC_OK) return s;
+      select_batch_set(c, set);
     }
-    if (set > 0 && bs.waited_mark != c->main_mark) {
-      ELLC_HIP(c, hipStreamWaitEvent(run_stream, c->ev_main, 0));
-      bs.waited_mark = c->main_mark;
-    }
-    // after the batches in flight that use one of its keyframe slots: compaction, H^-1 and saved weights are per slot
-    for (int i = 0; i < c->n_inflight; i++) {
-      const ellc_ctx::BatchSet& other = c->batch_set[c->inflight[i]];
-      bool shared = false;
-      for (int u = 0; u < nu && !shared; u++)
-        for (int v : other.kf_slots) shared = shared || (v == c->uniq_slot_h[u]);
-      if (!shared) continue;
-      if (other.adaptive && !other.resolved) {
-        // a state-driven batch may still need its continuation, which only the host can start: finish it first (the host
-        // waits here; batches on disjoint keyframes never do)
-        s = resolve_batch(c, c->inflight[i]);
-        if (s != ELLC_OK) return s;
-      }
-      ELLC_HIP(c, hipStreamWaitEvent(run_stream, other.done, 0));
-    }
+    ELLC_HIP(c, hipStreamWaitEvent(run_stream, other.done, 0));
   }
   {
     StreamScope scope(c, run_stream);
-    s = launch_align_graph(c, B, nu, mode, save_weights, set, false);
+    const ellc_status s = launch_align_graph(c, B, nu, bs.mode, bs.save_weights, set, false);
     if (s != ELLC_OK) return s;
-    if (track) ELLC_HIP(c, hipEventRecord(bs.done, c->stream));
+    ELLC_HIP(c, hipEventRecord(bs.done, c->stream));
   }
-  if (save_weights && mode == ELLC_MODE_FCA)
-    for (int b = 0; b < B; b++)
-      for (int l = 0; l < c->L; l++) c->kf_num_weights[kf_slots[b]][l]++;
 #ifdef ELLC_DIAG
   guard.keep = true;
 #endif
-  if (track) {
-    bs.kf_slots.assign(c->uniq_slot_h, c->uniq_slot_h + nu);
-    bs.B = B;
+  bs.launched = true;
+  bs.stream_idx = si;
+  bs.B = B;
+  bs.adaptive = schedule_is_adaptive(c, bs.mode, B);
+  bs.resolved = false;
+  bs.joined = (si == 0);
+  bs.run_reserved = reserved;
+  return ELLC_OK;
+}
+
+// forgets the group of a set (after its last batch has been fetched, or after a failed launch)
+static void free_set(ellc_ctx* c, int set) {
+  ellc_ctx::BatchSet& bs = c->batch_set[set];
+#ifdef ELLC_DIAG
+  run_release(c, bs.run_reserved);
+#endif
+  bs.run_reserved = 0;
+  bs.fill = bs.fetched = 0;
+  bs.launched = false;
+  bs.resolved = true;
+  bs.adaptive = false;
+  bs.kf_slots.clear();
+  if (c->open_set == set) c->open_set = -1;
+}
+
+// track: the batch is staged in a set (joining the open group when it can, see ellc_ctx::BatchSet) and enters the in-flight
+// queue ellc_align_fetch drains; untracked use (the timing hooks, nothing in flight) runs set 0 on the main stream at once.
+static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode,
+                                      int save_weights, bool track) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  if (mode != ELLC_MODE_FCA && mode != ELLC_MODE_ICA) return fail(c, ELLC_ERR_BAD_ARG, "unknown mode");
+  const int MB = c->cfg.max_batch;
+  if (!track) {
+    if (c->n_inflight > 0 || c->open_set >= 0) return fail(c, ELLC_ERR_NOT_READY, "fetch the enqueued batches first");
+    select_batch_set(c, 0);
+    int nu = 0;
+    ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
+    if (s != ELLC_OK) return s;
+#ifdef ELLC_DIAG
+    c->plan_persist = false;
+    int reserved = 0;
+    if (c->use_fused && c->use_run && c->use_persist) {
+      reserved = plan_runs(c, B, false, true).max_run_blocks;
+      if (run_reserve(c, reserved)) c->plan_persist = true;
+      else reserved = 0;
+    }
+    c->untracked_reserved += reserved;   // given back by the caller once the stream has drained (ellc_profile_align)
+#endif
+    return launch_align_graph(c, B, nu, mode, save_weights, 0, false);
+  }
+  // may this batch share a launch with others? full batches of one mode, nothing per-slot written (saved weights), not the
+  // state-driven tracking schedule, not the diagnostic run kernels
+  const bool co = c->coalesce > 1 && B == MB && !(save_weights && mode == ELLC_MODE_FCA) && !schedule_is_adaptive(c, mode, B) && !c->use_run;
+  if (c->open_set >= 0) {
+    ellc_ctx::BatchSet& og = c->batch_set[c->open_set];
+    if (!(co && og.coalescable && og.mode == mode && og.fill < c->coalesce)) {
+      const ellc_status s = launch_group(c, c->open_set);
+      if (s != ELLC_OK) return s;
+    }
+  }
+  int set = c->open_set;
+  if (set < 0) {
+    // the lowest free set: a caller with one batch at a time stays on set 0
+    if (c->n_inflight >= c->max_inflight)
+      return fail(c, ELLC_ERR_NOT_READY, "the limit of batches in flight is reached: call ellc_align_fetch first");
+    for (int p = 0; p < c->n_sets && set < 0; p++)
+      if (c->batch_set[p].fill == 0) set = p;
+    if (set < 0) return fail(c, ELLC_ERR_NOT_READY, "no batch set is free: call ellc_align_fetch first");
+  }
+  ellc_ctx::BatchSet& bs = c->batch_set[set];
+  const int slice = bs.fill;
+  select_batch_set(c, set, slice);
+  int nu = 0;
+  std::vector<int> uniq;
+  ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu, &uniq);
+  if (s != ELLC_OK) return s;
+  // saved weights are accumulated per keyframe slot (wlast, weight plane, numWeightsAdded): two alignments of one batch on the
+  // same slot would race on them
+  if (save_weights && mode == ELLC_MODE_FCA && nu < B)
+    return fail(c, ELLC_ERR_BAD_ARG, "save_weights needs a different keyframe slot for every alignment of the batch");
+  if (slice == 0) {
+    bs.coalescable = co;
     bs.mode = mode;
     bs.save_weights = save_weights ? 1 : 0;
-    bs.adaptive = schedule_is_adaptive(c, mode, B);
-    bs.resolved = false;
-    bs.joined = (set == 0);
-    bs.run_reserved = reserved;
-    c->inflight[c->n_inflight++] = set;
-  } else {
-    c->untracked_reserved += reserved;   // given back by the caller once the stream has drained (ellc_profile_align)
+    bs.fetched = 0;
+    bs.launched = false;
   }
-  return ELLC_OK;
+  bs.slice_B[slice] = B;
+  bs.fill = slice + 1;
+  c->inflight[c->n_inflight++] = set * ellc_ctx::MAX_COALESCE + slice;
+  if (save_weights && mode == ELLC_MODE_FCA)
+    for (int b = 0; b < B; b++)
+      for (int l = 0; l < c->L; l++) c->kf_num_weights[kf_slots[b]][l]++;
+  if (co && bs.fill < c->coalesce) {
+    c->open_set = set;   // waits for more batches (or for a fetch / another entry point, which launch it as it is)
+    return ELLC_OK;
+  }
+  s = launch_group(c, set);
+  if (s != ELLC_OK) {   // the batches of the group leave the queue: nothing of it runs
+    int w = 0;
+    for (int i = 0; i < c->n_inflight; i++)
+      if (c->inflight[i] / ellc_ctx::MAX_COALESCE != set) c->inflight[w++] = c->inflight[i];
+    c->n_inflight = w;
+    free_set(c, set);
+  }
+  return s;
 }
 
 ellc_status ellc_align_enqueue(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int save_weights) {
@@ -1393,28 +1524,33 @@ ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters
   ELLC_ENTER_BATCH(c);
   if (!c || B < 1 || B > c->cfg.max_batch) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (c->n_inflight < 1) return fail(c, ELLC_ERR_NOT_READY, "ellc_align_fetch: no batch in flight");
-  const int oldest = c->inflight[0];
-  const ellc_ctx::BatchSet& bs = c->batch_set[oldest];   // the oldest batch
-  if (B != bs.B) return fail(c, ELLC_ERR_BAD_ARG, "ellc_align_fetch: the oldest batch in flight has a different size");
-  const ellc_status rs = resolve_batch(c, oldest);   // waits; runs the continuation of a state-driven schedule if one is needed
+  const int set = c->inflight[0] / ellc_ctx::MAX_COALESCE, slice = c->inflight[0] % ellc_ctx::MAX_COALESCE;   // the oldest batch
+  ellc_ctx::BatchSet& bs = c->batch_set[set];
+  if (B != bs.slice_B[slice]) return fail(c, ELLC_ERR_BAD_ARG, "ellc_align_fetch: the oldest batch in flight has a different size");
+  ellc_status rs = ELLC_OK;
+  if (!bs.launched) rs = launch_group(c, set);   // its group was still open: it runs as it is
+  if (rs == ELLC_OK) rs = resolve_batch(c, set);   // waits; runs the continuation of a state-driven schedule if one is needed
   for (int i = 1; i < c->n_inflight; i++) c->inflight[i - 1] = c->inflight[i];   // the batch leaves the queue either way
   c->n_inflight--;
-#ifdef ELLC_DIAG
-  run_release(c, bs.run_reserved);
-#endif
-  c->batch_set[oldest].run_reserved = 0;
-  if (rs != ELLC_OK) return rs;
-  for (int b = 0; b < B; b++)
-    if (bs.result_h[b].pad != 0) {   // a run gave up waiting for its other blocks (bounded spin): clear the error words, report
-      (void)hipMemsetAsync(bs.sync_d, 0, 256 * (size_t)c->cfg.max_batch, c->stream);
-      return fail(c, ELLC_ERR_HIP, "ellc_align_fetch: the schedule did not complete on the device (no result was exported)");
-    }
-  for (int b = 0; b < B; b++) {
-    if (out_pose) std::memcpy(out_pose + b * 6, bs.result_h[b].pose, 24);
-    if (out_iters) for (int l = 0; l < c->L; l++) out_iters[b * c->L + l] = bs.result_h[b].iters[l];
-    if (out_weighted) out_weighted[b] = bs.result_h[b].weighted;
+  const ellc::AlignResult* res = bs.result_h + slice * c->cfg.max_batch;
+  bs.fetched++;
+  const bool last = (bs.fetched >= bs.fill);
+  ellc_status out = rs;
+  if (out == ELLC_OK) {
+    for (int b = 0; b < B && out == ELLC_OK; b++)
+      if (res[b].pad != 0) {   // a run gave up waiting for its other blocks (bounded spin): clear the error words, report
+        (void)hipMemsetAsync(bs.sync_d, 0, 256 * (size_t)c->group_cap, c->stream);
+        out = fail(c, ELLC_ERR_HIP, "ellc_align_fetch: the schedule did not complete on the device (no result was exported)");
+      }
   }
-  return ELLC_OK;
+  if (out == ELLC_OK)
+    for (int b = 0; b < B; b++) {
+      if (out_pose) std::memcpy(out_pose + b * 6, res[b].pose, 24);
+      if (out_iters) for (int l = 0; l < c->L; l++) out_iters[b * c->L + l] = res[b].iters[l];
+      if (out_weighted) out_weighted[b] = res[b].weighted;
+    }
+  if (last) free_set(c, set);
+  return out;
 }
 
 ellc_status ellc_align(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, const float* init_pose, int mode, int save_weights,
@@ -1442,6 +1578,7 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   if (!c || !pose || level < 0 || level >= c->L) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_gn_iterate: fetch the enqueued batches first");
   int nu = 0;
+  select_batch_set(c, 0);
   ellc_status s = stage_batch(c, 1, &kf_slot, &frame_slot, pose, &nu);
   if (s != ELLC_OK) return s;
   enqueue_stage_in(c, 0);   // staging only: the state keeps the level's H^-1 (gn_set_pose0)
@@ -1513,7 +1650,8 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   if (!c || level < 0 || level >= c->L || reps < 1) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   if (c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_profile_gn_kernel: fetch the enqueued batches first");
   int nu = 0;
-  ellc_status s = stage_batch(c, B, kf_slots, frame_slots, nullptr, &nu);
+  select_batch_set(c, 0);
+  ellc_status s = stage_batch(c, B, kf_slots, frame_slots, nullptr, &nu, nullptr, true);   // up to a whole launch group (cfg.coalesce batches)
   if (s != ELLC_OK) return s;
   enqueue_stage_in(c, 0);
   s = run_prep(c, nu, c->fast ? 8 : 2);
@@ -1533,8 +1671,8 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     fa.prev_level = level;
     fa.prev_nblk = a.nblk;
     fa.early_exit = 0;
-    fa.stride_state = c->cfg.max_batch;
-    fa.stride_part = (size_t)c->cfg.max_batch * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+    fa.stride_state = c->group_cap;
+    fa.stride_part = (size_t)c->group_cap * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
     auto launch = [&]() {
       launch_fused(c, grd, blk, fa, c->stream);
       fa.seq++;

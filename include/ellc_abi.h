@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define ELLC_MAX_LEVELS 8
-#define ELLC_ABI_VERSION 3
+#define ELLC_ABI_VERSION 4
 
 typedef enum {
   ELLC_OK = 0,
@@ -70,6 +70,10 @@ typedef struct {
                                  * fine-level grids for sharing the device. Fixed per context, so a batch's result does
                                  * not depend on what else happens to be in flight (the grid fixes the summation order) */
   int arith;                    /* ELLC_ARITH_EXACT (default) or ELLC_ARITH_FAST: arithmetic of the Gauss-Newton pixel pass and solve */
+  int coalesce;                 /* 1 (default) .. 3: full batches (B = max_batch) enqueued one after the other are launched side by
+                                 * side, up to this many per launch sequence, and 3 x coalesce batches may be in flight. Fixed per
+                                 * context: a full batch's grids are those of a full group whether it runs alone or not, so its
+                                 * result does not depend on what it was launched with */
 } ellc_config;
 
 typedef struct ellc_ctx ellc_ctx;

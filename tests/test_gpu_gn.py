@@ -368,17 +368,20 @@ def test_two_contexts_on_two_threads(ellc):
     assert not bad, bad[:3]
 
 
-@pytest.mark.parametrize("seed,concurrent", [(1, 3), (2, 3), (3, 1)])
-def test_pipelined_calls_equal_the_same_calls_made_one_by_one(ellc, seed, concurrent):
+@pytest.mark.parametrize("seed,concurrent,coalesce", [(1, 3, 1), (2, 3, 1), (3, 1, 1), (4, 3, 3), (5, 3, 2), (6, 12, 3)])
+def test_pipelined_calls_equal_the_same_calls_made_one_by_one(ellc, seed, concurrent, coalesce):
     """Differential test of the asynchronous queue: a random sequence of batches (FCA and ICA, with and without saved
     weights, overlapping and disjoint keyframe slots), frame / keyframe uploads and depth updates is applied to two
-    contexts — one keeps up to three batches in flight, the other runs every call synchronously. Every fetched result
-    and the final weight planes must be identical: concurrency may change when things run, never what they compute."""
+    contexts — one keeps up to three batches in flight (4 x coalesce with cfg.coalesce > 1, where full batches enqueued one
+    after the other run side by side in one launch sequence), the other runs every call synchronously. Every fetched result
+    and the final weight planes must be identical: concurrency and grouping may change when things run, never what they
+    compute."""
     w, h, L = 160, 120, 3
     rng = np.random.default_rng(seed)
     pairs = [synth.make_pair(w, h, seed=300 + i, rot=0.003 + 0.001 * i, trans=0.01) for i in range(5)]
     mi = (3, 4, 5)
-    kw = dict(early_exit=int(rng.integers(0, 2)), max_iter=mi, max_batch=4, concurrent_batches=concurrent)
+    kw = dict(early_exit=int(rng.integers(0, 2)), max_iter=mi, max_batch=4, concurrent_batches=concurrent, coalesce=coalesce)
+    limit = 3 if coalesce == 1 else 4 * coalesce
     a = gpu_problem(ellc, w, h, L, pairs, **kw)
     b = gpu_problem(ellc, w, h, L, pairs, **kw)
     for ctx in (a, b):
@@ -396,10 +399,12 @@ def test_pipelined_calls_equal_the_same_calls_made_one_by_one(ellc, seed, concur
             assert all(np.array_equal(x, y) for x, y in zip(got, ref))
             checked += 1
 
-    for step in range(60):
+    for step in range(60 if coalesce == 1 else 120):
         op = rng.random()
         if op < 0.6:
             B = int(rng.integers(1, 5))
+            if coalesce > 1 and rng.random() < 0.6:
+                B = 4                                  # full batches: the ones that share a launch
             kf = rng.integers(0, 5, size=B).astype(np.int32)
             fr = rng.integers(0, 5, size=B).astype(np.int32)
             mode = int(rng.integers(0, 2))
@@ -408,7 +413,7 @@ def test_pipelined_calls_equal_the_same_calls_made_one_by_one(ellc, seed, concur
                 kf = np.unique(kf).astype(np.int32)   # one accumulation per keyframe and call, as the reference does
                 fr, B = fr[: kf.size], kf.size
             init = (rng.normal(size=(B, 6)) * 1e-3).astype(np.float32)
-            if len(expected) == 3:
+            if len(expected) == limit:
                 drain(1)
             a.align_enqueue(kf, fr, init_pose=init, mode=mode, save_weights=sw)
             expected.append((B, b.align(kf, fr, init_pose=init, mode=mode, save_weights=sw)))
