@@ -442,7 +442,8 @@ def pmc_traffic(a, B, G, arith):
         try:
             d = json.load(open(f))
             run = d["profile_kernel_run"]
-            if run["batch"] == B and run["level"] == 0 and (run.get("concurrent_batches", 1) > 1) == (G > 1) and run.get("arith", "exact") == arith:
+            if (run["batch"] == B and run["level"] == 0 and (run.get("concurrent_batches", 1) > 1) == (G > 1) and run.get("arith", "exact") == arith and
+                    run.get("coalesce", 1) == max(1, min(3, a.coalesce))):
                 best = (d["hbm_traffic"]["traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
         except Exception:
             pass

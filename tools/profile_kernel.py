@@ -20,25 +20,27 @@ ap.add_argument("--level", type=int, default=0)
 ap.add_argument("--dense", action="store_true")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--calib-mb", type=int, default=512)
-ap.add_argument("--inflight", type=int, default=3, help="cfg.concurrent_batches, as bench.py's default (it sizes the grid)")
+ap.add_argument("--inflight", type=int, default=8, help="cfg.concurrent_batches, as bench.py's default (it sizes the grid)")
+ap.add_argument("--coalesce", type=int, default=2, help="cfg.coalesce, as bench.py's default: the launch covers this many batches side by side")
 ap.add_argument("--arith", choices=["fast", "exact"], default="fast")
 a = ap.parse_args()
 W, H, L, B = a.width, a.height, a.levels, a.batch
+K = B * a.coalesce   # alignments of one launch: a group of full batches
 fx, fy, cx, cy = synth.default_intrinsics(W, H)
 # the bench workload: B keyframes of one scene against ONE frame (semi-dense); dense (C4 shape): two scenes, own frame each
 pairs = [synth.make_pair(W, H, seed=0xC4 + i, dense=True) for i in range(2)] if a.dense else synth.make_shared_frame_batch(W, H, B, seed=0x5EED)
-ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_keyframes=B, max_frames=B, max_batch=B,
-                                     concurrent_batches=a.inflight, arith=api.ARITH_FAST if a.arith == "fast" else api.ARITH_EXACT))
-for b in range(B):
+ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_keyframes=K, max_frames=K, max_batch=B,
+                                     concurrent_batches=a.inflight, coalesce=a.coalesce, arith=api.ARITH_FAST if a.arith == "fast" else api.ARITH_EXACT))
+for b in range(K):
     p = pairs[b % len(pairs)]
     ctx.keyframe_upload(b, p["kf_image"]); ctx.keyframe_set_depth(b, p["depth0"], p["var0"])
-    if a.dense or b == 0:
-        ctx.frame_upload(b, p["cur_image"])
-slots = np.arange(B, dtype=np.int32)
-ms, alg, V = ctx.profile_gn_kernel(slots, slots if a.dense else np.zeros(B, np.int32), a.level, reps=a.reps)
+    if a.dense or b % B == 0:
+        ctx.frame_upload(b if a.dense else b // B, p["cur_image"])
+slots = np.arange(K, dtype=np.int32)
+ms, alg, V = ctx.profile_gn_kernel(slots, slots if a.dense else (slots // B).astype(np.int32), a.level, reps=a.reps)
 cal_bytes = a.calib_mb << 20
 cms = ctx.profile_calibrate_read(cal_bytes, reps=5)
-print(json.dumps({"kernel": "gn_fca_fused", "arith": a.arith, "size": [W, H, L], "dense": bool(a.dense), "level": a.level, "batch": B, "concurrent_batches": a.inflight, "avg_ms": ms, "algorithmic_bytes": alg, "valid_pixels": V,
+print(json.dumps({"kernel": "gn_fca_fused", "arith": a.arith, "size": [W, H, L], "dense": bool(a.dense), "level": a.level, "batch": B, "coalesce": a.coalesce, "alignments_per_launch": K, "concurrent_batches": a.inflight, "avg_ms": ms, "algorithmic_bytes": alg, "valid_pixels": V,
                   "achieved_GBps": alg / ms / 1e6, "launches": a.reps + 3, "calib_bytes_per_launch": cal_bytes, "calib_avg_ms": cms,
                   "calib_GBps": cal_bytes / cms / 1e6, "calib_launches": 6}))
 ctx.close()

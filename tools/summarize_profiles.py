@@ -107,15 +107,19 @@ if f:
         n = r["Kernel_Name"].split("(")[0]
         by[n] += 1
         dur[n] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    batches = sum(c for n, c in by.items() if "gn_fused_finish" in n)   # one final solve per batch
+    seqs = sum(c for n, c in by.items() if "gn_fused_finish" in n)   # one final solve per launch sequence
+    # a launch sequence covers a group of batches side by side (cfg.coalesce): the finish kernel runs one block per alignment
+    fin = [int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])) for r in rows if "gn_fused_finish" in r["Kernel_Name"]]
+    per_seq = (sum(fin) / len(fin)) if fin else 0
     rec = {"round": rnd, "source": "rocprofv3 --kernel-trace -- python3 bench.py --steps 10 --warmup 3 --trace-only",
-           "batches": batches, "kernels": {}}
+           "launch_sequences": seqs, "alignments_per_sequence_mean": per_seq, "batches_of_32_per_sequence_mean": per_seq / 32.0, "kernels": {}}
     for n, c in sorted(by.items(), key=lambda kv: -dur[kv[0]]):
-        rec["kernels"][n] = {"launches": c, "launches_per_batch": (c / batches) if batches else None, "avg_us": dur[n] / c, "total_us": dur[n]}
-    rec["alignment_launches_per_batch"] = sum(v["launches_per_batch"] for k, v in rec["kernels"].items()
-                                              if batches and any(t in k for t in ("gn_", "prep_", "stage_in", "ica_hinv")))
+        rec["kernels"][n] = {"launches": c, "launches_per_sequence": (c / seqs) if seqs else None, "avg_us": dur[n] / c, "total_us": dur[n]}
+    rec["alignment_launches_per_sequence"] = sum(v["launches_per_sequence"] for k, v in rec["kernels"].items()
+                                                 if seqs and any(t in k for t in ("gn_", "prep_", "stage_in", "ica_hinv")))
+    rec["alignment_launches_per_batch_of_32"] = rec["alignment_launches_per_sequence"] / (per_seq / 32.0) if per_seq else None
     json.dump(rec, open(os.path.join(dst, "%s_launches_per_batch.json" % rnd), "w"), indent=1)
-    print("launches per batch:", rec["alignment_launches_per_batch"])
+    print("launches per sequence:", rec["alignment_launches_per_sequence"], "alignments per sequence:", per_seq)
 
 # ---- depth kernels: average duration from the kernel trace, algorithmic bytes per pixel, PMC traffic
 f = newest(os.path.join("depth_trace", "*", "*_kernel_trace.csv"))
