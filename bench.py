@@ -247,8 +247,8 @@ def main():
         # ---- roofline of the dominant kernel (FCA residual/Jacobian/accumulate at level 0), HIP events on the library's stream
         k0 = wl.level0_kernel()
         traffic, tsrc = pmc_traffic(a, B, G, a.arith)
-        out["roofline"] = dict({"bound": "hbm", "kernel": "gn_fca_fused (level 0, batch %d, arith %s): solve of the previous iteration + residual/Jacobian/"
-                                "accumulate" % (B, a.arith), "peak": PEAK_GBPS, "unit": "GB/s", "traffic": traffic, "traffic_source": tsrc,
+        out["roofline"] = dict({"bound": "hbm", "kernel": "gn_fca_fused (level 0, one launch group = %d batches of %d side by side, arith %s): solve of the previous "
+                                "iteration + residual/Jacobian/accumulate" % (min(wl.coalesce, G), B, a.arith), "peak": PEAK_GBPS, "unit": "GB/s", "traffic": traffic, "traffic_source": tsrc,
                                 "level0_gn_iterations_per_s": B / (k0["avg_launch_ms"] * 1e-3)}, **k0)
         # what a kernel that only reads reaches on this box (2 GiB, 16-byte lanes, far larger than the 256 MB Infinity Cache)
         cal_bytes = 2 << 30

@@ -30,7 +30,8 @@ def default_config(width, height, levels=4, **kw):
 
 class Context:
     """Resident keyframe / frame slots, one depth map and an in-order queue of work on the GPU (ellc_ctx); up to three
-    alignment batches may be in flight at once (align_enqueue / align_fetch)."""
+    alignment batches may be in flight at once (align_enqueue / align_fetch) — 4 x cfg.coalesce with cfg.coalesce > 1, where
+    full batches enqueued one after the other run side by side in one launch sequence."""
 
     def __init__(self, cfg):
         self.cfg = cfg
