@@ -168,9 +168,10 @@ def main():
         else:   # rehearsal of several ranks on one GPU (RCCL refuses two ranks on one device): the same entry points over TCP
             comm = sharding.Comm(world, rank, max_total=B * world, transport="tcp", port=int(os.environ.get("MASTER_PORT", "29500")) + 17)
         outstanding = [0]
+        depth = min(G, 4)   # gathers in flight: the library keeps a ring of four (ellc_comm)
 
         def on_fetch(pose, iters, wgt):
-            if outstanding[0] == G:
+            if outstanding[0] == depth:
                 assert comm.finish(B * world).shape == (B * world, sharding.RECORD)
                 outstanding[0] -= 1
             comm.start(B * world, sharding.pack_results(pose, iters, wgt))
@@ -181,10 +182,11 @@ def main():
                 assert comm.finish(B * world).shape == (B * world, sharding.RECORD)
                 outstanding[0] -= 1
     else:
-        gatherer = sharding.ResultGatherer(B * world, device=(coll_dev if world > 1 else None), depth=G)
+        depth = min(G, 4)
+        gatherer = sharding.ResultGatherer(B * world, device=(coll_dev if world > 1 else None), depth=depth)
 
         def on_fetch(pose, iters, wgt):
-            if len(gatherer.pending) == G:
+            if len(gatherer.pending) == depth:
                 assert gatherer.finish().shape == (B * world, sharding.RECORD)
             gatherer.start(sharding.pack_results(pose, iters, wgt))
 

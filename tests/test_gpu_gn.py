@@ -440,6 +440,45 @@ def test_pipelined_calls_equal_the_same_calls_made_one_by_one(ellc, seed, concur
     a.close(); b.close()
 
 
+def test_coalesced_groups_flush_and_limits(ellc):
+    """cfg.coalesce = 2: a full batch waits for a second one to share its launch sequence; a fetch, or any other entry point,
+    launches it as it is; 4 x 2 batches may be in flight, the ninth is refused; every result equals the synchronous call's."""
+    w, h, L, B = 160, 120, 3, 2
+    pairs = [synth.make_pair(w, h, seed=400 + i, rot=0.004, trans=0.012) for i in range(4)]
+    kw = dict(early_exit=0, max_iter=(3, 4, 5), max_batch=B, concurrent_batches=8, coalesce=2)
+    ctx = gpu_problem(ellc, w, h, L, pairs, **kw)
+    batches = [np.array(x, np.int32) for x in ([0, 1], [2, 3], [1, 2], [3, 0])]
+    ref = [ctx.align(q, q) for q in batches]                     # a full batch alone: the grids of a full group all the same
+    # one batch, then a fetch: the open group is launched with one batch
+    ctx.align_enqueue(batches[0], batches[0])
+    got = ctx.align_fetch(B)
+    assert all(np.array_equal(x, y) for x, y in zip(got, ref[0]))
+    # one batch, then another entry point (an upload of the same pixels): launched before the upload, result unchanged
+    ctx.align_enqueue(batches[1], batches[1])
+    ctx.frame_upload(2, pairs[2]["cur_image"])
+    got = ctx.align_fetch(B)
+    assert all(np.array_equal(x, y) for x, y in zip(got, ref[1]))
+    # eight in flight (four groups of two), the ninth is refused and changes nothing
+    for i in range(8):
+        ctx.align_enqueue(batches[i % 4], batches[i % 4])
+    with pytest.raises(ellc.EllcError):
+        ctx.align_enqueue(batches[0], batches[0])
+    for i in range(8):
+        got = ctx.align_fetch(B)
+        assert all(np.array_equal(x, y) for x, y in zip(got, ref[i % 4])), i
+    # a partial batch (B < max_batch) never shares a launch; it may sit between full ones
+    ctx.align_enqueue(batches[0], batches[0])
+    ctx.align_enqueue(batches[1][:1], batches[1][:1])
+    ctx.align_enqueue(batches[2], batches[2])
+    r0 = ctx.align_fetch(B); r1 = ctx.align_fetch(1); r2 = ctx.align_fetch(B)
+    assert all(np.array_equal(x, y) for x, y in zip(r0, ref[0])) and all(np.array_equal(x, y) for x, y in zip(r2, ref[2]))
+    one = ctx.align(batches[1][:1], batches[1][:1])
+    assert all(np.array_equal(x, y) for x, y in zip(r1, one))
+    with pytest.raises(ellc.EllcError):
+        ctx.align_fetch(B)                                       # nothing in flight
+    ctx.close()
+
+
 def test_save_weights_rejects_a_shared_keyframe_slot(ellc):
     """Saved weights are accumulated per keyframe slot: a batch in which two alignments share one is refused, not raced."""
     pair = synth.make_pair(160, 120, seed=1)
