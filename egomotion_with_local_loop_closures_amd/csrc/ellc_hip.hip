@@ -391,7 +391,9 @@ static void set_age_split(ellc_ctx* c, FusedArgs& fa, int B) {
   fa.age_rounds = 0;
   for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
   const int per_round = std::max(1, c->resident_blocks / 4);   // one block per CU
-  const int total = fa.g.nblk * B;
+  // decided for the batch size the grids are chosen for (grid_batch): the split is part of what fixes a batch's bits, so a full
+  // batch gets the same one whether it runs alone or side by side with others (the balance is tuned for the full group)
+  const int total = fa.g.nblk * grid_batch(c, B);
   if (!c->age_balance || total % per_round != 0) return;
   const int R = total / per_round;
   if (R < 2 || R > 4 || fa.g.nblk % R != 0) return;

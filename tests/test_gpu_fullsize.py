@@ -162,6 +162,53 @@ def test_c2_32_keyframes_against_one_frame(oracle, ellc, lc_batch, arith, mode):
     ctx.close()
 
 
+@pytest.mark.parametrize("arith,coalesce", [("fast", 2), ("fast", 3), ("exact", 2)])
+def test_c2_coalesced_groups_equal_the_batches_alone(oracle, ellc, lc_batch, arith, coalesce):
+    """cfg.coalesce at the benchmark's size (640x480, batches of 32, where the age-balanced split of the fine-level grids is
+    active): batches launched side by side in one sequence give, bit for bit, what each gives when it runs alone — full
+    groups, a partial group flushed by the fetch, and the pipelined pattern bench.py uses — and stay within 1e-5 of the oracle."""
+    W, H, L, B = 640, 480, 4, 32
+    G = coalesce + 1
+    fx, fy, cx, cy = lc_batch[0]["intrinsics"]
+    cfg = ellc.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_keyframes=G * B, max_frames=G, max_batch=B,
+                              concurrent_batches=4 * coalesce, coalesce=coalesce, arith=ellc.ARITH_FAST if arith == "fast" else ellc.ARITH_EXACT)
+    ctx = ellc.Context(cfg)
+    rng = np.random.default_rng(5)
+    for g in range(G):
+        ctx.frame_upload(g, lc_batch[0]["cur_image"])
+        order = rng.permutation(B)                       # every slot group holds the 32 keyframes in its own order
+        for b in range(B):
+            p = lc_batch[int(order[b])]
+            ctx.keyframe_upload(g * B + b, p["kf_image"])
+            ctx.keyframe_set_depth(g * B + b, p["depth0"], p["var0"])
+        if g == 0:
+            first = order
+    kf = [np.arange(B, dtype=np.int32) + g * B for g in range(G)]
+    fr = [np.full(B, g, np.int32) for g in range(G)]
+    alone = [ctx.align(kf[g], fr[g]) for g in range(G)]
+    # against the oracle (slot group 0, three alignments)
+    for b in (0, 13, 31):
+        _, okf, ocur, odm = oracle_problem(oracle, W, H, L, lc_batch[int(first[b])], early_exit=0)
+        pose_ref, iters_ref, _ = oracle.align(okf, ocur, odm.depth_pyr())
+        assert list(alone[0][1][b]) == list(iters_ref) and np.linalg.norm(alone[0][0][b] - pose_ref) <= 1e-5
+    # full groups and one partial group (flushed by the fetch)
+    for g in range(G):
+        ctx.align_enqueue(kf[g], fr[g])
+    for g in range(G):
+        got = ctx.align_fetch(B)
+        assert all(np.array_equal(x, y) for x, y in zip(got, alone[g])), g
+    # the pipelined pattern: keep the queue full, fetch the oldest, enqueue the next
+    n_fly = min(4 * coalesce, G)
+    for s in range(n_fly):
+        ctx.align_enqueue(kf[s % G], fr[s % G])
+    for s in range(5 * G):
+        got = ctx.align_fetch(B)
+        assert all(np.array_equal(x, y) for x, y in zip(got, alone[s % G])), s
+        if s + n_fly < 5 * G:
+            ctx.align_enqueue(kf[(s + n_fly) % G], fr[(s + n_fly) % G])
+    ctx.close()
+
+
 def test_normal_equations_properties(ellc):
     """H is symmetric positive semi-definite; scaling all weights by c scales H and b by c and leaves delta unchanged (ICA)."""
     W, H, L = 320, 240, 4

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak test of the concurrent batch pipeline: thousands of pipelined batches over three slot groups, with uploads of the
+"""Soak test of the concurrent batch pipeline (usage: soak_pipeline.py [steps] [B] [coalesce]): thousands of pipelined batches over the slot groups, with uploads of the
 same images interleaved at random (they must not change anything, but they exercise the cross-stream ordering); every
 fetched table must equal, bit for bit, the one the same group produced on its first, synchronous, run."""
 import os
@@ -13,11 +13,13 @@ from egomotion_with_local_loop_closures_amd import api, synth  # noqa: E402
 
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32   # 1 or 2: the state-driven early-exit schedule (continuations included)
-W, H, L, G = 640, 480, 4, 3
+CO = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # cfg.coalesce: 2 or 3 runs groups of batches per launch sequence, 4 x CO in flight
+W, H, L = 640, 480, 4
+G = 3 if CO == 1 else 4 * CO
 fx, fy, cx, cy = synth.default_intrinsics(W, H)
 pairs = [synth.make_pair(W, H, seed=0x5EED + i) for i in range(5)] + [synth.make_pair(W, H, seed=22, rot=0.03, trans=0.08)]   # the last: > 20 iterations
 ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=G * B, max_frames=G * B,
-                                     max_batch=B, concurrent_batches=G))
+                                     max_batch=B, concurrent_batches=G, coalesce=CO))
 for b in range(G * B):
     p = pairs[(b * 7) % len(pairs)]
     ctx.keyframe_upload(b, p["kf_image"]); ctx.keyframe_set_depth(b, p["depth0"], p["var0"]); ctx.frame_upload(b, p["cur_image"])
