@@ -41,8 +41,8 @@ def parse():
     ap.add_argument("--mode", choices=["fca", "ica"], default="fca")
     ap.add_argument("--arith", choices=["fast", "exact"], default="fast", help="arithmetic of the Gauss-Newton pixel pass and solve (cfg.arith): "
                     "fast = tolerance mode (pose <= 1e-5 vs the oracle), exact = per-pixel bit-exact mode")
-    ap.add_argument("--inflight", type=int, default=8, help="batches in flight per GPU (1 .. 4 x --coalesce; 1 .. 3 with --coalesce 1), each on its own slot group")
-    ap.add_argument("--coalesce", type=int, default=2, help="cfg.coalesce: full batches enqueued one after the other run side by side in one "
+    ap.add_argument("--inflight", type=int, default=16, help="batches in flight per GPU (1 .. 4 x --coalesce; 1 .. 3 with --coalesce 1), each on its own slot group")
+    ap.add_argument("--coalesce", type=int, default=4, help="cfg.coalesce: full batches enqueued one after the other run side by side in one "
                     "launch sequence, up to this many (1: every batch is launched by itself, at most three in flight)")
     ap.add_argument("--early-exit", action="store_true", help="informational: the reference's early exit on (data-dependent iteration counts; "
                     "value then counts the iterations actually executed)")
@@ -65,7 +65,7 @@ class Workload:
         self.api = api
         self.W, self.H, self.L = W or a.width, H or a.height, L or a.levels
         self.B = B or a.batch
-        self.coalesce = max(1, min(3, a.coalesce if coalesce is None else coalesce))
+        self.coalesce = max(1, min(4, a.coalesce if coalesce is None else coalesce))
         self.G = G or max(1, min(4 * self.coalesce if self.coalesce > 1 else 3, a.inflight))
         self.sched = sched or [4, 7, 9, 12, 12, 12, 12, 12][:self.L]
         fx, fy, cx, cy = scenes[0]["intrinsics"]
@@ -287,7 +287,7 @@ def main():
                                      "pose_l2_diff_between_modes_max": float(np.linalg.norm(p2 - pose, axis=1).max())}
             w2.close()
             # ---- early exit on (the reference's default), one batch at a time: informational
-            w3 = Workload(api, a, scenes, a.arith, dev_index, early_exit=1, G=1, shared_frame=not a.dense)
+            w3 = Workload(api, a, scenes, a.arith, dev_index, early_exit=1, G=1, shared_frame=not a.dense, coalesce=1)
             _, it3, _ = w3.ctx.align(w3.kf[0], w3.fr[0], mode=w3.mode)
             t3 = time.perf_counter()
             for _ in range(10):
@@ -445,7 +445,7 @@ def pmc_traffic(a, B, G, arith):
             d = json.load(open(f))
             run = d["profile_kernel_run"]
             if (run["batch"] == B and run["level"] == 0 and (run.get("concurrent_batches", 1) > 1) == (G > 1) and run.get("arith", "exact") == arith and
-                    run.get("coalesce", 1) == max(1, min(3, a.coalesce))):
+                    run.get("coalesce", 1) == max(1, min(4, a.coalesce))):
                 best = (d["hbm_traffic"]["traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
         except Exception:
             pass

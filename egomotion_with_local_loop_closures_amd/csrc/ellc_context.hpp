@@ -68,7 +68,7 @@ struct ellc_ctx {
   // batches may be in flight (max_inflight): it takes the batches that arrive while the oldest group is being fetched. The members above point at the set / slice of the batch being
   // staged or the group being launched. All other entry points work on `stream`, launch a group that is still open and make
   // the stream wait for the groups in flight, so a caller sees one in-order queue per context as before.
-  static constexpr int MAX_COALESCE = 3;
+  static constexpr int MAX_COALESCE = 4;
   static constexpr int SETS = 4 * MAX_COALESCE + 1;   // of which max_inflight + 1 are used (n_sets): every batch in flight may be a group of its own
   static constexpr int STREAMS = 3;
   struct BatchSet {
@@ -87,7 +87,7 @@ struct ellc_ctx {
     int fetched = 0;                                // of which fetched (the set is free again when fetched == fill)
     bool launched = false;
     bool coalescable = false;                       // further full batches of the same mode may join until it is launched
-    int slice_B[MAX_COALESCE] = {0, 0, 0};          // size of each staged batch
+    int slice_B[MAX_COALESCE] = {0, 0, 0, 0};       // size of each staged batch
     int stream_idx = 0;                             // the batch stream it was launched on (0: the context's main stream)
     std::vector<int> kf_slots;                      // unique keyframe slots of the group
     int B = 0;                                      // alignments the launch covers

@@ -66,11 +66,11 @@ typedef struct {
   int max_frames;               /* current-frame slots resident in HBM */
   int max_batch;                /* largest B accepted by ellc_align */
   int device;                   /* HIP device ordinal */
-  int concurrent_batches;       /* 1..12: how many batches the caller keeps in flight (ellc_align_enqueue); > 1 sizes the
+  int concurrent_batches;       /* 1..16: how many batches the caller keeps in flight (ellc_align_enqueue); > 1 sizes the
                                  * fine-level grids for sharing the device. Fixed per context, so a batch's result does
                                  * not depend on what else happens to be in flight (the grid fixes the summation order) */
   int arith;                    /* ELLC_ARITH_EXACT (default) or ELLC_ARITH_FAST: arithmetic of the Gauss-Newton pixel pass and solve */
-  int coalesce;                 /* 1 (default) .. 3: full batches (B = max_batch) enqueued one after the other are launched side by
+  int coalesce;                 /* 1 (default) .. 4: full batches (B = max_batch) enqueued one after the other are launched side by
                                  * side, up to this many per launch sequence, and 3 x coalesce batches may be in flight. Fixed per
                                  * context: a full batch's grids are those of a full group whether it runs alone or not, so its
                                  * result does not depend on what it was launched with */

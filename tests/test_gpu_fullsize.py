@@ -162,7 +162,7 @@ def test_c2_32_keyframes_against_one_frame(oracle, ellc, lc_batch, arith, mode):
     ctx.close()
 
 
-@pytest.mark.parametrize("arith,coalesce", [("fast", 2), ("fast", 3), ("exact", 2)])
+@pytest.mark.parametrize("arith,coalesce", [("fast", 2), ("fast", 4), ("exact", 3)])
 def test_c2_coalesced_groups_equal_the_batches_alone(oracle, ellc, lc_batch, arith, coalesce):
     """cfg.coalesce at the benchmark's size (640x480, batches of 32, where the age-balanced split of the fine-level grids is
     active): batches launched side by side in one sequence give, bit for bit, what each gives when it runs alone — full

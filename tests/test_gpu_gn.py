@@ -368,7 +368,7 @@ def test_two_contexts_on_two_threads(ellc):
     assert not bad, bad[:3]
 
 
-@pytest.mark.parametrize("seed,concurrent,coalesce", [(1, 3, 1), (2, 3, 1), (3, 1, 1), (4, 3, 3), (5, 3, 2), (6, 12, 3)])
+@pytest.mark.parametrize("seed,concurrent,coalesce", [(1, 3, 1), (2, 3, 1), (3, 1, 1), (4, 3, 3), (5, 3, 2), (6, 12, 3), (7, 16, 4)])
 def test_pipelined_calls_equal_the_same_calls_made_one_by_one(ellc, seed, concurrent, coalesce):
     """Differential test of the asynchronous queue: a random sequence of batches (FCA and ICA, with and without saved
     weights, overlapping and disjoint keyframe slots), frame / keyframe uploads and depth updates is applied to two

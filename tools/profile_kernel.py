@@ -20,8 +20,8 @@ ap.add_argument("--level", type=int, default=0)
 ap.add_argument("--dense", action="store_true")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--calib-mb", type=int, default=512)
-ap.add_argument("--inflight", type=int, default=8, help="cfg.concurrent_batches, as bench.py's default (it sizes the grid)")
-ap.add_argument("--coalesce", type=int, default=2, help="cfg.coalesce, as bench.py's default: the launch covers this many batches side by side")
+ap.add_argument("--inflight", type=int, default=16, help="cfg.concurrent_batches, as bench.py's default (it sizes the grid)")
+ap.add_argument("--coalesce", type=int, default=4, help="cfg.coalesce, as bench.py's default: the launch covers this many batches side by side")
 ap.add_argument("--arith", choices=["fast", "exact"], default="fast")
 a = ap.parse_args()
 W, H, L, B = a.width, a.height, a.levels, a.batch
