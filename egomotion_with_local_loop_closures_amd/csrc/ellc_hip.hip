@@ -210,6 +210,7 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
     case 1: hipLaunchKernelGGL(prep_scatter<1>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL(prep_scatter<2>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL(prep_scatter<4>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
+    case 20: hipLaunchKernelGGL(prep_scatter<20>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     case 8: hipLaunchKernelGGL(prep_scatter<8>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     default: return fail(c, ELLC_ERR_BAD_ARG, "run_prep: unknown record set");
   }
@@ -1247,10 +1248,10 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
   // mask / count per level (updationOnPyrChange, ImageFunc.cpp:158) and the pose-independent per-pixel records. (Folding the
   // staging into the count launch — its tile blocks then read their keyframe slot from the pinned record, one PCIe round trip
   // per block — was measured in r02: the count launch went from 10 to 29 us at 32 keyframes; the separate 8 us launch stays.)
-  const int need = mode == ELLC_MODE_ICA ? (c->use_fused ? 4 : 1) : (c->fast ? 8 : 2);
+  const int need = mode == ELLC_MODE_ICA ? (c->use_fused ? (c->fast ? 20 : 4) : 1) : (c->fast ? 8 : 2);   // record sets of prep_scatter
   ellc_status s = run_prep(c, nu, need);
   if (s != ELLC_OK) return s;
-  if (need == 4) enqueue_ica_hinv(c, nu);
+  if (need & 4) enqueue_ica_hinv(c, nu);
   s = enqueue_schedule(c, B, mode, save_weights);
   if (s != ELLC_OK) return s;
   if (!c->use_fused)   // the fused schedules export from their finish kernel

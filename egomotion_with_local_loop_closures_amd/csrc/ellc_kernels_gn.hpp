@@ -1521,25 +1521,77 @@ __device__ __forceinline__ IcaIn ica_load(const IcaRec* irec, unsigned i) {
   in.sd[3] = c.x; in.sd[4] = c.y; in.sd[5] = c.z;
   return in;
 }
+// Tolerance mode: the pixel as a 20-byte record — one 16-byte word {x | y << 12 | I << 24, d = 1 / Z, saved weight, A} in the
+// slot's crec list and B in its cZ plane, A = fx gradx, B = fy grady of the KEYFRAME image at the integer pixel — instead of the
+// 48-byte IcaRec: the pass is bound by streaming its records (r02: 203 us for a level-0 launch over 128 alignments), and the
+// row of the template Jacobian is a handful of multiply-adds of (A, B, p, q, d):  J = [-(q T + B), p T + A, B p - A q, A d,
+// B d, -d T], T = A p + B q (PixelWisePyramid.cpp:561-680 in the form fcaf_pixel uses). H^-1 still comes from the
+// compaction's exact row (ica_hinv).
+struct IcaInF { uint32_t xyI; float d, W, A, B; };
+__device__ __forceinline__ IcaInF ica_load_fast(const KfLevelDev& K, unsigned i) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = *(const ELLC_GLOBAL u32x4*)((const ELLC_GLOBAL char*)K.crec + i * 16u);
+  IcaInF in;
+  const uint32_t w1 = v.y, w2 = v.z, w3 = v.w;   // (copied first: bit_cast of a vector element expression reads element 0)
+  in.xyI = v.x; in.d = __builtin_bit_cast(float, w1); in.W = __builtin_bit_cast(float, w2); in.A = __builtin_bit_cast(float, w3);
+  in.B = *(const ELLC_GLOBAL float*)((const ELLC_GLOBAL char*)K.cZ + i * 4u);
+  return in;
+}
+template <bool FAST> struct IcaInOf { typedef IcaIn type; };
+template <> struct IcaInOf<true> { typedef IcaInF type; };
 template <bool FAST>
-__device__ __forceinline__ void ica_accumulate_pixel(float (&acc)[6], const IcaIn& in, const LevelGeom& g, g_u8 cur, const float* S) {
-  Warp w;
-  if constexpr (FAST) {   // tolerance mode: fused multiply-adds and the hardware reciprocal in the projection
-    w.px = __builtin_fmaf(S[0], in.X, __builtin_fmaf(S[1], in.Y, __builtin_fmaf(S[2], in.Z, S[3])));
-    w.py = __builtin_fmaf(S[4], in.X, __builtin_fmaf(S[5], in.Y, __builtin_fmaf(S[6], in.Z, S[7])));
-    w.pz = __builtin_fmaf(S[8], in.X, __builtin_fmaf(S[9], in.Y, __builtin_fmaf(S[10], in.Z, S[11])));
-    const float rz = __builtin_amdgcn_rcpf(w.pz);
-    w.wx = __builtin_fmaf(w.px * rz, g.fx, g.cx);
-    w.wy = __builtin_fmaf(w.py * rz, g.fy, g.cy);
+__device__ __forceinline__ typename IcaInOf<FAST>::type ica_load_any(const KfLevelDev& K, unsigned i) {
+  if constexpr (FAST) return ica_load_fast(K, i);
+  else return ica_load(K.irec, i);
+}
+template <bool FAST>
+__device__ __forceinline__ typename IcaInOf<FAST>::type ica_in_empty() {
+  typename IcaInOf<FAST>::type in;
+  if constexpr (FAST) {
+    in.xyI = 0; in.d = 1.0f; in.W = 0.0f; in.A = 0.0f; in.B = 0.0f;
   } else {
-    w = warp_point<true>(in.X, in.Y, in.Z, g, S);
-  }
-  const Taps t = tap_point<false, FAST>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
-  const bool oob = (t.I == -1.0f);
-  const float residual = oob ? 0.0f : (t.I - in.Ikf);
-  const float rw = residual * in.W;
+    in.X = 0.0f; in.Y = 0.0f; in.Z = 1.0f; in.Ikf = 0.0f; in.W = 0.0f;
 #pragma unroll
-  for (int r = 0; r < 6; r++) acc[r] = __builtin_fmaf(in.sd[r], rw, acc[r]);
+    for (int r = 0; r < 6; r++) in.sd[r] = 0.0f;
+  }
+  return in;
+}
+
+template <bool FAST>
+__device__ __forceinline__ void ica_accumulate_pixel(float (&acc)[6], const typename IcaInOf<FAST>::type& in, const LevelGeom& g, g_u8 cur,
+                                                     const float* S) {
+  if constexpr (FAST) {
+    // the point divided by Z, (p, q, 1) + t d, projects to the same pixel (see fcaf_pixel): fused multiply-adds, hardware reciprocal
+    const float p = __builtin_fmaf((float)(in.xyI & 0xfffu), g.rfx, -(g.cx * g.rfx));
+    const float q = __builtin_fmaf((float)((in.xyI >> 12) & 0xfffu), g.rfy, -(g.cy * g.rfy));
+    const float d = in.d;
+    const float px = __builtin_fmaf(S[0], p, __builtin_fmaf(S[1], q, __builtin_fmaf(S[3], d, S[2])));
+    const float py = __builtin_fmaf(S[4], p, __builtin_fmaf(S[5], q, __builtin_fmaf(S[7], d, S[6])));
+    const float pz = __builtin_fmaf(S[8], p, __builtin_fmaf(S[9], q, __builtin_fmaf(S[11], d, S[10])));
+    const float rz = __builtin_amdgcn_rcpf(pz);
+    const float wx = __builtin_fmaf(px * rz, g.fx, g.cx);
+    const float wy = __builtin_fmaf(py * rz, g.fy, g.cy);
+    const Taps t = tap_point<false, true>(cur, g.sw, g.cols, g.rows, wx, wy);
+    const bool oob = (t.I == -1.0f);
+    const float residual = oob ? 0.0f : (t.I - byte_f32<3>(in.xyI));
+    const float rw = residual * in.W;
+    const float A = in.A, B = in.B;
+    const float T = __builtin_fmaf(A, p, B * q);
+    acc[0] = __builtin_fmaf(-__builtin_fmaf(q, T, B), rw, acc[0]);
+    acc[1] = __builtin_fmaf(__builtin_fmaf(p, T, A), rw, acc[1]);
+    acc[2] = __builtin_fmaf(__builtin_fmaf(B, p, -(A * q)), rw, acc[2]);
+    acc[3] = __builtin_fmaf(A * d, rw, acc[3]);
+    acc[4] = __builtin_fmaf(B * d, rw, acc[4]);
+    acc[5] = __builtin_fmaf(-(d * T), rw, acc[5]);
+  } else {
+    const Warp w = warp_point<true>(in.X, in.Y, in.Z, g, S);
+    const Taps t = tap_point<false, false>(cur, g.sw, g.cols, g.rows, w.wx, w.wy);
+    const bool oob = (t.I == -1.0f);
+    const float residual = oob ? 0.0f : (t.I - in.Ikf);
+    const float rw = residual * in.W;
+#pragma unroll
+    for (int r = 0; r < 6; r++) acc[r] = __builtin_fmaf(in.sd[r], rw, acc[r]);
+  }
 }
 
 template <bool FAST>
@@ -1562,11 +1614,8 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
   const int begin = sub * chunk;
   const int end = min(V, begin + chunk);
   g_u8 cur = as_global(F.img);
-  IcaIn first;
-  first.X = 0.0f; first.Y = 0.0f; first.Z = 1.0f; first.Ikf = 0.0f; first.W = 0.0f;
-#pragma unroll
-  for (int r = 0; r < 6; r++) first.sd[r] = 0.0f;
-  if (begin + t < end) first = ica_load(K.irec, (unsigned)(begin + t));
+  typename IcaInOf<FAST>::type first = ica_in_empty<FAST>();
+  if (begin + t < end) first = ica_load_any<FAST>(K, (unsigned)(begin + t));
   if (pending) {
     const float* hinv = a.kf_tab[fa.prev_level * a.max_kf + slot].hinv;
     solve_step<FAST>(sh, group_sum, 2, fa.prev_level, fa.early_exit, src, nullptr, hinv);
@@ -1598,7 +1647,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
   int i = begin + t;
   if (i < end) {
     ica_accumulate_pixel<FAST>(acc, first, g, cur, S);
-    for (i += ELLC_GN_THREADS; i < end; i += ELLC_GN_THREADS) ica_accumulate_pixel<FAST>(acc, ica_load(K.irec, (unsigned)i), g, cur, S);
+    for (i += ELLC_GN_THREADS; i < end; i += ELLC_GN_THREADS) ica_accumulate_pixel<FAST>(acc, ica_load_any<FAST>(K, (unsigned)i), g, cur, S);
   }
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
   block_reduce_store<6>(acc, out + 21);   // the b slots of the partial record; the H slots are not read by a mode-2 solve

@@ -20,7 +20,8 @@ struct PrepArgs {
   int levels, max_kf;
   int need;                    // bit 0: planes Z / I / saved weight (unfused ICA kernels); bit 1: FcaRec records (FCA);
                                // bit 2: IcaRec records + per-tile sums of H (fused ICA schedule); bit 3: FcaRecF records
-                               // (FCA in tolerance mode, cfg.arith = ELLC_ARITH_FAST)
+                               // (FCA in tolerance mode, cfg.arith = ELLC_ARITH_FAST); bit 4 (with bit 2): the ICA records in
+                               // the tolerance mode's 20-byte form (IcaInF) instead of IcaRec
   int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
   int tile0, level0;           // this launch covers tiles tile0 + blockIdx.x (count / scatter), levels level0 + blockIdx.x (scan)
 };
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   // 32-byte FCA records are stored directly (r01 A/B: the two extra barriers per 256 records cost more than the half-line
   // stores).
   constexpr int CH = 3;
-  __shared__ u32x4 s_rec[(NEED & 4) ? 256 * CH : 1];
+  __shared__ u32x4 s_rec[((NEED & 4) && !(NEED & 16)) ? 256 * CH : 1];
   ELLC_GLOBAL u32x4* rec_out = (ELLC_GLOBAL u32x4*)K.irec;
   for (int r0 = 0; r0 < nvalid; r0 += 256) {   // block-uniform trip count
     const int r = r0 + (int)threadIdx.x;
@@ -183,10 +184,17 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
       const float wsave = wgt[(unsigned)i];
       const float X = (((float)x - cx) * Z) / fx;
       const float Y = (((float)y - cy) * Z) / fy;
-      const unsigned t3 = 3u * threadIdx.x;
-      s_rec[t3] = (u32x4){__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, Ikf)};
-      s_rec[t3 + 1] = (u32x4){__builtin_bit_cast(uint32_t, wsave), __builtin_bit_cast(uint32_t, J[0]), __builtin_bit_cast(uint32_t, J[1]), __builtin_bit_cast(uint32_t, J[2])};
-      s_rec[t3 + 2] = (u32x4){__builtin_bit_cast(uint32_t, J[3]), __builtin_bit_cast(uint32_t, J[4]), __builtin_bit_cast(uint32_t, J[5]), 0u};
+      if (need & 16) {   // tolerance mode: 16-byte word + B (ica_load_fast)
+        const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)img[(unsigned)(y * sw + x)] << 24);
+        crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, __builtin_amdgcn_rcpf(Z)), __builtin_bit_cast(uint32_t, wsave),
+                            __builtin_bit_cast(uint32_t, fx * gradx)};
+        cZ[pos] = fy * grady;
+      } else {
+        const unsigned t3 = 3u * threadIdx.x;
+        s_rec[t3] = (u32x4){__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, Ikf)};
+        s_rec[t3 + 1] = (u32x4){__builtin_bit_cast(uint32_t, wsave), __builtin_bit_cast(uint32_t, J[0]), __builtin_bit_cast(uint32_t, J[1]), __builtin_bit_cast(uint32_t, J[2])};
+        s_rec[t3 + 2] = (u32x4){__builtin_bit_cast(uint32_t, J[3]), __builtin_bit_cast(uint32_t, J[4]), __builtin_bit_cast(uint32_t, J[5]), 0u};
+      }
       int q = 0;
 #pragma unroll
       for (int rr = 0; rr < 6; rr++) {
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
       crec[2u * pos + 1u] = hi;
     }
     }
-    if (NEED & 4) {
+    if ((NEED & 4) && !(NEED & 16)) {
       __syncthreads();
       const int chunks = min(256, nvalid - r0) * CH;
       const unsigned obase = (tile_off + (unsigned)r0) * CH;

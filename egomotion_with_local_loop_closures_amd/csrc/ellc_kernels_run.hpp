@@ -123,7 +123,7 @@ __device__ __forceinline__ void run_pixel_pass(const GnArgs& ga, const KfLevelDe
     float acc[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) acc[q] = 0.0f;
-    for (; i < end; i += stride) ica_accumulate_pixel<FAST>(acc, ica_load(K.irec, (unsigned)i), g, cur, S);
+    for (; i < end; i += stride) ica_accumulate_pixel<FAST>(acc, ica_load_any<FAST>(K, (unsigned)i), g, cur, S);
 #pragma unroll
     for (int q = 0; q < 6; q++) sums[q] = acc[q];   // the b sums; H^-1 of the level comes from the keyframe slot
   } else {
