@@ -307,6 +307,17 @@ def main():
                 out["roofline"]["one_batch_at_a_time_grid"] = w3.level0_kernel()
             w3.close()
             if not a.dense and a.mode == "fca":
+                # ---- the same batches in the constant-weight mode the reference's loop-closure thread uses (ICA, saved weights)
+                ns = argparse.Namespace(**vars(a))
+                ns.mode = "ica"
+                w4 = Workload(api, ns, scenes, a.arith, dev_index, shared_frame=True, prime=[a.warmup, a.steps])
+                w4.run(a.warmup)
+                d5, _, it5 = w4.timed(a.steps, sync)
+                out["ica_mode"] = {"workload": "the same batches, ELLC_MODE_ICA (PixelWisePyramid.cpp:561-974: template-gradient Jacobian, saved "
+                                               "weights, H^-1 once per keyframe and level), arith %s" % a.arith,
+                                   "value": B * iters_per_alignment * a.steps / d5, "ms_per_step": 1e3 * d5 / a.steps}
+                assert int(it5.sum()) == B * iters_per_alignment
+                w4.close()
                 out["c4_dense"] = c4_dense(api, synth, a, dev_index, sync)
                 out["depth"] = depth_kernels(api, synth, dev_index)
                 out["tracked_frame"] = tracked_frame(api, synth, a, dev_index)
