@@ -88,3 +88,23 @@ def test_header_is_plain_c_and_facade_is_cxx11(tmp_path):
     cc = tmp_path / "facade.cpp"
     cc.write_text('#include "ellc_facade.hpp"\nint main() { return 0; }\n')
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(cc)])
+
+
+def test_config_struct_matches_the_python_binding(tmp_path):
+    """ellc_config as the C header lays it out against the ctypes mirror in _lib.py: same size, and the defaults
+    ellc_default_config writes land in the fields of the same name (no GPU needed)."""
+    import ctypes
+    import subprocess
+    from egomotion_with_local_loop_closures_amd import _lib, api
+    c = tmp_path / "size.c"
+    c.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ellc_abi.h"\nint main(void) { printf("%zu %zu %zu", sizeof(ellc_config), '
+                 'offsetof(ellc_config, arith), offsetof(ellc_config, coalesce)); return 0; }\n')
+    exe = tmp_path / "size"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(c)])
+    size, off_arith, off_coalesce = (int(x) for x in subprocess.check_output([str(exe)]).split())
+    assert ctypes.sizeof(_lib.EllcConfig) == size
+    assert _lib.EllcConfig.arith.offset == off_arith and _lib.EllcConfig.coalesce.offset == off_coalesce
+    cfg = api.default_config(640, 480, 4)
+    assert (cfg.width, cfg.height, cfg.levels) == (640, 480, 4)
+    assert cfg.concurrent_batches == 1 and cfg.coalesce == 1 and cfg.early_exit == 1
+    assert list(cfg.max_iter)[:4] == [4, 7, 9, 12]
