@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--gather", choices=["cabi", "torch"], default="cabi", help="N>1: the gather of the poses through the library's C entry points "
                     "(ellc_gather_start/_finish: ncclAllGather in C++; torch.distributed only hands out the unique id) or through torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-at-1", action="store_true", help="N=1 only: run the per-batch gather all the same (RCCL communicator of one rank through "
+                    "the library's C entry points): what the exchange costs the loop, measured on one GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse ranks sharing one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-time budget of each CPU baseline variant")
     return ap.parse_args()
@@ -156,47 +158,74 @@ def main():
     wl = Workload(api, a, scenes, a.arith, dev_index, shared_frame=not a.dense, prime=[a.warmup, a.steps])
     G, sched = wl.G, wl.sched
     iters_per_alignment = sum(sched)
-    # ---- the single gather of the resulting se(3) poses (8 floats per alignment) per batch: enqueued when a batch is fetched,
-    # collected up to G steps later, so the exchange never stalls the loop. Default: the library's own C++ path
-    # (ellc_gather_start / ellc_gather_finish over RCCL); torch.distributed only carries rank 0's unique id to the others.
-    use_cabi = world > 1 and a.gather == "cabi"
+    # ---- the gather of the resulting se(3) poses (8 floats per alignment): the batches of one launch group complete together,
+    # so their tables are exchanged together — one all_gather per group of `coalesce` batches, enqueued when the group's last
+    # batch is fetched and collected a few groups later, so the exchange never stalls the loop. Default: the library's own C++
+    # path (ellc_gather_start / ellc_gather_finish over RCCL); torch.distributed only carries rank 0's unique id to the others.
+    gathering = world > 1 or a.gather_at_1
+    use_cabi = gathering and a.gather == "cabi"
+    bucket_n = wl.coalesce                      # batches per exchange
+    per_max = bucket_n * B * world              # rows of the largest gathered table
+    bucket = []
+    depth = 4                                   # exchanges in flight: the library keeps a ring of four (ellc_comm)
     if use_cabi:
         if a.backend == "nccl":
             ids = [sharding.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = sharding.Comm(world, rank, max_total=B * world, transport="rccl", device=dev_index, unique_id=ids[0])
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            comm = sharding.Comm(world, rank, max_total=per_max, transport="rccl", device=dev_index, unique_id=ids[0])
         else:   # rehearsal of several ranks on one GPU (RCCL refuses two ranks on one device): the same entry points over TCP
-            comm = sharding.Comm(world, rank, max_total=B * world, transport="tcp", port=int(os.environ.get("MASTER_PORT", "29500")) + 17)
-        outstanding = [0]
-        depth = min(G, 4)   # gathers in flight: the library keeps a ring of four (ellc_comm)
+            comm = sharding.Comm(world, rank, max_total=per_max, transport="tcp", port=int(os.environ.get("MASTER_PORT", "29500")) + 17)
+        outstanding = []   # rows of each exchange in flight, oldest first
 
-        def on_fetch(pose, iters, wgt):
-            if outstanding[0] == depth:
-                assert comm.finish(B * world).shape == (B * world, sharding.RECORD)
-                outstanding[0] -= 1
-            comm.start(B * world, sharding.pack_results(pose, iters, wgt))
-            outstanding[0] += 1
+        def finish_one():
+            rows = outstanding.pop(0)
+            assert comm.finish(rows).shape == (rows, sharding.RECORD)
 
-        def drain():
-            while outstanding[0]:
-                assert comm.finish(B * world).shape == (B * world, sharding.RECORD)
-                outstanding[0] -= 1
+        def start(table):
+            if len(outstanding) == depth:
+                finish_one()
+            comm.start(table.shape[0] * world, table)
+            outstanding.append(table.shape[0] * world)
+
+        def pending():
+            return len(outstanding)
     else:
-        depth = min(G, 4)
-        gatherer = sharding.ResultGatherer(B * world, device=(coll_dev if world > 1 else None), depth=depth)
+        gatherers = {}   # one preallocated ring per table size (full buckets, and the partial one that ends a run)
+        order = []
 
-        def on_fetch(pose, iters, wgt):
-            if len(gatherer.pending) == depth:
-                assert gatherer.finish().shape == (B * world, sharding.RECORD)
-            gatherer.start(sharding.pack_results(pose, iters, wgt))
+        def finish_one():
+            rows = order.pop(0)
+            assert gatherers[rows].finish().shape == (rows, sharding.RECORD)
 
-        def drain():
-            while gatherer.pending:
-                assert gatherer.finish().shape == (B * world, sharding.RECORD)
+        def start(table):
+            rows = table.shape[0] * world
+            if rows not in gatherers:
+                gatherers[rows] = sharding.ResultGatherer(rows, device=(coll_dev if world > 1 else None), depth=depth)
+            if len(order) == depth:
+                finish_one()
+            gatherers[rows].start(table)
+            order.append(rows)
+
+        def pending():
+            return len(order)
+
+    def on_fetch(pose, iters, wgt):
+        bucket.append(sharding.pack_results(pose, iters, wgt))
+        if len(bucket) == bucket_n:
+            start(np.concatenate(bucket))
+            bucket.clear()
+
+    def drain():
+        if bucket:
+            start(np.concatenate(bucket))
+            bucket.clear()
+        while pending():
+            finish_one()
 
     def run(nsteps):
-        r = wl.run(nsteps, on_fetch if world > 1 else None)
-        if world > 1:
+        r = wl.run(nsteps, on_fetch if gathering else None)
+        if gathering:
             drain()
         return r
 
@@ -232,7 +261,7 @@ def main():
                                "compaction included, arithmetic mode '%s' (%s), %d batches in flight, launched in groups of up to %d side by side (cfg.coalesce) on up to 3 streams%s"
                                % (shape, W, H, L, a.mode.upper(), sched, "ON: informational run" if a.early_exit else "off", a.arith,
                                   "pose <= 1e-5 vs the CPU path, tests/test_gpu_fast.py" if a.arith == "fast" else "per-pixel values bit-identical to the CPU path",
-                                  G, wl.coalesce, ", one all_gather of poses per step over %s (overlapped with the next batch)" % (("RCCL, issued by the library's C entry points" if use_cabi else "RCCL via torch.distributed") if a.backend == "nccl" else (a.backend + (" harness, gather through the library's C entry points over TCP" if use_cabi else ""))) if world > 1 else ""),
+                                  G, wl.coalesce, ", one all_gather of poses per launch group over %s (overlapped with the next groups)" % (("RCCL, issued by the library's C entry points" if use_cabi else "RCCL via torch.distributed") if a.backend == "nccl" else (a.backend + (" harness, gather through the library's C entry points over TCP" if use_cabi else ""))) if world > 1 else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "batches_in_flight": G, "coalesce": wl.coalesce, "gn_iterations_per_alignment": iters_per_alignment,
                    "alignments_per_s": world * B * a.steps / dt, "pixels": "dense" if a.dense else "semi-dense (maxAbsGradient>=5)", "arith": a.arith},
     }
