@@ -335,6 +335,14 @@ def main():
             if G > 1 and a.mode == "fca":
                 out["roofline"]["one_batch_at_a_time_grid"] = w3.level0_kernel()
             w3.close()
+            # the same with the queue kept full, as the timed region does it (launch groups, cfg.coalesce)
+            w5 = Workload(api, a, scenes, a.arith, dev_index, early_exit=1, shared_frame=not a.dense, prime=[a.warmup, a.steps])
+            w5.run(a.warmup)
+            d6, _, it6 = w5.timed(a.steps, sync)
+            out["early_exit_on"]["pipelined"] = {"ms_per_batch": 1e3 * d6 / a.steps, "alignments_per_s": B * a.steps / d6,
+                                                 "gn_iterations_per_s": float(np.asarray(it6).sum()) * a.steps / d6, "batches_in_flight": w5.G,
+                                                 "coalesce": w5.coalesce}
+            w5.close()
             if not a.dense and a.mode == "fca":
                 # ---- the same batches in the constant-weight mode the reference's loop-closure thread uses (ICA, saved weights)
                 ns = argparse.Namespace(**vars(a))
