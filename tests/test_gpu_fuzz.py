@@ -121,18 +121,26 @@ def _stable_case(oracle, w, h, L, seed, mi, ica):
     pytest.fail("no well-conditioned %s scene in 16 attempts" % ("ICA" if ica else "FCA"))
 
 
-@pytest.mark.parametrize("w,h,L,seed", [(96, 64, 3, 201), (101, 75, 3, 202), (160, 120, 4, 203), (128, 72, 3, 204), (240, 136, 4, 205),
-                                        (64, 48, 3, 206)])
+ALIGN_CASES = [(96, 64, 3, 201), (101, 75, 3, 202), (160, 120, 4, 203), (128, 72, 3, 204), (240, 136, 4, 205), (64, 48, 3, 206)]
+if _extra:   # the wide sweep: one further full-alignment case per ten per-pixel cases
+    _r2 = np.random.default_rng(54321)
+    ALIGN_CASES = ALIGN_CASES + [(int(_r2.integers(64, 260)), int(_r2.integers(48, 200)), 3, 2000 + i) for i in range(_extra // 10)]
+
+
+@pytest.mark.parametrize("w,h,L,seed", ALIGN_CASES)
 @pytest.mark.parametrize("ica", [False, True], ids=["fca", "ica"])
-def test_random_scene_full_alignment(oracle, ellc, w, h, L, seed, ica):
-    """Full fixed-schedule alignments of random scenes, FCA and ICA: final pose within 1e-5 of the oracle, no exceptions.
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_random_scene_full_alignment(oracle, ellc, w, h, L, seed, ica, arith):
+    """Full fixed-schedule alignments of random scenes, FCA and ICA, both arithmetic modes: final pose within 1e-5 of the
+    oracle, no exceptions.
     A tiny random scene can be ill-conditioned — the iteration does not contract and amplifies the rounding of the sums, the
     one thing that legitimately differs between product and oracle. Such a case is not excused with a wider bar: it is
     REGENERATED (_stable_case) until the oracle itself is stable; the first stable case is then held to 1e-5."""
     mi = (4, 7, 9, 12)[:L]
     pair, init, planes, pr, itr = _stable_case(oracle, w, h, L, seed, mi, ica)
     fx, fy, cx, cy = pair["intrinsics"]
-    ctx = ellc.Context(ellc.default_config(w, h, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_iter=mi))
+    ctx = ellc.Context(ellc.default_config(w, h, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_iter=mi,
+                                           arith=ellc.ARITH_FAST if arith == "fast" else ellc.ARITH_EXACT))
     ctx.keyframe_upload(0, pair["kf_image"]); ctx.keyframe_set_depth(0, pair["depth0"], pair["var0"]); ctx.frame_upload(0, pair["cur_image"])
     if ica:
         for l in range(L):
