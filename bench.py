@@ -262,7 +262,10 @@ def main():
                                % (shape, W, H, L, a.mode.upper(), sched, "ON: informational run" if a.early_exit else "off", a.arith,
                                   "pose <= 1e-5 vs the CPU path, tests/test_gpu_fast.py" if a.arith == "fast" else "per-pixel values bit-identical to the CPU path",
                                   G, wl.coalesce, ", one all_gather of poses per launch group over %s (overlapped with the next groups)" % (("RCCL, issued by the library's C entry points" if use_cabi else "RCCL via torch.distributed") if a.backend == "nccl" else (a.backend + (" harness, gather through the library's C entry points over TCP" if use_cabi else ""))) if world > 1 else ""),
-                   "batch_per_gpu": B, "global_batch": B * world, "batches_in_flight": G, "coalesce": wl.coalesce, "gn_iterations_per_alignment": iters_per_alignment,
+                   "batch_per_gpu": B, "global_batch": B * world, "batches_in_flight": G, "coalesce": wl.coalesce,
+                   "setup": "slots uploaded; hipGraphs captured by one untimed rehearsal of %d and %d steps (every launch sequence the warm-up "
+                            "and the timed steps replay), then the %d warm-up steps" % (a.warmup, a.steps, a.warmup),
+                   "gn_iterations_per_alignment": iters_per_alignment,
                    "alignments_per_s": world * B * a.steps / dt, "pixels": "dense" if a.dense else "semi-dense (maxAbsGradient>=5)", "arith": a.arith},
     }
 
