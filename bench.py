@@ -63,7 +63,7 @@ class Workload:
     """G slot groups of B keyframes + one frame each, resident on the device; step s works on group s % G."""
 
     def __init__(self, api, a, scenes, arith, dev_index, W=None, H=None, L=None, B=None, sched=None, early_exit=None, G=None, shared_frame=True,
-                 coalesce=None, prime=None):
+                 coalesce=None, prime=None, share_kf=False, cache_records=0):
         self.api = api
         self.W, self.H, self.L = W or a.width, H or a.height, L or a.levels
         self.B = B or a.batch
@@ -75,7 +75,8 @@ class Workload:
         self.shared = shared_frame
         self.cfg = api.default_config(self.W, self.H, self.L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=int(a.early_exit if early_exit is None else early_exit),
                                       max_iter=self.sched, max_keyframes=G * B, max_frames=(G if shared_frame else G * B), max_batch=B, device=dev_index,
-                                      concurrent_batches=G, coalesce=self.coalesce, arith=api.ARITH_FAST if arith == "fast" else api.ARITH_EXACT)
+                                      concurrent_batches=G, coalesce=self.coalesce, cache_records=int(cache_records),
+                                      arith=api.ARITH_FAST if arith == "fast" else api.ARITH_EXACT)
         self.ctx = api.Context(self.cfg)
         self.mode = api.MODE_FCA if a.mode == "fca" else api.MODE_ICA
         for g in range(G):
@@ -90,7 +91,7 @@ class Workload:
                 if a.mode == "ica":
                     for l in range(self.L):
                         self.ctx.keyframe_set_weights(g * B + b, l, np.full((self.H >> l, self.W >> l), 0.03, np.float32), 1)
-        self.kf = [np.arange(B, dtype=np.int32) + g * B for g in range(G)]
+        self.kf = [np.arange(B, dtype=np.int32) + (0 if share_kf else g * B) for g in range(G)]   # share_kf: every batch aligns the SAME keyframes
         self.fr = [np.full(B, g, np.int32) if shared_frame else self.kf[g] for g in range(G)]
         # set-up, not warm-up: launch sequences are captured into hipGraphs on first use, one per (buffer set, batches in the group);
         # a rehearsal of the step counts that will be run captures every one the measured runs replay (like the uploads above)
@@ -358,6 +359,19 @@ def main():
                                    "value": B * iters_per_alignment * a.steps / d5, "ms_per_step": 1e3 * d5 / a.steps}
                 assert int(it5.sum()) == B * iters_per_alignment
                 w4.close()
+                # ---- a loop-closure STREAM as the reference produces it: the same 32 candidate keyframes against one new frame after
+                # another. Batches in flight then share their keyframe slots: with per-call compaction (the default, and what
+                # `value` measures on distinct keyframes) they run one after the other; with cfg.cache_records the lists are built
+                # once and the batches only read them
+                rec = {"workload": "every batch aligns the SAME %d keyframes, against frame slot (step mod %d)" % (B, G)}
+                for cache in (0, 1):
+                    w6 = Workload(api, a, scenes, a.arith, dev_index, shared_frame=True, prime=[a.warmup, a.steps], share_kf=True, cache_records=cache)
+                    w6.run(a.warmup)
+                    d7, _, it7 = w6.timed(a.steps, sync)
+                    assert int(it7.sum()) == B * iters_per_alignment
+                    rec["cache_records_%d" % cache] = {"ms_per_step": 1e3 * d7 / a.steps, "value": B * iters_per_alignment * a.steps / d7}
+                    w6.close()
+                out["lc_stream_shared_keyframes"] = rec
                 out["c4_dense"] = c4_dense(api, synth, a, dev_index, sync)
                 out["depth"] = depth_kernels(api, synth, dev_index)
                 out["tracked_frame"] = tracked_frame(api, synth, a, dev_index)

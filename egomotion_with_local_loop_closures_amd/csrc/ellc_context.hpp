@@ -42,6 +42,11 @@ struct ellc_ctx {
   ellc::KfLevelDev* kf_tab_d = nullptr;
   ellc::FrLevelDev* fr_tab_d = nullptr;
   std::vector<char> kf_has_image, kf_has_depth, fr_has_image;
+  // cfg.cache_records: which record set (PrepArgs::need) the compact lists of a keyframe slot hold, 0 = none / stale. The lists
+  // are a pure function of the slot's image, depth pyramid and weight planes: every entry point that writes one of those
+  // clears the tag (ellc::invalidate_records); a batch rebuilds only the slots whose tag differs from what it needs.
+  std::vector<int> kf_rec_tag;
+  bool cache_records = false;
   std::vector<std::array<int, ELLC_MAX_LEVELS>> kf_num_weights;
   std::vector<float*> kf_maxgrad, fr_maxgrad;
   std::vector<int*> kf_maxgrad_count, fr_maxgrad_count;
@@ -89,7 +94,8 @@ struct ellc_ctx {
     bool coalescable = false;                       // further full batches of the same mode may join until it is launched
     int slice_B[MAX_COALESCE] = {0, 0, 0, 0};       // size of each staged batch
     int stream_idx = 0;                             // the batch stream it was launched on (0: the context's main stream)
-    std::vector<int> kf_slots;                      // unique keyframe slots of the group
+    std::vector<int> kf_slots;                      // unique keyframe slots of the group (all of them: the slots it reads)
+    std::vector<int> built_slots;                   // of which it rebuilds the compact lists (or accumulates saved weights into)
     int B = 0;                                      // alignments the launch covers
     bool joined = true;                             // the main stream already waits for `done`
     int mode = 0, save_weights = 0;
@@ -161,6 +167,7 @@ struct ellc_ctx {
 
 namespace ellc {
 ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg);
+void invalidate_records(ellc_ctx* c, int slot);   // cfg.cache_records: the slot's compact lists no longer match its planes
 #define ELLC_HIP(ctx, expr)                                                                               \
   do {                                                                                                    \
     hipError_t e__ = (expr);                                                                              \

@@ -104,6 +104,7 @@ ellc_status do_update_depth_image(ellc_ctx* c) {
   ELLC_HIP(c, hipGetLastError());
   ellc_status s = build_depth_pyramid_from(c, c->dm_kf_slot, steps + 1);   // buildInvVarDepth + mapDepthArr2Mat: the remaining levels
   if (s != ELLC_OK) return s;
+  invalidate_records(c, c->dm_kf_slot);
   c->kf_has_depth[c->dm_kf_slot] = 1;
   return ELLC_OK;
 }

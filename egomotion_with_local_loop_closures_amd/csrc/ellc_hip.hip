@@ -27,6 +27,11 @@ ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg) {
   return s;
 }
 
+// the compact lists of a keyframe slot no longer match its planes (cfg.cache_records)
+void invalidate_records(ellc_ctx* c, int slot) {
+  if (slot >= 0 && slot < (int)c->kf_rec_tag.size()) c->kf_rec_tag[slot] = 0;
+}
+
 // blocking copy on the context's own stream: the legacy default stream would synchronise with every other stream of the
 // process (another context's batches in flight) and take a hardware queue of its own
 static hipError_t copy_blocking(ellc_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
@@ -733,6 +738,7 @@ void ellc_default_config(ellc_config* cfg, int width, int height, int levels) {
   cfg->device = 0;
   cfg->concurrent_batches = 1;
   cfg->coalesce = 1;
+  cfg->cache_records = 0;
 }
 
 const char* ellc_last_error(const ellc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -857,6 +863,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   }
   c->kf_has_image.assign(MK, 0); c->kf_has_depth.assign(MK, 0); c->fr_has_image.assign(MF, 0);
   c->kf_num_weights.assign(MK, std::array<int, ELLC_MAX_LEVELS>{});
+  c->kf_rec_tag.assign(MK, 0);
+  c->cache_records = cfg->cache_records != 0;
   c->kf_maxgrad.assign(MK, nullptr); c->fr_maxgrad.assign(MF, nullptr);
   c->kf_maxgrad_count.assign(MK, nullptr); c->fr_maxgrad_count.assign(MF, nullptr);
   c->kf_maxgrad_valid.assign(MK, 0); c->fr_maxgrad_valid.assign(MF, 0);
@@ -1019,6 +1027,7 @@ ellc_status ellc_keyframe_upload(ellc_ctx* c, int slot, const uint8_t* image) {
   for (int l = 0; l < c->L; l++) img[l] = c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + slot].img;
   ellc_status s = upload_pyramid(c, img, image);
   if (s != ELLC_OK) return s;
+  invalidate_records(c, slot);
   c->kf_has_image[slot] = 1;
   c->kf_has_depth[slot] = 0;         // a fresh frame has no depth yet (as ellc_keyframe_from_frame): set_depth / update_depth_image follow
   for (int l = 0; l < c->L; l++) {   // frame::frame zeroes weight_pyramid / numWeightsAdded (Frame.cpp:114-122)
@@ -1039,6 +1048,7 @@ ellc_status ellc_keyframe_from_frame(ellc_ctx* c, int kf_slot, int frame_slot) {
     ELLC_HIP(c, hipMemsetAsync(c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + kf_slot].weight, 0, (size_t)g.n * 4, c->stream));
     c->kf_num_weights[kf_slot][l] = 0;
   }
+  invalidate_records(c, kf_slot);
   c->kf_has_image[kf_slot] = 1;
   c->kf_has_depth[kf_slot] = 0;
   return build_maxgrad(c, true, kf_slot);
@@ -1097,6 +1107,7 @@ ellc_status ellc_keyframe_set_depth(ellc_ctx* c, int slot, const float* depth0, 
   if (!c || !depth0 || !var0 || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   const KfLevelDev& k = c->kf_tab_h[slot];
   const size_t n0 = (size_t)c->geom_h[0].n;
+  invalidate_records(c, slot);
   ELLC_HIP(c, hipMemcpyAsync(k.depth, depth0, n0 * 4, hipMemcpyHostToDevice, c->stream));
   ELLC_HIP(c, hipMemcpyAsync(k.var, var0, n0 * 4, hipMemcpyHostToDevice, c->stream));
   ellc_status s = build_depth_pyramid(c, slot);
@@ -1110,6 +1121,7 @@ ellc_status ellc_keyframe_set_depth_level(ellc_ctx* c, int slot, int level, cons
   ELLC_ENTER(c);
   if (!c || !depth || !var || level < 0 || level >= c->L || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   const KfLevelDev& k = c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + slot];
+  invalidate_records(c, slot);
   ELLC_HIP(c, hipMemcpyAsync(k.depth, depth, (size_t)c->geom_h[level].n * 4, hipMemcpyHostToDevice, c->stream));
   ELLC_HIP(c, hipMemcpyAsync(k.var, var, (size_t)c->geom_h[level].n * 4, hipMemcpyHostToDevice, c->stream));
   ELLC_HIP(c, hipStreamSynchronize(c->stream));
@@ -1131,6 +1143,7 @@ ellc_status ellc_keyframe_set_weights(ellc_ctx* c, int slot, int level, const fl
   ELLC_ENTER(c);
   if (!c || !w || level < 0 || level >= c->L || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   const KfLevelDev& k = c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + slot];
+  invalidate_records(c, slot);
   ELLC_HIP(c, hipMemcpyAsync(k.weight, w, (size_t)c->geom_h[level].n * 4, hipMemcpyHostToDevice, c->stream));
   ELLC_HIP(c, hipStreamSynchronize(c->stream));
   c->kf_num_weights[slot][level] = num_added;
@@ -1152,6 +1165,7 @@ ellc_status ellc_keyframe_get_weights(ellc_ctx* c, int slot, int level, float* w
 ellc_status ellc_keyframe_finalise_weights(ellc_ctx* c, int slot) {
   ELLC_ENTER(c);
   if (!c || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  invalidate_records(c, slot);
   for (int l = c->L - 1; l >= 0; l--) {
     const int na = c->kf_num_weights[slot][l];
     if (na > 0) {
@@ -1223,6 +1237,7 @@ ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, i
     }
   }
   if (dst_is_kf) {
+    invalidate_records(c, dst);
     c->kf_has_image[dst] = 1;
     c->kf_has_depth[dst] = src_is_kf ? c->kf_has_depth[src] : 0;
     if (src_is_kf && c->kf_maxgrad_valid[src]) {
@@ -1243,15 +1258,25 @@ ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, i
 // ---- alignment -------------------------------------------------------------------------------------
 // prep + init + the whole level/iteration schedule; captured once per (B, unique keyframes, mode, save_weights)
 // into a hipGraph and replayed afterwards (the launches are too short to be issued one by one from the host)
+// the record set (PrepArgs::need) a schedule reads
+static int need_of(const ellc_ctx* c, int mode) {
+  return mode == ELLC_MODE_ICA ? (c->use_fused ? (c->fast ? 20 : 4) : 1) : (c->fast ? 8 : 2);
+}
+
+// nu: keyframe slots whose compact lists are (re)built — all the unique slots of the batch, or with cfg.cache_records only
+// those whose lists are stale (possibly none)
 static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int save_weights) {
   enqueue_stage_in(c, B);   // also initialises the B alignment states
   // mask / count per level (updationOnPyrChange, ImageFunc.cpp:158) and the pose-independent per-pixel records. (Folding the
   // staging into the count launch — its tile blocks then read their keyframe slot from the pinned record, one PCIe round trip
   // per block — was measured in r02: the count launch went from 10 to 29 us at 32 keyframes; the separate 8 us launch stays.)
-  const int need = mode == ELLC_MODE_ICA ? (c->use_fused ? (c->fast ? 20 : 4) : 1) : (c->fast ? 8 : 2);   // record sets of prep_scatter
-  ellc_status s = run_prep(c, nu, need);
-  if (s != ELLC_OK) return s;
-  if (need & 4) enqueue_ica_hinv(c, nu);
+  const int need = need_of(c, mode);
+  ellc_status s = ELLC_OK;
+  if (nu > 0) {
+    s = run_prep(c, nu, need);
+    if (s != ELLC_OK) return s;
+    if (need & 4) enqueue_ica_hinv(c, nu);
+  }
   s = enqueue_schedule(c, B, mode, save_weights);
   if (s != ELLC_OK) return s;
   if (!c->use_fused)   // the fused schedules export from their finish kernel
@@ -1306,7 +1331,10 @@ static ellc_status resolve_batch(ellc_ctx* c, int set) {
   if (bs.resolved) return ELLC_OK;
   bs.resolved = true;
   hipError_t ev = hipEventSynchronize(bs.done);   // the last kernel wrote bs.result_h (pinned, zero-copy)
-  if (ev != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("the batch failed on the device: ") + hipGetErrorString(ev));
+  if (ev != hipSuccess) {
+    std::fill(c->kf_rec_tag.begin(), c->kf_rec_tag.end(), 0);   // whatever was being built cannot be trusted
+    return fail(c, ELLC_ERR_HIP, std::string("the batch failed on the device: ") + hipGetErrorString(ev));
+  }
   if (!bs.adaptive) return ELLC_OK;
   bool unfinished = false;
   for (int b = 0; b < bs.B; b++) unfinished = unfinished || (bs.result_h[b].pad == 1);
@@ -1344,8 +1372,14 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
     for (int v : bs.kf_slots) seen = seen || (v == c->kf_slot_h[b]);
     if (!seen) bs.kf_slots.push_back(c->kf_slot_h[b]);
   }
-  const int nu = (int)bs.kf_slots.size();
-  for (int u = 0; u < nu; u++) c->uniq_slot_h[u] = bs.kf_slots[u];
+  // the slots whose lists this launch (re)builds: all of them, or with cfg.cache_records those whose lists are stale
+  const int need = need_of(c, bs.mode);
+  const bool saves = bs.save_weights && bs.mode == ELLC_MODE_FCA;
+  bs.built_slots.clear();
+  for (int v : bs.kf_slots)
+    if (!c->cache_records || c->kf_rec_tag[v] != need) bs.built_slots.push_back(v);
+  const int nu = (int)bs.built_slots.size();
+  for (int u = 0; u < nu; u++) c->uniq_slot_h[u] = bs.built_slots[u];
   // stream
   bool busy[ellc_ctx::STREAMS] = {false, false, false};
   for (int p = 0; p < ellc_ctx::SETS; p++)
@@ -1384,13 +1418,21 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
     ELLC_HIP(c, hipStreamWaitEvent(run_stream, c->ev_main, 0));
     c->stream_waited_mark[si] = c->main_mark;
   }
-  // after the groups in flight that use one of its keyframe slots: compaction, H^-1 and saved weights are per slot
+  // after the groups in flight with which it conflicts on a keyframe slot: one of the two writes what the other reads — the
+  // compact lists and H^-1 (a rebuild) or the saved weights, all of which live in the slot. (Without cfg.cache_records every
+  // group rebuilds every slot it uses: any shared slot is a conflict.)
+  auto hits = [](const std::vector<int>& a, const std::vector<int>& b) {
+    for (int u : a)
+      for (int v : b)
+        if (u == v) return true;
+    return false;
+  };
   for (int p = 0; p < ellc_ctx::SETS; p++) {
     ellc_ctx::BatchSet& other = c->batch_set[p];
     if (p == set || !other.launched) continue;
-    bool shared = false;
-    for (int u = 0; u < nu && !shared; u++)
-      for (int v : other.kf_slots) shared = shared || (v == bs.kf_slots[u]);
+    const bool other_saves = other.save_weights && other.mode == ELLC_MODE_FCA;
+    const bool shared = hits(bs.built_slots, other.kf_slots) || hits(bs.kf_slots, other.built_slots) ||
+                        ((saves || other_saves) && hits(bs.kf_slots, other.kf_slots));
     if (!shared) continue;
     if (other.adaptive && !other.resolved) {
       // a state-driven batch may still need its continuation, which only the host can start: finish it first (the host
@@ -1404,9 +1446,16 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
   {
     StreamScope scope(c, run_stream);
     const ellc_status s = launch_align_graph(c, B, nu, bs.mode, bs.save_weights, set, false);
-    if (s != ELLC_OK) return s;
+    if (s != ELLC_OK) {
+      for (int v : bs.built_slots) invalidate_records(c, v);
+      return s;
+    }
     ELLC_HIP(c, hipEventRecord(bs.done, c->stream));
   }
+  for (int v : bs.built_slots) c->kf_rec_tag[v] = need;
+  if (saves)   // the weight planes change: lists that carry the saved weight (the constant-weight record sets) are stale
+    for (int v : bs.kf_slots)
+      if (c->kf_rec_tag[v] != 8 && c->kf_rec_tag[v] != 2) invalidate_records(c, v);
 #ifdef ELLC_DIAG
   guard.keep = true;
 #endif
@@ -1432,6 +1481,7 @@ static void free_set(ellc_ctx* c, int set) {
   bs.resolved = true;
   bs.adaptive = false;
   bs.kf_slots.clear();
+  bs.built_slots.clear();
   if (c->open_set == set) c->open_set = -1;
 }
 
@@ -1458,6 +1508,7 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
     }
     c->untracked_reserved += reserved;   // given back by the caller once the stream has drained (ellc_profile_align)
 #endif
+    for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);   // rebuilt here, outside the cache's bookkeeping
     return launch_align_graph(c, B, nu, mode, save_weights, 0, false);
   }
   // may this batch share a launch with others? full batches of one mode, nothing per-slot written (saved weights), not the
@@ -1582,6 +1633,7 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   if (c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_gn_iterate: fetch the enqueued batches first");
   int nu = 0;
   select_batch_set(c, 0);
+  invalidate_records(c, kf_slot);   // the single-step API builds its own record set
   ellc_status s = stage_batch(c, 1, &kf_slot, &frame_slot, pose, &nu);
   if (s != ELLC_OK) return s;
   enqueue_stage_in(c, 0);   // staging only: the state keeps the level's H^-1 (gn_set_pose0)
@@ -1654,6 +1706,8 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   if (c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_profile_gn_kernel: fetch the enqueued batches first");
   int nu = 0;
   select_batch_set(c, 0);
+  if (kf_slots)
+    for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, nullptr, &nu, nullptr, true);   // up to a whole launch group (cfg.coalesce batches)
   if (s != ELLC_OK) return s;
   enqueue_stage_in(c, 0);

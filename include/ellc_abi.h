@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define ELLC_MAX_LEVELS 8
-#define ELLC_ABI_VERSION 4
+#define ELLC_ABI_VERSION 5
 
 typedef enum {
   ELLC_OK = 0,
@@ -74,6 +74,11 @@ typedef struct {
                                  * side, up to this many per launch sequence, and 3 x coalesce batches may be in flight. Fixed per
                                  * context: a full batch's grids are those of a full group whether it runs alone or not, so its
                                  * result does not depend on what it was launched with */
+  int cache_records;            /* 0 (default): the compact pixel lists of a batch's keyframes are rebuilt by every call, as the
+                                 * reference recomputes its masks per alignment (ImageFunc.cpp:158). 1: they are kept with the
+                                 * keyframe slot and rebuilt only after the slot's image, depth or weights have changed (every
+                                 * entry point that writes them marks the slot); batches that only READ a slot's lists then also
+                                 * run concurrently instead of one after the other. Results are identical either way */
 } ellc_config;
 
 typedef struct ellc_ctx ellc_ctx;

@@ -368,21 +368,23 @@ def test_two_contexts_on_two_threads(ellc):
     assert not bad, bad[:3]
 
 
-@pytest.mark.parametrize("seed,concurrent,coalesce", [(1, 3, 1), (2, 3, 1), (3, 1, 1), (4, 3, 3), (5, 3, 2), (6, 12, 3), (7, 16, 4)])
-def test_pipelined_calls_equal_the_same_calls_made_one_by_one(ellc, seed, concurrent, coalesce):
+@pytest.mark.parametrize("seed,concurrent,coalesce,cache", [(1, 3, 1, 0), (2, 3, 1, 0), (3, 1, 1, 0), (4, 3, 3, 0), (5, 3, 2, 0), (6, 12, 3, 0),
+                                                            (7, 16, 4, 0), (8, 3, 1, 1), (9, 16, 4, 1), (10, 8, 2, 1)])
+def test_pipelined_calls_equal_the_same_calls_made_one_by_one(ellc, seed, concurrent, coalesce, cache):
     """Differential test of the asynchronous queue: a random sequence of batches (FCA and ICA, with and without saved
     weights, overlapping and disjoint keyframe slots), frame / keyframe uploads and depth updates is applied to two
     contexts — one keeps up to three batches in flight (4 x coalesce with cfg.coalesce > 1, where full batches enqueued one
     after the other run side by side in one launch sequence), the other runs every call synchronously. Every fetched result
     and the final weight planes must be identical: concurrency and grouping may change when things run, never what they
-    compute."""
+    compute. cache = 1: the pipelined context also keeps the compact pixel lists with the keyframe slots (cfg.cache_records) and
+    rebuilds them only after a slot's image, depth or weights have changed — the synchronous context rebuilds them in every call."""
     w, h, L = 160, 120, 3
     rng = np.random.default_rng(seed)
     pairs = [synth.make_pair(w, h, seed=300 + i, rot=0.003 + 0.001 * i, trans=0.01) for i in range(5)]
     mi = (3, 4, 5)
     kw = dict(early_exit=int(rng.integers(0, 2)), max_iter=mi, max_batch=4, concurrent_batches=concurrent, coalesce=coalesce)
     limit = 3 if coalesce == 1 else 4 * coalesce
-    a = gpu_problem(ellc, w, h, L, pairs, **kw)
+    a = gpu_problem(ellc, w, h, L, pairs, cache_records=cache, **kw)
     b = gpu_problem(ellc, w, h, L, pairs, **kw)
     for ctx in (a, b):
         for s in range(5):
@@ -421,10 +423,22 @@ def test_pipelined_calls_equal_the_same_calls_made_one_by_one(ellc, seed, concur
             s, k = int(rng.integers(0, 5)), int(rng.integers(0, 5))
             for ctx in (a, b):
                 ctx.frame_upload(s, pairs[k]["cur_image"])
-        elif op < 0.85:
+        elif op < 0.82:
             s, k = int(rng.integers(0, 5)), int(rng.integers(0, 5))
             for ctx in (a, b):
                 ctx.keyframe_set_depth(s, pairs[k]["depth0"], pairs[k]["var0"])
+        elif op < 0.84:
+            s, l = int(rng.integers(0, 5)), int(rng.integers(0, L))
+            wnew = rng.uniform(0.01, 0.06, size=(h >> l, w >> l)).astype(np.float32)
+            for ctx in (a, b):
+                ctx.keyframe_set_weights(s, l, wnew, 1)
+        elif op < 0.85:
+            s, k = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+            for ctx in (a, b):   # a keyframe slot re-used for another keyframe
+                ctx.keyframe_upload(s, pairs[k]["kf_image"])
+                ctx.keyframe_set_depth(s, pairs[k]["depth0"], pairs[k]["var0"])
+                for l in range(L):
+                    ctx.keyframe_set_weights(s, l, np.full((h >> l, w >> l), 0.03, np.float32), 1)
         elif op < 0.93:
             drain(int(rng.integers(0, len(expected) + 1)))
         else:
@@ -437,6 +451,53 @@ def test_pipelined_calls_equal_the_same_calls_made_one_by_one(ellc, seed, concur
             wa, na = a.keyframe_weights(s, l)
             wb, nb = b.keyframe_weights(s, l)
             assert na == nb and np.array_equal(wa, wb)
+    a.close(); b.close()
+
+
+def test_record_cache_is_invalidated_by_every_writer(ellc):
+    """cfg.cache_records keeps a keyframe slot's compact pixel lists across calls. Every entry point that changes what the
+    lists are built from — image, depth pyramid, weight planes — must mark the slot: after each such call the cached context
+    gives, bit for bit, what a context without the cache gives (FCA and ICA, so both record sets are exercised)."""
+    w, h, L = 160, 120, 3
+    pairs = [synth.make_pair(w, h, seed=500 + i, rot=0.004, trans=0.012) for i in range(3)]
+    kw = dict(early_exit=0, max_iter=(3, 4, 5), max_batch=2, max_keyframes=4, max_frames=4)
+    a = gpu_problem(ellc, w, h, L, pairs, cache_records=1, **kw)
+    b = gpu_problem(ellc, w, h, L, pairs, **kw)
+    st = synth.make_depth_state(w, h, 7, pairs[1]["kf_image"], pairs[1]["idepth_true"])
+    rng = np.random.default_rng(4)
+    planes = [rng.uniform(0.01, 0.06, size=(h >> l, w >> l)).astype(np.float32) for l in range(L)]
+
+    def check(what):
+        for mode in (0, 1, 0):   # FCA, ICA, FCA again: the second FCA call finds the ICA lists in the slot
+            ra = a.align([0, 1], [0, 1], mode=mode)
+            rb = b.align([0, 1], [0, 1], mode=mode)
+            assert all(np.array_equal(x, y) for x, y in zip(ra, rb)), (what, mode)
+            ra = a.align([0, 1], [0, 1], mode=mode)   # and from the cache
+            assert all(np.array_equal(x, y) for x, y in zip(ra, rb)), (what, mode, "cached")
+
+    for ctx in (a, b):
+        for s in range(3):
+            for l in range(L):
+                ctx.keyframe_set_weights(s, l, np.full((h >> l, w >> l), 0.03, np.float32), 1)
+    check("initial")
+    writers = [
+        ("keyframe_set_depth", lambda c: c.keyframe_set_depth(0, pairs[2]["depth0"], pairs[2]["var0"])),
+        ("keyframe_set_depth_level", lambda c: c.keyframe_set_depth_level(1, 1, *[x.copy() for x in c.keyframe_depth_level(0, 1)])),
+        ("keyframe_set_weights", lambda c: [c.keyframe_set_weights(0, l, planes[l], 2) for l in range(L)]),
+        ("keyframe_finalise_weights", lambda c: c.keyframe_finalise_weights(0)),
+        ("keyframe_upload + depth", lambda c: (c.keyframe_upload(1, pairs[2]["kf_image"]), c.keyframe_set_depth(1, pairs[2]["depth0"], pairs[2]["var0"]),
+                                              [c.keyframe_set_weights(1, l, planes[l], 1) for l in range(L)])),
+        ("copy_slot", lambda c: c.copy_slot(1, 0, 1, 2)),
+        ("keyframe_from_frame + depth", lambda c: (c.keyframe_from_frame(1, 2), c.keyframe_set_depth(1, pairs[0]["depth0"], pairs[0]["var0"]),
+                                                  [c.keyframe_set_weights(1, l, planes[l], 1) for l in range(L)])),
+        ("depth map -> update_depth_image", lambda c: (c.depth_set_keyframe(1), c.depth_set_state(st), c.depth_regularize(False),
+                                                      c.depth_update_depth_image())),
+        ("saved weights", lambda c: c.align([0, 1], [1, 0], mode=0, save_weights=True)),
+        ("single-step API", lambda c: c.gn_iterate(0, 1, 1, np.zeros(6, np.float32))),
+    ]
+    for name, fn in writers:
+        fn(a); fn(b)
+        check(name)
     a.close(); b.close()
 
 

@@ -3,7 +3,7 @@
 import json
 import sys
 
-KEYS = ["repeat_blocks", "single_alignment", "exact_arith", "ica_mode", "early_exit_on", "c4_dense", "tracked_frame"]
+KEYS = ["repeat_blocks", "single_alignment", "exact_arith", "ica_mode", "lc_stream_shared_keyframes", "early_exit_on", "c4_dense", "tracked_frame"]
 for f in sys.argv[1:]:
     d = json.loads(open(f).read().strip().splitlines()[-1])
     r = d["roofline"]
