@@ -16,7 +16,9 @@ W, H, L = 640, 480, 4
 pair = synth.make_pair(W, H, seed=31, rot=0.006, trans=0.03)
 fx, fy, cx, cy = pair["intrinsics"]
 st = synth.make_depth_state(W, H, 9, pair["kf_image"], pair["idepth_true"])
-ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=2, max_frames=2))
+ARITH = sys.argv[2] if len(sys.argv) > 2 else "fast"   # usage: bench_track.py [frames] [fast|exact]
+ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=2, max_frames=2,
+                                     arith=api.ARITH_FAST if ARITH == "fast" else api.ARITH_EXACT))
 ctx.keyframe_upload(0, pair["kf_image"])
 ctx.depth_set_keyframe(0)
 ctx.depth_set_state(st)
@@ -41,6 +43,6 @@ for f in range(N):
     iters += int(np.asarray(it).sum())
 ctx.sync()
 dt = time.perf_counter() - t00
-print(json.dumps({"frames": N, "ms_per_frame": 1e3 * dt / N, "frames_per_s": N / dt, "mean_gn_iterations": iters / N,
+print(json.dumps({"arith": ARITH, "frames": N, "ms_per_frame": 1e3 * dt / N, "frames_per_s": N / dt, "mean_gn_iterations": iters / N,
                   "host_ms": {k: 1e3 * v / N for k, v in t.items()}}))
 ctx.close()
