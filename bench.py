@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
 """ELLC hot-path benchmark: Gauss-Newton iterations / second on 640x480 semi-dense alignments.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU. Either the driver starts the ranks (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from the environment), or — when WORLD_SIZE is
+not set — this program starts them itself: N child processes with that environment, BEFORE anything touches the GPU, rank 0's
+JSON line passed through. Nothing here imports torch: the ranks meet over the library's own host-side communicator (TCP on
+MASTER_ADDR:MASTER_PORT+17 — barrier, unique id, maximum of the timings) and the data path's one collective, the gather of the
+resulting se(3) poses, is ncclAllGather (RCCL over xGMI) issued by the library's C entry points (ellc_gather_start / _finish).
 
 One *step* = one pass of the hot path over one batch: the loop-closure batch in the reference's own shape
 (GlobalOptimize.cpp:566) — `--batch` different keyframes, each with its own semi-dense depth map, aligned against ONE
@@ -10,13 +17,15 @@ Gauss-Newton schedule with early exit disabled so the work is deterministic (32 
 when N>1 — by the single gather of the resulting se(3) poses over RCCL. Inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field). Besides the contract's fields it carries the
-same workload in the per-pixel bit-exact arithmetic mode (`exact_arith`), BASELINE configs[4] at 16 alignments per GPU
-(`c4_dense`), the depth-map kernels against their algorithmic bytes (`depth`), the single alignment and tracked frame of
-configs[1], and the CPU port timed on this box's host cores (`cpu_baseline`, with the pose error of the GPU result against it).
+same workload in the per-pixel bit-exact arithmetic mode (`exact_arith`, repeated in `config`), a sustained block of >= 2000
+steps, BASELINE configs[4] at 16 alignments per GPU (`c4_dense`), the depth-map kernels against their algorithmic bytes
+(`depth`), the single alignment and tracked frame of configs[1] (with and without the loop-closure batch running beside it),
+and the CPU port timed on this box's host cores (`cpu_baseline`, with the pose error of the GPU result against it).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -47,16 +56,91 @@ def parse():
     ap.add_argument("--early-exit", action="store_true", help="informational: the reference's early exit on (data-dependent iteration counts; "
                     "value then counts the iterations actually executed)")
     ap.add_argument("--blocks", type=int, default=25, help="after the timed region: this many further blocks of --steps steps, for the spread (N=1)")
+    ap.add_argument("--sustained", type=int, default=2000, help="after the timed region: one block of this many steps (N=1; 0: none)")
     ap.add_argument("--no-extras", action="store_true", help="only the contract's fields (no exact_arith / c4_dense / depth / tracking sub-records)")
     ap.add_argument("--trace-only", action="store_true", help="stop after the timed region (kernel traces of exactly the timed workload)")
-    ap.add_argument("--gather", choices=["cabi", "torch"], default="cabi", help="N>1: the gather of the poses through the library's C entry points "
-                    "(ellc_gather_start/_finish: ncclAllGather in C++; torch.distributed only hands out the unique id) or through torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-at-1", action="store_true", help="N=1 only: run the per-batch gather all the same (RCCL communicator of one rank through "
                     "the library's C entry points): what the exchange costs the loop, measured on one GPU")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse ranks sharing one GPU)")
+    ap.add_argument("--backend", choices=["nccl", "gloo", "tcp"], default="nccl", help="N>1: transport of the gather of the poses. nccl = RCCL "
+                    "(ncclAllGather over xGMI, one GPU per rank); gloo / tcp = the same entry points over the library's TCP transport "
+                    "(host memory): only to rehearse several ranks on ONE GPU, where RCCL refuses two ranks on a device")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-time budget of each CPU baseline variant")
+    ap.add_argument("--rehearse-launcher", action="store_true", help="no GPU work: start the ranks, run the control plane (barrier, id broadcast, "
+                    "max) and a few pipelined gathers of stand-in result tables over the TCP transport, print what each rank saw (CPU test of the launcher)")
+    ap.add_argument("--lib", default=None, help="diagnostic A/B only: load this build of the library instead of csrc/libellc_hip.so")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """--gpus N > 1 without a launcher: start N ranks of this very command (before this process has loaded the library or
+    touched a GPU), pass rank 0's output through, fail if any rank fails. The children find WORLD_SIZE set and run main()."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a free port for the ranks' rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:   # a rank failed: the others would wait for it until their time-outs
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+class Control:
+    """The ranks' control plane (never the data path): barrier, rank 0's 128-byte RCCL id to everyone, maximum of a number — each
+    one gather of host memory over the library's TCP communicator (ellc_comm_init_tcp). world == 1: nothing to do."""
+
+    def __init__(self, sharding, world, rank, host_only=False):
+        self.world, self.rank = world, rank
+        self.comm = None
+        if world > 1:
+            port = int(os.environ.get("MASTER_PORT", "29500")) + 17
+            self.comm = sharding.Comm(world, rank, max_total=8 * world, transport="tcp", host=os.environ.get("MASTER_ADDR", "127.0.0.1"), port=port,
+                                      host_only=host_only)
+
+    def _gather(self, rows_per_rank, mine):
+        import numpy as np
+        return self.comm.gather(rows_per_rank * self.world, np.asarray(mine, np.float32).reshape(rows_per_rank, 8))
+
+    def barrier(self):
+        if self.comm is not None:
+            self._gather(1, [0.0] * 8)
+
+    def max(self, x):
+        if self.comm is None:
+            return float(x)
+        import numpy as np
+        rec = np.zeros(8, np.float32)
+        rec[:2] = np.array([x], np.float64).view(np.float32)   # an f64 as two f32 words, moved bit for bit
+        t = self._gather(1, rec)
+        return float(max(np.ascontiguousarray(t[r, :2]).view(np.float64)[0] for r in range(self.world)))
+
+    def broadcast_id(self, make):
+        """rank 0's ellc_comm_unique_id bytes on every rank (128 bytes = 4 records of the gather, moved bit for bit)."""
+        import numpy as np
+        if self.comm is None:
+            return make()
+        mine = np.frombuffer(make() if self.rank == 0 else bytes(128), np.uint8).view(np.float32)
+        return self._gather(4, mine)[:4].tobytes()
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
 
 
 class Workload:
@@ -113,11 +197,11 @@ class Workload:
                 on_fetch(pose, iters, wgt)
         return pose, iters
 
-    def timed(self, nsteps, sync):
-        sync()
+    def timed(self, nsteps):
+        self.ctx.sync()
         t0 = time.perf_counter()
         pose, iters = self.run(nsteps)
-        sync()
+        self.ctx.sync()
         return time.perf_counter() - t0, pose, iters
 
     def level0_kernel(self, reps=50):
@@ -134,21 +218,26 @@ class Workload:
 
 def main():
     a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if world == 0 and a.gpus > 1:
+        sys.exit(spawn_ranks(a))   # this process never loads the library: nothing here has touched a GPU
+    world = max(1, world)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    import torch.distributed as dist
-    ndev = max(1, torch.cuda.device_count())
-    dev_index = local_rank % ndev
-    if world > 1:
-        torch.cuda.set_device(dev_index)
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(a.backend)
-    coll_dev = torch.device("cuda", dev_index) if a.backend == "nccl" else torch.device("cpu")
+    if a.rehearse_launcher:
+        return rehearse_launcher(a, world, rank, local_rank)
+    from egomotion_with_local_loop_closures_amd import _lib
+    if a.lib:
+        _lib.use_library(a.lib)
     from egomotion_with_local_loop_closures_amd import api, synth, sharding
+    ndev = _lib.lib().ellc_device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no HIP device is visible (there is no CPU fallback for the product path)")
+    if a.backend == "nccl" and world > 1 and local_rank >= ndev:
+        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible) and RCCL refuses two ranks on one device; "
+                         "--backend gloo rehearses several ranks on one GPU over the TCP transport" % (rank, ndev))
+    dev_index = local_rank % ndev
+    ctl = Control(sharding, world, rank)
 
     W, H, L, B = a.width, a.height, a.levels, a.batch
     # ---- synthetic inputs (seeded, per rank), uploaded once: resident in HBM before anything is timed
@@ -160,56 +249,36 @@ def main():
     G, sched = wl.G, wl.sched
     iters_per_alignment = sum(sched)
     # ---- the gather of the resulting se(3) poses (8 floats per alignment): the batches of one launch group complete together,
-    # so their tables are exchanged together — one all_gather per group of `coalesce` batches, enqueued when the group's last
-    # batch is fetched and collected a few groups later, so the exchange never stalls the loop. Default: the library's own C++
-    # path (ellc_gather_start / ellc_gather_finish over RCCL); torch.distributed only carries rank 0's unique id to the others.
+    # so their tables are exchanged together — one all-gather per group of `coalesce` batches, enqueued when the group's last
+    # batch is fetched and collected a few groups later, so the exchange never stalls the loop. It is the library's own C++
+    # path (ellc_gather_start / ellc_gather_finish: ncclAllGather on a stream of its own).
     gathering = world > 1 or a.gather_at_1
-    use_cabi = gathering and a.gather == "cabi"
     bucket_n = wl.coalesce                      # batches per exchange
     per_max = bucket_n * B * world              # rows of the largest gathered table
     bucket = []
     depth = 4                                   # exchanges in flight: the library keeps a ring of four (ellc_comm)
-    if use_cabi:
+    comm = None
+    if gathering:
         if a.backend == "nccl":
-            ids = [sharding.Comm.unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(ids, src=0)
-            comm = sharding.Comm(world, rank, max_total=per_max, transport="rccl", device=dev_index, unique_id=ids[0])
-        else:   # rehearsal of several ranks on one GPU (RCCL refuses two ranks on one device): the same entry points over TCP
-            comm = sharding.Comm(world, rank, max_total=per_max, transport="tcp", port=int(os.environ.get("MASTER_PORT", "29500")) + 17)
-        outstanding = []   # rows of each exchange in flight, oldest first
+            uid = ctl.broadcast_id(sharding.Comm.unique_id)
+            comm = sharding.Comm(world, rank, max_total=per_max, transport="rccl", device=dev_index, unique_id=uid)
+        else:   # rehearsal of several ranks on one GPU: the same entry points over TCP
+            comm = sharding.Comm(world, rank, max_total=per_max, transport="tcp", host=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                 port=int(os.environ.get("MASTER_PORT", "29500")) + 18)
+    outstanding = []   # rows of each exchange in flight, oldest first
+    gathered_rows = [0]
 
-        def finish_one():
-            rows = outstanding.pop(0)
-            assert comm.finish(rows).shape == (rows, sharding.RECORD)
+    def finish_one():
+        rows = outstanding.pop(0)
+        t = comm.finish(rows)
+        assert t.shape == (rows, sharding.RECORD)
+        gathered_rows[0] += rows
 
-        def start(table):
-            if len(outstanding) == depth:
-                finish_one()
-            comm.start(table.shape[0] * world, table)
-            outstanding.append(table.shape[0] * world)
-
-        def pending():
-            return len(outstanding)
-    else:
-        gatherers = {}   # one preallocated ring per table size (full buckets, and the partial one that ends a run)
-        order = []
-
-        def finish_one():
-            rows = order.pop(0)
-            assert gatherers[rows].finish().shape == (rows, sharding.RECORD)
-
-        def start(table):
-            rows = table.shape[0] * world
-            if rows not in gatherers:
-                gatherers[rows] = sharding.ResultGatherer(rows, device=(coll_dev if world > 1 else None), depth=depth)
-            if len(order) == depth:
-                finish_one()
-            gatherers[rows].start(table)
-            order.append(rows)
-
-        def pending():
-            return len(order)
+    def start(table):
+        if len(outstanding) == depth:
+            finish_one()
+        comm.start(table.shape[0] * world, table)
+        outstanding.append(table.shape[0] * world)
 
     def on_fetch(pose, iters, wgt):
         bucket.append(sharding.pack_results(pose, iters, wgt))
@@ -221,7 +290,7 @@ def main():
         if bucket:
             start(np.concatenate(bucket))
             bucket.clear()
-        while pending():
+        while outstanding:
             finish_one()
 
     def run(nsteps):
@@ -230,21 +299,16 @@ def main():
             drain()
         return r
 
+    sync = wl.ctx.sync   # ellc_sync: every stream of the context has drained (no torch in this process)
     if a.warmup > 0:
         run(a.warmup)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    ctl.barrier()
+    sync()
     t0 = time.perf_counter()
     pose, iters = run(a.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    sync()
+    ctl.barrier()
+    dt = ctl.max(time.perf_counter() - t0)
     if a.early_exit:   # every batch of a group repeats the same alignments: the last batch's count holds for all
         iters_per_alignment = float(iters.sum()) / B
     else:
@@ -253,6 +317,10 @@ def main():
 
     shape = ("%d different keyframes (own depth map each) against ONE current frame per batch, the reference's loop-closure shape" % B) if not a.dense \
         else ("%d independent dense keyframe<->frame alignments per batch" % B)
+    gather_txt = ""
+    if world > 1:
+        gather_txt = ", one all-gather of the poses per launch group, issued by the library's C entry points over %s (overlapped with the next groups)" % (
+            "RCCL (ncclAllGather, xGMI)" if a.backend == "nccl" else "the TCP transport (rehearsal: several ranks on one GPU)")
     out = {
         "metric": "GN iterations/sec (%dx%d %s)" % (W, H, "dense" if a.dense else "semi-dense"),
         "value": value, "unit": "GN iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -262,21 +330,30 @@ def main():
                                "compaction included, arithmetic mode '%s' (%s), %d batches in flight, launched in groups of up to %d side by side (cfg.coalesce) on up to 3 streams%s"
                                % (shape, W, H, L, a.mode.upper(), sched, "ON: informational run" if a.early_exit else "off", a.arith,
                                   "pose <= 1e-5 vs the CPU path, tests/test_gpu_fast.py" if a.arith == "fast" else "per-pixel values bit-identical to the CPU path",
-                                  G, wl.coalesce, ", one all_gather of poses per launch group over %s (overlapped with the next groups)" % (("RCCL, issued by the library's C entry points" if use_cabi else "RCCL via torch.distributed") if a.backend == "nccl" else (a.backend + (" harness, gather through the library's C entry points over TCP" if use_cabi else ""))) if world > 1 else ""),
+                                  G, wl.coalesce, gather_txt),
                    "batch_per_gpu": B, "global_batch": B * world, "batches_in_flight": G, "coalesce": wl.coalesce,
                    "setup": "slots uploaded; hipGraphs captured by one untimed rehearsal of %d and %d steps (every launch sequence the warm-up "
                             "and the timed steps replay), then the %d warm-up steps" % (a.warmup, a.steps, a.warmup),
+                   "launcher": ("ranks started by the caller (WORLD_SIZE in the environment)" if "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
+                                else "ranks started by bench.py itself") if world > 1 else "single process",
+                   "control_plane": "library TCP communicator (barrier, unique id, max of the timings); torch is not imported",
                    "gn_iterations_per_alignment": iters_per_alignment,
                    "alignments_per_s": world * B * a.steps / dt, "pixels": "dense" if a.dense else "semi-dense (maxAbsGradient>=5)", "arith": a.arith},
     }
+    if gathering:
+        out["config"]["gathered_records_rank0"] = gathered_rows[0]
+
+    def finish():
+        if comm is not None:
+            comm.close()
+        ctl.barrier()
+        ctl.close()
 
     if a.trace_only:
         if rank == 0:
             print(json.dumps(out), flush=True)
         wl.close()
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        finish()
         return
     if rank == 0:
         # ---- roofline of the dominant kernel (FCA residual/Jacobian/accumulate at level 0), HIP events on the library's stream
@@ -290,12 +367,15 @@ def main():
         cal_ms = wl.ctx.profile_stream_read(cal_bytes, reps=5)
         out["roofline"]["measured_stream_read_GBps"] = cal_bytes / (cal_ms * 1e-3) / 1e9
         if world == 1 and not a.no_extras:
-            sync = torch.cuda.synchronize
             # ---- spread: further blocks of --steps steps, each bracketed like the timed region
             if a.blocks > 0:
-                ms = sorted(1e3 * wl.timed(a.steps, sync)[0] / a.steps for _ in range(a.blocks))
+                ms = sorted(1e3 * wl.timed(a.steps)[0] / a.steps for _ in range(a.blocks))
                 out["repeat_blocks"] = {"blocks": a.blocks, "steps_per_block": a.steps, "ms_per_step_median": ms[len(ms) // 2], "ms_per_step_min": ms[0],
                                         "ms_per_step_max": ms[-1], "value_at_median": B * iters_per_alignment / (ms[len(ms) // 2] * 1e-3)}
+            # ---- sustained: ONE block of many steps (the driver's 20-step window holds the pipeline's fill and drain)
+            if a.sustained > 0:
+                ds, _, _ = wl.timed(a.sustained)
+                out["sustained"] = {"steps": a.sustained, "ms_per_step": 1e3 * ds / a.sustained, "value": B * iters_per_alignment * a.sustained / ds}
             # ---- C1: the same path at B = 1 (latency-bound single alignment)
             wl.ctx.align([0], [0], mode=wl.mode)
             n1 = 30
@@ -312,12 +392,15 @@ def main():
             other = "exact" if a.arith == "fast" else "fast"
             w2 = Workload(api, a, scenes, other, dev_index, shared_frame=not a.dense, prime=[a.warmup, a.steps])
             w2.run(a.warmup)
-            d2, p2, _ = w2.timed(a.steps, sync)
+            d2, p2, _ = w2.timed(a.steps)
             k2 = w2.level0_kernel()
             tr2, ts2 = pmc_traffic(a, B, G, other)
             out[other + "_arith"] = {"value": B * iters_per_alignment * a.steps / d2, "ms_per_step": 1e3 * d2 / a.steps,
                                      "roofline": dict({"traffic": tr2, "traffic_source": ts2}, **k2),
                                      "pose_l2_diff_between_modes_max": float(np.linalg.norm(p2 - pose, axis=1).max())}
+            # both arithmetic modes side by side where a reader of `config` sees them
+            out["config"]["arith_modes"] = {a.arith: {"value": value, "level0_kernel_frac": k0["frac"]},
+                                            other: {"value": out[other + "_arith"]["value"], "level0_kernel_frac": k2["frac"]}}
             w2.close()
             # ---- early exit on (the reference's default), one batch at a time: informational
             w3 = Workload(api, a, scenes, a.arith, dev_index, early_exit=1, G=1, shared_frame=not a.dense, coalesce=1)
@@ -342,7 +425,7 @@ def main():
             # the same with the queue kept full, as the timed region does it (launch groups, cfg.coalesce)
             w5 = Workload(api, a, scenes, a.arith, dev_index, early_exit=1, shared_frame=not a.dense, prime=[a.warmup, a.steps])
             w5.run(a.warmup)
-            d6, _, it6 = w5.timed(a.steps, sync)
+            d6, _, it6 = w5.timed(a.steps)
             out["early_exit_on"]["pipelined"] = {"ms_per_batch": 1e3 * d6 / a.steps, "alignments_per_s": B * a.steps / d6,
                                                  "gn_iterations_per_s": float(np.asarray(it6).sum()) * a.steps / d6, "batches_in_flight": w5.G,
                                                  "coalesce": w5.coalesce}
@@ -353,7 +436,7 @@ def main():
                 ns.mode = "ica"
                 w4 = Workload(api, ns, scenes, a.arith, dev_index, shared_frame=True, prime=[a.warmup, a.steps])
                 w4.run(a.warmup)
-                d5, _, it5 = w4.timed(a.steps, sync)
+                d5, _, it5 = w4.timed(a.steps)
                 out["ica_mode"] = {"workload": "the same batches, ELLC_MODE_ICA (PixelWisePyramid.cpp:561-974: template-gradient Jacobian, saved "
                                                "weights, H^-1 once per keyframe and level), arith %s" % a.arith,
                                    "value": B * iters_per_alignment * a.steps / d5, "ms_per_step": 1e3 * d5 / a.steps}
@@ -367,25 +450,56 @@ def main():
                 for cache in (0, 1):
                     w6 = Workload(api, a, scenes, a.arith, dev_index, shared_frame=True, prime=[a.warmup, a.steps], share_kf=True, cache_records=cache)
                     w6.run(a.warmup)
-                    d7, _, it7 = w6.timed(a.steps, sync)
+                    d7, _, it7 = w6.timed(a.steps)
                     assert int(it7.sum()) == B * iters_per_alignment
                     rec["cache_records_%d" % cache] = {"ms_per_step": 1e3 * d7 / a.steps, "value": B * iters_per_alignment * a.steps / d7}
                     w6.close()
                 out["lc_stream_shared_keyframes"] = rec
-                out["c4_dense"] = c4_dense(api, synth, a, dev_index, sync)
+                out["c4_dense"] = c4_dense(api, synth, a, dev_index)
                 out["depth"] = depth_kernels(api, synth, dev_index)
                 out["tracked_frame"] = tracked_frame(api, synth, a, dev_index)
+                out["tracked_frame_with_lc"] = tracked_frame(api, synth, a, dev_index, with_lc=True)
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(a, scenes[0], sched, value, gpu_pose0)
         print(json.dumps(out), flush=True)
     if wl is not None:
         wl.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish()
 
 
-def c4_dense(api, synth, a, dev_index, sync):
+def rehearse_launcher(a, world, rank, local_rank):
+    """The launcher and the ranks' control plane without a GPU (tests/test_bench_launcher.py): every rank joins the TCP
+    communicator, receives rank 0's id, runs a few pipelined gathers of stand-in result tables through the C entry points
+    (libellc_comm.so: the host-only build of csrc/ellc_comm.cpp) and the barrier / max; rank 0 prints what it saw."""
+    from egomotion_with_local_loop_closures_amd import sharding
+    ctl = Control(sharding, world, rank, host_only=True)
+    uid = ctl.broadcast_id(lambda: bytes((7 * i + 255) % 256 for i in range(128)))   # (holds NaN bit patterns: moved bit for bit)
+    B = a.batch
+    comm = sharding.Comm(world, rank, max_total=B * world, transport="tcp", host=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                         port=int(os.environ.get("MASTER_PORT", "29500")) + 18, host_only=True)
+    ok = True
+    for s in range(a.steps):
+        comm.start(B * world, np.full((B, 8), 1000.0 * s + rank, np.float32))
+        if s >= 3:
+            t = comm.finish(B * world)
+            ok = ok and all(np.all(t[r * B:(r + 1) * B] == 1000.0 * (s - 3) + r) for r in range(world))
+    for s in range(max(0, a.steps - 3), a.steps):
+        t = comm.finish(B * world)
+        ok = ok and all(np.all(t[r * B:(r + 1) * B] == 1000.0 * s + r) for r in range(world))
+    ctl.barrier()
+    mx = ctl.max(1.0 + rank)
+    envs = ctl._gather(1, np.array([rank, local_rank, int(os.environ["WORLD_SIZE"]), int(os.environ["MASTER_PORT"]), os.getpid() % 65536, 0, 0, 0], np.float32)) \
+        if world > 1 else np.array([[rank, local_rank, world, 0, 0, 0, 0, 0]], np.float32)
+    comm.close()
+    ctl.barrier()
+    ctl.close()
+    if rank == 0:
+        print(json.dumps({"rehearsal": "launcher + control plane over the TCP transport, no GPU work", "n_gpus": world, "steps": a.steps, "value": None,
+                          "gathers_ok": bool(ok), "id_ok": uid == bytes((7 * i + 255) % 256 for i in range(128)), "max_over_ranks": mx,
+                          "ranks": [{"rank": int(e[0]), "local_rank": int(e[1]), "world_size": int(e[2]), "master_port": int(e[3])} for e in envs]}), flush=True)
+
+
+def c4_dense(api, synth, a, dev_index):
     """BASELINE configs[4] at its per-GPU batch (the honest HBM test — the working set streams from HBM):
     1280x960, 5 levels {4,7,9,12,12}, dense residuals, 16 alignments per batch, pipelined as the main workload is; both arithmetic modes."""
     W, H, L, B = 1280, 960, 5, 16
@@ -398,7 +512,7 @@ def c4_dense(api, synth, a, dev_index, sync):
         steps = 12
         w = Workload(api, ns, scenes, arith, dev_index, W=W, H=H, L=L, B=B, shared_frame=False, prime=[3, steps])
         w.run(3)
-        d, _, iters = w.timed(steps, sync)
+        d, _, iters = w.timed(steps)
         assert int(iters.sum()) == B * 44
         # algorithmic bytes of one full-schedule alignment: sum over levels of iters_l * (4 N_l + 14 V_l), V_l = N_l (dense): 144.8 MB
         alg = 0.0
@@ -456,33 +570,84 @@ def depth_kernels(api, synth, dev_index):
     return rec
 
 
-def tracked_frame(api, synth, a, dev_index):
+def tracked_frame(api, synth, a, dev_index, with_lc=False):
     """BASELINE configs[1] as the reference's main loop runs it (main.cpp:330, 499-502): per frame an upload (+ pyramid), one FCA
     alignment against the active keyframe with early exit ON and saved weights, then observe / fill holes / regularise /
-    updateDepthImage enqueued behind it."""
+    updateDepthImage enqueued behind it.
+    with_lc: every 8th frame (KEYFRAME_PROPAGATE_INTERVAL) the finished keyframe goes to the loop-closure ring — a context of its
+    own — and is aligned against `n_cand` candidates in ONE constant-weight batch (GlobalOptimize.cpp:566), (a) on a host thread
+    beside tracking, joined at the next push (the reference's FLAG_DO_PARALLEL_SHORT_LOOP_CLOSURE, :241 / :161; what ellc_main
+    does), and (b) inline on the tracking thread, for comparison."""
+    import threading
     W, H, L = 640, 480, 4
     pair = synth.make_pair(W, H, seed=0x5EED)
     fx, fy, cx, cy = pair["intrinsics"]
-    ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=2, max_frames=2, device=dev_index,
-                                         arith=api.ARITH_FAST if a.arith == "fast" else api.ARITH_EXACT))
-    ctx.keyframe_upload(0, pair["kf_image"]); ctx.keyframe_set_depth(0, pair["depth0"], pair["var0"])
-    st = synth.make_depth_state(W, H, 9, pair["kf_image"], pair["idepth_true"])
-    ctx.depth_set_keyframe(0); ctx.depth_set_state(st)
-    n, its = 60, 0
-    for f in range(5 + n):
-        if f == 5:
-            ctx.sync()
-            t0 = time.perf_counter()
-            its = 0
-        ctx.frame_upload(f & 1, pair["cur_image"])
-        p, it, _ = ctx.align([0], [f & 1], save_weights=True)
-        its += int(it.sum())
-        ctx.depth_observe(f & 1, p[0]); ctx.depth_fill_holes(); ctx.depth_regularize(False); ctx.depth_update_depth_image()
-    ctx.sync()
-    d = (time.perf_counter() - t0) / n
-    ctx.close()
-    return {"workload": "C1 loop: upload + pyramid, one FCA alignment (early exit on, saved weights), observe + fill holes + regularise + export, "
-                        "640x480, 4 levels, arith %s" % a.arith, "ms_per_frame": 1e3 * d, "frames_per_s": 1.0 / d, "mean_gn_iterations_per_frame": its / n}
+    arith = api.ARITH_FAST if a.arith == "fast" else api.ARITH_EXACT
+    n_cand = 8
+
+    def loop(lc_mode):   # None | "thread" | "inline"
+        ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=2, max_frames=2, device=dev_index, arith=arith))
+        ctx.keyframe_upload(0, pair["kf_image"]); ctx.keyframe_set_depth(0, pair["depth0"], pair["var0"])
+        st = synth.make_depth_state(W, H, 9, pair["kf_image"], pair["idepth_true"])
+        ctx.depth_set_keyframe(0); ctx.depth_set_state(st)
+        ring = None
+        if lc_mode:
+            ring = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=n_cand + 1, max_frames=1, max_batch=n_cand,
+                                                  grid_batch=n_cand, device=dev_index, arith=arith))
+            for k in range(n_cand):
+                ring.keyframe_upload(k, pair["kf_image"]); ring.keyframe_set_depth(k, pair["depth0"], pair["var0"])
+                for l in range(L):
+                    ring.keyframe_set_weights(k, l, np.full((H >> l, W >> l), 0.03, np.float32), 1)
+        worker = [None]
+        batches = [0]
+
+        def match():   # the matching thread's device work: test keyframe -> frame slot, one ICA batch over the candidates
+            ring.copy_slot(False, 0, True, n_cand)
+            ring.align(np.arange(n_cand, dtype=np.int32), np.zeros(n_cand, np.int32), mode=api.MODE_ICA)
+            batches[0] += 1
+
+        n, its = 64, 0
+        for f in range(8 + n):
+            if f == 8:
+                if worker[0] is not None:
+                    worker[0].join(); worker[0] = None
+                ctx.sync()
+                t0 = time.perf_counter()
+                its = 0
+                batches[0] = 0
+            ctx.frame_upload(f & 1, pair["cur_image"])
+            p, it, _ = ctx.align([0], [f & 1], save_weights=True)
+            its += int(it.sum())
+            ctx.depth_observe(f & 1, p[0]); ctx.depth_fill_holes(); ctx.depth_regularize(False); ctx.depth_update_depth_image()
+            if lc_mode and f % 8 == 7:   # pushToArray: join the previous match thread, deep-copy the keyframe, start the next
+                if worker[0] is not None:
+                    worker[0].join(); worker[0] = None
+                api.copy_slot_across(ring, True, n_cand, ctx, True, 0)
+                if lc_mode == "thread":
+                    worker[0] = threading.Thread(target=match)
+                    worker[0].start()
+                else:
+                    match()
+        if worker[0] is not None:
+            worker[0].join()
+        ctx.sync()
+        if ring is not None:
+            ring.sync()
+        d = (time.perf_counter() - t0) / n
+        ctx.close()
+        if ring is not None:
+            ring.close()
+        return d, its / n, batches[0]
+
+    if not with_lc:
+        d, its, _ = loop(None)
+        return {"workload": "C1 loop: upload + pyramid, one FCA alignment (early exit on, saved weights), observe + fill holes + regularise + export, "
+                            "640x480, 4 levels, arith %s" % a.arith, "ms_per_frame": 1e3 * d, "frames_per_s": 1.0 / d, "mean_gn_iterations_per_frame": its}
+    dt_, its, nb = loop("thread")
+    di_, _, _ = loop("inline")
+    return {"workload": "the C1 loop with the loop-closure batch of every 8th frame (%d candidates, ICA, a context of its own): on a host thread beside "
+                        "tracking, joined at the next push (GlobalOptimize.cpp:241 / :161), against the same batch run inline" % n_cand,
+            "ms_per_frame": 1e3 * dt_, "frames_per_s": 1.0 / dt_, "ms_per_frame_lc_inline": 1e3 * di_, "lc_batches": nb, "mean_gn_iterations_per_frame": its}
 
 
 def load_profile_json(stem):

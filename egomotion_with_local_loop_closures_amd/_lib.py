@@ -8,12 +8,12 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.environ.get("ELLC_LIB_PATH") or os.path.join(CSRC, "libellc_hip.so")   # override: diagnostic builds only
+SO_PATH = os.path.join(CSRC, "libellc_hip.so")   # the shipping loader reads nothing from the environment; diagnostic tools call use_library()
 MAX_LEVELS = 8
 
 # every symbol include/ellc_abi.h declares (checked by tests/test_abi_symbols.py against the header text)
 ABI_SYMBOLS = [
-    "ellc_abi_version", "ellc_default_config", "ellc_ctx_create", "ellc_ctx_destroy", "ellc_last_error", "ellc_sync", "ellc_stream",
+    "ellc_abi_version", "ellc_device_count", "ellc_default_config", "ellc_ctx_create", "ellc_ctx_destroy", "ellc_last_error", "ellc_sync", "ellc_stream",
     "ellc_frame_upload", "ellc_keyframe_upload", "ellc_keyframe_from_frame", "ellc_get_image_level", "ellc_get_gradient",
     "ellc_get_max_gradient", "ellc_keyframe_set_depth", "ellc_keyframe_set_depth_level", "ellc_keyframe_get_depth_level",
     "ellc_keyframe_set_weights", "ellc_keyframe_get_weights", "ellc_keyframe_finalise_weights", "ellc_align", "ellc_align_enqueue",
@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "ellc_se3_log", "ellc_depth_set_state", "ellc_depth_get_state", "ellc_depth_set_keyframe", "ellc_depth_propagate",
     "ellc_depth_observe", "ellc_depth_fill_holes", "ellc_depth_regularize", "ellc_depth_make_inv_depth_one",
     "ellc_depth_update_depth_image", "ellc_depth_create_keyframe", "ellc_depth_seeds", "ellc_profile_gn_kernel", "ellc_profile_align",
-    "ellc_profile_calibrate_read", "ellc_profile_stream_read", "ellc_histogram", "ellc_kl_divergence", "ellc_copy_slot", "ellc_selftest_div_pair",
+    "ellc_profile_calibrate_read", "ellc_profile_stream_read", "ellc_histogram", "ellc_kl_divergence", "ellc_copy_slot", "ellc_copy_slot_across", "ellc_selftest_div_pair",
     "ellc_ingest_configure", "ellc_frame_ingest_bgr", "ellc_selftest_lu", "ellc_profile_depth_stage",
     "ellc_shard_range", "ellc_comm_unique_id", "ellc_comm_init_rccl", "ellc_comm_init_tcp", "ellc_comm_destroy", "ellc_comm_last_error",
     "ellc_gather_start", "ellc_gather_finish", "ellc_gather_results",
@@ -33,7 +33,7 @@ class EllcConfig(C.Structure):
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("max_iter", C.c_int * MAX_LEVELS), ("early_exit", C.c_int),
                 ("max_keyframes", C.c_int), ("max_frames", C.c_int), ("max_batch", C.c_int), ("device", C.c_int),
-                ("concurrent_batches", C.c_int), ("arith", C.c_int), ("coalesce", C.c_int), ("cache_records", C.c_int)]
+                ("concurrent_batches", C.c_int), ("arith", C.c_int), ("coalesce", C.c_int), ("cache_records", C.c_int), ("grid_batch", C.c_int)]
 
 
 class EllcHypotheses(C.Structure):
@@ -73,6 +73,15 @@ def comm_lib():
 
 
 _lib = None
+
+
+def use_library(path):
+    """Diagnostic tools only (tools/*.py with build/libellc_hip_diag.so or ..._stamps.so): load this build instead of the
+    shipping library. Must be called before the first lib(); the path is explicit, never taken from the environment."""
+    global SO_PATH
+    if _lib is not None:
+        raise EllcError("use_library: the library is already loaded")
+    SO_PATH = os.path.abspath(path)
 
 
 def lib():

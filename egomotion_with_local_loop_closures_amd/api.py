@@ -296,6 +296,13 @@ class Context:
         return ms.value
 
 
+def copy_slot_across(dst_ctx, dst_is_kf, dst, src_ctx, src_is_kf, src):
+    """ellc_copy_slot_across: a slot's planes from one context into another on the same device (the loop-closure ring's deep copy)."""
+    st = _lib.lib().ellc_copy_slot_across(dst_ctx.h, int(dst_is_kf), dst, src_ctx.h, int(src_is_kf), src)
+    if st != 0:
+        raise EllcError("ellc_copy_slot_across -> %d: %s" % (st, _lib.lib().ellc_last_error(dst_ctx.h).decode()))
+
+
 def concatenate_relative_pose(a, b):
     a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
     o = np.zeros(6, np.float32)

@@ -13,6 +13,8 @@
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
+#include <sys/time.h>
 #include <sys/socket.h>
 #include <unistd.h>
 #include <algorithm>
@@ -44,6 +46,7 @@ struct ellc_comm {
 #endif
   } slot[ELLC_GATHER_DEPTH];
   int head = 0, pending = 0;       // oldest outstanding slot, number outstanding
+  bool dead = false;               // a TCP exchange failed half-way: the streams are out of step, every later gather is refused
   // TCP
   int listen_fd = -1;
   std::vector<int> peer;           // rank 0: socket of every other rank (index = rank); others: [0] = socket to rank 0
@@ -88,6 +91,16 @@ bool recv_all(int fd, void* p, size_t n) {
   return true;
 }
 
+// every blocking socket call of the communicator has a deadline: a peer that died (or a stray connection) must not hang a rank
+const int kTimeoutSeconds = 60;
+void set_socket_timeouts(int fd) {
+  timeval tv;
+  tv.tv_sec = kTimeoutSeconds;
+  tv.tv_usec = 0;
+  ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+  ::setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+}
+
 }  // namespace
 
 extern "C" {
@@ -127,16 +140,25 @@ ellc_status ellc_comm_init_tcp(const char* host, int port, int world, int rank, 
     if (::bind(c->listen_fd, (sockaddr*)&addr, sizeof(addr)) != 0 || ::listen(c->listen_fd, world) != 0)
       return cfail(c, ELLC_ERR_HIP, std::string("bind/listen failed: ") + std::strerror(errno));
     c->peer.assign(world, -1);
-    for (int k = 1; k < world; k++) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(kTimeoutSeconds);
+    for (int k = 1; k < world;) {
+      const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+      pollfd pf;
+      pf.fd = c->listen_fd; pf.events = POLLIN; pf.revents = 0;
+      const int pr = left > 0 ? ::poll(&pf, 1, (int)left) : 0;
+      if (pr < 0 && errno == EINTR) continue;
+      if (pr <= 0) return cfail(c, ELLC_ERR_HIP, "ellc_comm_init_tcp: not every rank connected within 60 s");
       const int fd = ::accept(c->listen_fd, nullptr, nullptr);
       if (fd < 0) return cfail(c, ELLC_ERR_HIP, "accept() failed");
       ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+      set_socket_timeouts(fd);
       int r = -1;
       if (!recv_all(fd, &r, sizeof(r)) || r < 1 || r >= world || c->peer[r] != -1) {
-        ::close(fd);
-        return cfail(c, ELLC_ERR_BAD_ARG, "a peer announced an invalid or duplicate rank");
+        ::close(fd);   // a stray connection, or a rank announced twice: not one of ours — keep waiting for the real peers
+        continue;
       }
       c->peer[r] = fd;
+      k++;
     }
   } else {
     int fd = -1;
@@ -150,6 +172,7 @@ ellc_status ellc_comm_init_tcp(const char* host, int port, int world, int rank, 
     }
     if (fd < 0) return cfail(c, ELLC_ERR_HIP, "cannot connect to rank 0");
     ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+    set_socket_timeouts(fd);
     if (!send_all(fd, &rank, sizeof(rank))) return cfail(c, ELLC_ERR_HIP, "cannot announce the rank");
     c->peer.assign(1, fd);
   }
@@ -222,6 +245,7 @@ ellc_status ellc_comm_destroy(ellc_comm* c) {
 // ELLC_GATHER_DEPTH may be outstanding. Every rank calls it with the same `total`.
 ellc_status ellc_gather_start(ellc_comm* c, int total, const float* local8, int n_local) {
   if (!c || total < 1 || total > c->max_total || n_local < 0 || (n_local > 0 && !local8)) return cfail(c, ELLC_ERR_BAD_ARG, "ellc_gather_start: bad argument");
+  if (c->dead) return cfail(c, ELLC_ERR_HIP, "ellc_gather_start: an earlier exchange failed half-way; create a new communicator");
   if (c->pending >= ELLC_GATHER_DEPTH) return cfail(c, ELLC_ERR_NOT_READY, "ellc_gather_start: too many gathers outstanding, finish one first");
   const int per = (total + c->world - 1) / c->world;
   int lo, hi;
@@ -240,12 +264,20 @@ ellc_status ellc_gather_start(ellc_comm* c, int total, const float* local8, int 
     } else if (c->rank == 0) {
       std::memcpy(s.table.data(), mine.data(), mine.size() * sizeof(float));
       for (int r = 1; r < c->world; r++)
-        if (!recv_all(c->peer[r], s.table.data() + (size_t)r * per * ELLC_RECORD, (size_t)per * rec_b)) return cfail(c, ELLC_ERR_HIP, "gather: a peer closed the connection");
+        if (!recv_all(c->peer[r], s.table.data() + (size_t)r * per * ELLC_RECORD, (size_t)per * rec_b)) {
+          c->dead = true;
+          return cfail(c, ELLC_ERR_HIP, "gather: a peer closed the connection or timed out");
+        }
       for (int r = 1; r < c->world; r++)
-        if (!send_all(c->peer[r], s.table.data(), s.table.size() * sizeof(float))) return cfail(c, ELLC_ERR_HIP, "gather: cannot send the table");
+        if (!send_all(c->peer[r], s.table.data(), s.table.size() * sizeof(float))) {
+          c->dead = true;
+          return cfail(c, ELLC_ERR_HIP, "gather: cannot send the table");
+        }
     } else {
-      if (!send_all(c->peer[0], mine.data(), mine.size() * sizeof(float)) || !recv_all(c->peer[0], s.table.data(), s.table.size() * sizeof(float)))
-        return cfail(c, ELLC_ERR_HIP, "gather: exchange with rank 0 failed");
+      if (!send_all(c->peer[0], mine.data(), mine.size() * sizeof(float)) || !recv_all(c->peer[0], s.table.data(), s.table.size() * sizeof(float))) {
+        c->dead = true;
+        return cfail(c, ELLC_ERR_HIP, "gather: exchange with rank 0 failed or timed out");
+      }
     }
   }
 #ifdef ELLC_WITH_RCCL
@@ -269,11 +301,14 @@ ellc_status ellc_gather_start(ellc_comm* c, int total, const float* local8, int 
   return ELLC_OK;
 }
 
-// Wait for the OLDEST outstanding gather; out8 receives its `total` records in global order.
-ellc_status ellc_gather_finish(ellc_comm* c, float* out8) {
+// Wait for the OLDEST outstanding gather; out8 (room for out_capacity records) receives its `total` records in global order.
+ellc_status ellc_gather_finish(ellc_comm* c, float* out8, int out_capacity) {
   if (!c || !out8) return cfail(c, ELLC_ERR_BAD_ARG, "ellc_gather_finish: bad argument");
   if (c->pending < 1) return cfail(c, ELLC_ERR_NOT_READY, "ellc_gather_finish: no gather outstanding");
   ellc_comm::Slot& s = c->slot[c->head];
+  if (out_capacity < s.total)   // gathers of different sizes may be outstanding: never write past the caller's buffer
+    return cfail(c, ELLC_ERR_CAPACITY, "ellc_gather_finish: the oldest outstanding gather holds " + std::to_string(s.total) + " records, the buffer " +
+                                           std::to_string(out_capacity));
   const float* table = s.table.data();
 #ifdef ELLC_WITH_RCCL
   if (c->transport == 1) {
@@ -300,7 +335,7 @@ ellc_status ellc_gather_finish(ellc_comm* c, float* out8) {
 ellc_status ellc_gather_results(ellc_comm* c, int total, const float* local8, int n_local, float* out8) {
   const ellc_status s = ellc_gather_start(c, total, local8, n_local);
   if (s != ELLC_OK) return s;
-  return ellc_gather_finish(c, out8);
+  return ellc_gather_finish(c, out8, total);
 }
 
 }  // extern "C"

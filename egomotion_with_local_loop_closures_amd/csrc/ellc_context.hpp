@@ -11,8 +11,6 @@
 
 namespace ellc {
 
-struct RunSync;   // ellc_kernels_run.hpp
-
 struct DepthSoA {   // DepthHypothesis.h:14-40, live fields, structure of arrays
   float* invDepth = nullptr;
   float* invDepthSmoothed = nullptr;
@@ -85,8 +83,6 @@ struct ellc_ctx {
     int* stage_d = nullptr;                         // device copy of the staging record
     ellc::AlignState* state_d = nullptr;            // two launch-parity buffers
     float* partials_d = nullptr;
-    ellc::RunSync* sync_d = nullptr;                // per alignment: arrival / generation counters and the published state of a run
-    int run_reserved = 0;                           // blocks reserved in the device's run budget while the group is in flight
     // the group staged / in flight in this set
     int fill = 0;                                   // batches staged side by side: batch j = alignments [j * max_batch, ...)
     int fetched = 0;                                // of which fetched (the set is free again when fetched == fill)
@@ -112,20 +108,20 @@ struct ellc_ctx {
   int group_cap = 0;                                // alignments per set: coalesce * max_batch
   int open_set = -1;                                // the set whose group is staged but not launched yet (-1: none)
   hipEvent_t ev_main = nullptr;                     // marks the main stream behind the last non-batch call
+  hipEvent_t ev_xfer = nullptr;                     // ellc_copy_slot_across: orders this context's stream against another context's
   bool main_dirty = false;                          // a non-batch entry point ran since ev_main was recorded
   int main_mark = 0;
   int inflight[SETS * MAX_COALESCE] = {0};         // FIFO of the batches in flight: set * MAX_COALESCE + slice
   int n_inflight = 0;
   int cur_set = 0;                                  // the batch set the per-batch pointers below refer to (select_batch_set)
   float* partials_d = nullptr;
-  ellc::RunSync* sync_d = nullptr;
   float* planes_d = nullptr;
   float *scratch_a = nullptr, *scratch_b = nullptr;   // W*H f32 each
   int tile_begin[ELLC_MAX_LEVELS + 1];
   int cap[ELLC_MAX_LEVELS];                            // compact capacity per level (= n)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // captured launch sequences of ellc_align, keyed by (B, unique keyframes, mode, save_weights)
-  std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
+  // captured launch sequences of ellc_align, keyed by (B, unique keyframes, mode, flags: save_weights | persist | run | continuation, batch set)
+  std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
   bool use_graph = true;
   bool age_balance = true;      // age-balanced split of full-round grids (FusedArgs::age_rounds); ELLC_NO_AGE_BALANCE=1 disables
   double age_weight[5][4] = {{1, 1, 1, 1}, {1, 1, 1, 1}, {1.15, 0.85, 1, 1}, {1.2, 1.0, 0.8, 1}, {1.35, 1.15, 0.9, 0.6}};   // [rounds][round], ELLC_AGE_W (r01 sweep at 640x480, batch 32)
@@ -136,11 +132,6 @@ struct ellc_ctx {
   bool pipe = true;             // software-pipelined record loads in the fused FCA kernel (ELLC_PIPE=0 disables; r01: -10 % per launch at
                                 // 1280x960 dense where the records stream from HBM, neutral at 640x480 semi-dense)
   bool use_fused = true;        // the production schedules (ELLC_NO_FUSE=1, diagnostic builds: one accumulate + one solve launch per iteration)
-  bool use_run = false;         // diagnostic builds, ELLC_RUN=1: the run kernels (ellc_kernels_run.hpp: last-arriving block solves, runs of
-                                // iterations inside one launch) instead of the fused kernels; measured slower, see DESIGN.md section 4
-  bool use_persist = true;      // runs may cover all iterations of a level (ELLC_NO_PERSIST=1, diagnostic builds: single-iteration launches only)
-  bool plan_persist = false;    // decision for the batch being enqueued (the reservation succeeded)
-  int untracked_reserved = 0;   // run budget held by untracked enqueues (measurement hooks)
   int nblk_override[ELLC_MAX_LEVELS] = {0};
   int resident_blocks = 1280;   // 256-thread blocks of the accumulate kernel resident on the device at once
   // image uploads: ring of pinned staging buffers, so an upload only enqueues (ellc_hip.hip: upload_pyramid)

@@ -84,6 +84,7 @@ ellc_status do_rescale(ellc_ctx* c, float* factor_out) {
 ellc_status do_update_depth_image(ellc_ctx* c) {
   const int W = c->cfg.width, H = c->cfg.height;
   const KfLevelDev& k = c->kf_tab_h[c->dm_kf_slot];
+  invalidate_records(c, c->dm_kf_slot);   // before the first write (a failure half-way must not leave a valid tag)
   // levels that halve exactly go into the export's own launch (dm_export_pyramid); the rest take the per-level kernel
   int steps = 0;
   while (steps < 3 && steps + 1 < c->L && ((W >> steps) & 1) == 0 && ((H >> steps) & 1) == 0) steps++;
@@ -104,7 +105,6 @@ ellc_status do_update_depth_image(ellc_ctx* c) {
   ELLC_HIP(c, hipGetLastError());
   ellc_status s = build_depth_pyramid_from(c, c->dm_kf_slot, steps + 1);   // buildInvVarDepth + mapDepthArr2Mat: the remaining levels
   if (s != ELLC_OK) return s;
-  invalidate_records(c, c->dm_kf_slot);
   c->kf_has_depth[c->dm_kf_slot] = 1;
   return ELLC_OK;
 }

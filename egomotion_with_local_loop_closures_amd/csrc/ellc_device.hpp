@@ -90,7 +90,6 @@ struct AlignState {
   int pending;                // fused schedule: the previous launch left partial sums that are not solved yet
   int cur_level;              // state-driven schedule: the level of the pending sums / of the next pixel pass; -1: the schedule has ended
   int it_in_level;            //   iterations of cur_level already solved
-  unsigned ticket_base, gen_base;   // run kernels: values of the alignment's arrival / generation counters when the next launch starts
   int iters[ELLC_MAX_LEVELS];
   float H[36];
   float b[6];

@@ -4,10 +4,6 @@
 #include "ellc_kernels_image.hpp"
 #include "ellc_kernels_gn.hpp"
 #include "ellc_kernels_prep.hpp"
-#ifdef ELLC_DIAG
-#include "ellc_kernels_run.hpp"   // measured alternative to the fused schedule ("Runs"): diagnostic builds only
-#include <atomic>
-#endif
 #include <cstring>
 #include <cmath>
 #include <algorithm>
@@ -246,6 +242,9 @@ static bool slot_ok(int s, int n) { return s >= 0 && s < n; }
 // side with others in one launch: its block counts — they fix the order of the sums, i.e. the bits of the result — are those
 // of a full group either way. B here is what a launch covers: one batch, or k full batches.
 static int grid_batch(const ellc_ctx* c, int B) {
+  // cfg.grid_batch: every call's grids are those of a batch of that size, whatever B is — a shard of a batch (one rank's
+  // block of a loop-closure batch, ellc_shard_range) then produces the bits the whole batch produces on one GPU
+  if (c->cfg.grid_batch > 0) return c->cfg.grid_batch;
   return (c->coalesce > 1 && B % c->cfg.max_batch == 0) ? c->cfg.max_batch * c->coalesce : B;
 }
 
@@ -342,7 +341,6 @@ static void select_batch_set(ellc_ctx* c, int p, int slice = 0) {
   c->init_pose_d = (float*)(bs.stage_d + 3 * cap);
   c->state_d = bs.state_d;
   c->partials_d = bs.partials_d;
-  c->sync_d = bs.sync_d;
 }
 
 // stage slots / initial poses on the device and list the unique keyframe slots
@@ -389,7 +387,7 @@ static void enqueue_stage_in(ellc_ctx* c, int B) {
   const int n = 9 * c->group_cap;
   const int copy_blocks = (n + 255) / 256;
   hipLaunchKernelGGL(stage_in, dim3(copy_blocks + (B + 255) / 256), dim3(256), 0, c->stream, c->kf_slot_d, c->stage_dev_alias, n, copy_blocks,
-                     c->state_d, B, c->group_cap, (unsigned*)c->sync_d, c->L - 1);
+                     c->state_d, B, c->group_cap, c->L - 1);
 }
 
 // fills the age-balanced split of a launch (FusedArgs::age_rounds): on when the grid is 2..4 full rounds of one block per CU-slot
@@ -454,6 +452,7 @@ static void launch_add_saved_weights(ellc_ctx* c, int B) {
 // age-balanced split of the level-bound launches is lost.
 static bool schedule_is_adaptive(const ellc_ctx* c, int mode, int B) {
   if (!(c->use_fused && c->use_adaptive && c->cfg.early_exit && mode == ELLC_MODE_FCA && B <= c->adaptive_max_batch)) return false;
+  if (c->cfg.grid_batch > 0) return false;   // fixed grids: every call runs the level-bound schedule of the whole batch (same split, same bits)
   for (int l = 0; l < c->L; l++)
     if (c->cfg.max_iter[l] < 1) return false;   // a level without iterations: the level-bound schedule simply has no launch for it
   return true;
@@ -476,8 +475,9 @@ static int adaptive_first_launches(const ellc_ctx* c, int B) {
 
 // State-driven FCA schedule: `launches` launches of gn_fca_adaptive and the finish kernel. continuation: the records were
 // left by an earlier graph of the same batch (buffer 0, nothing pending), otherwise by stage_in.
-static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weights, int launches) {
+static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weights, int launches, bool continuation = false) {
   FusedArgs fa;
+  fa.continuation = continuation ? 1 : 0;
   fa.seq = 0;
   fa.prev_level = -1;
   fa.prev_nblk = 0;
@@ -524,6 +524,7 @@ static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weight
 // overlap gave; a one-block-per-alignment kernel running all coarse iterations — one CU is VALU-bound on a level.)
 static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) {
   FusedArgs fa;
+  fa.continuation = 0;
   fa.seq = 0;
   fa.prev_level = -1;
   fa.prev_nblk = 0;
@@ -556,6 +557,7 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
 // launch solves the previous launch's b sums in its prologue: one launch per iteration plus the final solve.
 static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
   FusedArgs fa;
+  fa.continuation = 0;
   fa.seq = 0;
   fa.prev_level = -1;
   fa.prev_nblk = 0;
@@ -586,106 +588,8 @@ static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
   return ELLC_OK;
 }
 
-#ifdef ELLC_DIAG
-// ---- the schedule as run kernels (ellc_kernels_run.hpp) ----------------------------------------------------------------
-// Blocks of multi-iteration runs wait for each other, so all of them must be resident at once — together with those of
-// every other run in flight on the device, whichever context enqueued it. Each device has one budget (the blocks of a run
-// kernel the device holds at once: four 256-thread blocks per CU, guaranteed by the kernel's launch bounds); a batch
-// reserves its largest run when it is enqueued and gives it back when it is fetched. A batch that does not fit is enqueued
-// as single-iteration launches, which need no residency — same sums, same bits, only slower.
-static std::atomic<int> g_run_reserved[64];
-
-static bool run_reserve(ellc_ctx* c, int blocks) {
-  if (blocks <= 0) return true;
-  std::atomic<int>& r = g_run_reserved[c->cfg.device & 63];
-  int cur = r.load();
-  while (cur + blocks <= c->resident_blocks)
-    if (r.compare_exchange_weak(cur, cur + blocks)) return true;
-  return false;
-}
-static void run_release(ellc_ctx* c, int blocks) {
-  if (blocks > 0) g_run_reserved[c->cfg.device & 63].fetch_sub(blocks);
-}
-
-struct RunPlan {
-  struct Seg { int lvl_hi, lvl_lo, grid_x; bool single_iterations; };
-  std::vector<Seg> segs;
-  int nblk[ELLC_MAX_LEVELS];
-  int max_run_blocks = 0;   // blocks of the largest multi-iteration run (what has to be reserved)
-};
-
-// Levels whose blocks (B x nblk) fit a batch's share of the device become runs that cover all their iterations; consecutive
-// such levels merge into one run unless weights are saved (the saved-weights kernel follows each level). The others are
-// launched iteration by iteration. persist = false plans single iterations throughout.
-static RunPlan plan_runs(const ellc_ctx* c, int B, bool save_w, bool persist) {
-  RunPlan p;
-  const int share = std::max(1, c->resident_blocks / std::max(1, c->cfg.concurrent_batches));
-  for (int l = 0; l < ELLC_MAX_LEVELS; l++) p.nblk[l] = 1;
-  for (int l = 0; l < c->L; l++) p.nblk[l] = std::min(64, choose_nblk(c, l, B));
-  for (int level = c->L - 1; level >= 0; level--) {
-    const bool fits = persist && c->cfg.max_iter[level] > 1 && B * p.nblk[level] <= share;
-    if (fits && !p.segs.empty() && !p.segs.back().single_iterations && !save_w &&
-        B * std::max(p.segs.back().grid_x, p.nblk[level]) <= share) {
-      p.segs.back().lvl_lo = level;
-      p.segs.back().grid_x = std::max(p.segs.back().grid_x, p.nblk[level]);
-    } else {
-      p.segs.push_back({level, level, p.nblk[level], !fits});
-    }
-  }
-  for (const auto& sg : p.segs)
-    if (!sg.single_iterations) p.max_run_blocks = std::max(p.max_run_blocks, B * sg.grid_x);
-  return p;
-}
-
-template <bool ICA>
-static void launch_run(ellc_ctx* c, dim3 grd, const RunArgs& ra) {
-  const dim3 blk(ELLC_GN_THREADS);
-  if (c->fast) hipLaunchKernelGGL((gn_run<ICA, true, false>), grd, blk, 0, c->stream, ra);
-  else if (!ICA && c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_run<ICA, false, true>), grd, blk, 0, c->stream, ra);
-  else hipLaunchKernelGGL((gn_run<ICA, false, false>), grd, blk, 0, c->stream, ra);
-}
-
-static ellc_status enqueue_schedule_runs(ellc_ctx* c, int B, int mode, int save_weights, bool persist) {
-  const bool save_w = save_weights && mode == ELLC_MODE_FCA;
-  const RunPlan plan = plan_runs(c, B, save_w, persist);
-  RunArgs ra;
-  ra.geom = c->geom_d; ra.kf_tab = c->kf_tab_d; ra.fr_tab = c->fr_tab_d; ra.kf_slot = c->kf_slot_d; ra.fr_slot = c->fr_slot_d;
-  ra.state = c->state_d; ra.partials = c->partials_d; ra.sync = c->sync_d; ra.res = c->result_dev_alias;
-  ra.max_kf = c->cfg.max_keyframes; ra.max_fr = c->cfg.max_frames;
-  ra.early_exit = c->cfg.early_exit; ra.save_w = save_w ? 1 : 0;
-  for (int l = 0; l < ELLC_MAX_LEVELS; l++) { ra.iters[l] = 0; ra.nblk[l] = plan.nblk[l]; }
-  for (size_t si = 0; si < plan.segs.size(); si++) {
-    const RunPlan::Seg& sg = plan.segs[si];
-    const bool last_seg = (si + 1 == plan.segs.size());
-    ra.lvl_hi = sg.lvl_hi; ra.lvl_lo = sg.lvl_lo;
-    const dim3 grd(sg.grid_x, B);
-    if (sg.single_iterations) {
-      const int level = sg.lvl_hi;
-      for (int l = 0; l < ELLC_MAX_LEVELS; l++) ra.iters[l] = (l == level) ? 1 : 0;
-      for (int it = 0; it < c->cfg.max_iter[level]; it++) {
-        ra.final = (last_seg && it + 1 == c->cfg.max_iter[level]) ? 1 : 0;
-        if (mode == ELLC_MODE_ICA) launch_run<true>(c, grd, ra); else launch_run<false>(c, grd, ra);
-      }
-    } else {
-      for (int l = 0; l < ELLC_MAX_LEVELS; l++) ra.iters[l] = (l <= sg.lvl_hi && l >= sg.lvl_lo) ? c->cfg.max_iter[l] : 0;
-      ra.final = last_seg ? 1 : 0;
-      if (mode == ELLC_MODE_ICA) launch_run<true>(c, grd, ra); else launch_run<false>(c, grd, ra);
-    }
-    if (save_w)   // one level per segment when weights are saved
-      hipLaunchKernelGGL(gn_add_saved_weights, dim3(64, B), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, sg.lvl_hi, c->cfg.max_keyframes,
-                         c->fast ? 1 : 0);
-  }
-  ELLC_HIP(c, hipGetLastError());
-  return ELLC_OK;
-}
-
-#endif   // ELLC_DIAG
-
 // the level / iteration schedule of GetImagePoseEstimate (ImageFunc.cpp:150-292) as a launch sequence
 static ellc_status enqueue_schedule(ellc_ctx* c, int B, int mode, int save_weights) {
-#ifdef ELLC_DIAG
-  if (c->use_fused && c->use_run) return enqueue_schedule_runs(c, B, mode, save_weights, c->plan_persist);
-#endif
   if (schedule_is_adaptive(c, mode, B)) return enqueue_schedule_adaptive(c, B, save_weights, adaptive_first_launches(c, B));
   if (mode == ELLC_MODE_FCA && c->use_fused) return enqueue_schedule_fused(c, B, save_weights);
   if (mode == ELLC_MODE_ICA && c->use_fused) return enqueue_schedule_ica_fused(c, B);
@@ -721,6 +625,11 @@ extern "C" {
 
 int ellc_abi_version(void) { return ELLC_ABI_VERSION; }
 
+int ellc_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 void ellc_default_config(ellc_config* cfg, int width, int height, int levels) {
   std::memset(cfg, 0, sizeof(*cfg));
   cfg->width = width;
@@ -739,6 +648,7 @@ void ellc_default_config(ellc_config* cfg, int width, int height, int levels) {
   cfg->concurrent_batches = 1;
   cfg->coalesce = 1;
   cfg->cache_records = 0;
+  cfg->grid_batch = 0;
 }
 
 const char* ellc_last_error(const ellc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -765,6 +675,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   if (cfg->max_keyframes < 1 || cfg->max_frames < 1 || cfg->max_batch < 1) return ELLC_ERR_BAD_ARG;
   if (cfg->coalesce < 0 || cfg->coalesce > ellc_ctx::MAX_COALESCE) return ELLC_ERR_BAD_ARG;   // 0: as 1
   if (cfg->concurrent_batches < 0 || cfg->concurrent_batches > 4 * ellc_ctx::MAX_COALESCE) return ELLC_ERR_BAD_ARG;   // 0: as 1
+  if (cfg->grid_batch < 0 || cfg->grid_batch > 65536) return ELLC_ERR_BAD_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ELLC_ERR_NO_DEVICE;
   if (cfg->device < 0 || cfg->device >= ndev) return ELLC_ERR_BAD_ARG;
@@ -888,7 +799,6 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     TRY(host_alloc(c, &bs.result_h, CAP));
     TRY(dev_alloc(c, &bs.state_d, 2 * CAP));
     TRY(dev_alloc(c, &bs.partials_d, 2 * CAP * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
-    TRY(dev_alloc(c, (char**)&bs.sync_d, 256 * CAP));   // RunSync records (diagnostic builds), 256 bytes each
     void *da = nullptr, *db = nullptr;
     if (hipHostGetDevicePointer(&da, bs.stage_h, 0) != hipSuccess || hipHostGetDevicePointer(&db, bs.result_h, 0) != hipSuccess ||
         hipEventCreateWithFlags(&bs.done, hipEventDisableTiming) != hipSuccess) {
@@ -961,8 +871,6 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       }
     }
     if (const char* ng = getenv("ELLC_NO_GRAPH")) c->use_graph = !(ng[0] == '1');
-    if (const char* nr = getenv("ELLC_RUN")) c->use_run = (nr[0] == '1');
-    if (const char* np = getenv("ELLC_NO_PERSIST")) c->use_persist = !(np[0] == '1');
     if (const char* nb = getenv("ELLC_NBLK")) {
       int l = 0;
       for (const char* q = nb; *q && l < ELLC_MAX_LEVELS; l++) {
@@ -982,8 +890,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
 }
 
 ellc_status ellc_ctx_destroy(ellc_ctx* c) {
-  ELLC_ENTER(c);
   if (!c) return ELLC_ERR_BAD_ARG;
+  (void)ellc::enter(c, true);   // launches an open group / resolves state-driven batches; whatever it reports, everything is torn down
   for (int i = 1; i < ellc_ctx::STREAMS; i++) if (c->batch_stream[i]) (void)hipStreamSynchronize(c->batch_stream[i]);
   (void)hipStreamSynchronize(c->stream);
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
@@ -1000,6 +908,7 @@ ellc_status ellc_ctx_destroy(ellc_ctx* c) {
   for (int i = 1; i < ellc_ctx::STREAMS; i++)
     if (c->batch_stream[i]) (void)hipStreamDestroy(c->batch_stream[i]);
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+  if (c->ev_xfer) (void)hipEventDestroy(c->ev_xfer);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
@@ -1025,9 +934,9 @@ ellc_status ellc_keyframe_upload(ellc_ctx* c, int slot, const uint8_t* image) {
   if (!c || !image || !slot_ok(slot, c->cfg.max_keyframes)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_keyframe_upload: bad argument");
   uint8_t* img[ELLC_MAX_LEVELS];
   for (int l = 0; l < c->L; l++) img[l] = c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + slot].img;
+  invalidate_records(c, slot);   // before the first write: a failure half-way must not leave a valid tag on overwritten planes
   ellc_status s = upload_pyramid(c, img, image);
   if (s != ELLC_OK) return s;
-  invalidate_records(c, slot);
   c->kf_has_image[slot] = 1;
   c->kf_has_depth[slot] = 0;         // a fresh frame has no depth yet (as ellc_keyframe_from_frame): set_depth / update_depth_image follow
   for (int l = 0; l < c->L; l++) {   // frame::frame zeroes weight_pyramid / numWeightsAdded (Frame.cpp:114-122)
@@ -1041,6 +950,7 @@ ellc_status ellc_keyframe_from_frame(ellc_ctx* c, int kf_slot, int frame_slot) {
   ELLC_ENTER(c);
   if (!c || !slot_ok(kf_slot, c->cfg.max_keyframes) || !slot_ok(frame_slot, c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "bad slot");
   if (!c->fr_has_image[frame_slot]) return fail(c, ELLC_ERR_NOT_READY, "frame slot empty");
+  invalidate_records(c, kf_slot);
   for (int l = 0; l < c->L; l++) {
     const LevelGeom& g = c->geom_h[l];
     ELLC_HIP(c, hipMemcpyAsync(c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + kf_slot].img, c->fr_tab_h[(size_t)l * c->cfg.max_frames + frame_slot].img,
@@ -1048,7 +958,6 @@ ellc_status ellc_keyframe_from_frame(ellc_ctx* c, int kf_slot, int frame_slot) {
     ELLC_HIP(c, hipMemsetAsync(c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + kf_slot].weight, 0, (size_t)g.n * 4, c->stream));
     c->kf_num_weights[kf_slot][l] = 0;
   }
-  invalidate_records(c, kf_slot);
   c->kf_has_image[kf_slot] = 1;
   c->kf_has_depth[kf_slot] = 0;
   return build_maxgrad(c, true, kf_slot);
@@ -1210,49 +1119,86 @@ double ellc_kl_divergence(const float* p, const float* q, int n) {
   return result;
 }
 
+// device-to-device copy of a slot's planes, enqueued on dc's stream; sc == dc, or another context on the same device with the
+// same geometry (the caller has ordered dc's stream behind sc's pending work)
+static ellc_status copy_slot_planes(ellc_ctx* dc, int dst_is_kf, int dst, ellc_ctx* sc, int src_is_kf, int src) {
+  ellc_ctx* c = dc;
+  const int MK = dc->cfg.max_keyframes, MF = dc->cfg.max_frames, SK = sc->cfg.max_keyframes, SF = sc->cfg.max_frames;
+  if (dst_is_kf) invalidate_records(dc, dst);
+  for (int l = 0; l < dc->L; l++) {
+    const LevelGeom& g = dc->geom_h[l];
+    const uint8_t* s_img = src_is_kf ? sc->kf_tab_h[(size_t)l * SK + src].img : sc->fr_tab_h[(size_t)l * SF + src].img;
+    uint8_t* d_img = dst_is_kf ? dc->kf_tab_h[(size_t)l * MK + dst].img : dc->fr_tab_h[(size_t)l * MF + dst].img;
+    ELLC_HIP(c, hipMemcpyAsync(d_img, s_img, (size_t)g.sw * g.sh, hipMemcpyDeviceToDevice, dc->stream));
+    if (dst_is_kf) {
+      KfLevelDev& d = dc->kf_tab_h[(size_t)l * MK + dst];
+      if (src_is_kf) {
+        const KfLevelDev& k = sc->kf_tab_h[(size_t)l * SK + src];
+        ELLC_HIP(c, hipMemcpyAsync(d.depth, k.depth, (size_t)g.n * 4, hipMemcpyDeviceToDevice, dc->stream));
+        ELLC_HIP(c, hipMemcpyAsync(d.var, k.var, (size_t)g.n * 4, hipMemcpyDeviceToDevice, dc->stream));
+        ELLC_HIP(c, hipMemcpyAsync(d.weight, k.weight, (size_t)g.n * 4, hipMemcpyDeviceToDevice, dc->stream));
+        dc->kf_num_weights[dst][l] = sc->kf_num_weights[src][l];
+      } else {
+        ELLC_HIP(c, hipMemsetAsync(d.weight, 0, (size_t)g.n * 4, dc->stream));
+        dc->kf_num_weights[dst][l] = 0;
+      }
+    }
+  }
+  if (dst_is_kf) {
+    dc->kf_has_image[dst] = 1;
+    dc->kf_has_depth[dst] = src_is_kf ? sc->kf_has_depth[src] : 0;
+    if (src_is_kf && sc->kf_maxgrad_valid[src]) {
+      const size_t n0 = (size_t)dc->cfg.width * dc->cfg.height;
+      ELLC_HIP(c, hipMemcpyAsync(dc->kf_maxgrad[dst], sc->kf_maxgrad[src], n0 * 4, hipMemcpyDeviceToDevice, dc->stream));
+      ELLC_HIP(c, hipMemcpyAsync(dc->kf_maxgrad_count[dst], sc->kf_maxgrad_count[src], 4, hipMemcpyDeviceToDevice, dc->stream));
+      dc->kf_maxgrad_valid[dst] = 1;
+    } else {
+      return build_maxgrad(dc, true, dst);
+    }
+  } else {
+    dc->fr_has_image[dst] = 1;
+    dc->fr_maxgrad_valid[dst] = 0;
+  }
+  return ELLC_OK;
+}
+
 ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, int src) {
   ELLC_ENTER(c);
   if (!c || !slot_ok(dst, dst_is_kf ? c->cfg.max_keyframes : c->cfg.max_frames) || !slot_ok(src, src_is_kf ? c->cfg.max_keyframes : c->cfg.max_frames))
     return fail(c, ELLC_ERR_BAD_ARG, "bad slot");
   if (!(src_is_kf ? c->kf_has_image[src] : c->fr_has_image[src])) return fail(c, ELLC_ERR_NOT_READY, "source slot empty");
   if (dst_is_kf == src_is_kf && dst == src) return ELLC_OK;
-  const int MK = c->cfg.max_keyframes, MF = c->cfg.max_frames;
-  for (int l = 0; l < c->L; l++) {
-    const LevelGeom& g = c->geom_h[l];
-    const uint8_t* s_img = src_is_kf ? c->kf_tab_h[(size_t)l * MK + src].img : c->fr_tab_h[(size_t)l * MF + src].img;
-    uint8_t* d_img = dst_is_kf ? c->kf_tab_h[(size_t)l * MK + dst].img : c->fr_tab_h[(size_t)l * MF + dst].img;
-    ELLC_HIP(c, hipMemcpyAsync(d_img, s_img, (size_t)g.sw * g.sh, hipMemcpyDeviceToDevice, c->stream));
-    if (dst_is_kf) {
-      KfLevelDev& d = c->kf_tab_h[(size_t)l * MK + dst];
-      if (src_is_kf) {
-        const KfLevelDev& k = c->kf_tab_h[(size_t)l * MK + src];
-        ELLC_HIP(c, hipMemcpyAsync(d.depth, k.depth, (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream));
-        ELLC_HIP(c, hipMemcpyAsync(d.var, k.var, (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream));
-        ELLC_HIP(c, hipMemcpyAsync(d.weight, k.weight, (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream));
-        c->kf_num_weights[dst][l] = c->kf_num_weights[src][l];
-      } else {
-        ELLC_HIP(c, hipMemsetAsync(d.weight, 0, (size_t)g.n * 4, c->stream));
-        c->kf_num_weights[dst][l] = 0;
-      }
-    }
+  return copy_slot_planes(c, dst_is_kf, dst, c, src_is_kf, src);
+}
+
+// The same between two contexts of one device (same width / height / levels): the reference's loop-closure thread works on deep
+// copies of the finished keyframe and its depth map (GlobalOptimize.cpp:185-186) while tracking goes on; here the copy goes
+// into the loop-closure context's ring slot. Device-side ordering only (events): dst's stream waits for what src has enqueued,
+// and src's later work waits for the copy. The caller serialises this call with every other call on EITHER context.
+ellc_status ellc_copy_slot_across(ellc_ctx* dc, int dst_is_kf, int dst, ellc_ctx* sc, int src_is_kf, int src) {
+  if (!dc || !sc) return ELLC_ERR_BAD_ARG;
+  if (dc == sc) return ellc_copy_slot(dc, dst_is_kf, dst, src_is_kf, src);
+  if (dc->cfg.device != sc->cfg.device || dc->cfg.width != sc->cfg.width || dc->cfg.height != sc->cfg.height || dc->L != sc->L)
+    return fail(dc, ELLC_ERR_BAD_ARG, "ellc_copy_slot_across: the contexts differ in device or geometry");
+  if (!slot_ok(dst, dst_is_kf ? dc->cfg.max_keyframes : dc->cfg.max_frames) || !slot_ok(src, src_is_kf ? sc->cfg.max_keyframes : sc->cfg.max_frames))
+    return fail(dc, ELLC_ERR_BAD_ARG, "bad slot");
+  if (!(src_is_kf ? sc->kf_has_image[src] : sc->fr_has_image[src])) return fail(dc, ELLC_ERR_NOT_READY, "source slot empty");
+  {
+    ellc_ctx* c = sc;   // (ELLC_ENTER / ELLC_HIP report into the context named c)
+    ELLC_ENTER(c);
+    if (!sc->ev_xfer) ELLC_HIP(c, hipEventCreateWithFlags(&sc->ev_xfer, hipEventDisableTiming));
+    ELLC_HIP(c, hipEventRecord(sc->ev_xfer, sc->stream));
   }
-  if (dst_is_kf) {
-    invalidate_records(c, dst);
-    c->kf_has_image[dst] = 1;
-    c->kf_has_depth[dst] = src_is_kf ? c->kf_has_depth[src] : 0;
-    if (src_is_kf && c->kf_maxgrad_valid[src]) {
-      const size_t n0 = (size_t)c->cfg.width * c->cfg.height;
-      ELLC_HIP(c, hipMemcpyAsync(c->kf_maxgrad[dst], c->kf_maxgrad[src], n0 * 4, hipMemcpyDeviceToDevice, c->stream));
-      ELLC_HIP(c, hipMemcpyAsync(c->kf_maxgrad_count[dst], c->kf_maxgrad_count[src], 4, hipMemcpyDeviceToDevice, c->stream));
-      c->kf_maxgrad_valid[dst] = 1;
-    } else {
-      return build_maxgrad(c, true, dst);
-    }
-  } else {
-    c->fr_has_image[dst] = 1;
-    c->fr_maxgrad_valid[dst] = 0;
-  }
-  return ELLC_OK;
+  ellc_ctx* c = dc;
+  ELLC_ENTER(c);
+  if (!dc->ev_xfer) ELLC_HIP(c, hipEventCreateWithFlags(&dc->ev_xfer, hipEventDisableTiming));
+  ELLC_HIP(c, hipStreamWaitEvent(dc->stream, sc->ev_xfer, 0));
+  const ellc_status st = copy_slot_planes(dc, dst_is_kf, dst, sc, src_is_kf, src);
+  // whatever was enqueued: the source must not be overwritten before it has been read
+  ELLC_HIP(c, hipEventRecord(dc->ev_xfer, dc->stream));
+  if (hipStreamWaitEvent(sc->stream, dc->ev_xfer, 0) != hipSuccess) return fail(sc, ELLC_ERR_HIP, "ellc_copy_slot_across: cannot order the source stream");
+  sc->main_dirty = true;
+  return st;
 }
 
 // ---- alignment -------------------------------------------------------------------------------------
@@ -1289,12 +1235,12 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
 // graph ended before every alignment had (enqueue_schedule_adaptive), for the batch set selected in the context.
 static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int save_weights, int set, bool continuation) {
   auto body = [&]() -> ellc_status {
-    if (continuation) return enqueue_schedule_adaptive(c, B, save_weights, schedule_total_iters(c) - adaptive_first_launches(c, B));
+    if (continuation) return enqueue_schedule_adaptive(c, B, save_weights, schedule_total_iters(c) - adaptive_first_launches(c, B), true);
     return enqueue_align_body(c, B, nu, mode, save_weights);
   };
   if (!c->use_graph) return body();
   const auto key = std::make_tuple(B, continuation ? 0 : nu, mode,
-                                   (save_weights ? 1 : 0) | (set << 1) | (c->plan_persist ? 16 : 0) | (c->use_run ? 32 : 0) | (continuation ? 64 : 0));
+                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0), set);
   auto it = c->graphs.find(key);
   if (it == c->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -1391,21 +1337,6 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
   }
   if (si > 0 && !c->batch_stream[si]) ELLC_HIP(c, hipStreamCreate(&c->batch_stream[si]));   // created on first use
   hipStream_t run_stream = c->batch_stream[si];
-  int reserved = 0;
-#ifdef ELLC_DIAG
-  // run kernels (diagnostic builds, ELLC_RUN=1): multi-iteration runs need their blocks resident together with every other
-  // run in flight on the device: reserve, or fall back to single-iteration launches (same results)
-  c->plan_persist = false;
-  if (c->use_fused && c->use_run && c->use_persist) {
-    reserved = plan_runs(c, B, bs.save_weights && bs.mode == ELLC_MODE_FCA, true).max_run_blocks;
-    if (run_reserve(c, reserved)) c->plan_persist = true;
-    else reserved = 0;
-  }
-  struct ReserveGuard {   // gives the reservation back unless the group was launched
-    ellc_ctx* c; int blocks; bool keep;
-    ~ReserveGuard() { if (!keep) run_release(c, blocks); }
-  } guard{c, reserved, false};
-#endif
   // A group on another stream runs after everything the caller has put on the main stream through the other entry
   // points (uploads, depth stages), but not after the groups that run there: the mark is recorded before them.
   // (a context that has only ever had one batch in flight has no other stream and never records the mark)
@@ -1456,26 +1387,18 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
   if (saves)   // the weight planes change: lists that carry the saved weight (the constant-weight record sets) are stale
     for (int v : bs.kf_slots)
       if (c->kf_rec_tag[v] != 8 && c->kf_rec_tag[v] != 2) invalidate_records(c, v);
-#ifdef ELLC_DIAG
-  guard.keep = true;
-#endif
   bs.launched = true;
   bs.stream_idx = si;
   bs.B = B;
   bs.adaptive = schedule_is_adaptive(c, bs.mode, B);
   bs.resolved = false;
   bs.joined = (si == 0);
-  bs.run_reserved = reserved;
   return ELLC_OK;
 }
 
 // forgets the group of a set (after its last batch has been fetched, or after a failed launch)
 static void free_set(ellc_ctx* c, int set) {
   ellc_ctx::BatchSet& bs = c->batch_set[set];
-#ifdef ELLC_DIAG
-  run_release(c, bs.run_reserved);
-#endif
-  bs.run_reserved = 0;
   bs.fill = bs.fetched = 0;
   bs.launched = false;
   bs.resolved = true;
@@ -1498,22 +1421,12 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
     int nu = 0;
     ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
     if (s != ELLC_OK) return s;
-#ifdef ELLC_DIAG
-    c->plan_persist = false;
-    int reserved = 0;
-    if (c->use_fused && c->use_run && c->use_persist) {
-      reserved = plan_runs(c, B, false, true).max_run_blocks;
-      if (run_reserve(c, reserved)) c->plan_persist = true;
-      else reserved = 0;
-    }
-    c->untracked_reserved += reserved;   // given back by the caller once the stream has drained (ellc_profile_align)
-#endif
     for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);   // rebuilt here, outside the cache's bookkeeping
     return launch_align_graph(c, B, nu, mode, save_weights, 0, false);
   }
   // may this batch share a launch with others? full batches of one mode, nothing per-slot written (saved weights), not the
-  // state-driven tracking schedule, not the diagnostic run kernels
-  const bool co = c->coalesce > 1 && B == MB && !(save_weights && mode == ELLC_MODE_FCA) && !schedule_is_adaptive(c, mode, B) && !c->use_run;
+  // state-driven tracking schedule
+  const bool co = c->coalesce > 1 && B == MB && !(save_weights && mode == ELLC_MODE_FCA) && !schedule_is_adaptive(c, mode, B);
   if (c->open_set >= 0) {
     ellc_ctx::BatchSet& og = c->batch_set[c->open_set];
     if (!(co && og.coalescable && og.mode == mode && og.fill < c->coalesce)) {
@@ -1592,8 +1505,7 @@ ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters
   ellc_status out = rs;
   if (out == ELLC_OK) {
     for (int b = 0; b < B && out == ELLC_OK; b++)
-      if (res[b].pad != 0) {   // a run gave up waiting for its other blocks (bounded spin): clear the error words, report
-        (void)hipMemsetAsync(bs.sync_d, 0, 256 * (size_t)c->group_cap, c->stream);
+      if (res[b].pad != 0) {   // the last kernel of the schedule never wrote the record
         out = fail(c, ELLC_ERR_HIP, "ellc_align_fetch: the schedule did not complete on the device (no result was exported)");
       }
   }
@@ -1719,6 +1631,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   if (c->use_fused) {
     // the production kernel of the FCA path: every launch first solves the previous launch's partial sums
     FusedArgs fa;
+    fa.continuation = 0;
     fa.g = a;
     fa.res = nullptr;
     fa.ica = 0;
@@ -1741,10 +1654,11 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
       hipGraphExec_t exec = nullptr;
       ELLC_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       for (int i = 0; i < reps; i++) launch();
-      ELLC_HIP(c, hipStreamEndCapture(c->stream, &graph));
-      ELLC_HIP(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(graph);
-      hipError_t e = hipGraphLaunch(exec, c->stream);   // warm
+      hipError_t e = hipStreamEndCapture(c->stream, &graph);
+      if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("profile graph capture: ") + hipGetErrorString(e));
+      e = hipGraphLaunch(exec, c->stream);   // warm
       if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
       if (e == hipSuccess) e = hipGraphLaunch(exec, c->stream);
       if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
@@ -1791,10 +1705,6 @@ ellc_status ellc_profile_align(ellc_ctx* c, int B, const int* kf_slots, const in
   }
   ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
   const hipError_t pe = hipEventSynchronize(c->ev1);
-#ifdef ELLC_DIAG
-  run_release(c, c->untracked_reserved);   // the untracked enqueues above have drained
-#endif
-  c->untracked_reserved = 0;
   ELLC_HIP(c, pe);
   float ms = 0;
   ELLC_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));

@@ -1201,6 +1201,8 @@ struct FusedArgs {
   int nblk_lv[ELLC_MAX_LEVELS];
   int max_it[ELLC_MAX_LEVELS];
   int nblk_grid;
+  int continuation;     // 1: this graph continues a state-driven schedule whose first graph has already run (and added the saved weights
+                        // of the alignments that ended there): its first launch marks those records cur_level = -2
 };
 
 // The pixel pass of one block of a fused launch over its chunk [begin, end) of the compact list, thread t taking the
@@ -1423,7 +1425,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
       if (t < 6) dst->pose[t] = src.pose[t];
       if (t < 12) dst->S[t] = src.S[t];
       if (t < ELLC_MAX_LEVELS) dst->iters[t] = src.iters[t];
-      if (t == 0) { dst->weighted = src.weighted; dst->level_done = src.level_done; dst->pending = 0; dst->cur_level = -1; dst->it_in_level = 0; }
+      // -1: ended, saved weights still to be added by the gn_add_saved_weights_all behind this graph; -2: ended in an earlier
+      // graph of the schedule, which added them (the first launch of a continuation marks the records it finds ended)
+      if (t == 0) { dst->weighted = src.weighted; dst->level_done = src.level_done; dst->pending = 0;
+                    dst->cur_level = (fa.continuation && fa.seq == 0) ? -2 : lvl; dst->it_in_level = 0; }
     }
     return;
   }
@@ -1703,7 +1708,7 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
     dst->weighted = sh.weighted;
     dst->level_done = sh.level_done;
     dst->pending = 0;
-    dst->cur_level = nl;
+    dst->cur_level = (ADAPT && lvl < 0) ? lvl : nl;   // -2 stays -2: the weights of this alignment were added by an earlier graph
     dst->it_in_level = nit;
   }
   if (fa.res) {
@@ -1737,17 +1742,14 @@ __device__ inline void init_state_record(AlignState& st, const float* init_pose,
 // copied from pinned host memory by the first copy_blocks blocks; the remaining blocks initialise the alignment states
 // straight from the staged initial poses (same launch: one dependent kernel boundary less at the head of every batch)
 __global__ void stage_in(int* __restrict__ dst, const int* __restrict__ src_host, int n, int copy_blocks, AlignState* state, int B, int max_batch,
-                         unsigned* sync_words, int top_level) {   // sync_words: the batch's RunSync records (64 words each); arrivals [0] and generation [16] start at 0
+                         int top_level) {
   if ((int)blockIdx.x < copy_blocks) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src_host[i];
     return;
   }
   const int b = ((int)blockIdx.x - copy_blocks) * blockDim.x + threadIdx.x;
-  if (b < B) {
-    init_state_record(state[b], (const float*)(src_host + 3 * max_batch), b, top_level);
-    if (sync_words) { sync_words[(size_t)b * 64] = 0u; sync_words[(size_t)b * 64 + 16] = 0u; }
-  }
+  if (b < B) init_state_record(state[b], (const float*)(src_host + 3 * max_batch), b, top_level);
 }
 
 __global__ void gn_init_state(AlignState* state, const float* init_pose, int B, int top_level) {
@@ -1767,8 +1769,6 @@ __device__ inline void init_state_record(AlignState& st, const float* init_pose,
   st.pending = 0;
   st.cur_level = top_level;
   st.it_in_level = 0;
-  st.ticket_base = 0;
-  st.gen_base = 0;
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) st.iters[l] = 0;
   for (int i = 0; i < 36; i++) { st.H[i] = 0.0f; st.Hinv[i] = 0.0f; }
   for (int i = 0; i < 6; i++) st.b[i] = 0.0f;
@@ -1796,11 +1796,12 @@ __global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slo
 
 // The same for every level in ONE launch at the end of a fused schedule (grid (x, B, L)): each level's wlast holds the
 // weights of that level's last executed pixel pass. Only once the alignment's schedule has ended (the state-driven schedule
-// may stop short of it and be continued: cur_level of the record the finish kernel wrote is -1 at the end).
+// may stop short of it and be continued: cur_level of the record the finish kernel wrote is -1 at the end) and only ONCE per
+// alignment: a continuation graph carries the alignments its first graph already ended as cur_level = -2 (gn_fca_adaptive).
 __global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, const AlignState* state, int max_kf,
                                          int fast_records) {
   const int b = blockIdx.y, level = blockIdx.z;
-  if (state[b].cur_level >= 0) return;
+  if (state[b].cur_level != -1) return;
   const KfLevelDev& K = kf_tab[level * max_kf + kf_slot[b]];
   const int V = *K.count;
   const int cols = geom[level].cols;

@@ -17,7 +17,9 @@
 //                    ellc_shard_range and its poses are gathered once per batch (ellc_gather_results); every rank writes
 //                    the same files into its own out_dir
 // Input is otherwise a header-less file of W*H u8 grey frames (the decode itself always stays outside).
-// In LC mode finished keyframes go through the loop-closure ring (facade class globalOptimize); tracking-loss recovery
+// In LC mode finished keyframes go through the loop-closure ring (facade class globalOptimize): matching and the batched
+// alignment of a pushed keyframe run on a second thread and a second context beside tracking, joined at the next push
+// (GlobalOptimize.cpp:241 / :161); tracking-loss recovery
 // (findConnection) and the MATLAB rotation averaging are not part of this path.
 #include "../../include/ellc_facade.hpp"
 #include <cstdio>
@@ -65,12 +67,8 @@ int main(int argc, char** argv) {
   try {
     ellc_config cfg;
     ellc_default_config(&cfg, W, H, levels);
-    if (lc) {   // keyframe slots 0,1: active / incoming; 2..44: the loop-closure ring; frame slot 3: the ring's test frame
-      cfg.max_keyframes = 2 + globalOptimize::MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
-      cfg.max_frames = 4;
-      cfg.max_batch = globalOptimize::MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
-    }
-    cfg.device = device;
+    cfg.device = device;   // the tracking context: keyframe slots 0,1 (active / incoming), one alignment at a time; in LC mode the
+                           // loop-closure ring and its batches live in a context of their own (facade class globalOptimize)
     Runtime rt(cfg);
     struct CommOwner {   // destroyed after the loop, before the runtime
       ellc_comm* c = nullptr;
@@ -84,6 +82,7 @@ int main(int argc, char** argv) {
         unsigned char id[128];
         if (rank == 0) {
           if (ellc_comm_unique_id(id) != ELLC_OK) { std::fprintf(stderr, "ellc_comm_unique_id failed\n"); return -2; }
+          std::remove(comm_id_file.c_str());   // a stale id from an earlier run must not be picked up (give every run a fresh path anyway)
           std::ofstream o((comm_id_file + ".tmp").c_str(), std::ios::binary);
           o.write((const char*)id, 128);
           o.close();
@@ -114,7 +113,7 @@ int main(int argc, char** argv) {
     }
     depthMap currentDepthMap(rt);
     std::unique_ptr<globalOptimize> globalOptimizeLoop;
-    if (lc) globalOptimizeLoop.reset(new globalOptimize(rt, outdir + "/matchframes_globalopt.txt", 2, 3));
+    if (lc) globalOptimizeLoop.reset(new globalOptimize(rt, outdir + "/matchframes_globalopt.txt"));
     std::vector<std::unique_ptr<frame>> frameptr_vector;
     frame* activeKeyFrame = nullptr;
     std::vector<uint8_t> buf(bgr ? (size_t)W * H * 48 : (size_t)W * H);
@@ -165,6 +164,7 @@ int main(int argc, char** argv) {
       currentDepthMap.doRegularization();
       currentDepthMap.updateDepthImage();
     }
+    if (globalOptimizeLoop) globalOptimizeLoop->join_all();   // the last keyframe's match thread (t_group.join_all)
   } catch (const std::exception& e) {
     std::fprintf(stderr, "ellc_main: %s\n", e.what());
     return -2;

@@ -143,6 +143,7 @@ class Comm:
         self._C = C
         self._l = _lib.comm_lib() if host_only else _lib.lib()
         self.world, self.rank, self.max_total = world, rank, max_total
+        self._totals = []   # totals of the outstanding gathers, oldest first (ellc_gather_finish returns the oldest)
         h = C.c_void_p()
         if transport == "rccl":
             assert unique_id is not None and len(unique_id) == 128
@@ -179,12 +180,20 @@ class Comm:
 
     def start(self, total, local):
         loc = np.ascontiguousarray(local, np.float32).reshape(-1, RECORD)
-        self._total = total
         self._ck(self._l.ellc_gather_start(self.h, total, loc.ctypes.data_as(self._C.c_void_p), loc.shape[0]), "ellc_gather_start")
+        self._totals.append(total)
 
     def finish(self, total=None):
-        out = np.zeros((self._total if total is None else total, RECORD), np.float32)
-        self._ck(self._l.ellc_gather_finish(self.h, out.ctypes.data_as(self._C.c_void_p)), "ellc_gather_finish")
+        """The table of the OLDEST outstanding gather. `total`, when given, must be that gather's total."""
+        if not self._totals:
+            from . import _lib
+            raise _lib.EllcError("Comm.finish: no gather outstanding")
+        if total is not None and total != self._totals[0]:
+            from . import _lib
+            raise _lib.EllcError("Comm.finish: the oldest outstanding gather has %d records, not %d" % (self._totals[0], total))
+        out = np.zeros((self._totals[0], RECORD), np.float32)
+        self._ck(self._l.ellc_gather_finish(self.h, out.ctypes.data_as(self._C.c_void_p), out.shape[0]), "ellc_gather_finish")
+        self._totals.pop(0)
         return out
 
     def gather(self, total, local):

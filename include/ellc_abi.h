@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define ELLC_MAX_LEVELS 8
-#define ELLC_ABI_VERSION 5
+#define ELLC_ABI_VERSION 6
 
 typedef enum {
   ELLC_OK = 0,
@@ -71,7 +71,7 @@ typedef struct {
                                  * not depend on what else happens to be in flight (the grid fixes the summation order) */
   int arith;                    /* ELLC_ARITH_EXACT (default) or ELLC_ARITH_FAST: arithmetic of the Gauss-Newton pixel pass and solve */
   int coalesce;                 /* 1 (default) .. 4: full batches (B = max_batch) enqueued one after the other are launched side by
-                                 * side, up to this many per launch sequence, and 3 x coalesce batches may be in flight. Fixed per
+                                 * side, up to this many per launch sequence, and 4 x coalesce batches may be in flight. Fixed per
                                  * context: a full batch's grids are those of a full group whether it runs alone or not, so its
                                  * result does not depend on what it was launched with */
   int cache_records;            /* 0 (default): the compact pixel lists of a batch's keyframes are rebuilt by every call, as the
@@ -79,12 +79,19 @@ typedef struct {
                                  * keyframe slot and rebuilt only after the slot's image, depth or weights have changed (every
                                  * entry point that writes them marks the slot); batches that only READ a slot's lists then also
                                  * run concurrently instead of one after the other. Results are identical either way */
+  int grid_batch;               /* 0 (default): the launch grids — which fix the order of the 27 sums, i.e. the last bits of a result —
+                                 * are chosen for the size of each call's batch. N > 0: for a batch of N, whatever a call's B is.
+                                 * A rank that aligns its block of a sharded loop-closure batch (ellc_shard_range) sets the same N on
+                                 * every rank (e.g. max_batch): every alignment's result is then bit-identical to what ONE context
+                                 * with the same N computes for the whole batch, for every world size (such a context always runs
+                                 * the level-bound schedule, also for one or two alignments) */
 } ellc_config;
 
 typedef struct ellc_ctx ellc_ctx;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */
 int ellc_abi_version(void);
+int ellc_device_count(void);                           /* HIP devices visible to the process (0: none); a launcher maps LOCAL_RANK to cfg.device with it */
 void ellc_default_config(ellc_config* cfg, int width, int height, int levels);
 ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out);
 ellc_status ellc_ctx_destroy(ellc_ctx* ctx);
@@ -198,6 +205,13 @@ double ellc_kl_divergence(const float* p, const float* q, int n);
 /* pushToArray deep-copies the finished keyframe and its depth map into a ring slot (:185-223): device-to-device copy of a
  * slot's pyramids (keyframe -> keyframe also copies depth / variance / weight pyramids, maxAbsGradient and weight counts). */
 ellc_status ellc_copy_slot(ellc_ctx* ctx, int dst_is_keyframe, int dst_slot, int src_is_keyframe, int src_slot);
+/* The same between two contexts on one device with the same width / height / levels. The reference hands its loop-closure
+ * thread deep copies of the finished keyframe and depth map (new frame(*currentframe), new depthMap(*currentDepthMap),
+ * GlobalOptimize.cpp:185-186) and lets it run beside tracking (:241, joined at :161): here the loop-closure ring lives in a
+ * context of its own (own streams, own batches) and this call is the deep copy. Ordered on the device: the copy runs behind
+ * everything enqueued on src_ctx so far, and src_ctx's later work behind the copy; the host does not wait. The caller
+ * serialises it with every other call on either context. */
+ellc_status ellc_copy_slot_across(ellc_ctx* dst_ctx, int dst_is_keyframe, int dst_slot, ellc_ctx* src_ctx, int src_is_keyframe, int src_slot);
 
 /* ---- semi-dense depth map: class depthMap (DepthPropagation.cpp) -----------------------------------
  * One depth map per context (the reference's currentDepthMap). State is SoA on device:
@@ -246,7 +260,7 @@ ellc_status ellc_comm_init_tcp(const char* host_ipv4, int port, int world, int r
 ellc_status ellc_comm_destroy(ellc_comm* comm);
 const char* ellc_comm_last_error(const ellc_comm* comm);
 ellc_status ellc_gather_start(ellc_comm* comm, int total, const float* local8, int n_local);
-ellc_status ellc_gather_finish(ellc_comm* comm, float* out8);
+ellc_status ellc_gather_finish(ellc_comm* comm, float* out8, int out_capacity);   /* out8 holds out_capacity records: ELLC_ERR_CAPACITY (the gather stays outstanding) if the oldest gather's total is larger */
 ellc_status ellc_gather_results(ellc_comm* comm, int total, const float* local8, int n_local, float* out8);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------- */

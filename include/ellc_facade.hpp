@@ -23,6 +23,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace ellc {
@@ -328,6 +329,13 @@ inline std::vector<float> GetImagePoseEstimate(frame* prev_frame, frame* current
 // ALL selected candidates with ONE batched constant-weight alignment (the reference runs them one by one, :566).
 // The candidate sequence does not depend on the alignment results (the reference restores the test frame's poses after
 // every match, :591-606), so collecting first and aligning once is equivalent.
+//   As in the reference with FLAG_DO_PARALLEL_SHORT_LOOP_CLOSURE (on in LC mode, ToggleFlags.h:53-59), the matching of a pushed
+// keyframe runs on a thread of its own beside tracking (t_group.create_thread, :241) and is joined at the next pushToArray
+// (:161) — and when the object goes away. The ring lives in a Runtime of its own (`ring`: a second context with its own
+// streams, so its batch overlaps the tracking context's work on the device); pushToArray deep-copies the finished keyframe
+// into it (ellc_copy_slot_across = new frame(*currentframe) / new depthMap(*currentDepthMap), :185-186) and the thread only
+// ever touches the ring context. The ring context fixes its launch grids (cfg.grid_batch = max_batch): a rank's shard of a
+// batch has the bits of the whole batch.
 class globalOptimize {
  public:
   static const int MAX_LOOP_ARRAY_LENGTH = 20;                                   // ExternVariable.h:161
@@ -340,9 +348,11 @@ class globalOptimize {
     bool isValid = false;
     float rescaleFactor = 1.0f;   // this_frame->rescaleFactor
     float seeds = 0.0f;           // this_currentDepthMap->calculate_no_of_Seeds()
-    int kf_slot = -1;             // device slot holding this_frame / this_currentDepthMap
+    int kf_slot = -1;             // ring-context slot holding this_frame / this_currentDepthMap
   };
-  Runtime* rt;
+  Runtime* rt;            // the tracking runtime (source of the finished keyframes; its comm / world / rank shard the batch)
+  Runtime ring;           // the loop-closure context: keyframe slots [0, 43) = the ring, frame slot 0 = the test keyframe
+  bool FLAG_DO_PARALLEL_SHORT_LOOP_CLOSURE = true;
   loopFrame loopFrameArray[MAX_LOOP_ARRAY_LENGTH_SCALE_AVG];
   loopFrame currentLoopFrame;
   std::ofstream match_file;
@@ -352,22 +362,47 @@ class globalOptimize {
   int currentArrayId = 0, nextArrayId = 1;
   int match_window_beg = 0, match_window_end = MAX_LOOP_ARRAY_LENGTH - 1;
   float matchValue = 0, rms_error = 0, relative_view_angle = 0;
-  int ring_slot_base;   // keyframe slots [ring_slot_base, ring_slot_base + 43) belong to the ring
-  int test_frame_slot;  // frame slot that holds the test keyframe's pyramid during the batched alignment
 
-  // The runtime must have been created with max_keyframes >= ring_slot_base + 43, max_frames > test_frame_slot and
-  // max_batch >= MAX_LOOP_ARRAY_LENGTH_SCALE_AVG.
-  globalOptimize(Runtime& r, const std::string& matchfilepath, int ring_base, int test_slot)
-      : rt(&r), ring_slot_base(ring_base), test_frame_slot(test_slot) {
+  static ellc_config ring_config(const ellc_config& tracking) {
+    ellc_config c = tracking;
+    c.max_keyframes = MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
+    c.max_frames = 1;
+    c.max_batch = MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
+    c.grid_batch = c.max_batch;   // world-size invariant bits (ellc_abi.h)
+    c.concurrent_batches = 1;
+    c.coalesce = 1;
+    return c;
+  }
+  globalOptimize(Runtime& r, const std::string& matchfilepath) : rt(&r), ring(ring_config(r.cfg)) {
+    ring.BATCH_START_ID = r.BATCH_START_ID;
     match_file.open(matchfilepath.c_str());
+  }
+  ~globalOptimize() {
+    try { join_all(); } catch (...) {}
+  }
+  // t_group.join_all() (:161); rethrows what the matching thread failed with
+  void join_all() {
+    if (t_group.joinable()) t_group.join();
+    if (!thread_error.empty()) {
+      const std::string e = thread_error;
+      thread_error.clear();
+      throw std::runtime_error(e);
+    }
   }
 
   // GlobalOptimize.cpp:151-272 (FLAG_USE_LOOP_CLOSURE_TRIGGER off: every finished keyframe is tested)
   void pushToArray(frame* currentframe, depthMap* currentDepthMap) {
+    join_all();   // :161 wait for the match thread before pushing another frame
     loopFrame& slot = loopFrameArray[currentArrayId];
-    slot.kf_slot = ring_slot_base + currentArrayId;
-    calculateImageHistogram(currentframe);
-    rt->check(ellc_copy_slot(rt->ctx, 1, slot.kf_slot, 1, currentframe->kf_slot), "ellc_copy_slot");   // :185-186 deep copies
+    slot.kf_slot = currentArrayId;
+    // :185-186 deep copies of the keyframe and its depth map, into the ring context
+    rt->check(ellc_copy_slot_across(ring.ctx, 1, slot.kf_slot, rt->ctx, 1, currentframe->kf_slot), "ellc_copy_slot_across");
+    TestFrame test;
+    test.frameId = currentframe->frameId;
+    test.ring_slot = slot.kf_slot;
+    std::memcpy(test.poseWrtWorld, currentframe->poseWrtWorld, 24);
+    std::memcpy(test.poseWrtOrigin, currentframe->poseWrtOrigin, 24);
+    calculateImageHistogram(test);
     slot.frameId = currentLoopFrame.frameId;
     slot.isValid = currentLoopFrame.isValid;
     std::memcpy(slot.image_histogram, currentLoopFrame.image_histogram, sizeof(slot.image_histogram));
@@ -375,19 +410,34 @@ class globalOptimize {
     std::memcpy(slot.poseWrtOrigin, currentframe->poseWrtOrigin, 24);
     slot.rescaleFactor = currentframe->rescaleFactor;
     slot.seeds = currentDepthMap->calculate_no_of_Seeds();
-    findMatchParallel(currentframe);
+    if (FLAG_DO_PARALLEL_SHORT_LOOP_CLOSURE) {   // :239-241
+      t_group = std::thread([this, test]() {
+        try { findMatchParallel(test); } catch (const std::exception& e) { thread_error = e.what(); }
+      });
+    } else {
+      findMatchParallel(test);
+    }
   }
 
  private:
-  // :40-100
-  void calculateImageHistogram(frame* currentframe) {
+  // what the matching thread keeps of the pushed keyframe (the reference hands it loopFrameArray[currentArrayId].this_frame, a
+  // deep copy: the caller's frame object may be gone before the thread ends)
+  struct TestFrame {
+    int frameId, ring_slot;
+    float poseWrtWorld[6], poseWrtOrigin[6];
+  };
+  std::thread t_group;
+  std::string thread_error;
+
+  // :40-100 (the histogram of the copy in the ring context: the same image)
+  void calculateImageHistogram(const TestFrame& f) {
     isloopClosureDetected = false;
     loopClosureArrayId = -1;
     currentLoopFrame.isValid = true;
-    currentLoopFrame.frameId = currentframe->frameId;
-    std::memcpy(currentLoopFrame.poseWrtWorld, currentframe->poseWrtWorld, 24);
-    std::memcpy(currentLoopFrame.poseWrtOrigin, currentframe->poseWrtOrigin, 24);
-    rt->check(ellc_histogram(rt->ctx, 1, currentframe->kf_slot, currentLoopFrame.image_histogram), "ellc_histogram");
+    currentLoopFrame.frameId = f.frameId;
+    std::memcpy(currentLoopFrame.poseWrtWorld, f.poseWrtWorld, 24);
+    std::memcpy(currentLoopFrame.poseWrtOrigin, f.poseWrtOrigin, 24);
+    ring.check(ellc_histogram(ring.ctx, 1, f.ring_slot, currentLoopFrame.image_histogram), "ellc_histogram");
   }
   // :436-452  third row of the rotation of exp(pose)
   static void calculateViewVec(const float* pose, float* view_vec) {
@@ -407,7 +457,7 @@ class globalOptimize {
     relative_view_angle = (relative_view_angle * 180) / 3.14f;   // sic: 3.14
   }
   // :274-416 (strayFlag = false)
-  bool findMatch(frame* currentframe) {
+  bool findMatch(const TestFrame& currentframe) {
     const int RING = MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
     calculateImageHistogram(currentframe);
     int i;
@@ -425,7 +475,7 @@ class globalOptimize {
       } else if (loopFrameArray[i].isValid == false) conditionToTerminateLoop = 1;
       if (conditionToTerminateLoop == 1) { lastTestedLoopClosureArrayId = -1; break; }
       if (loopFrameArray[i].isValid == 0) { lastTestedLoopClosureArrayId = -1; return false; }
-      if (currentframe->frameId - loopFrameArray[i].frameId > 8) {   // MIN_MATCH_DIFFERENCE = KEYFRAME_PROPAGATE_INTERVAL
+      if (currentframe.frameId - loopFrameArray[i].frameId > 8) {   // MIN_MATCH_DIFFERENCE = KEYFRAME_PROPAGATE_INTERVAL
         matchValue = (float)ellc_kl_divergence(loopFrameArray[i].image_histogram, currentLoopFrame.image_histogram, 256);
         calculateRotationStats(loopFrameArray[i].poseWrtWorld, currentLoopFrame.poseWrtWorld);
         if (matchValue <= 0.1f) {                       // MATCH_THRESHOLD
@@ -442,11 +492,11 @@ class globalOptimize {
     return isloopClosureDetected;
   }
   // :454-646
-  void findMatchParallel(frame* testFrame) {
+  void findMatchParallel(const TestFrame& testFrame) {
     const int RING = MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
     struct Match { int arrayId; float matchValue, rms, angle; };
     std::vector<Match> matches;
-    loopFrameArray[nextArrayId].frameId = testFrame->frameId;
+    loopFrameArray[nextArrayId].frameId = testFrame.frameId;
     lastTestedLoopClosureArrayId = -1;
     firstTestedLoopClosureArrayId = -1;
     int num_matches = 0;
@@ -462,13 +512,13 @@ class globalOptimize {
     if (!matches.empty()) {
       // one batched constant-weight alignment for all candidates (GetImagePoseEstimate(..., fromLoopClosure = true), :566)
       const int B = (int)matches.size();
-      std::vector<int> kf(B), fr(B, test_frame_slot);
+      std::vector<int> kf(B), fr(B, 0);
       std::vector<float> init((size_t)B * 6), out((size_t)B * 6);
-      rt->check(ellc_copy_slot(rt->ctx, 0, test_frame_slot, 1, testFrame->kf_slot), "ellc_copy_slot");
+      ring.check(ellc_copy_slot(ring.ctx, 0, 0, 1, testFrame.ring_slot), "ellc_copy_slot");
       for (int b = 0; b < B; b++) {
         const loopFrame& m = loopFrameArray[matches[b].arrayId];
         kf[b] = m.kf_slot;
-        ellc_concatenate_origin_pose(testFrame->poseWrtWorld, m.poseWrtWorld, &init[(size_t)b * 6]);   // ImageFunc.cpp:106
+        ellc_concatenate_origin_pose(testFrame.poseWrtWorld, m.poseWrtWorld, &init[(size_t)b * 6]);   // ImageFunc.cpp:106
       }
       if (rt->comm && rt->world > 1) {
         // this rank's contiguous block of the candidates on its own GPU, then the one exchange of the batch: 8 floats per
@@ -477,15 +527,15 @@ class globalOptimize {
         ellc_shard_range(B, rt->world, rt->rank, &lo, &hi);
         const int n = hi - lo;
         std::vector<float> pose((size_t)std::max(n, 1) * 6), wgt((size_t)std::max(n, 1)), local((size_t)std::max(n, 1) * 8), table((size_t)B * 8);
-        std::vector<int> iters((size_t)std::max(n, 1) * rt->cfg.levels);
+        std::vector<int> iters((size_t)std::max(n, 1) * ring.cfg.levels);
         if (n > 0)
-          rt->check(ellc_align(rt->ctx, n, kf.data() + lo, fr.data() + lo, init.data() + (size_t)lo * 6, ELLC_MODE_ICA, 0, pose.data(), iters.data(), wgt.data()),
-                    "ellc_align");
+          ring.check(ellc_align(ring.ctx, n, kf.data() + lo, fr.data() + lo, init.data() + (size_t)lo * 6, ELLC_MODE_ICA, 0, pose.data(), iters.data(), wgt.data()),
+                     "ellc_align");
         for (int b = 0; b < n; b++) {
           for (int k = 0; k < 6; k++) local[(size_t)b * 8 + k] = pose[(size_t)b * 6 + k];
           local[(size_t)b * 8 + 6] = wgt[b];
           int it = 0;
-          for (int l = 0; l < rt->cfg.levels; l++) it += iters[(size_t)b * rt->cfg.levels + l];
+          for (int l = 0; l < ring.cfg.levels; l++) it += iters[(size_t)b * ring.cfg.levels + l];
           local[(size_t)b * 8 + 7] = (float)it;
         }
         if (ellc_gather_results(rt->comm, B, local.data(), n, table.data()) != ELLC_OK)
@@ -493,7 +543,7 @@ class globalOptimize {
         for (int b = 0; b < B; b++)
           for (int k = 0; k < 6; k++) out[(size_t)b * 6 + k] = table[(size_t)b * 8 + k];
       } else {
-        rt->check(ellc_align(rt->ctx, B, kf.data(), fr.data(), init.data(), ELLC_MODE_ICA, 0, out.data(), nullptr, nullptr), "ellc_align");
+        ring.check(ellc_align(ring.ctx, B, kf.data(), fr.data(), init.data(), ELLC_MODE_ICA, 0, out.data(), nullptr, nullptr), "ellc_align");
       }
       for (int b = 0; b < B; b++) {
         const loopFrame& m = loopFrameArray[matches[b].arrayId];
@@ -501,7 +551,7 @@ class globalOptimize {
         ellc_concatenate_relative_pose(&out[(size_t)b * 6], m.poseWrtOrigin, poseWrtOrigin);   // ImageFunc.cpp:305
         const int seeds_num = (int)m.seeds;   // `int seeds_num` in the reference (:466)
         if (match_file.is_open()) {           // :580
-          match_file << (testFrame->frameId + rt->BATCH_START_ID - 1) << " " << (m.frameId + rt->BATCH_START_ID - 1) << " " << poseWrtOrigin[0] << " "
+          match_file << (testFrame.frameId + rt->BATCH_START_ID - 1) << " " << (m.frameId + rt->BATCH_START_ID - 1) << " " << poseWrtOrigin[0] << " "
                      << poseWrtOrigin[1] << " " << poseWrtOrigin[2] << " " << poseWrtOrigin[3] << " " << poseWrtOrigin[4] << " " << poseWrtOrigin[5]
                      << " " << m.rescaleFactor << " " << seeds_num << " " << matches[b].matchValue << " " << matches[b].rms << " "
                      << matches[b].angle << "\n";

@@ -45,6 +45,21 @@ WORKER = textwrap.dedent("""
         comm.start(9, shard(9, rep))
     for rep in range(4):
         assert np.array_equal(comm.finish(9), expect(9, rep))
+    # outstanding gathers of DIFFERENT sizes: finish() returns the oldest, sized by its own total (r02 sized it by the newest: a
+    # heap overflow); a wrong explicit total is refused and the gather stays outstanding; the C side refuses a short buffer
+    comm.start(40, shard(40, 7)); comm.start(8, shard(8, 8)); comm.start(33, shard(33, 9))
+    try:
+        comm.finish(8)
+        raise SystemExit("finish(8) accepted although the oldest gather has 40 records")
+    except _lib.EllcError:
+        pass
+    import ctypes as C
+    small = np.zeros((8, 8), np.float32)
+    assert comm._l.ellc_gather_finish(comm.h, small.ctypes.data_as(C.c_void_p), 8) == -5     # ELLC_ERR_CAPACITY, nothing written
+    assert not small.any()
+    assert np.array_equal(comm.finish(), expect(40, 7))
+    assert np.array_equal(comm.finish(8), expect(8, 8))
+    assert np.array_equal(comm.finish(33), expect(33, 9))
     # misuse is refused
     for bad in (lambda: comm.finish(9), lambda: comm.start(41, shard(40, 0)), lambda: comm.start(8, np.zeros((0 if rank else 1, 8), np.float32))):
         try:

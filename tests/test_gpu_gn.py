@@ -176,6 +176,102 @@ def test_save_weights_accumulates_last_iteration(oracle, ellc):
     ctx.close()
 
 
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_save_weights_once_when_a_batch_needs_the_continuation(oracle, ellc, arith):
+    """Early exit on, B = 2, saved weights: alignment 0 ends inside the first graph of the state-driven schedule (16 iterations),
+    alignment 1 needs the continuation (29). Both graphs end with gn_add_saved_weights_all: the weights of alignment 0 must be
+    added ONCE (r02 added them again behind the continuation). Checked against the oracle's saved weights and against the same
+    alignment run alone."""
+    cases = [(21, 0.02, 0.05), (22, 0.03, 0.08)]
+    pairs = [synth.make_pair(W, H, seed=s, rot=r, trans=t) for s, r, t in cases]
+    kw = dict(arith=ellc.ARITH_FAST) if arith == "fast" else {}
+    ctx = gpu_problem(ellc, W, H, L, pairs, early_exit=1, **kw)
+    _, iters, _ = ctx.align([0, 1], [0, 1], save_weights=True)
+    assert int(iters[0].sum()) <= 20 < int(iters[1].sum())   # one ends in the first graph, the other in the continuation
+    solo = gpu_problem(ellc, W, H, L, pairs, early_exit=1, **kw)
+    solo.align([0], [0], save_weights=True)
+    solo.align([1], [1], save_weights=True)
+    for i, pair in enumerate(pairs):
+        _, kf, cur, dm = oracle_problem(oracle, W, H, L, pair, early_exit=1)
+        oracle.align(kf, cur, dm.depth_pyr(), save_weights=True)
+        for l in range(L):
+            wr, nr = kf.weights(l)
+            wg, ng = ctx.keyframe_weights(i, l)
+            ws, ns = solo.keyframe_weights(i, l)
+            assert nr == ng == ns == 1
+            assert np.array_equal(wg == 0, ws == 0)
+            assert np.allclose(wg, ws, rtol=1e-3, atol=5e-6), (i, l, np.abs(wg - ws).max())   # a double add would be a factor of two
+            if arith == "exact":
+                assert np.allclose(wg, wr, rtol=1e-3, atol=5e-6), (i, l, np.abs(wg - wr).max())
+    ctx.close(); solo.close()
+
+
+@pytest.mark.parametrize("arith,mode", [("exact", 0), ("fast", 0), ("exact", 1), ("fast", 1)])
+def test_grid_batch_makes_a_shard_bit_identical_to_the_whole_batch(ellc, arith, mode):
+    """cfg.grid_batch = N: the launch grids (the order of the 27 sums) are those of a batch of N whatever B is, so the blocks
+    ellc_shard_range cuts a batch into — here for world sizes 1, 2, 3 and 5 — give, alignment for alignment, the bits of the
+    whole batch (the loop GlobalOptimize.cpp:480-610 sharded over ranks). Without it the grids follow B."""
+    from egomotion_with_local_loop_closures_amd import sharding
+    n = 5
+    pairs = [synth.make_pair(W, H, seed=40 + i, rot=0.004 + 0.001 * i, trans=0.01) for i in range(n)]
+    kw = dict(arith=ellc.ARITH_FAST) if arith == "fast" else {}
+    ctx = gpu_problem(ellc, W, H, L, pairs, early_exit=1, grid_batch=n, **kw)
+    if mode == 1:
+        for i in range(n):
+            for l in range(L):
+                ctx.keyframe_set_weights(i, l, np.full((H >> l, W >> l), 0.04, np.float32), 1)
+    idx = np.arange(n)
+    whole = ctx.align(idx, idx, mode=mode)
+    for world in (2, 3, 5):
+        for rank in range(world):
+            lo, hi = sharding.shard_range(n, world, rank)
+            if hi > lo:
+                part = ctx.align(idx[lo:hi], idx[lo:hi], mode=mode)
+                for a_, b_ in zip(part, whole):
+                    assert np.array_equal(a_, b_[lo:hi]), (world, rank)
+    ctx.close()
+
+
+def test_copy_slot_across_contexts(ellc):
+    """ellc_copy_slot_across: the loop-closure ring's deep copy (GlobalOptimize.cpp:185-186) between two contexts of one
+    device — image pyramid, depth / variance / weight pyramids, weight counts, maxAbsGradient — ordered on the device against
+    both contexts' streams; an alignment on the copy equals the alignment on the original."""
+    pair = synth.make_pair(W, H, seed=77)
+    a = gpu_problem(ellc, W, H, L, [pair])
+    b = gpu_problem(ellc, W, H, L, [synth.make_pair(W, H, seed=78)], max_keyframes=3)
+    for l in range(L):
+        a.keyframe_set_weights(0, l, np.full((H >> l, W >> l), 0.03 + 0.01 * l, np.float32), 2 + l)
+    ellc.copy_slot_across(b, True, 2, a, True, 0)
+    a.keyframe_upload(0, pair["cur_image"])   # overwriting the source afterwards must not disturb the copy (device-side ordering)
+    ellc.copy_slot_across(b, False, 0, a, False, 0)
+    for l in range(L):
+        assert np.array_equal(b.image_level(True, 2, l)[0], gpu_problem_image(ellc, pair, l))
+        wa, na = b.keyframe_weights(2, l)
+        assert na == 2 + l and np.all(wa == np.float32(0.03 + 0.01 * l))
+    ref = gpu_problem(ellc, W, H, L, [pair])
+    d0, v0 = ref.keyframe_depth_level(0, 0)
+    d1, v1 = b.keyframe_depth_level(2, 0)
+    assert np.array_equal(d0, d1) and np.array_equal(v0, v1)
+    assert np.array_equal(b.max_gradient(True, 2)[0], ref.max_gradient(True, 0)[0])
+    pr, ir, wr = ref.align([0], [0])
+    pb, ib, wb = b.align([2], [0])
+    assert np.array_equal(pr, pb) and np.array_equal(ir, ib) and np.array_equal(wr, wb)
+    with pytest.raises(ellc.EllcError):
+        small = ellc.Context(ellc.default_config(W // 2, H // 2, L))
+        try:
+            ellc.copy_slot_across(small, True, 0, a, True, 0)
+        finally:
+            small.close()
+    a.close(); b.close(); ref.close()
+
+
+def gpu_problem_image(ellc, pair, level):
+    c = gpu_problem(ellc, W, H, L, [pair])
+    img = c.image_level(True, 0, level)[0]
+    c.close()
+    return img
+
+
 def test_batch_alignments_are_independent(oracle, ellc):
     """B=4 distinct keyframes in one launch sequence == four single alignments."""
     pairs = synth.make_loop_closure_batch(W, H, 4, seed=100)

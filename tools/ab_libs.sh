@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 for r in $(seq 1 "$ROUNDS"); do
   for lib in "${LIBS[@]}"; do
     name=$(basename "$lib" .so)
-    ELLC_LIB_PATH=$lib python bench.py --no-extras --no-cpu-baseline --steps 40 --warmup 200 "$@" > "$OUT/${name}_r$r.json" 2>> "$OUT/err.log" || exit 1
+    python bench.py --lib $lib --no-extras --no-cpu-baseline --steps 40 --warmup 200 "$@" > "$OUT/${name}_r$r.json" 2>> "$OUT/err.log" || exit 1
   done
 done
 python - "$OUT" <<'PY'

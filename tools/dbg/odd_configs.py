@@ -6,6 +6,8 @@ import sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from egomotion_with_local_loop_closures_amd import api, synth
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # noqa: E402
+import diaglib  # noqa: E402,F401  (ELLC_LIB_PATH -> _lib.use_library: diagnostic builds)
 from helpers import gpu_problem
 w, h, L = 160, 120, 3
 pairs = [synth.make_pair(w, h, seed=700 + i, rot=0.004, trans=0.012) for i in range(6)]

@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 from egomotion_with_local_loop_closures_amd import api, synth  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))  # noqa: E402
+import diaglib  # noqa: E402,F401  (ELLC_LIB_PATH -> _lib.use_library: diagnostic builds)
 
 NC = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 NF = int(sys.argv[2]) if len(sys.argv) > 2 else 1
