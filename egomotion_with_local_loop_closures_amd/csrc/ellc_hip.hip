@@ -112,7 +112,12 @@ int choose_nblk(const ellc_ctx* c, int level, int B) {
   // one round of resident blocks (measured best for a batch that has the device to itself: r01 sweep); half a round when
   // the caller keeps several batches in flight (cfg.concurrent_batches), so that the fine-level launches of two batches can share the device (r01 sweep with three
   // in flight at B=32: 32/32 blocks 0.375 ms per batch, 16/16 0.338, 12/12 0.339, 8/8 0.348, 64/32 0.392)
-  const int per = std::max(1, c->resident_blocks / B / (c->cfg.concurrent_batches > 1 ? 2 : 1));
+  // (r03: a launch that covers a whole group of batches keeps the full round where that still leaves a thread plenty of pixels —
+  // level 0 of 640x480 over 128 alignments: 8 blocks per alignment instead of 4, the launch 49 instead of 61 us alone, the
+  // pipeline's rate unchanged (tools/dbg/nblk_bench.sh); level 1 is slower with the full round)
+  const int per_full = std::max(1, c->resident_blocks / B);
+  const bool share = c->cfg.concurrent_batches > 1 && (double)n / (256.0 * per_full) < 100.0;
+  const int per = std::max(1, per_full / (share ? 2 : 1));
   int nblk = std::min(ELLC_NBLK_MAX, std::min(by_px, per));
   // small levels: one block per CU runs the (serial) solve prologue and the short pixel pass fastest, as long as a
   // thread does not get more than ~4 pixels (r01 sweep: level 2 at B=32, 8 blocks beat 30; level 1 keeps 32)
@@ -414,6 +419,17 @@ static void set_age_split(ellc_ctx* c, FusedArgs& fa, int B) {
   fa.age_rounds = R;
 }
 
+// Which levels serve their taps from LDS windows (fca_chunk_pass_win): those whose launches are long enough for the two
+// barriers and the staging round trip per band to pay — at least win_min_px pixels of the level per thread of the launch
+static void set_window_levels(const ellc_ctx* c, FusedArgs& fa, int B) {
+  for (int l = 0; l < ELLC_MAX_LEVELS; l++) {
+    fa.win_lv[l] = 0;
+    if (l >= c->L || !c->use_windows || !ELLC_WIN_ENABLED) continue;
+    const int nblk = choose_nblk(c, l, grid_batch(c, B));
+    fa.win_lv[l] = ((double)c->geom_h[l].n / (256.0 * nblk) >= c->win_min_px) ? 1 : 0;
+  }
+}
+
 static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
   const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
   const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
@@ -478,6 +494,7 @@ static int adaptive_first_launches(const ellc_ctx* c, int B) {
 static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weights, int launches, bool continuation = false) {
   FusedArgs fa;
   fa.continuation = continuation ? 1 : 0;
+  for (int l = 0; l < ELLC_MAX_LEVELS; l++) fa.win_lv[l] = 0;   // (the state-driven tracking schedule keeps the global-memory taps)
   fa.seq = 0;
   fa.prev_level = -1;
   fa.prev_nblk = 0;
@@ -525,6 +542,7 @@ static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weight
 static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) {
   FusedArgs fa;
   fa.continuation = 0;
+  set_window_levels(c, fa, B);
   fa.seq = 0;
   fa.prev_level = -1;
   fa.prev_nblk = 0;
@@ -558,6 +576,7 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
 static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
   FusedArgs fa;
   fa.continuation = 0;
+  for (int l = 0; l < ELLC_MAX_LEVELS; l++) fa.win_lv[l] = 0;
   fa.seq = 0;
   fa.prev_level = -1;
   fa.prev_nblk = 0;
@@ -756,14 +775,14 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     const int tiles = c->tile_begin[l + 1] - c->tile_begin[l];
     for (int s = 0; s < MK; s++) {
       KfLevelDev& k = c->kf_tab_h[(size_t)l * MK + s];
-      TRY(dev_alloc(c, &k.img, ni));
+      TRY(dev_alloc(c, &k.img, ni + 16));   // + 16: the window staging reads whole 16-byte words (stage_window), the last may reach past the image
       TRY(dev_alloc(c, &k.depth, n)); TRY(dev_alloc(c, &k.var, n)); TRY(dev_alloc(c, &k.weight, n));
       TRY(dev_alloc(c, &k.cxy, n)); TRY(dev_alloc(c, &k.cZ, n)); TRY(dev_alloc(c, &k.cI, n));
       TRY(dev_alloc(c, &k.crec, n)); TRY(dev_alloc(c, &k.cW, n)); TRY(dev_alloc(c, &k.wlast, n)); TRY(dev_alloc(c, &k.sd, 6 * n));
       TRY(dev_alloc(c, &k.count, 4)); TRY(dev_alloc(c, &k.tile_count, tiles + 1));
       TRY(dev_alloc(c, &k.irec, n)); TRY(dev_alloc(c, &k.hpart, (size_t)(tiles + 1) * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
     }
-    for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni));
+    for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni + 16));
   }
   TRY(dev_alloc(c, &c->kf_tab_d, c->kf_tab_h.size()));
   TRY(dev_alloc(c, &c->fr_tab_d, c->fr_tab_h.size()));
@@ -857,6 +876,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     if (const char* pp = getenv("ELLC_PIPE")) c->pipe = (pp[0] == '1');
     if (const char* am = getenv("ELLC_AGE_MIN_PX")) c->age_min_px_per_thread = atof(am);
     if (getenv("ELLC_NO_ADAPTIVE")) c->use_adaptive = false;
+    if (getenv("ELLC_NO_WINDOWS")) c->use_windows = false;
+    if (const char* wm = getenv("ELLC_WIN_MIN")) c->win_min_px = atof(wm);
     if (const char* ab = getenv("ELLC_ADAPTIVE_MAX_BATCH")) c->adaptive_max_batch = atoi(ab);
     if (const char* af = getenv("ELLC_ADAPTIVE_FIRST")) c->adaptive_first_override = atoi(af);
     if (const char* aw = getenv("ELLC_AGE_W")) {   // "R:w0,w1,..": weights for grids of R rounds
@@ -1632,6 +1653,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     // the production kernel of the FCA path: every launch first solves the previous launch's partial sums
     FusedArgs fa;
     fa.continuation = 0;
+    set_window_levels(c, fa, B);
     fa.g = a;
     fa.res = nullptr;
     fa.ica = 0;
@@ -1717,6 +1739,18 @@ __global__ __launch_bounds__(256) void calib_read_f32(const float* __restrict__ 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += p[i];
   if (acc == 1.2345e-30f) sink[0] = acc;   // keeps the loads alive
 }
+
+#ifdef ELLC_WINSTATS
+// statistics build only: the window statistics (g_win_stats), read and cleared
+ellc_status ellc_debug_win_stats(ellc_ctx* c, unsigned long long* out8) {
+  ELLC_ENTER(c);
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  ELLC_HIP(c, hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_win_stats), 8 * sizeof(unsigned long long)));
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  ELLC_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(g_win_stats), z, sizeof(z)));
+  return ELLC_OK;
+}
+#endif
 
 #ifdef ELLC_STAMPS
 // diagnostic build only: copies the cycle stamps of block (0,0) of the last fused launch

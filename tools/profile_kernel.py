@@ -25,12 +25,14 @@ ap.add_argument("--calib-mb", type=int, default=512)
 ap.add_argument("--inflight", type=int, default=16, help="cfg.concurrent_batches, as bench.py's default (it sizes the grid)")
 ap.add_argument("--coalesce", type=int, default=4, help="cfg.coalesce, as bench.py's default: the launch covers this many batches side by side")
 ap.add_argument("--arith", choices=["fast", "exact"], default="fast")
+ap.add_argument("--rot", type=float, default=0.01, help="rotation of the synthetic camera motion (rad)")
+ap.add_argument("--trans", type=float, default=0.02, help="translation of the synthetic camera motion")
 a = ap.parse_args()
 W, H, L, B = a.width, a.height, a.levels, a.batch
 K = B * a.coalesce   # alignments of one launch: a group of full batches
 fx, fy, cx, cy = synth.default_intrinsics(W, H)
 # the bench workload: B keyframes of one scene against ONE frame (semi-dense); dense (C4 shape): two scenes, own frame each
-pairs = [synth.make_pair(W, H, seed=0xC4 + i, dense=True) for i in range(2)] if a.dense else synth.make_shared_frame_batch(W, H, B, seed=0x5EED)
+pairs = [synth.make_pair(W, H, seed=0xC4 + i, dense=True, rot=a.rot, trans=a.trans) for i in range(2)] if a.dense else synth.make_shared_frame_batch(W, H, B, seed=0x5EED, rot=a.rot, trans=a.trans)
 ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_keyframes=K, max_frames=K, max_batch=B,
                                      concurrent_batches=a.inflight, coalesce=a.coalesce, arith=api.ARITH_FAST if a.arith == "fast" else api.ARITH_EXACT))
 for b in range(K):
@@ -40,6 +42,13 @@ for b in range(K):
         ctx.frame_upload(b if a.dense else b // B, p["cur_image"])
 slots = np.arange(K, dtype=np.int32)
 ms, alg, V = ctx.profile_gn_kernel(slots, slots if a.dense else (slots // B).astype(np.int32), a.level, reps=a.reps)
+try:   # diagnostic build: how the window path was used
+    import ctypes as C
+    st = (C.c_ulonglong * 8)()
+    if ctx._l.ellc_debug_win_stats(ctx.h, st) == 0:
+        print("win_stats bands_on %d bands_off %d wave_steps lds %d global_interior %d general %d" % tuple(st[:5]), file=sys.stderr)
+except AttributeError:
+    pass
 cal_bytes = a.calib_mb << 20
 cms = ctx.profile_calibrate_read(cal_bytes, reps=5)
 print(json.dumps({"kernel": "gn_fca_fused", "arith": a.arith, "size": [W, H, L], "dense": bool(a.dense), "level": a.level, "batch": B, "coalesce": a.coalesce, "alignments_per_launch": K, "concurrent_batches": a.inflight, "avg_ms": ms, "algorithmic_bytes": alg, "valid_pixels": V,
