@@ -52,35 +52,12 @@ template <class T>
 __device__ __forceinline__ ELLC_GLOBAL T* as_global_rw(T* p) { return (ELLC_GLOBAL T*)p; }
 
 // ---------------------------------------------------------------------------------------------------
-// wave-wide sums (64 lanes) with DPP row operations; the total lands in lane 63.
+// one DPP step of a wave-wide sum (see wave_sum_rows)
 template <int CTRL, int RMASK>
 __device__ __forceinline__ float dpp_add(float v) {
   const int x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false);
   return v + __builtin_bit_cast(float, x);
 }
-// NV independent reductions, one DPP stage at a time across all values so the two wait states a DPP
-// read needs after the producing VALU are filled with the other values' adds instead of s_nop.
-template <int NV>
-__device__ __forceinline__ void wave_sum_all(float (&v)[NV]) {
-#pragma unroll
-  for (int j = 0; j < NV; j++) v[j] = dpp_add<0xB1, 0xf>(v[j]);    // quad_perm [1,0,3,2]
-#pragma unroll
-  for (int j = 0; j < NV; j++) v[j] = dpp_add<0x4E, 0xf>(v[j]);    // quad_perm [2,3,0,1]
-#pragma unroll
-  for (int j = 0; j < NV; j++) v[j] = dpp_add<0x141, 0xf>(v[j]);   // row_half_mirror
-#pragma unroll
-  for (int j = 0; j < NV; j++) v[j] = dpp_add<0x140, 0xf>(v[j]);   // row_mirror
-#pragma unroll
-  for (int j = 0; j < NV; j++) v[j] = dpp_add<0x142, 0xa>(v[j]);   // row_bcast:15 into rows 1,3
-#pragma unroll
-  for (int j = 0; j < NV; j++) v[j] = dpp_add<0x143, 0xc>(v[j]);   // row_bcast:31 into rows 2,3
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  float a[1] = {v};
-  wave_sum_all<1>(a);
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[0]), 63));
-}
-
 // ExternVariable.h:232 clamps (double)v away from zero at +-1e-10 and rounds back to f32. For an f32 argument that is
 // a pure f32 select: with C = RN_f32(1e-10) = 0x1.b7cdfep-34 > 1e-10 and its predecessor below 1e-10,
 // "(double)v < 1e-10" <=> "v < C" and the clamped result (float)1e-10 is C (negative side mirrored; NaN passes).
@@ -408,15 +385,56 @@ struct GnArgs {
   int save_w;                   // write per-pixel weights of this iteration into kf.wlast
 };
 
+// Wave-wide sums of NV values by a halving transpose: v_permlane32_swap exchanges the upper half of one register with the
+// lower half of another, so ONE swap and ONE add turn two values into one register whose halves carry one value each (summed
+// over lane pairs l, l + 32); v_permlane16_swap does the same with the 16-lane rows. After the two stages ceil(NV / 4)
+// registers hold four values each — one per row — and four DPP steps finish the sums inside the rows: for 27 values 14 + 7
+// swaps, 21 + 28 adds instead of the 162 DPP adds of wave_sum_all (r02: 1.2 us per launch, at the tail of every launch).
+// Row q of out[j] holds value 4 j + 2 (q & 1) + (q >> 1), the same total in every lane of the row. Fixed order: deterministic.
+template <int NV>
+struct WaveRows {
+  static constexpr int N1 = (NV + 1) / 2, N2 = (N1 + 1) / 2;
+};
+template <int NV>
+__device__ __forceinline__ void wave_sum_rows(const float (&v)[NV], float (&out)[WaveRows<NV>::N2]) {
+  constexpr int N1 = WaveRows<NV>::N1, N2 = WaveRows<NV>::N2;
+  float s1[N1];
+#pragma unroll
+  for (int j = 0; j < N1; j++) {
+    const float a = v[2 * j], b = (2 * j + 1 < NV) ? v[2 * j + 1] : 0.0f;   // (an odd value out pairs with zero: a register swapped with itself is a no-op)
+    const auto t = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned t0 = t[0], t1 = t[1];   // (copied to scalars first: __builtin_bit_cast of a vector element expression reads element 0)
+    s1[j] = __builtin_bit_cast(float, t0) + __builtin_bit_cast(float, t1);
+  }
+#pragma unroll
+  for (int j = 0; j < N2; j++) {
+    const float a = s1[2 * j], b = (2 * j + 1 < N1) ? s1[2 * j + 1] : 0.0f;
+    const auto t = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned t0 = t[0], t1 = t[1];
+    out[j] = __builtin_bit_cast(float, t0) + __builtin_bit_cast(float, t1);
+  }
+#pragma unroll
+  for (int j = 0; j < N2; j++) out[j] = dpp_add<0xB1, 0xf>(out[j]);    // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int j = 0; j < N2; j++) out[j] = dpp_add<0x4E, 0xf>(out[j]);    // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int j = 0; j < N2; j++) out[j] = dpp_add<0x141, 0xf>(out[j]);   // row_half_mirror
+#pragma unroll
+  for (int j = 0; j < N2; j++) out[j] = dpp_add<0x140, 0xf>(out[j]);   // row_mirror: every lane of a row holds the row's total
+}
+
 // block reduction of NV per-thread accumulators; thread 0..NV-1 of the block ends up writing value j.
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float* __restrict__ out) {
   __shared__ float red[ELLC_GN_THREADS / 64][32];
+  static_assert(NV <= 28, "one partial record holds 32 floats");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  wave_sum_all<NV>(acc);
-  if (lane == 63) {
+  float rows[WaveRows<NV>::N2];
+  wave_sum_rows<NV>(acc, rows);
+  if ((lane & 15) == 0) {   // the first lane of each row stores the row's value of every register
+    const int q = lane >> 4, col = 2 * (q & 1) + (q >> 1);
 #pragma unroll
-    for (int j = 0; j < NV; j++) red[wave][j] = acc[j];
+    for (int j = 0; j < WaveRows<NV>::N2; j++) red[wave][4 * j + col] = rows[j];
   }
   __syncthreads();
   if (threadIdx.x < NV) {
