@@ -152,7 +152,7 @@ struct ellc_ctx {
   float dm_depth_scale = 1.0f, dm_global_scale = 1.0f;
   float *dm_deptharr0 = nullptr, *dm_vararr0 = nullptr;     // level-0 arrays in the reference's array convention
   // propagate scratch
-  int *pr_tgt = nullptr, *pr_winner = nullptr, *pr_val = nullptr, *pr_remaining = nullptr;
+  int *pr_tgt = nullptr, *pr_cnt = nullptr, *pr_slots = nullptr, *pr_val = nullptr, *pr_remaining = nullptr;   // pr_remaining: a counter word (ellc_depth_seeds)
   float *pr_id = nullptr, *pr_var = nullptr;
   double* red_scratch = nullptr;                            // reductions (rescale factor)
   float Kinv[9], Kmat[9];

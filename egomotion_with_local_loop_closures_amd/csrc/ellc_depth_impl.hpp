@@ -48,30 +48,37 @@ ellc_status need_map(ellc_ctx* c) {
 
 ellc_status do_regularize(ellc_ctx* c, int removeOcclusions) {
   const int W = c->cfg.width, H = c->cfg.height;
-  dim3 blk(DM_TX, DM_TY);
-  hipLaunchKernelGGL(dm_regularize, grid2(W, H, blk), blk, 0, c->stream, c->dm_cur, c->dm_oth, W, H, removeOcclusions);
+  const int tiles_x = (W + DM_TX - 1) / DM_TX, tiles = tiles_x * ((H + DM_TY - 1) / DM_TY);
+  // in place, except for the validity flags: they go to the other map's plane, which becomes this map's
+  hipLaunchKernelGGL(dm_regularize, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth.isValid, W, H, removeOcclusions,
+                     tiles_x, tiles);
   ELLC_HIP(c, hipGetLastError());
-  swap_maps(c);
+  std::swap(c->dm_cur.isValid, c->dm_oth.isValid);
   return ELLC_OK;
 }
 
 ellc_status do_fill_holes(ellc_ctx* c) {
   const int W = c->cfg.width, H = c->cfg.height;
-  dim3 blk(DM_TX, DM_TY);
-  hipLaunchKernelGGL(dm_fill_holes, grid2(W, H, blk), blk, 0, c->stream, c->dm_cur, c->dm_oth, c->kf_maxgrad[c->dm_kf_slot], W, H);
+  const int tiles_x = (W + DM_TX - 1) / DM_TX, tiles = tiles_x * ((H + DM_TY - 1) / DM_TY);
+  hipLaunchKernelGGL(dm_fill_holes, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth, c->kf_maxgrad[c->dm_kf_slot], W, H,
+                     tiles_x, tiles);
   ELLC_HIP(c, hipGetLastError());
   swap_maps(c);
   return ELLC_OK;
 }
 
-ellc_status do_rescale(ellc_ctx* c, float* factor_out) {
+// makeInvDepthOne (:1546-1587), enqueue only: the factor stays on the device (the second stage of the sum is redone by every
+// block of the rescale: 256 partials, one launch less); do_rescale_finish fetches it
+ellc_status do_rescale_enqueue(ellc_ctx* c) {
   const int n = c->cfg.width * c->cfg.height;
   const int nb = 256;
   hipLaunchKernelGGL(dm_sum_stage1, dim3(nb), dim3(256), 0, c->stream, c->dm_cur, n, c->red_scratch);
-  hipLaunchKernelGGL(dm_sum_stage2, dim3(1), dim3(256), 0, c->stream, c->red_scratch, nb, c->red_scratch + 2 * nb);
-  const float* factor_d = (const float*)(c->red_scratch + 2 * nb + 2);
-  hipLaunchKernelGGL(dm_rescale, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dm_cur, n, factor_d);
+  hipLaunchKernelGGL(dm_rescale, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dm_cur, n, c->red_scratch, nb, (float*)(c->red_scratch + 2 * nb + 2));
   ELLC_HIP(c, hipGetLastError());
+  return ELLC_OK;
+}
+ellc_status do_rescale_finish(ellc_ctx* c, float* factor_out) {
+  const float* factor_d = (const float*)(c->red_scratch + 2 * 256 + 2);
   float f = 0;
   ELLC_HIP(c, hipMemcpyAsync(&f, factor_d, 4, hipMemcpyDeviceToHost, c->stream));
   ELLC_HIP(c, hipStreamSynchronize(c->stream));
@@ -79,6 +86,10 @@ ellc_status do_rescale(ellc_ctx* c, float* factor_out) {
   c->dm_global_scale *= f;   // util::GLOABL_DEPTH_SCALE, kept per context
   if (factor_out) *factor_out = f;
   return ELLC_OK;
+}
+ellc_status do_rescale(ellc_ctx* c, float* factor_out) {
+  const ellc_status s = do_rescale_enqueue(c);
+  return s != ELLC_OK ? s : do_rescale_finish(c, factor_out);
 }
 
 ellc_status do_update_depth_image(ellc_ctx* c) {
@@ -131,25 +142,11 @@ ellc_status do_propagate(ellc_ctx* c, int new_kf_slot, const float* pose_new_wrt
   }
   a.fx = c->cfg.fx; a.fy = c->cfg.fy; a.cx = c->cfg.cx; a.cy = c->cfg.cy;
   a.fxi = c->Kinv[0]; a.cxi = c->Kinv[2]; a.fyi = c->Kinv[4]; a.cyi = c->Kinv[5];
-  a.tgt = c->pr_tgt; a.nid = c->pr_id; a.nvar = c->pr_var; a.nval = c->pr_val; a.winner = c->pr_winner; a.remaining = c->pr_remaining;
+  a.tgt = c->pr_tgt; a.nid = c->pr_id; a.nvar = c->pr_var; a.nval = c->pr_val; a.cnt = c->pr_cnt; a.slots = c->pr_slots;
   dim3 blk(32, 8);
   hipLaunchKernelGGL(dm_prop_project, grid2(W, H, blk), blk, 0, c->stream, a);
-  // rounds: at most as many as the deepest collision chain; checked every 4 rounds
-  int remaining = 1;
-  for (int guard = 0; guard < 64 && remaining != 0; guard++) {
-    for (int r = 0; r < 4; r++) {
-      ELLC_HIP(c, hipMemsetAsync(c->pr_remaining, 0, 4, c->stream));
-      hipLaunchKernelGGL(dm_prop_select, dim3((n + 255) / 256), dim3(256), 0, c->stream, a, n);
-      hipLaunchKernelGGL(dm_prop_apply, dim3((n + 255) / 256), dim3(256), 0, c->stream, a, n);
-    }
-    ELLC_HIP(c, hipGetLastError());
-    ELLC_HIP(c, hipMemcpyAsync(&remaining, c->pr_remaining, 4, hipMemcpyDeviceToHost, c->stream));
-    ELLC_HIP(c, hipStreamSynchronize(c->stream));
-  }
-  // 256 rounds resolve every collision chain a map of <= 2^24 pixels can hold in practice; if sources were still unresolved the
-  // target map would differ from the reference's raster-order fold: report it instead of returning a wrong map (the current
-  // map is left untouched: no swap)
-  if (remaining != 0) return fail(c, ELLC_ERR_CAPACITY, "ellc_depth_propagate: collision chains deeper than 256 rounds");
+  hipLaunchKernelGGL(dm_prop_fold, dim3((n + 255) / 256), dim3(256), 0, c->stream, a, n);
+  ELLC_HIP(c, hipGetLastError());
   swap_maps(c);   // std::swap(currentDepthHypothesis, otherDepthHypothesis) (:1154)
   return ELLC_OK;
 }
@@ -276,8 +273,9 @@ ellc_status ellc_depth_create_keyframe(ellc_ctx* c, int new_kf_slot, const float
   if ((s = do_regularize(c, 1)) == ELLC_OK &&                                      // :1775
       (s = do_fill_holes(c)) == ELLC_OK &&                                         // :1777 doRegularization(false)
       (s = do_regularize(c, 0)) == ELLC_OK &&
-      (s = do_rescale(c, rescale_factor)) == ELLC_OK)                              // :1779
-    s = do_update_depth_image(c);                                                  // :1781
+      (s = do_rescale_enqueue(c)) == ELLC_OK &&                                    // :1779
+      (s = do_update_depth_image(c)) == ELLC_OK)                                   // :1781
+    s = do_rescale_finish(c, rescale_factor);   // the one host wait of the whole sequence: the factor the caller is handed
   if (s != ELLC_OK) {   // a device error part-way: the map no longer matches either keyframe
     c->dm_kf_slot = old_slot;
     c->dm_ready = false;

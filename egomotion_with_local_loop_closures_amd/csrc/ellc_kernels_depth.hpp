@@ -78,9 +78,21 @@ struct DmTile {
   int validity[DM_TH][DM_TW];
   uint8_t valid[DM_TH][DM_TW];
 };
-__device__ __forceinline__ void dm_tile_load(DmTile& t, const DepthSoA& in, int W, int H) {
-  const int x0 = blockIdx.x * DM_TX - DM_HALO, y0 = blockIdx.y * DM_TY - DM_HALO;
-  for (int k = threadIdx.y * DM_TX + threadIdx.x; k < DM_TW * DM_TH; k += DM_TX * DM_TY) {
+// Tile of a stencil launch, XCD-aware: workgroups are dealt round-robin over the 8 XCDs (each with an L2 of its own), so with
+// the plain numbering every tile's neighbours — whose pixels are its halo — sit on other XCDs and every halo line is fetched
+// from memory once per XCD (r02 counters: dm_regularize read 3.2 x its algorithmic bytes). Renumbered, XCD k owns the k-th
+// eighth of the tiles in raster order: a band of whole tile rows, whose halos its own L2 serves. Pure relabelling.
+__device__ __forceinline__ bool dm_tile_of_block(int tiles_x, int tiles_total, int& bx, int& by) {
+  const int per = (tiles_total + 7) >> 3;
+  const int tile = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || tile >= tiles_total) return false;
+  by = tile / tiles_x;
+  bx = tile - by * tiles_x;
+  return true;
+}
+__device__ __forceinline__ void dm_tile_load_at(DmTile& t, const DepthSoA& in, int W, int H, int bx, int by) {
+  const int x0 = bx * DM_TX - DM_HALO, y0 = by * DM_TY - DM_HALO;
+  for (int k = threadIdx.x; k < DM_TW * DM_TH; k += DM_TX * DM_TY) {
     const int ty = k / DM_TW, tx = k - ty * DM_TW;
     const int x = x0 + tx, y = y0 + ty;
     const bool inside = (x >= 0 && x < W && y >= 0 && y < H);
@@ -93,26 +105,61 @@ __device__ __forceinline__ void dm_tile_load(DmTile& t, const DepthSoA& in, int 
   __syncthreads();
 }
 
-// depthMap::regularizeDepthMap (:1436-1543). Reads `in` (the memcpy snapshot), writes every pixel of `out`.
-__global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA in, DepthSoA out, int W, int H, int removeOcclusions) {
+// The pixels of a tile that have work to do, gathered so that full waves process them: a semi-dense map holds a hypothesis at
+// a fifth of its pixels, but nearly every wave of a pixel-per-lane launch holds at least one — and then runs the 25-neighbour
+// loop with its IEEE divisions for all 64 lanes. Returns the number of candidates; list[k] = thread index of candidate k, in
+// thread order (deterministic). Ends with a barrier.
+__device__ __forceinline__ int dm_compact_candidates(bool cand, uint8_t* list, int* wave_count) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(cand);
+  if (lane == 0) wave_count[wave] = __popcll(m);
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < (DM_TX * DM_TY) / 64; w++) {
+    const int c = wave_count[w];
+    if (w < wave) base += c;
+    total += c;
+  }
+  if (cand) list[base + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = (uint8_t)threadIdx.x;
+  __syncthreads();
+  return total;
+}
+
+// depthMap::regularizeDepthMap (:1436-1543). The stencil reads the snapshot's invDepth / variance / validity / isValid, a
+// pixel's update writes only its own invDepthSmoothed / varianceSmoothed / blacklisted — which no stencil reads — and isValid:
+// so the map is updated IN PLACE and only the new validity flags go to a plane of their own (valid_out, which the caller then
+// swaps in): 13 bytes read (x the halo) and at most 13 written per pixel instead of 25 + 25 through a second copy of the map.
+__global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA s, uint8_t* __restrict__ valid_out, int W, int H, int removeOcclusions,
+                                                               int tiles_x, int tiles_total) {
   __shared__ DmTile t;
-  dm_tile_load(t, in, W, H);
-  const int x = blockIdx.x * DM_TX + threadIdx.x;
-  const int y = blockIdx.y * DM_TY + threadIdx.y;
-  if (x >= W || y >= H) return;
-  const int i = x + y * W;
-  const int cx = threadIdx.x + DM_HALO, cy = threadIdx.y + DM_HALO;
-  Hyp d = hyp_load(in, i);
-  if (y >= 3 && y < H - 3 && x >= 2 && x < W - 2 && d.valid) {
+  __shared__ uint8_t list[DM_TX * DM_TY];
+  __shared__ int wave_count[(DM_TX * DM_TY) / 64];
+  __shared__ float r_ids[DM_TX * DM_TY], r_vars[DM_TX * DM_TY];
+  __shared__ uint8_t r_code[DM_TX * DM_TY];   // 0: unchanged, 1: smoothed values, 2: invalidated + blacklist step, 3: invalidated (occluded)
+  int bx, by;
+  if (!dm_tile_of_block(tiles_x, tiles_total, bx, by)) return;
+  dm_tile_load_at(t, s, W, H, bx, by);
+  const int tx = threadIdx.x & (DM_TX - 1), ty = threadIdx.x / DM_TX;
+  const int x = bx * DM_TX + tx, y = by * DM_TY + ty;
+  const bool inside = (x < W && y < H);
+  const bool dvalid = t.valid[ty + DM_HALO][tx + DM_HALO] != 0;
+  const bool cand = inside && y >= 3 && y < H - 3 && x >= 2 && x < W - 2 && dvalid;
+  r_code[threadIdx.x] = 0;
+  const int ncand = dm_compact_candidates(cand, list, wave_count);
+  for (int k = threadIdx.x; k < ncand; k += DM_TX * DM_TY) {
+    const int p = list[k];
+    const int cx = (p & (DM_TX - 1)) + DM_HALO, cy = p / DM_TX + DM_HALO;
+    const float did = t.id[cy][cx], dvar = t.var[cy][cx];
     float sum = 0.0f, val_sum = 0.0f, sumIvar = 0.0f;
     int numOccluding = 0, numNotOccluding = 0;
     for (int dx = -2; dx <= 2; dx++)
       for (int dy = -2; dy <= 2; dy++) {
         if (!t.valid[cy + dy][cx + dx]) continue;
         const float sid = t.id[cy + dy][cx + dx], svar = t.var[cy + dy][cx + dx];
-        const float diff = sid - d.id;
-        if (1.0f * diff * diff > svar + d.var) {
-          if (removeOcclusions && sid > d.id) numOccluding++;
+        const float diff = sid - did;
+        if (1.0f * diff * diff > svar + dvar) {
+          if (removeOcclusions && sid > did) numOccluding++;
           continue;
         }
         val_sum += (float)t.validity[cy + dy][cx + dx];
@@ -123,57 +170,87 @@ __global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA in, Dept
         sumIvar += ivar;
       }
     if (val_sum < (float)(int)DM_VAL_SUM_MIN_FOR_KEEP) {
-      d.valid = false;
-      d.bl--;
+      r_code[p] = 2;
     } else if (removeOcclusions && numOccluding > numNotOccluding) {
-      d.valid = false;
+      r_code[p] = 3;
     } else {
       sum = sum / sumIvar;
-      d.ids = unzero_f(sum);
-      d.vars = 1.0f / sumIvar;
+      r_ids[p] = unzero_f(sum);
+      r_vars[p] = 1.0f / sumIvar;
+      r_code[p] = 1;
     }
   }
-  hyp_store(out, i, d);
+  __syncthreads();
+  if (!inside) return;
+  const int i = x + y * W;
+  const int code = r_code[threadIdx.x];
+  valid_out[i] = (dvalid && code < 2) ? 1 : 0;
+  if (code == 1) {
+    s.invDepthSmoothed[i] = r_ids[threadIdx.x];
+    s.varianceSmoothed[i] = r_vars[threadIdx.x];
+  } else if (code == 2) {
+    s.blacklisted[i] = s.blacklisted[i] - 1;
+  }
 }
 
 // depthMap::fillDepthHoles (:1317-1400) with buildValIntegralBuffer (:1403-1432) folded in: the reference
 // indexes a per-row prefix sum as if it were a 2-D integral image, which evaluates to
 //   val = sum_{x-2..x+2} validity(row y+2) - sum_{x-2..x+2} validity(row y-3)
 // with rows outside [3, H-3) contributing 0 (never written, zero-initialised).
-__global__ __launch_bounds__(DM_TX * DM_TY) void dm_fill_holes(DepthSoA in, DepthSoA out, const float* __restrict__ maxgrad, int W, int H) {
+// A filled hole writes fields its neighbours' stencils read, so this stage keeps the second copy of the map (in -> out). The
+// few pixels that pass the validity test are gathered (dm_compact_candidates) before the 25-neighbour average with its 50
+// divisions.
+__global__ __launch_bounds__(DM_TX * DM_TY) void dm_fill_holes(DepthSoA in, DepthSoA out, const float* __restrict__ maxgrad, int W, int H,
+                                                               int tiles_x, int tiles_total) {
   __shared__ DmTile t;
-  dm_tile_load(t, in, W, H);
-  const int x = blockIdx.x * DM_TX + threadIdx.x;
-  const int y = blockIdx.y * DM_TY + threadIdx.y;
-  if (x >= W || y >= H) return;
-  const int i = x + y * W;
-  const int cx = threadIdx.x + DM_HALO, cy = threadIdx.y + DM_HALO;
-  Hyp d = hyp_load(in, i);
-  if (y >= 3 && y < H - 3 && x >= 3 && x < W - 2 && !d.valid && !(maxgrad[i] < DM_MIN_ABS_GRAD_DECREASE)) {
+  __shared__ uint8_t list[DM_TX * DM_TY];
+  __shared__ int wave_count[(DM_TX * DM_TY) / 64];
+  __shared__ float r_id[DM_TX * DM_TY];
+  int bx, by;
+  if (!dm_tile_of_block(tiles_x, tiles_total, bx, by)) return;
+  dm_tile_load_at(t, in, W, H, bx, by);
+  const int tx = threadIdx.x & (DM_TX - 1), ty = threadIdx.x / DM_TX;
+  const int x = bx * DM_TX + tx, y = by * DM_TY + ty;
+  const bool inside = (x < W && y < H);
+  const int i = inside ? (x + y * W) : 0;
+  const int cx = tx + DM_HALO, cy = ty + DM_HALO;
+  Hyp d;
+  d.valid = false; d.bl = 0;
+  if (inside) d = hyp_load(in, i);
+  bool fill = false;
+  if (inside && y >= 3 && y < H - 3 && x >= 3 && x < W - 2 && !d.valid && !(maxgrad[i] < DM_MIN_ABS_GRAD_DECREASE)) {
     int val = 0;
     const int ya = y + 2, yb = y - 3;
     if (ya >= 3 && ya < H - 3)
       for (int dx = -2; dx <= 2; dx++) { if (t.valid[cy + 2][cx + dx]) val += t.validity[cy + 2][cx + dx]; }
     if (yb >= 3 && yb < H - 3)
       for (int dx = -2; dx <= 2; dx++) { if (t.valid[cy - 3][cx + dx]) val -= t.validity[cy - 3][cx + dx]; }
-    if ((d.bl >= DM_MIN_BLACKLIST && (float)val > DM_VAL_SUM_MIN_FOR_CREATE) || (float)val > DM_VAL_SUM_MIN_FOR_UNBLACKLIST) {
-      float sumIdepthObs = 0.0f, sumIVarObs = 0.0f;
-      for (int dy = -2; dy < 3; dy++)
-        for (int dx = -2; dx < 3; dx++) {
-          if (!t.valid[cy + dy][cx + dx]) continue;
-          const float v = t.var[cy + dy][cx + dx];
-          sumIdepthObs += t.id[cy + dy][cx + dx] / v;
-          sumIVarObs += 1.0f / v;
-        }
-      float idepthObs = sumIdepthObs / sumIVarObs;
-      d.id = unzero_f(idepthObs);
-      d.var = DM_VAR_RANDOM_INIT_INITIAL;
-      d.validity = 0;
-      d.valid = true;
-      d.bl = 0;
-      d.ids = -1.0f;
-      d.vars = -1.0f;
-    }
+    fill = (d.bl >= DM_MIN_BLACKLIST && (float)val > DM_VAL_SUM_MIN_FOR_CREATE) || (float)val > DM_VAL_SUM_MIN_FOR_UNBLACKLIST;
+  }
+  const int ncand = dm_compact_candidates(fill, list, wave_count);
+  for (int k = threadIdx.x; k < ncand; k += DM_TX * DM_TY) {
+    const int p = list[k];
+    const int px = (p & (DM_TX - 1)) + DM_HALO, py = p / DM_TX + DM_HALO;
+    float sumIdepthObs = 0.0f, sumIVarObs = 0.0f;
+    for (int dy = -2; dy < 3; dy++)
+      for (int dx = -2; dx < 3; dx++) {
+        if (!t.valid[py + dy][px + dx]) continue;
+        const float v = t.var[py + dy][px + dx];
+        sumIdepthObs += t.id[py + dy][px + dx] / v;
+        sumIVarObs += 1.0f / v;
+      }
+    r_id[p] = unzero_f(sumIdepthObs / sumIVarObs);
+  }
+  __syncthreads();
+  if (!inside) return;
+  if (fill) {
+    d.id = r_id[threadIdx.x];
+    d.var = DM_VAR_RANDOM_INIT_INITIAL;
+    d.validity = 0;
+    d.valid = true;
+    d.bl = 0;
+    d.ids = -1.0f;
+    d.vars = -1.0f;
   }
   hyp_store(out, i, d);
 }
@@ -314,10 +391,23 @@ __global__ __launch_bounds__(256) void dm_sum_stage2(const double* __restrict__ 
     ((float*)(out + 2))[0] = num / sum;   // rescaleFactor = numIdepth / sumIdepth (f32)
   }
 }
-__global__ void dm_rescale(DepthSoA s, int n, const float* __restrict__ factor) {
+// every block redoes the second stage of the sum (dm_sum_stage2's fixed tree over the nblocks <= 256 partials: same bits) and
+// rescales its pixels; block 0 leaves the factor at factor_out for the host
+__global__ __launch_bounds__(256) void dm_rescale(DepthSoA s, int n, const double* __restrict__ part, int nblocks, float* __restrict__ factor_out) {
+  __shared__ double sa[256], sc[256];
+  const int t = threadIdx.x;
+  sa[t] = (t < nblocks) ? part[2 * t] : 0.0;
+  sc[t] = (t < nblocks) ? part[2 * t + 1] : 0.0;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off) { sa[t] += sa[t + off]; sc[t] += sc[t + off]; }
+    __syncthreads();
+  }
+  const float f = (float)sc[0] / (float)sa[0];   // rescaleFactor = numIdepth / sumIdepth (f32)
+  if (blockIdx.x == 0 && t == 0) *factor_out = f;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !s.isValid[i]) return;
-  const float f = *factor, f2 = f * f;
+  const float f2 = f * f;
   s.invDepth[i] *= f;
   s.invDepthSmoothed[i] *= f;
   s.variance[i] *= f2;
@@ -333,10 +423,10 @@ __global__ void dm_count_valid(DepthSoA s, int n, int* count) {
 
 // ------------------------------------------------------------------------------------------------
 // depthMap::propagateDepth (:1003-1157). The reference is a serial raster-order scatter whose collisions are
-// resolved by read-modify-write on the target. Here: (1) every valid source computes its candidate and target
-// in parallel; (2) rounds: in round r each target accepts the r-th source (in raster order) that maps to it
-// — selected with atomicMin on the source index — and applies the reference's occlusion / EKF-merge fold.
-// Targets are independent of one another, so this reproduces the serial result exactly.
+// resolved by read-modify-write on the target. Here: (1) dm_prop_project: every valid source computes its candidate and
+// target in parallel and enters the target's bucket; (2) dm_prop_fold: one thread per target applies the reference's
+// occlusion / EKF-merge fold to its sources in ascending source index. Targets are independent of one another, so this
+// reproduces the serial result exactly.
 struct PropArgs {
   DepthSoA src, dst;
   const uint8_t* oldImg;     // old keyframe level-0 image
@@ -345,8 +435,11 @@ struct PropArgs {
   int W, H, sw;
   float R[9], t[3];          // new <- old (SE3poseThisWrtOther of the new keyframe)
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;
-  int* tgt; float* nid; float* nvar; int* nval; int* winner; int* remaining;
+  int* tgt; float* nid; float* nvar; int* nval;
+  int* cnt;      // per target: sources that map to it (zero between calls: dm_prop_fold leaves it so)
+  int* slots;    // per target: the first DM_PROP_SLOTS of them, in arrival order
 };
+#define DM_PROP_SLOTS 4
 
 __global__ void dm_prop_project(PropArgs a) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -356,7 +449,6 @@ __global__ void dm_prop_project(PropArgs a) {
   // wipe the destination map (:1009-1014) and the per-target selection slot
   a.dst.isValid[i] = 0;
   a.dst.blacklisted[i] = 0;
-  a.winner[i] = 0x7fffffff;
   int target = -1;
   float new_idepth = 0.0f, new_var = 0.0f;
   if (a.src.isValid[i]) {
@@ -392,62 +484,78 @@ __global__ void dm_prop_project(PropArgs a) {
   a.nid[i] = new_idepth;
   a.nvar[i] = new_var;
   a.nval[i] = a.src.validity[i];
-}
-
-__global__ void dm_prop_select(PropArgs a, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int t = a.tgt[i];
-  if (t >= 0) atomicMin(&a.winner[t], i);
-}
-
-__global__ void dm_prop_apply(PropArgs a, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int t = a.tgt[i];
-  if (t < 0) return;
-  if (a.winner[t] != i) {   // a lower-indexed source goes first; try again next round
-    atomicAdd(a.remaining, 1);
-    return;
+  if (target >= 0) {   // bucket the source with its target (dm_prop_fold)
+    const int pos = atomicAdd(&a.cnt[target], 1);
+    if (pos < DM_PROP_SLOTS) a.slots[target * DM_PROP_SLOTS + pos] = i;
   }
-  const float new_idepth = a.nid[i], new_var = a.nvar[i];
-  const int src_validity = a.nval[i];
-  bool tvalid = a.dst.isValid[t] != 0;
-  bool skip = false;
+}
+
+// One source folded into its target's hypothesis (:1090-1148): occlusion check, then create or EKF-merge. The target's fields
+// live in registers while its sources are applied one after the other.
+struct PropTarget { float id, var; int validity; bool valid, touched; };
+__device__ __forceinline__ void prop_fold_one(PropTarget& T, float new_idepth, float new_var, int src_validity) {
+  bool tvalid = T.valid;
   if (tvalid) {   // occlusion check (:1090-1107)
-    const float tid = a.dst.invDepth[t];
-    const float diff = tid - new_idepth;
-    if (1.0f * diff * diff > new_var + a.dst.variance[t]) {
-      if (new_idepth < tid) skip = true;
-      else tvalid = false;
+    const float diff = T.id - new_idepth;
+    if (1.0f * diff * diff > new_var + T.var) {
+      if (new_idepth < T.id) return;
+      tvalid = false;
     }
   }
-  if (!skip) {
-    if (!tvalid) {
-      a.dst.invDepth[t] = new_idepth;
-      a.dst.variance[t] = new_var;
-      a.dst.varianceSmoothed[t] = -1.0f;
-      a.dst.invDepthSmoothed[t] = -1.0f;
-      a.dst.validity[t] = src_validity;
-      a.dst.isValid[t] = 1;
-      a.dst.blacklisted[t] = 0;
-    } else {   // EKF merge (:1124-1148)
-      const float tvar = a.dst.variance[t], tid = a.dst.invDepth[t];
-      const float w = new_var / (tvar + new_var);
-      const float merged = w * tid + (1.0f - w) * new_idepth;
-      int mv = src_validity + a.dst.validity[t];
-      if ((float)mv > DM_VALIDITY_COUNTER_MAX + DM_VALIDITY_COUNTER_MAX_VARIABLE) mv = (int)(DM_VALIDITY_COUNTER_MAX + DM_VALIDITY_COUNTER_MAX_VARIABLE);
-      a.dst.invDepth[t] = merged;
-      a.dst.variance[t] = 1.0f / (1.0f / tvar + 1.0f / new_var);
-      a.dst.validity[t] = mv;
-      a.dst.isValid[t] = 1;
-      a.dst.blacklisted[t] = 0;
-      a.dst.invDepthSmoothed[t] = -1.0f;
-      a.dst.varianceSmoothed[t] = -1.0f;
-    }
+  if (!tvalid) {
+    T.id = new_idepth;
+    T.var = new_var;
+    T.validity = src_validity;
+  } else {   // EKF merge (:1124-1148)
+    const float tvar = T.var, tid = T.id;
+    const float w = new_var / (tvar + new_var);
+    const float merged = w * tid + (1.0f - w) * new_idepth;
+    int mv = src_validity + T.validity;
+    if ((float)mv > DM_VALIDITY_COUNTER_MAX + DM_VALIDITY_COUNTER_MAX_VARIABLE) mv = (int)(DM_VALIDITY_COUNTER_MAX + DM_VALIDITY_COUNTER_MAX_VARIABLE);
+    T.id = merged;
+    T.var = 1.0f / (1.0f / tvar + 1.0f / new_var);
+    T.validity = mv;
   }
-  a.tgt[i] = -1;              // this source is done
-  a.winner[t] = 0x7fffffff;   // only the winner of the round resets its target's slot
+  T.valid = true;
+  T.touched = true;
+}
+
+// One thread per TARGET: its sources, sorted by source index — the reference's raster order — are folded one after the other.
+// No rounds, no host in the loop (r02: rounds of atomicMin selection with a host check every four); the serial result exactly
+// (targets are independent). A target with more than DM_PROP_SLOTS sources (a map shrinking by more than 2 x: never seen)
+// finds them by scanning the source list in order — slow for that one thread, still exact.
+__global__ __launch_bounds__(256) void dm_prop_fold(PropArgs a, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int c = a.cnt[t];
+  if (c == 0) return;
+  a.cnt[t] = 0;   // ready for the next propagation
+  PropTarget T;
+  T.id = 0.0f; T.var = 0.0f; T.validity = 0; T.valid = false; T.touched = false;   // the destination map was wiped by dm_prop_project
+  if (c > DM_PROP_SLOTS) {
+    for (int i = 0; i < n; i++)
+      if (a.tgt[i] == t) prop_fold_one(T, a.nid[i], a.nvar[i], a.nval[i]);
+  } else {
+  int s[DM_PROP_SLOTS];
+#pragma unroll
+  for (int k = 0; k < DM_PROP_SLOTS; k++) s[k] = (k < c) ? a.slots[t * DM_PROP_SLOTS + k] : 0x7fffffff;
+  // sorting network for four keys (ascending)
+#define DM_CSWAP(i, j) { const int lo = min(s[i], s[j]), hi = max(s[i], s[j]); s[i] = lo; s[j] = hi; }
+  DM_CSWAP(0, 1) DM_CSWAP(2, 3) DM_CSWAP(0, 2) DM_CSWAP(1, 3) DM_CSWAP(1, 2)
+#undef DM_CSWAP
+#pragma unroll
+  for (int k = 0; k < DM_PROP_SLOTS; k++)
+    if (k < c) prop_fold_one(T, a.nid[s[k]], a.nvar[s[k]], a.nval[s[k]]);
+  }
+  if (T.touched) {
+    a.dst.invDepth[t] = T.id;
+    a.dst.variance[t] = T.var;
+    a.dst.varianceSmoothed[t] = -1.0f;
+    a.dst.invDepthSmoothed[t] = -1.0f;
+    a.dst.validity[t] = T.validity;
+    a.dst.isValid[t] = 1;
+    a.dst.blacklisted[t] = 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
