@@ -585,7 +585,7 @@ def tracked_frame(api, synth, a, dev_index, with_lc=False):
     arith = api.ARITH_FAST if a.arith == "fast" else api.ARITH_EXACT
     n_cand = 8
 
-    def loop(lc_mode):   # None | "thread" | "inline"
+    def loop(lc_mode, fused=False):   # lc_mode: None | "thread" | "inline"
         ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=2, max_frames=2, device=dev_index, arith=arith))
         ctx.keyframe_upload(0, pair["kf_image"]); ctx.keyframe_set_depth(0, pair["depth0"], pair["var0"])
         st = synth.make_depth_state(W, H, 9, pair["kf_image"], pair["idepth_true"])
@@ -616,9 +616,12 @@ def tracked_frame(api, synth, a, dev_index, with_lc=False):
                 its = 0
                 batches[0] = 0
             ctx.frame_upload(f & 1, pair["cur_image"])
-            p, it, _ = ctx.align([0], [f & 1], save_weights=True)
+            if fused:   # ellc_track_frame: the depth stages start behind the alignment on the device
+                _, it, _, _ = ctx.track_frame(f & 1, save_weights=True)
+            else:
+                p, it, _ = ctx.align([0], [f & 1], save_weights=True)
+                ctx.depth_observe(f & 1, p[0]); ctx.depth_fill_holes(); ctx.depth_regularize(False); ctx.depth_update_depth_image()
             its += int(it.sum())
-            ctx.depth_observe(f & 1, p[0]); ctx.depth_fill_holes(); ctx.depth_regularize(False); ctx.depth_update_depth_image()
             if lc_mode and f % 8 == 7:   # pushToArray: join the previous match thread, deep-copy the keyframe, start the next
                 if worker[0] is not None:
                     worker[0].join(); worker[0] = None
@@ -640,9 +643,12 @@ def tracked_frame(api, synth, a, dev_index, with_lc=False):
         return d, its / n, batches[0]
 
     if not with_lc:
-        d, its, _ = loop(None)
+        d, its, _ = loop(None, fused=False)
+        df, _, _ = loop(None, fused=True)
         return {"workload": "C1 loop: upload + pyramid, one FCA alignment (early exit on, saved weights), observe + fill holes + regularise + export, "
-                            "640x480, 4 levels, arith %s" % a.arith, "ms_per_frame": 1e3 * d, "frames_per_s": 1.0 / d, "mean_gn_iterations_per_frame": its}
+                            "640x480, 4 levels, arith %s; ms_per_frame_fused_call: the same through ONE ellc_track_frame call per frame (the depth "
+                            "stages enqueued behind the alignment, matrices built on the device)" % a.arith,
+                "ms_per_frame": 1e3 * d, "frames_per_s": 1.0 / d, "mean_gn_iterations_per_frame": its, "ms_per_frame_fused_call": 1e3 * df}
     dt_, its, nb = loop("thread")
     di_, _, _ = loop("inline")
     return {"workload": "the C1 loop with the loop-closure batch of every 8th frame (%d candidates, ICA, a context of its own): on a host thread beside "

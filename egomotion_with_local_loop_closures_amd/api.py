@@ -221,6 +221,14 @@ class Context:
         self._ck(self._l.ellc_depth_create_keyframe(self.h, new_kf_slot, _p(p), C.byref(f)), "ellc_depth_create_keyframe")
         return f.value
 
+    def track_frame(self, frame_slot, init_pose=None, save_weights=False):
+        """ellc_track_frame: alignment against the depth map's keyframe + observe / fill holes / regularise / export behind it on the
+        device. Returns pose (6,), iters (levels,), weightedPose, seeds percent (of the map before the observation)."""
+        ip = np.zeros(6, np.float32) if init_pose is None else np.ascontiguousarray(init_pose, np.float32).reshape(6)
+        pose = np.zeros(6, np.float32); iters = np.zeros(self.levels, np.int32); w = C.c_float(0); sd = C.c_float(0)
+        self._ck(self._l.ellc_track_frame(self.h, frame_slot, _p(ip), int(save_weights), _p(pose), _p(iters), C.byref(w), C.byref(sd)), "ellc_track_frame")
+        return pose, iters, w.value, sd.value
+
     def depth_seeds(self):
         f = C.c_float(0)
         self._ck(self._l.ellc_depth_seeds(self.h, C.byref(f)), "ellc_depth_seeds")

@@ -155,6 +155,11 @@ struct ellc_ctx {
   int *pr_tgt = nullptr, *pr_cnt = nullptr, *pr_slots = nullptr, *pr_val = nullptr, *pr_remaining = nullptr;   // pr_remaining: a counter word (ellc_depth_seeds)
   float *pr_id = nullptr, *pr_var = nullptr;
   double* red_scratch = nullptr;                            // reductions (rescale factor)
+  // ellc_track_frame: the observation's matrices and the gate, built on the device behind the alignment; a host-visible record
+  void* track_mats_d = nullptr;
+  int* track_gate_d = nullptr;
+  int* track_h = nullptr;
+  int* track_dev_alias = nullptr;
   float Kinv[9], Kmat[9];
 };
 

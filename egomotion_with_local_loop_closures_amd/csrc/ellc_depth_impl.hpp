@@ -11,30 +11,16 @@ namespace {
 
 dim3 grid2(int w, int h, dim3 blk) { return dim3((w + blk.x - 1) / blk.x, (h + blk.y - 1) / blk.y); }
 
-// frame::calculateSE3poseOtherWrtThis (Frame.cpp:376-413) for a frame whose poseWrtOrigin is `pose`
-// against the keyframe (poseWrtOrigin = 0): 12-float [R|t] of Other-w.r.t.-This and This-w.r.t.-Other,
-// plus K*R, K*t of both (f32 products, summed left to right as Eigen's 3x3 f32 product does).
-struct RelMats {
-  float otw[12], two[12];
-  float K_two_r[9], K_two_t[3];
-};
+// the matrices new <- old of a propagation (frame::calculateSE3poseOtherWrtThis, Frame.cpp:376-413): This-w.r.t.-Other of the new keyframe
+struct RelMats { float two[12]; };
 RelMats relative_matrices(const ellc_ctx* c, const float* pose) {
   RelMats m;
   const float zero[6] = {0, 0, 0, 0, 0, 0};
-  float rel[6];
-  concat_origin_f32(zero, pose, rel);   // concatenateOriginPose(other->poseWrtOrigin, poseWrtOrigin, .)
-  exp_se3_f32(rel, m.otw);
-  invert_f32(m.otw, m.two);
-  for (int r = 0; r < 3; r++) {
-    for (int q = 0; q < 3; q++) {
-      float s = 0;
-      for (int k = 0; k < 3; k++) s += c->Kmat[r * 3 + k] * m.two[k * 4 + q];
-      m.K_two_r[r * 3 + q] = s;
-    }
-    float s = 0;
-    for (int k = 0; k < 3; k++) s += c->Kmat[r * 3 + k] * m.two[k * 4 + 3];
-    m.K_two_t[r] = s;
-  }
+  float rel[6], otw[12];
+  concat_origin_f32(zero, pose, rel);
+  exp_se3_f32(rel, otw);
+  invert_f32(otw, m.two);
+  (void)c;
   return m;
 }
 
@@ -46,22 +32,22 @@ ellc_status need_map(ellc_ctx* c) {
   return ELLC_OK;
 }
 
-ellc_status do_regularize(ellc_ctx* c, int removeOcclusions) {
+ellc_status do_regularize(ellc_ctx* c, int removeOcclusions, const int* gate = nullptr) {
   const int W = c->cfg.width, H = c->cfg.height;
   const int tiles_x = (W + DM_TX - 1) / DM_TX, tiles = tiles_x * ((H + DM_TY - 1) / DM_TY);
   // in place, except for the validity flags: they go to the other map's plane, which becomes this map's
   hipLaunchKernelGGL(dm_regularize, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth.isValid, W, H, removeOcclusions,
-                     tiles_x, tiles);
+                     tiles_x, tiles, gate);
   ELLC_HIP(c, hipGetLastError());
   std::swap(c->dm_cur.isValid, c->dm_oth.isValid);
   return ELLC_OK;
 }
 
-ellc_status do_fill_holes(ellc_ctx* c) {
+ellc_status do_fill_holes(ellc_ctx* c, const int* gate = nullptr) {
   const int W = c->cfg.width, H = c->cfg.height;
   const int tiles_x = (W + DM_TX - 1) / DM_TX, tiles = tiles_x * ((H + DM_TY - 1) / DM_TY);
   hipLaunchKernelGGL(dm_fill_holes, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth, c->kf_maxgrad[c->dm_kf_slot], W, H,
-                     tiles_x, tiles);
+                     tiles_x, tiles, gate);
   ELLC_HIP(c, hipGetLastError());
   swap_maps(c);
   return ELLC_OK;
@@ -128,7 +114,7 @@ ellc_status do_propagate(ellc_ctx* c, int new_kf_slot, const float* pose_new_wrt
     if (s != ELLC_OK) return s;
   }
   const int W = c->cfg.width, H = c->cfg.height, n = W * H;
-  const RelMats m = relative_matrices(c, pose_new_wrt_old);
+  const RelMats m = relative_matrices(c, pose_new_wrt_old);   // new <- old
   PropArgs a;
   a.src = c->dm_cur;
   a.dst = c->dm_oth;
@@ -205,13 +191,7 @@ ellc_status ellc_depth_propagate(ellc_ctx* c, int new_kf_slot, const float* pose
   return do_propagate(c, new_kf_slot, pose_new_wrt_old);
 }
 
-ellc_status ellc_depth_observe(ellc_ctx* c, int frame_slot, const float* pose_frame_wrt_kf) {
-  ELLC_ENTER(c);
-  ellc_status s = need_map(c);
-  if (s != ELLC_OK) return s;
-  if (frame_slot < 0 || frame_slot >= c->cfg.max_frames || !pose_frame_wrt_kf) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
-  if (!c->fr_has_image[frame_slot]) return fail(c, ELLC_ERR_NOT_READY, "frame slot has no image");
-  const RelMats m = relative_matrices(c, pose_frame_wrt_kf);   // observeDepthRowParallel :1935
+static ObsArgs observe_args(const ellc_ctx* c, int frame_slot) {
   ObsArgs a;
   a.s = c->dm_cur;
   a.kfImg = c->kf_tab_h[c->dm_kf_slot].img;
@@ -220,18 +200,87 @@ ellc_status ellc_depth_observe(ellc_ctx* c, int frame_slot, const float* pose_fr
   a.W = c->cfg.width; a.H = c->cfg.height; a.sw = c->geom_h[0].sw;
   a.fx = c->cfg.fx; a.fy = c->cfg.fy; a.cx = c->cfg.cx; a.cy = c->cfg.cy;
   a.fxi = c->Kinv[0]; a.cxi = c->Kinv[2]; a.fyi = c->Kinv[4]; a.cyi = c->Kinv[5];
-  for (int r = 0; r < 3; r++) {
-    a.otw_t[r] = m.otw[r * 4 + 3];
-    a.Kt[r] = m.K_two_t[r];
-    a.tt[r] = m.two[r * 4 + 3];
-    for (int q = 0; q < 3; q++) {
-      a.Kr[r * 3 + q] = m.K_two_r[r * 3 + q];
-      a.Rr[r * 3 + q] = m.two[r * 4 + q];
-    }
-  }
-  dim3 blk(32, 8);
-  hipLaunchKernelGGL(dm_observe, grid2(a.W, a.H, blk), blk, 0, c->stream, a);
+  a.mats = nullptr;
+  a.gate = nullptr;
+  return a;
+}
+
+static ellc_status do_observe(ellc_ctx* c, int frame_slot, const float* pose_frame_wrt_kf) {
+  ObsArgs a = observe_args(c, frame_slot);
+  ObsMats m;
+  build_obs_mats(c->Kmat, pose_frame_wrt_kf, m);   // observeDepthRowParallel :1935
+  for (int i = 0; i < 3; i++) { a.otw_t[i] = m.otw_t[i]; a.Kt[i] = m.Kt[i]; a.tt[i] = m.tt[i]; }
+  for (int i = 0; i < 9; i++) { a.Kr[i] = m.Kr[i]; a.Rr[i] = m.Rr[i]; }
+  hipLaunchKernelGGL(dm_observe<false>, dim3((a.W + 31) / 32, (a.H + 7) / 8), dim3(256), 0, c->stream, a);   // a 32 x 8 tile per 256-thread block
   ELLC_HIP(c, hipGetLastError());
+  return ELLC_OK;
+}
+
+ellc_status ellc_depth_observe(ellc_ctx* c, int frame_slot, const float* pose_frame_wrt_kf) {
+  ELLC_ENTER(c);
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  if (frame_slot < 0 || frame_slot >= c->cfg.max_frames || !pose_frame_wrt_kf) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (!c->fr_has_image[frame_slot]) return fail(c, ELLC_ERR_NOT_READY, "frame slot has no image");
+  return do_observe(c, frame_slot, pose_frame_wrt_kf);
+}
+
+// main.cpp:330 + :499-502 for a frame that does not switch the keyframe, as ONE device sequence: the alignment against the depth
+// map's keyframe, then — without the pose travelling to the host and back — observeDepthRowParallel, doRegularization and
+// updateDepthImage with the matrices built on the device from the alignment's result record (dm_track_setup). The host fetches
+// the pose while the depth stages run. seeds_percent: calculate_no_of_Seeds (:1804-1830) of the map BEFORE this observation,
+// which main.cpp writes beside the pose (main.cpp:368-373).
+ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose, int save_weights, float* out_pose, int* out_iters,
+                             float* out_weighted, float* seeds_percent) {
+  ELLC_ENTER(c);
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  if (frame_slot < 0 || frame_slot >= c->cfg.max_frames) return fail(c, ELLC_ERR_BAD_ARG, "bad frame slot");
+  if (!c->fr_has_image[frame_slot]) return fail(c, ELLC_ERR_NOT_READY, "frame slot has no image");
+  if (c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_track_frame: fetch the enqueued batches first");
+  const int n = c->cfg.width * c->cfg.height;
+  if (!c->track_h) {   // host-visible record: [0] valid hypotheses before the observation
+    ELLC_HIP(c, hipHostMalloc((void**)&c->track_h, 64, hipHostMallocDefault));
+    c->host_allocs.push_back(c->track_h);
+    void* da = nullptr;
+    ELLC_HIP(c, hipHostGetDevicePointer(&da, c->track_h, 0));
+    c->track_dev_alias = (int*)da;
+  }
+  hipLaunchKernelGGL(dm_count_valid_block, dim3(1), dim3(1024), 0, c->stream, c->dm_cur.isValid, n, c->track_dev_alias);
+  const int kf = c->dm_kf_slot;
+  s = ellc_align_enqueue(c, 1, &kf, &frame_slot, init_pose, ELLC_MODE_FCA, save_weights);   // one batch: it runs on the main stream
+  if (s != ELLC_OK) return s;
+  const int set = c->inflight[0] / ellc_ctx::MAX_COALESCE;
+  ellc_ctx::BatchSet& bs = c->batch_set[set];
+  if (!bs.launched || bs.stream_idx != 0) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the alignment did not take the main stream");
+  TrackSetupArgs ta;
+  ta.state = bs.state_d;   // the final record lands in state buffer 0 (gn_fused_finish)
+  for (int i = 0; i < 9; i++) ta.Kmat[i] = c->Kmat[i];
+  ta.mats = (ObsMats*)c->track_mats_d;
+  ta.gate = c->track_gate_d;
+  hipLaunchKernelGGL(dm_track_setup, dim3(1), dim3(64), 0, c->stream, ta);
+  ObsArgs a = observe_args(c, frame_slot);
+  a.mats = ta.mats;
+  a.gate = ta.gate;
+  hipLaunchKernelGGL(dm_observe<true>, dim3((a.W + 31) / 32, (a.H + 7) / 8), dim3(256), 0, c->stream, a);
+  ELLC_HIP(c, hipGetLastError());
+  if ((s = do_fill_holes(c, ta.gate)) != ELLC_OK || (s = do_regularize(c, 0, ta.gate)) != ELLC_OK) return s;   // doRegularization(false) :1627-1635
+  if ((s = do_update_depth_image(c)) != ELLC_OK) return s;   // (an unchanged map exports the same planes)
+  // the pose: waits for the alignment only (its event was recorded in front of the depth stages)
+  if (hipEventSynchronize(bs.done) != hipSuccess) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the alignment failed on the device");
+  const bool continued = bs.adaptive && bs.result_h[0].pad == 1;   // the state-driven schedule needs its continuation: the gate stayed closed
+  float pose[6];
+  s = ellc_align_fetch(c, 1, pose, out_iters, out_weighted);   // (runs the continuation when one is needed)
+  if (s != ELLC_OK) return s;
+  if (out_pose) std::memcpy(out_pose, pose, sizeof(pose));
+  if (seeds_percent) *seeds_percent = (float)c->track_h[0] / (float)n * 100;
+  if (continued) {   // rare: the depth stages again, the usual way
+    float pwo[6];
+    const float zero[6] = {0, 0, 0, 0, 0, 0};
+    concat_relative_f32(pose, zero, pwo);
+    if ((s = do_observe(c, frame_slot, pwo)) != ELLC_OK || (s = do_fill_holes(c)) != ELLC_OK || (s = do_regularize(c, 0)) != ELLC_OK) return s;
+    return do_update_depth_image(c);
+  }
   return ELLC_OK;
 }
 
@@ -295,7 +344,7 @@ ellc_status ellc_profile_depth_stage(ellc_ctx* c, int stage, int frame_slot, con
     switch (stage) {
       case 0: return do_regularize(c, 0);
       case 1: return do_fill_holes(c);
-      case 2: return ellc_depth_observe(c, frame_slot, pose_frame_wrt_kf);
+      case 2: return do_observe(c, frame_slot, pose_frame_wrt_kf);
       default: return do_update_depth_image(c);
     }
   };
@@ -317,7 +366,7 @@ ellc_status ellc_depth_seeds(ellc_ctx* c, float* percent) {
   if (s != ELLC_OK) return s;
   const int n = c->cfg.width * c->cfg.height;
   ELLC_HIP(c, hipMemsetAsync(c->pr_remaining, 0, 4, c->stream));
-  hipLaunchKernelGGL(dm_count_valid, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dm_cur, n, c->pr_remaining);
+  hipLaunchKernelGGL(dm_count_valid, dim3(std::min(128, (n + 255) / 256)), dim3(256), 0, c->stream, c->dm_cur, n, c->pr_remaining);
   ELLC_HIP(c, hipGetLastError());
   int cnt = 0;
   ELLC_HIP(c, hipMemcpyAsync(&cnt, c->pr_remaining, 4, hipMemcpyDeviceToHost, c->stream));

@@ -846,6 +846,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   TRY(dev_alloc(c, &c->pr_tgt, n0)); TRY(dev_alloc(c, &c->pr_cnt, n0)); TRY(dev_alloc(c, &c->pr_slots, 4 * n0)); TRY(dev_alloc(c, &c->pr_val, n0));
   TRY(dev_alloc(c, &c->pr_id, n0)); TRY(dev_alloc(c, &c->pr_var, n0)); TRY(dev_alloc(c, &c->pr_remaining, 4));
   TRY(dev_alloc(c, &c->red_scratch, 4096));
+  TRY(dev_alloc(c, (char**)&c->track_mats_d, 256)); TRY(dev_alloc(c, &c->track_gate_d, 4));
   // K and Kinv (EigenInitialization.cpp:20-34): cv 3x3 f32 inverse = f32 cofactors scaled by 1/det in double
   {
     const float K[9] = {cfg->fx, 0, cfg->cx, 0, cfg->fy, cfg->cy, 0, 0, 1};

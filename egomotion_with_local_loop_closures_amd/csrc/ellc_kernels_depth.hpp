@@ -131,7 +131,7 @@ __device__ __forceinline__ int dm_compact_candidates(bool cand, uint8_t* list, i
 // so the map is updated IN PLACE and only the new validity flags go to a plane of their own (valid_out, which the caller then
 // swaps in): 13 bytes read (x the halo) and at most 13 written per pixel instead of 25 + 25 through a second copy of the map.
 __global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA s, uint8_t* __restrict__ valid_out, int W, int H, int removeOcclusions,
-                                                               int tiles_x, int tiles_total) {
+                                                               int tiles_x, int tiles_total, const int* __restrict__ gate) {
   __shared__ DmTile t;
   __shared__ uint8_t list[DM_TX * DM_TY];
   __shared__ int wave_count[(DM_TX * DM_TY) / 64];
@@ -144,7 +144,8 @@ __global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA s, uint8
   const int x = bx * DM_TX + tx, y = by * DM_TY + ty;
   const bool inside = (x < W && y < H);
   const bool dvalid = t.valid[ty + DM_HALO][tx + DM_HALO] != 0;
-  const bool cand = inside && y >= 3 && y < H - 3 && x >= 2 && x < W - 2 && dvalid;
+  const bool open = (gate == nullptr) || (*gate != 0);   // a closed gate (ellc_track_frame): the map passes through unchanged
+  const bool cand = open && inside && y >= 3 && y < H - 3 && x >= 2 && x < W - 2 && dvalid;
   r_code[threadIdx.x] = 0;
   const int ncand = dm_compact_candidates(cand, list, wave_count);
   for (int k = threadIdx.x; k < ncand; k += DM_TX * DM_TY) {
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA s, uint8
 // few pixels that pass the validity test are gathered (dm_compact_candidates) before the 25-neighbour average with its 50
 // divisions.
 __global__ __launch_bounds__(DM_TX * DM_TY) void dm_fill_holes(DepthSoA in, DepthSoA out, const float* __restrict__ maxgrad, int W, int H,
-                                                               int tiles_x, int tiles_total) {
+                                                               int tiles_x, int tiles_total, const int* __restrict__ gate) {
   __shared__ DmTile t;
   __shared__ uint8_t list[DM_TX * DM_TY];
   __shared__ int wave_count[(DM_TX * DM_TY) / 64];
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(DM_TX * DM_TY) void dm_fill_holes(DepthSoA in, Dept
   d.valid = false; d.bl = 0;
   if (inside) d = hyp_load(in, i);
   bool fill = false;
-  if (inside && y >= 3 && y < H - 3 && x >= 3 && x < W - 2 && !d.valid && !(maxgrad[i] < DM_MIN_ABS_GRAD_DECREASE)) {
+  const bool open = (gate == nullptr) || (*gate != 0);
+  if (open && inside && y >= 3 && y < H - 3 && x >= 3 && x < W - 2 && !d.valid && !(maxgrad[i] < DM_MIN_ABS_GRAD_DECREASE)) {
     int val = 0;
     const int ya = y + 2, yb = y - 3;
     if (ya >= 3 && ya < H - 3)
@@ -414,11 +416,20 @@ __global__ __launch_bounds__(256) void dm_rescale(DepthSoA s, int n, const doubl
   s.varianceSmoothed[i] *= f2;
 }
 
-__global__ void dm_count_valid(DepthSoA s, int n, int* count) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool v = (i < n) && s.isValid[i];
-  const unsigned long long m = __ballot(v);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
+// (one atomic per BLOCK of a small grid: an atomic per wave of a pixel-per-lane grid — 4 800 adds to one word at 640x480 —
+// serialises at the memory side and took 55 us)
+__global__ __launch_bounds__(256) void dm_count_valid(DepthSoA s, int n, int* count) {
+  int mine = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) mine += s.isValid[i] ? 1 : 0;
+  __shared__ int part[4];
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) mine += __shfl_xor(mine, m, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = part[0] + part[1] + part[2] + part[3];
+    if (tot) atomicAdd(count, tot);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -571,7 +582,96 @@ struct ObsArgs {
   float otw_t[3];            // SE3poseOtherWrtThis_t of the current frame (keyframe w.r.t. current)
   float Kr[9], Kt[3];        // K_SE3poseThisWrtOther_r / _t
   float Rr[9], tt[3];        // SE3poseThisWrtOther_r / _t
+  const struct ObsMats* mats;   // dm_observe<true>: the five matrices above come from here (device memory, dm_track_setup)
+  const int* gate;              //   and nothing is done unless *gate != 0
 };
+
+// The matrices of frame::calculateSE3poseOtherWrtThis (Frame.cpp:376-413) that observeDepthRow uses, for a frame whose
+// poseWrtOrigin is `pose` against the keyframe (poseWrtOrigin = 0): [R|t] of Other-w.r.t.-This and This-w.r.t.-Other and K R,
+// K t of the latter (f32 products, summed left to right as Eigen's 3x3 f32 product does). Host and device: the tracked-frame
+// call builds them on the device from the alignment's result (dm_track_setup), every other caller on the host.
+struct ObsMats {
+  float otw_t[3], Kr[9], Kt[3], Rr[9], tt[3];
+};
+// (device: exp / log as real function calls — inlined, the setup kernel is 15 000 instructions of straight-line code that one
+// lane executes once: it ran for 19 us, most of it instruction fetch)
+__host__ __device__ __attribute__((noinline)) void obs_exp_se3_f32(const float* pose, float* S) { exp_se3_f32(pose, S); }
+__host__ __device__ __attribute__((noinline)) void obs_log_se3_f32(const float* S, float* pose) { log_se3_f32(S, pose); }
+ELLC_HD void build_obs_mats(const float* Kmat, const float* pose, ObsMats& m) {
+  float rel[6], otw[12], two[12];
+  {
+    // concatenateOriginPose(other->poseWrtOrigin = 0, poseWrtOrigin, .) = log(exp(0) exp(pose)^-1): exp(0) is the identity and a
+    // product with it is exact in compose_f32, so this is concat_origin_f32(zero, pose, rel) bit for bit, two exps shorter
+    float B[12], Bi[12];
+    obs_exp_se3_f32(pose, B);
+    invert_f32(B, Bi);
+    obs_log_se3_f32(Bi, rel);
+  }
+  obs_exp_se3_f32(rel, otw);
+  invert_f32(otw, two);
+  for (int r = 0; r < 3; r++) {
+    for (int q = 0; q < 3; q++) {
+      float sum = 0;
+      for (int k = 0; k < 3; k++) sum += Kmat[r * 3 + k] * two[k * 4 + q];
+      m.Kr[r * 3 + q] = sum;
+      m.Rr[r * 3 + q] = two[r * 4 + q];
+    }
+    float sum = 0;
+    for (int k = 0; k < 3; k++) sum += Kmat[r * 3 + k] * two[k * 4 + 3];
+    m.Kt[r] = sum;
+    m.tt[r] = two[r * 4 + 3];
+    m.otw_t[r] = otw[r * 4 + 3];
+  }
+}
+
+// Tracked-frame call (ellc_track_frame): behind the alignment's last kernel, one thread turns the pose it left in the state
+// record into poseWrtOrigin = concatenateRelativePose(pose, 0) (ImageFunc.cpp:305; the keyframe's own poseWrtOrigin is zero) and
+// the observation's matrices. gate = 1 when the alignment's schedule has ended (a state-driven schedule may need a continuation
+// that only the host can start: the depth stages behind this kernel then do nothing and the host runs them afterwards).
+struct TrackSetupArgs {
+  const AlignState* state;   // the alignment's final record (state buffer 0)
+  float Kmat[9];
+  ObsMats* mats;
+  int* gate;
+};
+__global__ __launch_bounds__(64) void dm_track_setup(TrackSetupArgs a) {   // (one wave: the compiler may then keep everything in registers)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const AlignState& st = *a.state;
+  float pose[6], pwo[6], E[12];
+  for (int i = 0; i < 6; i++) pose[i] = st.pose[i];
+  obs_exp_se3_f32(pose, E);     // concat_relative_f32(pose, 0, pwo) = log(exp(pose) exp(0)): the product with the identity is exact
+  obs_log_se3_f32(E, pwo);
+  ObsMats m;
+  build_obs_mats(a.Kmat, pwo, m);
+  *a.mats = m;
+  *a.gate = (st.cur_level < 0) ? 1 : 0;
+}
+// number of valid hypotheses, then its copy into host-visible memory (the seeds figure main.cpp writes beside the pose, counted
+// BEFORE the frame's observation)
+// (one block: a single launch in front of the alignment instead of clear + count + copy)
+__global__ __launch_bounds__(1024) void dm_count_valid_block(const uint8_t* __restrict__ valid, int n, int* __restrict__ host_visible) {
+  int mine = 0;
+  const int n16 = n >> 4;
+  const uint4* v16 = (const uint4*)valid;   // plane buffers are 256-byte aligned
+  for (int i = threadIdx.x; i < n16; i += 1024) {
+    const uint4 w = v16[i];
+    const unsigned q[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)   // non-zero bytes of a word
+      mine += ((q[k] & 0xffu) != 0) + ((q[k] & 0xff00u) != 0) + ((q[k] & 0xff0000u) != 0) + ((q[k] & 0xff000000u) != 0);
+  }
+  for (int i = (n16 << 4) + threadIdx.x; i < n; i += 1024) mine += valid[i] ? 1 : 0;
+  __shared__ int part[16];
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) mine += __shfl_xor(mine, m, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < 16; w++) tot += part[w];
+    *host_visible = tot;
+  }
+}
 
 __device__ __forceinline__ float dot3f(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 
@@ -686,6 +786,9 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
   int loopCBest = -1, loopCSecond = -1;
   // the walk is bounded: the segment is at most MAX_EPL_LENGTH_CROP + padding long and inside the image
   const int loopCap = W + H;
+#ifdef ELLC_OBS_NOUNROLL
+#pragma unroll 1
+#endif
   while ((((incx < 0) == (cpx > pClose[0]) && (incy < 0) == (cpy > pClose[1])) || loopCounter == 0) && loopCounter < loopCap) {
     val_cp_p2 = tap_plain(a.curImg, a.sw, W, H, cpx + 2 * incx, cpy + 2 * incy);
     float ee = 0;
@@ -802,22 +905,35 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
   return best_match_err;
 }
 
-__global__ __launch_bounds__(256) void dm_observe(ObsArgs a) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x < 3 || x >= a.W - 3 || y < 3 || y >= a.H - 3) return;
-  const int idx = x + y * a.W;
-  Hyp t = hyp_load(a.s, idx);
-  const bool hasHypothesis = t.valid;
-  const float mg = a.kfMaxGrad[idx];
-  if (hasHypothesis && mg < DM_MIN_ABS_GRAD_DECREASE) {
-    a.s.isValid[idx] = 0;
-    return;
+// How long will the epipolar walk of do_line_stereo be for this pixel? A cheap restatement of its geometry (no taps, not bit
+// for bit: it only ORDERS the work, every candidate still runs do_line_stereo itself): 0 when the walk will not start.
+__device__ __forceinline__ float line_stereo_walk_estimate(const ObsArgs& a, float u, float v, float min_idepth, float prior_idepth, float max_idepth) {
+  const float KinvP[3] = {a.fxi * u + a.cxi, a.fyi * v + a.cyi, 1.0f};
+  const float pInf[3] = {dot3f(a.Kr, KinvP), dot3f(a.Kr + 3, KinvP), dot3f(a.Kr + 6, KinvP)};
+  const float rescaleFactor = (pInf[2] / prior_idepth + a.Kt[2]) * prior_idepth;
+  if (!(rescaleFactor > 0.7f && rescaleFactor < 1.4f)) return 0.0f;
+  float pcz = pInf[2] + a.Kt[2] * max_idepth;
+  if (pcz < 0.001f) {
+    max_idepth = (0.001f - pInf[2]) / a.Kt[2];
+    pcz = pInf[2] + a.Kt[2] * max_idepth;
   }
-  if (mg < DM_MIN_ABS_GRAD_CREATE || t.bl < DM_MIN_BLACKLIST) return;
-  float epx, epy;
-  if (!make_and_check_epl(a, x, y, epx, epy)) return;   // create: -1 / update: -5, no state change
-  if (!hasHypothesis) {
+  const float pfz = pInf[2] + a.Kt[2] * min_idepth;
+  if (pfz < 0.001f || max_idepth < min_idepth) return 0.0f;
+  const float cx = (pInf[0] + a.Kt[0] * max_idepth) / pcz, cy = (pInf[1] + a.Kt[1] * max_idepth) / pcz;
+  const float fx = (pInf[0] + a.Kt[0] * min_idepth) / pfz, fy = (pInf[1] + a.Kt[1] * min_idepth) / pfz;
+  const float len = sqrtf((cx - fx) * (cx - fx) + (cy - fy) * (cy - fy));
+  if (!(len > 0.0f) || isinf(len)) return 0.0f;
+  const float Bd = DM_SAMPLE_POINT_TO_BORDER;
+  if (fx <= Bd || fx >= (float)a.W - Bd || fy <= Bd || fy >= (float)a.H - Bd) return 0.0f;
+  return fminf(fmaxf(len, DM_MIN_EPL_LENGTH_CROP), DM_MAX_EPL_LENGTH_CROP) + 2.0f;
+}
+
+// observeDepthRow for one pixel whose epipolar direction (epx, epy) passed makeAndCheckEPL: observeDepthCreate (:267-308) or
+// observeDepthUpdate (:888-999)
+__device__ __forceinline__ void observe_pixel(const ObsArgs& a, int x, int y, int idx, float epx, float epy) {
+  Hyp t = hyp_load(a.s, idx);
+  const float mg = a.kfMaxGrad[idx];
+  if (!t.valid) {
     // observeDepthCreate
     float rid = 0.0f, rvar = 0.0f;
     const float error = do_line_stereo(a, (float)x, (float)y, epx, epy, 0.0f, 1.0f, 1.0f / DM_MIN_DEPTH, rid, rvar);
@@ -873,6 +989,85 @@ __global__ __launch_bounds__(256) void dm_observe(ObsArgs a) {
     const float cap = DM_VALIDITY_COUNTER_MAX + mg * (DM_VALIDITY_COUNTER_MAX_VARIABLE) / 255.0f;
     if ((float)t.validity > cap) t.validity = (int)cap;
     hyp_store(a.s, idx, t);
+  }
+}
+
+// Two phases per 32 x 8 tile. Phase 1, one lane per pixel: the cheap tests of observeDepthRow (:191-263) and makeAndCheckEPL;
+// the pixels that go on to the line stereo are entered in a list ordered by the estimated LENGTH of their walk. Phase 2: the
+// waves take consecutive list entries, so lanes of one wave walk about equally far. (Pixel per lane all the way, a wave ran
+// as long as its longest walk — a depth creation spans the whole inverse-depth range, ~30 steps, an update a few — with a
+// third of its lanes active: 19.7 M wave instructions per launch in r02, 47 us.) The pixels are independent: same results.
+#define DM_OBS_BUCKETS 4
+__device__ __forceinline__ void observe_tile(const ObsArgs& a) {
+  __shared__ uint8_t list[256];
+  __shared__ float s_epx[256], s_epy[256];
+  __shared__ int counts[DM_OBS_BUCKETS][4];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int x = blockIdx.x * 32 + tx, y = blockIdx.y * 8 + ty;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int bucket = -1;
+  if (x >= 3 && x < a.W - 3 && y >= 3 && y < a.H - 3) {
+    const int idx = x + y * a.W;
+    const bool hasHypothesis = a.s.isValid[idx] != 0;
+    const float mg = a.kfMaxGrad[idx];
+    if (hasHypothesis && mg < DM_MIN_ABS_GRAD_DECREASE) {
+      a.s.isValid[idx] = 0;
+    } else if (!(mg < DM_MIN_ABS_GRAD_CREATE || a.s.blacklisted[idx] < DM_MIN_BLACKLIST)) {
+      float epx, epy;
+      if (make_and_check_epl(a, x, y, epx, epy)) {   // (else create: -1 / update: -5, no state change)
+        s_epx[threadIdx.x] = epx;
+        s_epy[threadIdx.x] = epy;
+        float est;
+        if (!hasHypothesis) {
+          est = line_stereo_walk_estimate(a, (float)x, (float)y, 0.0f, 1.0f, 1.0f / DM_MIN_DEPTH);
+        } else {
+          const float ids = a.s.invDepthSmoothed[idx], sv = sqrtf(a.s.varianceSmoothed[idx]);
+          est = line_stereo_walk_estimate(a, (float)x, (float)y, fmaxf(ids - sv * DM_STEREO_EPL_VAR_FAC, 0.0f), ids,
+                                          fminf(ids + sv * DM_STEREO_EPL_VAR_FAC, 1 / DM_MIN_DEPTH));
+        }
+        bucket = est >= 24.0f ? 0 : (est >= 12.0f ? 1 : (est >= 6.0f ? 2 : 3));   // NaN: bucket 3
+      }
+    }
+  }
+  unsigned long long mine = 0ull;
+#pragma unroll
+  for (int b = 0; b < DM_OBS_BUCKETS; b++) {
+    const unsigned long long m = __ballot(bucket == b);
+    if (lane == 0) counts[b][wave] = __popcll(m);
+    if (bucket == b) mine = m;
+  }
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int b = 0; b < DM_OBS_BUCKETS; b++)
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const int c = counts[b][w];
+      if (b < bucket || (b == bucket && w < wave)) base += c;
+      total += c;
+    }
+  if (bucket >= 0) list[base + __popcll(mine & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = (uint8_t)threadIdx.x;
+  __syncthreads();
+  for (int k = threadIdx.x; k < total; k += 256) {
+    const int p = list[k];
+    const int px = blockIdx.x * 32 + (p & 31), py = blockIdx.y * 8 + (p >> 5);
+    observe_pixel(a, px, py, px + py * a.W, s_epx[p], s_epy[p]);
+  }
+}
+// DEV: the tracked-frame call — matrices from device memory (dm_track_setup), nothing done while the gate is closed
+template <bool DEV>
+__global__ __launch_bounds__(256) void dm_observe(ObsArgs a) {
+  if (DEV) {
+    if (*a.gate == 0) return;
+    ObsArgs b = a;
+    const ObsMats& m = *a.mats;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { b.otw_t[i] = m.otw_t[i]; b.Kt[i] = m.Kt[i]; b.tt[i] = m.tt[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { b.Kr[i] = m.Kr[i]; b.Rr[i] = m.Rr[i]; }
+    observe_tile(b);
+  } else {
+    observe_tile(a);
   }
 }
 

@@ -8,6 +8,9 @@
 //                    keyframe switch (ImageFunc.cpp:73-87, Frame.cpp:697-871); --replicate DIR reads them back (:58-66)
 // --init-poses FILE  FLAG_INITIALIZE_NONZERO_POSE (main.cpp:207-225): one line "frameNo wx wy wz vx vy vz" (world pose,
 //                    the so3poses7.txt of the rotation-averaging step) per tracked frame; supplies the initial rotation
+// --fused            tracked frames through ellc_track_frame: the depth stages are enqueued behind the alignment and read its pose on the
+//                    device (same files; measured r03: 0.305 ms per frame against 0.282 for the separate calls — building the
+//                    observation's matrices takes one lane 14 us of dependent f64 arithmetic, more than the host round trip it replaces)
 // --bgr              the input holds decoded full-size BGR frames (4W x 4H x 3 bytes each): grey conversion, undistortion with
 //                    the reference's hard-coded camera (ExternVariable.h:53-62, scaled to the input size) and the 1/4
 //                    resize run on the device (Frame.cpp:45-75); --no-undistort = FLAG_DO_UNDISTORTION off
@@ -40,7 +43,7 @@ int main(int argc, char** argv) {
   bool lc = false;
   int levels = 4;
   std::string save_mats, replicate, init_poses;
-  bool bgr = false, undistort = true;
+  bool bgr = false, undistort = true, no_fused = true;
   int world = 1, rank = 0, device = 0, comm_port = 0;
   std::string comm_id_file;
   for (int i = 6; i < argc; i++) {
@@ -51,6 +54,8 @@ int main(int argc, char** argv) {
     else if (a == "--init-poses" && i + 1 < argc) init_poses = argv[++i];
     else if (a == "--bgr") bgr = true;
     else if (a == "--no-undistort") undistort = false;
+    else if (a == "--fused") no_fused = false;   // tracked frames through ellc_track_frame (alignment + depth stages as one device sequence)
+    else if (a == "--no-fused") no_fused = true;   // (default) every stage as its own call: GetImagePoseEstimate, then observe / regularise / export
     else if (a == "--world" && i + 1 < argc) world = std::atoi(argv[++i]);
     else if (a == "--rank" && i + 1 < argc) rank = std::atoi(argv[++i]);
     else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
@@ -140,8 +145,16 @@ int main(int argc, char** argv) {
         initialize_pose_file >> temp_frame_no >> initial_pose[0] >> initial_pose[1] >> initial_pose[2] >> initial_pose[3] >> initial_pose[4] >> initial_pose[5];
         if (!initialize_pose_file) { std::fprintf(stderr, "initial-pose file ends before frame %d\n", frame_counter); return -1; }
       }
-      GetImagePoseEstimate(activeKeyFrame, cur, frame_counter, &currentDepthMap, tminus1, have_init ? initial_pose : nullptr);   // main.cpp:330
-      const float seeds_num = currentDepthMap.calculate_no_of_Seeds();
+      // a frame that switches the keyframe (main.cpp:404) is aligned on its own; with --fused every other frame goes through the
+      // fused call: alignment + observe + regularise + export as one device sequence (TrackFrameAndObserve)
+      const bool kf_switch = (frame_counter % KEYFRAME_PROPAGATE_INTERVAL == 0) || (frame_counter == max_frame_counter);
+      float seeds_num = 0;
+      if (kf_switch || no_fused) {
+        GetImagePoseEstimate(activeKeyFrame, cur, frame_counter, &currentDepthMap, tminus1, have_init ? initial_pose : nullptr);   // main.cpp:330
+        seeds_num = currentDepthMap.calculate_no_of_Seeds();
+      } else {
+        TrackFrameAndObserve(activeKeyFrame, cur, &currentDepthMap, tminus1, have_init ? initial_pose : nullptr, &seeds_num);
+      }
       const int id = cur->frameId + rt.BATCH_START_ID - 1, kid = activeKeyFrame->frameId + rt.BATCH_START_ID - 1;
       pose_file_orig << id << " " << kid << " " << cur->poseWrtWorld[0] << " " << cur->poseWrtWorld[1] << " " << cur->poseWrtWorld[2] << " "
                      << cur->poseWrtWorld[3] << " " << cur->poseWrtWorld[4] << " " << cur->poseWrtWorld[5] << " " << activeKeyFrame->rescaleFactor
@@ -149,8 +162,8 @@ int main(int argc, char** argv) {
       match_file << id << " " << kid << " " << cur->poseWrtOrigin[0] << " " << cur->poseWrtOrigin[1] << " " << cur->poseWrtOrigin[2] << " "
                  << cur->poseWrtOrigin[3] << " " << cur->poseWrtOrigin[4] << " " << cur->poseWrtOrigin[5] << " " << activeKeyFrame->rescaleFactor
                  << " " << seeds_num << " " << "0" << " " << "0" << " " << "0" << "\n";
-      currentDepthMap.formDepthMap(cur);   // main.cpp:391
-      if ((frame_counter % KEYFRAME_PROPAGATE_INTERVAL == 0) || (frame_counter == max_frame_counter)) {   // main.cpp:404
+      if (kf_switch || no_fused) currentDepthMap.formDepthMap(cur);   // main.cpp:391
+      if (kf_switch) {   // main.cpp:404
         if (lc) activeKeyFrame->finaliseWeights();
         currentDepthMap.finaliseKeyframe();
         if (lc) globalOptimizeLoop->pushToArray(activeKeyFrame, &currentDepthMap);   // main.cpp:462
@@ -159,10 +172,12 @@ int main(int argc, char** argv) {
         frameptr_vector.erase(frameptr_vector.begin(), frameptr_vector.end() - 1);   // keep only the most recent frame
         continue;
       }
-      currentDepthMap.updateKeyFrame();   // main.cpp:499-502
-      currentDepthMap.observeDepthRowParallel();
-      currentDepthMap.doRegularization();
-      currentDepthMap.updateDepthImage();
+      if (no_fused) {
+        currentDepthMap.updateKeyFrame();   // main.cpp:499-502
+        currentDepthMap.observeDepthRowParallel();
+        currentDepthMap.doRegularization();
+        currentDepthMap.updateDepthImage();
+      }
     }
     if (globalOptimizeLoop) globalOptimizeLoop->join_all();   // the last keyframe's match thread (t_group.join_all)
   } catch (const std::exception& e) {

@@ -242,6 +242,16 @@ ellc_status ellc_depth_update_depth_image(ellc_ctx* ctx);
  * rescale, export; the new slot becomes the depth map's keyframe. */
 ellc_status ellc_depth_create_keyframe(ellc_ctx* ctx, int new_kf_slot, const float* pose_new_wrt_old, float* rescale_factor);
 ellc_status ellc_depth_seeds(ellc_ctx* ctx, float* percent);              /* calculate_no_of_Seeds :1804-1830 */
+/* One tracked frame that does not switch the keyframe, main.cpp:330 + :499-502, as ONE device sequence: GetImagePoseEstimate
+ * (ImageFunc.cpp:49-315; FCA) of frame slot `frame_slot` against the depth map's keyframe from init_pose, then — behind it on the
+ * device, the pose never travelling to the host and back in between — observeDepthRowParallel with poseWrtOrigin =
+ * concatenateRelativePose(pose, 0) (ImageFunc.cpp:305), doRegularization(false) and updateDepthImage. The call returns once the
+ * POSE is there; the depth stages are still running (every later call is ordered behind them). seeds_percent (may be NULL):
+ * calculate_no_of_Seeds of the map BEFORE this frame's observation (what main.cpp:368-373 writes beside the pose). Results are
+ * those of ellc_align + ellc_depth_seeds + ellc_depth_observe + ellc_depth_fill_holes + ellc_depth_regularize(0) +
+ * ellc_depth_update_depth_image. */
+ellc_status ellc_track_frame(ellc_ctx* ctx, int frame_slot, const float* init_pose, int save_weights, float* out_pose, int* out_iters,
+                             float* out_weighted, float* seeds_percent);
 
 /* ---- multi-GPU: the loop-closure batch sharded over the ranks of one node, one gather of the results ------
  * The batch loop of globalOptimize::findMatchParallel (GlobalOptimize.cpp:480-610) runs B independent alignments; rank r of

@@ -286,9 +286,9 @@ class PixelWisePyramid {
 // ImageFunc.cpp:49-315. The level / iteration loops run on the device (ellc_align); weights of the last executed
 // iteration of every level are saved into the keyframe when the runtime is in LC mode and the call does not come
 // from loop closure (ImageFunc.cpp:280-288).
-inline std::vector<float> GetImagePoseEstimate(frame* prev_frame, frame* current_frame, int /*frame_num*/, depthMap* /*currDepthMap*/,
-                                               frame* tminus1_prev_frame, float* initial_pose_estimate, bool fromLoopClosure = false,
-                                               bool /*homo*/ = false) {
+namespace detail {
+// ImageFunc.cpp:58-131: the text checkpoints at a keyframe switch and the initial relative pose of the alignment
+inline void initial_pose_estimate(frame* prev_frame, frame* current_frame, frame* tminus1_prev_frame, float* initial_pose_estimate, bool fromLoopClosure, float* pose) {
   Runtime* rt = prev_frame->rt;
   if (prev_frame->kf_slot < 0) throw std::runtime_error("GetImagePoseEstimate: prev_frame is not a keyframe");
   const bool kf_switch = !fromLoopClosure && (current_frame->frameId % rt->KEYFRAME_PROPAGATE_INTERVAL == 0);
@@ -302,7 +302,6 @@ inline std::vector<float> GetImagePoseEstimate(frame* prev_frame, frame* current
     prev_frame->saveMatAsText("Depth_pyr0", rt->SAVED_MATS_PATH);
     prev_frame->saveArrayAsText("DepthVarArr_pyr0", rt->SAVED_MATS_PATH, 0);
   }
-  float pose[6];
   prev_frame->concatenateOriginPose(tminus1_prev_frame->poseWrtWorld, prev_frame->poseWrtWorld, pose);   // :106
   if (initial_pose_estimate) {
     // FLAG_INITIALIZE_NONZERO_POSE (:109-131): the given world pose (so3poses7.txt) is converted to a pose w.r.t. the
@@ -313,6 +312,15 @@ inline std::vector<float> GetImagePoseEstimate(frame* prev_frame, frame* current
     pose[1] = from_file[1];
     pose[2] = from_file[2];
   }
+}
+}  // namespace detail
+
+inline std::vector<float> GetImagePoseEstimate(frame* prev_frame, frame* current_frame, int /*frame_num*/, depthMap* /*currDepthMap*/,
+                                               frame* tminus1_prev_frame, float* initial_pose_estimate, bool fromLoopClosure = false,
+                                               bool /*homo*/ = false) {
+  Runtime* rt = prev_frame->rt;
+  float pose[6];
+  detail::initial_pose_estimate(prev_frame, current_frame, tminus1_prev_frame, initial_pose_estimate, fromLoopClosure, pose);
   const int save = (rt->FLAG_DO_LOOP_CLOSURE && !fromLoopClosure) ? 1 : 0;
   float out[6];
   rt->check(ellc_align(rt->ctx, 1, &prev_frame->kf_slot, &current_frame->slot, pose, fromLoopClosure ? ELLC_MODE_ICA : ELLC_MODE_FCA, save, out,
@@ -320,6 +328,27 @@ inline std::vector<float> GetImagePoseEstimate(frame* prev_frame, frame* current
   if (save) for (int l = 0; l < rt->cfg.levels; l++) prev_frame->numWeightsAdded[l]++;
   current_frame->calculatePoseWrtOrigin(prev_frame, out);   // :305
   current_frame->calculatePoseWrtWorld(prev_frame, out);    // :306
+  return std::vector<float>(out, out + 6);
+}
+
+// A tracked frame that does not switch the keyframe — main.cpp:330 (GetImagePoseEstimate), :368 (calculate_no_of_Seeds) and
+// :499-502 (updateKeyFrame, observeDepthRowParallel, doRegularization, updateDepthImage) — as ONE device sequence
+// (ellc_track_frame): the depth stages start behind the alignment's last kernel without waiting for the host. prev_frame must be
+// the depth map's keyframe. *seeds_num: the seeds figure of the map before this frame's observation, as main.cpp writes it.
+inline std::vector<float> TrackFrameAndObserve(frame* prev_frame, frame* current_frame, depthMap* currDepthMap, frame* tminus1_prev_frame,
+                                               float* initial_pose_estimate, float* seeds_num) {
+  Runtime* rt = prev_frame->rt;
+  if (currDepthMap->keyFrame != prev_frame) throw std::runtime_error("TrackFrameAndObserve: prev_frame is not the depth map's keyframe");
+  float pose[6];
+  detail::initial_pose_estimate(prev_frame, current_frame, tminus1_prev_frame, initial_pose_estimate, false, pose);
+  const int save = rt->FLAG_DO_LOOP_CLOSURE ? 1 : 0;
+  float out[6], seeds = 0;
+  rt->check(ellc_track_frame(rt->ctx, current_frame->slot, pose, save, out, nullptr, nullptr, &seeds), "ellc_track_frame");
+  if (save) for (int l = 0; l < rt->cfg.levels; l++) prev_frame->numWeightsAdded[l]++;
+  current_frame->calculatePoseWrtOrigin(prev_frame, out);   // :305
+  current_frame->calculatePoseWrtWorld(prev_frame, out);    // :306
+  if (seeds_num) *seeds_num = seeds;
+  currDepthMap->formDepthMap(current_frame);   // main.cpp:391 (bookkeeping only beyond the first frame)
   return std::vector<float>(out, out + 6);
 }
 

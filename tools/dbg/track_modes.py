@@ -1,0 +1,10 @@
+#!/usr/bin/env python3
+"""The tracked-frame loop of bench.py alone: fused call vs separate calls, with / without the loop-closure batch."""
+import json, os, sys, argparse
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from egomotion_with_local_loop_closures_amd import api, synth  # noqa: E402
+a = argparse.Namespace(arith=sys.argv[1] if len(sys.argv) > 1 else "fast")
+print(json.dumps({k: v for k, v in bench.tracked_frame(api, synth, a, 0).items() if k != "workload"}))
+print(json.dumps({k: v for k, v in bench.tracked_frame(api, synth, a, 0, with_lc=True).items() if k != "workload"}))
