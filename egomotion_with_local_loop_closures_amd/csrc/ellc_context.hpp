@@ -96,6 +96,7 @@ struct ellc_ctx {
     bool joined = true;                             // the main stream already waits for `done`
     int mode = 0, save_weights = 0;
     bool adaptive = false;                          // the group (one batch) runs the state-driven schedule (gn_fca_adaptive)
+    int adaptive_first = 0;                         //   whose first graph holds this many launches
     bool resolved = true;                           // `done` has been waited for and the continuation, if one was needed, has run
   } batch_set[SETS];
   hipStream_t batch_stream[STREAMS] = {nullptr, nullptr, nullptr};   // [0] = stream; the others are created when first needed
@@ -130,6 +131,8 @@ struct ellc_ctx {
   double win_min_px = 24.0;             //   on levels with at least this many pixels per thread of the launch; ELLC_WIN_MIN (diag)
   bool use_adaptive = true;             // early-exit FCA schedules are state-driven (gn_fca_adaptive); ELLC_NO_ADAPTIVE=1 (diag) turns it off
   int adaptive_max_batch = 2;           //   for batches of at most this many alignments; ELLC_ADAPTIVE_MAX_BATCH (diag)
+  int adaptive_hint = 0;                //   launches of the next first graph, from what the previous call needed (0: none yet)
+  int cur_adaptive_first = 0;           //   launches of the first graph of the schedule being enqueued / continued
   int adaptive_first_override = 0;      //   launches of the first graph; ELLC_ADAPTIVE_FIRST (diag)
   bool pipe = true;             // software-pipelined record loads in the fused FCA kernel (ELLC_PIPE=0 disables; r01: -10 % per launch at
                                 // 1280x960 dense where the records stream from HBM, neutral at 640x480 semi-dense)
@@ -141,6 +144,10 @@ struct ellc_ctx {
   uint8_t* upload_stage[UPLOAD_RING] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t upload_done[UPLOAD_RING] = {nullptr, nullptr, nullptr, nullptr};
   int upload_cursor = 0;
+  // frame uploads run on a stream of their own (created by the first ellc_frame_upload): per frame slot the event of its last
+  // main-stream reader (mark_frame_use) and of its last upload
+  hipStream_t upload_stream = nullptr;
+  std::vector<hipEvent_t> fr_use_ev, fr_ready_ev;
   // frame ingest (ellc_ingest_configure): fixed-point undistortion map of the 2x2 source pixels of every output pixel
   void* ingest_map = nullptr;
   uint8_t* ingest_bgr = nullptr;    // staging for one full-size BGR frame
@@ -190,5 +197,6 @@ ellc_status run_prep(ellc_ctx* c, int n_unique, int need);
 ellc_status build_depth_pyramid(ellc_ctx* c, int slot);
 ellc_status build_depth_pyramid_from(ellc_ctx* c, int slot, int first_level);
 ellc_status build_maxgrad(ellc_ctx* c, bool is_kf, int slot);
-ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img);
+ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img, hipStream_t st);
+ellc_status mark_frame_use(ellc_ctx* c, int slot);
 }  // namespace ellc

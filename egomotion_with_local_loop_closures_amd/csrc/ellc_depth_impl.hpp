@@ -213,7 +213,7 @@ static ellc_status do_observe(ellc_ctx* c, int frame_slot, const float* pose_fra
   for (int i = 0; i < 9; i++) { a.Kr[i] = m.Kr[i]; a.Rr[i] = m.Rr[i]; }
   hipLaunchKernelGGL(dm_observe<false>, dim3((a.W + 31) / 32, (a.H + 7) / 8), dim3(256), 0, c->stream, a);   // a 32 x 8 tile per 256-thread block
   ELLC_HIP(c, hipGetLastError());
-  return ELLC_OK;
+  return mark_frame_use(c, frame_slot);
 }
 
 ellc_status ellc_depth_observe(ellc_ctx* c, int frame_slot, const float* pose_frame_wrt_kf) {
@@ -264,6 +264,7 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
   a.gate = ta.gate;
   hipLaunchKernelGGL(dm_observe<true>, dim3((a.W + 31) / 32, (a.H + 7) / 8), dim3(256), 0, c->stream, a);
   ELLC_HIP(c, hipGetLastError());
+  if ((s = mark_frame_use(c, frame_slot)) != ELLC_OK) return s;
   if ((s = do_fill_holes(c, ta.gate)) != ELLC_OK || (s = do_regularize(c, 0, ta.gate)) != ELLC_OK) return s;   // doRegularization(false) :1627-1635
   if ((s = do_update_depth_image(c)) != ELLC_OK) return s;   // (an unchanged map exports the same planes)
   // the pose: waits for the alignment only (its event was recorded in front of the depth stages)

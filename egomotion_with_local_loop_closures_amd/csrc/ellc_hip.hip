@@ -132,7 +132,7 @@ int choose_nblk(const ellc_ctx* c, int level, int B) {
 static dim3 grid2d(int w, int h, dim3 blk) { return dim3((w + blk.x - 1) / blk.x, (h + blk.y - 1) / blk.y); }
 
 // the u8 pyramid below level 0 of `img[]`: one launch per three levels (pyr_down_chain_u8)
-ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img) {
+ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img, hipStream_t st) {
   const LevelGeom* g = c->geom_h;
   for (int l = 0; l + 1 < c->L; l += 3) {
     PyrChainArgs a;
@@ -145,7 +145,7 @@ ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img) {
     }
     for (int k = 0; k < 3; k++) a.dst[k] = img[std::min(l + 1 + k, c->L - 1)];
     const int dw = g[l + a.steps].sw, dh = g[l + a.steps].sh;
-    hipLaunchKernelGGL(pyr_down_chain_u8, dim3((dw + ELLC_PT - 1) / ELLC_PT, (dh + ELLC_PT - 1) / ELLC_PT), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(pyr_down_chain_u8, dim3((dw + ELLC_PT - 1) / ELLC_PT, (dh + ELLC_PT - 1) / ELLC_PT), dim3(256), 0, st, a);
   }
   ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
@@ -154,8 +154,31 @@ ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img) {
 // Upload + pyramid without stalling the caller: the image is copied into one of a ring of pinned staging buffers (so the
 // caller's buffer is free when this returns, as with the blocking copy it replaces), and the host-to-device copy and the
 // pyramid launch are only enqueued. A staging buffer is reused once the copy that read it has completed (event).
-static ellc_status upload_pyramid(ellc_ctx* c, uint8_t* const* img, const uint8_t* host) {
+// frame_slot >= 0: the upload of a current-frame slot runs on a stream of its own, so that the copy and the pyramid overlap what
+// is already enqueued on the main stream (in a tracking loop: the previous frame's depth stages, which read the OTHER frame
+// slot). Ordered on the device: behind the readers of this slot that are already enqueued (mark_frame_use, batches in flight),
+// and everything enqueued later on the main stream waits for it.
+static ellc_status upload_pyramid(ellc_ctx* c, uint8_t* const* img, const uint8_t* host, int frame_slot = -1) {
   const LevelGeom* g = c->geom_h;
+  hipStream_t st = c->stream;
+  if (frame_slot >= 0) {
+    if (!c->upload_stream) {
+      ELLC_HIP(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
+      c->fr_use_ev.assign(c->cfg.max_frames, nullptr);
+      c->fr_ready_ev.assign(c->cfg.max_frames, nullptr);
+      // readers enqueued before the stream existed were not marked: this once, behind everything on the main stream
+      hipEvent_t all = nullptr;
+      ELLC_HIP(c, hipEventCreateWithFlags(&all, hipEventDisableTiming));
+      hipError_t e = hipEventRecord(all, c->stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(c->upload_stream, all, 0);
+      (void)hipEventDestroy(all);   // (released once the wait has completed)
+      ELLC_HIP(c, e);
+    }
+    st = c->upload_stream;
+    if (c->fr_use_ev[frame_slot]) ELLC_HIP(c, hipStreamWaitEvent(st, c->fr_use_ev[frame_slot], 0));   // its last main-stream reader
+    for (int p = 0; p < ellc_ctx::SETS; p++)   // batches in flight may read it (ELLC_ENTER has launched an open group)
+      if (c->batch_set[p].launched) ELLC_HIP(c, hipStreamWaitEvent(st, c->batch_set[p].done, 0));
+  }
   const size_t bytes = (size_t)g[0].sw * g[0].sh;
   const int k = c->upload_cursor;
   c->upload_cursor = (c->upload_cursor + 1) % ellc_ctx::UPLOAD_RING;
@@ -166,9 +189,22 @@ static ellc_status upload_pyramid(ellc_ctx* c, uint8_t* const* img, const uint8_
     ELLC_HIP(c, hipEventSynchronize(c->upload_done[k]));
   }
   std::memcpy(c->upload_stage[k], host, bytes);
-  ELLC_HIP(c, hipMemcpyAsync(img[0], c->upload_stage[k], bytes, hipMemcpyHostToDevice, c->stream));
-  ELLC_HIP(c, hipEventRecord(c->upload_done[k], c->stream));
-  return build_image_pyramid(c, img);
+  ELLC_HIP(c, hipMemcpyAsync(img[0], c->upload_stage[k], bytes, hipMemcpyHostToDevice, st));
+  ELLC_HIP(c, hipEventRecord(c->upload_done[k], st));
+  const ellc_status s = build_image_pyramid(c, img, st);
+  if (s != ELLC_OK || frame_slot < 0) return s;
+  if (!c->fr_ready_ev[frame_slot]) ELLC_HIP(c, hipEventCreateWithFlags(&c->fr_ready_ev[frame_slot], hipEventDisableTiming));
+  ELLC_HIP(c, hipEventRecord(c->fr_ready_ev[frame_slot], st));
+  ELLC_HIP(c, hipStreamWaitEvent(c->stream, c->fr_ready_ev[frame_slot], 0));   // whatever is enqueued from here on sees the new pyramid
+  return ELLC_OK;
+}
+
+// a main-stream reader of frame slot `slot` has just been enqueued: a later upload into the slot waits for it (upload_pyramid)
+ellc_status mark_frame_use(ellc_ctx* c, int slot) {
+  if (!c->upload_stream) return ELLC_OK;   // no upload has left the main stream yet: plain stream order holds
+  if (!c->fr_use_ev[slot]) ELLC_HIP(c, hipEventCreateWithFlags(&c->fr_use_ev[slot], hipEventDisableTiming));
+  ELLC_HIP(c, hipEventRecord(c->fr_use_ev[slot], c->stream));
+  return ELLC_OK;
 }
 
 ellc_status build_maxgrad(ellc_ctx* c, bool is_kf, int slot) {
@@ -480,9 +516,11 @@ static int schedule_total_iters(const ellc_ctx* c) {
 }
 // launches of the first graph: five eighths of the iteration caps (20 of {4,7,9,12}; tracked frames run 13-17 iterations); the
 // continuation holds the rest
+// — or, once the context has run such a call, what the previous one needed plus two (adaptive_hint: consecutive frames of a
+// tracked sequence need about the same; r03: 20 launches of which a tracked frame used 15, the other five still cost 4.8 us each)
 static int adaptive_first_launches(const ellc_ctx* c, int B) {
   const int total = schedule_total_iters(c);
-  int first = (total * 5 + 7) / 8;
+  int first = c->adaptive_hint > 0 ? c->adaptive_hint : (total * 5 + 7) / 8;
 #ifdef ELLC_DIAG
   if (c->adaptive_first_override > 0) first = c->adaptive_first_override;   // ELLC_ADAPTIVE_FIRST
 #endif
@@ -609,7 +647,7 @@ static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
 
 // the level / iteration schedule of GetImagePoseEstimate (ImageFunc.cpp:150-292) as a launch sequence
 static ellc_status enqueue_schedule(ellc_ctx* c, int B, int mode, int save_weights) {
-  if (schedule_is_adaptive(c, mode, B)) return enqueue_schedule_adaptive(c, B, save_weights, adaptive_first_launches(c, B));
+  if (schedule_is_adaptive(c, mode, B)) return enqueue_schedule_adaptive(c, B, save_weights, c->cur_adaptive_first);
   if (mode == ELLC_MODE_FCA && c->use_fused) return enqueue_schedule_fused(c, B, save_weights);
   if (mode == ELLC_MODE_ICA && c->use_fused) return enqueue_schedule_ica_fused(c, B);
   for (int level = c->L - 1; level >= 0; level--) {
@@ -931,6 +969,12 @@ ellc_status ellc_ctx_destroy(ellc_ctx* c) {
     if (c->batch_stream[i]) (void)hipStreamDestroy(c->batch_stream[i]);
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
   if (c->ev_xfer) (void)hipEventDestroy(c->ev_xfer);
+  if (c->upload_stream) {
+    (void)hipStreamSynchronize(c->upload_stream);
+    for (hipEvent_t e : c->fr_use_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->fr_ready_ev) if (e) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->upload_stream);
+  }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
@@ -944,7 +988,7 @@ ellc_status ellc_frame_upload(ellc_ctx* c, int slot, const uint8_t* image) {
   if (!c || !image || !slot_ok(slot, c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_frame_upload: bad argument");
   uint8_t* img[ELLC_MAX_LEVELS];
   for (int l = 0; l < c->L; l++) img[l] = c->fr_tab_h[(size_t)l * c->cfg.max_frames + slot].img;
-  ellc_status s = upload_pyramid(c, img, image);
+  ellc_status s = upload_pyramid(c, img, image, slot);
   if (s != ELLC_OK) return s;
   c->fr_has_image[slot] = 1;
   c->fr_maxgrad_valid[slot] = 0;
@@ -982,6 +1026,8 @@ ellc_status ellc_keyframe_from_frame(ellc_ctx* c, int kf_slot, int frame_slot) {
   }
   c->kf_has_image[kf_slot] = 1;
   c->kf_has_depth[kf_slot] = 0;
+  const ellc_status ms = mark_frame_use(c, frame_slot);
+  if (ms != ELLC_OK) return ms;
   return build_maxgrad(c, true, kf_slot);
 }
 
@@ -1183,6 +1229,12 @@ static ellc_status copy_slot_planes(ellc_ctx* dc, int dst_is_kf, int dst, ellc_c
   }
   return ELLC_OK;
 }
+static ellc_status mark_copy_uses(ellc_ctx* dc, int dst_is_kf, int dst, ellc_ctx* sc, int src_is_kf, int src) {
+  ellc_status s = ELLC_OK;
+  if (!src_is_kf) s = mark_frame_use(sc, src);
+  if (s == ELLC_OK && !dst_is_kf && dc == sc) s = mark_frame_use(dc, dst);
+  return s;
+}
 
 ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, int src) {
   ELLC_ENTER(c);
@@ -1190,7 +1242,10 @@ ellc_status ellc_copy_slot(ellc_ctx* c, int dst_is_kf, int dst, int src_is_kf, i
     return fail(c, ELLC_ERR_BAD_ARG, "bad slot");
   if (!(src_is_kf ? c->kf_has_image[src] : c->fr_has_image[src])) return fail(c, ELLC_ERR_NOT_READY, "source slot empty");
   if (dst_is_kf == src_is_kf && dst == src) return ELLC_OK;
-  return copy_slot_planes(c, dst_is_kf, dst, c, src_is_kf, src);
+  // a frame slot written here: behind an upload of its own that may still be running on the upload stream? (uploads make the
+  // main stream wait at once, so plain stream order covers it); read or written here: later uploads wait for this copy
+  const ellc_status st = copy_slot_planes(c, dst_is_kf, dst, c, src_is_kf, src);
+  return st != ELLC_OK ? st : mark_copy_uses(c, dst_is_kf, dst, c, src_is_kf, src);
 }
 
 // The same between two contexts of one device (same width / height / levels): the reference's loop-closure thread works on deep
@@ -1216,7 +1271,8 @@ ellc_status ellc_copy_slot_across(ellc_ctx* dc, int dst_is_kf, int dst, ellc_ctx
   if (!dc->ev_xfer) ELLC_HIP(c, hipEventCreateWithFlags(&dc->ev_xfer, hipEventDisableTiming));
   ELLC_HIP(c, hipStreamWaitEvent(dc->stream, sc->ev_xfer, 0));
   const ellc_status st = copy_slot_planes(dc, dst_is_kf, dst, sc, src_is_kf, src);
-  // whatever was enqueued: the source must not be overwritten before it has been read
+  // whatever was enqueued: the source must not be overwritten before it has been read (the source context's main stream waits
+  // for the copy below, and with it every later upload there: mark_frame_use on sc is not needed)
   ELLC_HIP(c, hipEventRecord(dc->ev_xfer, dc->stream));
   if (hipStreamWaitEvent(sc->stream, dc->ev_xfer, 0) != hipSuccess) return fail(sc, ELLC_ERR_HIP, "ellc_copy_slot_across: cannot order the source stream");
   sc->main_dirty = true;
@@ -1257,12 +1313,14 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
 // graph ended before every alignment had (enqueue_schedule_adaptive), for the batch set selected in the context.
 static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int save_weights, int set, bool continuation) {
   auto body = [&]() -> ellc_status {
-    if (continuation) return enqueue_schedule_adaptive(c, B, save_weights, schedule_total_iters(c) - adaptive_first_launches(c, B), true);
+    if (continuation) return enqueue_schedule_adaptive(c, B, save_weights, schedule_total_iters(c) - c->cur_adaptive_first, true);
     return enqueue_align_body(c, B, nu, mode, save_weights);
   };
   if (!c->use_graph) return body();
+  // (cur_adaptive_first: launches of the first graph of a state-driven schedule; it varies with the context's hint)
+  const int first = schedule_is_adaptive(c, mode, B) ? c->cur_adaptive_first : 0;
   const auto key = std::make_tuple(B, continuation ? 0 : nu, mode,
-                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0), set);
+                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0) | (first << 4), set);
   auto it = c->graphs.find(key);
   if (it == c->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -1309,6 +1367,7 @@ static ellc_status resolve_batch(ellc_ctx* c, int set) {
   if (!unfinished) return ELLC_OK;
   const int selected = c->cur_set;
   select_batch_set(c, set);
+  c->cur_adaptive_first = bs.adaptive_first;
   ellc_status s = ELLC_OK;
   {
     StreamScope scope(c, c->batch_stream[bs.stream_idx]);
@@ -1396,6 +1455,8 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
     }
     ELLC_HIP(c, hipStreamWaitEvent(run_stream, other.done, 0));
   }
+  c->cur_adaptive_first = adaptive_first_launches(c, B);
+  bs.adaptive_first = c->cur_adaptive_first;
   {
     StreamScope scope(c, run_stream);
     const ellc_status s = launch_align_graph(c, B, nu, bs.mode, bs.save_weights, set, false);
@@ -1444,6 +1505,7 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
     ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
     if (s != ELLC_OK) return s;
     for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);   // rebuilt here, outside the cache's bookkeeping
+    c->cur_adaptive_first = adaptive_first_launches(c, B);
     return launch_align_graph(c, B, nu, mode, save_weights, 0, false);
   }
   // may this batch share a launch with others? full batches of one mode, nothing per-slot written (saved weights), not the
@@ -1530,6 +1592,15 @@ ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters
       if (res[b].pad != 0) {   // the last kernel of the schedule never wrote the record
         out = fail(c, ELLC_ERR_HIP, "ellc_align_fetch: the schedule did not complete on the device (no result was exported)");
       }
+  }
+  if (out == ELLC_OK && bs.adaptive) {   // the next state-driven call starts with a graph as long as this one needed, plus two
+    int most = 0;
+    for (int b = 0; b < B; b++) {
+      int it = 0;
+      for (int l = 0; l < c->L; l++) it += res[b].iters[l];
+      most = std::max(most, it);
+    }
+    c->adaptive_hint = std::min(schedule_total_iters(c), std::max(c->L, (most + 3) & ~1));
   }
   if (out == ELLC_OK)
     for (int b = 0; b < B; b++) {
