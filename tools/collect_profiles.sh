@@ -3,7 +3,7 @@
 # tools/summarize_profiles.py rNN condenses into profiles/. Counters are collected in their own passes (never together with
 # trace domains other than --kernel-trace); the program itself follows `--` (no env / shell hop).
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
@@ -33,4 +33,6 @@ done
 trace depth_trace $ROOT/tools/bench_depth.py
 pmc depth_pmc_fetch FETCH_SIZE $ROOT/tools/bench_depth.py
 pmc depth_pmc_write WRITE_SIZE $ROOT/tools/bench_depth.py
+# C4 level-0 kernel: where the waves wait
+$ROOT/tools/pmc_c4.sh profiles_$R/pmc_c4 > $OUT/pmc_c4.log 2>&1; echo "pmc_c4 rc=$?"
 ls $OUT | head -60

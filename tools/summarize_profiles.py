@@ -11,7 +11,7 @@ import os
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "profiles_" + rnd)
 dst = os.path.join(ROOT, "profiles")
@@ -126,14 +126,14 @@ f = newest(os.path.join("depth_trace", "*", "*_kernel_trace.csv"))
 if f:
     N = 640 * 480
     bpp = {"dm_regularize": 50.0, "dm_fill_holes": 50.0, "dm_observe": 94.0, "dm_export_level0": 21.0, "depth_pyr_level": None,
-           "dm_prop_project": None, "dm_prop_select": None, "dm_prop_apply": None, "dm_rescale": None, "dm_sum_stage1": None}
+           "dm_prop_project": 61.0, "dm_prop_fold": None, "dm_rescale": None, "dm_sum_stage1": None}
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        n = r["Kernel_Name"].split("(")[0].replace("ellc::", "").replace("void ", "")
+        n = r["Kernel_Name"].split("(")[0].split("<")[0].replace("ellc::", "").replace("void ", "")
         d[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 
     def dm_match(n):
-        n = n.split("(")[0].replace("ellc::", "").replace("void ", "")
+        n = n.split("(")[0].split("<")[0].replace("ellc::", "").replace("void ", "")
         return n if (n.startswith("dm_") or n.startswith("depth_pyr")) else None
     fe = counters("depth_pmc_fetch", dm_match)
     wr = counters("depth_pmc_write", dm_match)
@@ -155,3 +155,11 @@ if f:
         out["kernels"][n] = k
     json.dump(out, open(os.path.join(dst, "%s_depth_roofline.json" % rnd), "w"), indent=1)
     print("depth kernels:", {k: round(v["avg_us"], 1) for k, v in out["kernels"].items()})
+
+# ---- C4 level-0 kernel: where the waves wait (tools/pmc_c4.sh: SQ / TCP / TCC passes)
+f = os.path.join(src, "pmc_c4", "summary.json")
+if os.path.exists(f):
+    d = json.load(open(f))
+    d = {"round": rnd, "source": "tools/pmc_c4.sh: rocprofv3 --kernel-trace --pmc <one set per pass> -- python3 tools/profile_kernel.py --width 1280 --height 960 "
+         "--levels 5 --dense --batch 16 --arith fast (gn_fca_fused at level 0 over 64 alignments, averages per launch; SQ_* in quad-cycles summed over waves)", "counters": d}
+    json.dump(d, open(os.path.join(dst, "%s_c4_wait_counters.json" % rnd), "w"), indent=1)
