@@ -988,7 +988,11 @@ ellc_status ellc_frame_upload(ellc_ctx* c, int slot, const uint8_t* image) {
   if (!c || !image || !slot_ok(slot, c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_frame_upload: bad argument");
   uint8_t* img[ELLC_MAX_LEVELS];
   for (int l = 0; l < c->L; l++) img[l] = c->fr_tab_h[(size_t)l * c->cfg.max_frames + slot].img;
-  ellc_status s = upload_pyramid(c, img, image, slot);
+  // (a stream of its own only in contexts that keep one batch in flight — the tracking context: a process gets three hardware
+  // queues that run concurrently, and a context with batches in flight needs them for its batch streams; r03: with the fourth
+  // stream the pipeline of sixteen batches fell from 7.7 to 6.3 M iterations/s)
+  const bool own_stream = c->cfg.concurrent_batches <= 1 && c->coalesce <= 1;
+  ellc_status s = upload_pyramid(c, img, image, own_stream ? slot : -1);
   if (s != ELLC_OK) return s;
   c->fr_has_image[slot] = 1;
   c->fr_maxgrad_valid[slot] = 0;
