@@ -102,18 +102,23 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   __shared__ int before[4]; // per wave: valid pixels in the tiles of this level that precede this one
   __shared__ uint32_t s_idx[ELLC_TILE];
   __shared__ float s_Z[ELLC_TILE];
-  {   // this tile's offset in the level's list = sum of the counts prep_count left for the tiles before it (at most a few hundred)
-    int part = 0, tot;
-    for (int i = (int)threadIdx.x; i < local; i += 256) part += K.tile_count[i];
-    wave_inclusive_scan(part, tot);
-    if (lane == 0) before[wave] = tot;
-  }
+  // the eight depth loads first, then the loads of the tile counts: both sets are in flight together (r03: a block's life is a
+  // chain of memory round trips of 2-3 us each under load — table entry, counts, depths, gathers, stores: 12 us for 2048 pixels)
   float d[8];
-  unsigned long long m[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const int i = base + j * 256;
     d[j] = (i < n) ? gptr(K.depth)[(unsigned)i] : 0.0f;
+  }
+  {   // this tile's offset in the level's list = sum of the counts prep_count left for the tiles before it (at most a few hundred)
+    int part = 0, tot;
+    for (int i = (int)threadIdx.x; i < local; i += 256) part += gptr(K.tile_count)[(unsigned)i];
+    wave_inclusive_scan(part, tot);
+    if (lane == 0) before[wave] = tot;
+  }
+  unsigned long long m[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
     m[j] = __ballot(d[j] > 0.0f);
     if (lane == 0) cnt[j * 4 + wave] = __popcll(m[j]);
   }
@@ -162,6 +167,56 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   constexpr int CH = 3;
   __shared__ u32x4 s_rec[((NEED & 4) && !(NEED & 16)) ? 256 * CH : 1];
   ELLC_GLOBAL u32x4* rec_out = (ELLC_GLOBAL u32x4*)K.irec;
+  if constexpr (NEED == 8 || NEED == 2) {
+    // FCA records: up to four records per thread and trip, all their gathers (the image byte and the variance of each) issued
+    // before the first is used — one memory round trip per 1024 records instead of one per 256
+    constexpr int U = 4;
+    for (int r0 = 0; r0 < nvalid; r0 += U * 256) {   // block-uniform trip count
+      int ii[U], xx[U], yy[U];
+      float ZZ[U], vv[U];
+      uint8_t Ib[U];
+      bool act[U];
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        const int r = r0 + k * 256 + (int)threadIdx.x;
+        act[k] = r < nvalid;
+        const int rr = act[k] ? r : 0;   // (an idle lane reads entry 0: a valid address, nothing is stored)
+        ii[k] = (int)s_idx[rr];
+        ZZ[k] = s_Z[rr];
+        int y = (int)(((float)ii[k] + 0.5f) * inv_cols);   // i < 2^24: exact conversion; corrected below
+        if (y * cols > ii[k]) y--;
+        if ((y + 1) * cols <= ii[k]) y++;
+        yy[k] = y;
+        xx[k] = ii[k] - y * cols;
+        Ib[k] = img[(unsigned)(y * sw + xx[k])];
+        vv[k] = var[(unsigned)ii[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        if (!act[k]) continue;
+        const unsigned pos = tile_off + (unsigned)(r0 + k * 256) + threadIdx.x;
+        const int x = xx[k], y = yy[k];
+        const float Z = ZZ[k];
+        if constexpr (NEED == 8) {   // tolerance mode: one 16-byte record per pixel (FcaRecF)
+          const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)Ib[k] << 24);
+          const float dd = __builtin_amdgcn_rcpf(Z);
+          const float pn = ((float)x - g.cx) * g.rfx;   // u / fx (fcaf_pixel forms v / fy from y)
+          crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, vv[k]), __builtin_bit_cast(uint32_t, dd)};
+        } else {   // one 32-byte record per pixel (FcaRec), stored as two 16-byte words
+          const uint32_t xy = ((uint32_t)y << 16) | (uint32_t)x;
+          const float Ikf = (float)Ib[k];
+          const float X = (((float)x - cx) * Z) / fx;
+          const float Y = (((float)y - cy) * Z) / fy;
+          const double invZ = 1.0 / (double)Z;
+          const unsigned long long zb = __builtin_bit_cast(unsigned long long, invZ);
+          const u32x4 lo = {xy, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, vv[k]), __builtin_bit_cast(uint32_t, Ikf)};
+          const u32x4 hi = {__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), (uint32_t)zb, (uint32_t)(zb >> 32)};
+          crec[2u * pos] = lo;
+          crec[2u * pos + 1u] = hi;
+        }
+      }
+    }
+  } else
   for (int r0 = 0; r0 < nvalid; r0 += 256) {   // block-uniform trip count
     const int r = r0 + (int)threadIdx.x;
     if (r < nvalid) {
