@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "ellc_frame_upload", "ellc_keyframe_upload", "ellc_keyframe_from_frame", "ellc_get_image_level", "ellc_get_gradient",
     "ellc_get_max_gradient", "ellc_keyframe_set_depth", "ellc_keyframe_set_depth_level", "ellc_keyframe_get_depth_level",
     "ellc_keyframe_set_weights", "ellc_keyframe_get_weights", "ellc_keyframe_finalise_weights", "ellc_align", "ellc_align_enqueue",
-    "ellc_align_fetch", "ellc_gn_iterate", "ellc_concatenate_relative_pose", "ellc_concatenate_origin_pose", "ellc_se3_exp",
+    "ellc_align_fetch", "ellc_gn_iterate", "ellc_gn_display_planes", "ellc_concatenate_relative_pose", "ellc_concatenate_origin_pose", "ellc_se3_exp",
     "ellc_se3_log", "ellc_depth_set_state", "ellc_depth_get_state", "ellc_depth_set_keyframe", "ellc_depth_propagate",
     "ellc_depth_observe", "ellc_depth_fill_holes", "ellc_depth_regularize", "ellc_depth_make_inv_depth_one",
     "ellc_depth_update_depth_image", "ellc_depth_create_keyframe", "ellc_depth_seeds", "ellc_track_frame", "ellc_profile_gn_kernel", "ellc_profile_align",

@@ -168,6 +168,14 @@ class Context:
             out.update(residual=pl[0], weight=pl[1], warpedX=pl[2], warpedY=pl[3], J=pl[4:10])
         return out
 
+    def gn_display_planes(self, kf_slot, frame_slot, level, pose):
+        """display_templateimg / display_2bewarpedimg (u8), display_warpedimg / display_origres (f32) of one pass."""
+        pose = np.ascontiguousarray(pose, np.float32)
+        shp = self.level_shape(level)
+        t = np.zeros(shp, np.uint8); k = np.zeros(shp, np.uint8); w = np.zeros(shp, np.float32); o = np.zeros(shp, np.float32)
+        self._ck(self._l.ellc_gn_display_planes(self.h, kf_slot, frame_slot, level, _p(pose), _p(t), _p(k), _p(w), _p(o)), "ellc_gn_display_planes")
+        return dict(templateimg=t, tobewarpedimg=k, warpedimg=w, origres=o)
+
     # ---- depth map
     def _hyp(self, st):
         arrs = [np.ascontiguousarray(st["invDepth"], np.float32), np.ascontiguousarray(st["invDepthSmoothed"], np.float32),

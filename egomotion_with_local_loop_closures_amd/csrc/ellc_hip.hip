@@ -1684,6 +1684,35 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   return ELLC_OK;
 }
 
+ellc_status ellc_gn_display_planes(ellc_ctx* c, int kf_slot, int frame_slot, int level, const float* pose, uint8_t* templateimg,
+                                   uint8_t* tobewarpedimg, float* warpedimg, float* origres) {
+  ELLC_ENTER(c);
+  if (!c || !pose || level < 0 || level >= c->L) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (c->n_inflight > 0) return fail(c, ELLC_ERR_NOT_READY, "ellc_gn_display_planes: fetch the enqueued batches first");
+  int nu = 0;
+  select_batch_set(c, 0);
+  ellc_status s = stage_batch(c, 1, &kf_slot, &frame_slot, pose, &nu);
+  if (s != ELLC_OK) return s;
+  enqueue_stage_in(c, 0);   // staging only
+  hipLaunchKernelGGL(gn_set_pose0, dim3(1), dim3(1), 0, c->stream, c->state_d, c->init_pose_d);
+  const LevelGeom& g = c->geom_h[level];
+  const size_t n = (size_t)g.n;
+  float* warped_d = c->planes_d;             // scratch: two f32 planes and two u8 planes of the level
+  float* orig_d = c->planes_d + n;
+  uint8_t* tmpl_d = (uint8_t*)(c->planes_d + 2 * n);
+  uint8_t* tbw_d = tmpl_d + n;
+  GnArgs a = make_gn_args(c, level, 1, 0, nullptr);
+  dim3 blk(32, 8);
+  hipLaunchKernelGGL(gn_display_planes, grid2d(g.cols, g.rows, blk), blk, 0, c->stream, a, tmpl_d, tbw_d, warped_d, orig_d);
+  ELLC_HIP(c, hipGetLastError());
+  if (templateimg) ELLC_HIP(c, hipMemcpyAsync(templateimg, tmpl_d, n, hipMemcpyDeviceToHost, c->stream));
+  if (tobewarpedimg) ELLC_HIP(c, hipMemcpyAsync(tobewarpedimg, tbw_d, n, hipMemcpyDeviceToHost, c->stream));
+  if (warpedimg) ELLC_HIP(c, hipMemcpyAsync(warpedimg, warped_d, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (origres) ELLC_HIP(c, hipMemcpyAsync(origres, orig_d, n * 4, hipMemcpyDeviceToHost, c->stream));
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  return ELLC_OK;
+}
+
 void ellc_concatenate_relative_pose(const float* a, const float* b, float* dest) {
   float o[6];
   concat_relative_f32(a, b, o);

@@ -1969,6 +1969,38 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
   }
 }
 
+// PixelWisePyramid's display planes of one pass (PixelWisePyramid.cpp:209-225 and :275-284): for every pixel of the level where
+// the keyframe has a depth — display_templateimg = the current image, display_2bewarpedimg = the keyframe image,
+// display_origres = their difference before warping (uchar - uchar, as an int), display_warpedimg = the current image
+// interpolated at the warped point (0 when it falls outside) — and 0 where the pixel is masked. One thread per pixel of the
+// plane, the reference's expressions (GUI inputs in the reference: DisplayWarpedImgPxelWise, ImageFunc.cpp:277).
+__global__ void gn_display_planes(GnArgs a, uint8_t* __restrict__ templateimg, uint8_t* __restrict__ tobewarpedimg, float* __restrict__ warpedimg,
+                                  float* __restrict__ origres) {
+  const LevelGeom g = a.geom[a.level];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= g.cols || y >= g.rows) return;
+  const KfLevelDev& K = a.kf_tab[a.level * a.max_kf + a.kf_slot[0]];
+  const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[0]];
+  const int p = y * g.cols + x;
+  const float Z = K.depth[p];
+  uint8_t t = 0, k = 0;
+  float w = 0.0f, o = 0.0f;
+  if (Z > 0.0f) {   // mask = depth_pyramid > 0 (Frame.cpp:295-301)
+    float S[12];
+    for (int i = 0; i < 12; i++) S[i] = a.state[0].S[i];
+    t = F.img[y * g.sw + x];
+    k = K.img[y * g.sw + x];
+    o = (float)((int)t - (int)k);
+    const Warp wp = warp_pixel<false>(x, y, Z, g, S);
+    const Taps tp = tap_point<false>(as_global(F.img), g.sw, g.cols, g.rows, wp.wx, wp.wy);
+    w = (tp.I == -1.0f) ? 0.0f : tp.I;
+  }
+  templateimg[p] = t;
+  tobewarpedimg[p] = k;
+  warpedimg[p] = w;
+  origres[p] = o;
+}
+
 // result export for schedules that do not end in gn_fused_finish
 __global__ void gn_export_results(const AlignState* state, AlignResult* res, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -189,6 +189,15 @@ ellc_status ellc_align_fetch(ellc_ctx* ctx, int B, float* out_pose, int* out_ite
 ellc_status ellc_gn_iterate(ellc_ctx* ctx, int kf_slot, int frame_slot, int level, int mode, int iter, const float* pose,
                             float* H36, float* b6, float* delta6, float* new_pose6, float* weighted, float* planes);
 
+/* The display planes PixelWisePyramid fills beside the residual and the weights in a pass at `level` with `pose`
+ * (PixelWisePyramid.cpp:209-225, :275-284; the reference shows display_warpedimg, ImageFunc.cpp:277): where the keyframe has a
+ * depth, display_templateimg = the current image (u8), display_2bewarpedimg = the keyframe image (u8), display_origres = their
+ * difference before warping, display_warpedimg = the current image interpolated at the warped point (0 outside); 0 where
+ * masked. rows*cols elements each; any pointer may be NULL. (display_iterationres, display_weightimg and the saved warped
+ * points are planes 0-3 of ellc_gn_iterate.) */
+ellc_status ellc_gn_display_planes(ellc_ctx* ctx, int kf_slot, int frame_slot, int level, const float* pose, uint8_t* templateimg,
+                                   uint8_t* tobewarpedimg, float* warpedimg, float* origres);
+
 /* se(3) helpers used by callers (frame::concatenateRelativePose Frame.cpp:503-530,
  * frame::concatenateOriginPose :534-562); host-side, no device work. */
 void ellc_concatenate_relative_pose(const float* src_1wrt2, const float* src_2wrt3, float* dest_1wrt3);

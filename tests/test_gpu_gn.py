@@ -176,6 +176,31 @@ def test_save_weights_accumulates_last_iteration(oracle, ellc):
     ctx.close()
 
 
+@pytest.mark.parametrize("level", [2, 0])
+def test_display_planes_of_a_pass(problem, oracle, level):
+    """PixelWisePyramid's display planes (PixelWisePyramid.cpp:209-225, :275-284): template / to-be-warped image, original
+    residual, warped image — against the oracle's warped points and its bilinear tap (Frame.h:181-279), bit for bit."""
+    pose = np.array([0.004, -0.003, 0.002, 0.01, -0.005, 0.008], np.float32)
+    kf, cur, ctx = problem["kf"], problem["cur"], problem["ctx"]
+    st = oracle.GNStepper(kf, cur, problem["dm"].depth_pyr(), level, pose, planes=True)
+    st.step(0)
+    pl = st.get_planes()
+    st.close()
+    got = ctx.gn_display_planes(0, 0, level, pose)
+    rows, cols = H >> level, W >> level
+    mask = kf.depth(level) > 0
+    ki = kf.image(level)[:rows, :cols]
+    ci = cur.image(level)[:rows, :cols]
+    assert np.array_equal(got["templateimg"], np.where(mask, ci, 0))
+    assert np.array_equal(got["tobewarpedimg"], np.where(mask, ki, 0))
+    assert np.array_equal(got["origres"], np.where(mask, ci.astype(np.int32) - ki.astype(np.int32), 0).astype(np.float32))
+    inb = mask & (pl["warpedX"] != -1.0)
+    exp = np.zeros((rows, cols), np.float32)
+    exp[inb] = oracle.tap_u8(cur.image(level), pl["warpedX"][inb], pl["warpedY"][inb], check=1, rows=rows, cols=cols)
+    assert bits_equal(got["warpedimg"], exp)
+    assert inb.sum() > 100 and (mask & ~inb).sum() >= 0
+
+
 @pytest.mark.parametrize("arith", ["exact", "fast"])
 def test_save_weights_once_when_a_batch_needs_the_continuation(oracle, ellc, arith):
     """Early exit on, B = 2, saved weights: alignment 0 ends inside the first graph of the state-driven schedule (16 iterations),
