@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-time budget of each CPU baseline variant")
     ap.add_argument("--rehearse-launcher", action="store_true", help="no GPU work: start the ranks, run the control plane (barrier, id broadcast, "
                     "max) and a few pipelined gathers of stand-in result tables over the TCP transport, print what each rank saw (CPU test of the launcher)")
+    ap.add_argument("--coarse", type=int, default=0, help="cfg.coarse (diagnostic A/B: 1 = gn_fca_coarse for the small levels)")
+    ap.add_argument("--streams", type=int, default=3, help="diagnostic: batch streams the loaded library build has (ELLC_STREAMS)")
     ap.add_argument("--lib", default=None, help="diagnostic A/B only: load this build of the library instead of csrc/libellc_hip.so")
     return ap.parse_args()
 
@@ -152,14 +154,14 @@ class Workload:
         self.W, self.H, self.L = W or a.width, H or a.height, L or a.levels
         self.B = B or a.batch
         self.coalesce = max(1, min(4, a.coalesce if coalesce is None else coalesce))
-        self.G = G or max(1, min(4 * self.coalesce if self.coalesce > 1 else 3, a.inflight))
+        self.G = G or max(1, min((a.streams + 1) * self.coalesce if self.coalesce > 1 else a.streams, a.inflight))
         self.sched = sched or [4, 7, 9, 12, 12, 12, 12, 12][:self.L]
         fx, fy, cx, cy = scenes[0]["intrinsics"]
         B, G = self.B, self.G
         self.shared = shared_frame
         self.cfg = api.default_config(self.W, self.H, self.L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=int(a.early_exit if early_exit is None else early_exit),
                                       max_iter=self.sched, max_keyframes=G * B, max_frames=(G if shared_frame else G * B), max_batch=B, device=dev_index,
-                                      concurrent_batches=G, coalesce=self.coalesce, cache_records=int(cache_records),
+                                      concurrent_batches=G, coalesce=self.coalesce, cache_records=int(cache_records), coarse=a.coarse,
                                       arith=api.ARITH_FAST if arith == "fast" else api.ARITH_EXACT)
         self.ctx = api.Context(self.cfg)
         self.mode = api.MODE_FCA if a.mode == "fca" else api.MODE_ICA

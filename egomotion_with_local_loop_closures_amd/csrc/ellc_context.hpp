@@ -72,8 +72,11 @@ struct ellc_ctx {
   // staged or the group being launched. All other entry points work on `stream`, launch a group that is still open and make
   // the stream wait for the groups in flight, so a caller sees one in-order queue per context as before.
   static constexpr int MAX_COALESCE = 4;
-  static constexpr int SETS = 4 * MAX_COALESCE + 1;   // of which max_inflight + 1 are used (n_sets): every batch in flight may be a group of its own
-  static constexpr int STREAMS = 3;
+#ifndef ELLC_STREAMS
+#define ELLC_STREAMS 3
+#endif
+  static constexpr int STREAMS = ELLC_STREAMS;
+  static constexpr int SETS = (STREAMS + 1) * MAX_COALESCE + 1;   // of which max_inflight + 1 are used (n_sets): every batch in flight may be a group of its own
   struct BatchSet {
     int* stage_h = nullptr;                         // 9 * cap ints: kf slots, frame slots, unique slots, initial poses (cap = coalesce * max_batch)
     const int* stage_dev_alias = nullptr;
@@ -99,8 +102,8 @@ struct ellc_ctx {
     int adaptive_first = 0;                         //   whose first graph holds this many launches
     bool resolved = true;                           // `done` has been waited for and the continuation, if one was needed, has run
   } batch_set[SETS];
-  hipStream_t batch_stream[STREAMS] = {nullptr, nullptr, nullptr};   // [0] = stream; the others are created when first needed
-  int stream_waited_mark[STREAMS] = {0, 0, 0};      // the main-stream mark each batch stream has been ordered after
+  hipStream_t batch_stream[STREAMS] = {};   // [0] = stream; the others are created when first needed
+  int stream_waited_mark[STREAMS] = {};      // the main-stream mark each batch stream has been ordered after
   int coalesce = 1;                                 // cfg.coalesce clamped to 1..MAX_COALESCE
   int max_inflight = 3;                             // batches in flight: 3 with coalesce = 1; 4 x coalesce otherwise (three groups
                                                     // running and a fourth queued behind the oldest, so that the device never waits
