@@ -68,7 +68,6 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-time budget of each CPU baseline variant")
     ap.add_argument("--rehearse-launcher", action="store_true", help="no GPU work: start the ranks, run the control plane (barrier, id broadcast, "
                     "max) and a few pipelined gathers of stand-in result tables over the TCP transport, print what each rank saw (CPU test of the launcher)")
-    ap.add_argument("--coarse", type=int, default=0, help="cfg.coarse (diagnostic A/B: 1 = gn_fca_coarse for the small levels)")
     ap.add_argument("--streams", type=int, default=3, help="diagnostic: batch streams the loaded library build has (ELLC_STREAMS)")
     ap.add_argument("--lib", default=None, help="diagnostic A/B only: load this build of the library instead of csrc/libellc_hip.so")
     return ap.parse_args()
@@ -161,7 +160,7 @@ class Workload:
         self.shared = shared_frame
         self.cfg = api.default_config(self.W, self.H, self.L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=int(a.early_exit if early_exit is None else early_exit),
                                       max_iter=self.sched, max_keyframes=G * B, max_frames=(G if shared_frame else G * B), max_batch=B, device=dev_index,
-                                      concurrent_batches=G, coalesce=self.coalesce, cache_records=int(cache_records), coarse=a.coarse,
+                                      concurrent_batches=G, coalesce=self.coalesce, cache_records=int(cache_records),
                                       arith=api.ARITH_FAST if arith == "fast" else api.ARITH_EXACT)
         self.ctx = api.Context(self.cfg)
         self.mode = api.MODE_FCA if a.mode == "fca" else api.MODE_ICA

@@ -33,7 +33,7 @@ class EllcConfig(C.Structure):
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("max_iter", C.c_int * MAX_LEVELS), ("early_exit", C.c_int),
                 ("max_keyframes", C.c_int), ("max_frames", C.c_int), ("max_batch", C.c_int), ("device", C.c_int),
-                ("concurrent_batches", C.c_int), ("arith", C.c_int), ("coalesce", C.c_int), ("cache_records", C.c_int), ("grid_batch", C.c_int), ("coarse", C.c_int)]
+                ("concurrent_batches", C.c_int), ("arith", C.c_int), ("coalesce", C.c_int), ("cache_records", C.c_int), ("grid_batch", C.c_int)]
 
 
 class EllcHypotheses(C.Structure):

@@ -289,39 +289,6 @@ static int grid_batch(const ellc_ctx* c, int B) {
   return (c->coalesce > 1 && B % c->cfg.max_batch == 0) ? c->cfg.max_batch * c->coalesce : B;
 }
 
-// cfg.coarse = 1: the coarse levels of the FCA schedules, levels L-1 .. coarse_min_level(c, B), run inside gn_fca_coarse (one
-// block per alignment, all their iterations in one launch); coarse_min_level returns L when there are none. A level qualifies
-// by its pixel count: up to 80x60 always; up to 160x120 when the launch covers at least ELLC_COARSE_WIDE_BATCH alignments.
-// Measured in r03 and NOT the default ("One launch for the coarse levels"): one CU needs 4.5 us for the
-// pixel pass of an 80x60 level and 10 us for 160x120 (two waves per SIMD, half the waves on the per-tap border path), the
-// reduction and solve add 3 us — against 6.8 us (alone) to 9.8 us (pipeline) for a launch that spreads the level over several
-// CUs. 640x480: one alignment 0.174 against 0.191 ms per call at equal block counts, but 0.181 with the block counts launches
-// are free to choose; the pipelined rate is unchanged (tools/dbg/coarse_ab.sh, coarse_iter.py, coarse_stamps.py).
-static constexpr int ELLC_COARSE_PX = 4800, ELLC_COARSE_PX_WIDE = 19200, ELLC_COARSE_WIDE_BATCH = 64;
-static int coarse_min_level(const ellc_ctx* c, int B) {
-  const int px = grid_batch(c, B) >= ELLC_COARSE_WIDE_BATCH ? ELLC_COARSE_PX_WIDE : ELLC_COARSE_PX;
-  int lo = c->L;
-  for (int l = c->L - 1; l >= 0 && c->geom_h[l].n <= px; l--) lo = l;
-  return lo;
-}
-static bool use_coarse_kernel(const ellc_ctx* c, int B) { return c->cfg.coarse > 0 && coarse_min_level(c, B) < c->L; }
-// blocks per alignment of an FCA schedule's launches. cfg.coarse != 0: ELLC_COARSE_NB at the coarse levels, whether gn_fca_coarse
-// runs them (1) or launches do (-1) — the same split, the same bits
-static int fca_nblk(const ellc_ctx* c, int level, int B) {
-#ifdef ELLC_DIAG
-  if (c->nblk_override[level] > 0) return choose_nblk(c, level, grid_batch(c, B));
-#endif
-  if (c->cfg.coarse != 0 && level >= coarse_min_level(c, B)) return ELLC_COARSE_NB;
-  return choose_nblk(c, level, grid_batch(c, B));
-}
-// iterations the launches behind gn_fca_coarse may need: the caps of the levels it does not run
-static int fine_total_iters(const ellc_ctx* c, int B) {
-  const int top = use_coarse_kernel(c, B) ? coarse_min_level(c, B) - 1 : c->L - 1;
-  int total = 0;
-  for (int l = 0; l <= top; l++) total += c->cfg.max_iter[l];
-  return total;
-}
-
 static GnArgs make_gn_args(ellc_ctx* c, int level, int B, int save_w, float* planes) {
   GnArgs a;
   a.geom = c->geom_d;
@@ -514,24 +481,6 @@ static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, h
   }
 }
 
-// gn_fca_coarse for the levels L-1 .. coarse_min_level: reads state buffer seq & 1, leaves the records in the other one
-static void launch_coarse(ellc_ctx* c, int B, FusedArgs& fa) {
-  fa.coarse_top = c->L - 1;
-  fa.coarse_min = coarse_min_level(c, B);
-  for (int l = 0; l < ELLC_MAX_LEVELS; l++) fa.max_it[l] = l < c->L ? c->cfg.max_iter[l] : 0;
-  const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
-  const dim3 grd(B), blk(ELLC_COARSE_THREADS);
-  if (c->fast) {
-    if (fa.g.save_w) hipLaunchKernelGGL((gn_fca_coarse<false, true, 1>), grd, blk, 0, c->stream, src_state, fa);
-    else hipLaunchKernelGGL((gn_fca_coarse<false, true, 0>), grd, blk, 0, c->stream, src_state, fa);
-  } else if (c->geom_h[0].divc_ok) {
-    hipLaunchKernelGGL((gn_fca_coarse<true, false, -1>), grd, blk, 0, c->stream, src_state, fa);
-  } else {
-    hipLaunchKernelGGL((gn_fca_coarse<false, false, -1>), grd, blk, 0, c->stream, src_state, fa);
-  }
-  fa.seq++;
-}
-
 static void launch_finish(ellc_ctx* c, int B, const FusedArgs& fa, bool adaptive = false) {
   if (adaptive) {
     if (c->fast) hipLaunchKernelGGL((gn_fused_finish<true, true>), dim3(B), dim3(ELLC_SOLVE_THREADS), 0, c->stream, fa);
@@ -560,17 +509,22 @@ static bool schedule_is_adaptive(const ellc_ctx* c, int mode, int B) {
     if (c->cfg.max_iter[l] < 1) return false;   // a level without iterations: the level-bound schedule simply has no launch for it
   return true;
 }
+static int schedule_total_iters(const ellc_ctx* c) {
+  int total = 0;
+  for (int l = 0; l < c->L; l++) total += c->cfg.max_iter[l];
+  return total;
+}
 // launches of the first graph: five eighths of the iteration caps (20 of {4,7,9,12}; tracked frames run 13-17 iterations); the
 // continuation holds the rest
 // — or, once the context has run such a call, what the previous one needed plus two (adaptive_hint: consecutive frames of a
 // tracked sequence need about the same; r03: 20 launches of which a tracked frame used 15, the other five still cost 4.8 us each)
 static int adaptive_first_launches(const ellc_ctx* c, int B) {
-  const int total = fine_total_iters(c, B);   // (the coarse levels run inside gn_fca_coarse, ahead of these launches)
+  const int total = schedule_total_iters(c);
   int first = c->adaptive_hint > 0 ? c->adaptive_hint : (total * 5 + 7) / 8;
 #ifdef ELLC_DIAG
   if (c->adaptive_first_override > 0) first = c->adaptive_first_override;   // ELLC_ADAPTIVE_FIRST
 #endif
-  return std::min(total, std::max(std::min(c->L, total), first));
+  return std::min(total, std::max(c->L, first));
 }
 
 // State-driven FCA schedule: `launches` launches of gn_fca_adaptive and the finish kernel. continuation: the records were
@@ -592,15 +546,13 @@ static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weight
   fa.age_rounds = 0;
   for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
   int grid_x = 1;
-  fa.coarse_top = fa.coarse_min = 0;
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) {
-    fa.nblk_lv[l] = l < c->L ? fca_nblk(c, l, B) : 1;
+    fa.nblk_lv[l] = l < c->L ? choose_nblk(c, l, grid_batch(c, B)) : 1;
     fa.max_it[l] = l < c->L ? c->cfg.max_iter[l] : 0;
     grid_x = std::max(grid_x, fa.nblk_lv[l]);
   }
   fa.nblk_grid = grid_x;
   const dim3 grd(grid_x, B), blk(ELLC_GN_THREADS);
-  if (!continuation && use_coarse_kernel(c, B)) launch_coarse(c, B, fa);
   for (int i = 0; i < launches; i++) {
     const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
     const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
@@ -639,19 +591,12 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
   fa.res = c->result_dev_alias;
   fa.ica = 0;
   fa.xcd_map = (B % 8 == 0) ? 1 : 0;
-  fa.coarse_top = fa.coarse_min = 0;
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) { fa.nblk_lv[l] = 1; fa.max_it[l] = 0; }
   fa.nblk_grid = 1;
   fa.age_rounds = 0;
   for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
-  int top = c->L - 1;
-  if (use_coarse_kernel(c, B)) {
-    launch_coarse(c, B, fa);
-    top = coarse_min_level(c, B) - 1;
-  }
-  for (int level = top; level >= 0; level--) {
+  for (int level = c->L - 1; level >= 0; level--) {
     fa.g = make_gn_args(c, level, B, save_weights ? 1 : 0, nullptr);
-    fa.g.nblk = fca_nblk(c, level, B);
     set_age_split(c, fa, B);
     const dim3 grd(fa.g.nblk, B), blk(ELLC_GN_THREADS);
     for (int it = 0; it < c->cfg.max_iter[level]; it++) {
@@ -764,7 +709,6 @@ void ellc_default_config(ellc_config* cfg, int width, int height, int levels) {
   cfg->coalesce = 1;
   cfg->cache_records = 0;
   cfg->grid_batch = 0;
-  cfg->coarse = 0;
 }
 
 const char* ellc_last_error(const ellc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -792,7 +736,6 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   if (cfg->coalesce < 0 || cfg->coalesce > ellc_ctx::MAX_COALESCE) return ELLC_ERR_BAD_ARG;   // 0: as 1
   if (cfg->concurrent_batches < 0 || cfg->concurrent_batches > (ellc_ctx::STREAMS + 1) * ellc_ctx::MAX_COALESCE) return ELLC_ERR_BAD_ARG;   // 0: as 1
   if (cfg->grid_batch < 0 || cfg->grid_batch > 65536) return ELLC_ERR_BAD_ARG;
-  if (cfg->coarse < -1 || cfg->coarse > 1) return ELLC_ERR_BAD_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ELLC_ERR_NO_DEVICE;
   if (cfg->device < 0 || cfg->device >= ndev) return ELLC_ERR_BAD_ARG;
@@ -1377,7 +1320,7 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
 // graph ended before every alignment had (enqueue_schedule_adaptive), for the batch set selected in the context.
 static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int save_weights, int set, bool continuation) {
   auto body = [&]() -> ellc_status {
-    if (continuation) return enqueue_schedule_adaptive(c, B, save_weights, fine_total_iters(c, B) - c->cur_adaptive_first, true);
+    if (continuation) return enqueue_schedule_adaptive(c, B, save_weights, schedule_total_iters(c) - c->cur_adaptive_first, true);
     return enqueue_align_body(c, B, nu, mode, save_weights);
   };
   if (!c->use_graph) return body();
@@ -1659,13 +1602,12 @@ ellc_status ellc_align_fetch(ellc_ctx* c, int B, float* out_pose, int* out_iters
   }
   if (out == ELLC_OK && bs.adaptive) {   // the next state-driven call starts with a graph as long as this one needed, plus two
     int most = 0;
-    const int fine_top = use_coarse_kernel(c, B) ? coarse_min_level(c, B) - 1 : c->L - 1;   // the launches' levels
     for (int b = 0; b < B; b++) {
       int it = 0;
-      for (int l = 0; l <= fine_top; l++) it += res[b].iters[l];
+      for (int l = 0; l < c->L; l++) it += res[b].iters[l];
       most = std::max(most, it);
     }
-    c->adaptive_hint = std::min(fine_total_iters(c, B), std::max(std::min(c->L, fine_total_iters(c, B)), (most + 3) & ~1));
+    c->adaptive_hint = std::min(schedule_total_iters(c), std::max(c->L, (most + 3) & ~1));
   }
   if (out == ELLC_OK)
     for (int b = 0; b < B; b++) {

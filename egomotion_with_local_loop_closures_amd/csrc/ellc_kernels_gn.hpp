@@ -34,19 +34,8 @@ __device__ unsigned long long g_block_stamps[4 * 8192];   // per block: start, p
       g_stamps[id] = t__;                                                                                    \
     }                                                                                                        \
   } while (0)
-// gn_fca_coarse: stamps 4 * iteration + k of the first 15 iterations of block 0 (k: pass start, pixels done, sums combined, solved)
-#define ELLC_CSTAMP(k)                                                                                       \
-  do {                                                                                                       \
-    if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_it < 15) {                                              \
-      unsigned long long t__;                                                                                \
-      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                        \
-      g_stamps[4 * stamp_it + (k)] = t__;                                                                    \
-      if ((k) == 3) stamp_it++;                                                                              \
-    }                                                                                                        \
-  } while (0)
 #else
 #define ELLC_STAMP(id) do { } while (0)
-#define ELLC_CSTAMP(k) do { } while (0)
 #define ELLC_BSTAMP(slot) do { } while (0)
 #endif
 
@@ -1287,7 +1276,6 @@ struct FusedArgs {
   int max_it[ELLC_MAX_LEVELS];
   int nblk_grid;
   int win_lv[ELLC_MAX_LEVELS];   // 1: the pixel pass of this level serves its taps from LDS windows (fca_chunk_pass_win)
-  int coarse_top, coarse_min;   // gn_fca_coarse: the levels it runs, coarse_top down to coarse_min
   int continuation;     // 1: this graph continues a state-driven schedule whose first graph has already run (and added the saved weights
                         // of the alignments that ended there): its first launch marks those records cur_level = -2
 };
@@ -1297,9 +1285,9 @@ struct FusedArgs {
 // was requested by the caller before the solve. newS: exp(pose) of this iteration (LDS). Leaves the thread's 27 sums.
 template <bool DIVC, bool PIPE, bool FAST, int SAVEW>
 __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const float* newS, int begin,
-                                               int end, const FcaIn& first, const FcaInF& firstf, const FcaPre& first_pre, float (&sums)[27],
-                                               int t = (int)threadIdx.x) {   // t: the thread's index among the 256 that share the chunk
+                                               int end, const FcaIn& first, const FcaInF& firstf, const FcaPre& first_pre, float (&sums)[27]) {
   constexpr int stride = ELLC_GN_THREADS;
+  const int t = threadIdx.x;
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = newS[i];
@@ -1766,116 +1754,6 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
   fca_chunk_pass<DIVC, true, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
   block_reduce_store<27>(sums, out);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// cfg.coarse = 1 (opt-in; measured in r03, not the default): the coarse levels of an FCA schedule in ONE launch — one block
-// per alignment runs every iteration of the levels fa.coarse_top .. fa.coarse_min (pixel pass, reduction, solve, early-exit
-// test) without leaving the kernel; the pending sums go through LDS and the pose never leaves the block. The idea: 21 of the 32
-// launches of the 640x480 schedule are levels of 80x60 and 160x120 pixels, about 9 us each in the pipeline for a microsecond of
-// arithmetic. The measurement (stamps of block 0, tools/dbg/coarse_stamps.py): an iteration inside the kernel is 4.5 us of pixel
-// pass at 80x60 (10 us at 160x120: one CU, two waves per SIMD, and at these sizes about half the waves hold a point on the
-// image border and take the per-tap path), 2 us of reduction behind the slowest wave, 1.1 us of solve (2.7 us exact) — no
-// faster than a launch that spreads the level over several CUs. Staging the level's image and records in LDS made it slower
-// (5.3 us; the pass is bound by the CU's issue rate, not by its loads).
-//   The block is ELLC_COARSE_NB groups of 256 threads; group v takes chunk v of the level's list exactly as block v of a
-// level-bound launch with ELLC_COARSE_NB blocks per alignment does, its waves are reduced in that block's order, and the
-// groups' sums are combined in the order of partial_group_sum + solve_step: the bits are those of the launch-per-iteration
-// schedule with that block count (cfg.coarse = -1, fca_nblk), for any batch size — the kernel's parity test. The record goes
-// to the other state buffer with nothing pending and cur_level = coarse_min - 1: gn_fca_fused / gn_fca_adaptive /
-// gn_fused_finish continue from it as from a freshly staged one.
-#define ELLC_COARSE_NB 2
-#define ELLC_COARSE_THREADS (ELLC_COARSE_NB * ELLC_GN_THREADS)
-template <bool DIVC, bool FAST, int SAVEW>
-__global__ __launch_bounds__(ELLC_COARSE_THREADS) void gn_fca_coarse(const AlignState* src_state, FusedArgs fa) {
-  const GnArgs& a = fa.g;
-  const int b = blockIdx.x;
-  const AlignState& src = src_state[b];
-  AlignState* dst = a.state + (size_t)((fa.seq + 1) & 1) * fa.stride_state + b;
-  __shared__ SolveShared sh;
-  __shared__ float red[ELLC_COARSE_THREADS / 64][32];
-  __shared__ int s_iters[ELLC_MAX_LEVELS];
-  const int t = threadIdx.x, vb = t / ELLC_GN_THREADS, tv = t - vb * ELLC_GN_THREADS;
-  const int lane = t & 63, wave = t >> 6;
-  const int slot = a.kf_slot[b], frs = a.fr_slot[b];
-  int stamp_it = 0;
-  (void)stamp_it;
-  if (t < 6) sh.newpose[t] = src.pose[t];
-  if (t < 12) sh.newS[t] = src.S[t];
-  if (t == 0) { sh.weighted = src.weighted; sh.level_done = src.level_done; }
-  if (t < ELLC_MAX_LEVELS) s_iters[t] = src.iters[t];
-  __syncthreads();
-  for (int lvl = fa.coarse_top; lvl >= fa.coarse_min; lvl--) {
-    const int cap = fa.max_it[lvl];
-    if (cap < 1) continue;
-    const LevelGeom g = a.geom[lvl];
-    const KfLevelDev K = a.kf_tab[lvl * a.max_kf + slot];
-    const FrLevelDev& F = a.fr_tab[lvl * a.max_fr + frs];
-    const int V = *as_global(K.count);
-    const int chunk = (V + ELLC_COARSE_NB - 1) / ELLC_COARSE_NB;
-    const int begin = vb * chunk, end = min(V, begin + chunk);
-    g_u8 cur = as_global(F.img);
-    // the thread's first record is the same in every iteration of the level: loaded (exact mode: and prepared) once
-    FcaIn first;
-    first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.X = 0.0f; first.Y = 0.0f; first.invZ = 1.0;
-    FcaInF firstf;
-    firstf.xyI = 0; firstf.p = 0.0f; firstf.var = 0.0f; firstf.d = 1.0f;
-    FcaPre first_pre;
-    if constexpr (FAST) {
-      if (begin + tv < end) firstf = fcaf_load(K, (unsigned)(begin + tv));
-    } else {
-      if (begin + tv < end) first = fca_load(K, (unsigned)(begin + tv));
-      first_pre = fca_prepare<DIVC>(g, first);
-    }
-    int it = 0;
-    for (;;) {
-      ELLC_CSTAMP(0);
-      float sums[27];
-      fca_chunk_pass<DIVC, true, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums, tv);
-      ELLC_CSTAMP(1);
-      // block_reduce_store per group of four waves ...
-      float rows[WaveRows<27>::N2];
-      wave_sum_rows<27>(sums, rows);
-      if ((lane & 15) == 0) {
-        const int q = lane >> 4, col = 2 * (q & 1) + (q >> 1);
-#pragma unroll
-        for (int j = 0; j < WaveRows<27>::N2; j++) red[wave][4 * j + col] = rows[j];
-      }
-      __syncthreads();
-      // ... and partial_group_sum + the combine of solve_step over the ELLC_COARSE_NB "block records"
-      if (t < 27) {
-        double s = 0.0;
-#pragma unroll
-        for (int v = 0; v < ELLC_COARSE_NB; v++) {
-          float p = red[4 * v][t];
-#pragma unroll
-          for (int w = 1; w < ELLC_GN_THREADS / 64; w++) p += red[4 * v + w][t];
-          const double grp = 0.0 + (double)p;
-          s = (v == 0) ? grp : s + grp;
-        }
-        sh.sums[t] = s + 0.0;   // (the groups without a record contribute +0.0)
-      }
-      __syncthreads();
-      ELLC_CSTAMP(2);
-      if (FAST) solve_finish_fast(sh, 0, lvl, fa.early_exit, src, sh.newS, sh.level_done, nullptr);
-      else solve_finish(sh, 0, lvl, fa.early_exit, src, sh.newS, sh.level_done, nullptr);
-      ELLC_CSTAMP(3);
-      it++;
-      if (sh.level_done == lvl || it >= cap) break;   // block-uniform (LDS, behind the barrier that ends the solve)
-    }
-    if (t == 0) s_iters[lvl] += it;
-  }
-  __syncthreads();
-  if (t < 6) dst->pose[t] = sh.newpose[t];
-  if (t < 12) dst->S[t] = sh.newS[t];
-  if (t < ELLC_MAX_LEVELS) dst->iters[t] = s_iters[t];
-  if (t == 0) {
-    dst->weighted = sh.weighted;
-    dst->level_done = sh.level_done;
-    dst->pending = 0;
-    dst->cur_level = fa.coarse_min - 1;
-    dst->it_in_level = 0;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------

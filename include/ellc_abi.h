@@ -85,11 +85,6 @@ typedef struct {
                                  * every rank (e.g. max_batch): every alignment's result is then bit-identical to what ONE context
                                  * with the same N computes for the whole batch, for every world size (such a context always runs
                                  * the level-bound schedule, also for one or two alignments) */
-  int coarse;                   /* 0 (default): every Gauss-Newton iteration is a launch. 1: the smallest pyramid levels of an FCA
-                                 * schedule — up to 80x60 pixels; up to 160x120 when a launch covers 64 alignments or more — run ALL
-                                 * their iterations inside one launch, one workgroup per alignment (gn_fca_coarse; measured in r03:
-                                 * no faster than the launches). -1: the launches of those levels with the
-                                 * kernel's split of the pixels over threads: bit-identical to 1 (the kernel's parity check) */
 } ellc_config;
 
 typedef struct ellc_ctx ellc_ctx;

@@ -257,37 +257,6 @@ def test_grid_batch_makes_a_shard_bit_identical_to_the_whole_batch(ellc, arith, 
     ctx.close()
 
 
-@pytest.mark.parametrize("arith", ["exact", "fast"])
-@pytest.mark.parametrize("early_exit", [0, 1])
-def test_coarse_kernel_gives_the_bits_of_one_launch_per_iteration(ellc, arith, early_exit):
-    """cfg.coarse = 1: the small pyramid levels run all their iterations inside one launch, one workgroup per alignment
-    (gn_fca_coarse); cfg.coarse = -1 runs them as one launch per iteration like the others, with the kernel's block count.
-    Same split of the pixels over the
-    threads, same order of the 27 sums: poses, iteration counts, weightedPose and the saved weights are bit-identical — for a
-    batch (level-bound schedule), for one alignment (state-driven schedule when the early exit is on) and with the levels up to
-    160x120 in the kernel (the rule for launches over 64 alignments and more, here through cfg.grid_batch)."""
-    n = 3
-    pairs = [synth.make_pair(W, H, seed=60 + i, rot=0.003 + 0.002 * i, trans=0.012) for i in range(n)]
-    kw = dict(arith=ellc.ARITH_FAST) if arith == "fast" else {}
-    idx = np.arange(n)
-    for extra in (dict(), dict(grid_batch=64)):
-        ctxs = [gpu_problem(ellc, W, H, L, pairs, early_exit=early_exit, coarse=c, **extra, **kw) for c in (1, -1)]
-        out = []
-        for ctx in ctxs:
-            r = [ctx.align(idx, idx, save_weights=True), ctx.align([1], [1]), ctx.align([2, 0], [0, 2])]
-            w = [ctx.keyframe_weights(i, l) for i in range(n) for l in range(L)]
-            out.append((r, w))
-        for ra, rb in zip(out[0][0], out[1][0]):
-            for a_, b_ in zip(ra, rb):
-                assert np.array_equal(a_, b_), extra
-        for (wa, na), (wb, nb) in zip(out[0][1], out[1][1]):
-            assert na == nb and np.array_equal(wa, wb), extra
-        it = out[0][0][0][1]
-        assert np.all(it[:, L - 1] >= 1) and (early_exit or np.all(it == np.array([4, 7, 9, 12])[None, :L]))
-        for ctx in ctxs:
-            ctx.close()
-
-
 def test_copy_slot_across_contexts(ellc):
     """ellc_copy_slot_across: the loop-closure ring's deep copy (GlobalOptimize.cpp:185-186) between two contexts of one
     device — image pyramid, depth / variance / weight pyramids, weight counts, maxAbsGradient — ordered on the device against
