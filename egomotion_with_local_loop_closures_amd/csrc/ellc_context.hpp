@@ -168,6 +168,7 @@ struct ellc_ctx {
   // ellc_track_frame: the observation's matrices and the gate, built on the device behind the alignment; a host-visible record
   void* track_mats_d = nullptr;
   int* track_gate_d = nullptr;
+  int *obs_list = nullptr, *obs_ctr = nullptr;   // work list of dm_observe_select / dm_observe_walk and its counters (zero between calls)
   int* track_h = nullptr;
   int* track_dev_alias = nullptr;
   float Kinv[9], Kmat[9];

@@ -202,7 +202,28 @@ static ObsArgs observe_args(const ellc_ctx* c, int frame_slot) {
   a.fxi = c->Kinv[0]; a.cxi = c->Kinv[2]; a.fyi = c->Kinv[4]; a.cyi = c->Kinv[5];
   a.mats = nullptr;
   a.gate = nullptr;
+  a.list = c->obs_list;
+  a.ctr = c->obs_ctr;
+  {   // a region holds every pixel of the select blocks that append to it (block b -> region b mod DM_OBS_REGIONS)
+    const int blocks = ((a.W + 31) / 32) * ((a.H + 7) / 8);
+    a.region_cap = ((blocks + DM_OBS_REGIONS - 1) / DM_OBS_REGIONS) * 256;
+  }
   return a;
+}
+
+// observeDepthRow: candidate selection (a 32 x 8 tile per block), then the line stereo over the work list — a grid for the most
+// candidates there can be, the blocks past the list's end leave at once
+static void launch_observe(ellc_ctx* c, const ObsArgs& a, bool dev) {
+  const dim3 tiles((a.W + 31) / 32, (a.H + 7) / 8), blk(256);
+  const int most = std::max(0, a.W - 6) * std::max(0, a.H - 6);
+  const dim3 walk(std::max(1, (most + 255) / 256));
+  if (dev) {
+    hipLaunchKernelGGL(dm_observe_select<true>, tiles, blk, 0, c->stream, a);
+    hipLaunchKernelGGL(dm_observe_walk<true>, walk, blk, 0, c->stream, a);
+  } else {
+    hipLaunchKernelGGL(dm_observe_select<false>, tiles, blk, 0, c->stream, a);
+    hipLaunchKernelGGL(dm_observe_walk<false>, walk, blk, 0, c->stream, a);
+  }
 }
 
 static ellc_status do_observe(ellc_ctx* c, int frame_slot, const float* pose_frame_wrt_kf) {
@@ -211,7 +232,7 @@ static ellc_status do_observe(ellc_ctx* c, int frame_slot, const float* pose_fra
   build_obs_mats(c->Kmat, pose_frame_wrt_kf, m);   // observeDepthRowParallel :1935
   for (int i = 0; i < 3; i++) { a.otw_t[i] = m.otw_t[i]; a.Kt[i] = m.Kt[i]; a.tt[i] = m.tt[i]; }
   for (int i = 0; i < 9; i++) { a.Kr[i] = m.Kr[i]; a.Rr[i] = m.Rr[i]; }
-  hipLaunchKernelGGL(dm_observe<false>, dim3((a.W + 31) / 32, (a.H + 7) / 8), dim3(256), 0, c->stream, a);   // a 32 x 8 tile per 256-thread block
+  launch_observe(c, a, false);
   ELLC_HIP(c, hipGetLastError());
   return mark_frame_use(c, frame_slot);
 }
@@ -262,7 +283,7 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
   ObsArgs a = observe_args(c, frame_slot);
   a.mats = ta.mats;
   a.gate = ta.gate;
-  hipLaunchKernelGGL(dm_observe<true>, dim3((a.W + 31) / 32, (a.H + 7) / 8), dim3(256), 0, c->stream, a);
+  launch_observe(c, a, true);
   ELLC_HIP(c, hipGetLastError());
   if ((s = mark_frame_use(c, frame_slot)) != ELLC_OK) return s;
   if ((s = do_fill_holes(c, ta.gate)) != ELLC_OK || (s = do_regularize(c, 0, ta.gate)) != ELLC_OK) return s;   // doRegularization(false) :1627-1635

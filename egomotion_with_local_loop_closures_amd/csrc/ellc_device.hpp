@@ -81,6 +81,8 @@ struct FrLevelDev {
 };
 
 // Per-alignment state that persists across the launches of one ellc_align.
+#define DM_OBS_REGIONS 64   // regions of the depth map's observation work list (dm_observe_select / dm_observe_walk)
+
 struct AlignState {
   float pose[6];
   float S[12];                // exp(pose^) rounded to f32: r11 r12 r13 t1 | r21.. t2 | r31.. t3

@@ -888,6 +888,11 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   TRY(dev_alloc(c, &c->pr_id, n0)); TRY(dev_alloc(c, &c->pr_var, n0)); TRY(dev_alloc(c, &c->pr_remaining, 4));
   TRY(dev_alloc(c, &c->red_scratch, 4096));
   TRY(dev_alloc(c, (char**)&c->track_mats_d, 256)); TRY(dev_alloc(c, &c->track_gate_d, 4));
+  {   // (the arena is zeroed: the counters start at 0)
+    const size_t blocks = (size_t)((cfg->width + 31) / 32) * ((cfg->height + 7) / 8);
+    TRY(dev_alloc(c, &c->obs_list, ((blocks + DM_OBS_REGIONS - 1) / DM_OBS_REGIONS) * 256 * DM_OBS_REGIONS));
+    TRY(dev_alloc(c, &c->obs_ctr, 2 * DM_OBS_REGIONS + 1));
+  }
   // K and Kinv (EigenInitialization.cpp:20-34): cv 3x3 f32 inverse = f32 cofactors scaled by 1/det in double
   {
     const float K[9] = {cfg->fx, 0, cfg->cx, 0, cfg->fy, cfg->cy, 0, 0, 1};

@@ -22,6 +22,9 @@ namespace ellc {
 #define DM_MIN_EPL_LENGTH_CROP 3.0f        // :102
 #define DM_GRADIENT_SAMPLE_DIST 1.0f       // :105
 #define DM_SAMPLE_POINT_TO_BORDER 7.0f     // :108
+#ifndef DM_OBS_AHEAD
+#define DM_OBS_AHEAD 4                     // taps in flight ahead of the line stereo's walk (do_line_stereo)
+#endif
 #define DM_MAX_ERROR_STEREO 1300.0f        // :111
 #define DM_MIN_DISTANCE_ERROR_STEREO 1.5f  // :112
 #define DM_STEREO_EPL_VAR_FAC 2.0f         // :115
@@ -60,6 +63,38 @@ __device__ __forceinline__ void hyp_store(const DepthSoA& s, int i, const Hyp& h
 __device__ __forceinline__ float tap_plain(const uint8_t* img, int sw, int cols, int rows, float x, float y) {
   const Taps t = tap_point<false>(as_global(img), sw, cols, rows, x, y);
   return (t.I == -1.0f) ? 0.0f : t.I;   // four zero samples interpolate to 0 (NaN coordinates: reference UB)
+}
+
+// The same tap with its two loads issued ahead of its use. The line stereo is a chain of taps whose POSITIONS do not depend on
+// the image (an epipolar walk of up to 30 + steps, one tap each): taken one at a time every step waits a trip to L2 / HBM
+// (~1 us), and the launch lasts as long as its longest walk. raw_tap_load fetches the two rows of the 2 x 2 neighbourhood as
+// (byte-unaligned) words for a position, clamped into the interior so that a look-ahead past the walk's end stays in the image;
+// tap_plain_raw turns them into the tap when the position is interior — tap_point's interior expression, the same bits — and
+// falls back to tap_plain (its per-tap bounds path) when it is not.
+struct RawTap { uint32_t wb, wc; };
+__device__ __forceinline__ RawTap raw_tap_load(const uint8_t* img, int sw, int cols, int rows, float x, float y) {
+  const float fx0 = fminf(fmaxf(floorf(x), 1.0f), (float)(cols - 3)), fy0 = fminf(fmaxf(floorf(y), 1.0f), (float)(rows - 3));   // NaN -> 1
+  const unsigned ob = __umul24((unsigned)(int)fy0, (unsigned)sw) + (unsigned)(int)fx0 - 1u;
+  RawTap r;
+  r.wb = load_u32_unaligned(as_global(img), ob);
+  r.wc = load_u32_unaligned(as_global(img), ob + (unsigned)sw);
+  return r;
+}
+__device__ __forceinline__ float tap_plain_raw(const uint8_t* img, int sw, int cols, int rows, float x, float y, const RawTap& r) {
+  const float fx0 = floorf(x), fy0 = floorf(y);
+  const bool interior = (__builtin_amdgcn_fmed3f(fx0, 1.0f, (float)(cols - 3)) == fx0) & (__builtin_amdgcn_fmed3f(fy0, 1.0f, (float)(rows - 3)) == fy0);
+  float v;
+  if (interior) {
+    const float wx = x - fx0, wy = y - fy0;
+    const float omx = 1.0f - wx, omy = 1.0f - wy;
+    const float Pbb = byte_f32<1>(r.wb), Pbc = byte_f32<2>(r.wb), Pcb = byte_f32<1>(r.wc), Pcc = byte_f32<2>(r.wc);
+    const float top = (omx * Pbb) + (wx * Pbc);
+    const float btm = (omx * Pcb) + (wx * Pcc);
+    v = (omy * top) + (wy * btm);
+  } else {
+    v = tap_plain(img, sw, cols, rows, x, y);
+  }
+  return v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -584,6 +619,9 @@ struct ObsArgs {
   float Rr[9], tt[3];        // SE3poseThisWrtOther_r / _t
   const struct ObsMats* mats;   // dm_observe<true>: the five matrices above come from here (device memory, dm_track_setup)
   const int* gate;              //   and nothing is done unless *gate != 0
+  int* list;                    // work list of the two observe kernels: DM_OBS_REGIONS regions of region_cap pixel indices each,
+  int region_cap;               //   a region filled with creations from its front and updates from its back
+  int* ctr;                     //   [2 r + kind] entries of region r, [2 DM_OBS_REGIONS] blocks of dm_observe_walk that have finished
 };
 
 // The matrices of frame::calculateSE3poseOtherWrtThis (Frame.cpp:376-413) that observeDepthRow uses, for a frame whose
@@ -711,11 +749,17 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
     return -1.0f;
   if (!(rescaleFactor > 0.7f && rescaleFactor < 1.4f)) return -1.0f;
 
-  const float realVal_p1 = tap_plain(a.kfImg, a.sw, W, H, u + epxn * rescaleFactor, v + epyn * rescaleFactor);
-  const float realVal_m1 = tap_plain(a.kfImg, a.sw, W, H, u - epxn * rescaleFactor, v - epyn * rescaleFactor);
-  const float realVal = tap_plain(a.kfImg, a.sw, W, H, u, v);
-  const float realVal_m2 = tap_plain(a.kfImg, a.sw, W, H, u - 2 * epxn * rescaleFactor, v - 2 * epyn * rescaleFactor);
-  const float realVal_p2 = tap_plain(a.kfImg, a.sw, W, H, u + 2 * epxn * rescaleFactor, v + 2 * epyn * rescaleFactor);
+  // (the five keyframe taps: loads issued together, see raw_tap_load)
+  const float kx_p1 = u + epxn * rescaleFactor, ky_p1 = v + epyn * rescaleFactor, kx_m1 = u - epxn * rescaleFactor, ky_m1 = v - epyn * rescaleFactor;
+  const float kx_m2 = u - 2 * epxn * rescaleFactor, ky_m2 = v - 2 * epyn * rescaleFactor, kx_p2 = u + 2 * epxn * rescaleFactor, ky_p2 = v + 2 * epyn * rescaleFactor;
+  const RawTap rk_p1 = raw_tap_load(a.kfImg, a.sw, W, H, kx_p1, ky_p1), rk_m1 = raw_tap_load(a.kfImg, a.sw, W, H, kx_m1, ky_m1);
+  const RawTap rk_0 = raw_tap_load(a.kfImg, a.sw, W, H, u, v);
+  const RawTap rk_m2 = raw_tap_load(a.kfImg, a.sw, W, H, kx_m2, ky_m2), rk_p2 = raw_tap_load(a.kfImg, a.sw, W, H, kx_p2, ky_p2);
+  const float realVal_p1 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_p1, ky_p1, rk_p1);
+  const float realVal_m1 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_m1, ky_m1, rk_m1);
+  const float realVal = tap_plain_raw(a.kfImg, a.sw, W, H, u, v, rk_0);
+  const float realVal_m2 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_m2, ky_m2, rk_m2);
+  const float realVal_p2 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_p2, ky_p2, rk_p2);
 
   float pClose[3] = {pInf[0] + a.Kt[0] * max_idepth, pInf[1] + a.Kt[1] * max_idepth, pInf[2] + a.Kt[2] * max_idepth};
   if (pClose[2] < 0.001f) {
@@ -770,10 +814,24 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
   }
 
   float cpx = pFar[0], cpy = pFar[1];
-  float val_cp_m2 = tap_plain(a.curImg, a.sw, W, H, cpx - 2.0f * incx, cpy - 2.0f * incy);
-  float val_cp_m1 = tap_plain(a.curImg, a.sw, W, H, cpx - incx, cpy - incy);
-  float val_cp = tap_plain(a.curImg, a.sw, W, H, cpx, cpy);
-  float val_cp_p1 = tap_plain(a.curImg, a.sw, W, H, cpx + incx, cpy + incy);
+  // the taps of the next DM_OBS_AHEAD steps are in flight while a step is evaluated: (lx, ly) runs that many steps ahead of
+  // (cpx, cpy) through the walk's own recurrence (the same additions from the same start: the same positions, bit for bit)
+  constexpr int AHEAD = DM_OBS_AHEAD;
+  RawTap q[AHEAD];
+  float lx = cpx, ly = cpy;
+  const RawTap rc_m2 = raw_tap_load(a.curImg, a.sw, W, H, cpx - 2.0f * incx, cpy - 2.0f * incy);
+  const RawTap rc_m1 = raw_tap_load(a.curImg, a.sw, W, H, cpx - incx, cpy - incy);
+  const RawTap rc_0 = raw_tap_load(a.curImg, a.sw, W, H, cpx, cpy);
+  const RawTap rc_p1 = raw_tap_load(a.curImg, a.sw, W, H, cpx + incx, cpy + incy);
+#pragma unroll
+  for (int d = 0; d < AHEAD; d++) {
+    q[d] = raw_tap_load(a.curImg, a.sw, W, H, lx + 2 * incx, ly + 2 * incy);
+    lx += incx; ly += incy;
+  }
+  float val_cp_m2 = tap_plain_raw(a.curImg, a.sw, W, H, cpx - 2.0f * incx, cpy - 2.0f * incy, rc_m2);
+  float val_cp_m1 = tap_plain_raw(a.curImg, a.sw, W, H, cpx - incx, cpy - incy, rc_m1);
+  float val_cp = tap_plain_raw(a.curImg, a.sw, W, H, cpx, cpy, rc_0);
+  float val_cp_p1 = tap_plain_raw(a.curImg, a.sw, W, H, cpx + incx, cpy + incy, rc_p1);
   float val_cp_p2;
 
   int loopCounter = 0;
@@ -790,7 +848,11 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
 #pragma unroll 1
 #endif
   while ((((incx < 0) == (cpx > pClose[0]) && (incy < 0) == (cpy > pClose[1])) || loopCounter == 0) && loopCounter < loopCap) {
-    val_cp_p2 = tap_plain(a.curImg, a.sw, W, H, cpx + 2 * incx, cpy + 2 * incy);
+    val_cp_p2 = tap_plain_raw(a.curImg, a.sw, W, H, cpx + 2 * incx, cpy + 2 * incy, q[0]);
+#pragma unroll
+    for (int d = 0; d + 1 < AHEAD; d++) q[d] = q[d + 1];
+    q[AHEAD - 1] = raw_tap_load(a.curImg, a.sw, W, H, lx + 2 * incx, ly + 2 * incy);
+    lx += incx; ly += incy;
     float ee = 0;
     if (loopCounter % 2 == 0) {
       e1A = val_cp_p2 - realVal_p2; ee += e1A * e1A;
@@ -905,38 +967,26 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
   return best_match_err;
 }
 
-// How long will the epipolar walk of do_line_stereo be for this pixel? A cheap restatement of its geometry (no taps, not bit
-// for bit: it only ORDERS the work, every candidate still runs do_line_stereo itself): 0 when the walk will not start.
-__device__ __forceinline__ float line_stereo_walk_estimate(const ObsArgs& a, float u, float v, float min_idepth, float prior_idepth, float max_idepth) {
-  const float KinvP[3] = {a.fxi * u + a.cxi, a.fyi * v + a.cyi, 1.0f};
-  const float pInf[3] = {dot3f(a.Kr, KinvP), dot3f(a.Kr + 3, KinvP), dot3f(a.Kr + 6, KinvP)};
-  const float rescaleFactor = (pInf[2] / prior_idepth + a.Kt[2]) * prior_idepth;
-  if (!(rescaleFactor > 0.7f && rescaleFactor < 1.4f)) return 0.0f;
-  float pcz = pInf[2] + a.Kt[2] * max_idepth;
-  if (pcz < 0.001f) {
-    max_idepth = (0.001f - pInf[2]) / a.Kt[2];
-    pcz = pInf[2] + a.Kt[2] * max_idepth;
-  }
-  const float pfz = pInf[2] + a.Kt[2] * min_idepth;
-  if (pfz < 0.001f || max_idepth < min_idepth) return 0.0f;
-  const float cx = (pInf[0] + a.Kt[0] * max_idepth) / pcz, cy = (pInf[1] + a.Kt[1] * max_idepth) / pcz;
-  const float fx = (pInf[0] + a.Kt[0] * min_idepth) / pfz, fy = (pInf[1] + a.Kt[1] * min_idepth) / pfz;
-  const float len = sqrtf((cx - fx) * (cx - fx) + (cy - fy) * (cy - fy));
-  if (!(len > 0.0f) || isinf(len)) return 0.0f;
-  const float Bd = DM_SAMPLE_POINT_TO_BORDER;
-  if (fx <= Bd || fx >= (float)a.W - Bd || fy <= Bd || fy >= (float)a.H - Bd) return 0.0f;
-  return fminf(fmaxf(len, DM_MIN_EPL_LENGTH_CROP), DM_MAX_EPL_LENGTH_CROP) + 2.0f;
-}
-
 // observeDepthRow for one pixel whose epipolar direction (epx, epy) passed makeAndCheckEPL: observeDepthCreate (:267-308) or
-// observeDepthUpdate (:888-999)
+// observeDepthUpdate (:888-999). One call site of do_line_stereo for both — its search range is what differs — so that a wave
+// holding creations and updates runs the 2 300 instructions around the walk once, not once per kind.
 __device__ __forceinline__ void observe_pixel(const ObsArgs& a, int x, int y, int idx, float epx, float epy) {
   Hyp t = hyp_load(a.s, idx);
   const float mg = a.kfMaxGrad[idx];
-  if (!t.valid) {
+  const bool create = !t.valid;
+  float min_idepth = 0.0f, prior_idepth = 1.0f, max_idepth = 1.0f / DM_MIN_DEPTH;
+  if (!create) {
+    const float sv = sqrtf(t.vars);
+    min_idepth = t.ids - sv * DM_STEREO_EPL_VAR_FAC;
+    max_idepth = t.ids + sv * DM_STEREO_EPL_VAR_FAC;
+    if (min_idepth < 0) min_idepth = 0;
+    if (max_idepth > 1 / DM_MIN_DEPTH) max_idepth = 1 / DM_MIN_DEPTH;
+    prior_idepth = t.ids;
+  }
+  float rid = 0.0f, rvar = 0.0f;
+  const float error = do_line_stereo(a, (float)x, (float)y, epx, epy, min_idepth, prior_idepth, max_idepth, rid, rvar);
+  if (create) {
     // observeDepthCreate
-    float rid = 0.0f, rvar = 0.0f;
-    const float error = do_line_stereo(a, (float)x, (float)y, epx, epy, 0.0f, 1.0f, 1.0f / DM_MIN_DEPTH, rid, rvar);
     if (error == -3.0f || error == -2.0f) t.bl--;
     if (error < 0 || rvar > DM_MAX_VAR) {
       a.s.blacklisted[idx] = t.bl;
@@ -952,13 +1002,6 @@ __device__ __forceinline__ void observe_pixel(const ObsArgs& a, int x, int y, in
     hyp_store(a.s, idx, t);
   } else {
     // observeDepthUpdate
-    const float sv = sqrtf(t.vars);
-    float min_idepth = t.ids - sv * DM_STEREO_EPL_VAR_FAC;
-    float max_idepth = t.ids + sv * DM_STEREO_EPL_VAR_FAC;
-    if (min_idepth < 0) min_idepth = 0;
-    if (max_idepth > 1 / DM_MIN_DEPTH) max_idepth = 1 / DM_MIN_DEPTH;
-    float rid = 0.0f, rvar = 0.0f;
-    const float error = do_line_stereo(a, (float)x, (float)y, epx, epy, min_idepth, t.ids, max_idepth, rid, rvar);
     const float diff = rid - t.ids;
     if (error == -1.0f) return;
     if (error == -2.0f) {
@@ -992,82 +1035,119 @@ __device__ __forceinline__ void observe_pixel(const ObsArgs& a, int x, int y, in
   }
 }
 
-// Two phases per 32 x 8 tile. Phase 1, one lane per pixel: the cheap tests of observeDepthRow (:191-263) and makeAndCheckEPL;
-// the pixels that go on to the line stereo are entered in a list ordered by the estimated LENGTH of their walk. Phase 2: the
-// waves take consecutive list entries, so lanes of one wave walk about equally far. (Pixel per lane all the way, a wave ran
-// as long as its longest walk — a depth creation spans the whole inverse-depth range, ~30 steps, an update a few — with a
-// third of its lanes active: 19.7 M wave instructions per launch in r02, 47 us.) The pixels are independent: same results.
-#define DM_OBS_BUCKETS 4
-__device__ __forceinline__ void observe_tile(const ObsArgs& a) {
-  __shared__ uint8_t list[256];
-  __shared__ float s_epx[256], s_epy[256];
-  __shared__ int counts[DM_OBS_BUCKETS][4];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int x = blockIdx.x * 32 + tx, y = blockIdx.y * 8 + ty;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int bucket = -1;
+// the matrices of a tracked-frame call come from device memory (dm_track_setup)
+__device__ __forceinline__ void obs_load_mats(ObsArgs& b) {
+  const ObsMats& m = *b.mats;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { b.otw_t[i] = m.otw_t[i]; b.Kt[i] = m.Kt[i]; b.tt[i] = m.tt[i]; }
+#pragma unroll
+  for (int i = 0; i < 9; i++) { b.Kr[i] = m.Kr[i]; b.Rr[i] = m.Rr[i]; }
+}
+
+// observeDepthRow in two launches. dm_observe_select, one lane per pixel: the cheap tests (:191-263) and makeAndCheckEPL; the
+// pixels that go on to the line stereo are appended to a device-wide work list — creations (no hypothesis: the search spans
+// the whole inverse-depth range, a walk of ~30 steps) and updates (a few steps) apart. dm_observe_walk: lane k takes entry k of
+// all creations followed by all updates, so every wave is full and, but for the one that straddles the boundary, holds walks
+// of one kind. (One launch with a pixel per lane ran every wave as long as its longest walk with a third of its lanes active:
+// 19.7 M wave instructions, 47 us in r02; compacted and sorted per 32 x 8 tile, r03, still 12 000 instructions per tile in two
+// waves, one of them a tenth full: 42 us.) The pixels are independent, so their order does not matter: same results.
+//   The list is DM_OBS_REGIONS regions, block b appending to region b mod DM_OBS_REGIONS with one atomic per kind —
+// creations from the region's front, updates from its back (a region holds every pixel of its blocks: the ends never meet).
+// (One list with one pair of counters and an atomic per wave: 9 600 atomics on two words serialise, the select launch took 98 us;
+// 64 regions: 24 us; with the waves' counts combined in LDS, one atomic per block and kind.) A walk block scans
+// the 2 x 64 counters in LDS and finds an entry's region by bisection. The counters are zero between calls: the last block of
+// dm_observe_walk to finish clears them (every block has read them by then). DEV: the tracked-frame call — nothing is done
+// while the gate is closed.
+template <bool DEV>
+__global__ __launch_bounds__(256) void dm_observe_select(ObsArgs a) {
+  if (DEV) {
+    if (*a.gate == 0) return;
+    obs_load_mats(a);
+  }
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  const int lane = threadIdx.x & 63;
+  const int idx = x + y * a.W;
+  int kind = -1;   // 0: creation, 1: update
   if (x >= 3 && x < a.W - 3 && y >= 3 && y < a.H - 3) {
-    const int idx = x + y * a.W;
     const bool hasHypothesis = a.s.isValid[idx] != 0;
     const float mg = a.kfMaxGrad[idx];
     if (hasHypothesis && mg < DM_MIN_ABS_GRAD_DECREASE) {
       a.s.isValid[idx] = 0;
     } else if (!(mg < DM_MIN_ABS_GRAD_CREATE || a.s.blacklisted[idx] < DM_MIN_BLACKLIST)) {
       float epx, epy;
-      if (make_and_check_epl(a, x, y, epx, epy)) {   // (else create: -1 / update: -5, no state change)
-        s_epx[threadIdx.x] = epx;
-        s_epy[threadIdx.x] = epy;
-        float est;
-        if (!hasHypothesis) {
-          est = line_stereo_walk_estimate(a, (float)x, (float)y, 0.0f, 1.0f, 1.0f / DM_MIN_DEPTH);
-        } else {
-          const float ids = a.s.invDepthSmoothed[idx], sv = sqrtf(a.s.varianceSmoothed[idx]);
-          est = line_stereo_walk_estimate(a, (float)x, (float)y, fmaxf(ids - sv * DM_STEREO_EPL_VAR_FAC, 0.0f), ids,
-                                          fminf(ids + sv * DM_STEREO_EPL_VAR_FAC, 1 / DM_MIN_DEPTH));
-        }
-        bucket = est >= 24.0f ? 0 : (est >= 12.0f ? 1 : (est >= 6.0f ? 2 : 3));   // NaN: bucket 3
-      }
+      if (make_and_check_epl(a, x, y, epx, epy)) kind = hasHypothesis ? 1 : 0;   // (else create: -1 / update: -5, no state change)
     }
   }
+  // one atomic per block and kind: the waves' counts meet in LDS
+  __shared__ int cnt[2][4], base[2];
+  const int wave = threadIdx.x >> 6;
   unsigned long long mine = 0ull;
 #pragma unroll
-  for (int b = 0; b < DM_OBS_BUCKETS; b++) {
-    const unsigned long long m = __ballot(bucket == b);
-    if (lane == 0) counts[b][wave] = __popcll(m);
-    if (bucket == b) mine = m;
+  for (int k = 0; k < 2; k++) {
+    const unsigned long long m = __ballot(kind == k);
+    if (lane == 0) cnt[k][wave] = __popcll(m);
+    if (kind == k) mine = m;
   }
   __syncthreads();
-  int base = 0, total = 0;
-#pragma unroll
-  for (int b = 0; b < DM_OBS_BUCKETS; b++)
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      const int c = counts[b][w];
-      if (b < bucket || (b == bucket && w < wave)) base += c;
-      total += c;
-    }
-  if (bucket >= 0) list[base + __popcll(mine & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = (uint8_t)threadIdx.x;
+  const int region = (int)((blockIdx.y * gridDim.x + blockIdx.x) % DM_OBS_REGIONS);
+  if (threadIdx.x < 2) {
+    const int k = threadIdx.x, total = cnt[k][0] + cnt[k][1] + cnt[k][2] + cnt[k][3];
+    base[k] = total > 0 ? atomicAdd(&a.ctr[2 * region + k], total) : 0;
+  }
   __syncthreads();
-  for (int k = threadIdx.x; k < total; k += 256) {
-    const int p = list[k];
-    const int px = blockIdx.x * 32 + (p & 31), py = blockIdx.y * 8 + (p >> 5);
-    observe_pixel(a, px, py, px + py * a.W, s_epx[p], s_epy[p]);
+  if (kind >= 0) {
+    int pos = base[kind] + __popcll(mine & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+    for (int w = 0; w < wave; w++) pos += cnt[kind][w];
+    int* rlist = a.list + (size_t)region * a.region_cap;
+    if (pos < a.region_cap) rlist[kind == 0 ? pos : a.region_cap - 1 - pos] = idx;
   }
 }
-// DEV: the tracked-frame call — matrices from device memory (dm_track_setup), nothing done while the gate is closed
+
 template <bool DEV>
-__global__ __launch_bounds__(256) void dm_observe(ObsArgs a) {
+__global__ __launch_bounds__(256) void dm_observe_walk(ObsArgs a) {
   if (DEV) {
     if (*a.gate == 0) return;
-    ObsArgs b = a;
-    const ObsMats& m = *a.mats;
+    obs_load_mats(a);
+  }
+  // exclusive prefixes of the regions' creation / update counts (wave 0 and wave 1 scan one kind each)
+  __shared__ int pre[2][DM_OBS_REGIONS + 1];
+  {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (w < 2) {
+      static_assert(DM_OBS_REGIONS == 64, "one lane per region");
+      const int c = min(max(a.ctr[2 * lane + w], 0), a.region_cap);
+      int incl = c;
 #pragma unroll
-    for (int i = 0; i < 3; i++) { b.otw_t[i] = m.otw_t[i]; b.Kt[i] = m.Kt[i]; b.tt[i] = m.tt[i]; }
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+      }
+      pre[w][lane + 1] = incl;
+      if (lane == 0) pre[w][0] = 0;
+    }
+  }
+  __syncthreads();
+  const int C = pre[0][DM_OBS_REGIONS], U = pre[1][DM_OBS_REGIONS];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < C + U) {
+    const int kind = (k < C) ? 0 : 1;
+    const int kk = kind ? k - C : k;
+    int lo = 0;   // the region r with pre[r] <= kk < pre[r + 1]
 #pragma unroll
-    for (int i = 0; i < 9; i++) { b.Kr[i] = m.Kr[i]; b.Rr[i] = m.Rr[i]; }
-    observe_tile(b);
-  } else {
-    observe_tile(a);
+    for (int step = DM_OBS_REGIONS / 2; step >= 1; step >>= 1)
+      if (pre[kind][lo + step] <= kk) lo += step;
+    const int off = kk - pre[kind][lo];
+    const int* rlist = a.list + (size_t)lo * a.region_cap;
+    const int idx = kind ? rlist[a.region_cap - 1 - off] : rlist[off];
+    const int y = idx / a.W, x = idx - y * a.W;
+    float epx, epy;
+    if (make_and_check_epl(a, x, y, epx, epy)) observe_pixel(a, x, y, idx, epx, epy);   // (true again: it put the pixel on the list)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int done = atomicAdd(&a.ctr[2 * DM_OBS_REGIONS], 1);
+    if (done == (int)gridDim.x - 1)   // every block has read the counters: ready for the next call
+      for (int i = 0; i <= 2 * DM_OBS_REGIONS; i++) a.ctr[i] = 0;
   }
 }
 

@@ -125,7 +125,7 @@ if f:
 f = newest(os.path.join("depth_trace", "*", "*_kernel_trace.csv"))
 if f:
     N = 640 * 480
-    bpp = {"dm_regularize": 50.0, "dm_fill_holes": 50.0, "dm_observe": 94.0, "dm_export_level0": 21.0, "depth_pyr_level": None,
+    bpp = {"dm_regularize": 50.0, "dm_fill_holes": 50.0, "dm_observe_walk": 94.0, "dm_observe_select": None, "dm_export_level0": 21.0, "depth_pyr_level": None,
            "dm_prop_project": 61.0, "dm_prop_fold": None, "dm_rescale": None, "dm_sum_stage1": None}
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
