@@ -755,11 +755,12 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
   const RawTap rk_p1 = raw_tap_load(a.kfImg, a.sw, W, H, kx_p1, ky_p1), rk_m1 = raw_tap_load(a.kfImg, a.sw, W, H, kx_m1, ky_m1);
   const RawTap rk_0 = raw_tap_load(a.kfImg, a.sw, W, H, u, v);
   const RawTap rk_m2 = raw_tap_load(a.kfImg, a.sw, W, H, kx_m2, ky_m2), rk_p2 = raw_tap_load(a.kfImg, a.sw, W, H, kx_p2, ky_p2);
-  const float realVal_p1 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_p1, ky_p1, rk_p1);
-  const float realVal_m1 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_m1, ky_m1, rk_m1);
-  const float realVal = tap_plain_raw(a.kfImg, a.sw, W, H, u, v, rk_0);
-  const float realVal_m2 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_m2, ky_m2, rk_m2);
-  const float realVal_p2 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_p2, ky_p2, rk_p2);
+  // ... and the four neighbours of (u, v) the tail's keyframe gradient is made of (u, v are whole pixels, 3 <= x < W - 3: the
+  // bilinear gradient tap of Frame.h:283-394 collapses to the central differences of its sample at weight 1, bit for bit);
+  // all of them are used behind the geometry below, so that it runs while they are in flight
+  const unsigned kc = __umul24((unsigned)(int)v, (unsigned)a.sw) + (unsigned)(int)u;
+  const uint8_t kg_l = as_global(a.kfImg)[kc - 1u], kg_r = as_global(a.kfImg)[kc + 1u];
+  const uint8_t kg_u = as_global(a.kfImg)[kc - (unsigned)a.sw], kg_d = as_global(a.kfImg)[kc + (unsigned)a.sw];
 
   float pClose[3] = {pInf[0] + a.Kt[0] * max_idepth, pInf[1] + a.Kt[1] * max_idepth, pInf[2] + a.Kt[2] * max_idepth};
   if (pClose[2] < 0.001f) {
@@ -828,6 +829,11 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
     q[d] = raw_tap_load(a.curImg, a.sw, W, H, lx + 2 * incx, ly + 2 * incy);
     lx += incx; ly += incy;
   }
+  const float realVal_p1 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_p1, ky_p1, rk_p1);
+  const float realVal_m1 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_m1, ky_m1, rk_m1);
+  const float realVal = tap_plain_raw(a.kfImg, a.sw, W, H, u, v, rk_0);
+  const float realVal_m2 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_m2, ky_m2, rk_m2);
+  const float realVal_p2 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_p2, ky_p2, rk_p2);
   float val_cp_m2 = tap_plain_raw(a.curImg, a.sw, W, H, cpx - 2.0f * incx, cpy - 2.0f * incy, rc_m2);
   float val_cp_m1 = tap_plain_raw(a.curImg, a.sw, W, H, cpx - incx, cpy - incy, rc_m1);
   float val_cp = tap_plain_raw(a.curImg, a.sw, W, H, cpx, cpy, rc_0);
@@ -843,7 +849,11 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
   float e1A = NaNf, e1B = NaNf, e2A = NaNf, e2B = NaNf, e3A = NaNf, e3B = NaNf, e4A = NaNf, e4B = NaNf, e5A = NaNf, e5B = NaNf;
   int loopCBest = -1, loopCSecond = -1;
   // the walk is bounded: the segment is at most MAX_EPL_LENGTH_CROP + padding long and inside the image
+#ifdef DM_OBS_NOLOOP   // timing experiment (wrong results): the launch without its walks
+  const int loopCap = 0;
+#else
   const int loopCap = W + H;
+#endif
 #ifdef ELLC_OBS_NOUNROLL
 #pragma unroll 1
 #endif
@@ -958,8 +968,7 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
   if (idnew_best_match < 0) return -2.0f;
   const float photoDispError = 4.0f * (float)DM_CAMERA_PIXEL_NOISE / (gradAlongLine + DM_DIVISION_EPS);
   const float trackingErrorFac = 0.25f * 1.0f;
-  const Taps gt = tap_point<true>(as_global(a.kfImg), a.sw, W, H, u, v);
-  const float g0 = gt.gx, g1 = gt.gy;
+  const float g0 = 0.5f * ((float)kg_r - (float)kg_l), g1 = 0.5f * ((float)kg_d - (float)kg_u);   // keyframe gradient at (u, v), see above
   float geoDispError = (g0 * epxn + g1 * epyn) + DM_DIVISION_EPS;
   geoDispError = trackingErrorFac * trackingErrorFac * (g0 * g0 + g1 * g1) / (geoDispError * geoDispError);
   result_var = alpha * alpha * ((didSubpixel ? 0.05f : 0.5f) * sampleDist * sampleDist + geoDispError + photoDispError);
