@@ -849,14 +849,7 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
   float e1A = NaNf, e1B = NaNf, e2A = NaNf, e2B = NaNf, e3A = NaNf, e3B = NaNf, e4A = NaNf, e4B = NaNf, e5A = NaNf, e5B = NaNf;
   int loopCBest = -1, loopCSecond = -1;
   // the walk is bounded: the segment is at most MAX_EPL_LENGTH_CROP + padding long and inside the image
-#ifdef DM_OBS_NOLOOP   // timing experiment (wrong results): the launch without its walks
-  const int loopCap = 0;
-#else
   const int loopCap = W + H;
-#endif
-#ifdef ELLC_OBS_NOUNROLL
-#pragma unroll 1
-#endif
   while ((((incx < 0) == (cpx > pClose[0]) && (incy < 0) == (cpy > pClose[1])) || loopCounter == 0) && loopCounter < loopCap) {
     val_cp_p2 = tap_plain_raw(a.curImg, a.sw, W, H, cpx + 2 * incx, cpy + 2 * incy, q[0]);
 #pragma unroll
