@@ -227,6 +227,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.rehearse_launcher:
         return rehearse_launcher(a, world, rank, local_rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (before the HIP runtime starts: RCCL's IPC needs the dmabuf mode on this host driver)
     from egomotion_with_local_loop_closures_amd import _lib
     if a.lib:
         _lib.use_library(a.lib)
@@ -234,9 +235,12 @@ def main():
     ndev = _lib.lib().ellc_device_count()
     if ndev < 1:
         raise SystemExit("bench.py: no HIP device is visible (there is no CPU fallback for the product path)")
-    if a.backend == "nccl" and world > 1 and local_rank >= ndev:
-        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible) and RCCL refuses two ranks on one device; "
-                         "--backend gloo rehearses several ranks on one GPU over the TCP transport" % (rank, ndev))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if a.backend == "nccl" and world > 1 and local_world > ndev:   # (the same on every rank of the node: no rank starts RCCL)
+        sys.stderr.write("bench.py: rank %d: %d ranks on this node but %d GPU(s) visible — RCCL refuses two ranks on one device: the poses are "
+                         "gathered over the TCP transport and the ranks SHARE GPUs (not a scaling measurement)\n" % (rank, local_world, ndev))
+        a.backend = "tcp"
+        a.ranks_share_gpus = True
     dev_index = local_rank % ndev
     ctl = Control(sharding, world, rank)
 
@@ -260,10 +264,22 @@ def main():
     depth = 4                                   # exchanges in flight: the library keeps a ring of four (ellc_comm)
     comm = None
     if gathering:
-        if a.backend == "nccl":
+        transport = "rccl" if a.backend == "nccl" else "tcp"
+        rccl_error = ""
+        if transport == "rccl":
             uid = ctl.broadcast_id(sharding.Comm.unique_id)
-            comm = sharding.Comm(world, rank, max_total=per_max, transport="rccl", device=dev_index, unique_id=uid)
-        else:   # rehearsal of several ranks on one GPU: the same entry points over TCP
+            try:
+                comm = sharding.Comm(world, rank, max_total=per_max, transport="rccl", device=dev_index, unique_id=uid)
+            except Exception as e:   # (the ranks then agree on the TCP transport below, and the line says so)
+                rccl_error = "%s: %s" % (type(e).__name__, e)
+            if ctl.max(1.0 if comm is None else 0.0) > 0.0:   # some rank has no RCCL communicator: none uses it
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                transport = "tcp"
+                sys.stderr.write("bench.py: rank %d: RCCL communicator not available (%s): the poses are gathered over the TCP transport\n"
+                                 % (rank, rccl_error or "another rank failed"))
+        if transport == "tcp":   # rehearsal of several ranks on one GPU, or the fallback: the same entry points over TCP
             comm = sharding.Comm(world, rank, max_total=per_max, transport="tcp", host=os.environ.get("MASTER_ADDR", "127.0.0.1"),
                                  port=int(os.environ.get("MASTER_PORT", "29500")) + 18)
     outstanding = []   # rows of each exchange in flight, oldest first
@@ -321,7 +337,8 @@ def main():
     gather_txt = ""
     if world > 1:
         gather_txt = ", one all-gather of the poses per launch group, issued by the library's C entry points over %s (overlapped with the next groups)" % (
-            "RCCL (ncclAllGather, xGMI)" if a.backend == "nccl" else "the TCP transport (rehearsal: several ranks on one GPU)")
+            "RCCL (ncclAllGather, xGMI)" if transport == "rccl" else
+            ("the TCP transport (rehearsal: several ranks on one GPU)" if a.backend != "nccl" else "the TCP transport (NO RCCL communicator could be created: fallback)"))
     out = {
         "metric": "GN iterations/sec (%dx%d %s)" % (W, H, "dense" if a.dense else "semi-dense"),
         "value": value, "unit": "GN iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -341,6 +358,8 @@ def main():
                    "gn_iterations_per_alignment": iters_per_alignment,
                    "alignments_per_s": world * B * a.steps / dt, "pixels": "dense" if a.dense else "semi-dense (maxAbsGradient>=5)", "arith": a.arith},
     }
+    if getattr(a, "ranks_share_gpus", False):
+        out["config"]["ranks_share_gpus"] = "%d ranks on %d visible GPU(s): NOT a scaling measurement" % (world, ndev)
     if gathering:
         out["config"]["gathered_records_rank0"] = gathered_rows[0]
 
