@@ -613,7 +613,7 @@ def tracked_frame(api, synth, a, dev_index, with_lc=False):
         ring = None
         if lc_mode:
             ring = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=n_cand + 1, max_frames=1, max_batch=n_cand,
-                                                  grid_batch=n_cand, device=dev_index, arith=arith))
+                                                  grid_batch=n_cand, cache_records=1, device=dev_index, arith=arith))   # (as the facade's ring context)
             for k in range(n_cand):
                 ring.keyframe_upload(k, pair["kf_image"]); ring.keyframe_set_depth(k, pair["depth0"], pair["var0"])
                 for l in range(L):

@@ -400,6 +400,7 @@ class globalOptimize {
     c.grid_batch = c.max_batch;   // world-size invariant bits (ellc_abi.h)
     c.concurrent_batches = 1;
     c.coalesce = 1;
+    c.cache_records = 1;          // the ring's keyframes stay from push to push: only the slot a push replaces has its pixel lists rebuilt (same results)
     return c;
   }
   globalOptimize(Runtime& r, const std::string& matchfilepath) : rt(&r), ring(ring_config(r.cfg)) {
