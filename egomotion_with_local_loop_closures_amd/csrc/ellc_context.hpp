@@ -127,6 +127,7 @@ struct ellc_ctx {
   // captured launch sequences of ellc_align, keyed by (B, unique keyframes, mode, flags: save_weights | persist | run | continuation, batch set)
   std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
   bool use_graph = true;
+  bool graph_adaptive = false;  // the state-driven (tracking) schedule as a captured graph too; ELLC_GRAPH_ADAPTIVE=1 (diag)
   bool age_balance = true;      // age-balanced split of full-round grids (FusedArgs::age_rounds); ELLC_NO_AGE_BALANCE=1 disables
   double age_weight[5][4] = {{1, 1, 1, 1}, {1, 1, 1, 1}, {1.15, 0.85, 1, 1}, {1.2, 1.0, 0.8, 1}, {1.35, 1.15, 0.9, 0.6}};   // [rounds][round], ELLC_AGE_W (r01 sweep at 640x480, batch 32)
   double age_min_px_per_thread = 5.0;   // ELLC_AGE_MIN_PX

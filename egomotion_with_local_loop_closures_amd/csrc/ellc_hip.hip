@@ -939,6 +939,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       }
     }
     if (const char* ng = getenv("ELLC_NO_GRAPH")) c->use_graph = !(ng[0] == '1');
+    if (const char* ga = getenv("ELLC_GRAPH_ADAPTIVE")) c->graph_adaptive = (ga[0] == '1');
     if (const char* nb = getenv("ELLC_NBLK")) {
       int l = 0;
       for (const char* q = nb; *q && l < ELLC_MAX_LEVELS; l++) {
@@ -1328,7 +1329,11 @@ static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int 
     if (continuation) return enqueue_schedule_adaptive(c, B, save_weights, schedule_total_iters(c) - c->cur_adaptive_first, true);
     return enqueue_align_body(c, B, nu, mode, save_weights);
   };
-  if (!c->use_graph) return body();
+  // The state-driven schedule (the tracking call: one or two alignments) is launched kernel by kernel: its launches are ~6 us
+  // each and dependent, so the host stays ahead of the device without a graph, the depth stages that follow start without the
+  // ~14 us a graph's end costs the next launch on the stream (r03 timeline: tracked frame 0.252 -> 0.245 ms), and a first graph
+  // whose length follows the previous frame's iteration count (adaptive_hint) needs no re-capture when that count changes.
+  if (!c->use_graph || (!c->graph_adaptive && schedule_is_adaptive(c, mode, B))) return body();
   // (cur_adaptive_first: launches of the first graph of a state-driven schedule; it varies with the context's hint)
   const int first = schedule_is_adaptive(c, mode, B) ? c->cur_adaptive_first : 0;
   const auto key = std::make_tuple(B, continuation ? 0 : nu, mode,

@@ -3,6 +3,8 @@
 import json, os, sys, argparse
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import diaglib  # noqa: E402,F401  (ELLC_LIB_PATH -> _lib.use_library: diagnostic builds)
 import bench  # noqa: E402
 from egomotion_with_local_loop_closures_amd import api, synth  # noqa: E402
 a = argparse.Namespace(arith=sys.argv[1] if len(sys.argv) > 1 else "fast")
