@@ -127,6 +127,8 @@ struct ellc_ctx {
   // captured launch sequences of ellc_align, keyed by (B, unique keyframes, mode, flags: save_weights | persist | run | continuation, batch set)
   std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
   bool use_graph = true;
+  bool direct_launch = false;   // the launch sequence being enqueued is not captured: its staging record goes through kernel arguments
+  int direct_nu = 0;            //   unique keyframe slots whose lists it (re)builds
   bool graph_adaptive = false;  // the state-driven (tracking) schedule as a captured graph too; ELLC_GRAPH_ADAPTIVE=1 (diag)
   bool age_balance = true;      // age-balanced split of full-round grids (FusedArgs::age_rounds); ELLC_NO_AGE_BALANCE=1 disables
   double age_weight[5][4] = {{1, 1, 1, 1}, {1, 1, 1, 1}, {1.15, 0.85, 1, 1}, {1.2, 1.0, 0.8, 1}, {1.35, 1.15, 0.9, 0.6}};   // [rounds][round], ELLC_AGE_W (r01 sweep at 640x480, batch 32)
@@ -169,6 +171,7 @@ struct ellc_ctx {
   // ellc_track_frame: the observation's matrices and the gate, built on the device behind the alignment; a host-visible record
   void* track_mats_d = nullptr;
   int* track_gate_d = nullptr;
+  int* seed_acc = nullptr;   // dm_count_valid_block: sum and arrival ticket (zero between calls)
   int *obs_list = nullptr, *obs_ctr = nullptr;   // work list of dm_observe_select / dm_observe_walk and its counters (zero between calls)
   int* track_h = nullptr;
   int* track_dev_alias = nullptr;

@@ -267,7 +267,8 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
     ELLC_HIP(c, hipHostGetDevicePointer(&da, c->track_h, 0));
     c->track_dev_alias = (int*)da;
   }
-  hipLaunchKernelGGL(dm_count_valid_block, dim3(1), dim3(1024), 0, c->stream, c->dm_cur.isValid, n, c->track_dev_alias);
+  hipLaunchKernelGGL(dm_count_valid_block, dim3(std::max(1, ((n >> 4) + 1023) / 1024)), dim3(1024), 0, c->stream, c->dm_cur.isValid, n, c->seed_acc,
+                     c->track_dev_alias);
   const int kf = c->dm_kf_slot;
   s = ellc_align_enqueue(c, 1, &kf, &frame_slot, init_pose, ELLC_MODE_FCA, save_weights);   // one batch: it runs on the main stream
   if (s != ELLC_OK) return s;

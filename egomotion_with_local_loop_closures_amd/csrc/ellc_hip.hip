@@ -425,6 +425,17 @@ static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const in
 
 // device copy of the staged batch description, as a kernel reading the pinned record (part of the captured graph)
 static void enqueue_stage_in(ellc_ctx* c, int B) {
+  if (c->direct_launch && B <= 2) {   // not being captured: the record travels in the kernel arguments (stage_in_args)
+    StageSmall ss;
+    for (int b = 0; b < 2; b++) {
+      ss.kf[b] = b < B ? c->kf_slot_h[b] : 0;
+      ss.fr[b] = b < B ? c->fr_slot_h[b] : 0;
+      ss.uniq[b] = b < c->direct_nu ? c->uniq_slot_h[b] : 0;   // the slots whose lists this launch (re)builds (launch_group)
+      for (int i = 0; i < 6; i++) ss.pose[b * 6 + i] = b < B ? c->init_pose_h[b * 6 + i] : 0.0f;
+    }
+    hipLaunchKernelGGL(stage_in_args, dim3(1), dim3(64), 0, c->stream, c->kf_slot_d, ss, B, c->direct_nu, c->group_cap, c->state_d, c->L - 1);
+    return;
+  }
   const int n = 9 * c->group_cap;
   const int copy_blocks = (n + 255) / 256;
   hipLaunchKernelGGL(stage_in, dim3(copy_blocks + (B + 255) / 256), dim3(256), 0, c->stream, c->kf_slot_d, c->stage_dev_alias, n, copy_blocks,
@@ -887,7 +898,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   TRY(dev_alloc(c, &c->pr_tgt, n0)); TRY(dev_alloc(c, &c->pr_cnt, n0)); TRY(dev_alloc(c, &c->pr_slots, 4 * n0)); TRY(dev_alloc(c, &c->pr_val, n0));
   TRY(dev_alloc(c, &c->pr_id, n0)); TRY(dev_alloc(c, &c->pr_var, n0)); TRY(dev_alloc(c, &c->pr_remaining, 4));
   TRY(dev_alloc(c, &c->red_scratch, 4096));
-  TRY(dev_alloc(c, (char**)&c->track_mats_d, 256)); TRY(dev_alloc(c, &c->track_gate_d, 4));
+  TRY(dev_alloc(c, (char**)&c->track_mats_d, 256)); TRY(dev_alloc(c, &c->track_gate_d, 4)); TRY(dev_alloc(c, &c->seed_acc, 4));
   {   // (the arena is zeroed: the counters start at 0)
     const size_t blocks = (size_t)((cfg->width + 31) / 32) * ((cfg->height + 7) / 8);
     TRY(dev_alloc(c, &c->obs_list, ((blocks + DM_OBS_REGIONS - 1) / DM_OBS_REGIONS) * 256 * DM_OBS_REGIONS));
@@ -1333,7 +1344,13 @@ static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int 
   // each and dependent, so the host stays ahead of the device without a graph, the depth stages that follow start without the
   // ~14 us a graph's end costs the next launch on the stream (r03 timeline: tracked frame 0.252 -> 0.245 ms), and a first graph
   // whose length follows the previous frame's iteration count (adaptive_hint) needs no re-capture when that count changes.
-  if (!c->use_graph || (!c->graph_adaptive && schedule_is_adaptive(c, mode, B))) return body();
+  if (!c->use_graph || (!c->graph_adaptive && schedule_is_adaptive(c, mode, B))) {
+    c->direct_launch = !continuation;   // (a continuation has no staging)
+    c->direct_nu = nu;
+    const ellc_status s = body();
+    c->direct_launch = false;
+    return s;
+  }
   // (cur_adaptive_first: launches of the first graph of a state-driven schedule; it varies with the context's hint)
   const int first = schedule_is_adaptive(c, mode, B) ? c->cur_adaptive_first : 0;
   const auto key = std::make_tuple(B, continuation ? 0 : nu, mode,

@@ -672,33 +672,80 @@ struct TrackSetupArgs {
   ObsMats* mats;
   int* gate;
 };
-__global__ __launch_bounds__(64) void dm_track_setup(TrackSetupArgs a) {   // (one wave: the compiler may then keep everything in registers)
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// exp_se3_f32 by one wave whose lanes all hold the same twist: lane 3 r + k evaluates entry (r, k) — the operations exp_se3
+// performs for it (exp_se3_entry) — and every lane receives the twelve results: the same bits as exp_se3_f32 at a ninth of its
+// dependent f64 arithmetic per lane
+__device__ __forceinline__ void wave_exp_se3_f32(const float* pose, float* S) {
+  const int lane = threadIdx.x & 63;
+  const int l9 = min(lane, 8), r3 = l9 / 3, k3 = l9 - 3 * r3;
+  double Rrk, Vv;
+  exp_se3_entry((double)pose[0], (double)pose[1], (double)pose[2], (double)pose[3], (double)pose[4], (double)pose[5], r3, k3, Rrk, Vv);
+  const double trow = (Vv + __shfl_down(Vv, 1)) + __shfl_down(Vv, 2);   // t[r] in lanes 0, 3, 6
+  const float Rf = (float)Rrk, Tf = (float)trow;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) S[r * 4 + k] = __shfl(Rf, 3 * r + k);
+    S[r * 4 + 3] = __shfl(Tf, 3 * r);
+  }
+}
+// build_obs_mats, every lane of the wave evaluating it on the same pose (the three exps through wave_exp_se3_f32)
+__device__ __forceinline__ void build_obs_mats_wave(const float* Kmat, const float* pose, ObsMats& m) {
+  float rel[6], otw[12], two[12];
+  {
+    float B[12], Bi[12];
+    wave_exp_se3_f32(pose, B);
+    invert_f32(B, Bi);
+    obs_log_se3_f32(Bi, rel);
+  }
+  wave_exp_se3_f32(rel, otw);
+  invert_f32(otw, two);
+  for (int r = 0; r < 3; r++) {
+    for (int q = 0; q < 3; q++) {
+      float sum = 0;
+      for (int k = 0; k < 3; k++) sum += Kmat[r * 3 + k] * two[k * 4 + q];
+      m.Kr[r * 3 + q] = sum;
+      m.Rr[r * 3 + q] = two[r * 4 + q];
+    }
+    float sum = 0;
+    for (int k = 0; k < 3; k++) sum += Kmat[r * 3 + k] * two[k * 4 + 3];
+    m.Kt[r] = sum;
+    m.tt[r] = two[r * 4 + 3];
+    m.otw_t[r] = otw[r * 4 + 3];
+  }
+}
+__global__ __launch_bounds__(64) void dm_track_setup(TrackSetupArgs a) {   // one wave
+  if (blockIdx.x != 0) return;
   const AlignState& st = *a.state;
   float pose[6], pwo[6], E[12];
   for (int i = 0; i < 6; i++) pose[i] = st.pose[i];
-  obs_exp_se3_f32(pose, E);     // concat_relative_f32(pose, 0, pwo) = log(exp(pose) exp(0)): the product with the identity is exact
+  wave_exp_se3_f32(pose, E);     // concat_relative_f32(pose, 0, pwo) = log(exp(pose) exp(0)): the product with the identity is exact
   obs_log_se3_f32(E, pwo);
   ObsMats m;
-  build_obs_mats(a.Kmat, pwo, m);
-  *a.mats = m;
-  *a.gate = (st.cur_level < 0) ? 1 : 0;
+  build_obs_mats_wave(a.Kmat, pwo, m);
+  if (threadIdx.x == 0) {
+    *a.mats = m;
+    *a.gate = (st.cur_level < 0) ? 1 : 0;
+  }
 }
 // number of valid hypotheses, then its copy into host-visible memory (the seeds figure main.cpp writes beside the pose, counted
 // BEFORE the frame's observation)
-// (one block: a single launch in front of the alignment instead of clear + count + copy)
-__global__ __launch_bounds__(1024) void dm_count_valid_block(const uint8_t* __restrict__ valid, int n, int* __restrict__ host_visible) {
+// (a single launch in front of the alignment instead of clear + count + copy: one 16-byte word per thread, the blocks' sums
+// meet in acc[0]; the last block to arrive — ticket acc[1] — moves the total to the host-visible word and leaves both zero)
+__global__ __launch_bounds__(1024) void dm_count_valid_block(const uint8_t* __restrict__ valid, int n, int* __restrict__ acc, int* __restrict__ host_visible) {
   int mine = 0;
   const int n16 = n >> 4;
   const uint4* v16 = (const uint4*)valid;   // plane buffers are 256-byte aligned
-  for (int i = threadIdx.x; i < n16; i += 1024) {
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  if (i < n16) {
     const uint4 w = v16[i];
     const unsigned q[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
     for (int k = 0; k < 4; k++)   // non-zero bytes of a word
       mine += ((q[k] & 0xffu) != 0) + ((q[k] & 0xff00u) != 0) + ((q[k] & 0xff0000u) != 0) + ((q[k] & 0xff000000u) != 0);
   }
-  for (int i = (n16 << 4) + threadIdx.x; i < n; i += 1024) mine += valid[i] ? 1 : 0;
+  if (blockIdx.x == 0)
+    for (int k = (n16 << 4) + threadIdx.x; k < n; k += 1024) mine += valid[k] ? 1 : 0;
   __shared__ int part[16];
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) mine += __shfl_xor(mine, m, 64);
@@ -707,7 +754,12 @@ __global__ __launch_bounds__(1024) void dm_count_valid_block(const uint8_t* __re
   if (threadIdx.x == 0) {
     int tot = 0;
     for (int w = 0; w < 16; w++) tot += part[w];
-    *host_visible = tot;
+    atomicAdd(&acc[0], tot);
+    __threadfence();
+    if (atomicAdd(&acc[1], 1) == (int)gridDim.x - 1) {
+      *host_visible = atomicExch(&acc[0], 0);
+      acc[1] = 0;
+    }
   }
 }
 

@@ -2030,6 +2030,38 @@ __global__ void stage_in(int* __restrict__ dst, const int* __restrict__ src_host
   if (b < B) init_state_record(state[b], (const float*)(src_host + 3 * max_batch), b, top_level);
 }
 
+// The same for a schedule that is launched kernel by kernel (the tracking call, one or two alignments): the staged record
+// arrives in the kernel arguments instead of being read from pinned host memory (a PCIe round trip at the head of the chain)
+struct StageSmall {
+  int kf[2], fr[2], uniq[2];
+  float pose[12];
+};
+__global__ void stage_in_args(int* __restrict__ dst, StageSmall s, int B, int n_unique, int cap, AlignState* state, int top_level) {
+  const int t = threadIdx.x;
+  if (t < B) { dst[t] = s.kf[t]; dst[cap + t] = s.fr[t]; }
+  if (t < n_unique) dst[2 * cap + t] = s.uniq[t];
+  if (t < 6 * B) ((float*)(dst + 3 * cap))[t] = s.pose[t];
+  // init_state_record with exp(pose) spread over nine lanes per alignment (lane 3 r + k of a group of 16 evaluates entry (r, k):
+  // the operations exp_se3 performs for it, see exp_se3_entry), instead of ~5 us of dependent f64 arithmetic on one lane
+  const int b = t >> 4, l = t & 15;
+  const int bb = min(b, 1), l9 = min(l, 8), r3 = l9 / 3, k3 = l9 - 3 * r3;
+  const float* p = s.pose + bb * 6;
+  double Rrk, Vv;
+  exp_se3_entry((double)p[0], (double)p[1], (double)p[2], (double)p[3], (double)p[4], (double)p[5], r3, k3, Rrk, Vv);
+  const double trow = (Vv + __shfl_down(Vv, 1)) + __shfl_down(Vv, 2);   // t[r] in lanes 0, 3, 6 of the group
+  if (b < B) {
+    AlignState& st = state[b];
+    if (l < 9) {
+      st.S[r3 * 4 + k3] = (float)Rrk;
+      if (k3 == 0) st.S[r3 * 4 + 3] = (float)trow;
+    }
+    if (l < 6) { st.pose[l] = p[l]; st.delta[l] = 0.0f; st.b[l] = 0.0f; }
+    if (l < ELLC_MAX_LEVELS) st.iters[l] = 0;
+    if (l == 9) { st.weighted = 0.0f; st.level_done = -1; st.pending = 0; st.cur_level = top_level; st.it_in_level = 0; }
+    for (int i = l; i < 36; i += 16) { st.H[i] = 0.0f; st.Hinv[i] = 0.0f; }
+  }
+}
+
 __global__ void gn_init_state(AlignState* state, const float* init_pose, int B, int top_level) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;

@@ -59,14 +59,14 @@ def test_track_frame_errors(ellc):
 
 
 def test_driver_fused_and_unfused_write_the_same_files(tmp_path):
-    """ellc_main --fused tracks through ellc_track_frame; by default every stage is its own call: identical files."""
+    """ellc_main tracks through ellc_track_frame (--fused, the default); with --no-fused every stage is its own call: identical files."""
     from test_gpu_driver import make_sequence, W as DW, H as DH, N
     frames, _ = make_sequence()
     raw = tmp_path / "frames.raw"
     raw.write_bytes(b"".join(np.ascontiguousarray(f, np.uint8).tobytes() for f in frames))
     exe = os.path.join(ROOT, "egomotion_with_local_loop_closures_amd", "csrc", "ellc_main")
     outs = []
-    for name, extra in (("fused", ["--fused"]), ("unfused", [])):
+    for name, extra in (("fused", ["--fused"]), ("unfused", ["--no-fused"])):
         d = tmp_path / name; d.mkdir()
         r = subprocess.run([exe, str(raw), str(DW), str(DH), str(N), str(d), "LC"] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         assert r.returncode == 0, r.stdout.decode()
