@@ -129,6 +129,7 @@ struct ellc_ctx {
   bool use_graph = true;
   bool direct_launch = false;   // the launch sequence being enqueued is not captured: its staging record goes through kernel arguments
   int direct_nu = 0;            //   unique keyframe slots whose lists it (re)builds
+  int direct_max_batch = 0;     // level-bound launch sequences over at most this many alignments are launched kernel by kernel too (measured for B = 1: 0.225 ms either way)
   bool graph_adaptive = false;  // the state-driven (tracking) schedule as a captured graph too; ELLC_GRAPH_ADAPTIVE=1 (diag)
   bool age_balance = true;      // age-balanced split of full-round grids (FusedArgs::age_rounds); ELLC_NO_AGE_BALANCE=1 disables
   double age_weight[5][4] = {{1, 1, 1, 1}, {1, 1, 1, 1}, {1.15, 0.85, 1, 1}, {1.2, 1.0, 0.8, 1}, {1.35, 1.15, 0.9, 0.6}};   // [rounds][round], ELLC_AGE_W (r01 sweep at 640x480, batch 32)

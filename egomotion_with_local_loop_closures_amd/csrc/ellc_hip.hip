@@ -1344,7 +1344,7 @@ static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int 
   // each and dependent, so the host stays ahead of the device without a graph, the depth stages that follow start without the
   // ~14 us a graph's end costs the next launch on the stream (r03 timeline: tracked frame 0.252 -> 0.245 ms), and a first graph
   // whose length follows the previous frame's iteration count (adaptive_hint) needs no re-capture when that count changes.
-  if (!c->use_graph || (!c->graph_adaptive && schedule_is_adaptive(c, mode, B))) {
+  if (!c->use_graph || (!c->graph_adaptive && (schedule_is_adaptive(c, mode, B) || B <= c->direct_max_batch))) {
     c->direct_launch = !continuation;   // (a continuation has no staging)
     c->direct_nu = nu;
     const ellc_status s = body();
