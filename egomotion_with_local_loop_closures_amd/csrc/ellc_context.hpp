@@ -172,6 +172,7 @@ struct ellc_ctx {
   // ellc_track_frame: the observation's matrices and the gate, built on the device behind the alignment; a host-visible record
   void* track_mats_d = nullptr;
   int* track_gate_d = nullptr;
+  bool track_call = false;   // the alignment being enqueued belongs to ellc_track_frame (set_track_fields)
   int* seed_acc = nullptr;   // dm_count_valid_block: sum and arrival ticket (zero between calls)
   int *obs_list = nullptr, *obs_ctr = nullptr;   // work list of dm_observe_select / dm_observe_walk and its counters (zero between calls)
   int* track_h = nullptr;

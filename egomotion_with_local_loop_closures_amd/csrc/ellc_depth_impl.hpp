@@ -248,7 +248,7 @@ ellc_status ellc_depth_observe(ellc_ctx* c, int frame_slot, const float* pose_fr
 
 // main.cpp:330 + :499-502 for a frame that does not switch the keyframe, as ONE device sequence: the alignment against the depth
 // map's keyframe, then — without the pose travelling to the host and back — observeDepthRowParallel, doRegularization and
-// updateDepthImage with the matrices built on the device from the alignment's result record (dm_track_setup). The host fetches
+// updateDepthImage with the matrices built on the device from the alignment's pose in its finish kernel (track_setup_wave). The host fetches
 // the pose while the depth stages run. seeds_percent: calculate_no_of_Seeds (:1804-1830) of the map BEFORE this observation,
 // which main.cpp writes beside the pose (main.cpp:368-373).
 ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose, int save_weights, float* out_pose, int* out_iters,
@@ -270,24 +270,20 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
   hipLaunchKernelGGL(dm_count_valid_block, dim3(std::max(1, ((n >> 4) + 1023) / 1024)), dim3(1024), 0, c->stream, c->dm_cur.isValid, n, c->seed_acc,
                      c->track_dev_alias);
   const int kf = c->dm_kf_slot;
+  c->track_call = true;   // this alignment's finish kernel builds the observation's matrices and sets the gate
   s = ellc_align_enqueue(c, 1, &kf, &frame_slot, init_pose, ELLC_MODE_FCA, save_weights);   // one batch: it runs on the main stream
+  c->track_call = false;
   if (s != ELLC_OK) return s;
   const int set = c->inflight[0] / ellc_ctx::MAX_COALESCE;
   ellc_ctx::BatchSet& bs = c->batch_set[set];
   if (!bs.launched || bs.stream_idx != 0) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the alignment did not take the main stream");
-  TrackSetupArgs ta;
-  ta.state = bs.state_d;   // the final record lands in state buffer 0 (gn_fused_finish)
-  for (int i = 0; i < 9; i++) ta.Kmat[i] = c->Kmat[i];
-  ta.mats = (ObsMats*)c->track_mats_d;
-  ta.gate = c->track_gate_d;
-  hipLaunchKernelGGL(dm_track_setup, dim3(1), dim3(64), 0, c->stream, ta);
   ObsArgs a = observe_args(c, frame_slot);
-  a.mats = ta.mats;
-  a.gate = ta.gate;
+  a.mats = (ObsMats*)c->track_mats_d;
+  a.gate = c->track_gate_d;
   launch_observe(c, a, true);
   ELLC_HIP(c, hipGetLastError());
   if ((s = mark_frame_use(c, frame_slot)) != ELLC_OK) return s;
-  if ((s = do_fill_holes(c, ta.gate)) != ELLC_OK || (s = do_regularize(c, 0, ta.gate)) != ELLC_OK) return s;   // doRegularization(false) :1627-1635
+  if ((s = do_fill_holes(c, c->track_gate_d)) != ELLC_OK || (s = do_regularize(c, 0, c->track_gate_d)) != ELLC_OK) return s;   // doRegularization(false) :1627-1635
   if ((s = do_update_depth_image(c)) != ELLC_OK) return s;   // (an unchanged map exports the same planes)
   // the pose: waits for the alignment only (its event was recorded in front of the depth stages)
   if (hipEventSynchronize(bs.done) != hipSuccess) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the alignment failed on the device");

@@ -538,11 +538,21 @@ static int adaptive_first_launches(const ellc_ctx* c, int B) {
   return std::min(total, std::max(c->L, first));
 }
 
+// ellc_track_frame marks the alignment it enqueues (c->track_call): that schedule's finish kernel also builds the observation's
+// matrices and sets the depth stages' gate. (A continuation does not: the host then runs the depth stages the usual way.)
+static void set_track_fields(const ellc_ctx* c, FusedArgs& fa, bool continuation) {
+  const bool on = c->track_call && !continuation;
+  fa.track_mats = on ? (ObsMats*)c->track_mats_d : nullptr;
+  fa.track_gate = on ? c->track_gate_d : nullptr;
+  for (int i = 0; i < 9; i++) fa.track_K[i] = c->Kmat[i];
+}
+
 // State-driven FCA schedule: `launches` launches of gn_fca_adaptive and the finish kernel. continuation: the records were
 // left by an earlier graph of the same batch (buffer 0, nothing pending), otherwise by stage_in.
 static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weights, int launches, bool continuation = false) {
   FusedArgs fa;
   fa.continuation = continuation ? 1 : 0;
+  set_track_fields(c, fa, continuation);
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) fa.win_lv[l] = 0;   // (the state-driven tracking schedule keeps the global-memory taps)
   fa.seq = 0;
   fa.prev_level = -1;
@@ -591,6 +601,7 @@ static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weight
 static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) {
   FusedArgs fa;
   fa.continuation = 0;
+  set_track_fields(c, fa, false);
   set_window_levels(c, fa, B);
   fa.seq = 0;
   fa.prev_level = -1;
@@ -628,6 +639,7 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
 static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
   FusedArgs fa;
   fa.continuation = 0;
+  set_track_fields(c, fa, false);
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) fa.win_lv[l] = 0;
   fa.seq = 0;
   fa.prev_level = -1;
@@ -1354,7 +1366,7 @@ static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int 
   // (cur_adaptive_first: launches of the first graph of a state-driven schedule; it varies with the context's hint)
   const int first = schedule_is_adaptive(c, mode, B) ? c->cur_adaptive_first : 0;
   const auto key = std::make_tuple(B, continuation ? 0 : nu, mode,
-                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0) | (first << 4), set);
+                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0) | (c->track_call ? 4 : 0) | (first << 4), set);
   auto it = c->graphs.find(key);
   if (it == c->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -1788,6 +1800,8 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     // the production kernel of the FCA path: every launch first solves the previous launch's partial sums
     FusedArgs fa;
     fa.continuation = 0;
+    set_track_fields(c, fa, false);
+  set_track_fields(c, fa, false);
     set_window_levels(c, fa, B);
     fa.g = a;
     fa.res = nullptr;

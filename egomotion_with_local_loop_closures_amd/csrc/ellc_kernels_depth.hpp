@@ -617,7 +617,7 @@ struct ObsArgs {
   float otw_t[3];            // SE3poseOtherWrtThis_t of the current frame (keyframe w.r.t. current)
   float Kr[9], Kt[3];        // K_SE3poseThisWrtOther_r / _t
   float Rr[9], tt[3];        // SE3poseThisWrtOther_r / _t
-  const struct ObsMats* mats;   // dm_observe<true>: the five matrices above come from here (device memory, dm_track_setup)
+  const struct ObsMats* mats;   // dm_observe<true>: the five matrices above come from here (device memory, track_setup_wave)
   const int* gate;              //   and nothing is done unless *gate != 0
   int* list;                    // work list of the two observe kernels: DM_OBS_REGIONS regions of region_cap pixel indices each,
   int region_cap;               //   a region filled with creations from its front and updates from its back
@@ -627,7 +627,7 @@ struct ObsArgs {
 // The matrices of frame::calculateSE3poseOtherWrtThis (Frame.cpp:376-413) that observeDepthRow uses, for a frame whose
 // poseWrtOrigin is `pose` against the keyframe (poseWrtOrigin = 0): [R|t] of Other-w.r.t.-This and This-w.r.t.-Other and K R,
 // K t of the latter (f32 products, summed left to right as Eigen's 3x3 f32 product does). Host and device: the tracked-frame
-// call builds them on the device from the alignment's result (dm_track_setup), every other caller on the host.
+// call builds them on the device from the alignment's result (track_setup_wave, in its finish kernel), every other caller on the host.
 struct ObsMats {
   float otw_t[3], Kr[9], Kt[3], Rr[9], tt[3];
 };
@@ -662,16 +662,10 @@ ELLC_HD void build_obs_mats(const float* Kmat, const float* pose, ObsMats& m) {
   }
 }
 
-// Tracked-frame call (ellc_track_frame): behind the alignment's last kernel, one thread turns the pose it left in the state
-// record into poseWrtOrigin = concatenateRelativePose(pose, 0) (ImageFunc.cpp:305; the keyframe's own poseWrtOrigin is zero) and
-// the observation's matrices. gate = 1 when the alignment's schedule has ended (a state-driven schedule may need a continuation
-// that only the host can start: the depth stages behind this kernel then do nothing and the host runs them afterwards).
-struct TrackSetupArgs {
-  const AlignState* state;   // the alignment's final record (state buffer 0)
-  float Kmat[9];
-  ObsMats* mats;
-  int* gate;
-};
+// Tracked-frame call (ellc_track_frame): the alignment's finish kernel turns the pose it has just computed into poseWrtOrigin and
+// the observation's matrices (track_setup_wave below) and sets gate = 1 when the alignment's schedule has ended (a state-driven
+// schedule may need a continuation that only the host can start: the depth stages behind it then do nothing and the host runs
+// them afterwards).
 // exp_se3_f32 by one wave whose lanes all hold the same twist: lane 3 r + k evaluates entry (r, k) — the operations exp_se3
 // performs for it (exp_se3_entry) — and every lane receives the twelve results: the same bits as exp_se3_f32 at a ninth of its
 // dependent f64 arithmetic per lane
@@ -714,19 +708,15 @@ __device__ __forceinline__ void build_obs_mats_wave(const float* Kmat, const flo
     m.otw_t[r] = otw[r * 4 + 3];
   }
 }
-__global__ __launch_bounds__(64) void dm_track_setup(TrackSetupArgs a) {   // one wave
-  if (blockIdx.x != 0) return;
-  const AlignState& st = *a.state;
-  float pose[6], pwo[6], E[12];
-  for (int i = 0; i < 6; i++) pose[i] = st.pose[i];
+// the body of the tracked-frame setup, run by the first wave of gn_fused_finish behind the alignment's last solve: pose ->
+// poseWrtOrigin = concatenateRelativePose(pose, 0) (ImageFunc.cpp:305; the keyframe's own poseWrtOrigin is zero) -> the matrices
+__device__ void track_setup_wave(const float* pose, const float* Kmat, ObsMats* mats) {
+  float pwo[6], E[12];
   wave_exp_se3_f32(pose, E);     // concat_relative_f32(pose, 0, pwo) = log(exp(pose) exp(0)): the product with the identity is exact
   obs_log_se3_f32(E, pwo);
   ObsMats m;
-  build_obs_mats_wave(a.Kmat, pwo, m);
-  if (threadIdx.x == 0) {
-    *a.mats = m;
-    *a.gate = (st.cur_level < 0) ? 1 : 0;
-  }
+  build_obs_mats_wave(Kmat, pwo, m);
+  if ((threadIdx.x & 63) == 0) *mats = m;
 }
 // number of valid hypotheses, then its copy into host-visible memory (the seeds figure main.cpp writes beside the pose, counted
 // BEFORE the frame's observation)
@@ -1089,7 +1079,7 @@ __device__ __forceinline__ void observe_pixel(const ObsArgs& a, int x, int y, in
   }
 }
 
-// the matrices of a tracked-frame call come from device memory (dm_track_setup)
+// the matrices of a tracked-frame call come from device memory (track_setup_wave)
 __device__ __forceinline__ void obs_load_mats(ObsArgs& b) {
   const ObsMats& m = *b.mats;
 #pragma unroll

@@ -1252,6 +1252,8 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_solve(SolveArgs a) {
 // block of the alignment redoes the tiny solve, so no extra launch and no cross-block synchronisation is needed),
 // then runs its own pixel pass with the fresh pose. State and partials are double-buffered by launch parity:
 // launch n reads state[n&1] / partials[(n+1)&1] and writes state[(n+1)&1] / partials[n&1].
+struct ObsMats;
+__device__ void track_setup_wave(const float* pose, const float* Kmat, ObsMats* mats);   // ellc_kernels_depth.hpp
 struct FusedArgs {
   GnArgs g;
   int seq;          // launch index inside the schedule
@@ -1276,6 +1278,11 @@ struct FusedArgs {
   int max_it[ELLC_MAX_LEVELS];
   int nblk_grid;
   int win_lv[ELLC_MAX_LEVELS];   // 1: the pixel pass of this level serves its taps from LDS windows (fca_chunk_pass_win)
+  // tracked-frame call (ellc_track_frame): the finish kernel goes on to build the observation's matrices from the pose it has just
+  // computed (track_setup_wave, ellc_kernels_depth.hpp) and opens the gate of the depth stages behind it; null: not such a call
+  struct ObsMats* track_mats;
+  int* track_gate;
+  float track_K[9];
   int continuation;     // 1: this graph continues a state-driven schedule whose first graph has already run (and added the saved weights
                         // of the alignments that ended there): its first launch marks those records cur_level = -2
 };
@@ -1966,6 +1973,12 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
     } else if (t == 0) {
       r->pad = 1;
     }
+  }  if (fa.track_mats && b == 0 && t < 64) {   // (sh.newpose is final: every path above ends in a block barrier before the stores)
+    float p[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) p[i] = sh.newpose[i];
+    track_setup_wave(p, fa.track_K, fa.track_mats);
+    if (t == 0) *fa.track_gate = ended ? 1 : 0;   // closed: the schedule needs a continuation only the host can start
   }
 }
 
