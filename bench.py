@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-time budget of each CPU baseline variant")
     ap.add_argument("--rehearse-launcher", action="store_true", help="no GPU work: start the ranks, run the control plane (barrier, id broadcast, "
                     "max) and a few pipelined gathers of stand-in result tables over the TCP transport, print what each rank saw (CPU test of the launcher)")
+    ap.add_argument("--device-warmup", type=int, default=200, help="untimed steps run once before the --warmup steps (part of the setup, like the "
+                    "graph-capture rehearsal; 0: none)")
     ap.add_argument("--streams", type=int, default=3, help="diagnostic: batch streams the loaded library build has (ELLC_STREAMS)")
     ap.add_argument("--lib", default=None, help="diagnostic A/B only: load this build of the library instead of csrc/libellc_hip.so")
     return ap.parse_args()
@@ -317,6 +319,9 @@ def main():
         return r
 
     sync = wl.ctx.sync   # ellc_sync: every stream of the context has drained (no torch in this process)
+    if a.device_warmup > 0:   # untimed, before the W warm-up steps: the same steps until clocks, TLBs and the host's call paths are warm
+        run(a.device_warmup)   # (measured: the 20 timed steps take 0.150 ms each behind 5 warm-up steps alone, 0.140 behind 200)
+        sync()
     if a.warmup > 0:
         run(a.warmup)
     ctl.barrier()
@@ -351,7 +356,7 @@ def main():
                                   G, wl.coalesce, gather_txt),
                    "batch_per_gpu": B, "global_batch": B * world, "batches_in_flight": G, "coalesce": wl.coalesce,
                    "setup": "slots uploaded; hipGraphs captured by one untimed rehearsal of %d and %d steps (every launch sequence the warm-up "
-                            "and the timed steps replay), then the %d warm-up steps" % (a.warmup, a.steps, a.warmup),
+                            "and the timed steps replay), %d further untimed steps to bring the device to its working state (--device-warmup), then the %d warm-up steps" % (a.warmup, a.steps, a.device_warmup, a.warmup),
                    "launcher": ("ranks started by the caller (WORLD_SIZE in the environment)" if "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
                                 else "ranks started by bench.py itself") if world > 1 else "single process",
                    "control_plane": "library TCP communicator (barrier, unique id, max of the timings); torch is not imported",
