@@ -25,6 +25,7 @@ ap.add_argument("--calib-mb", type=int, default=512)
 ap.add_argument("--inflight", type=int, default=16, help="cfg.concurrent_batches, as bench.py's default (it sizes the grid)")
 ap.add_argument("--coalesce", type=int, default=4, help="cfg.coalesce, as bench.py's default: the launch covers this many batches side by side")
 ap.add_argument("--arith", choices=["fast", "exact"], default="fast")
+ap.add_argument("--device-warmup", type=int, default=300, help="untimed launches before the measured ones")
 ap.add_argument("--rot", type=float, default=0.01, help="rotation of the synthetic camera motion (rad)")
 ap.add_argument("--trans", type=float, default=0.02, help="translation of the synthetic camera motion")
 a = ap.parse_args()
@@ -41,7 +42,10 @@ for b in range(K):
     if a.dense or b % B == 0:
         ctx.frame_upload(b if a.dense else b // B, p["cur_image"])
 slots = np.arange(K, dtype=np.int32)
-ms, alg, V = ctx.profile_gn_kernel(slots, slots if a.dense else (slots // B).astype(np.int32), a.level, reps=a.reps)
+fr_slots = slots if a.dense else (slots // B).astype(np.int32)
+if a.device_warmup > 0:   # the same launches, untimed, until the device is in its working state (as bench.py's --device-warmup)
+    ctx.profile_gn_kernel(slots, fr_slots, a.level, reps=a.device_warmup)
+ms, alg, V = ctx.profile_gn_kernel(slots, fr_slots, a.level, reps=a.reps)
 try:   # diagnostic build: how the window path was used
     import ctypes as C
     st = (C.c_ulonglong * 8)()
@@ -52,6 +56,6 @@ except AttributeError:
 cal_bytes = a.calib_mb << 20
 cms = ctx.profile_calibrate_read(cal_bytes, reps=5)
 print(json.dumps({"kernel": "gn_fca_fused", "arith": a.arith, "size": [W, H, L], "dense": bool(a.dense), "level": a.level, "batch": B, "coalesce": a.coalesce, "alignments_per_launch": K, "concurrent_batches": a.inflight, "avg_ms": ms, "algorithmic_bytes": alg, "valid_pixels": V,
-                  "achieved_GBps": alg / ms / 1e6, "launches": a.reps + 3, "calib_bytes_per_launch": cal_bytes, "calib_avg_ms": cms,
+                  "achieved_GBps": alg / ms / 1e6, "launches": a.reps + 3, "warmup_launches": (a.device_warmup + 3) if a.device_warmup > 0 else 0, "calib_bytes_per_launch": cal_bytes, "calib_avg_ms": cms,
                   "calib_GBps": cal_bytes / cms / 1e6, "calib_launches": 6}))
 ctx.close()
