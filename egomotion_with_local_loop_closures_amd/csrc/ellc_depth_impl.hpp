@@ -36,8 +36,11 @@ ellc_status do_regularize(ellc_ctx* c, int removeOcclusions, const int* gate = n
   const int W = c->cfg.width, H = c->cfg.height;
   const int tiles_x = (W + DM_TX - 1) / DM_TX, tiles = tiles_x * ((H + DM_TY - 1) / DM_TY);
   // in place, except for the validity flags: they go to the other map's plane, which becomes this map's
-  hipLaunchKernelGGL(dm_regularize, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth.isValid, W, H, removeOcclusions,
-                     tiles_x, tiles, gate);
+  ExportPyrArgs none;
+  for (int l = 0; l < 4; l++) { none.depth[l] = nullptr; none.var[l] = nullptr; }
+  none.W = W; none.H = H; none.steps = 0;
+  hipLaunchKernelGGL(dm_regularize<false>, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth.isValid, W, H, removeOcclusions,
+                     tiles_x, tiles, gate, none);
   ELLC_HIP(c, hipGetLastError());
   std::swap(c->dm_cur.isValid, c->dm_oth.isValid);
   return ELLC_OK;
@@ -101,6 +104,35 @@ ellc_status do_update_depth_image(ellc_ctx* c) {
   }
   ELLC_HIP(c, hipGetLastError());
   ellc_status s = build_depth_pyramid_from(c, c->dm_kf_slot, steps + 1);   // buildInvVarDepth + mapDepthArr2Mat: the remaining levels
+  if (s != ELLC_OK) return s;
+  c->kf_has_depth[c->dm_kf_slot] = 1;
+  return ELLC_OK;
+}
+
+// doRegularization(false) + updateDepthImage as one launch (dm_regularize<true>) when the image tiles into 32 x 8 blocks that halve
+// exactly for the pyramid levels the export's own launch would produce; otherwise the two stages one after the other
+ellc_status do_regularize_and_update_depth_image(ellc_ctx* c, int removeOcclusions, const int* gate) {
+  const int W = c->cfg.width, H = c->cfg.height;
+  int steps = 0;
+  while (steps < 3 && steps + 1 < c->L && ((W >> steps) & 1) == 0 && ((H >> steps) & 1) == 0) steps++;
+  if (!(steps > 0 && (W % DM_TX) == 0 && (H % DM_TY) == 0 && (DM_TX >> steps) >= 1 && (DM_TY >> steps) >= 1)) {
+    ellc_status s = do_regularize(c, removeOcclusions, gate);
+    return s != ELLC_OK ? s : do_update_depth_image(c);
+  }
+  invalidate_records(c, c->dm_kf_slot);   // before the first write (a failure half-way must not leave a valid tag)
+  ExportPyrArgs ea;
+  ea.W = W; ea.H = H; ea.steps = steps;
+  for (int l = 0; l < 4; l++) {
+    const KfLevelDev& kl = c->kf_tab_h[(size_t)std::min(l, c->L - 1) * c->cfg.max_keyframes + c->dm_kf_slot];
+    ea.depth[l] = kl.depth;
+    ea.var[l] = kl.var;
+  }
+  const int tiles_x = W / DM_TX, tiles = tiles_x * (H / DM_TY);
+  hipLaunchKernelGGL(dm_regularize<true>, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth.isValid, W, H, removeOcclusions,
+                     tiles_x, tiles, gate, ea);
+  ELLC_HIP(c, hipGetLastError());
+  std::swap(c->dm_cur.isValid, c->dm_oth.isValid);
+  ellc_status s = build_depth_pyramid_from(c, c->dm_kf_slot, steps + 1);   // the remaining levels
   if (s != ELLC_OK) return s;
   c->kf_has_depth[c->dm_kf_slot] = 1;
   return ELLC_OK;
@@ -283,8 +315,8 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
   launch_observe(c, a, true);
   ELLC_HIP(c, hipGetLastError());
   if ((s = mark_frame_use(c, frame_slot)) != ELLC_OK) return s;
-  if ((s = do_fill_holes(c, c->track_gate_d)) != ELLC_OK || (s = do_regularize(c, 0, c->track_gate_d)) != ELLC_OK) return s;   // doRegularization(false) :1627-1635
-  if ((s = do_update_depth_image(c)) != ELLC_OK) return s;   // (an unchanged map exports the same planes)
+  if ((s = do_fill_holes(c, c->track_gate_d)) != ELLC_OK) return s;   // doRegularization(false) :1627-1635 ...
+  if ((s = do_regularize_and_update_depth_image(c, 0, c->track_gate_d)) != ELLC_OK) return s;   // ... and updateDepthImage (an unchanged map exports the same planes)
   // the pose: waits for the alignment only (its event was recorded in front of the depth stages)
   if (hipEventSynchronize(bs.done) != hipSuccess) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the alignment failed on the device");
   const bool continued = bs.adaptive && bs.result_h[0].pad == 1;   // the state-driven schedule needs its continuation: the gate stayed closed

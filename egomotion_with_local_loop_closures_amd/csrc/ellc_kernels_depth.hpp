@@ -161,12 +161,43 @@ __device__ __forceinline__ int dm_compact_candidates(bool cand, uint8_t* list, i
   return total;
 }
 
+struct ExportPyrArgs {
+  float* depth[4];     // levels 0..3 of the keyframe's depth pyramid (frame::depth_pyramid)
+  float* var[4];       // depthMap::depthvararrptr
+  int W, H, steps;     // steps = pyramid levels produced below level 0 (0..3)
+};
+__device__ __forceinline__ void depth_pyr_merge(const float d[4], const float v[4], float& od, float& ov) {
+  float idepthSumsSum = 0.0f, ivarSumsSum = 0.0f;
+  int num = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    if (v[q] > 0.0f) {
+      const float ivar = 1.0f / v[q];
+      ivarSumsSum += ivar;
+      idepthSumsSum += ivar * 1.0f / d[q];
+      num++;
+    }
+  }
+  if (num > 0) {
+    od = ivarSumsSum / idepthSumsSum;
+    ov = (float)num / ivarSumsSum;
+  } else {
+    od = 0.0f;
+    ov = -1.0f;
+  }
+}
+
 // depthMap::regularizeDepthMap (:1436-1543). The stencil reads the snapshot's invDepth / variance / validity / isValid, a
 // pixel's update writes only its own invDepthSmoothed / varianceSmoothed / blacklisted — which no stencil reads — and isValid:
 // so the map is updated IN PLACE and only the new validity flags go to a plane of their own (valid_out, which the caller then
 // swaps in): 13 bytes read (x the halo) and at most 13 written per pixel instead of 25 + 25 through a second copy of the map.
+// EXPORT (the tracked frame's last regularisation, ellc_track_frame): the block goes on to updateDepthImage for its tile — level 0 of
+// the keyframe's depth / variance planes from the values it has just computed, and the 16 x 4, 8 x 2 and 4 x 1 cells of the next
+// three pyramid levels its 32 x 8 pixels cover (dm_export_pyramid's arithmetic; image sizes that are multiples of 32 x 8 and halve
+// exactly `steps` times) — one launch less behind it.
+template <bool EXPORT>
 __global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA s, uint8_t* __restrict__ valid_out, int W, int H, int removeOcclusions,
-                                                               int tiles_x, int tiles_total, const int* __restrict__ gate) {
+                                                               int tiles_x, int tiles_total, const int* __restrict__ gate, ExportPyrArgs ex) {
   __shared__ DmTile t;
   __shared__ uint8_t list[DM_TX * DM_TY];
   __shared__ int wave_count[(DM_TX * DM_TY) / 64];
@@ -217,15 +248,60 @@ __global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA s, uint8
     }
   }
   __syncthreads();
-  if (!inside) return;
+  if (!EXPORT && !inside) return;
   const int i = x + y * W;
   const int code = r_code[threadIdx.x];
-  valid_out[i] = (dvalid && code < 2) ? 1 : 0;
-  if (code == 1) {
-    s.invDepthSmoothed[i] = r_ids[threadIdx.x];
-    s.varianceSmoothed[i] = r_vars[threadIdx.x];
-  } else if (code == 2) {
-    s.blacklisted[i] = s.blacklisted[i] - 1;
+  bool nvalid = dvalid && code < 2;
+  if (EXPORT && inside && (y < 3 || y >= H - 3 || x < 3 || x >= W - 3)) nvalid = false;   // updateDepthImage clears the border's flags (:1254-1315)
+  if (inside) {
+    valid_out[i] = nvalid ? 1 : 0;
+    if (code == 1) {
+      s.invDepthSmoothed[i] = r_ids[threadIdx.x];
+      s.varianceSmoothed[i] = r_vars[threadIdx.x];
+    } else if (code == 2) {
+      s.blacklisted[i] = s.blacklisted[i] - 1;
+    }
+  }
+  if constexpr (EXPORT) {
+    // ping-pong planes of the tile's pyramid cells: level l in [l & 1] (dm_export_pyramid with a 32 x 8 tile)
+    __shared__ float ld[2][DM_TX * DM_TY], lv[2][DM_TX * DM_TY];
+    float d = 0.0f, v = -1.0f;
+    if (inside) {
+      const float ids = (code == 1) ? r_ids[threadIdx.x] : s.invDepthSmoothed[i];
+      if (nvalid && ids >= -0.05f) {
+        d = 1.0f / ids;
+        v = (code == 1) ? r_vars[threadIdx.x] : s.varianceSmoothed[i];
+      }
+      ex.depth[0][i] = d;
+      ex.var[0][i] = v;
+    }
+    ld[0][threadIdx.x] = d;
+    lv[0][threadIdx.x] = v;
+    __syncthreads();
+    int ew = DM_TX, eh = DM_TY;
+    for (int l = 1; l <= ex.steps; l++) {
+      const int w2 = ew >> 1, h2 = eh >> 1;   // the tile's cells at level l
+      const int wl = W >> l, hl = H >> l;
+      const float* sd = ld[(l - 1) & 1];
+      const float* sv = lv[(l - 1) & 1];
+      if ((int)threadIdx.x < w2 * h2) {
+        const int cy = (int)threadIdx.x / w2, cx = (int)threadIdx.x - cy * w2;
+        const int q0 = (2 * cy) * ew + 2 * cx;
+        const float d4[4] = {sd[q0], sd[q0 + 1], sd[q0 + ew], sd[q0 + ew + 1]};
+        const float v4[4] = {sv[q0], sv[q0 + 1], sv[q0 + ew], sv[q0 + ew + 1]};
+        float od, ov;
+        depth_pyr_merge(d4, v4, od, ov);
+        const int gx = ((bx * DM_TX) >> l) + cx, gy = ((by * DM_TY) >> l) + cy;
+        if (gx < wl && gy < hl) {
+          ex.depth[l][gx + gy * wl] = od;
+          ex.var[l][gx + gy * wl] = ov;
+        }
+        ld[l & 1][cy * w2 + cx] = od;
+        lv[l & 1][cy * w2 + cx] = ov;
+      }
+      __syncthreads();
+      ew = w2; eh = h2;
+    }
   }
 }
 
@@ -318,31 +394,6 @@ __global__ void dm_export_level0(DepthSoA s, float* __restrict__ depthMat, float
 // through LDS, writing every level. Only for level sizes that halve exactly (W >> l == 2 (W >> (l + 1)) for the levels
 // produced): the reference reads a source level with the stride 2 * (destination width), which is the source's own width
 // exactly then; other sizes take the per-level kernels. Same operations per value as the kernels it replaces.
-struct ExportPyrArgs {
-  float* depth[4];     // levels 0..3 of the keyframe's depth pyramid (frame::depth_pyramid)
-  float* var[4];       // depthMap::depthvararrptr
-  int W, H, steps;     // steps = pyramid levels produced below level 0 (0..3)
-};
-__device__ __forceinline__ void depth_pyr_merge(const float d[4], const float v[4], float& od, float& ov) {
-  float idepthSumsSum = 0.0f, ivarSumsSum = 0.0f;
-  int num = 0;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    if (v[q] > 0.0f) {
-      const float ivar = 1.0f / v[q];
-      ivarSumsSum += ivar;
-      idepthSumsSum += ivar * 1.0f / d[q];
-      num++;
-    }
-  }
-  if (num > 0) {
-    od = ivarSumsSum / idepthSumsSum;
-    ov = (float)num / ivarSumsSum;
-  } else {
-    od = 0.0f;
-    ov = -1.0f;
-  }
-}
 __global__ __launch_bounds__(256) void dm_export_pyramid(DepthSoA s, ExportPyrArgs a) {
   __shared__ float ld[2][32 * 32], lv[2][32 * 32];   // ping-pong: level l in [l & 1]
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
