@@ -172,6 +172,8 @@ struct ellc_ctx {
   // ellc_track_frame: the observation's matrices and the gate, built on the device behind the alignment; a host-visible record
   void* track_mats_d = nullptr;
   int* track_gate_d = nullptr;
+  const void* track_count_valid = nullptr;   // ellc_track_frame: the validity plane whose count the staging launch takes along
+  int track_count_n = 0;                     //   and its size (0: nothing pending)
   bool track_call = false;   // the alignment being enqueued belongs to ellc_track_frame (set_track_fields)
   int* seed_acc = nullptr;   // dm_count_valid_block: sum and arrival ticket (zero between calls)
   int *obs_list = nullptr, *obs_ctr = nullptr;   // work list of dm_observe_select / dm_observe_walk and its counters (zero between calls)

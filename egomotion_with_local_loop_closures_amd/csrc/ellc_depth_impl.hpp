@@ -299,13 +299,22 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
     ELLC_HIP(c, hipHostGetDevicePointer(&da, c->track_h, 0));
     c->track_dev_alias = (int*)da;
   }
-  hipLaunchKernelGGL(dm_count_valid_block, dim3(std::max(1, ((n >> 4) + 1023) / 1024)), dim3(1024), 0, c->stream, c->dm_cur.isValid, n, c->seed_acc,
-                     c->track_dev_alias);
   const int kf = c->dm_kf_slot;
+  // the seeds figure: the count of the valid hypotheses rides along in the alignment's staging launch when that sequence is launched
+  // kernel by kernel (stage_in_args); in front of a captured sequence it is a launch of its own
+  const bool rides = launches_directly(c, ELLC_MODE_FCA, 1);
+  if (!rides)
+    hipLaunchKernelGGL(dm_count_valid_block, dim3(std::max(1, ((n >> 4) + 1023) / 1024)), dim3(1024), 0, c->stream, c->dm_cur.isValid, n, c->seed_acc,
+                       c->track_dev_alias);
   c->track_call = true;   // this alignment's finish kernel builds the observation's matrices and sets the gate
+  c->track_count_valid = c->dm_cur.isValid;
+  c->track_count_n = rides ? n : 0;
   s = ellc_align_enqueue(c, 1, &kf, &frame_slot, init_pose, ELLC_MODE_FCA, save_weights);   // one batch: it runs on the main stream
   c->track_call = false;
+  const bool counted = !rides || c->track_count_n == 0;
+  c->track_count_n = 0;
   if (s != ELLC_OK) return s;
+  if (!counted) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the staging launch did not take the count along");
   const int set = c->inflight[0] / ellc_ctx::MAX_COALESCE;
   ellc_ctx::BatchSet& bs = c->batch_set[set];
   if (!bs.launched || bs.stream_idx != 0) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the alignment did not take the main stream");

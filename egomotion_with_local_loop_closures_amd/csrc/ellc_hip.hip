@@ -433,7 +433,11 @@ static void enqueue_stage_in(ellc_ctx* c, int B) {
       ss.uniq[b] = b < c->direct_nu ? c->uniq_slot_h[b] : 0;   // the slots whose lists this launch (re)builds (launch_group)
       for (int i = 0; i < 6; i++) ss.pose[b * 6 + i] = b < B ? c->init_pose_h[b * 6 + i] : 0.0f;
     }
-    hipLaunchKernelGGL(stage_in_args, dim3(1), dim3(64), 0, c->stream, c->kf_slot_d, ss, B, c->direct_nu, c->group_cap, c->state_d, c->L - 1);
+    // (ellc_track_frame's count of the valid hypotheses rides along in further blocks of the same launch)
+    const int count_blocks = c->track_count_n > 0 ? std::max(1, ((c->track_count_n >> 4) + 1023) / 1024) : 0;
+    hipLaunchKernelGGL(stage_in_args, dim3(1 + count_blocks), dim3(1024), 0, c->stream, c->kf_slot_d, ss, B, c->direct_nu, c->group_cap, c->state_d, c->L - 1,
+                       (const uint8_t*)c->track_count_valid, c->track_count_n, c->seed_acc, c->track_dev_alias);
+    c->track_count_n = 0;   // done (the caller launches the count by itself if this launch did not take it)
     return;
   }
   const int n = 9 * c->group_cap;
@@ -1344,6 +1348,11 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
   return ELLC_OK;
 }
 
+// true: the batch's launch sequence is launched kernel by kernel; false: replayed from a captured graph
+static bool launches_directly(const ellc_ctx* c, int mode, int B) {
+  return !c->use_graph || (!c->graph_adaptive && (schedule_is_adaptive(c, mode, B) || B <= c->direct_max_batch));
+}
+
 // Enqueues the launch sequence of one batch on c->stream — replayed from a hipGraph captured on first use, keyed by
 // (B, unique keyframes, mode, save_weights, batch set, part). continuation: the rest of a state-driven schedule whose first
 // graph ended before every alignment had (enqueue_schedule_adaptive), for the batch set selected in the context.
@@ -1356,7 +1365,7 @@ static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int 
   // each and dependent, so the host stays ahead of the device without a graph, the depth stages that follow start without the
   // ~14 us a graph's end costs the next launch on the stream (r03 timeline: tracked frame 0.252 -> 0.245 ms), and a first graph
   // whose length follows the previous frame's iteration count (adaptive_hint) needs no re-capture when that count changes.
-  if (!c->use_graph || (!c->graph_adaptive && (schedule_is_adaptive(c, mode, B) || B <= c->direct_max_batch))) {
+  if (launches_directly(c, mode, B)) {
     c->direct_launch = !continuation;   // (a continuation has no staging)
     c->direct_nu = nu;
     const ellc_status s = body();

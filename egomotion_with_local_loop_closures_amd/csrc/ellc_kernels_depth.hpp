@@ -773,11 +773,11 @@ __device__ void track_setup_wave(const float* pose, const float* Kmat, ObsMats* 
 // BEFORE the frame's observation)
 // (a single launch in front of the alignment instead of clear + count + copy: one 16-byte word per thread, the blocks' sums
 // meet in acc[0]; the last block to arrive — ticket acc[1] — moves the total to the host-visible word and leaves both zero)
-__global__ __launch_bounds__(1024) void dm_count_valid_block(const uint8_t* __restrict__ valid, int n, int* __restrict__ acc, int* __restrict__ host_visible) {
+__device__ void dm_count_valid_body(const uint8_t* __restrict__ valid, int n, int* __restrict__ acc, int* __restrict__ host_visible, int block, int nblocks) {
   int mine = 0;
   const int n16 = n >> 4;
   const uint4* v16 = (const uint4*)valid;   // plane buffers are 256-byte aligned
-  const int i = blockIdx.x * 1024 + threadIdx.x;
+  const int i = block * 1024 + threadIdx.x;
   if (i < n16) {
     const uint4 w = v16[i];
     const unsigned q[4] = {w.x, w.y, w.z, w.w};
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(1024) void dm_count_valid_block(const uint8_t* __re
     for (int k = 0; k < 4; k++)   // non-zero bytes of a word
       mine += ((q[k] & 0xffu) != 0) + ((q[k] & 0xff00u) != 0) + ((q[k] & 0xff0000u) != 0) + ((q[k] & 0xff000000u) != 0);
   }
-  if (blockIdx.x == 0)
+  if (block == 0)
     for (int k = (n16 << 4) + threadIdx.x; k < n; k += 1024) mine += valid[k] ? 1 : 0;
   __shared__ int part[16];
 #pragma unroll
@@ -797,11 +797,14 @@ __global__ __launch_bounds__(1024) void dm_count_valid_block(const uint8_t* __re
     for (int w = 0; w < 16; w++) tot += part[w];
     atomicAdd(&acc[0], tot);
     __threadfence();
-    if (atomicAdd(&acc[1], 1) == (int)gridDim.x - 1) {
+    if (atomicAdd(&acc[1], 1) == nblocks - 1) {
       *host_visible = atomicExch(&acc[0], 0);
       acc[1] = 0;
     }
   }
+}
+__global__ __launch_bounds__(1024) void dm_count_valid_block(const uint8_t* __restrict__ valid, int n, int* __restrict__ acc, int* __restrict__ host_visible) {
+  dm_count_valid_body(valid, n, acc, host_visible, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __device__ __forceinline__ float dot3f(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }

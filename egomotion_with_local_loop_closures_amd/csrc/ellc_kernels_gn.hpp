@@ -2049,8 +2049,17 @@ struct StageSmall {
   int kf[2], fr[2], uniq[2];
   float pose[12];
 };
-__global__ void stage_in_args(int* __restrict__ dst, StageSmall s, int B, int n_unique, int cap, AlignState* state, int top_level) {
+// count_*: ellc_track_frame's seeds figure rides along — blocks 1.. count the depth map's valid hypotheses (dm_count_valid_body,
+// ellc_kernels_depth.hpp) while block 0 stages; count_valid == nullptr: a launch of one block
+__device__ void dm_count_valid_body(const uint8_t* valid, int n, int* acc, int* host_visible, int block, int nblocks);
+__global__ __launch_bounds__(1024) void stage_in_args(int* __restrict__ dst, StageSmall s, int B, int n_unique, int cap, AlignState* state, int top_level,
+                                                      const uint8_t* count_valid, int count_n, int* count_acc, int* count_host) {
+  if (blockIdx.x > 0) {
+    dm_count_valid_body(count_valid, count_n, count_acc, count_host, (int)blockIdx.x - 1, (int)gridDim.x - 1);
+    return;
+  }
   const int t = threadIdx.x;
+  if (t >= 64) return;
   if (t < B) { dst[t] = s.kf[t]; dst[cap + t] = s.fr[t]; }
   if (t < n_unique) dst[2 * cap + t] = s.uniq[t];
   if (t < 6 * B) ((float*)(dst + 3 * cap))[t] = s.pose[t];

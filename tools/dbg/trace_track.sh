@@ -10,8 +10,8 @@ import csv, glob, sys, os
 f = glob.glob(os.path.join(sys.argv[1], "*", "*kernel_trace.csv"))[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-# frames of the fused loop start with dm_count_valid_block
-starts = [i for i, n in enumerate(names) if "dm_count_valid_block" in n]
+# frames of the fused loop start with stage_in_args (which also counts the valid hypotheses)
+starts = [i for i, n in enumerate(names) if "stage_in_args" in n]
 i0, i1 = starts[30], starts[31]
 t0 = int(rows[i0]["Start_Timestamp"])
 # include the upload's pyramid kernel in front
