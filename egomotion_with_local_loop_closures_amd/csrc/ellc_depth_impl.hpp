@@ -323,9 +323,11 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
   a.gate = c->track_gate_d;
   launch_observe(c, a, true);
   ELLC_HIP(c, hipGetLastError());
-  if ((s = mark_frame_use(c, frame_slot)) != ELLC_OK) return s;
   if ((s = do_fill_holes(c, c->track_gate_d)) != ELLC_OK) return s;   // doRegularization(false) :1627-1635 ...
   if ((s = do_regularize_and_update_depth_image(c, 0, c->track_gate_d)) != ELLC_OK) return s;   // ... and updateDepthImage (an unchanged map exports the same planes)
+  // the frame slot's "last read" mark goes behind the whole chain, not behind the observation that reads it: an event record in the
+  // middle of the chain held the next launch back ~10 us, and the next upload into this slot is a frame away either way
+  if ((s = mark_frame_use(c, frame_slot)) != ELLC_OK) return s;
   // the pose: waits for the alignment only (its event was recorded in front of the depth stages)
   if (hipEventSynchronize(bs.done) != hipSuccess) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the alignment failed on the device");
   const bool continued = bs.adaptive && bs.result_h[0].pad == 1;   // the state-driven schedule needs its continuation: the gate stayed closed
