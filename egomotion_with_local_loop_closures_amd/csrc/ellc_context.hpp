@@ -126,6 +126,7 @@ struct ellc_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // captured launch sequences of ellc_align, keyed by (B, unique keyframes, mode, flags: save_weights | persist | run | continuation, batch set)
   std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
+  bool poll_results = true;     // resolve_batch polls the pinned result records of small single-stream batches; ELLC_NO_POLL=1 (diag)
   bool use_graph = true;
   bool direct_launch = false;   // the launch sequence being enqueued is not captured: its staging record goes through kernel arguments
   int direct_nu = 0;            //   unique keyframe slots whose lists it (re)builds
@@ -174,6 +175,7 @@ struct ellc_ctx {
   int* track_gate_d = nullptr;
   const void* track_count_valid = nullptr;   // ellc_track_frame: the validity plane whose count the staging launch takes along
   int track_count_n = 0;                     //   and its size (0: nothing pending)
+  bool done_deferred = false;   // launch_group left the group's `done` event to its caller (ellc_track_frame records it behind the depth stages)
   bool track_call = false;   // the alignment being enqueued belongs to ellc_track_frame (set_track_fields)
   int* seed_acc = nullptr;   // dm_count_valid_block: sum and arrival ticket (zero between calls)
   int *obs_list = nullptr, *obs_ctr = nullptr;   // work list of dm_observe_select / dm_observe_walk and its counters (zero between calls)

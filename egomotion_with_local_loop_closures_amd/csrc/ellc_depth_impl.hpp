@@ -306,6 +306,7 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
   if (!rides)
     hipLaunchKernelGGL(dm_count_valid_block, dim3(std::max(1, ((n >> 4) + 1023) / 1024)), dim3(1024), 0, c->stream, c->dm_cur.isValid, n, c->seed_acc,
                        c->track_dev_alias);
+  c->done_deferred = false;
   c->track_call = true;   // this alignment's finish kernel builds the observation's matrices and sets the gate
   c->track_count_valid = c->dm_cur.isValid;
   c->track_count_n = rides ? n : 0;
@@ -317,6 +318,12 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
   if (!counted) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the staging launch did not take the count along");
   const int set = c->inflight[0] / ellc_ctx::MAX_COALESCE;
   ellc_ctx::BatchSet& bs = c->batch_set[set];
+  // (launch_group may have left the group's `done` event to this call: it is recorded behind the depth stages, on every way out)
+  struct DoneGuard {
+    ellc_ctx* c; hipEvent_t ev; bool armed;
+    ~DoneGuard() { if (armed) (void)hipEventRecord(ev, c->stream); }
+  } done_guard{c, bs.done, c->done_deferred};
+  c->done_deferred = false;
   if (!bs.launched || bs.stream_idx != 0) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the alignment did not take the main stream");
   ObsArgs a = observe_args(c, frame_slot);
   a.mats = (ObsMats*)c->track_mats_d;
@@ -328,8 +335,12 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
   // the frame slot's "last read" mark goes behind the whole chain, not behind the observation that reads it: an event record in the
   // middle of the chain held the next launch back ~10 us, and the next upload into this slot is a frame away either way
   if ((s = mark_frame_use(c, frame_slot)) != ELLC_OK) return s;
-  // the pose: waits for the alignment only (its event was recorded in front of the depth stages)
-  if (hipEventSynchronize(bs.done) != hipSuccess) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the alignment failed on the device");
+  if (done_guard.armed) {
+    done_guard.armed = false;
+    ELLC_HIP(c, hipEventRecord(bs.done, c->stream));
+  }
+  // the pose: waits for the alignment only (its result record, or its event, recorded in front of the depth stages)
+  if (wait_batch_results(c, bs) != hipSuccess) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the alignment failed on the device");
   const bool continued = bs.adaptive && bs.result_h[0].pad == 1;   // the state-driven schedule needs its continuation: the gate stayed closed
   float pose[6];
   s = ellc_align_fetch(c, 1, pose, out_iters, out_weighted);   // (runs the continuation when one is needed)

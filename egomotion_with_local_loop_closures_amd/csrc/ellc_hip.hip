@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <chrono>
+#include <atomic>
 #include <mutex>
 
 using namespace ellc;
@@ -966,6 +968,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       }
     }
     if (const char* ng = getenv("ELLC_NO_GRAPH")) c->use_graph = !(ng[0] == '1');
+    if (const char* np = getenv("ELLC_NO_POLL")) c->poll_results = !(np[0] == '1');
     if (const char* ga = getenv("ELLC_GRAPH_ADAPTIVE")) c->graph_adaptive = (ga[0] == '1');
     if (const char* nb = getenv("ELLC_NBLK")) {
       int l = 0;
@@ -1405,13 +1408,39 @@ struct StreamScope {
   ~StreamScope() { c->stream = saved; }
 };
 
+// Waits until the launched group's result records are there. One or two alignments with nothing else in flight (the tracking
+// call, a single alignment): the host polls the pad words of the records the finish kernel writes into pinned
+// memory — a microsecond after the kernel's store instead of the event's completion path — and falls back to the event after
+// 2 ms (a failed launch never writes them). Everything the context does next is on the same stream, behind whatever of this
+// batch is still running (saved weights, the depth stages of a tracked frame).
+static bool polls_results(const ellc_ctx* c, int B, int stream_idx) {
+  // the only batch in flight, on the main stream: whatever the context launches next — the next group takes the lowest free set
+  // and stream, i.e. these — is ordered behind this batch's trailing kernels by the stream itself
+  return c->poll_results && c->use_fused && B <= 2 && stream_idx == 0 && c->n_inflight <= 1;
+}
+static hipError_t wait_batch_results(ellc_ctx* c, ellc_ctx::BatchSet& bs) {
+  if (polls_results(c, bs.B, bs.stream_idx)) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spin = 0;; spin++) {
+      bool all = true;
+      for (int b = 0; b < bs.B; b++) all = all && (*(volatile const int*)&bs.result_h[b].pad != -1);
+      if (all) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return hipSuccess;
+      }
+      if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+  }
+  return hipEventSynchronize(bs.done);
+}
+
 // Waits for a launched group and, when it ran the state-driven schedule and one of its alignments had not ended when the
 // first graph did (result pad = 1, gn_fused_finish), replays the continuation graph on the group's stream and waits again.
 static ellc_status resolve_batch(ellc_ctx* c, int set) {
   ellc_ctx::BatchSet& bs = c->batch_set[set];
   if (bs.resolved) return ELLC_OK;
   bs.resolved = true;
-  hipError_t ev = hipEventSynchronize(bs.done);   // the last kernel wrote bs.result_h (pinned, zero-copy)
+  hipError_t ev = wait_batch_results(c, bs);   // the last kernel wrote bs.result_h (pinned, zero-copy)
   if (ev != hipSuccess) {
     std::fill(c->kf_rec_tag.begin(), c->kf_rec_tag.end(), 0);   // whatever was being built cannot be trusted
     return fail(c, ELLC_ERR_HIP, std::string("the batch failed on the device: ") + hipGetErrorString(ev));
@@ -1519,7 +1548,10 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
       for (int v : bs.built_slots) invalidate_records(c, v);
       return s;
     }
-    ELLC_HIP(c, hipEventRecord(bs.done, c->stream));
+    // (ellc_track_frame, whose host side polls the result record: the event goes behind the depth stages it enqueues next — in
+    // front of them the record would hold their first launch back ~6 us)
+    c->done_deferred = c->track_call && polls_results(c, B, si);
+    if (!c->done_deferred) ELLC_HIP(c, hipEventRecord(bs.done, c->stream));
   }
   for (int v : bs.built_slots) c->kf_rec_tag[v] = need;
   if (saves)   // the weight planes change: lists that carry the saved weight (the constant-weight record sets) are stale

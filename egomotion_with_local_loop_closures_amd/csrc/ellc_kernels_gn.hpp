@@ -1965,15 +1965,22 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
     dst->it_in_level = nit;
   }
   if (fa.res) {
+    // the record lives in pinned host memory and a host thread may be polling its pad word (resolve_batch): the fields first,
+    // made visible system-wide, then the word that says they are there
     AlignResult* r = fa.res + b;
     if (ended) {
       if (t < 6) r->pose[t] = sh.newpose[t];
       if (t < ELLC_MAX_LEVELS) r->iters[t] = it_copy[t] + ((pending && t == lvl) ? 1 : 0);
-      if (t == 0) { r->weighted = sh.weighted; r->pad = 0; }
-    } else if (t == 0) {
-      r->pad = 1;
+      if (t == 0) r->weighted = sh.weighted;
+      __threadfence_system();
     }
-  }  if (fa.track_mats && b == 0 && t < 64) {   // (sh.newpose is final: every path above ends in a block barrier before the stores)
+    __syncthreads();
+    if (t == 0) {
+      __threadfence_system();
+      *(volatile int*)&r->pad = ended ? 0 : 1;
+    }
+  }
+  if (fa.track_mats && b == 0 && t < 64) {   // (sh.newpose is final: every path above ends in a block barrier before the stores)
     float p[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) p[i] = sh.newpose[i];

@@ -12,7 +12,9 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # frames of the fused loop start with stage_in_args (which also counts the valid hypotheses)
 starts = [i for i, n in enumerate(names) if "stage_in_args" in n]
-i0, i1 = starts[30], starts[31]
+import os as _os
+k = int(_os.environ.get("ELLC_TRACE_FRAME", "30"))   # 30: the fused loop; 100: the loop of separate calls
+i0, i1 = starts[k], starts[k + 1]
 t0 = int(rows[i0]["Start_Timestamp"])
 # include the upload's pyramid kernel in front
 for r in rows[i0 - 2:i1]:
