@@ -1408,7 +1408,7 @@ struct StreamScope {
   ~StreamScope() { c->stream = saved; }
 };
 
-// Waits until the launched group's result records are there. One or two alignments with nothing else in flight (the tracking
+// Waits until the launched group's result records are there. A batch (of at most 64 alignments) with nothing else in flight (the tracking
 // call, a single alignment): the host polls the pad words of the records the finish kernel writes into pinned
 // memory — a microsecond after the kernel's store instead of the event's completion path — and falls back to the event after
 // 2 ms (a failed launch never writes them). Everything the context does next is on the same stream, behind whatever of this
@@ -1416,7 +1416,7 @@ struct StreamScope {
 static bool polls_results(const ellc_ctx* c, int B, int stream_idx) {
   // the only batch in flight, on the main stream: whatever the context launches next — the next group takes the lowest free set
   // and stream, i.e. these — is ordered behind this batch's trailing kernels by the stream itself
-  return c->poll_results && c->use_fused && B <= 2 && stream_idx == 0 && c->n_inflight <= 1;
+  return c->poll_results && c->use_fused && B <= 64 && stream_idx == 0 && c->n_inflight <= 1;
 }
 static hipError_t wait_batch_results(ellc_ctx* c, ellc_ctx::BatchSet& bs) {
   if (polls_results(c, bs.B, bs.stream_idx)) {
