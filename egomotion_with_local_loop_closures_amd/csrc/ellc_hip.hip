@@ -510,7 +510,9 @@ static void launch_finish(ellc_ctx* c, int B, const FusedArgs& fa, bool adaptive
 
 // saved weights of every level, after the finish kernel (gn_add_saved_weights_all reads the record it wrote)
 static void launch_add_saved_weights(ellc_ctx* c, int B) {
-  hipLaunchKernelGGL(gn_add_saved_weights_all, dim3(32, B, c->L), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, c->state_d,
+  // (blocks per alignment and level: enough for ~2 records per thread at level 0 of a semi-dense map when the batch is small —
+  // the loop is a chain of three dependent memory operations per record)
+  hipLaunchKernelGGL(gn_add_saved_weights_all, dim3(B <= 4 ? 128 : 32, B, c->L), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, c->state_d,
                      c->cfg.max_keyframes, c->fast ? 1 : 0);
 }
 
