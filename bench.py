@@ -668,17 +668,17 @@ def tracked_frame(api, synth, a, dev_index, with_lc=False):
         return d, its / n, batches[0]
 
     if not with_lc:
-        d, its, _ = loop(None, fused=True)
-        ds, _, _ = loop(None, fused=False)
+        d, its, _ = loop(None, fused=False)
+        df, _, _ = loop(None, fused=True)
         return {"workload": "C1 loop: upload + pyramid, one FCA alignment (early exit on, saved weights), observe + fill holes + regularise + export, "
-                            "640x480, 4 levels, arith %s, ONE ellc_track_frame call per frame (the depth stages enqueued behind the alignment, "
-                            "matrices built on the device; what ellc_main does); ms_per_frame_separate_calls: the same as five calls per frame, "
-                            "the pose through the host (same bits)" % a.arith,
-                "ms_per_frame": 1e3 * d, "frames_per_s": 1.0 / d, "mean_gn_iterations_per_frame": its, "ms_per_frame_separate_calls": 1e3 * ds}
-    dt_, its, nb = loop("thread", fused=True)
-    di_, _, _ = loop("inline", fused=True)
-    return {"workload": "the C1 loop (ellc_track_frame per frame) with the loop-closure batch of every 8th frame (%d candidates, ICA, a context of its "
-                        "own): on a host thread beside tracking, joined at the next push (GlobalOptimize.cpp:241 / :161), against the same batch run inline" % n_cand,
+                            "640x480, 4 levels, arith %s, five calls per frame with the pose through the host (what ellc_main does); "
+                            "ms_per_frame_fused_call: the same through ONE ellc_track_frame call per frame (the depth stages enqueued behind the "
+                            "alignment, matrices built on the device; same bits)" % a.arith,
+                "ms_per_frame": 1e3 * d, "frames_per_s": 1.0 / d, "mean_gn_iterations_per_frame": its, "ms_per_frame_fused_call": 1e3 * df}
+    dt_, its, nb = loop("thread")
+    di_, _, _ = loop("inline")
+    return {"workload": "the C1 loop with the loop-closure batch of every 8th frame (%d candidates, ICA, a context of its own): on a host thread beside "
+                        "tracking, joined at the next push (GlobalOptimize.cpp:241 / :161), against the same batch run inline" % n_cand,
             "ms_per_frame": 1e3 * dt_, "frames_per_s": 1.0 / dt_, "ms_per_frame_lc_inline": 1e3 * di_, "lc_batches": nb, "mean_gn_iterations_per_frame": its}
 
 
