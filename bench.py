@@ -631,9 +631,10 @@ def tracked_frame(api, synth, a, dev_index, with_lc=False):
             ring.align(np.arange(n_cand, dtype=np.int32), np.zeros(n_cand, np.int32), mode=api.MODE_ICA)
             batches[0] += 1
 
-        n, its = 64, 0
-        for f in range(8 + n):
-            if f == 8:
+        n, its = 256, 0
+        warm = 200   # untimed frames first: the loop is timed on a device in its working state (as the main workload, --device-warmup)
+        for f in range(warm + n):
+            if f == warm:
                 if worker[0] is not None:
                     worker[0].join(); worker[0] = None
                 ctx.sync()
