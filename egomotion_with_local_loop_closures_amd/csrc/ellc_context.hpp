@@ -100,6 +100,7 @@ struct ellc_ctx {
     int mode = 0, save_weights = 0;
     bool adaptive = false;                          // the group (one batch) runs the state-driven schedule (gn_fca_adaptive)
     int adaptive_first = 0;                         //   whose first graph holds this many launches
+    bool pollable = false;                          // its finish kernel ordered its result records for a polling host (FusedArgs::host_polls)
     bool resolved = true;                           // `done` has been waited for and the continuation, if one was needed, has run
   } batch_set[SETS];
   hipStream_t batch_stream[STREAMS] = {};   // [0] = stream; the others are created when first needed
@@ -175,6 +176,7 @@ struct ellc_ctx {
   int* track_gate_d = nullptr;
   const void* track_count_valid = nullptr;   // ellc_track_frame: the validity plane whose count the staging launch takes along
   int track_count_n = 0;                     //   and its size (0: nothing pending)
+  bool cur_pollable = false;    // the launch sequence being enqueued ends in a finish kernel the host may poll
   bool done_deferred = false;   // launch_group left the group's `done` event to its caller (ellc_track_frame records it behind the depth stages)
   bool track_call = false;   // the alignment being enqueued belongs to ellc_track_frame (set_track_fields)
   int* seed_acc = nullptr;   // dm_count_valid_block: sum and arrival ticket (zero between calls)

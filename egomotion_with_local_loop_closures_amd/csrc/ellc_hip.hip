@@ -549,6 +549,7 @@ static int adaptive_first_launches(const ellc_ctx* c, int B) {
 // ellc_track_frame marks the alignment it enqueues (c->track_call): that schedule's finish kernel also builds the observation's
 // matrices and sets the depth stages' gate. (A continuation does not: the host then runs the depth stages the usual way.)
 static void set_track_fields(const ellc_ctx* c, FusedArgs& fa, bool continuation) {
+  fa.host_polls = c->cur_pollable ? 1 : 0;
   const bool on = c->track_call && !continuation;
   fa.track_mats = on ? (ObsMats*)c->track_mats_d : nullptr;
   fa.track_gate = on ? c->track_gate_d : nullptr;
@@ -1380,7 +1381,7 @@ static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int 
   // (cur_adaptive_first: launches of the first graph of a state-driven schedule; it varies with the context's hint)
   const int first = schedule_is_adaptive(c, mode, B) ? c->cur_adaptive_first : 0;
   const auto key = std::make_tuple(B, continuation ? 0 : nu, mode,
-                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0) | (c->track_call ? 4 : 0) | (first << 4), set);
+                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0) | (c->track_call ? 4 : 0) | (c->cur_pollable ? 8 : 0) | (first << 4), set);
   auto it = c->graphs.find(key);
   if (it == c->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -1415,13 +1416,15 @@ struct StreamScope {
 // memory — a microsecond after the kernel's store instead of the event's completion path — and falls back to the event after
 // 2 ms (a failed launch never writes them). Everything the context does next is on the same stream, behind whatever of this
 // batch is still running (saved weights, the depth stages of a tracked frame).
+// (decided when the group is launched — its finish kernel then orders its stores for the host, FusedArgs::host_polls — and again
+// when it is waited for: nothing else may have been enqueued in between)
 static bool polls_results(const ellc_ctx* c, int B, int stream_idx) {
   // the only batch in flight, on the main stream: whatever the context launches next — the next group takes the lowest free set
   // and stream, i.e. these — is ordered behind this batch's trailing kernels by the stream itself
   return c->poll_results && c->use_fused && B <= 64 && stream_idx == 0 && c->n_inflight <= 1;
 }
 static hipError_t wait_batch_results(ellc_ctx* c, ellc_ctx::BatchSet& bs) {
-  if (polls_results(c, bs.B, bs.stream_idx)) {
+  if (bs.pollable && polls_results(c, bs.B, bs.stream_idx)) {
     const auto t0 = std::chrono::steady_clock::now();
     for (int spin = 0;; spin++) {
       bool all = true;
@@ -1545,14 +1548,17 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
   bs.adaptive_first = c->cur_adaptive_first;
   {
     StreamScope scope(c, run_stream);
+    bs.pollable = polls_results(c, B, si);
+    c->cur_pollable = bs.pollable;
     const ellc_status s = launch_align_graph(c, B, nu, bs.mode, bs.save_weights, set, false);
+    c->cur_pollable = false;
     if (s != ELLC_OK) {
       for (int v : bs.built_slots) invalidate_records(c, v);
       return s;
     }
     // (ellc_track_frame, whose host side polls the result record: the event goes behind the depth stages it enqueues next — in
     // front of them the record would hold their first launch back ~6 us)
-    c->done_deferred = c->track_call && polls_results(c, B, si);
+    c->done_deferred = c->track_call && bs.pollable;
     if (!c->done_deferred) ELLC_HIP(c, hipEventRecord(bs.done, c->stream));
   }
   for (int v : bs.built_slots) c->kf_rec_tag[v] = need;
