@@ -4,6 +4,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r03/track_trace3
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export ELLC_TRACK_NO_LC=1   # the two-thread loop crashes rocprofv3 (SIGSEGV inside its HIP interception; fine without the profiler)
 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/dbg/track_modes.py > $OUT/run.log 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, sys, os
