@@ -113,6 +113,8 @@ __global__ __launch_bounds__(256) void maxgrad_horizontal(const float* __restric
 // the level above, the (4PT+9)^2 region two above, from the (8PT+21)^2 region of the source — writing the part of each level
 // it owns (a 2x / 4x larger tile; the halo is recomputed by the neighbours: 1.9x / 2.4x redundant arithmetic at PT = 4 on images
 // of a few hundred KB, against two kernel boundaries saved; PT = 8 gave 80 blocks at 640x480 and a 17 us launch). Same integer arithmetic as pyr_down_u8, so the same bytes.
+// (r03, measured and dropped: the separable 5 + 5 form — row sums of the region above in LDS, then the column pass, 10 reads per value
+// instead of 25 — 12.96 against 11.45 us at 640x480: the launch is bound by its barriers and index arithmetic, not by its LDS reads.)
 // Regions are kept in image coordinates clipped to the level (REFLECT_101 is applied to coordinates, and a reflected
 // coordinate of a position the tile needs lies inside the clipped region).
 #define ELLC_PT 4
@@ -122,10 +124,27 @@ struct PyrChainArgs {
   int w[4], h[4];                // stored sizes of levels l .. l+3
   int steps;                     // 1..3
 };
+__device__ __forceinline__ int pyr5(const uint8_t* t, int stride, int x0, int y0, int lox, int loy, int sw, int sh, int x, int y) {
+  // (sum over the 5x5 [1 4 6 4 1]^2 window centred at (2x, 2y) of the level above + 128) >> 8; t holds that level from (lox, loy)
+  const int wk[5] = {1, 4, 6, 4, 1};
+  int cx[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) cx[k] = reflect101(2 * x + k - 2, sw) - lox;
+  int v = 0;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const uint8_t* r = t + (reflect101(2 * y + j - 2, sh) - loy) * stride;
+    int hsum = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) hsum += wk[k] * (int)r[cx[k]];
+    v += wk[j] * hsum;
+  }
+  (void)x0; (void)y0;
+  return (v + 128) >> 8;
+}
 __global__ __launch_bounds__(256) void pyr_down_chain_u8(PyrChainArgs a) {
   constexpr int R1 = 2 * ELLC_PT + 3, R2 = 2 * R1 + 3, R3 = 2 * R2 + 3;   // 11, 25, 53: region edge one, two, three levels above the tile
   __shared__ uint8_t lds[R3 * R3 + R2 * R2 + R1 * R1];   // three regions: 53^2, 25^2, 11^2
-  __shared__ uint16_t hs[R3 * R2];   // row sums of the separable form: (rows of the level above) x (columns of this level), each <= 16 * 255
   const int S = a.steps;
   // owned tile at the deepest produced level (level index S relative to the source)
   int lox[4], loy[4], hix[4], hiy[4];   // needed region per level (relative index 0 = source), [lo, hi) clipped to the level
@@ -154,30 +173,14 @@ __global__ __launch_bounds__(256) void pyr_down_chain_u8(PyrChainArgs a) {
   for (int l = 1; l <= S; l++) {
     const int wdt = stride(l), hgt = hiy[l] - loy[l];
     const uint8_t* up = buf(l - 1);
-    const int ustride = stride(l - 1), uh = hiy[l - 1] - loy[l - 1];
+    const int ustride = stride(l - 1);
     // what this block owns of level l: the 2^(S-l) times larger tile (the region beyond it is halo, recomputed by neighbours)
     const int sc = ELLC_PT << (S - l);
     const int ox0 = blockIdx.x * sc, oy0 = blockIdx.y * sc, ox1 = ox0 + sc, oy1 = oy0 + sc;
-    // The 5 x 5 kernel is [1 4 6 4 1]^T [1 4 6 4 1] and the arithmetic is integer, so the two passes of the separable form give the
-    // sum pyr5 gives (r03: 10 reads per value instead of 25). Horizontal: every row of the region above, at this level's columns.
-    for (int i = threadIdx.x; i < wdt * uh; i += 256) {
-      const int r = i / wdt, xx = i - r * wdt;
-      const int x = lox[l] + xx;
-      const uint8_t* row = up + r * ustride;
-      const int c0 = reflect101(2 * x - 2, a.w[l - 1]) - lox[l - 1], c1 = reflect101(2 * x - 1, a.w[l - 1]) - lox[l - 1];
-      const int c2 = reflect101(2 * x, a.w[l - 1]) - lox[l - 1], c3 = reflect101(2 * x + 1, a.w[l - 1]) - lox[l - 1];
-      const int c4 = reflect101(2 * x + 2, a.w[l - 1]) - lox[l - 1];
-      hs[i] = (uint16_t)((int)row[c0] + 4 * (int)row[c1] + 6 * (int)row[c2] + 4 * (int)row[c3] + (int)row[c4]);
-    }
-    __syncthreads();
-    // vertical: five row sums per value, rounding as cv::pyrDown does
     for (int i = threadIdx.x; i < wdt * hgt; i += 256) {
       const int yy = i / wdt, xx = i - yy * wdt;
       const int x = lox[l] + xx, y = loy[l] + yy;
-      const int r0 = reflect101(2 * y - 2, a.h[l - 1]) - loy[l - 1], r1 = reflect101(2 * y - 1, a.h[l - 1]) - loy[l - 1];
-      const int r2 = reflect101(2 * y, a.h[l - 1]) - loy[l - 1], r3 = reflect101(2 * y + 1, a.h[l - 1]) - loy[l - 1];
-      const int r4 = reflect101(2 * y + 2, a.h[l - 1]) - loy[l - 1];
-      const int v = ((int)hs[r0 * wdt + xx] + 4 * (int)hs[r1 * wdt + xx] + 6 * (int)hs[r2 * wdt + xx] + 4 * (int)hs[r3 * wdt + xx] + (int)hs[r4 * wdt + xx] + 128) >> 8;
+      const int v = pyr5(up, ustride, 0, 0, lox[l - 1], loy[l - 1], a.w[l - 1], a.h[l - 1], x, y);
       if (l < S) buf(l)[i] = (uint8_t)v;
       if (x >= ox0 && x < ox1 && y >= oy0 && y < oy1) a.dst[l - 1][(size_t)y * a.w[l] + x] = (uint8_t)v;
     }
