@@ -196,3 +196,37 @@ def test_depth_calls_fail_loudly_without_state(ellc):
     with pytest.raises(ellc.EllcError):
         ctx.depth_set_keyframe(0)     # slot has no image
     ctx.close()
+
+
+# ---- random scenes for the observation chain: a few by default, ELLC_DEPTH_FUZZ=n for a one-off wide sweep (r03: 60 cases, all green)
+import os  # noqa: E402
+_depth_fuzz = int(os.environ.get("ELLC_DEPTH_FUZZ", "3"))
+
+
+@pytest.mark.parametrize("case", range(_depth_fuzz))
+def test_observe_chain_bit_exact_on_random_scenes(oracle, ellc, case):
+    """observeDepthRow (candidate selection + line stereo over the work list), fillDepthHoles, regularizeDepthMap and the exported
+    depth on random scenes — size, camera motion, hypothesis density, which pixels hold hypotheses — against the oracle, bit for bit:
+    the two-launch observation must not depend on how the candidates fall into tiles, list regions and waves."""
+    rng = np.random.default_rng(1000 + case)
+    W, H = [(320, 240), (480, 270), (256, 192), (640, 480)][case % 4]
+    pair = synth.make_pair(W, H, seed=500 + case, rot=float(rng.uniform(0.001, 0.012)), trans=float(rng.uniform(0.005, 0.06)))
+    fx, fy, cx, cy = pair["intrinsics"]
+    ocfg = oracle.make_config(W, H, L, fx, fy, cx, cy)
+    kf = oracle.Frame(ocfg, pair["kf_image"], 1)
+    cur = oracle.Frame(ocfg, pair["cur_image"], 2)
+    cur.set_pose(origin=pair["xi_true"], world=pair["xi_true"])
+    st = synth.make_depth_state(W, H, 40 + case, pair["kf_image"], pair["idepth_true"])
+    drop = rng.random(st["valid"].shape) < rng.uniform(0.0, 0.7)   # thin the map: more depth creations, fewer updates
+    st["valid"][drop] = 0
+    dm = oracle.DepthMap(ocfg)
+    dm.set_keyframe(kf); dm.set_current(cur); dm.set_state(st)
+    ctx = ellc.Context(ellc.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, max_keyframes=1, max_frames=1))
+    ctx.keyframe_upload(0, pair["kf_image"]); ctx.frame_upload(0, pair["cur_image"])
+    ctx.depth_set_keyframe(0); ctx.depth_set_state(st)
+    dm.observe(); ctx.depth_observe(0, pair["xi_true"])
+    assert_state_equal(ctx.depth_get_state(), dm.get_state(), "observe (case %d)" % case)
+    dm.fill_holes(); ctx.depth_fill_holes()
+    dm.regularize(False); ctx.depth_regularize(False)
+    assert_state_equal(ctx.depth_get_state(), dm.get_state(), "fill + regularise (case %d)" % case)
+    ctx.close()
