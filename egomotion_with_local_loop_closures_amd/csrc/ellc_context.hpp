@@ -136,8 +136,6 @@ struct ellc_ctx {
   bool age_balance = true;      // age-balanced split of full-round grids (FusedArgs::age_rounds); ELLC_NO_AGE_BALANCE=1 disables
   double age_weight[5][4] = {{1, 1, 1, 1}, {1, 1, 1, 1}, {1.15, 0.85, 1, 1}, {1.2, 1.0, 0.8, 1}, {1.35, 1.15, 0.9, 0.6}};   // [rounds][round], ELLC_AGE_W (r01 sweep at 640x480, batch 32)
   double age_min_px_per_thread = 5.0;   // ELLC_AGE_MIN_PX
-  bool use_windows = true;              // LDS-staged image windows for the taps (fca_chunk_pass_win); ELLC_NO_WINDOWS=1 (diag) turns them off
-  double win_min_px = 24.0;             //   on levels with at least this many pixels per thread of the launch; ELLC_WIN_MIN (diag)
   bool use_adaptive = true;             // early-exit FCA schedules are state-driven (gn_fca_adaptive); ELLC_NO_ADAPTIVE=1 (diag) turns it off
   int adaptive_max_batch = 2;           //   for batches of at most this many alignments; ELLC_ADAPTIVE_MAX_BATCH (diag)
   int adaptive_hint = 0;                //   launches of the next first graph, from what the previous call needed (0: none yet)

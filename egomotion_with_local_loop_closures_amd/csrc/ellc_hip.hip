@@ -472,17 +472,6 @@ static void set_age_split(ellc_ctx* c, FusedArgs& fa, int B) {
   fa.age_rounds = R;
 }
 
-// Which levels serve their taps from LDS windows (fca_chunk_pass_win): those whose launches are long enough for the two
-// barriers and the staging round trip per band to pay — at least win_min_px pixels of the level per thread of the launch
-static void set_window_levels(const ellc_ctx* c, FusedArgs& fa, int B) {
-  for (int l = 0; l < ELLC_MAX_LEVELS; l++) {
-    fa.win_lv[l] = 0;
-    if (l >= c->L || !c->use_windows || !ELLC_WIN_ENABLED) continue;
-    const int nblk = choose_nblk(c, l, grid_batch(c, B));
-    fa.win_lv[l] = ((double)c->geom_h[l].n / (256.0 * nblk) >= c->win_min_px) ? 1 : 0;
-  }
-}
-
 static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
   const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
   const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
@@ -562,7 +551,6 @@ static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weight
   FusedArgs fa;
   fa.continuation = continuation ? 1 : 0;
   set_track_fields(c, fa, continuation);
-  for (int l = 0; l < ELLC_MAX_LEVELS; l++) fa.win_lv[l] = 0;   // (the state-driven tracking schedule keeps the global-memory taps)
   fa.seq = 0;
   fa.prev_level = -1;
   fa.prev_nblk = 0;
@@ -611,7 +599,6 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
   FusedArgs fa;
   fa.continuation = 0;
   set_track_fields(c, fa, false);
-  set_window_levels(c, fa, B);
   fa.seq = 0;
   fa.prev_level = -1;
   fa.prev_nblk = 0;
@@ -649,7 +636,6 @@ static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
   FusedArgs fa;
   fa.continuation = 0;
   set_track_fields(c, fa, false);
-  for (int l = 0; l < ELLC_MAX_LEVELS; l++) fa.win_lv[l] = 0;
   fa.seq = 0;
   fa.prev_level = -1;
   fa.prev_nblk = 0;
@@ -955,8 +941,6 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     if (const char* pp = getenv("ELLC_PIPE")) c->pipe = (pp[0] == '1');
     if (const char* am = getenv("ELLC_AGE_MIN_PX")) c->age_min_px_per_thread = atof(am);
     if (getenv("ELLC_NO_ADAPTIVE")) c->use_adaptive = false;
-    if (getenv("ELLC_NO_WINDOWS")) c->use_windows = false;
-    if (const char* wm = getenv("ELLC_WIN_MIN")) c->win_min_px = atof(wm);
     if (const char* ab = getenv("ELLC_ADAPTIVE_MAX_BATCH")) c->adaptive_max_batch = atoi(ab);
     if (const char* af = getenv("ELLC_ADAPTIVE_FIRST")) c->adaptive_first_override = atoi(af);
     if (const char* aw = getenv("ELLC_AGE_W")) {   // "R:w0,w1,..": weights for grids of R rounds
@@ -1851,7 +1835,6 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     fa.continuation = 0;
     set_track_fields(c, fa, false);
   set_track_fields(c, fa, false);
-    set_window_levels(c, fa, B);
     fa.g = a;
     fa.res = nullptr;
     fa.ica = 0;
@@ -1937,18 +1920,6 @@ __global__ __launch_bounds__(256) void calib_read_f32(const float* __restrict__ 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += p[i];
   if (acc == 1.2345e-30f) sink[0] = acc;   // keeps the loads alive
 }
-
-#ifdef ELLC_WINSTATS
-// statistics build only: the window statistics (g_win_stats), read and cleared
-ellc_status ellc_debug_win_stats(ellc_ctx* c, unsigned long long* out8) {
-  ELLC_ENTER(c);
-  ELLC_HIP(c, hipStreamSynchronize(c->stream));
-  ELLC_HIP(c, hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_win_stats), 8 * sizeof(unsigned long long)));
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  ELLC_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(g_win_stats), z, sizeof(z)));
-  return ELLC_OK;
-}
-#endif
 
 #ifdef ELLC_STAMPS
 // diagnostic build only: copies the cycle stamps of block (0,0) of the last fused launch

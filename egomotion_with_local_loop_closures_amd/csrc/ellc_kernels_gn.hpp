@@ -77,35 +77,9 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(g_u8 base, unsigned byte_
 template <int N>
 __device__ __forceinline__ float byte_f32(uint32_t w) { return (float)((w >> (8 * N)) & 0xffu); }   // v_cvt_f32_ubyteN
 
-// ---------------------------------------------------------------------------------------------------
-// LDS-staged image window (compiled with -DELLC_WINDOWS only: `make variant NAME=win DEFS=-DELLC_WINDOWS`; measured in r03 and
-// NOT shipped, see DESIGN.md section 4 "Why the taps are not staged in LDS"). A block works through its chunk of the (raster-ordered) compact list in BANDS; the pixels of a
-// band lie in a few keyframe rows and warp into a bounded window of the current image, which the block stages in LDS once per
-// band (coalesced 16-byte loads) and serves the 4 x 4 tap neighbourhoods from with ds_read2_b32 + v_alignbyte_b32.
-// Why (r03 counters and tools/micro/tap_paths.hip): the vector cache returns in order, so the cache-hit tap gathers of a wave
-// queue behind the misses of the record stream — every tap wait costs a trip to HBM (level-0 launch at 1280x960 dense: waves
-// parked 60 % of their cycles, VALU issuing 30 %, HBM at 2.6 TB/s: bound by neither). With the taps in LDS the only vector
-// loads of the pixel loop are its records, which can then be requested several iterations ahead.
-// Points whose neighbourhood is not wholly inside the window take the global-memory path (same arithmetic, same bits).
+// (r03 built an LDS-staged window variant of the taps behind -DELLC_WINDOWS: measured slower; removed from the
+// tree in r04 — it is in the history at 99afb34.)
 #define ELLC_LDS __attribute__((address_space(3)))
-#ifdef ELLC_WINDOWS
-#define ELLC_WIN_ENABLED 1
-#else
-#define ELLC_WIN_ENABLED 0
-#endif
-#ifdef ELLC_WINSTATS
-__device__ unsigned long long g_win_stats[8];   // make variant NAME=winstats DEFS="-DELLC_DIAG -DELLC_WINSTATS": bands with / without a window, wave-steps served from LDS / global interior / general path
-#define ELLC_WINSTAT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_win_stats[k], 1ull); } while (0)
-#else
-#define ELLC_WINSTAT(k) do { } while (0)
-#endif
-#define ELLC_WIN_BYTES (34 * 1024)
-struct TapWin {
-  const ELLC_LDS uint8_t* lds;
-  int on;                                  // block-uniform: a window is staged for this band
-  int y_lo, x_lo, pitch;                   // image row of window row 0, image column of window column 0 (multiple of 16), bytes per row
-  float fx_min, fx_max, fy_min, fy_max;    // floor(x1) / floor(y1) ranges whose neighbourhoods the window holds (subset of the interior)
-};
 
 struct Taps {
   float I;      // u8 tap (Frame.h:181-279), -1 when all four taps are out of bounds
@@ -125,46 +99,22 @@ struct Taps {
 // to come back from HBM before the (cache-resident) taps count as complete; issued behind them it stays in flight while
 // this pixel's arithmetic runs.
 struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
-template <bool WANT_GRAD, bool FAST = false, class AfterIssue = NoPrefetch, bool WIN = false>
-__device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, float x1, float y1, AfterIssue after_issue = AfterIssue(),
-                                          const TapWin* win = nullptr) {
+template <bool WANT_GRAD, bool FAST = false, class AfterIssue = NoPrefetch>
+__device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, float x1, float y1, AfterIssue after_issue = AfterIssue()) {
   Taps o;
   const float fx0 = floorf(x1), fy0 = floorf(y1);
   const float wx = x1 - fx0, wy = y1 - fy0;
   const float omx = 1.0f - wx, omy = 1.0f - wy;
   // fx0 in [1, cols-3] and fy0 in [1, rows-3], false for NaN: a value equals its clamp (v_med3_f32) exactly when it is in range.
-  // With a staged window the ranges are the window's (a subset of the interior): the same two clamps, other bounds.
-  const bool use_win = ELLC_WIN_ENABLED && WIN && win->on;   // block-uniform
-  const float bx_lo = use_win ? win->fx_min : 1.0f, bx_hi = use_win ? win->fx_max : (float)(cols - 3);
-  const float by_lo = use_win ? win->fy_min : 1.0f, by_hi = use_win ? win->fy_max : (float)(rows - 3);
-  const bool interior = (__builtin_amdgcn_fmed3f(fx0, bx_lo, bx_hi) == fx0) & (__builtin_amdgcn_fmed3f(fy0, by_lo, by_hi) == fy0);
+  const bool interior = (__builtin_amdgcn_fmed3f(fx0, 1.0f, (float)(cols - 3)) == fx0) & (__builtin_amdgcn_fmed3f(fy0, 1.0f, (float)(rows - 3)) == fy0);
   if (__builtin_amdgcn_ballot_w64(!interior) == 0ull) {
     // The 4x4 neighbourhood is fetched as one (byte-unaligned) 32-bit word per image row: columns x0-1 .. x0+2.
     const int x0 = (int)fx0, y0 = (int)fy0;
     uint32_t wa = 0, wb, wc, wd = 0;
-    if (WIN) ELLC_WINSTAT(use_win ? 2 : 3);
-    if (use_win) {
-      // from the LDS window: two aligned dwords per row and a funnel shift (an unaligned ds_read_b32 is served a lane at a
-      // time: 7 x slower, tools/micro/tap_paths.hip). The pitch is a multiple of 16, so every row has the same byte shift.
-      const unsigned o = __umul24((unsigned)(y0 - 1 - win->y_lo), (unsigned)win->pitch) + (unsigned)(x0 - 1 - win->x_lo);   // row y0 - 1
-      const unsigned sh = o & 3u;
-      const ELLC_LDS uint32_t* pa = (const ELLC_LDS uint32_t*)(win->lds + (o & ~3u));
-      const unsigned pw = (unsigned)win->pitch >> 2;
-      const ELLC_LDS uint32_t* pb = pa + pw;
-      const ELLC_LDS uint32_t* pc = pb + pw;
-      wb = __builtin_amdgcn_alignbyte(pb[1], pb[0], sh);
-      wc = __builtin_amdgcn_alignbyte(pc[1], pc[0], sh);
-      if (WANT_GRAD) {
-        const ELLC_LDS uint32_t* pd = pc + pw;
-        wa = __builtin_amdgcn_alignbyte(pa[1], pa[0], sh);
-        wd = __builtin_amdgcn_alignbyte(pd[1], pd[0], sh);
-      }
-    } else {
-      const unsigned ob = __umul24((unsigned)y0, (unsigned)sw) + (unsigned)x0 - 1u, oc = ob + (unsigned)sw;   // y0 >= 1, sw < 2^24: full-rate v_mad_u32_u24
-      wb = load_u32_unaligned(img, ob);
-      wc = load_u32_unaligned(img, oc);
-      if (WANT_GRAD) { wa = load_u32_unaligned(img, ob - (unsigned)sw); wd = load_u32_unaligned(img, oc + (unsigned)sw); }
-    }
+    const unsigned ob = __umul24((unsigned)y0, (unsigned)sw) + (unsigned)x0 - 1u, oc = ob + (unsigned)sw;   // y0 >= 1, sw < 2^24: full-rate v_mad_u32_u24
+    wb = load_u32_unaligned(img, ob);
+    wc = load_u32_unaligned(img, oc);
+    if (WANT_GRAD) { wa = load_u32_unaligned(img, ob - (unsigned)sw); wd = load_u32_unaligned(img, oc + (unsigned)sw); }
     __builtin_amdgcn_sched_barrier(0);
     after_issue();
     __builtin_amdgcn_sched_barrier(0);
@@ -211,7 +161,6 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
     return o;
   }
   // ---- general path: per-tap bounds tests of the reference (Frame.h:211-275)
-  if (WIN) ELLC_WINSTAT(4);
   after_issue();
   if (x1 != x1 || y1 != y1) {  // NaN: reference behaviour undefined; treated as out of bounds
     o.I = -1.0f; o.gx = 0.0f; o.gy = 0.0f;
@@ -508,11 +457,11 @@ __device__ __forceinline__ void jacobian_row_pre(float gradx, float grady, const
   J[5] = jt5 + jb5;
 }
 
-template <bool DEBUG, class PF = NoPrefetch, bool WIN = false>
+template <bool DEBUG, class PF = NoPrefetch>
 __device__ __forceinline__ FcaPix fca_pixel_pre(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
-                                                const float* S, unsigned i, const FcaIn& in, const FcaPre& pre, PF pf = PF(), const TapWin* win = nullptr) {
+                                                const float* S, unsigned i, const FcaIn& in, const FcaPre& pre, PF pf = PF()) {
   const Warp w = warp_point<true>(in.X, in.Y, in.Z, g, S);
-  const Taps t = tap_point<true, false, PF, WIN>(cur, g.sw, g.cols, g.rows, w.wx, w.wy, pf, win);
+  const Taps t = tap_point<true, false, PF>(cur, g.sw, g.cols, g.rows, w.wx, w.wy, pf);
   FcaPix o;
   jacobian_row_pre(t.gx, t.gy, pre, o.J);
   const bool oob = (t.I == -1.0f);
@@ -532,10 +481,10 @@ __device__ __forceinline__ FcaPix fca_pixel_pre(const GnArgs& a, const KfLevelDe
   return o;
 }
 
-template <bool DEBUG, bool DIVC, class PF = NoPrefetch, bool WIN = false>
+template <bool DEBUG, bool DIVC, class PF = NoPrefetch>
 __device__ __forceinline__ FcaPix fca_pixel_in(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
-                                               const float* S, unsigned i, const FcaIn& in, PF pf = PF(), const TapWin* win = nullptr) {
-  return fca_pixel_pre<DEBUG, PF, WIN>(a, K, g, cur, S, i, in, fca_prepare<DIVC>(g, in), pf, win);
+                                               const float* S, unsigned i, const FcaIn& in, PF pf = PF()) {
+  return fca_pixel_pre<DEBUG, PF>(a, K, g, cur, S, i, in, fca_prepare<DIVC>(g, in), pf);
 }
 
 template <bool DEBUG, bool DIVC>
@@ -563,9 +512,9 @@ __device__ __forceinline__ FcaInF fcaf_load(const KfLevelDev& K, unsigned i) {
 }
 
 // SAVEW: 1 = store the weights (saved-weights call), 0 = do not, -1 = a.save_w decides at run time
-template <bool DEBUG, class PF = NoPrefetch, int SAVEW = -1, bool WIN = false>
+template <bool DEBUG, class PF = NoPrefetch, int SAVEW = -1>
 __device__ __forceinline__ FcaPix fcaf_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const float* S, unsigned i,
-                                             const FcaInF& in, PF pf = PF(), const TapWin* win = nullptr) {
+                                             const FcaInF& in, PF pf = PF()) {
   const int y = (int)((in.xyI >> 12) & 0xfffu);
   const float Ikf = byte_f32<3>(in.xyI);
   const float p = in.p, q = __builtin_fmaf((float)y, g.rfy, -(g.cy * g.rfy));   // u / fx, v / fy
@@ -579,7 +528,7 @@ __device__ __forceinline__ FcaPix fcaf_pixel(const GnArgs& a, const KfLevelDev& 
   const float rz = __builtin_amdgcn_rcpf(pz);
   const float wx = __builtin_fmaf(px * rz, g.fx, g.cx);
   const float wy = __builtin_fmaf(py * rz, g.fy, g.cy);
-  const Taps t = tap_point<true, true, PF, WIN>(cur, g.sw, g.cols, g.rows, wx, wy, pf, win);
+  const Taps t = tap_point<true, true, PF>(cur, g.sw, g.cols, g.rows, wx, wy, pf);
   FcaPix o;
   // 1x6 row (:296-320) with A = fx gradx, B = fy grady, T = A p + B q:
   //   J = [-(q T + B), p T + A, B p - A q, A d, B d, -d T]
@@ -1277,7 +1226,6 @@ struct FusedArgs {
   int nblk_lv[ELLC_MAX_LEVELS];
   int max_it[ELLC_MAX_LEVELS];
   int nblk_grid;
-  int win_lv[ELLC_MAX_LEVELS];   // 1: the pixel pass of this level serves its taps from LDS windows (fca_chunk_pass_win)
   // tracked-frame call (ellc_track_frame): the finish kernel goes on to build the observation's matrices from the pose it has just
   // computed (track_setup_wave, ellc_kernels_depth.hpp) and opens the gate of the depth stages behind it; null: not such a call
   int host_polls;       // 1: the host may poll the result records' flag words (resolve_batch): the finish kernel orders its stores system-wide
@@ -1348,172 +1296,6 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
       for (i += stride; i < end; i += stride) {
         const FcaPix q = fca_pixel<false, DIVC>(a, K, g, cur, S, (unsigned)i);
         fca_accumulate_pixel(acc, q);
-      }
-    }
-  }
-  fca_acc_unpack<FAST>(acc, sums);
-}
-
-// ---- the same pass with the taps served from LDS windows (TapWin) -----------------------------------------------------------
-// position word of compact entry idx (block-uniform index: the band's first / last entry)
-template <bool FAST>
-__device__ __forceinline__ uint32_t rec_position_word(const KfLevelDev& K, int idx) {
-  return *(const ELLC_GLOBAL uint32_t*)((const ELLC_GLOBAL char*)K.crec + (unsigned)idx * (FAST ? 16u : 32u));
-}
-
-// The window of the band whose first / last entries sit at keyframe pixels (xf, yf) / (xl, yl) (raster order: the band lies in
-// rows yf .. yl, all columns unless yf == yl) with inverse depths in [dmin, dmax] (the level's range, left by the compaction).
-// For a fixed inverse depth the warp is a homography of the keyframe plane, and along the inverse depth a point moves on its
-// epipolar line monotonically (while p'z > 0): the bounding box of the warped band is that of the rectangle's four corners at
-// dmin and at dmax. Lanes 0..7 of every wave warp one corner each; the result is wave-uniform and identical in every wave.
-template <bool FAST>
-__device__ __forceinline__ void band_window(TapWin& w, int& nrows, const LevelGeom& g, const float* S, uint32_t first_pos, uint32_t last_pos,
-                                            float dmin, float dmax) {
-  const int xf = FAST ? (int)(first_pos & 0xfffu) : (int)(first_pos & 0xffffu), yf = FAST ? (int)((first_pos >> 12) & 0xfffu) : (int)(first_pos >> 16);
-  const int xl = FAST ? (int)(last_pos & 0xfffu) : (int)(last_pos & 0xffffu), yl = FAST ? (int)((last_pos >> 12) & 0xfffu) : (int)(last_pos >> 16);
-  const int c = (int)(threadIdx.x & 7u);
-  const float xs = (c & 1) ? ((yf == yl) ? (float)xl : (float)(g.cols - 1)) : ((yf == yl) ? (float)xf : 0.0f);
-  const float ys = (c & 2) ? (float)yl : (float)yf;
-  const float d = (c & 4) ? dmax : dmin;
-  const float p = (xs - g.cx) * g.rfx, q = (ys - g.cy) * g.rfy;
-  const float px = __builtin_fmaf(S[0], p, __builtin_fmaf(S[1], q, __builtin_fmaf(S[3], d, S[2])));
-  const float py = __builtin_fmaf(S[4], p, __builtin_fmaf(S[5], q, __builtin_fmaf(S[7], d, S[6])));
-  const float pz = __builtin_fmaf(S[8], p, __builtin_fmaf(S[9], q, __builtin_fmaf(S[11], d, S[10])));
-  const float rz = __builtin_amdgcn_rcpf(pz);
-  float x_lo = __builtin_fmaf(px * rz, g.fx, g.cx), y_lo = __builtin_fmaf(py * rz, g.fy, g.cy);
-  float x_hi = x_lo, y_hi = y_lo;
-  int ok = (pz > 1e-4f) && (fabsf(x_lo) < 1e6f) && (fabsf(y_lo) < 1e6f) && (dmax >= dmin);
-#pragma unroll
-  for (int m = 1; m < 8; m <<= 1) {
-    x_lo = fminf(x_lo, __shfl_xor(x_lo, m, 64)); x_hi = fmaxf(x_hi, __shfl_xor(x_hi, m, 64));
-    y_lo = fminf(y_lo, __shfl_xor(y_lo, m, 64)); y_hi = fmaxf(y_hi, __shfl_xor(y_hi, m, 64));
-    ok &= __shfl_xor(ok, m, 64);
-  }
-  // + the 4 x 4 neighbourhood (-1 .. +2) and one pixel for the rounding of the exact path's warp (it differs from this one in the last bits)
-  int iy0 = max(0, (int)floorf(y_lo) - 2), iy1 = min(g.rows - 1, (int)floorf(y_hi) + 3);
-  int ix0 = max(0, (int)floorf(x_lo) - 2) & ~15, ix1 = min(g.cols - 1, (int)floorf(x_hi) + 3);
-  iy0 = __builtin_amdgcn_readfirstlane(iy0); iy1 = __builtin_amdgcn_readfirstlane(iy1);
-  ix0 = __builtin_amdgcn_readfirstlane(ix0); ix1 = __builtin_amdgcn_readfirstlane(ix1);
-  ok = __builtin_amdgcn_readfirstlane(ok);
-  const int pitch = ((ix1 - ix0 + 1) + 15) & ~15;
-  nrows = iy1 - iy0 + 1;
-  const int bx0 = max(1, ix0 + 1), bx1 = min(g.cols - 3, ix1 - 2), by0 = max(1, iy0 + 1), by1 = min(g.rows - 3, iy1 - 2);
-  // (an empty range must switch the window off: v_med3 with crossed bounds would call points between them interior)
-  w.on = (ok && bx0 <= bx1 && by0 <= by1 && nrows * pitch <= ELLC_WIN_BYTES) ? 1 : 0;
-  w.y_lo = iy0; w.x_lo = ix0; w.pitch = pitch;
-  w.fx_min = (float)bx0; w.fx_max = (float)bx1;
-  w.fy_min = (float)by0; w.fy_max = (float)by1;
-}
-
-// window rows y_lo .. y_lo + nrows - 1, columns x_lo .. x_lo + pitch - 1 of the image into LDS: 16 bytes per lane and step, four
-// steps in flight. (Columns past the image row and the tail of the last row read into the following bytes: the image buffers
-// are allocated with 16 spare bytes; those window bytes are never used, the interior test keeps taps left of cols - 1.)
-__device__ __forceinline__ void stage_window(const TapWin& w, int nrows, g_u8 img, int sw, ELLC_LDS uint8_t* lds) {
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  typedef u32x4 u32x4_a1 __attribute__((aligned(1)));
-  const int n16 = w.pitch >> 4, total = nrows * n16;
-  const int dq = ELLC_GN_THREADS / n16, dr = ELLC_GN_THREADS - dq * n16;   // 256 = dq * n16 + dr (uniform)
-  int r = (int)threadIdx.x / n16, c = (int)threadIdx.x - r * n16;
-  for (int base = 0; base < total; base += 4 * ELLC_GN_THREADS) {   // uniform trip count
-    u32x4 v[4];
-    int rr[4], cc[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      rr[k] = r; cc[k] = c;
-      const int rl = min(r, nrows - 1);   // (lanes past the end load a valid address and store nothing)
-      v[k] = *(const ELLC_GLOBAL u32x4_a1*)(img + (unsigned)((w.y_lo + rl) * sw + w.x_lo + 16 * c));
-      c += dr; r += dq;
-      if (c >= n16) { c -= n16; r++; }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (rr[k] < nrows) *(ELLC_LDS u32x4*)(lds + rr[k] * w.pitch + 16 * cc[k]) = v[k];
-  }
-}
-
-// band length in iterations (even, so that the two record slots are back in phase at every band start): three quarters of the
-// rows the window holds (the rest is the neighbourhood, the margin and the drift of a rotated band), at the level's density
-__device__ __forceinline__ int band_iterations(const LevelGeom& g, int V) {
-  const int pitch_est = ((g.cols + 15) & ~15) + 16;
-  const float rows_budget = 0.75f * (float)(ELLC_WIN_BYTES / pitch_est - 8);
-  const float entries = rows_budget * (float)g.cols * ((float)V / (float)g.n);
-  int ni = (int)(entries * (1.0f / ELLC_GN_THREADS));
-  ni = min(64, max(4, ni)) & ~3;   // a multiple of the record slots of the windowed loop (ELLC_WIN_SLOTS), which are then in phase at every band start
-  return __builtin_amdgcn_readfirstlane(ni);
-}
-
-#ifndef ELLC_WIN_SLOTS
-#define ELLC_WIN_SLOTS 4   // record slots of the windowed tolerance-mode loop: ELLC_WIN_SLOTS - 1 records in flight per thread
-#endif
-template <bool DIVC, bool FAST, int SAVEW>
-__device__ __forceinline__ void fca_chunk_pass_win(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const float* newS, int begin,
-                                                   int end, int V, const FcaIn& first, const FcaInF& firstf, ELLC_LDS uint8_t* lds, float (&sums)[27]) {
-  constexpr int stride = ELLC_GN_THREADS;
-  const int t = threadIdx.x;
-  float S[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) S[i] = newS[i];
-  FcaAcc acc;
-  fca_acc_zero(acc);
-  const int band = band_iterations(g, V) * stride;
-  const float dmin = __builtin_bit_cast(float, (uint32_t)as_global(K.count)[1]), dmax = __builtin_bit_cast(float, (uint32_t)as_global(K.count)[2]);
-  uint32_t pos_first = 0, pos_last = 0;
-  if (begin < end) {
-    pos_first = rec_position_word<FAST>(K, begin);
-    pos_last = rec_position_word<FAST>(K, min(end, begin + band) - 1);
-  }
-  TapWin w;
-  w.lds = lds;
-  int i = begin + t;
-  // With the taps in LDS the loop's only vector loads are its records, so (unlike in fca_chunk_pass, where every tap wait
-  // also waits for the older record load) several can be kept in flight: slot k holds the record of step k mod SLOTS and is
-  // refilled, behind that step's LDS reads, with the record SLOTS - 1 steps ahead.
-  constexpr int SLOTS = ELLC_WIN_SLOTS;
-  FcaInF fs[SLOTS];
-  fs[0] = firstf;
-  if constexpr (FAST) {
-#pragma unroll
-    for (int k = 1; k < SLOTS - 1; k++) fs[k] = fcaf_load(K, (unsigned)max(0, min(i + k * stride, end - 1)));
-    fs[SLOTS - 1] = firstf;
-  }
-  FcaIn e0 = first, e1 = first;
-  for (int bs = begin; bs < end; bs += band) {   // block-uniform
-    const int be = min(end, bs + band);
-    int nrows;
-    band_window<FAST>(w, nrows, g, S, pos_first, pos_last, dmin, dmax);
-    if (bs + band < end) {   // the next band's first / last entries, requested a band ahead
-      pos_first = rec_position_word<FAST>(K, bs + band);
-      pos_last = rec_position_word<FAST>(K, min(end, bs + 2 * band) - 1);
-    }
-    __syncthreads();   // the previous band's reads of the window are done
-    if (threadIdx.x == 0) ELLC_WINSTAT(w.on ? 0 : 1);
-    if (w.on) stage_window(w, nrows, cur, g.sw, lds);
-    __syncthreads();
-    if constexpr (FAST) {
-      auto step = [&](const FcaInF& in, FcaInF& fill) {
-        const int ia = i + (SLOTS - 1) * stride;
-        auto prefetch = [&]() { fill = fcaf_load(K, (unsigned)min(ia, end - 1)); };
-        fca_accumulate_pixel(acc, fcaf_pixel<false, decltype(prefetch), SAVEW, true>(a, K, g, cur, S, (unsigned)i, in, prefetch, &w));
-        i += stride;
-      };
-      while (i < be) {   // a band is a multiple of SLOTS steps (band_iterations), the last band ends with the chunk
-#pragma unroll
-        for (int k = 0; k < SLOTS; k++) {
-          step(fs[k], fs[(k + SLOTS - 1) % SLOTS]);
-          if (i >= be) break;
-        }
-      }
-    } else {
-      auto step = [&](const FcaIn& in, FcaIn& fill) {
-        const int i1 = i + stride;
-        auto prefetch = [&]() { fill = fca_load(K, (unsigned)min(i1, end - 1)); };
-        fca_accumulate_pixel(acc, fca_pixel_in<false, DIVC, decltype(prefetch), true>(a, K, g, cur, S, (unsigned)i, in, prefetch, &w));
-        i += stride;
-      };
-      while (i < be) {
-        step(e0, e1);
-        if (i >= be) break;
-        step(e1, e0);
       }
     }
   }
@@ -1622,12 +1404,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   }
   if (skip) return;
   float sums[27];
-  if (ELLC_WIN_ENABLED && FAST && fa.win_lv[a.level]) {   // launch-uniform (exact mode: the windowed pass spills at 128 registers)
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[ELLC_WIN_BYTES + 16];
-    fca_chunk_pass_win<DIVC, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, V, first, firstf, (ELLC_LDS uint8_t*)s_win, sums);
-  } else {
-    fca_chunk_pass<DIVC, PIPE, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
-  }
+  fca_chunk_pass<DIVC, PIPE, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
   ELLC_STAMP(7);
   ELLC_BSTAMP(2);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;

@@ -75,11 +75,6 @@ __global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
   __syncthreads();
   if (threadIdx.x == 0) {
     K.tile_count[local] = ws[0] + ws[1] + ws[2] + ws[3];
-    // the level's inverse-depth range [count[1], count[2]] (f32 bit patterns: positive floats order like integers), gathered by
-    // prep_scatter with atomicMin / atomicMax; the Gauss-Newton passes bound their image windows with it (band_window)
-#ifdef ELLC_WINDOWS
-    if (local == 0) { K.count[1] = 0x7f800000; K.count[2] = 0; }
-#endif
   }
 }
 
@@ -159,7 +154,6 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   float hacc[27];
 #pragma unroll
   for (int q = 0; q < 27; q++) hacc[q] = 0.0f;
-  float dlo = __builtin_inff(), dhi = 0.0f;   // inverse-depth range of this thread's records
   // The 48-byte ICA records leave through an LDS staging block of 256 records so that consecutive lanes store consecutive
   // 16-byte words (lane-per-record, every store instruction would touch a third of each line): -5 % on the kernel. The
   // 32-byte FCA records are stored directly (r01 A/B: the two extra barriers per 256 records cost more than the half-line
@@ -222,12 +216,6 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
     if (r < nvalid) {
     const int i = (int)s_idx[r];
     const float Z = s_Z[r];
-#ifdef ELLC_WINDOWS
-    {
-      const float dd = __builtin_amdgcn_rcpf(Z);
-      dlo = fminf(dlo, dd); dhi = fmaxf(dhi, dd);
-    }
-#endif
     const unsigned pos = tile_off + (unsigned)r;
     int y = (int)(((float)i + 0.5f) * inv_cols);   // i < 2^24: exact conversion; corrected below
     if (y * cols > i) y--;
@@ -298,21 +286,6 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
     }
   }
   if (need & 4) block_reduce_store<27>(hacc, K.hpart + (size_t)local * ELLC_PART_STRIDE);   // block-uniform condition
-#ifdef ELLC_WINDOWS
-  if (nvalid > 0) {   // block-uniform: the tile's inverse-depth range joins the level's (a little wider than exact: rcp is 1 ulp)
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-      dlo = fminf(dlo, __shfl_xor(dlo, m, 64));
-      dhi = fmaxf(dhi, __shfl_xor(dhi, m, 64));
-    }
-    if (lane == 0 && dhi > 0.0f) {
-      atomicMin((unsigned*)(K.count + 1), __builtin_bit_cast(unsigned, dlo * 0.999999f));
-      atomicMax((unsigned*)(K.count + 2), __builtin_bit_cast(unsigned, dhi * 1.000001f));
-    }
-  }
-#else
-  (void)dlo; (void)dhi;
-#endif
 }
 
 // ICA: H of one (keyframe slot, level) from the per-tile sums (fixed-order f64 combine), then cv::Mat::inv(DECOMP_LU)

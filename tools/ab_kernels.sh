@@ -4,8 +4,7 @@
 OUT=gpurun_out/$1; shift
 mkdir -p $OUT
 for v in "$@"; do
-  unset ELLC_NO_WINDOWS
-  if [ "$v" = tree ]; then unset ELLC_LIB_PATH; LIBARG=""; elif [ "$v" = nowin ]; then export ELLC_LIB_PATH=$PWD/build/libellc_hip_diag.so ELLC_NO_WINDOWS=1; LIBARG="--lib $ELLC_LIB_PATH"; else export ELLC_LIB_PATH=$PWD/build/libellc_hip_$v.so; LIBARG="--lib $ELLC_LIB_PATH"; fi
+  if [ "$v" = tree ]; then unset ELLC_LIB_PATH; LIBARG=""; else export ELLC_LIB_PATH=$PWD/build/libellc_hip_$v.so; LIBARG="--lib $ELLC_LIB_PATH"; fi
   for rep in 1 2; do
     python3 tools/profile_kernel.py --arith fast > $OUT/k640_${v}_$rep.json 2>> $OUT/err.log
     python3 tools/profile_kernel.py --arith fast --width 1280 --height 960 --levels 5 --dense --batch 16 --reps 10 > $OUT/kc4_${v}_$rep.json 2>> $OUT/err.log

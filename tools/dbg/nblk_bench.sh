@@ -1,4 +1,4 @@
-export ELLC_LIB_PATH=$PWD/build/libellc_hip_diag.so ELLC_NO_WINDOWS=1
+export ELLC_LIB_PATH=$PWD/build/libellc_hip_diag.so
 for N in "" "8" "8,8" "8,4,2" "6" "16"; do
   for rep in 1 2; do
   echo -n "bench NBLK='$N': "; ELLC_NBLK=$N python3 bench.py --lib $ELLC_LIB_PATH --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('value %.3fM ms/step %.4f k0 %.1f us' % (d['value']/1e6, d['ms_per_step'], 1e3*d['roofline']['avg_launch_ms']))"

@@ -46,13 +46,6 @@ fr_slots = slots if a.dense else (slots // B).astype(np.int32)
 if a.device_warmup > 0:   # the same launches, untimed, until the device is in its working state (as bench.py's --device-warmup)
     ctx.profile_gn_kernel(slots, fr_slots, a.level, reps=a.device_warmup)
 ms, alg, V = ctx.profile_gn_kernel(slots, fr_slots, a.level, reps=a.reps)
-try:   # diagnostic build: how the window path was used
-    import ctypes as C
-    st = (C.c_ulonglong * 8)()
-    if ctx._l.ellc_debug_win_stats(ctx.h, st) == 0:
-        print("win_stats bands_on %d bands_off %d wave_steps lds %d global_interior %d general %d" % tuple(st[:5]), file=sys.stderr)
-except AttributeError:
-    pass
 cal_bytes = a.calib_mb << 20
 cms = ctx.profile_calibrate_read(cal_bytes, reps=5)
 print(json.dumps({"kernel": "gn_fca_fused", "arith": a.arith, "size": [W, H, L], "dense": bool(a.dense), "level": a.level, "batch": B, "coalesce": a.coalesce, "alignments_per_launch": K, "concurrent_batches": a.inflight, "avg_ms": ms, "algorithmic_bytes": alg, "valid_pixels": V,
