@@ -37,12 +37,14 @@ struct __attribute__((aligned(16))) FcaRec {
   double invZ;
 };
 
-// The same pixel as the tolerance-mode FCA pass reads it (cfg.arith = ELLC_ARITH_FAST): 16 bytes. Position and keyframe
-// intensity share one word (x: bits 0-11, y: bits 12-23, intensity: bits 24-31, hence width, height <= 4096 in this mode);
-// p = (x - cx) / fx is stored (one conversion less per pixel and iteration; q comes from y with one fma), d = 1/Z in f32.
-// Z itself is not needed: the pass warps (p, q, 1) + t d, the point divided by Z (see fcaf_pixel).
+// The same pixel as the tolerance-mode FCA pass reads it (cfg.arith = ELLC_ARITH_FAST): 16 bytes. The first word is the row y AS
+// AN f32 with the keyframe intensity in its eight low mantissa bits (y < 4096 leaves the twelve low bits of its f32 zero; hence
+// width, height <= 4096 in this mode): the pass masks the byte off and has y ready for its multiply-add, no integer field to
+// extract and convert. p = (x - cx) / fx is stored (q comes from y with one fma; x itself is needed only where weights are saved or
+// planes are dumped, and comes back as rint(p fx + cx): fcaf_position), d = 1/Z in f32. Z itself is not needed: the pass warps
+// (p, q, 1) + t d, the point divided by Z (see fcaf_pixel).
 struct __attribute__((aligned(16))) FcaRecF {
-  uint32_t xyI;
+  uint32_t yI;
   float p, var, d;
 };
 
@@ -76,9 +78,19 @@ struct KfLevelDev {
   int* tile_count;            // per-tile (ELLC_TILE pixels) counts, then exclusive offsets
 };
 
+// One current-frame slot at one level. tex (tolerance mode only, r04): one 32-bit TEXEL per pixel, pitch sw — the grey value and
+// TWICE the two central differences of frame::calculateGradient (Frame.cpp:185-285), integers all three:
+//   bits 0-7 I,  bits 14-22 I(x+1,y) - I(x-1,y) (9-bit two's complement),  bits 23-31 I(x,y+1) - I(x,y-1)
+// so that the bilinear taps of image and gradient planes at a warped point are its 2 x 2 texels — two 8-byte loads — instead of a
+// 4 x 4 byte neighbourhood fetched as four unaligned dwords (the CU's vector cache delivers about 32 bytes per cycle to the lanes and
+// an unaligned dword costs two aligned ones: tools/micro/gather_rate.hip). Border texels carry gradient 0: only points whose four
+// texels are interior read them (the others take the per-tap path on the u8 image, which has the reference's border rules).
 struct FrLevelDev {
   uint8_t* img;               // sw*sh
+  uint32_t* tex;              // sw*sh texels, or null (exact arithmetic)
 };
+#define ELLC_TEX_GX_SHIFT 14
+#define ELLC_TEX_GY_SHIFT 23
 
 // Per-alignment state that persists across the launches of one ellc_align.
 #define DM_OBS_REGIONS 64   // regions of the depth map's observation work list (dm_observe_select / dm_observe_walk)

@@ -80,11 +80,82 @@ __device__ __forceinline__ float byte_f32(uint32_t w) { return (float)((w >> (8 
 // (r03 built an LDS-staged window variant of the taps behind -DELLC_WINDOWS: measured slower; removed from the
 // tree in r04 — it is in the history at 99afb34.)
 #define ELLC_LDS __attribute__((address_space(3)))
+#ifndef ELLC_FCAF_PIPE_MIN
+#define ELLC_FCAF_PIPE_MIN 96   // the tolerance-mode pixel loop is software-pipelined over pixels from this many pixels per thread on (fca_chunk_pass)
+#endif
 
 struct Taps {
   float I;      // u8 tap (Frame.h:181-279), -1 when all four taps are out of bounds
   float gx, gy; // gradient taps (Frame.h:283-394) on frame::calculateGradient's planes (Frame.cpp:185-285)
 };
+
+// The general path of the taps: per-tap bounds tests of the reference (Frame.h:211-275). FAST: the gradients are returned twice
+// their value, as the interior branches of that mode return them.
+template <bool WANT_GRAD, bool FAST>
+__device__ __forceinline__ Taps tap_general(g_u8 img, int sw, int cols, int rows, float x1, float y1) {
+  Taps o;
+  const float fx0 = floorf(x1), fy0 = floorf(y1);
+  const float wx = x1 - fx0, wy = y1 - fy0;
+  const float omx = 1.0f - wx, omy = 1.0f - wy;
+  if (x1 != x1 || y1 != y1) {  // NaN: reference behaviour undefined; treated as out of bounds
+    o.I = -1.0f; o.gx = 0.0f; o.gy = 0.0f;
+    return o;
+  }
+  const float nC = (float)(cols - 1), nR = (float)(rows - 1);
+  const bool xf_bad = (fx0 < 0.0f) || (fx0 > nC);
+  const bool xc_bad = (x1 < 0.0f) || (x1 > nC);
+  const bool yf_bad = (fy0 < 0.0f) || (fy0 > nR);
+  const bool yc_bad = (y1 < 0.0f) || (y1 > nR);
+  const bool v00 = !(xf_bad || yf_bad), v01 = !(xc_bad || yf_bad), v10 = !(xf_bad || yc_bad), v11 = !(xc_bad || yc_bad);
+  if (!(v00 || v01 || v10 || v11)) {
+    o.I = -1.0f; o.gx = 0.0f; o.gy = 0.0f;   // gradient taps: four zero samples interpolate to 0
+    return o;
+  }
+  const int x0 = (int)fminf(fmaxf(fx0, -4.0f), nC + 4.0f);
+  const int y0 = (int)fminf(fmaxf(fy0, -4.0f), nR + 4.0f);
+  const int xb = clampi(x0, 0, cols - 1), xc = clampi(x0 + 1, 0, cols - 1);
+  const int yb = clampi(y0, 0, rows - 1), yc = clampi(y0 + 1, 0, rows - 1);
+  // uniform base pointer + unsigned 32-bit lane offsets (SGPR-base global loads, no 64-bit lane arithmetic)
+  const unsigned rb = __umul24((unsigned)yb, (unsigned)sw), rc = __umul24((unsigned)yc, (unsigned)sw);   // rows are clamped to >= 0
+  const float Pbb = (float)img[rb + (unsigned)xb], Pbc = (float)img[rb + (unsigned)xc];
+  const float Pcb = (float)img[rc + (unsigned)xb], Pcc = (float)img[rc + (unsigned)xc];
+  {
+    const float p00 = v00 ? Pbb : 0.0f, p01 = v01 ? Pbc : 0.0f, p10 = v10 ? Pcb : 0.0f, p11 = v11 ? Pcc : 0.0f;
+    const float top = (omx * p00) + (wx * p01);
+    const float btm = (omx * p10) + (wx * p11);
+    o.I = (omy * top) + (wy * btm);
+  }
+  if (WANT_GRAD) {
+    const int xa = clampi(x0 - 1, 0, cols - 1), xd = clampi(x0 + 2, 0, cols - 1);
+    const int ya = clampi(y0 - 1, 0, rows - 1), yd = clampi(y0 + 2, 0, rows - 1);
+    const unsigned ra = __umul24((unsigned)ya, (unsigned)sw), rd = __umul24((unsigned)yd, (unsigned)sw);
+    const float Pba = (float)img[rb + (unsigned)xa], Pbd = (float)img[rb + (unsigned)xd];
+    const float Pca = (float)img[rc + (unsigned)xa], Pcd = (float)img[rc + (unsigned)xd];
+    const float Pab = (float)img[ra + (unsigned)xb], Pac = (float)img[ra + (unsigned)xc];
+    const float Pdb = (float)img[rd + (unsigned)xb], Pdc = (float)img[rd + (unsigned)xc];
+    // scale 1 on the border column/row of the tap itself, 0.5 inside
+    const float sx0 = (x0 <= 0 || x0 >= cols - 1) ? 1.0f : 0.5f;
+    const float sx1 = (x0 + 1 <= 0 || x0 + 1 >= cols - 1) ? 1.0f : 0.5f;
+    const float sy0 = (y0 <= 0 || y0 >= rows - 1) ? 1.0f : 0.5f;
+    const float sy1 = (y0 + 1 <= 0 || y0 + 1 >= rows - 1) ? 1.0f : 0.5f;
+    // d/dx at (yb,x0) (yb,x0+1) (yc,x0) (yc,x0+1)
+    float g00 = sx0 * (Pbc - Pba), g01 = sx1 * (Pbd - Pbb), g10 = sx0 * (Pcc - Pca), g11 = sx1 * (Pcd - Pcb);
+    g00 = v00 ? g00 : 0.0f; g01 = v01 ? g01 : 0.0f; g10 = v10 ? g10 : 0.0f; g11 = v11 ? g11 : 0.0f;
+    float top = (omx * g00) + (wx * g01);
+    float btm = (omx * g10) + (wx * g11);
+    o.gx = (omy * top) + (wy * btm);
+    // d/dy at the same four positions
+    float h00 = sy0 * (Pcb - Pab), h01 = sy0 * (Pcc - Pac), h10 = sy1 * (Pdb - Pbb), h11 = sy1 * (Pdc - Pbc);
+    h00 = v00 ? h00 : 0.0f; h01 = v01 ? h01 : 0.0f; h10 = v10 ? h10 : 0.0f; h11 = v11 ? h11 : 0.0f;
+    top = (omx * h00) + (wx * h01);
+    btm = (omx * h10) + (wx * h11);
+    o.gy = (omy * top) + (wy * btm);
+    if (FAST) { o.gx *= 2.0f; o.gy *= 2.0f; }   // as the interior branch of this mode returns them
+  } else {
+    o.gx = 0.0f; o.gy = 0.0f;
+  }
+  return o;
+}
 
 // The three bilinear taps of one warped point. The gradient planes are never materialised: the four
 // gradient samples are rebuilt from the u8 image with the reference's border rules (interior central
@@ -160,66 +231,102 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
     }
     return o;
   }
-  // ---- general path: per-tap bounds tests of the reference (Frame.h:211-275)
   after_issue();
-  if (x1 != x1 || y1 != y1) {  // NaN: reference behaviour undefined; treated as out of bounds
-    o.I = -1.0f; o.gx = 0.0f; o.gy = 0.0f;
+  return tap_general<WANT_GRAD, FAST>(img, sw, cols, rows, x1, y1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The taps of the tolerance mode (cfg.arith = ELLC_ARITH_FAST), written against what the vector ALU of gfx950 issues at which
+// rate (tools/micro/valu_rates.hip, r04; cycles per wave-instruction with four or more waves per SIMD):
+//   ~2.4  v_add / sub / mul / fma / fmac_f32, v_mov, v_and / or / xor, v_add / sub_u32, v_lshrrev, v_ashrrev — with VGPR, inline or
+//         literal operands only;
+//   ~4.4  every other vector instruction — conversions, floor / fract, min / max / med3, compares, selects, the three-operand
+//         integer forms, v_lshlrev, SDWA and DPP forms, f64, the packed f32 forms (v_pk_fma_f32 does two fmas for the price of 1.8) —
+//         AND any instruction of the first group that names an SGPR;
+//   ~8.5  v_rcp / v_rsq_f32.
+// Hence: the per-block constants live in VGPRs (FcafConst); floor and fraction come from v_cvt_flr_i32_f32 and v_fract_f32 (the
+// interior test is two unsigned compares on the integers); the two texel rows are two uniform base pointers with ONE lane offset;
+// and, since the CU's vector cache hands the lanes about 32 bytes per cycle and an unaligned dword costs two aligned ones
+// (tools/micro/gather_rate.hip: 18 cycles for an unaligned dword gather of 64 lanes, 8.7 aligned, 16.4 for 8 bytes at a 4-aligned
+// address; the 4 x 4 byte neighbourhood as four unaligned dwords: 72 cycles per pixel step of a wave, more than the step's
+// arithmetic takes a CU), the taps come from the frame's TEXEL planes (FrLevelDev::tex): grey value and twice the two central
+// differences per pixel in one word, so that image and gradient taps are the point's 2 x 2 texels — two 8-byte loads, 33 cycles.
+typedef const ELLC_GLOBAL uint32_t* g_tex;
+struct TapTex { g_tex r0, r1; };   // texel rows y0 and y0 + 1 sit at r0 / r1 + y0 * pitch + x0
+__device__ __forceinline__ TapTex tap_tex(const uint32_t* tex, int sw) {
+  TapTex t;
+  t.r0 = (g_tex)tex;
+  t.r1 = t.r0 + sw;
+  return t;
+}
+template <int N>
+__device__ __forceinline__ float cvt_ubyte(uint32_t w) {   // opaque to the optimiser on purpose, see above
+  float f;
+  if (N == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(w));
+  else if (N == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(w));
+  else if (N == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(w));
+  else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(w));
+  return f;
+}
+__device__ __forceinline__ int cvt_floor_i32(float x) {   // floor, then the saturating conversion (NaN gives 0)
+  int i;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(x));
+  return i;
+}
+__device__ __forceinline__ float tex_gx2(uint32_t w) { return (float)(int)__builtin_amdgcn_sbfe(w, ELLC_TEX_GX_SHIFT, 9); }   // (the builtin returns unsigned)
+__device__ __forceinline__ float tex_gy2(uint32_t w) { return (float)((int)w >> ELLC_TEX_GY_SHIFT); }
+// Two halves, so that a pixel loop can put other work between the request and the use of the texels (fca_chunk_pass requests the
+// next pixel's texels before it works on the current pixel's): tap_request_f decides interior / general for the wave and requests
+// the 2 x 2 texels; tap_finish_f turns them (or, on the general path, the synchronous per-tap loads from the u8 image) into the taps.
+struct TapReq {
+  uint32_t t00, t01, t10, t11;   // texels (x0, y0) (x0 + 1, y0) (x0, y0 + 1) (x0 + 1, y0 + 1), valid when interior
+  bool interior;                 // wave-uniform: every lane that was active at the request samples the interior
+};
+template <class AfterIssue = NoPrefetch>
+__device__ __forceinline__ TapReq tap_request_f(const TapTex& tt, int sw, int cols, int rows, float x1, float y1, AfterIssue after_issue = AfterIssue()) {
+  TapReq q;
+  const int x0 = cvt_floor_i32(x1), y0 = cvt_floor_i32(y1);
+  // x0 in [1, cols - 3] and y0 in [1, rows - 3]: the four texels carry central differences (all 16 neighbours in range, none of the
+  // four taps on a border column / row); a NaN coordinate converts to 0 and an infinite one saturates: neither is interior
+  const bool interior = ((unsigned)(x0 - 1) <= (unsigned)(cols - 4)) & ((unsigned)(y0 - 1) <= (unsigned)(rows - 4));
+  q.interior = (__builtin_amdgcn_ballot_w64(!interior) == 0ull);
+  // The texels are requested unconditionally — a lane that is not interior asks for the plane's first texels instead — so that the
+  // request is straight-line code: tap_finish_f uses the words only when the whole wave is interior. (A branch here makes the
+  // compiler duplicate the caller's record refill into both arms; the refilled slot is carried around the caller's loop as a
+  // 128-bit register tuple while its load is in flight, and merging two tuples costs copies that wait for the load.)
+  const unsigned off = interior ? (__umul24((unsigned)y0, (unsigned)sw) + (unsigned)x0) * 4u : 0u;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+#ifdef ELLC_X_NOTAPS   // experiment: no tap loads (the words are made up from the offset)
+  q.t00 = off * 0x9e3779b1u; q.t01 = off * 0x85ebca6bu; q.t10 = off * 0xc2b2ae35u; q.t11 = off * 0x27d4eb2fu;
+#else
+  const u32x2 a = *(const ELLC_GLOBAL u32x2*)((const ELLC_GLOBAL char*)tt.r0 + off);
+  const u32x2 b = *(const ELLC_GLOBAL u32x2*)((const ELLC_GLOBAL char*)tt.r1 + off);
+  q.t00 = a.x; q.t01 = a.y; q.t10 = b.x; q.t11 = b.y;
+#endif
+  __builtin_amdgcn_sched_barrier(0);
+  after_issue();   // behind the texel requests: vector loads return in issue order
+  __builtin_amdgcn_sched_barrier(0);
+  return q;
+}
+__device__ __forceinline__ Taps tap_finish_f(const TapReq& q, g_u8 img, int sw, int cols, int rows, float x1, float y1) {
+  if (q.interior) {
+    Taps o;
+    const float wx = __builtin_amdgcn_fractf(x1), wy = __builtin_amdgcn_fractf(y1);   // x - floor(x), exact for x >= 1
+    const float I00 = cvt_ubyte<0>(q.t00), I01 = cvt_ubyte<0>(q.t01), I10 = cvt_ubyte<0>(q.t10), I11 = cvt_ubyte<0>(q.t11);
+    const float top = __builtin_fmaf(wx, I01 - I00, I00);
+    const float btm = __builtin_fmaf(wx, I11 - I10, I10);
+    o.I = __builtin_fmaf(wy, btm - top, top);
+    const float g00 = tex_gx2(q.t00), g01 = tex_gx2(q.t01), g10 = tex_gx2(q.t10), g11 = tex_gx2(q.t11);   // twice the central differences
+    float t2 = __builtin_fmaf(wx, g01 - g00, g00);
+    float b2 = __builtin_fmaf(wx, g11 - g10, g10);
+    o.gx = __builtin_fmaf(wy, b2 - t2, t2);   // TWICE the gradient (the caller folds the 0.5 in)
+    const float h00 = tex_gy2(q.t00), h01 = tex_gy2(q.t01), h10 = tex_gy2(q.t10), h11 = tex_gy2(q.t11);
+    t2 = __builtin_fmaf(wx, h01 - h00, h00);
+    b2 = __builtin_fmaf(wx, h11 - h10, h10);
+    o.gy = __builtin_fmaf(wy, b2 - t2, t2);
     return o;
   }
-  const float nC = (float)(cols - 1), nR = (float)(rows - 1);
-  const bool xf_bad = (fx0 < 0.0f) || (fx0 > nC);
-  const bool xc_bad = (x1 < 0.0f) || (x1 > nC);
-  const bool yf_bad = (fy0 < 0.0f) || (fy0 > nR);
-  const bool yc_bad = (y1 < 0.0f) || (y1 > nR);
-  const bool v00 = !(xf_bad || yf_bad), v01 = !(xc_bad || yf_bad), v10 = !(xf_bad || yc_bad), v11 = !(xc_bad || yc_bad);
-  if (!(v00 || v01 || v10 || v11)) {
-    o.I = -1.0f; o.gx = 0.0f; o.gy = 0.0f;   // gradient taps: four zero samples interpolate to 0
-    return o;
-  }
-  const int x0 = (int)fminf(fmaxf(fx0, -4.0f), nC + 4.0f);
-  const int y0 = (int)fminf(fmaxf(fy0, -4.0f), nR + 4.0f);
-  const int xb = clampi(x0, 0, cols - 1), xc = clampi(x0 + 1, 0, cols - 1);
-  const int yb = clampi(y0, 0, rows - 1), yc = clampi(y0 + 1, 0, rows - 1);
-  // uniform base pointer + unsigned 32-bit lane offsets (SGPR-base global loads, no 64-bit lane arithmetic)
-  const unsigned rb = __umul24((unsigned)yb, (unsigned)sw), rc = __umul24((unsigned)yc, (unsigned)sw);   // rows are clamped to >= 0
-  const float Pbb = (float)img[rb + (unsigned)xb], Pbc = (float)img[rb + (unsigned)xc];
-  const float Pcb = (float)img[rc + (unsigned)xb], Pcc = (float)img[rc + (unsigned)xc];
-  {
-    const float p00 = v00 ? Pbb : 0.0f, p01 = v01 ? Pbc : 0.0f, p10 = v10 ? Pcb : 0.0f, p11 = v11 ? Pcc : 0.0f;
-    const float top = (omx * p00) + (wx * p01);
-    const float btm = (omx * p10) + (wx * p11);
-    o.I = (omy * top) + (wy * btm);
-  }
-  if (WANT_GRAD) {
-    const int xa = clampi(x0 - 1, 0, cols - 1), xd = clampi(x0 + 2, 0, cols - 1);
-    const int ya = clampi(y0 - 1, 0, rows - 1), yd = clampi(y0 + 2, 0, rows - 1);
-    const unsigned ra = __umul24((unsigned)ya, (unsigned)sw), rd = __umul24((unsigned)yd, (unsigned)sw);
-    const float Pba = (float)img[rb + (unsigned)xa], Pbd = (float)img[rb + (unsigned)xd];
-    const float Pca = (float)img[rc + (unsigned)xa], Pcd = (float)img[rc + (unsigned)xd];
-    const float Pab = (float)img[ra + (unsigned)xb], Pac = (float)img[ra + (unsigned)xc];
-    const float Pdb = (float)img[rd + (unsigned)xb], Pdc = (float)img[rd + (unsigned)xc];
-    // scale 1 on the border column/row of the tap itself, 0.5 inside
-    const float sx0 = (x0 <= 0 || x0 >= cols - 1) ? 1.0f : 0.5f;
-    const float sx1 = (x0 + 1 <= 0 || x0 + 1 >= cols - 1) ? 1.0f : 0.5f;
-    const float sy0 = (y0 <= 0 || y0 >= rows - 1) ? 1.0f : 0.5f;
-    const float sy1 = (y0 + 1 <= 0 || y0 + 1 >= rows - 1) ? 1.0f : 0.5f;
-    // d/dx at (yb,x0) (yb,x0+1) (yc,x0) (yc,x0+1)
-    float g00 = sx0 * (Pbc - Pba), g01 = sx1 * (Pbd - Pbb), g10 = sx0 * (Pcc - Pca), g11 = sx1 * (Pcd - Pcb);
-    g00 = v00 ? g00 : 0.0f; g01 = v01 ? g01 : 0.0f; g10 = v10 ? g10 : 0.0f; g11 = v11 ? g11 : 0.0f;
-    float top = (omx * g00) + (wx * g01);
-    float btm = (omx * g10) + (wx * g11);
-    o.gx = (omy * top) + (wy * btm);
-    // d/dy at the same four positions
-    float h00 = sy0 * (Pcb - Pab), h01 = sy0 * (Pcc - Pac), h10 = sy1 * (Pdb - Pbb), h11 = sy1 * (Pdc - Pbc);
-    h00 = v00 ? h00 : 0.0f; h01 = v01 ? h01 : 0.0f; h10 = v10 ? h10 : 0.0f; h11 = v11 ? h11 : 0.0f;
-    top = (omx * h00) + (wx * h01);
-    btm = (omx * h10) + (wx * h11);
-    o.gy = (omy * top) + (wy * btm);
-    if (FAST) { o.gx *= 2.0f; o.gy *= 2.0f; }   // as the interior branch of this mode returns them
-  } else {
-    o.gx = 0.0f; o.gy = 0.0f;
-  }
-  return o;
+  return tap_general<true, true>(img, sw, cols, rows, x1, y1);
 }
 
 // a / b for a per-level constant b with rb = RN(1/b): q = RN(a rb), e = a - b q (exact, fma), RN(q + e rb).
@@ -498,43 +605,93 @@ __device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K
 // with fused multiply-adds and the hardware reciprocal / reciprocal square root (1 ulp) in place of the IEEE division and
 // sqrt sequences, and f32 products where the reference's pow() promotes to double. Per-pixel values agree with the
 // exact path to a few 1e-7 relative (tests/test_gpu_fast.py states the bounds); the final pose to well below the 1e-5 bar.
-// About 130 VALU instructions per pixel instead of 285, 16-byte records instead of 32.
-struct FcaInF { uint32_t xyI; float p, var, d; };   // FcaRecF: x | y << 12 | I << 24, p = (x - cx) / fx, variance, d = 1 / Z
+// 16-byte records instead of 32; r04: written for the issue classes of the vector ALU (see tap_point_f).
+// (kept as ONE 128-bit value: a record slot is carried around the pixel loop while its load is in flight, and a slot made of four
+// scalars makes the register allocator copy them at the loop's back edge — copies that wait for the load)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+struct FcaInF { u32x4_t v; };   // FcaRecF: f32(y) with I in its 8 low mantissa bits, p = (x - cx) / fx, variance, d = 1 / Z
+__device__ __forceinline__ FcaInF fcaf_empty() { FcaInF in; in.v = (u32x4_t){0u, 0u, 0u, 0x3f800000u}; return in; }   // y = 0, I = 0, p = 0, var = 0, d = 1
 
-__device__ __forceinline__ FcaInF fcaf_load(const KfLevelDev& K, unsigned i) {
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4 v = *(const ELLC_GLOBAL u32x4*)((const ELLC_GLOBAL char*)K.crec + i * 16u);
+__device__ __forceinline__ FcaInF fcaf_load_off(const KfLevelDev& K, unsigned byte_off) {
   FcaInF in;
-  // (elements are copied to scalars first: __builtin_bit_cast applied to a vector element expression reads element 0)
-  const uint32_t w1 = v.y, w2 = v.z, w3 = v.w;
-  in.xyI = v.x; in.p = __builtin_bit_cast(float, w1); in.var = __builtin_bit_cast(float, w2); in.d = __builtin_bit_cast(float, w3);
+  in.v = *(const ELLC_GLOBAL u32x4_t*)((const ELLC_GLOBAL char*)K.crec + byte_off);
   return in;
 }
+__device__ __forceinline__ FcaInF fcaf_load(const KfLevelDev& K, unsigned i) { return fcaf_load_off(K, i * 16u); }
+// position of a tolerance-mode record: y from the first word, x back from p = (x - cx) / fx (|p fx + cx - x| < 1e-3 for x < 4096)
+__device__ __forceinline__ void fcaf_position(const FcaRecF& r, const LevelGeom& g, int& x, int& y) {
+  y = (int)__builtin_bit_cast(float, r.yI & 0xffffff00u);
+  x = (int)rintf(__builtin_fmaf(r.p, g.fx, g.cx));
+}
 
-// SAVEW: 1 = store the weights (saved-weights call), 0 = do not, -1 = a.save_w decides at run time
-template <bool DEBUG, class PF = NoPrefetch, int SAVEW = -1>
-__device__ __forceinline__ FcaPix fcaf_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const float* S, unsigned i,
-                                             const FcaInF& in, PF pf = PF()) {
-  const int y = (int)((in.xyI >> 12) & 0xfffu);
-  const float Ikf = byte_f32<3>(in.xyI);
-  const float p = in.p, q = __builtin_fmaf((float)y, g.rfy, -(g.cy * g.rfy));   // u / fx, v / fy
-  const float d = in.d;
-  // the warped point divided by Z — (p, q, 1) + t d — projects to the same pixel, and the factors of Z cancel in the
-  // weight below (1 / (pz^2 d) = Z rz^2 with the true pz; here pz is pz / Z): no product with Z is needed
-  const float px = __builtin_fmaf(S[0], p, __builtin_fmaf(S[1], q, __builtin_fmaf(S[3], d, S[2])));
-  const float py = __builtin_fmaf(S[4], p, __builtin_fmaf(S[5], q, __builtin_fmaf(S[7], d, S[6])));
-  const float pz = __builtin_fmaf(S[8], p, __builtin_fmaf(S[9], q, __builtin_fmaf(S[11], d, S[10])));
+// What the pixel step needs of the level and of the pose, in VECTOR registers (an SGPR operand halves the issue rate of the f32
+// multiply-adds, tools/micro/valu_rates.hip). P = K S with K = [fx 0 cx; 0 fy cy; 0 0 1] and S = exp(pose) (3 x 4): the warped point
+// comes out in pixel units times its depth, so the projection is one multiplication per coordinate.
+struct FcafConst {
+  float P[12];
+  float rfy, qc;     // q = (y - cy) / fy = y rfy + qc
+  float hfx, hfy;    // fx / 2, fy / 2 (the taps return twice the gradient)
+};
+__device__ __forceinline__ FcafConst fcaf_const(const LevelGeom& g, const float* S) {
+  FcafConst c;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    c.P[k] = __builtin_fmaf(g.fx, S[k], g.cx * S[8 + k]);
+    c.P[4 + k] = __builtin_fmaf(g.fy, S[4 + k], g.cy * S[8 + k]);
+    c.P[8 + k] = S[8 + k];
+  }
+  c.rfy = g.rfy; c.qc = -(g.cy * g.rfy);
+  c.hfx = 0.5f * g.fx; c.hfy = 0.5f * g.fy;
+#pragma unroll
+  for (int k = 0; k < 12; k++) asm volatile("" : "+v"(c.P[k]));
+  asm volatile("" : "+v"(c.rfy), "+v"(c.qc), "+v"(c.hfx), "+v"(c.hfy));
+  return c;
+}
+
+// The pixel step in two stages (see tap_request_f): stage A decodes the record, warps the point and requests its rows; stage B
+// interpolates, forms the Jacobian row and the weight. FcafStage is what B needs of A (the record's registers are free after A).
+struct FcafStage {
+  TapReq tq;
+  float x1, y1;              // warped position in the current image
+  float p, q, d, var, Ikf;
+  float px, py, pz, rz;
+};
+template <class PF = NoPrefetch>
+__device__ __forceinline__ FcafStage fcaf_stage_a(const LevelGeom& g, const TapTex& tt, const FcafConst& c, const FcaInF& in, PF pf = PF()) {
+  FcafStage s;
+  // (elements are copied to scalars first: __builtin_bit_cast applied to a vector element expression reads element 0)
+  const uint32_t yI = in.v.x, w1 = in.v.y, w2 = in.v.z, w3 = in.v.w;
+  const float yf = __builtin_bit_cast(float, yI & 0xffffff00u);
+  s.Ikf = cvt_ubyte<0>(yI);
+  // p, var, d are COPIED out of the record's registers (three moves the optimiser cannot see through): the caller refills the
+  // record slot right behind this stage, while the stage's values stay live through the next step's stage B
+  asm volatile("v_mov_b32 %0, %1" : "=v"(s.p) : "v"(w1));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(s.var) : "v"(w2));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(s.d) : "v"(w3));
+  s.q = __builtin_fmaf(yf, c.rfy, c.qc);   // p = u / fx, q = v / fy
+  // K ((p, q, 1) + t d): the warped point divided by the keyframe depth Z, in pixel units times its own depth. The factors of Z
+  // cancel in the projection and in the weight (1 / (pz^2 d) = Z rz^2 with the true pz; here pz is pz / Z).
+  s.px = __builtin_fmaf(c.P[0], s.p, __builtin_fmaf(c.P[1], s.q, __builtin_fmaf(c.P[3], s.d, c.P[2])));
+  s.py = __builtin_fmaf(c.P[4], s.p, __builtin_fmaf(c.P[5], s.q, __builtin_fmaf(c.P[7], s.d, c.P[6])));
+  s.pz = __builtin_fmaf(c.P[8], s.p, __builtin_fmaf(c.P[9], s.q, __builtin_fmaf(c.P[11], s.d, c.P[10])));
   // no clamp of pz away from zero (ExternVariable.h:232): 1/0 = inf sends the point out of bounds, as the clamped value does
-  const float rz = __builtin_amdgcn_rcpf(pz);
-  const float wx = __builtin_fmaf(px * rz, g.fx, g.cx);
-  const float wy = __builtin_fmaf(py * rz, g.fy, g.cy);
-  const Taps t = tap_point<true, true, PF>(cur, g.sw, g.cols, g.rows, wx, wy, pf);
+  s.rz = __builtin_amdgcn_rcpf(s.pz);
+  s.x1 = s.px * s.rz; s.y1 = s.py * s.rz;
+  s.tq = tap_request_f<PF>(tt, g.sw, g.cols, g.rows, s.x1, s.y1, pf);
+  return s;
+}
+// SAVEW: 1 = store the weights (saved-weights call), 0 = do not, -1 = a.save_w decides at run time
+template <bool DEBUG, int SAVEW = -1>
+__device__ __forceinline__ FcaPix fcaf_stage_b(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const FcafConst& c, unsigned i,
+                                               const FcafStage& s) {
+  const Taps t = tap_finish_f(s.tq, cur, g.sw, g.cols, g.rows, s.x1, s.y1);
+  const float p = s.p, q = s.q, d = s.d;
   FcaPix o;
   // 1x6 row (:296-320) with A = fx gradx, B = fy grady, T = A p + B q:
   //   J = [-(q T + B), p T + A, B p - A q, A d, B d, -d T]
-  // (tap_point returns twice the gradients in this mode.) Entries 0 and 5 are carried with the opposite sign — the
-  // accumulators then hold sign-flipped sums, exactly (rounding is symmetric), and fca_acc_unpack<true> flips them back
-  const float A = (0.5f * g.fx) * t.gx, B = (0.5f * g.fy) * t.gy;
+  // (the taps return twice the gradients.) Entries 0 and 5 are carried with the opposite sign — the accumulators then hold
+  // sign-flipped sums, exactly (rounding is symmetric), and fca_acc_unpack<true> flips them back
+  const float A = c.hfx * t.gx, B = c.hfy * t.gy;
   const float T = __builtin_fmaf(A, p, B * q);
   o.J[0] = __builtin_fmaf(q, T, B);   // -J[0]
   o.J[1] = __builtin_fmaf(p, T, A);
@@ -542,31 +699,40 @@ __device__ __forceinline__ FcaPix fcaf_pixel(const GnArgs& a, const KfLevelDev& 
   o.J[3] = A * d;
   o.J[4] = B * d;
   o.J[5] = d * T;                     // -J[5]
-  const bool oob = (t.I == -1.0f);
-  const float res = t.I - Ikf;
+  const float res = t.I - s.Ikf;
   // weight (:341-358): w_p = 1 / D, sqrt(w_p) = rsq(D);  Huber: w_p below the knee (|r| sqrt(w_p) < 1.5), 1.5 sqrt(w_p) / |r|
-  // above it — the smaller of the two
-  const float tx = S[3], ty = S[7], tz = S[11];
-  const float n0 = __builtin_fmaf(tx, pz, -(tz * px)), n1 = __builtin_fmaf(ty, pz, -(tz * py));
-  const float drpdd = __builtin_fmaf(A, n0, B * n1) * (rz * rz);
-  const float D = __builtin_fmaf(in.var * drpdd, drpdd, 16.0f);
+  // above it — the smaller of the two. With the point in pixel units, t' = K t:  fx (tx pz - tz px) = t'x pz - tz px', so
+  // drpdd = (A n0 + B n1) rz^2 = (gx2 n0' + gy2 n1') rz^2 / 2  (gx2, gy2: twice the gradients)
+  const float n0 = __builtin_fmaf(c.P[3], s.pz, -(c.P[11] * s.px)), n1 = __builtin_fmaf(c.P[7], s.pz, -(c.P[11] * s.py));
+  const float drpdd = __builtin_fmaf(t.gx, n0, t.gy * n1) * (0.5f * (s.rz * s.rz));
+  const float D = __builtin_fmaf(s.var * drpdd, drpdd, 16.0f);
   const float r = __builtin_amdgcn_rsqf(D);
-  const float wgt = r * fminf(r, 1.5f * __builtin_amdgcn_rcpf(fabsf(res)));
-  // out of bounds: weight 0 (the gradients, hence J, are 0 and the residual is finite: every sum gets 0)
+  // r min(r, k) = min(r r, r k), the middle one of (0, r r, r k); a NaN (a point at pz = 0: it is out of bounds, its J is zero, and
+  // NaN 0 would still poison the sums) comes out as 0: v_med3_f32 returns the minimum of the operands that are numbers
+  const float wgt = __builtin_amdgcn_fmed3f(r * r, r * (1.5f * __builtin_amdgcn_rcpf(fabsf(res))), 0.0f);
+  // out of bounds (I = -1: all four taps outside): the gradients, hence J, are 0 and the residual is finite, so every sum gets 0
+  // whatever the weight; the weight itself must read 0 only where it is stored
+  const bool oob = (t.I == -1.0f);
   o.residual = DEBUG ? (oob ? 0.0f : res) : res;
-  o.wgt = oob ? 0.0f : wgt;
+  if (DEBUG || SAVEW != 0) o.wgt = oob ? 0.0f : wgt;
+  else o.wgt = wgt;
   if (SAVEW > 0 || (SAVEW < 0 && a.save_w)) *(ELLC_GLOBAL float*)((ELLC_GLOBAL char*)K.wlast + i * 4u) = o.wgt;
   if (DEBUG) {
-    const int x = (int)(in.xyI & 0xfffu);
+    const int y = (int)rintf(__builtin_fmaf(q, g.fy, g.cy)), x = (int)rintf(__builtin_fmaf(p, g.fx, g.cx));
     const size_t n = (size_t)g.n, pp = (size_t)y * g.cols + x;
     a.planes[0 * n + pp] = o.residual;
     a.planes[1 * n + pp] = o.wgt;
-    a.planes[2 * n + pp] = oob ? -1.0f : wx;
-    a.planes[3 * n + pp] = oob ? -1.0f : wy;
+    a.planes[2 * n + pp] = oob ? -1.0f : s.x1;
+    a.planes[3 * n + pp] = oob ? -1.0f : s.y1;
 #pragma unroll
     for (int k = 0; k < 6; k++) a.planes[(4 + k) * n + pp] = (k == 0 || k == 5) ? -o.J[k] : o.J[k];
   }
   return o;
+}
+template <bool DEBUG, int SAVEW = -1>
+__device__ __forceinline__ FcaPix fcaf_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const TapTex& tt, const FcafConst& c,
+                                             unsigned i, const FcaInF& in) {
+  return fcaf_stage_b<DEBUG, SAVEW>(a, K, g, cur, c, i, fcaf_stage_a(g, tt, c, in));
 }
 
 // H += (w J)^T J (upper triangle), b += J (r w)   (PixelWisePyramid.cpp:364-374)
@@ -644,9 +810,11 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   g_u8 cur = as_global(F.img);
   FcaAcc acc;
   fca_acc_zero(acc);
+  const TapTex tt = tap_tex(F.tex, g.sw);
+  const FcafConst fc = fcaf_const(g, S);
   for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
     FcaPix p;
-    if constexpr (FAST) p = fcaf_pixel<DEBUG>(a, K, g, cur, S, (unsigned)i, fcaf_load(K, (unsigned)i));
+    if constexpr (FAST) p = fcaf_pixel<DEBUG>(a, K, g, cur, tt, fc, (unsigned)i, fcaf_load(K, (unsigned)i));
     else p = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
     fca_accumulate_pixel(acc, p);
   }
@@ -1239,8 +1407,9 @@ struct FusedArgs {
 // The pixel pass of one block of a fused launch over its chunk [begin, end) of the compact list, thread t taking the
 // entries begin + t, begin + t + 256, ...; the thread's first record (and, in the exact mode, its pose-independent products)
 // was requested by the caller before the solve. newS: exp(pose) of this iteration (LDS). Leaves the thread's 27 sums.
-template <bool DIVC, bool PIPE, bool FAST, int SAVEW>
-__device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const float* newS, int begin,
+// SWP (tolerance mode): chunks of at least ELLC_FCAF_PIPE_MIN pixels per thread take the software-pipelined loop.
+template <bool DIVC, bool PIPE, bool FAST, int SAVEW, bool SWP = false>
+__device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const uint32_t* cur_tex, const float* newS, int begin,
                                                int end, const FcaIn& first, const FcaInF& firstf, const FcaPre& first_pre, float (&sums)[27]) {
   constexpr int stride = ELLC_GN_THREADS;
   const int t = threadIdx.x;
@@ -1250,25 +1419,81 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
   FcaAcc acc;
   fca_acc_zero(acc);
   int i = begin + t;
-  // Software pipeline of both loops: the record of pixel i + 256 is requested while pixel i is processed (index clamped, so
-  // the load is unconditional), behind pixel i's tap loads, see tap_point. The two record slots alternate through an
-  // explicitly unrolled loop body: a register copy of a slot would have to wait for the load that fills it. (More records
-  // in flight were measured no faster, neither at 640x480 semi-dense, where the lists are cache resident, nor at 1280x960
-  // dense x 16, where they stream from HBM: the pixel phase is bound by VALU issue, not by the record loads.)
   if constexpr (FAST) {
-    if (i < end) {
-      FcaInF r0 = firstf, r1 = firstf;
-      auto step = [&](const FcaInF& in, FcaInF& fill) {
-        const int i1 = i + stride;
-        auto prefetch = [&]() { fill = fcaf_load(K, (unsigned)min(i1, end - 1)); };
-        fca_accumulate_pixel(acc, fcaf_pixel<false, decltype(prefetch), SAVEW>(a, K, g, cur, S, (unsigned)i, in, prefetch));
-        i += stride;
+    if (begin < end) {   // block-uniform
+      const TapTex tt = tap_tex(cur_tex, g.sw);
+      const FcafConst fc = fcaf_const(g, S);
+      // The record stream is walked by byte offset, clamped to the chunk's last record, so that every request is unconditional, and
+      // the trip count is block-uniform — every thread of the block has n_full pixels, the first `rem` threads one more — so that the
+      // loop is a plain scalar loop: a per-lane exit in the middle of an unrolled body makes the compiler merge the record slots at
+      // the back edge with register copies, and a copy of a slot waits for the load that fills it.
+      unsigned off = (unsigned)i * 16u;
+      const unsigned off_last = (unsigned)(end - 1) * 16u;
+      constexpr unsigned S16 = stride * 16u;
+      const int n_full = __builtin_amdgcn_readfirstlane((end - begin) / stride);
+      const bool has_rem = t < (end - begin) - n_full * stride;
+      auto finish = [&](const FcafStage& cur_s) {
+#ifdef ELLC_X_NOACC   // experiment: the pixel's values are kept alive but not accumulated
+        const FcaPix px_ = fcaf_stage_b<false, SAVEW>(a, K, g, cur, fc, off >> 4, cur_s);
+        asm volatile("" ::"v"(px_.J[0]), "v"(px_.J[1]), "v"(px_.J[2]), "v"(px_.J[3]), "v"(px_.J[4]), "v"(px_.J[5]), "v"(px_.residual), "v"(px_.wgt));
+#else
+        fca_accumulate_pixel(acc, fcaf_stage_b<false, SAVEW>(a, K, g, cur, fc, off >> 4, cur_s));
+#endif
       };
-      for (;;) {
-        step(r0, r1);
-        if (i >= end) break;
-        step(r1, r0);
-        if (i >= end) break;
+      if (SWP && n_full >= ELLC_FCAF_PIPE_MIN) {
+        // Long chunks (the dense levels: hundreds of pixels per thread): software pipeline over pixels (r04). While a pixel is
+        // interpolated and accumulated (stage B) the texels of the thread's NEXT pixel are already requested (stage A), and its
+        // records are requested three pixels ahead: vector loads return in issue order — ... texels(i), record(i+2), texels(i+1),
+        // record(i+3) ... — so the texels have one whole step and a record two steps to arrive before anything waits for them. Two
+        // stage records and two record slots alternate through an explicitly unrolled body; a thread runs stage A once more than it
+        // has pixels (harmless: loads only). 1280x960 dense x 64: 374 against 394 us; at 640x480 semi-dense (37 pixels per thread)
+        // the plain loop below is the faster one (tools/ab_level0.sh).
+        FcaInF r0 = firstf;
+        FcaInF r1 = fcaf_load_off(K, min(off + S16, off_last));
+        FcafStage s0, s1;
+        {
+          auto fill0 = [&]() { r0 = fcaf_load_off(K, min(off + 2u * S16, off_last)); };
+          s0 = fcaf_stage_a(g, tt, fc, r0, fill0);
+        }
+        auto step = [&](const FcafStage& cur_s, FcafStage& next_s, FcaInF& next_rec) {
+          // next_rec holds the record of pixel off + S16; once stage A has read it, the slot takes the record of pixel off + 3 S16
+          auto refill = [&]() { next_rec = fcaf_load_off(K, min(off + 3u * S16, off_last)); };
+          next_s = fcaf_stage_a(g, tt, fc, next_rec, refill);
+          finish(cur_s);
+          off += S16;
+        };
+        int k = 0;
+        for (; k + 2 <= n_full; k += 2) {
+          step(s0, s1, r1);
+          step(s1, s0, r0);
+        }
+        if (k < n_full) {   // block-uniform: one more full step, then the remainder pixel sits in s1
+          step(s0, s1, r1);
+          if (has_rem) finish(s1);
+        } else if (has_rem) {
+          finish(s0);
+        }
+      } else {
+        // one pixel at a time: the texels are requested and used in the same step; the next pixel's record is requested behind them
+        // (two record slots alternate through an explicitly unrolled body)
+        FcaInF r0 = firstf, r1 = firstf;
+        auto step = [&](const FcaInF& cur_rec, FcaInF& next_rec) {
+          auto refill = [&]() { next_rec = fcaf_load_off(K, min(off + S16, off_last)); };
+          const FcafStage st = fcaf_stage_a(g, tt, fc, cur_rec, refill);
+          finish(st);
+          off += S16;
+        };
+        int k = 0;
+        for (; k + 2 <= n_full; k += 2) {
+          step(r0, r1);
+          step(r1, r0);
+        }
+        if (k < n_full) {
+          step(r0, r1);
+          if (has_rem) step(r1, r0);
+        } else if (has_rem) {
+          step(r0, r1);
+        }
       }
     }
   } else if (i < end) {
@@ -1365,11 +1590,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   // this thread's first compact pixel, requested before the solve (exact mode: together with its pose-independent products)
   FcaIn first;
   first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.X = 0.0f; first.Y = 0.0f; first.invZ = 1.0;
-  FcaInF firstf;
-  firstf.xyI = 0; firstf.p = 0.0f; firstf.var = 0.0f; firstf.d = 1.0f;
+  FcaInF firstf = fcaf_empty();
   FcaPre first_pre;
   if constexpr (FAST) {
-    if (begin + t < end) firstf = fcaf_load(K, (unsigned)(begin + t));
+    if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));   // (a thread past the chunk's end starts on a copy of its last record: the pixel loop is block-uniform)
   } else {
     if (begin + t < end) {
       first = fca_load(K, (unsigned)(begin + t));
@@ -1404,7 +1628,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   }
   if (skip) return;
   float sums[27];
-  fca_chunk_pass<DIVC, PIPE, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
+  fca_chunk_pass<DIVC, PIPE, FAST, SAVEW, true>(a, K, g, cur, F.tex, sh.newS, begin, end, first, firstf, first_pre, sums);
   ELLC_STAMP(7);
   ELLC_BSTAMP(2);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
@@ -1480,11 +1704,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
   // this thread's first record (exact mode: and its pose-independent products), requested before the solve
   FcaIn first;
   first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.X = 0.0f; first.Y = 0.0f; first.invZ = 1.0;
-  FcaInF firstf;
-  firstf.xyI = 0; firstf.p = 0.0f; firstf.var = 0.0f; firstf.d = 1.0f;
+  FcaInF firstf = fcaf_empty();
   FcaPre first_pre;
   if constexpr (FAST) {
-    if (sub < nb_l && begin + t < end) firstf = fcaf_load(K, (unsigned)(begin + t));
+    if (sub < nb_l && begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));
   } else {
     if (sub < nb_l && begin + t < end) first = fca_load(K, (unsigned)(begin + t));
     first_pre = fca_prepare<DIVC>(g, first);
@@ -1526,7 +1749,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
     begin = sub * chunk;
     end = min(V, begin + chunk);
     if constexpr (FAST) {
-      if (begin + t < end) firstf = fcaf_load(K, (unsigned)(begin + t));
+      if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));   // (a thread past the chunk's end starts on a copy of its last record: the pixel loop is block-uniform)
     } else {
       if (begin + t < end) first = fca_load(K, (unsigned)(begin + t));
       first_pre = fca_prepare<DIVC>(g, first);
@@ -1536,7 +1759,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
   }
   g_u8 cur = as_global(F->img);
   float sums[27];
-  fca_chunk_pass<DIVC, true, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
+  fca_chunk_pass<DIVC, true, FAST, SAVEW>(a, K, g, cur, F->tex, sh.newS, begin, end, first, firstf, first_pre, sums);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
   block_reduce_store<27>(sums, out);
 }
@@ -1903,8 +2126,9 @@ __global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slo
     // saved weights exist in the FCA schedule only: its records carry the pixel position
     size_t p;
     if (fast_records) {
-      const uint32_t xyI = ((const FcaRecF*)K.crec)[i].xyI;
-      p = (size_t)((xyI >> 12) & 0xfffu) * cols + (xyI & 0xfffu);
+      int x, y;
+      fcaf_position(((const FcaRecF*)K.crec)[i], geom[level], x, y);
+      p = (size_t)y * cols + x;
     } else {
       const uint32_t xy = K.crec[i].xy;
       p = (size_t)(xy >> 16) * cols + (xy & 0xffffu);
@@ -1927,8 +2151,9 @@ __global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
     size_t p;
     if (fast_records) {
-      const uint32_t xyI = ((const FcaRecF*)K.crec)[i].xyI;
-      p = (size_t)((xyI >> 12) & 0xfffu) * cols + (xyI & 0xfffu);
+      int x, y;
+      fcaf_position(((const FcaRecF*)K.crec)[i], geom[level], x, y);
+      p = (size_t)y * cols + x;
     } else {
       const uint32_t xy = K.crec[i].xy;
       p = (size_t)(xy >> 16) * cols + (xy & 0xffffu);

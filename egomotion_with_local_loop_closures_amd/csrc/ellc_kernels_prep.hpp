@@ -192,10 +192,10 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
         const int x = xx[k], y = yy[k];
         const float Z = ZZ[k];
         if constexpr (NEED == 8) {   // tolerance mode: one 16-byte record per pixel (FcaRecF)
-          const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)Ib[k] << 24);
+          const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | (uint32_t)Ib[k];   // FcaRecF: y < 4096 as f32 has its 12 low bits clear
           const float dd = __builtin_amdgcn_rcpf(Z);
           const float pn = ((float)x - g.cx) * g.rfx;   // u / fx (fcaf_pixel forms v / fy from y)
-          crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, vv[k]), __builtin_bit_cast(uint32_t, dd)};
+          crec[pos] = (u32x4){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, vv[k]), __builtin_bit_cast(uint32_t, dd)};
         } else {   // one 32-byte record per pixel (FcaRec), stored as two 16-byte words
           const uint32_t xy = ((uint32_t)y << 16) | (uint32_t)x;
           const float Ikf = (float)Ib[k];
@@ -261,10 +261,10 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
       }
     }
     if (need & 8) {   // FCA in tolerance mode: one 16-byte record per pixel (FcaRecF)
-      const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)img[(unsigned)(y * sw + x)] << 24);
+      const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | (uint32_t)img[(unsigned)(y * sw + x)];
       const float d = __builtin_amdgcn_rcpf(Z);
       const float pn = ((float)x - g.cx) * g.rfx;   // u / fx (fcaf_pixel forms v / fy from y)
-      crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, d)};
+      crec[pos] = (u32x4){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, d)};
     }
     if (need & 2) {   // FCA reads one 32-byte record per pixel (FcaRec), stored as two 16-byte words
       const float X = (((float)x - cx) * Z) / fx;
