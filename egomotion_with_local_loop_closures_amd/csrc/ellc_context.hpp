@@ -211,6 +211,6 @@ ellc_status run_prep(ellc_ctx* c, int n_unique, int need);
 ellc_status build_depth_pyramid(ellc_ctx* c, int slot);
 ellc_status build_depth_pyramid_from(ellc_ctx* c, int slot, int first_level);
 ellc_status build_maxgrad(ellc_ctx* c, bool is_kf, int slot);
-ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img, hipStream_t st, uint32_t* const* tex = nullptr);
+ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img, hipStream_t st);
 ellc_status mark_frame_use(ellc_ctx* c, int slot);
 }  // namespace ellc

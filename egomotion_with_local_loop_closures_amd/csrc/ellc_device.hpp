@@ -78,19 +78,9 @@ struct KfLevelDev {
   int* tile_count;            // per-tile (ELLC_TILE pixels) counts, then exclusive offsets
 };
 
-// One current-frame slot at one level. tex (tolerance mode only, r04): one 32-bit TEXEL per pixel, pitch sw — the grey value and
-// TWICE the two central differences of frame::calculateGradient (Frame.cpp:185-285), integers all three:
-//   bits 0-7 I,  bits 14-22 I(x+1,y) - I(x-1,y) (9-bit two's complement),  bits 23-31 I(x,y+1) - I(x,y-1)
-// so that the bilinear taps of image and gradient planes at a warped point are its 2 x 2 texels — two 8-byte loads — instead of a
-// 4 x 4 byte neighbourhood fetched as four unaligned dwords (the CU's vector cache delivers about 32 bytes per cycle to the lanes and
-// an unaligned dword costs two aligned ones: tools/micro/gather_rate.hip). Border texels carry gradient 0: only points whose four
-// texels are interior read them (the others take the per-tap path on the u8 image, which has the reference's border rules).
 struct FrLevelDev {
   uint8_t* img;               // sw*sh
-  uint32_t* tex;              // sw*sh texels, or null (exact arithmetic)
 };
-#define ELLC_TEX_GX_SHIFT 14
-#define ELLC_TEX_GY_SHIFT 23
 
 // Per-alignment state that persists across the launches of one ellc_align.
 #define DM_OBS_REGIONS 64   // regions of the depth map's observation work list (dm_observe_select / dm_observe_walk)

@@ -134,20 +134,7 @@ int choose_nblk(const ellc_ctx* c, int level, int B) {
 static dim3 grid2d(int w, int h, dim3 blk) { return dim3((w + blk.x - 1) / blk.x, (h + blk.y - 1) / blk.y); }
 
 // the u8 pyramid below level 0 of `img[]`: one launch per three levels (pyr_down_chain_u8)
-static void launch_frame_texels(ellc_ctx* c, uint8_t* const* img, uint32_t* const* tex, hipStream_t st) {
-  const LevelGeom* g = c->geom_h;
-  TexArgs t;
-  for (int l = 0; l < ELLC_MAX_LEVELS; l++) {
-    const int q = std::min(l, c->L - 1);
-    t.img[l] = img[q]; t.tex[l] = tex[q];
-    t.sw[l] = g[q].sw; t.sh[l] = g[q].sh; t.cols[l] = g[q].cols; t.rows[l] = g[q].rows;
-  }
-  const int nb = std::max(1, std::min(1024, (g[0].sw * g[0].sh + 1023) / 1024));   // four texels per thread at level 0
-  hipLaunchKernelGGL(frame_texels, dim3(nb, c->L), dim3(256), 0, st, t);
-}
-
-// tex != null (a current-frame slot of a tolerance-mode context): the levels' texel planes behind it (frame_texels, one launch)
-ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img, hipStream_t st, uint32_t* const* tex) {
+ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img, hipStream_t st) {
   const LevelGeom* g = c->geom_h;
   for (int l = 0; l + 1 < c->L; l += 3) {
     PyrChainArgs a;
@@ -162,14 +149,8 @@ ellc_status build_image_pyramid(ellc_ctx* c, uint8_t* const* img, hipStream_t st
     const int dw = g[l + a.steps].sw, dh = g[l + a.steps].sh;
     hipLaunchKernelGGL(pyr_down_chain_u8, dim3((dw + ELLC_PT - 1) / ELLC_PT, (dh + ELLC_PT - 1) / ELLC_PT), dim3(256), 0, st, a);
   }
-  if (tex && tex[0]) launch_frame_texels(c, img, tex, st);
   ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
-}
-
-// the texel planes of frame slot `slot` (null entries: the context has none)
-static void frame_tex_ptrs(const ellc_ctx* c, int slot, uint32_t** tex) {
-  for (int l = 0; l < ELLC_MAX_LEVELS; l++) tex[l] = l < c->L ? c->fr_tab_h[(size_t)l * c->cfg.max_frames + slot].tex : nullptr;
 }
 
 // Upload + pyramid without stalling the caller: the image is copied into one of a ring of pinned staging buffers (so the
@@ -179,7 +160,7 @@ static void frame_tex_ptrs(const ellc_ctx* c, int slot, uint32_t** tex) {
 // is already enqueued on the main stream (in a tracking loop: the previous frame's depth stages, which read the OTHER frame
 // slot). Ordered on the device: behind the readers of this slot that are already enqueued (mark_frame_use, batches in flight),
 // and everything enqueued later on the main stream waits for it.
-static ellc_status upload_pyramid(ellc_ctx* c, uint8_t* const* img, const uint8_t* host, int frame_slot = -1, uint32_t* const* tex = nullptr) {
+static ellc_status upload_pyramid(ellc_ctx* c, uint8_t* const* img, const uint8_t* host, int frame_slot = -1) {
   const LevelGeom* g = c->geom_h;
   hipStream_t st = c->stream;
   if (frame_slot >= 0) {
@@ -212,7 +193,7 @@ static ellc_status upload_pyramid(ellc_ctx* c, uint8_t* const* img, const uint8_
   std::memcpy(c->upload_stage[k], host, bytes);
   ELLC_HIP(c, hipMemcpyAsync(img[0], c->upload_stage[k], bytes, hipMemcpyHostToDevice, st));
   ELLC_HIP(c, hipEventRecord(c->upload_done[k], st));
-  const ellc_status s = build_image_pyramid(c, img, st, tex);
+  const ellc_status s = build_image_pyramid(c, img, st);
   if (s != ELLC_OK || frame_slot < 0) return s;
   if (!c->fr_ready_ev[frame_slot]) ELLC_HIP(c, hipEventCreateWithFlags(&c->fr_ready_ev[frame_slot], hipEventDisableTiming));
   ELLC_HIP(c, hipEventRecord(c->fr_ready_ev[frame_slot], st));
@@ -860,10 +841,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       TRY(dev_alloc(c, &k.count, 4)); TRY(dev_alloc(c, &k.tile_count, tiles + 1));
       TRY(dev_alloc(c, &k.irec, n)); TRY(dev_alloc(c, &k.hpart, (size_t)(tiles + 1) * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
     }
-    for (int s = 0; s < MF; s++) {
-      TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni + 16));
-      if (c->fast) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].tex, ni + 8));   // texel planes (tolerance mode): 4 bytes per pixel
-    }
+    for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni + 16));
   }
   TRY(dev_alloc(c, &c->kf_tab_d, c->kf_tab_h.size()));
   TRY(dev_alloc(c, &c->fr_tab_d, c->fr_tab_h.size()));
@@ -1040,9 +1018,7 @@ ellc_status ellc_frame_upload(ellc_ctx* c, int slot, const uint8_t* image) {
   // queues that run concurrently, and a context with batches in flight needs them for its batch streams; r03: with the fourth
   // stream the pipeline of sixteen batches fell from 7.7 to 6.3 M iterations/s)
   const bool own_stream = c->cfg.concurrent_batches <= 1 && c->coalesce <= 1;
-  uint32_t* tex[ELLC_MAX_LEVELS];
-  frame_tex_ptrs(c, slot, tex);
-  ellc_status s = upload_pyramid(c, img, image, own_stream ? slot : -1, tex);
+  ellc_status s = upload_pyramid(c, img, image, own_stream ? slot : -1);
   if (s != ELLC_OK) return s;
   c->fr_has_image[slot] = 1;
   c->fr_maxgrad_valid[slot] = 0;
@@ -1247,17 +1223,11 @@ static ellc_status copy_slot_planes(ellc_ctx* dc, int dst_is_kf, int dst, ellc_c
   ellc_ctx* c = dc;
   const int MK = dc->cfg.max_keyframes, MF = dc->cfg.max_frames, SK = sc->cfg.max_keyframes, SF = sc->cfg.max_frames;
   if (dst_is_kf) invalidate_records(dc, dst);
-  bool need_tex = false;
   for (int l = 0; l < dc->L; l++) {
     const LevelGeom& g = dc->geom_h[l];
     const uint8_t* s_img = src_is_kf ? sc->kf_tab_h[(size_t)l * SK + src].img : sc->fr_tab_h[(size_t)l * SF + src].img;
     uint8_t* d_img = dst_is_kf ? dc->kf_tab_h[(size_t)l * MK + dst].img : dc->fr_tab_h[(size_t)l * MF + dst].img;
     ELLC_HIP(c, hipMemcpyAsync(d_img, s_img, (size_t)g.sw * g.sh, hipMemcpyDeviceToDevice, dc->stream));
-    if (!dst_is_kf && dc->fr_tab_h[(size_t)l * MF + dst].tex) {   // a frame slot's texel planes: copied from a frame, rebuilt below from a keyframe
-      const uint32_t* s_tex = src_is_kf ? nullptr : sc->fr_tab_h[(size_t)l * SF + src].tex;
-      if (s_tex) ELLC_HIP(c, hipMemcpyAsync(dc->fr_tab_h[(size_t)l * MF + dst].tex, s_tex, (size_t)g.sw * g.sh * 4, hipMemcpyDeviceToDevice, dc->stream));
-      else need_tex = true;
-    }
     if (dst_is_kf) {
       KfLevelDev& d = dc->kf_tab_h[(size_t)l * MK + dst];
       if (src_is_kf) {
@@ -1286,14 +1256,6 @@ static ellc_status copy_slot_planes(ellc_ctx* dc, int dst_is_kf, int dst, ellc_c
   } else {
     dc->fr_has_image[dst] = 1;
     dc->fr_maxgrad_valid[dst] = 0;
-    if (need_tex) {   // the source had no texel planes (a keyframe slot, or a context in the exact arithmetic): built from the copied images
-      uint8_t* img[ELLC_MAX_LEVELS];
-      uint32_t* tex[ELLC_MAX_LEVELS];
-      for (int l = 0; l < ELLC_MAX_LEVELS; l++) img[l] = l < dc->L ? dc->fr_tab_h[(size_t)l * MF + dst].img : nullptr;
-      frame_tex_ptrs(dc, dst, tex);
-      launch_frame_texels(dc, img, tex, dc->stream);
-      ELLC_HIP(c, hipGetLastError());
-    }
   }
   return ELLC_OK;
 }

@@ -213,9 +213,7 @@ ellc_status ellc_frame_ingest_bgr(ellc_ctx* c, int slot, const uint8_t* bgr, uin
   hipLaunchKernelGGL(ingest_frame, grid2d(ow, oh, blk), blk, 0, c->stream, c->ingest_bgr, w, h, (const IngestMapEntry*)c->ingest_map, img[0], ow, oh,
                      g[0].sw, gd, ud);
   hipError_t e = hipGetLastError();
-  uint32_t* tex[ELLC_MAX_LEVELS];
-  for (int l = 0; l < ELLC_MAX_LEVELS; l++) tex[l] = l < c->L ? c->fr_tab_h[(size_t)l * c->cfg.max_frames + slot].tex : nullptr;
-  if (e == hipSuccess && build_image_pyramid(c, img, c->stream, tex) != ELLC_OK) e = hipErrorUnknown;
+  if (e == hipSuccess && build_image_pyramid(c, img, c->stream) != ELLC_OK) e = hipErrorUnknown;
   if (e == hipSuccess && gd) e = hipMemcpyAsync(gray_probe, gd, (size_t)ow * oh, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess && ud) e = hipMemcpyAsync(undistorted_probe, ud, (size_t)ow * oh * 4, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the host frame buffer may be pageable

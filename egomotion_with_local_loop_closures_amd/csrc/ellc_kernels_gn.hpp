@@ -80,9 +80,6 @@ __device__ __forceinline__ float byte_f32(uint32_t w) { return (float)((w >> (8 
 // (r03 built an LDS-staged window variant of the taps behind -DELLC_WINDOWS: measured slower; removed from the
 // tree in r04 — it is in the history at 99afb34.)
 #define ELLC_LDS __attribute__((address_space(3)))
-#ifndef ELLC_FCAF_PIPE_MIN
-#define ELLC_FCAF_PIPE_MIN 96   // the tolerance-mode pixel loop is software-pipelined over pixels from this many pixels per thread on (fca_chunk_pass)
-#endif
 
 struct Taps {
   float I;      // u8 tap (Frame.h:181-279), -1 when all four taps are out of bounds
@@ -244,20 +241,23 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
 //         integer forms, v_lshlrev, SDWA and DPP forms, f64, the packed f32 forms (v_pk_fma_f32 does two fmas for the price of 1.8) —
 //         AND any instruction of the first group that names an SGPR;
 //   ~8.5  v_rcp / v_rsq_f32.
-// Hence: the per-block constants live in VGPRs (FcafConst); floor and fraction come from v_cvt_flr_i32_f32 and v_fract_f32 (the
-// interior test is two unsigned compares on the integers); the two texel rows are two uniform base pointers with ONE lane offset;
-// and, since the CU's vector cache hands the lanes about 32 bytes per cycle and an unaligned dword costs two aligned ones
-// (tools/micro/gather_rate.hip: 18 cycles for an unaligned dword gather of 64 lanes, 8.7 aligned, 16.4 for 8 bytes at a 4-aligned
-// address; the 4 x 4 byte neighbourhood as four unaligned dwords: 72 cycles per pixel step of a wave, more than the step's
-// arithmetic takes a CU), the taps come from the frame's TEXEL planes (FrLevelDev::tex): grey value and twice the two central
-// differences per pixel in one word, so that image and gradient taps are the point's 2 x 2 texels — two 8-byte loads, 33 cycles.
-typedef const ELLC_GLOBAL uint32_t* g_tex;
-struct TapTex { g_tex r0, r1; };   // texel rows y0 and y0 + 1 sit at r0 / r1 + y0 * pitch + x0
-__device__ __forceinline__ TapTex tap_tex(const uint32_t* tex, int sw) {
-  TapTex t;
-  t.r0 = (g_tex)tex;
-  t.r1 = t.r0 + sw;
-  return t;
+// Hence: the per-block constants live in VGPRs (FcafConst); the four rows of the 4 x 4 neighbourhood are four uniform base
+// pointers with ONE lane offset (no per-row address arithmetic in the vector ALU); floor and fraction come from v_cvt_flr_i32_f32
+// and v_fract_f32 (the interior test is two unsigned compares on the integers); the twelve bytes are converted by twelve
+// v_cvt_f32_ubyteN and differenced in f32 (left to itself the compiler subtracts the bytes with SDWA integer instructions and
+// converts the differences: 26 slow instructions for these 12 + 8 fast ones).
+// What it bought (r04, tools/ab_levels.sh, tools/ab_libs.sh, interleaved on one box): 124 -> 110 vector instructions per pixel,
+// 460 -> 396 cycles of modelled issue (tools/isa_cost.py); the level-0 launch over 128 alignments 45.8 -> 43.6 us, the batch
+// pipeline 0.1331 -> 0.1312 ms per step. Far less than the instructions saved: the pass is bound by the CU's memory pipeline as much
+// as by its vector ALU (the same loop without its loads: 214 of 389 us at 1280x960 dense, 33 of 44 us at 640x480).
+struct TapRows { g_u8 ra, rb, rc, rd; };   // image - 1 + (-1, 0, 1, 2) * pitch: column x0 - 1 of rows y0 - 1 .. y0 + 2 sits at row pointer + y0 * pitch + x0
+__device__ __forceinline__ TapRows tap_rows(g_u8 img, int sw) {
+  TapRows r;
+  r.rb = img - 1;
+  r.ra = r.rb - sw;
+  r.rc = r.rb + sw;
+  r.rd = r.rc + sw;
+  return r;
 }
 template <int N>
 __device__ __forceinline__ float cvt_ubyte(uint32_t w) {   // opaque to the optimiser on purpose, see above
@@ -273,60 +273,65 @@ __device__ __forceinline__ int cvt_floor_i32(float x) {   // floor, then the sat
   asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(x));
   return i;
 }
-__device__ __forceinline__ float tex_gx2(uint32_t w) { return (float)(int)__builtin_amdgcn_sbfe(w, ELLC_TEX_GX_SHIFT, 9); }   // (the builtin returns unsigned)
-__device__ __forceinline__ float tex_gy2(uint32_t w) { return (float)((int)w >> ELLC_TEX_GY_SHIFT); }
-// Two halves, so that a pixel loop can put other work between the request and the use of the texels (fca_chunk_pass requests the
-// next pixel's texels before it works on the current pixel's): tap_request_f decides interior / general for the wave and requests
-// the 2 x 2 texels; tap_finish_f turns them (or, on the general path, the synchronous per-tap loads from the u8 image) into the taps.
+// Two halves: tap_request_f decides interior / general for the wave and requests the four rows; tap_finish_f turns them (or, on the
+// general path, the synchronous per-tap loads) into the taps. (r04 put the next pixel's request in front of the current pixel's
+// finish — a software pipeline over pixels: 1280x960 dense 387 against 389 us, 640x480 5 % slower, 125 registers: not kept.)
 struct TapReq {
-  uint32_t t00, t01, t10, t11;   // texels (x0, y0) (x0 + 1, y0) (x0, y0 + 1) (x0 + 1, y0 + 1), valid when interior
-  bool interior;                 // wave-uniform: every lane that was active at the request samples the interior
+  uint32_t wa, wb, wc, wd;   // rows y0 - 1 .. y0 + 2, columns x0 - 1 .. x0 + 2 (valid when interior)
+  bool interior;             // wave-uniform: every lane that was active at the request samples the interior
 };
-template <class AfterIssue = NoPrefetch>
-__device__ __forceinline__ TapReq tap_request_f(const TapTex& tt, int sw, int cols, int rows, float x1, float y1, AfterIssue after_issue = AfterIssue()) {
+template <bool WANT_GRAD, class AfterIssue = NoPrefetch>
+__device__ __forceinline__ TapReq tap_request_f(const TapRows& tr, int sw, int cols, int rows, float x1, float y1, AfterIssue after_issue = AfterIssue()) {
   TapReq q;
+  q.wa = 0; q.wd = 0;
   const int x0 = cvt_floor_i32(x1), y0 = cvt_floor_i32(y1);
-  // x0 in [1, cols - 3] and y0 in [1, rows - 3]: the four texels carry central differences (all 16 neighbours in range, none of the
-  // four taps on a border column / row); a NaN coordinate converts to 0 and an infinite one saturates: neither is interior
+  // x0 in [1, cols - 3] and y0 in [1, rows - 3] (all 16 neighbours in range, none of the four taps on a border column / row); a
+  // NaN coordinate converts to 0 and an infinite one saturates: neither is interior
   const bool interior = ((unsigned)(x0 - 1) <= (unsigned)(cols - 4)) & ((unsigned)(y0 - 1) <= (unsigned)(rows - 4));
   q.interior = (__builtin_amdgcn_ballot_w64(!interior) == 0ull);
-  // The texels are requested unconditionally — a lane that is not interior asks for the plane's first texels instead — so that the
-  // request is straight-line code: tap_finish_f uses the words only when the whole wave is interior. (A branch here makes the
-  // compiler duplicate the caller's record refill into both arms; the refilled slot is carried around the caller's loop as a
-  // 128-bit register tuple while its load is in flight, and merging two tuples costs copies that wait for the load.)
-  const unsigned off = interior ? (__umul24((unsigned)y0, (unsigned)sw) + (unsigned)x0) * 4u : 0u;
-  typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
-#ifdef ELLC_X_NOTAPS   // experiment: no tap loads (the words are made up from the offset)
-  q.t00 = off * 0x9e3779b1u; q.t01 = off * 0x85ebca6bu; q.t10 = off * 0xc2b2ae35u; q.t11 = off * 0x27d4eb2fu;
-#else
-  const u32x2 a = *(const ELLC_GLOBAL u32x2*)((const ELLC_GLOBAL char*)tt.r0 + off);
-  const u32x2 b = *(const ELLC_GLOBAL u32x2*)((const ELLC_GLOBAL char*)tt.r1 + off);
-  q.t00 = a.x; q.t01 = a.y; q.t10 = b.x; q.t11 = b.y;
-#endif
-  __builtin_amdgcn_sched_barrier(0);
-  after_issue();   // behind the texel requests: vector loads return in issue order
-  __builtin_amdgcn_sched_barrier(0);
+  // (r04 measured the straight-line form — the rows requested unconditionally, a lane that is not interior asking for the image's
+  // first bytes — which a software pipeline over pixels needs: 5 % slower on the batch pipeline, the coarse levels' waves on the
+  // image border pay for four requests they do not use)
+  q.wb = 0; q.wc = 0;
+  if (q.interior) {
+    const unsigned off = __umul24((unsigned)y0, (unsigned)sw) + (unsigned)x0;
+    q.wb = load_u32_unaligned(tr.rb, off);
+    q.wc = load_u32_unaligned(tr.rc, off);
+    if (WANT_GRAD) { q.wa = load_u32_unaligned(tr.ra, off); q.wd = load_u32_unaligned(tr.rd, off); }
+    __builtin_amdgcn_sched_barrier(0);
+    after_issue();   // behind the row requests: vector loads return in issue order
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+    after_issue();
+  }
   return q;
 }
+template <bool WANT_GRAD>
 __device__ __forceinline__ Taps tap_finish_f(const TapReq& q, g_u8 img, int sw, int cols, int rows, float x1, float y1) {
   if (q.interior) {
     Taps o;
     const float wx = __builtin_amdgcn_fractf(x1), wy = __builtin_amdgcn_fractf(y1);   // x - floor(x), exact for x >= 1
-    const float I00 = cvt_ubyte<0>(q.t00), I01 = cvt_ubyte<0>(q.t01), I10 = cvt_ubyte<0>(q.t10), I11 = cvt_ubyte<0>(q.t11);
-    const float top = __builtin_fmaf(wx, I01 - I00, I00);
-    const float btm = __builtin_fmaf(wx, I11 - I10, I10);
+    const float Pbb = cvt_ubyte<1>(q.wb), Pbc = cvt_ubyte<2>(q.wb), Pcb = cvt_ubyte<1>(q.wc), Pcc = cvt_ubyte<2>(q.wc);
+    const float top = __builtin_fmaf(wx, Pbc - Pbb, Pbb);
+    const float btm = __builtin_fmaf(wx, Pcc - Pcb, Pcb);
     o.I = __builtin_fmaf(wy, btm - top, top);
-    const float g00 = tex_gx2(q.t00), g01 = tex_gx2(q.t01), g10 = tex_gx2(q.t10), g11 = tex_gx2(q.t11);   // twice the central differences
-    float t2 = __builtin_fmaf(wx, g01 - g00, g00);
-    float b2 = __builtin_fmaf(wx, g11 - g10, g10);
-    o.gx = __builtin_fmaf(wy, b2 - t2, t2);   // TWICE the gradient (the caller folds the 0.5 in)
-    const float h00 = tex_gy2(q.t00), h01 = tex_gy2(q.t01), h10 = tex_gy2(q.t10), h11 = tex_gy2(q.t11);
-    t2 = __builtin_fmaf(wx, h01 - h00, h00);
-    b2 = __builtin_fmaf(wx, h11 - h10, h10);
-    o.gy = __builtin_fmaf(wy, b2 - t2, t2);
+    if (WANT_GRAD) {
+      const float Pba = cvt_ubyte<0>(q.wb), Pbd = cvt_ubyte<3>(q.wb), Pca = cvt_ubyte<0>(q.wc), Pcd = cvt_ubyte<3>(q.wc);
+      const float Pab = cvt_ubyte<1>(q.wa), Pac = cvt_ubyte<2>(q.wa), Pdb = cvt_ubyte<1>(q.wd), Pdc = cvt_ubyte<2>(q.wd);
+      const float g00 = Pbc - Pba, g01 = Pbd - Pbb, g10 = Pcc - Pca, g11 = Pcd - Pcb;   // twice the central differences
+      float t2 = __builtin_fmaf(wx, g01 - g00, g00);
+      float b2 = __builtin_fmaf(wx, g11 - g10, g10);
+      o.gx = __builtin_fmaf(wy, b2 - t2, t2);   // TWICE the gradient (the caller folds the 0.5 in)
+      const float h00 = Pcb - Pab, h01 = Pcc - Pac, h10 = Pdb - Pbb, h11 = Pdc - Pbc;
+      t2 = __builtin_fmaf(wx, h01 - h00, h00);
+      b2 = __builtin_fmaf(wx, h11 - h10, h10);
+      o.gy = __builtin_fmaf(wy, b2 - t2, t2);
+    } else {
+      o.gx = 0.0f; o.gy = 0.0f;
+    }
     return o;
   }
-  return tap_general<true, true>(img, sw, cols, rows, x1, y1);
+  return tap_general<WANT_GRAD, true>(img, sw, cols, rows, x1, y1);
 }
 
 // a / b for a per-level constant b with rb = RN(1/b): q = RN(a rb), e = a - b q (exact, fma), RN(q + e rb).
@@ -649,7 +654,7 @@ __device__ __forceinline__ FcafConst fcaf_const(const LevelGeom& g, const float*
 }
 
 // The pixel step in two stages (see tap_request_f): stage A decodes the record, warps the point and requests its rows; stage B
-// interpolates, forms the Jacobian row and the weight. FcafStage is what B needs of A (the record's registers are free after A).
+// interpolates, forms the Jacobian row and the weight. FcafStage is what B needs of A.
 struct FcafStage {
   TapReq tq;
   float x1, y1;              // warped position in the current image
@@ -657,17 +662,13 @@ struct FcafStage {
   float px, py, pz, rz;
 };
 template <class PF = NoPrefetch>
-__device__ __forceinline__ FcafStage fcaf_stage_a(const LevelGeom& g, const TapTex& tt, const FcafConst& c, const FcaInF& in, PF pf = PF()) {
+__device__ __forceinline__ FcafStage fcaf_stage_a(const LevelGeom& g, const TapRows& tr, const FcafConst& c, const FcaInF& in, PF pf = PF()) {
   FcafStage s;
   // (elements are copied to scalars first: __builtin_bit_cast applied to a vector element expression reads element 0)
   const uint32_t yI = in.v.x, w1 = in.v.y, w2 = in.v.z, w3 = in.v.w;
   const float yf = __builtin_bit_cast(float, yI & 0xffffff00u);
   s.Ikf = cvt_ubyte<0>(yI);
-  // p, var, d are COPIED out of the record's registers (three moves the optimiser cannot see through): the caller refills the
-  // record slot right behind this stage, while the stage's values stay live through the next step's stage B
-  asm volatile("v_mov_b32 %0, %1" : "=v"(s.p) : "v"(w1));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(s.var) : "v"(w2));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(s.d) : "v"(w3));
+  s.p = __builtin_bit_cast(float, w1); s.var = __builtin_bit_cast(float, w2); s.d = __builtin_bit_cast(float, w3);
   s.q = __builtin_fmaf(yf, c.rfy, c.qc);   // p = u / fx, q = v / fy
   // K ((p, q, 1) + t d): the warped point divided by the keyframe depth Z, in pixel units times its own depth. The factors of Z
   // cancel in the projection and in the weight (1 / (pz^2 d) = Z rz^2 with the true pz; here pz is pz / Z).
@@ -677,14 +678,14 @@ __device__ __forceinline__ FcafStage fcaf_stage_a(const LevelGeom& g, const TapT
   // no clamp of pz away from zero (ExternVariable.h:232): 1/0 = inf sends the point out of bounds, as the clamped value does
   s.rz = __builtin_amdgcn_rcpf(s.pz);
   s.x1 = s.px * s.rz; s.y1 = s.py * s.rz;
-  s.tq = tap_request_f<PF>(tt, g.sw, g.cols, g.rows, s.x1, s.y1, pf);
+  s.tq = tap_request_f<true, PF>(tr, g.sw, g.cols, g.rows, s.x1, s.y1, pf);
   return s;
 }
 // SAVEW: 1 = store the weights (saved-weights call), 0 = do not, -1 = a.save_w decides at run time
 template <bool DEBUG, int SAVEW = -1>
 __device__ __forceinline__ FcaPix fcaf_stage_b(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const FcafConst& c, unsigned i,
                                                const FcafStage& s) {
-  const Taps t = tap_finish_f(s.tq, cur, g.sw, g.cols, g.rows, s.x1, s.y1);
+  const Taps t = tap_finish_f<true>(s.tq, cur, g.sw, g.cols, g.rows, s.x1, s.y1);
   const float p = s.p, q = s.q, d = s.d;
   FcaPix o;
   // 1x6 row (:296-320) with A = fx gradx, B = fy grady, T = A p + B q:
@@ -730,9 +731,9 @@ __device__ __forceinline__ FcaPix fcaf_stage_b(const GnArgs& a, const KfLevelDev
   return o;
 }
 template <bool DEBUG, int SAVEW = -1>
-__device__ __forceinline__ FcaPix fcaf_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const TapTex& tt, const FcafConst& c,
+__device__ __forceinline__ FcaPix fcaf_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const TapRows& tr, const FcafConst& c,
                                              unsigned i, const FcaInF& in) {
-  return fcaf_stage_b<DEBUG, SAVEW>(a, K, g, cur, c, i, fcaf_stage_a(g, tt, c, in));
+  return fcaf_stage_b<DEBUG, SAVEW>(a, K, g, cur, c, i, fcaf_stage_a(g, tr, c, in));
 }
 
 // H += (w J)^T J (upper triangle), b += J (r w)   (PixelWisePyramid.cpp:364-374)
@@ -810,11 +811,11 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   g_u8 cur = as_global(F.img);
   FcaAcc acc;
   fca_acc_zero(acc);
-  const TapTex tt = tap_tex(F.tex, g.sw);
+  const TapRows tr = tap_rows(cur, g.sw);
   const FcafConst fc = fcaf_const(g, S);
   for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
     FcaPix p;
-    if constexpr (FAST) p = fcaf_pixel<DEBUG>(a, K, g, cur, tt, fc, (unsigned)i, fcaf_load(K, (unsigned)i));
+    if constexpr (FAST) p = fcaf_pixel<DEBUG>(a, K, g, cur, tr, fc, (unsigned)i, fcaf_load(K, (unsigned)i));
     else p = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
     fca_accumulate_pixel(acc, p);
   }
@@ -1407,9 +1408,8 @@ struct FusedArgs {
 // The pixel pass of one block of a fused launch over its chunk [begin, end) of the compact list, thread t taking the
 // entries begin + t, begin + t + 256, ...; the thread's first record (and, in the exact mode, its pose-independent products)
 // was requested by the caller before the solve. newS: exp(pose) of this iteration (LDS). Leaves the thread's 27 sums.
-// SWP (tolerance mode): chunks of at least ELLC_FCAF_PIPE_MIN pixels per thread take the software-pipelined loop.
-template <bool DIVC, bool PIPE, bool FAST, int SAVEW, bool SWP = false>
-__device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const uint32_t* cur_tex, const float* newS, int begin,
+template <bool DIVC, bool PIPE, bool FAST, int SAVEW>
+__device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const float* newS, int begin,
                                                int end, const FcaIn& first, const FcaInF& firstf, const FcaPre& first_pre, float (&sums)[27]) {
   constexpr int stride = ELLC_GN_THREADS;
   const int t = threadIdx.x;
@@ -1421,79 +1421,33 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
   int i = begin + t;
   if constexpr (FAST) {
     if (begin < end) {   // block-uniform
-      const TapTex tt = tap_tex(cur_tex, g.sw);
+      const TapRows tr = tap_rows(cur, g.sw);
       const FcafConst fc = fcaf_const(g, S);
-      // The record stream is walked by byte offset, clamped to the chunk's last record, so that every request is unconditional, and
-      // the trip count is block-uniform — every thread of the block has n_full pixels, the first `rem` threads one more — so that the
-      // loop is a plain scalar loop: a per-lane exit in the middle of an unrolled body makes the compiler merge the record slots at
-      // the back edge with register copies, and a copy of a slot waits for the load that fills it.
+      // One pixel per step: the rows are requested and used in the same step; the next pixel's record is requested behind them. The
+      // record stream is walked by byte offset, clamped to the chunk's last record, so that every request is unconditional, and the
+      // trip count is block-uniform — every thread of the block has n_full pixels, the first `rem` threads one more, and a thread
+      // without a pixel in the last step runs it on a copy of the chunk's last record without accumulating — so that the loop is a
+      // plain scalar loop: a per-lane exit in the middle of the unrolled body makes the compiler merge the two record slots at the
+      // back edge with register copies, and a copy of a slot waits for the load that fills it. The two slots alternate through the
+      // explicitly unrolled body.
       unsigned off = (unsigned)i * 16u;
       const unsigned off_last = (unsigned)(end - 1) * 16u;
       constexpr unsigned S16 = stride * 16u;
       const int n_full = __builtin_amdgcn_readfirstlane((end - begin) / stride);
-      const bool has_rem = t < (end - begin) - n_full * stride;
-      auto finish = [&](const FcafStage& cur_s) {
-#ifdef ELLC_X_NOACC   // experiment: the pixel's values are kept alive but not accumulated
-        const FcaPix px_ = fcaf_stage_b<false, SAVEW>(a, K, g, cur, fc, off >> 4, cur_s);
-        asm volatile("" ::"v"(px_.J[0]), "v"(px_.J[1]), "v"(px_.J[2]), "v"(px_.J[3]), "v"(px_.J[4]), "v"(px_.J[5]), "v"(px_.residual), "v"(px_.wgt));
-#else
-        fca_accumulate_pixel(acc, fcaf_stage_b<false, SAVEW>(a, K, g, cur, fc, off >> 4, cur_s));
-#endif
+      const int rem = __builtin_amdgcn_readfirstlane((end - begin) - n_full * stride);
+      const int n_steps = n_full + (rem > 0 ? 1 : 0);
+      FcaInF r0 = firstf, r1 = firstf;
+      auto step = [&](const FcaInF& cur_rec, FcaInF& next_rec, bool last) {
+        const bool active = !last || rem == 0 || t < rem;
+        auto refill = [&]() { next_rec = fcaf_load_off(K, min(off + S16, off_last)); };
+        const FcafStage st = fcaf_stage_a(g, tr, fc, cur_rec, refill);
+        if (active) fca_accumulate_pixel(acc, fcaf_stage_b<false, SAVEW>(a, K, g, cur, fc, off >> 4, st));
+        off += S16;
       };
-      if (SWP && n_full >= ELLC_FCAF_PIPE_MIN) {
-        // Long chunks (the dense levels: hundreds of pixels per thread): software pipeline over pixels (r04). While a pixel is
-        // interpolated and accumulated (stage B) the texels of the thread's NEXT pixel are already requested (stage A), and its
-        // records are requested three pixels ahead: vector loads return in issue order — ... texels(i), record(i+2), texels(i+1),
-        // record(i+3) ... — so the texels have one whole step and a record two steps to arrive before anything waits for them. Two
-        // stage records and two record slots alternate through an explicitly unrolled body; a thread runs stage A once more than it
-        // has pixels (harmless: loads only). 1280x960 dense x 64: 374 against 394 us; at 640x480 semi-dense (37 pixels per thread)
-        // the plain loop below is the faster one (tools/ab_level0.sh).
-        FcaInF r0 = firstf;
-        FcaInF r1 = fcaf_load_off(K, min(off + S16, off_last));
-        FcafStage s0, s1;
-        {
-          auto fill0 = [&]() { r0 = fcaf_load_off(K, min(off + 2u * S16, off_last)); };
-          s0 = fcaf_stage_a(g, tt, fc, r0, fill0);
-        }
-        auto step = [&](const FcafStage& cur_s, FcafStage& next_s, FcaInF& next_rec) {
-          // next_rec holds the record of pixel off + S16; once stage A has read it, the slot takes the record of pixel off + 3 S16
-          auto refill = [&]() { next_rec = fcaf_load_off(K, min(off + 3u * S16, off_last)); };
-          next_s = fcaf_stage_a(g, tt, fc, next_rec, refill);
-          finish(cur_s);
-          off += S16;
-        };
-        int k = 0;
-        for (; k + 2 <= n_full; k += 2) {
-          step(s0, s1, r1);
-          step(s1, s0, r0);
-        }
-        if (k < n_full) {   // block-uniform: one more full step, then the remainder pixel sits in s1
-          step(s0, s1, r1);
-          if (has_rem) finish(s1);
-        } else if (has_rem) {
-          finish(s0);
-        }
-      } else {
-        // one pixel at a time: the texels are requested and used in the same step; the next pixel's record is requested behind them
-        // (two record slots alternate through an explicitly unrolled body)
-        FcaInF r0 = firstf, r1 = firstf;
-        auto step = [&](const FcaInF& cur_rec, FcaInF& next_rec) {
-          auto refill = [&]() { next_rec = fcaf_load_off(K, min(off + S16, off_last)); };
-          const FcafStage st = fcaf_stage_a(g, tt, fc, cur_rec, refill);
-          finish(st);
-          off += S16;
-        };
-        int k = 0;
-        for (; k + 2 <= n_full; k += 2) {
-          step(r0, r1);
-          step(r1, r0);
-        }
-        if (k < n_full) {
-          step(r0, r1);
-          if (has_rem) step(r1, r0);
-        } else if (has_rem) {
-          step(r0, r1);
-        }
+      for (int k = 0; k < n_steps; k += 2) {
+        step(r0, r1, k == n_steps - 1);
+        if (k + 1 >= n_steps) break;   // block-uniform
+        step(r1, r0, k + 1 == n_steps - 1);
       }
     }
   } else if (i < end) {
@@ -1628,7 +1582,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   }
   if (skip) return;
   float sums[27];
-  fca_chunk_pass<DIVC, PIPE, FAST, SAVEW, true>(a, K, g, cur, F.tex, sh.newS, begin, end, first, firstf, first_pre, sums);
+  fca_chunk_pass<DIVC, PIPE, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
   ELLC_STAMP(7);
   ELLC_BSTAMP(2);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
@@ -1759,7 +1713,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
   }
   g_u8 cur = as_global(F->img);
   float sums[27];
-  fca_chunk_pass<DIVC, true, FAST, SAVEW>(a, K, g, cur, F->tex, sh.newS, begin, end, first, firstf, first_pre, sums);
+  fca_chunk_pass<DIVC, true, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
   block_reduce_store<27>(sums, out);
 }

@@ -41,31 +41,6 @@ __global__ void pyr_down_u8(const uint8_t* __restrict__ src, int sw, int sh, uin
   dst[(size_t)y * dw + x] = (uint8_t)((v + 128) >> 8);
 }
 
-// The texel planes of a current-frame slot (FrLevelDev::tex), all levels in one launch: grid (x blocks of the largest level, levels).
-struct TexArgs {
-  const uint8_t* img[ELLC_MAX_LEVELS];
-  uint32_t* tex[ELLC_MAX_LEVELS];
-  int sw[ELLC_MAX_LEVELS], sh[ELLC_MAX_LEVELS], cols[ELLC_MAX_LEVELS], rows[ELLC_MAX_LEVELS];
-};
-__global__ __launch_bounds__(256) void frame_texels(TexArgs a) {
-  const int l = blockIdx.y;
-  const int sw = a.sw[l], sh = a.sh[l], cols = a.cols[l], rows = a.rows[l];
-  const ELLC_GLOBAL uint8_t* img = gptr(a.img[l]);
-  ELLC_GLOBAL uint32_t* tex = gptr_rw(a.tex[l]);
-  const int n = sw * sh;
-  for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < n; i += (int)gridDim.x * 256) {
-    const int y = i / sw, x = i - y * sw;
-    uint32_t w = img[(unsigned)i];
-    if (x >= 1 && x <= cols - 2 && y >= 1 && y <= rows - 2) {
-      const int gx2 = (int)img[(unsigned)i + 1u] - (int)img[(unsigned)i - 1u];
-      const int gy2 = (int)img[(unsigned)(i + sw)] - (int)img[(unsigned)(i - sw)];
-      w |= ((uint32_t)gx2 & 0x1ffu) << ELLC_TEX_GX_SHIFT;
-      w |= (uint32_t)gy2 << ELLC_TEX_GY_SHIFT;
-    }
-    tex[(unsigned)i] = w;
-  }
-}
-
 // frame::calculateGradient (Frame.cpp:185-285) at one level, planes rows x cols
 __device__ __forceinline__ void grad_at(const uint8_t* __restrict__ img, int sw, int cols, int rows, int x, int y, float& gx, float& gy) {
   const int xm = x > 0 ? x - 1 : 0, xp = x < cols - 1 ? x + 1 : cols - 1;
