@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--device-warmup", type=int, default=200, help="untimed steps run once before the --warmup steps (part of the setup, like the "
                     "graph-capture rehearsal; 0: none)")
     ap.add_argument("--streams", type=int, default=3, help="diagnostic: batch streams the loaded library build has (ELLC_STREAMS)")
+    ap.add_argument("--no-affinity", action="store_true", help="N>1: do not pin the rank to its share of the host's CPUs")
     ap.add_argument("--lib", default=None, help="diagnostic A/B only: load this build of the library instead of csrc/libellc_hip.so")
     return ap.parse_args()
 
@@ -79,9 +80,26 @@ def spawn_ranks(a):
     """--gpus N > 1 without a launcher: start N ranks of this very command (before this process has loaded the library or
     touched a GPU), pass rank 0's output through, fail if any rank fails. The children find WORLD_SIZE set and run main()."""
     import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a free port for the ranks' rendezvous
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = 0
+    for _ in range(64):   # MASTER_PORT such that the two ports the ranks really bind (control plane + 17, TCP gather + 18) are free now
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            cand = sk.getsockname()[1]
+        ok = cand + 18 < 65536
+        for off in (17, 18):
+            if not ok:
+                break
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                try:
+                    sk.bind(("127.0.0.1", cand + off))
+                except OSError:
+                    ok = False
+        if ok:
+            port = cand
+            break
+    if not port:
+        sys.stderr.write("bench.py: no free rendezvous ports found\n")
+        return 1
     procs = []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
@@ -124,14 +142,18 @@ class Control:
         if self.comm is not None:
             self._gather(1, [0.0] * 8)
 
-    def max(self, x):
+    def all(self, x):
+        """every rank's x (an f64 as two f32 words, moved bit for bit), in rank order"""
         if self.comm is None:
-            return float(x)
+            return [float(x)]
         import numpy as np
         rec = np.zeros(8, np.float32)
-        rec[:2] = np.array([x], np.float64).view(np.float32)   # an f64 as two f32 words, moved bit for bit
+        rec[:2] = np.array([x], np.float64).view(np.float32)
         t = self._gather(1, rec)
-        return float(max(np.ascontiguousarray(t[r, :2]).view(np.float64)[0] for r in range(self.world)))
+        return [float(np.ascontiguousarray(t[r, :2]).view(np.float64)[0]) for r in range(self.world)]
+
+    def max(self, x):
+        return max(self.all(x))
 
     def broadcast_id(self, make):
         """rank 0's ellc_comm_unique_id bytes on every rank (128 bytes = 4 records of the gather, moved bit for bit)."""
@@ -219,6 +241,35 @@ class Workload:
         self.ctx.close()
 
 
+def workload_name(a, world):
+    """BASELINE.json's name of what is being run"""
+    if a.dense and (a.width, a.height, a.levels) == (1280, 960, 5):
+        return "C4 (configs[4]: 1280x960, 5 levels, dense residuals, %d per GPU x %d GPU%s = batch %d)" % (a.batch, world, "s" if world > 1 else "", a.batch * world)
+    if not a.dense and (a.width, a.height, a.levels) == (640, 480, 4):
+        return "C2 (configs[2]: batch of %d loop-closure candidate alignments)" % a.batch if world == 1 else \
+               "C3 (configs[3]: %d independent alignments sharded %d per GPU, one gather of the se(3) poses)" % (a.batch * world, a.batch)
+    return "custom (%dx%d, %d levels, %s, %d per GPU)" % (a.width, a.height, a.levels, "dense" if a.dense else "semi-dense", a.batch)
+
+
+def pin_rank_to_cpus(a, world, local_rank):
+    """N > 1: each rank keeps to its own contiguous share of the CPUs this process may run on (sorted ids: on the two-socket hosts of an
+    8-GPU node the lower half of the ids is the socket of GPUs 0-3) — host threads of different ranks (the fetch loop, the CPU baseline)
+    do not migrate over each other. Before the library is loaded. Returns what was done, for the JSON line."""
+    if world <= 1 or a.no_affinity or not hasattr(os, "sched_setaffinity"):
+        return "none"
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // max(1, local_world)
+    if per < 1:
+        return "none (fewer CPUs than ranks)"
+    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError as e:
+        return "none (%s)" % e
+    return "rank-local block of %d CPUs (%d..%d)" % (len(mine), mine[0], mine[-1])
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "0"))
@@ -230,6 +281,7 @@ def main():
     if a.rehearse_launcher:
         return rehearse_launcher(a, world, rank, local_rank)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (before the HIP runtime starts: RCCL's IPC needs the dmabuf mode on this host driver)
+    affinity = pin_rank_to_cpus(a, world, local_rank)          # before the library (and its threads) exist
     from egomotion_with_local_loop_closures_amd import _lib
     if a.lib:
         _lib.use_library(a.lib)
@@ -239,9 +291,10 @@ def main():
         raise SystemExit("bench.py: no HIP device is visible (there is no CPU fallback for the product path)")
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     if a.backend == "nccl" and world > 1 and local_world > ndev:   # (the same on every rank of the node: no rank starts RCCL)
-        sys.stderr.write("bench.py: rank %d: %d ranks on this node but %d GPU(s) visible — RCCL refuses two ranks on one device: the poses are "
-                         "gathered over the TCP transport and the ranks SHARE GPUs (not a scaling measurement)\n" % (rank, local_world, ndev))
-        a.backend = "tcp"
+        raise SystemExit("bench.py: rank %d: %d ranks on this node but %d GPU(s) visible — RCCL refuses two ranks on one device. A scaling run needs a GPU "
+                         "per rank; to REHEARSE several ranks on one GPU ask for it: --backend gloo (TCP transport, the ranks share the device, "
+                         "n_gpus then counts devices and `value` is null)" % (rank, local_world, ndev))
+    if world > 1 and local_world > ndev:
         a.ranks_share_gpus = True
     dev_index = local_rank % ndev
     ctl = Control(sharding, world, rank)
@@ -274,12 +327,11 @@ def main():
                 comm = sharding.Comm(world, rank, max_total=per_max, transport="rccl", device=dev_index, unique_id=uid)
             except Exception as e:   # (the ranks then agree on the TCP transport below, and the line says so)
                 rccl_error = "%s: %s" % (type(e).__name__, e)
-            if ctl.max(1.0 if comm is None else 0.0) > 0.0:   # some rank has no RCCL communicator: none uses it
+            if ctl.max(1.0 if comm is None else 0.0) > 0.0:   # some rank has no RCCL communicator: the run is not the one asked for
                 if comm is not None:
                     comm.close()
-                    comm = None
-                transport = "tcp"
-                sys.stderr.write("bench.py: rank %d: RCCL communicator not available (%s): the poses are gathered over the TCP transport\n"
+                ctl.close()
+                raise SystemExit("bench.py: rank %d: RCCL communicator not available (%s) — no silent fallback: --backend gloo asks for the TCP transport explicitly"
                                  % (rank, rccl_error or "another rank failed"))
         if transport == "tcp":   # rehearsal of several ranks on one GPU, or the fallback: the same entry points over TCP
             comm = sharding.Comm(world, rank, max_total=per_max, transport="tcp", host=os.environ.get("MASTER_ADDR", "127.0.0.1"),
@@ -330,7 +382,9 @@ def main():
     pose, iters = run(a.steps)
     sync()
     ctl.barrier()
-    dt = ctl.max(time.perf_counter() - t0)
+    dt_mine = time.perf_counter() - t0
+    dt = ctl.max(dt_mine)
+    per_rank_ms = [1e3 * x / a.steps for x in ctl.all(dt_mine)]   # every rank's own time for its K steps (the contract's T is their maximum)
     if a.early_exit:   # every batch of a group repeats the same alignments: the last batch's count holds for all
         iters_per_alignment = float(iters.sum()) / B
     else:
@@ -349,7 +403,7 @@ def main():
         "value": value, "unit": "GN iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C2 (N=1) / C3 (32 per GPU, N>1): %s, %dx%d, %d-level pyramid, %s Gauss-Newton, schedule %s (early exit %s), per-call mask "
+        "config": {"workload": workload_name(a, world) + ": %s, %dx%d, %d-level pyramid, %s Gauss-Newton, schedule %s (early exit %s), per-call mask "
                                "compaction included, arithmetic mode '%s' (%s), %d batches in flight, launched in groups of up to %d side by side (cfg.coalesce) on up to 3 streams%s"
                                % (shape, W, H, L, a.mode.upper(), sched, "ON: informational run" if a.early_exit else "off", a.arith,
                                   "pose <= 1e-5 vs the CPU path, tests/test_gpu_fast.py" if a.arith == "fast" else "per-pixel values bit-identical to the CPU path",
@@ -363,8 +417,13 @@ def main():
                    "gn_iterations_per_alignment": iters_per_alignment,
                    "alignments_per_s": world * B * a.steps / dt, "pixels": "dense" if a.dense else "semi-dense (maxAbsGradient>=5)", "arith": a.arith},
     }
-    if getattr(a, "ranks_share_gpus", False):
+    out["config"]["per_rank_ms_per_step"] = per_rank_ms
+    out["config"]["cpu_affinity"] = affinity
+    if getattr(a, "ranks_share_gpus", False):   # an explicit rehearsal (--backend gloo): the line must not read as a scaling point
         out["config"]["ranks_share_gpus"] = "%d ranks on %d visible GPU(s): NOT a scaling measurement" % (world, ndev)
+        out["config"]["rehearsal_value"] = value
+        out["n_gpus"] = ndev
+        out["value"] = None
     if gathering:
         out["config"]["gathered_records_rank0"] = gathered_rows[0]
 
@@ -486,6 +545,12 @@ def main():
                 out["tracked_frame_with_lc"] = tracked_frame(api, synth, a, dev_index, with_lc=True)
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(a, scenes[0], sched, value, gpu_pose0)
+        elif world > 1 and not a.no_cpu_baseline:
+            # N > 1: rank 0 times the CPU path AFTER the timed region, on its own share of the host's cores, while the other ranks wait at
+            # the closing barrier (the communicator's 60 s deadline covers the bounded sample: three variants of --cpu-seconds each, halved here)
+            a.cpu_seconds = min(a.cpu_seconds, 2.0)
+            out["cpu_baseline"] = cpu_baseline(a, scenes[0], sched, value / world, pose[0].copy(), pools=False)
+            out["cpu_baseline"]["note"] = "timed on rank 0 after the timed region; gpu_over_cpu ratios are per GPU (value / n_gpus)"
         print(json.dumps(out), flush=True)
     if wl is not None:
         wl.close()
@@ -715,7 +780,7 @@ def pmc_traffic(a, B, G, arith):
     return best
 
 
-def cpu_baseline(a, pair, sched, gpu_value, gpu_pose):
+def cpu_baseline(a, pair, sched, gpu_value, gpu_pose, pools=True):
     """The CPU restatement (oracle, kind 'port') timed on this box's host cores on a bounded sample of the same
     workload: full-schedule alignments of one 640x480 pair. Variants: one thread; 3 row-band threads created / joined per
     iteration exactly as the reference does (NUM_POSE_THREADS=3, PixelWisePyramid.cpp:424-436) — the headline `value`;
@@ -749,14 +814,14 @@ def cpu_baseline(a, pair, sched, gpu_value, gpu_pose):
     three = timed(3, spawn_threads=True)
     pool = {}
     for nt in (8, 16, 32, 64):
-        if nt <= ncores:
+        if pools and nt <= ncores:
             pool[nt] = timed(nt, pool=True)
     best = max(pool.values(), key=lambda r: r["value"]) if pool else three
     cpu_pose = O.align(kf, cur, dp, loop_closure=lc)[0]
     return {"value": three["value"], "unit": "GN iterations/s", "cores": 3, "kind": "port",
-            "sample": "%d full-schedule alignments (x2 runs, faster kept) of alignment 0 of the GPU batch, a %dx%d semi-dense pair (same schedule/inputs), "
+            "sample": "%d full-schedule alignments (x2 runs, faster kept) of alignment 0 of the GPU batch, a %dx%d %s pair (same schedule/inputs), "
                       "faithful-f32 restatement, 3 row-band threads created/joined per iteration as the reference does; host has %d hardware threads"
-                      % (three["alignments"], W, H, ncores),
+                      % (three["alignments"], W, H, "dense" if a.dense else "semi-dense", ncores),
             "1T": one, "3T": three, "3T_over_1T": three["value"] / one["value"],
             "best": dict(best, threading="persistent pool, %d row bands" % best["cores"]),
             "pool_sweep": {str(k): v["value"] for k, v in pool.items()},

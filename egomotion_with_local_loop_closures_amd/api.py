@@ -65,6 +65,15 @@ class Context:
     def sync(self):
         self._ck(self._l.ellc_sync(self.h), "ellc_sync")
 
+    def counters(self):
+        """Diagnostic counters (ELLC_CTR_* of ellc_abi.h): polled / poll_timeout / event_wait / continuation."""
+        out = (C.c_longlong * 4)()
+        self._ck(self._l.ellc_ctx_counters(self.h, out, 4), "ellc_ctx_counters")
+        return dict(polled=out[0], poll_timeout=out[1], event_wait=out[2], continuation=out[3])
+
+    def set_poll_timeout_us(self, us):
+        self._ck(self._l.ellc_ctx_set_poll_timeout_us(self.h, int(us)), "ellc_ctx_set_poll_timeout_us")
+
     def level_shape(self, level):
         return (self.cfg.height >> level, self.cfg.width >> level)
 

@@ -127,6 +127,8 @@ struct ellc_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // captured launch sequences of ellc_align, keyed by (B, unique keyframes, mode, flags: save_weights | persist | run | continuation, batch set)
   std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
+  long long counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ELLC_CTR_* (ellc_abi.h): ellc_ctx_counters
+  int poll_timeout_us = 2000;   // resolve_batch polls this long before it falls back to the event
   bool poll_results = true;     // resolve_batch polls the pinned result records of small single-stream batches; ELLC_NO_POLL=1 (diag)
   bool use_graph = true;
   bool direct_launch = false;   // the launch sequence being enqueued is not captured: its staging record goes through kernel arguments

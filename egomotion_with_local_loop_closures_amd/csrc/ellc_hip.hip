@@ -1008,6 +1008,19 @@ ellc_status ellc_ctx_destroy(ellc_ctx* c) {
   return ELLC_OK;
 }
 
+// diagnostic counters of the context (how results were waited for, continuations run): see ellc_abi.h
+ellc_status ellc_ctx_counters(ellc_ctx* c, long long* out, int n) {
+  if (!c || !out || n < 0) return ELLC_ERR_BAD_ARG;
+  for (int i = 0; i < n; i++) out[i] = i < ELLC_CTR_COUNT ? c->counters[i] : 0;
+  return ELLC_OK;
+}
+// the time resolve_batch polls the result records before it falls back to the event (default 2000 us; tests shorten it)
+ellc_status ellc_ctx_set_poll_timeout_us(ellc_ctx* c, int us) {
+  if (!c || us < 0) return ELLC_ERR_BAD_ARG;
+  c->poll_timeout_us = us;
+  return ELLC_OK;
+}
+
 // ---- frame side ----------------------------------------------------------------------------------
 ellc_status ellc_frame_upload(ellc_ctx* c, int slot, const uint8_t* image) {
   ELLC_ENTER(c);
@@ -1415,11 +1428,19 @@ static hipError_t wait_batch_results(ellc_ctx* c, ellc_ctx::BatchSet& bs) {
       for (int b = 0; b < bs.B; b++) all = all && (*(volatile const int*)&bs.result_h[b].pad != -1);
       if (all) {
         std::atomic_thread_fence(std::memory_order_acquire);
+        // The batch's trailing kernels (saved weights, the depth stages of a tracked frame) may still be running on the main stream,
+        // and once the set is freed nothing else remembers them: a group placed on ANOTHER stream next (it may rebuild lists from
+        // the weight planes the saved-weights kernel is adding to) has to be ordered behind the main stream as it is now. The
+        // event wait this poll replaces gave that order by itself (r03 advisor finding).
+        c->main_dirty = true;
+        c->counters[ELLC_CTR_POLLED]++;
         return hipSuccess;
       }
-      if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+      if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(c->poll_timeout_us)) break;
     }
+    c->counters[ELLC_CTR_POLL_TIMEOUT]++;
   }
+  c->counters[ELLC_CTR_EVENT_WAIT]++;
   return hipEventSynchronize(bs.done);
 }
 
@@ -1449,6 +1470,7 @@ static ellc_status resolve_batch(ellc_ctx* c, int set) {
   }
   select_batch_set(c, selected);
   if (s != ELLC_OK) return s;
+  c->counters[ELLC_CTR_CONTINUATION]++;
   ev = hipEventSynchronize(bs.done);
   if (ev != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("the batch failed on the device: ") + hipGetErrorString(ev));
   return ELLC_OK;

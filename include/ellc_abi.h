@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define ELLC_MAX_LEVELS 8
-#define ELLC_ABI_VERSION 6
+#define ELLC_ABI_VERSION 7
 
 typedef enum {
   ELLC_OK = 0,
@@ -97,6 +97,17 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out);
 ellc_status ellc_ctx_destroy(ellc_ctx* ctx);
 const char* ellc_last_error(const ellc_ctx* ctx);   /* human-readable text of the last failure */
 ellc_status ellc_sync(ellc_ctx* ctx);               /* hipStreamSynchronize on the context stream */
+/* Diagnostic counters since the context was created (v7; no reference counterpart: they make the library's two ways of waiting for a
+ * batch observable to tests). out[i], i < n: ELLC_CTR_* below, 0 beyond ELLC_CTR_COUNT. */
+enum {
+  ELLC_CTR_POLLED = 0,        /* batches whose result records the host polled successfully (pinned memory, no event wait) */
+  ELLC_CTR_POLL_TIMEOUT = 1,  /* polls that ran out (ellc_ctx_set_poll_timeout_us, default 2 ms) and fell back to the event */
+  ELLC_CTR_EVENT_WAIT = 2,    /* batches waited for through their event (never polled, or after a timeout) */
+  ELLC_CTR_CONTINUATION = 3,  /* continuation graphs of the state-driven early-exit schedule */
+  ELLC_CTR_COUNT = 4
+};
+ellc_status ellc_ctx_counters(ellc_ctx* ctx, long long* out, int n);
+ellc_status ellc_ctx_set_poll_timeout_us(ellc_ctx* ctx, int microseconds);
 void* ellc_stream(ellc_ctx* ctx);                   /* the context's hipStream_t (for event timing by callers) */
 
 /* ---- frame side: frame::frame / constructImagePyramids / calculateGradient / buildMaxGradients

@@ -90,6 +90,11 @@ class Runtime {
   // ranks and its results gathered once per batch (ellc_gather_results). comm == nullptr: single process.
   ellc_comm* comm = nullptr;
   int world = 1, rank = 0;
+  // The loop-closure context's launch grids are fixed (cfg.grid_batch = max_batch) so that the files a run writes do not depend on how
+  // many ranks shared the batch — including one (ellc_main --world 2 equals the single process byte for byte). A single process that
+  // does not need that may clear this before it constructs globalOptimize: its small batches (usually 1-5 candidates) then get grids
+  // of their own size and the state-driven schedule (r03 advisor finding).
+  bool lc_fixed_grids = true;
   int frame_ring = 3;             // tracking uses frame slots [0, frame_ring): current, t-1 and one spare
   int next_frame_slot() { int s = frame_cursor_; frame_cursor_ = (frame_cursor_ + 1) % frame_ring; return s; }
   int other_keyframe_slot(int current) const { return (current + 1) % 2; }   // keyframe slots 0 / 1: active and incoming
@@ -363,8 +368,8 @@ inline std::vector<float> TrackFrameAndObserve(frame* prev_frame, frame* current
 // (:161) — and when the object goes away. The ring lives in a Runtime of its own (`ring`: a second context with its own
 // streams, so its batch overlaps the tracking context's work on the device); pushToArray deep-copies the finished keyframe
 // into it (ellc_copy_slot_across = new frame(*currentframe) / new depthMap(*currentDepthMap), :185-186) and the thread only
-// ever touches the ring context. The ring context fixes its launch grids (cfg.grid_batch = max_batch): a rank's shard of a
-// batch has the bits of the whole batch.
+// ever touches the ring context. The ring context fixes its launch grids (cfg.grid_batch = max_batch; Runtime::lc_fixed_grids):
+// a rank's shard of a batch has the bits of the whole batch.
 class globalOptimize {
  public:
   static const int MAX_LOOP_ARRAY_LENGTH = 20;                                   // ExternVariable.h:161
@@ -392,18 +397,18 @@ class globalOptimize {
   int match_window_beg = 0, match_window_end = MAX_LOOP_ARRAY_LENGTH - 1;
   float matchValue = 0, rms_error = 0, relative_view_angle = 0;
 
-  static ellc_config ring_config(const ellc_config& tracking) {
+  static ellc_config ring_config(const ellc_config& tracking, bool fixed_grids) {
     ellc_config c = tracking;
     c.max_keyframes = MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
     c.max_frames = 1;
     c.max_batch = MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
-    c.grid_batch = c.max_batch;   // world-size invariant bits (ellc_abi.h)
+    c.grid_batch = fixed_grids ? c.max_batch : 0;   // world-size invariant bits (ellc_abi.h; Runtime::lc_fixed_grids)
     c.concurrent_batches = 1;
     c.coalesce = 1;
     c.cache_records = 1;          // the ring's keyframes stay from push to push: only the slot a push replaces has its pixel lists rebuilt (same results)
     return c;
   }
-  globalOptimize(Runtime& r, const std::string& matchfilepath) : rt(&r), ring(ring_config(r.cfg)) {
+  globalOptimize(Runtime& r, const std::string& matchfilepath) : rt(&r), ring(ring_config(r.cfg, r.lc_fixed_grids || r.world > 1)) {
     ring.BATCH_START_ID = r.BATCH_START_ID;
     match_file.open(matchfilepath.c_str());
   }

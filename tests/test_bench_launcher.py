@@ -34,9 +34,19 @@ def test_three_ranks_and_a_failing_rank_fails_the_launch():
     r = run(["--gpus", "3", "--steps", "4", "--batch", "2", "--rehearse-launcher"])
     assert r.returncode == 0, r.stderr.decode()
     assert json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])["n_gpus"] == 3
-    # a rank that cannot run (here: the product path on a box without a GPU) makes the whole launch fail loudly, not hang
-    r = run(["--gpus", "2", "--steps", "2", "--no-extras"], timeout=300)
+    # a rank that cannot run makes the whole launch fail loudly, not hang: the product path with a library that does not exist
+    # (deterministic with or without a GPU on the box: the loader fails before anything touches a device)
+    r = run(["--gpus", "2", "--steps", "2", "--no-extras", "--lib", "/nonexistent/libellc_hip.so"], timeout=300)
     assert r.returncode != 0
+
+
+def test_eight_ranks_rehearsal():
+    """The launcher at the node's size (configs[3] / configs[4] run with --gpus 8): eight ranks, control plane and pipelined gathers."""
+    r = run(["--gpus", "8", "--steps", "4", "--batch", "3", "--rehearse-launcher"], timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["gathers_ok"] and out["id_ok"] and out["max_over_ranks"] == 8.0
+    assert sorted(e["rank"] for e in out["ranks"]) == list(range(8))
 
 
 def test_ranks_started_by_a_launcher_are_not_respawned():

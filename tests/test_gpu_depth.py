@@ -142,6 +142,38 @@ def test_propagate_collisions_follow_raster_order(scene, oracle):
     ctx.keyframe_from_frame(1, 0)
 
 
+def test_propagate_more_than_four_sources_per_target(scene, oracle):
+    """dm_prop_fold keeps four source slots per target; a target hit by more finds its sources by scanning the source list
+    (csrc/ellc_kernels_depth.hpp, the `c > DM_PROP_SLOTS` branch; DepthPropagation.cpp:1090-1148 folds them in raster order).
+    A DENSE map (every pixel a hypothesis, inverse depth about 1 with outliers) seen from 1.6 depths further back shrinks by
+    2.6 in each direction: about seven sources per target."""
+    dm, ctx = fresh(scene, oracle)
+    rng = np.random.default_rng(5)
+    H, W = scene["st"]["valid"].shape
+    valid = np.ones((H, W), bool)
+    valid[:3, :] = False; valid[-3:, :] = False; valid[:, :3] = False; valid[:, -3:] = False
+    idm = (1.0 + 0.05 * rng.normal(size=(H, W))).astype(np.float32)
+    idm = np.where(rng.random((H, W)) < 0.05, idm * 1.8, idm).astype(np.float32)   # occluders: the fold's order-dependent branch
+    var = (0.01 * rng.uniform(0.5, 2.0, size=(H, W))).astype(np.float32)
+    st = dict(invDepth=np.where(valid, idm, 0).astype(np.float32), invDepthSmoothed=np.where(valid, idm, 0).astype(np.float32),
+              variance=np.where(valid, var, 0).astype(np.float32), varianceSmoothed=np.where(valid, var, 0).astype(np.float32),
+              validity=np.where(valid, rng.integers(0, 60, size=(H, W)), 0).astype(np.int32),
+              blacklisted=np.zeros((H, W), np.int32), valid=valid.astype(np.uint8))
+    dm.set_state(st); ctx.depth_set_state(st)
+    pose = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 1.6], np.float32)
+    newkf = oracle.Frame(scene["ocfg"], scene["pair"]["kf_image"], 5)
+    newkf.set_pose(origin=pose)
+    ctx.keyframe_upload(1, scene["pair"]["kf_image"])
+    dm.propagate(newkf)
+    ctx.depth_propagate(1, pose)
+    ref, got = dm.get_state(), ctx.depth_get_state()
+    n_src = int(valid.sum()); n_dst = int(ref["valid"].sum())
+    print("sources %d -> targets %d (%.1f per target)" % (n_src, n_dst, n_src / max(n_dst, 1)))
+    assert n_dst > 100 and n_src > 5.5 * n_dst    # far beyond four sources per target on average: the scanning branch runs
+    assert_state_equal(got, ref, "propagate, more than four sources per target")
+    ctx.keyframe_from_frame(1, 0)
+
+
 def test_update_depth_image_and_pyramid_bit_exact(scene, oracle):
     dm, ctx = fresh(scene, oracle)
     dm.regularize(False); ctx.depth_regularize(False)

@@ -151,6 +151,37 @@ def test_ica_constant_weight_path(problem, oracle):
     assert np.linalg.norm(pose_g[0] - pose_ref) <= 1e-5
 
 
+@pytest.mark.parametrize("save_weights", [False, True])
+def test_result_poll_and_its_timeout_fallback(problem, oracle, ellc, save_weights):
+    """A single alignment with nothing else in flight is waited for by polling the pinned result record (resolve_batch);
+    when the poll runs out the library falls back to the batch's event. Both ways must hand back the same bits, and the
+    oracle's pose: here the second call's poll is cut to 0 us, so it falls back at once (ELLC_CTR_POLL_TIMEOUT counts it).
+    With saved weights the batch's trailing kernel is still running when a successful poll returns: the weight planes read
+    back afterwards must equal those of the event-waited call (the order the r03 advisor found missing)."""
+    pair = problem["pair"]
+    pose_ref, iters_ref, _ = oracle.align(problem["kf"], problem["cur"], problem["dm"].depth_pyr())
+    got = []
+    for timeout_us in (2000, 0):
+        ctx = gpu_problem(ellc, W, H, L, [pair])
+        ctx.set_poll_timeout_us(timeout_us)
+        c0 = ctx.counters()
+        pose, iters, _ = ctx.align([0], [0], save_weights=save_weights)
+        c1 = ctx.counters()
+        if timeout_us == 0:
+            assert c1["poll_timeout"] == c0["poll_timeout"] + 1 and c1["event_wait"] == c0["event_wait"] + 1, (c0, c1)
+            assert c1["polled"] == c0["polled"]
+        else:
+            assert c1["polled"] == c0["polled"] + 1 and c1["poll_timeout"] == c0["poll_timeout"], (c0, c1)
+        assert list(iters[0]) == list(iters_ref)
+        assert np.linalg.norm(pose[0] - pose_ref) <= 1e-5
+        weights = [ctx.keyframe_weights(0, l)[0].copy() for l in range(L)] if save_weights else []
+        got.append((pose.copy(), weights))
+        ctx.close()
+    assert np.array_equal(got[0][0], got[1][0])
+    for wa, wb in zip(got[0][1], got[1][1]):
+        assert np.array_equal(wa, wb) and (not save_weights or np.any(wa != 0))
+
+
 def test_save_weights_accumulates_last_iteration(oracle, ellc):
     pair = synth.make_pair(W, H, seed=21)
     ocfg, kf, cur, dm = oracle_problem(oracle, W, H, L, pair)
