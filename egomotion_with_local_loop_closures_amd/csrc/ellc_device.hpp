@@ -7,7 +7,6 @@
 #define ELLC_PART_STRIDE 32     // floats per block partial record (27 used: 21 upper-triangular H + 6 b)
 #define ELLC_NBLK_MAX 256       // max accumulate-blocks per alignment
 #define ELLC_GN_THREADS 256
-#define ELLC_TILE 2048           // pixels per compaction block and per segment of the compact lists (KfLevelDev)
 
 namespace ellc {
 
@@ -75,14 +74,8 @@ struct KfLevelDev {
   float* cW;                  // compact saved weight (ICA)
   float* wlast;               // compact weight of the most recent iteration (for saveWeights)
   float* sd;                  // ICA steepest-descent planes, 6 x cap (plane k at sd + k*cap)
-  // The compact lists are kept in per-TILE SEGMENTS (r04): entry r of tile t (ELLC_TILE pixels of the plane, raster order) sits at
-  // t * ELLC_TILE + r of every compact array. The list's logical order — what the Gauss-Newton passes split into chunks — is the
-  // tiles' concatenation; tile_pref maps it: a logical index i with tile_pref[t] <= i < tile_pref[t + 1] is entry i - tile_pref[t] of
-  // tile t. One compaction launch writes records, counts and (its last block per slot and level) the prefix: no count pass.
-  int* count;                 // V = number of compact entries = tile_pref[tiles]
-  int* tile_count;            // [tiles] entries per tile
-  int* tile_pref;             // [tiles + 2] exclusive prefix of tile_count; [tiles] = V; [tiles + 1] = INT_MAX (the cursors read one ahead)
-  int* ticket;                // arrival counter of the compaction's blocks (0 between launches)
+  int* count;                 // V = number of compact entries
+  int* tile_count;            // per-tile (ELLC_TILE pixels) counts, then exclusive offsets
 };
 
 struct FrLevelDev {

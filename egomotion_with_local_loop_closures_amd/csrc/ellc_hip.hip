@@ -249,6 +249,7 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
   a.tile0 = c->tile_begin[lvl_lo];
   a.level0 = lvl_lo;
   const int tiles = c->tile_begin[lvl_hi + 1] - c->tile_begin[lvl_lo];
+  hipLaunchKernelGGL(prep_count, dim3(tiles, n_unique), dim3(256), 0, st, a);
   switch (need) {
     case 1: hipLaunchKernelGGL(prep_scatter<1>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL(prep_scatter<2>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
@@ -471,21 +472,18 @@ static void set_age_split(ellc_ctx* c, FusedArgs& fa, int B) {
   fa.age_rounds = R;
 }
 
-// dynamic LDS of the fused Gauss-Newton kernels: their copy of a level's tile prefix (KfLevelDev::tile_pref, seg_stage)
-static size_t seg_lds_bytes(const ellc_ctx* c, int level) { return (size_t)(c->tile_begin[level + 1] - c->tile_begin[level] + 2) * sizeof(int); }
-
 static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
   const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
   const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
   if (c->fast) {
-    if (fa.g.save_w) hipLaunchKernelGGL((gn_fca_fused<false, true, true, 1>), grd, blk, seg_lds_bytes(c, fa.g.level), st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
-    else hipLaunchKernelGGL((gn_fca_fused<false, true, true, 0>), grd, blk, seg_lds_bytes(c, fa.g.level), st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    if (fa.g.save_w) hipLaunchKernelGGL((gn_fca_fused<false, true, true, 1>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, true, true, 0>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
   } else if (c->pipe) {
-    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, true>), grd, blk, seg_lds_bytes(c, fa.g.level), st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
-    else hipLaunchKernelGGL((gn_fca_fused<false, true>), grd, blk, seg_lds_bytes(c, fa.g.level), st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, true>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, true>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
   } else {
-    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, false>), grd, blk, seg_lds_bytes(c, fa.g.level), st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
-    else hipLaunchKernelGGL((gn_fca_fused<false, false>), grd, blk, seg_lds_bytes(c, fa.g.level), st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, false>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, false>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
   }
 }
 
@@ -577,12 +575,12 @@ static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weight
     const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
     const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
     if (c->fast) {
-      if (save_weights) hipLaunchKernelGGL((gn_fca_adaptive<false, true, 1>), grd, blk, seg_lds_bytes(c, 0), c->stream, src_state, prev_part, grid_x, fa);
-      else hipLaunchKernelGGL((gn_fca_adaptive<false, true, 0>), grd, blk, seg_lds_bytes(c, 0), c->stream, src_state, prev_part, grid_x, fa);
+      if (save_weights) hipLaunchKernelGGL((gn_fca_adaptive<false, true, 1>), grd, blk, 0, c->stream, src_state, prev_part, grid_x, fa);
+      else hipLaunchKernelGGL((gn_fca_adaptive<false, true, 0>), grd, blk, 0, c->stream, src_state, prev_part, grid_x, fa);
     } else if (c->geom_h[0].divc_ok) {
-      hipLaunchKernelGGL((gn_fca_adaptive<true, false, -1>), grd, blk, seg_lds_bytes(c, 0), c->stream, src_state, prev_part, grid_x, fa);
+      hipLaunchKernelGGL((gn_fca_adaptive<true, false, -1>), grd, blk, 0, c->stream, src_state, prev_part, grid_x, fa);
     } else {
-      hipLaunchKernelGGL((gn_fca_adaptive<false, false, -1>), grd, blk, seg_lds_bytes(c, 0), c->stream, src_state, prev_part, grid_x, fa);
+      hipLaunchKernelGGL((gn_fca_adaptive<false, false, -1>), grd, blk, 0, c->stream, src_state, prev_part, grid_x, fa);
     }
     fa.seq++;
   }
@@ -656,8 +654,8 @@ static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
     for (int it = 0; it < c->cfg.max_iter[level]; it++) {
       const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
       const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
-      if (c->fast) hipLaunchKernelGGL(gn_ica_fused<true>, grd, blk, seg_lds_bytes(c, level), c->stream, src_state, prev_part, fa.prev_nblk, fa);
-      else hipLaunchKernelGGL(gn_ica_fused<false>, grd, blk, seg_lds_bytes(c, level), c->stream, src_state, prev_part, fa.prev_nblk, fa);
+      if (c->fast) hipLaunchKernelGGL(gn_ica_fused<true>, grd, blk, 0, c->stream, src_state, prev_part, fa.prev_nblk, fa);
+      else hipLaunchKernelGGL(gn_ica_fused<false>, grd, blk, 0, c->stream, src_state, prev_part, fa.prev_nblk, fa);
       fa.prev_level = level;
       fa.prev_nblk = fa.g.nblk;
       fa.seq++;
@@ -840,7 +838,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       TRY(dev_alloc(c, &k.depth, n)); TRY(dev_alloc(c, &k.var, n)); TRY(dev_alloc(c, &k.weight, n));
       TRY(dev_alloc(c, &k.cxy, n)); TRY(dev_alloc(c, &k.cZ, n)); TRY(dev_alloc(c, &k.cI, n));
       TRY(dev_alloc(c, &k.crec, n)); TRY(dev_alloc(c, &k.cW, n)); TRY(dev_alloc(c, &k.wlast, n)); TRY(dev_alloc(c, &k.sd, 6 * n));
-      TRY(dev_alloc(c, &k.count, 4)); TRY(dev_alloc(c, &k.tile_count, tiles + 1)); TRY(dev_alloc(c, &k.tile_pref, tiles + 2)); TRY(dev_alloc(c, &k.ticket, 4));
+      TRY(dev_alloc(c, &k.count, 4)); TRY(dev_alloc(c, &k.tile_count, tiles + 1));
       TRY(dev_alloc(c, &k.irec, n)); TRY(dev_alloc(c, &k.hpart, (size_t)(tiles + 1) * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
     }
     for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni + 16));

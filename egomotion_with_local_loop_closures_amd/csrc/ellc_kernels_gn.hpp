@@ -433,41 +433,6 @@ __device__ __forceinline__ float fca_weight(const Warp& w, float d, float residu
   return wh * w_p;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Segmented compact lists (KfLevelDev, r04): logical index -> physical index. pref: the exclusive prefix of the tile counts
-// (tile_pref: [T] = V, [T + 1] = INT_MAX), in global memory or staged in LDS by the block (seg_stage). A cursor serves a
-// non-decreasing sequence of logical indices: a compare per index while it stays in its tile, one prefix entry read (one ahead, so
-// that nothing waits for it) when it crosses into the next.
-struct SegCursor { int t, hi, hi_next, delta; };   // tile, pref[t + 1], pref[t + 2], t * ELLC_TILE - pref[t]
-template <class P>
-__device__ __forceinline__ void seg_seek(SegCursor& c, P pref, int T, int i) {   // 0 <= i < V
-  int lo = 0, hi = T;   // pref[lo] <= i < pref[hi]
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (pref[mid] <= i) lo = mid; else hi = mid;
-  }
-  c.t = lo;
-  c.delta = lo * ELLC_TILE - pref[lo];
-  c.hi = pref[lo + 1];
-  c.hi_next = pref[lo + 2];
-}
-template <class P>
-__device__ __forceinline__ unsigned seg_phys(SegCursor& c, P pref, int i) {   // i: not below the previous call's, < V
-  while (i >= c.hi) {
-    c.t++;
-    c.delta = c.t * ELLC_TILE - c.hi;
-    c.hi = c.hi_next;
-    c.hi_next = pref[c.t + 2];
-  }
-  return (unsigned)(i + c.delta);
-}
-typedef const ELLC_LDS int* lds_pref;
-// the block's copy of a level's prefix (T + 2 entries) in LDS; the caller synchronises
-__device__ __forceinline__ void seg_stage(ELLC_LDS int* s, const int* pref, int T) {
-  for (int k = (int)threadIdx.x; k < T + 2; k += (int)blockDim.x) s[k] = as_global(pref)[k];
-}
-__device__ __forceinline__ int seg_tiles(const LevelGeom& g) { return (g.n + ELLC_TILE - 1) / ELLC_TILE; }
-
 struct GnArgs {
   const LevelGeom* geom;        // [levels]
   const KfLevelDev* kf_tab;     // [levels][max_kf]
@@ -848,16 +813,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   fca_acc_zero(acc);
   const TapRows tr = tap_rows(cur, g.sw);
   const FcafConst fc = fcaf_const(g, S);
-  // (not a hot kernel: the cursor reads the tile prefix from global memory)
-  const ELLC_GLOBAL int* pref = as_global(K.tile_pref);
-  SegCursor sc;
-  int i = begin + (int)threadIdx.x;
-  if (i < end) seg_seek(sc, pref, seg_tiles(g), i);
-  for (; i < end; i += ELLC_GN_THREADS) {
-    const unsigned ph = seg_phys(sc, pref, i);
+  for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
     FcaPix p;
-    if constexpr (FAST) p = fcaf_pixel<DEBUG>(a, K, g, cur, tr, fc, ph, fcaf_load(K, ph));
-    else p = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, ph);
+    if constexpr (FAST) p = fcaf_pixel<DEBUG>(a, K, g, cur, tr, fc, (unsigned)i, fcaf_load(K, (unsigned)i));
+    else p = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
     fca_accumulate_pixel(acc, p);
   }
   float sums[27];
@@ -886,11 +845,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_precompute(GnArgs a, i
   float acc[21];
 #pragma unroll
   for (int i = 0; i < 21; i++) acc[i] = 0.0f;
-  const ELLC_GLOBAL int* pref = as_global(K.tile_pref);   // (not a hot kernel: the cursor reads the tile prefix from global memory)
-  SegCursor sc;
-  if (begin + (int)threadIdx.x < end) seg_seek(sc, pref, seg_tiles(g), begin + (int)threadIdx.x);
-  for (int li = begin + (int)threadIdx.x; li < end; li += stride) {
-    const unsigned i = seg_phys(sc, pref, li);   // physical index: the lists are kept in per-tile segments (KfLevelDev)
+  for (int i = begin + (int)threadIdx.x; i < end; i += stride) {
     const uint32_t xy = as_global(K.cxy)[i];
     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
     const float Z = as_global(K.cZ)[i];
@@ -946,11 +901,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
   float acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0.0f;
-  const ELLC_GLOBAL int* pref = as_global(K.tile_pref);   // (not a hot kernel: the cursor reads the tile prefix from global memory)
-  SegCursor sc;
-  if (begin + (int)threadIdx.x < end) seg_seek(sc, pref, seg_tiles(g), begin + (int)threadIdx.x);
-  for (int li = begin + (int)threadIdx.x; li < end; li += stride) {
-    const unsigned i = seg_phys(sc, pref, li);   // physical index: the lists are kept in per-tile segments (KfLevelDev)
+  for (int i = begin + (int)threadIdx.x; i < end; i += stride) {
     const uint32_t xy = as_global(K.cxy)[i];
     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
     const float Z = as_global(K.cZ)[i];
@@ -1457,12 +1408,9 @@ struct FusedArgs {
 // The pixel pass of one block of a fused launch over its chunk [begin, end) of the compact list, thread t taking the
 // entries begin + t, begin + t + 256, ...; the thread's first record (and, in the exact mode, its pose-independent products)
 // was requested by the caller before the solve. newS: exp(pose) of this iteration (LDS). Leaves the thread's 27 sums.
-// seg / sc / ph0: the block's LDS copy of the level's tile prefix, the thread's cursor on it and the physical index of its first
-// record (the lists are kept in per-tile segments: KfLevelDev, seg_phys).
 template <bool DIVC, bool PIPE, bool FAST, int SAVEW>
 __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const float* newS, int begin,
-                                               int end, const FcaIn& first, const FcaInF& firstf, const FcaPre& first_pre, lds_pref seg, SegCursor sc,
-                                               unsigned ph0, float (&sums)[27]) {
+                                               int end, const FcaIn& first, const FcaInF& firstf, const FcaPre& first_pre, float (&sums)[27]) {
   constexpr int stride = ELLC_GN_THREADS;
   const int t = threadIdx.x;
   float S[12];
@@ -1470,32 +1418,31 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
   for (int i = 0; i < 12; i++) S[i] = newS[i];
   FcaAcc acc;
   fca_acc_zero(acc);
-  int i = begin + t;       // logical index of the thread's current pixel
-  unsigned ph = ph0;       // and where its record sits
+  int i = begin + t;
   if constexpr (FAST) {
     if (begin < end) {   // block-uniform
       const TapRows tr = tap_rows(cur, g.sw);
       const FcafConst fc = fcaf_const(g, S);
       // One pixel per step: the rows are requested and used in the same step; the next pixel's record is requested behind them. The
-      // next index is clamped to the chunk's last record, so that every request is unconditional, and the trip count is
-      // block-uniform — every thread of the block has n_full pixels, the first `rem` threads one more, and a thread without a pixel
-      // in the last step runs it on a copy of the chunk's last record without accumulating — so that the loop is a plain scalar
-      // loop: a per-lane exit in the middle of the unrolled body makes the compiler merge the two record slots at the back edge
-      // with register copies, and a copy of a slot waits for the load that fills it. The two slots alternate through the explicitly
-      // unrolled body.
+      // record stream is walked by byte offset, clamped to the chunk's last record, so that every request is unconditional, and the
+      // trip count is block-uniform — every thread of the block has n_full pixels, the first `rem` threads one more, and a thread
+      // without a pixel in the last step runs it on a copy of the chunk's last record without accumulating — so that the loop is a
+      // plain scalar loop: a per-lane exit in the middle of the unrolled body makes the compiler merge the two record slots at the
+      // back edge with register copies, and a copy of a slot waits for the load that fills it. The two slots alternate through the
+      // explicitly unrolled body.
+      unsigned off = (unsigned)i * 16u;
+      const unsigned off_last = (unsigned)(end - 1) * 16u;
+      constexpr unsigned S16 = stride * 16u;
       const int n_full = __builtin_amdgcn_readfirstlane((end - begin) / stride);
       const int rem = __builtin_amdgcn_readfirstlane((end - begin) - n_full * stride);
       const int n_steps = n_full + (rem > 0 ? 1 : 0);
       FcaInF r0 = firstf, r1 = firstf;
       auto step = [&](const FcaInF& cur_rec, FcaInF& next_rec, bool last) {
         const bool active = !last || rem == 0 || t < rem;
-        const int i1 = min(i + stride, end - 1);
-        const unsigned ph1 = seg_phys(sc, seg, i1);
-        auto refill = [&]() { next_rec = fcaf_load(K, ph1); };
+        auto refill = [&]() { next_rec = fcaf_load_off(K, min(off + S16, off_last)); };
         const FcafStage st = fcaf_stage_a(g, tr, fc, cur_rec, refill);
-        if (active) fca_accumulate_pixel(acc, fcaf_stage_b<false, SAVEW>(a, K, g, cur, fc, ph, st));
-        i = i1;
-        ph = ph1;
+        if (active) fca_accumulate_pixel(acc, fcaf_stage_b<false, SAVEW>(a, K, g, cur, fc, off >> 4, st));
+        off += S16;
       };
       for (int k = 0; k < n_steps; k += 2) {
         step(r0, r1, k == n_steps - 1);
@@ -1507,18 +1454,16 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
     if (PIPE) {   // exact mode: one record ahead (two slots; a third costs registers this kernel does not have)
       FcaIn r0 = first, r1 = first;
       {
-        const unsigned ph1 = seg_phys(sc, seg, min(i + stride, end - 1));
-        auto prefetch = [&]() { r1 = fca_load(K, ph1); };
-        fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, ph, first, first_pre, prefetch));
+        const int i1 = i + stride;
+        auto prefetch = [&]() { r1 = fca_load(K, (unsigned)min(i1, end - 1)); };
+        fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre, prefetch));
         i += stride;
-        ph = ph1;
       }
       auto step = [&](const FcaIn& in, FcaIn& fill) {
-        const unsigned ph1 = seg_phys(sc, seg, min(i + stride, end - 1));
-        auto prefetch = [&]() { fill = fca_load(K, ph1); };
-        fca_accumulate_pixel(acc, fca_pixel_in<false, DIVC>(a, K, g, cur, S, ph, in, prefetch));
+        const int i1 = i + stride;
+        auto prefetch = [&]() { fill = fca_load(K, (unsigned)min(i1, end - 1)); };
+        fca_accumulate_pixel(acc, fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, in, prefetch));
         i += stride;
-        ph = ph1;
       };
       while (i < end) {
         step(r1, r0);
@@ -1526,10 +1471,9 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
         step(r0, r1);
       }
     } else {
-      fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, ph, first, first_pre));
+      fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre));
       for (i += stride; i < end; i += stride) {
-        ph = seg_phys(sc, seg, i);
-        const FcaPix q = fca_pixel<false, DIVC>(a, K, g, cur, S, ph);
+        const FcaPix q = fca_pixel<false, DIVC>(a, K, g, cur, S, (unsigned)i);
         fca_accumulate_pixel(acc, q);
       }
     }
@@ -1602,25 +1546,11 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.X = 0.0f; first.Y = 0.0f; first.invZ = 1.0;
   FcaInF firstf = fcaf_empty();
   FcaPre first_pre;
-  // the level's tile prefix into LDS, then this thread's cursor on it (the lists are kept in per-tile segments, KfLevelDev)
-  extern __shared__ int s_seg_raw[];
-  ELLC_LDS int* s_seg = (ELLC_LDS int*)s_seg_raw;
-  const int T = seg_tiles(g);
-  seg_stage(s_seg, K.tile_pref, T);
-  __syncthreads();
-  SegCursor sc;
-  sc.t = 0; sc.hi = 0x7fffffff; sc.hi_next = 0x7fffffff; sc.delta = 0;
-  unsigned ph0 = 0;
-  if (begin < end) {   // (a thread past the chunk's end starts on a copy of the chunk's last record: the tolerance mode's loop is block-uniform)
-    const int i0 = min(begin + t, end - 1);
-    seg_seek(sc, (lds_pref)s_seg, T, i0);
-    ph0 = (unsigned)(i0 + sc.delta);
-  }
   if constexpr (FAST) {
-    if (begin < end) firstf = fcaf_load(K, ph0);
+    if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));   // (a thread past the chunk's end starts on a copy of its last record: the pixel loop is block-uniform)
   } else {
     if (begin + t < end) {
-      first = fca_load(K, ph0);
+      first = fca_load(K, (unsigned)(begin + t));
     }
     first_pre = fca_prepare<DIVC>(g, first);
     // pin the arithmetic here (the compiler would otherwise sink it below the solve, onto the critical path)
@@ -1652,7 +1582,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   }
   if (skip) return;
   float sums[27];
-  fca_chunk_pass<DIVC, PIPE, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, (lds_pref)s_seg, sc, ph0, sums);
+  fca_chunk_pass<DIVC, PIPE, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
   ELLC_STAMP(7);
   ELLC_BSTAMP(2);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
@@ -1730,24 +1660,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
   first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.X = 0.0f; first.Y = 0.0f; first.invZ = 1.0;
   FcaInF firstf = fcaf_empty();
   FcaPre first_pre;
-  // the level's tile prefix into LDS, then this thread's cursor on it (see gn_fca_fused)
-  extern __shared__ int s_seg_raw[];
-  ELLC_LDS int* s_seg = (ELLC_LDS int*)s_seg_raw;
-  int T = seg_tiles(g);
-  seg_stage(s_seg, K.tile_pref, T);
-  __syncthreads();
-  SegCursor sc;
-  sc.t = 0; sc.hi = 0x7fffffff; sc.hi_next = 0x7fffffff; sc.delta = 0;
-  unsigned ph0 = 0;
-  if (sub < nb_l && begin < end) {
-    const int i0 = min(begin + t, end - 1);
-    seg_seek(sc, (lds_pref)s_seg, T, i0);
-    ph0 = (unsigned)(i0 + sc.delta);
-  }
   if constexpr (FAST) {
-    if (sub < nb_l && begin < end) firstf = fcaf_load(K, ph0);
+    if (sub < nb_l && begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));
   } else {
-    if (sub < nb_l && begin + t < end) first = fca_load(K, ph0);
+    if (sub < nb_l && begin + t < end) first = fca_load(K, (unsigned)(begin + t));
     first_pre = fca_prepare<DIVC>(g, first);
     asm volatile("" ::"v"(first_pre.c_t0), "v"(first_pre.c_b1), "v"(first_pre.d), "v"(first_pre.fxz), "v"(first_pre.fyz),
                  "v"(first_pre.nvz), "v"(first_pre.nuz));   // pinned above the solve, see gn_fca_fused
@@ -1786,20 +1702,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
     const int chunk = (V + nb_n - 1) / nb_n;
     begin = sub * chunk;
     end = min(V, begin + chunk);
-    T = seg_tiles(g);
-    __syncthreads();   // every cursor of the coarser level is done with the LDS copy (block-uniform branch)
-    seg_stage(s_seg, K.tile_pref, T);
-    __syncthreads();
-    ph0 = 0;
-    if (begin < end) {
-      const int i0 = min(begin + t, end - 1);
-      seg_seek(sc, (lds_pref)s_seg, T, i0);
-      ph0 = (unsigned)(i0 + sc.delta);
-    }
     if constexpr (FAST) {
-      if (begin < end) firstf = fcaf_load(K, ph0);
+      if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));   // (a thread past the chunk's end starts on a copy of its last record: the pixel loop is block-uniform)
     } else {
-      if (begin + t < end) first = fca_load(K, ph0);
+      if (begin + t < end) first = fca_load(K, (unsigned)(begin + t));
       first_pre = fca_prepare<DIVC>(g, first);
     }
   } else if (sub >= nb_l) {
@@ -1807,7 +1713,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
   }
   g_u8 cur = as_global(F->img);
   float sums[27];
-  fca_chunk_pass<DIVC, true, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, (lds_pref)s_seg, sc, ph0, sums);
+  fca_chunk_pass<DIVC, true, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
   block_reduce_store<27>(sums, out);
 }
@@ -1922,18 +1828,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
   const int end = min(V, begin + chunk);
   g_u8 cur = as_global(F.img);
   typename IcaInOf<FAST>::type first = ica_in_empty<FAST>();
-  // the level's tile prefix into LDS, then this thread's cursor on it (see gn_fca_fused)
-  extern __shared__ int s_seg_raw[];
-  ELLC_LDS int* s_seg = (ELLC_LDS int*)s_seg_raw;
-  const int T = seg_tiles(g);
-  seg_stage(s_seg, K.tile_pref, T);
-  __syncthreads();
-  SegCursor sc;
-  sc.t = 0; sc.hi = 0x7fffffff; sc.hi_next = 0x7fffffff; sc.delta = 0;
-  if (begin + t < end) {
-    seg_seek(sc, (lds_pref)s_seg, T, begin + t);
-    first = ica_load_any<FAST>(K, (unsigned)(begin + t + sc.delta));
-  }
+  if (begin + t < end) first = ica_load_any<FAST>(K, (unsigned)(begin + t));
   if (pending) {
     const float* hinv = a.kf_tab[fa.prev_level * a.max_kf + slot].hinv;
     solve_step<FAST>(sh, group_sum, 2, fa.prev_level, fa.early_exit, src, nullptr, hinv);
@@ -1965,7 +1860,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
   int i = begin + t;
   if (i < end) {
     ica_accumulate_pixel<FAST>(acc, first, g, cur, S);
-    for (i += ELLC_GN_THREADS; i < end; i += ELLC_GN_THREADS) ica_accumulate_pixel<FAST>(acc, ica_load_any<FAST>(K, seg_phys(sc, (lds_pref)s_seg, i)), g, cur, S);
+    for (i += ELLC_GN_THREADS; i < end; i += ELLC_GN_THREADS) ica_accumulate_pixel<FAST>(acc, ica_load_any<FAST>(K, (unsigned)i), g, cur, S);
   }
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
   block_reduce_store<6>(acc, out + 21);   // the b slots of the partial record; the H slots are not read by a mode-2 solve
@@ -2179,11 +2074,9 @@ __device__ inline void init_state_record(AlignState& st, const float* init_pose,
 __global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, int level, int max_kf, int fast_records) {
   const int b = blockIdx.y;
   const KfLevelDev& K = kf_tab[level * max_kf + kf_slot[b]];
+  const int V = *K.count;
   const int cols = geom[level].cols;
-  // every entry of every tile's segment (KfLevelDev): physical index i = tile * ELLC_TILE + rank, rank < the tile's count
-  const int np = seg_tiles(geom[level]) * ELLC_TILE;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
-    if ((i & (ELLC_TILE - 1)) >= K.tile_count[i / ELLC_TILE]) continue;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
     // saved weights exist in the FCA schedule only: its records carry the pixel position
     size_t p;
     if (fast_records) {
@@ -2207,10 +2100,9 @@ __global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf
   const int b = blockIdx.y, level = blockIdx.z;
   if (state[b].cur_level != -1) return;
   const KfLevelDev& K = kf_tab[level * max_kf + kf_slot[b]];
+  const int V = *K.count;
   const int cols = geom[level].cols;
-  const int np = seg_tiles(geom[level]) * ELLC_TILE;   // every entry of every tile's segment, see gn_add_saved_weights
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
-    if ((i & (ELLC_TILE - 1)) >= K.tile_count[i / ELLC_TILE]) continue;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
     size_t p;
     if (fast_records) {
       int x, y;

@@ -10,10 +10,8 @@ namespace ellc {
 
 // ---------------------------------------------------------------------------------------------------
 // Compaction of the keyframe's valid pixels (mask = depth_pyramid[l] > 0, Frame.cpp:295-301), raster
-// order preserved. ONE launch covers all levels of all listed keyframe slots: a block compacts its tile of ELLC_TILE pixels into
-// the tile's segment of the lists (KfLevelDev) and leaves the tile's count; the last block of a (slot, level) to arrive turns the
-// counts into the prefix the Gauss-Newton passes map their logical indices with. (r01-r03: a count launch that read every depth
-// plane a second time — 45 us of a launch group's 830 — so that the scatter could place a tile behind its predecessors.)
+// order preserved. Two launches (count per tile, then scatter) cover all levels of all listed keyframe slots.
+#define ELLC_TILE 2048          // pixels per block: 256 threads x 8 consecutive pixels (two float4 loads)
 
 struct PrepArgs {
   const LevelGeom* geom;
@@ -35,6 +33,18 @@ __device__ __forceinline__ int prep_level_of(const PrepArgs& a, int tile, int& l
   return l;
 }
 
+// eight consecutive depths of this thread (zeros past the end of the plane)
+__device__ __forceinline__ void prep_load8(const float* __restrict__ depth, int i0, int n, float (&d)[8]) {
+  if (i0 + 7 < n) {
+    const float4 a = *reinterpret_cast<const float4*>(depth + i0);
+    const float4 b = *reinterpret_cast<const float4*>(depth + i0 + 4);
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) d[j] = (i0 + j < n) ? depth[i0 + j] : 0.0f;
+  }
+}
+
 // inclusive scan inside a wave; returns the wave total through `total`
 __device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
   const int lane = threadIdx.x & 63;
@@ -45,6 +55,27 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
   }
   total = __shfl(v, 63, 64);
   return v;
+}
+
+__global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
+  int local;
+  const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
+  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const int n = a.geom[level].n;
+  const int i0 = local * ELLC_TILE + threadIdx.x * 8;
+  float d[8];
+  prep_load8(K.depth, i0, n, d);
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) c += (d[j] > 0.0f) ? 1 : 0;
+  __shared__ int ws[4];
+  int tot;
+  wave_inclusive_scan(c, tot);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    K.tile_count[local] = ws[0] + ws[1] + ws[2] + ws[3];
+  }
 }
 
 // Scatter, two phases per tile of ELLC_TILE pixels. Phase 1: thread t owns pixels base + j*256 + t (j = 0..7), so the
@@ -63,13 +94,22 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   const int base = local * ELLC_TILE + (int)threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ int cnt[33];   // [j][wave] exclusive offsets, [32] = tile total
+  __shared__ int before[4]; // per wave: valid pixels in the tiles of this level that precede this one
   __shared__ uint32_t s_idx[ELLC_TILE];
   __shared__ float s_Z[ELLC_TILE];
+  // the eight depth loads first, then the loads of the tile counts: both sets are in flight together (r03: a block's life is a
+  // chain of memory round trips of 2-3 us each under load — table entry, counts, depths, gathers, stores: 12 us for 2048 pixels)
   float d[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const int i = base + j * 256;
     d[j] = (i < n) ? gptr(K.depth)[(unsigned)i] : 0.0f;
+  }
+  {   // this tile's offset in the level's list = sum of the counts prep_count left for the tiles before it (at most a few hundred)
+    int part = 0, tot;
+    for (int i = (int)threadIdx.x; i < local; i += 256) part += gptr(K.tile_count)[(unsigned)i];
+    wave_inclusive_scan(part, tot);
+    if (lane == 0) before[wave] = tot;
   }
   unsigned long long m[8];
 #pragma unroll
@@ -96,7 +136,8 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   }
   __syncthreads();
   const int nvalid = cnt[32];
-  const unsigned tile_off = (unsigned)local * ELLC_TILE;   // the tile's segment of the lists
+  const unsigned tile_off = (unsigned)(before[0] + before[1] + before[2] + before[3]);
+  if (threadIdx.x == 0 && local == a.tile_begin[level + 1] - a.tile_begin[level] - 1) *K.count = (int)tile_off + nvalid;   // last tile: the level's total
   const float inv_cols = 1.0f / (float)g.cols;
   const ELLC_GLOBAL float* var = gptr(K.var);
   const ELLC_GLOBAL float* wgt = gptr(K.weight);
@@ -245,40 +286,6 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
     }
   }
   if (need & 4) block_reduce_store<27>(hacc, K.hpart + (size_t)local * ELLC_PART_STRIDE);   // block-uniform condition
-  // ---- the tile's count, and — by the last block of this (slot, level) to get here — the prefix of all counts
-  const int T = a.tile_begin[level + 1] - a.tile_begin[level];
-  __shared__ int s_last;
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(K.tile_count + local, nvalid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();   // the count before the ticket
-    s_last = (__hip_atomic_fetch_add(K.ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == T - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;   // block-uniform
-  __shared__ int s_wsum[4], s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  for (int t0 = 0; t0 < T; t0 += 256) {   // 256 counts per round: block-wide exclusive scan, carried over the rounds
-    const int tt = t0 + (int)threadIdx.x;
-    const int c = (tt < T) ? __hip_atomic_load(K.tile_count + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;   // (past this CU's L1)
-    int wtot;
-    const int inc = wave_inclusive_scan(c, wtot);
-    if (lane == 63) s_wsum[wave] = wtot;
-    __syncthreads();
-    int off = s_carry;
-    for (int w = 0; w < wave; w++) off += s_wsum[w];
-    if (tt < T) K.tile_pref[tt] = off + inc - c;
-    __syncthreads();
-    if (threadIdx.x == 255) s_carry = off + inc;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const int V = s_carry;
-    K.tile_pref[T] = V;
-    K.tile_pref[T + 1] = 0x7fffffff;
-    *K.count = V;
-    __hip_atomic_store(K.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next compaction of this slot and level
-  }
 }
 
 // ICA: H of one (keyframe slot, level) from the per-tile sums (fixed-order f64 combine), then cv::Mat::inv(DECOMP_LU)
