@@ -235,6 +235,7 @@ static ObsArgs observe_args(const ellc_ctx* c, int frame_slot) {
   a.mats = nullptr;
   a.gate = nullptr;
   a.list = c->obs_list;
+  a.list_ep = c->obs_list_ep;
   a.ctr = c->obs_ctr;
   {   // a region holds every pixel of the select blocks that append to it (block b -> region b mod DM_OBS_REGIONS)
     const int blocks = ((a.W + 31) / 32) * ((a.H + 7) / 8);
@@ -248,7 +249,7 @@ static ObsArgs observe_args(const ellc_ctx* c, int frame_slot) {
 static void launch_observe(ellc_ctx* c, const ObsArgs& a, bool dev) {
   const dim3 tiles((a.W + 31) / 32, (a.H + 7) / 8), blk(256);
   const int most = std::max(0, a.W - 6) * std::max(0, a.H - 6);
-  const dim3 walk(std::max(1, (most + 255) / 256));
+  const dim3 walk(std::max(1, (most + 255) / 256 + 1));   // a wave per chunk of 64 entries of one kind: at most two partial chunks more than most / 64
   if (dev) {
     hipLaunchKernelGGL(dm_observe_select<true>, tiles, blk, 0, c->stream, a);
     hipLaunchKernelGGL(dm_observe_walk<true>, walk, blk, 0, c->stream, a);

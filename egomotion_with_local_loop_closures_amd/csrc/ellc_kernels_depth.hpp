@@ -97,6 +97,34 @@ __device__ __forceinline__ float tap_plain_raw(const uint8_t* img, int sw, int c
   return v;
 }
 
+// raw_tap_load with the two loads issued by hand. The compiler's own wait-count insertion does not see through the walk's loop: it
+// waits for EVERYTHING in flight before a slot is used (s_waitcnt vmcnt(0) in every step, whatever the look-ahead), so the walk
+// keeps its own count: raw_tap_issue requests a slot, raw_tap_wait<N> waits until at most N younger requests are outstanding (vector
+// loads return in issue order) and ties the slot's registers to the wait, so that nothing reads them earlier. A slot that may
+// still be in flight when the walk ends is drained by raw_tap_wait<0> before its registers are reused.
+__device__ __forceinline__ void raw_tap_issue(RawTap& r, const uint8_t* img, int sw, int cols, int rows, float x, float y) {
+  const float fx0 = fminf(fmaxf(floorf(x), 1.0f), (float)(cols - 3)), fy0 = fminf(fmaxf(floorf(y), 1.0f), (float)(rows - 3));   // NaN -> 1
+  const unsigned ob = __umul24((unsigned)(int)fy0, (unsigned)sw) + (unsigned)(int)fx0 - 1u, oc = ob + (unsigned)sw;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(r.wb) : "v"(ob), "s"(img) : "memory");
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(r.wc) : "v"(oc), "s"(img) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void raw_tap_wait(RawTap& r) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.wb), "+v"(r.wc) : "n"(N));
+}
+
+// the tap at a position KNOWN to be interior (floor(x) in [1, cols - 3], floor(y) in [1, rows - 3]): tap_plain_raw's interior
+// expression without its test and its fallback — straight-line code
+__device__ __forceinline__ float tap_interior_raw(float x, float y, const RawTap& r) {
+  const float fx0 = floorf(x), fy0 = floorf(y);
+  const float wx = x - fx0, wy = y - fy0;
+  const float omx = 1.0f - wx, omy = 1.0f - wy;
+  const float Pbb = byte_f32<1>(r.wb), Pbc = byte_f32<2>(r.wb), Pcb = byte_f32<1>(r.wc), Pcc = byte_f32<2>(r.wc);
+  const float top = (omx * Pbb) + (wx * Pbc);
+  const float btm = (omx * Pcb) + (wx * Pcc);
+  return (omy * top) + (wy * btm);
+}
+
 // ------------------------------------------------------------------------------------------------
 // 5x5 / row-pair stencils over the hypothesis map. A block is DM_TX x DM_TY pixels; the four fields the stencils read
 // (invDepth, variance, validity, isValid) of the tile plus a halo of DM_HALO pixels are staged in LDS once — 25 (or up to
@@ -672,6 +700,7 @@ struct ObsArgs {
   const int* gate;              //   and nothing is done unless *gate != 0
   int* list;                    // work list of the two observe kernels: DM_OBS_REGIONS regions of region_cap pixel indices each,
   int region_cap;               //   a region filled with creations from its front and updates from its back
+  float2* list_ep;              //   beside every list entry: the epipolar direction makeAndCheckEPL gave its pixel (the walk does not compute it again)
   int* ctr;                     //   [2 r + kind] entries of region r, [2 DM_OBS_REGIONS] blocks of dm_observe_walk that have finished
 };
 
@@ -911,32 +940,39 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
   }
 
   float cpx = pFar[0], cpy = pFar[1];
-  // the taps of the next DM_OBS_AHEAD steps are in flight while a step is evaluated: (lx, ly) runs that many steps ahead of
-  // (cpx, cpy) through the walk's own recurrence (the same additions from the same start: the same positions, bit for bit)
-  constexpr int AHEAD = DM_OBS_AHEAD;
-  RawTap q[AHEAD];
+  // The walk (DepthPropagation.cpp:612-710), laid out for the wave instead of for one pixel (r04):
+  //  * the taps of the next four steps are in flight while a step is evaluated: (lx, ly) runs four steps ahead of (cpx, cpy) through
+  //    the walk's own recurrence (the same additions from the same start: the same positions, bit for bit), and the four tap slots are
+  //    NAMED — the loop body is four steps, step j consumes slot j and refills it — because a queue that shifts (q[d] = q[d + 1], r03)
+  //    compiles to register copies at the loop's back edge, and a copy of a slot waits for the load that has just been issued into
+  //    it: r03's look-ahead never was in flight across an iteration (s_waitcnt vmcnt(0) in every step);
+  //  * the loop is uniform over the wave: every lane steps until the last lane's segment ends (`alive` guards a lane's bookkeeping;
+  //    the refills are unconditional — a finished lane's look-ahead position is clamped into the image by raw_tap_load), so there
+  //    is no per-lane exit whose merges would bring the copies back;
+  //  * the reference alternates two sets of differences (e1A.. / e1B..) by the parity of its loop counter: with an even number of
+  //    steps in the body the parity is a step's position in it, not a run-time test.
   float lx = cpx, ly = cpy;
   const RawTap rc_m2 = raw_tap_load(a.curImg, a.sw, W, H, cpx - 2.0f * incx, cpy - 2.0f * incy);
   const RawTap rc_m1 = raw_tap_load(a.curImg, a.sw, W, H, cpx - incx, cpy - incy);
   const RawTap rc_0 = raw_tap_load(a.curImg, a.sw, W, H, cpx, cpy);
   const RawTap rc_p1 = raw_tap_load(a.curImg, a.sw, W, H, cpx + incx, cpy + incy);
-#pragma unroll
-  for (int d = 0; d < AHEAD; d++) {
-    q[d] = raw_tap_load(a.curImg, a.sw, W, H, lx + 2 * incx, ly + 2 * incy);
-    lx += incx; ly += incy;
-  }
+  RawTap q0, q1, q2, q3;   // requested by hand, see raw_tap_issue: every use is behind a raw_tap_wait
+  raw_tap_issue(q0, a.curImg, a.sw, W, H, lx + 2 * incx, ly + 2 * incy); lx += incx; ly += incy;
+  raw_tap_issue(q1, a.curImg, a.sw, W, H, lx + 2 * incx, ly + 2 * incy); lx += incx; ly += incy;
+  raw_tap_issue(q2, a.curImg, a.sw, W, H, lx + 2 * incx, ly + 2 * incy); lx += incx; ly += incy;
+  raw_tap_issue(q3, a.curImg, a.sw, W, H, lx + 2 * incx, ly + 2 * incy); lx += incx; ly += incy;
   const float realVal_p1 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_p1, ky_p1, rk_p1);
   const float realVal_m1 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_m1, ky_m1, rk_m1);
   const float realVal = tap_plain_raw(a.kfImg, a.sw, W, H, u, v, rk_0);
   const float realVal_m2 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_m2, ky_m2, rk_m2);
   const float realVal_p2 = tap_plain_raw(a.kfImg, a.sw, W, H, kx_p2, ky_p2, rk_p2);
-  float val_cp_m2 = tap_plain_raw(a.curImg, a.sw, W, H, cpx - 2.0f * incx, cpy - 2.0f * incy, rc_m2);
-  float val_cp_m1 = tap_plain_raw(a.curImg, a.sw, W, H, cpx - incx, cpy - incy, rc_m1);
-  float val_cp = tap_plain_raw(a.curImg, a.sw, W, H, cpx, cpy, rc_0);
-  float val_cp_p1 = tap_plain_raw(a.curImg, a.sw, W, H, cpx + incx, cpy + incy, rc_p1);
-  float val_cp_p2;
+  // (the walk's first four taps: interior without a test, as the walk's own, see walk_step)
+  float val_cp_m2 = tap_interior_raw(cpx - 2.0f * incx, cpy - 2.0f * incy, rc_m2);
+  float val_cp_m1 = tap_interior_raw(cpx - incx, cpy - incy, rc_m1);
+  float val_cp = tap_interior_raw(cpx, cpy, rc_0);
+  float val_cp_p1 = tap_interior_raw(cpx + incx, cpy + incy, rc_p1);
 
-  int loopCounter = 0;
+  int loopCounter = 0;   // the same in every lane that is still walking
   float best_match_x = -1, best_match_y = -1;
   float best_match_err = __builtin_inff(), second_best_match_err = __builtin_inff();   // float = 1e50
   float best_match_errPre = NaNf, best_match_errPost = NaNf, best_match_DiffErrPre = NaNf, best_match_DiffErrPost = NaNf;
@@ -946,55 +982,71 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
   int loopCBest = -1, loopCSecond = -1;
   // the walk is bounded: the segment is at most MAX_EPL_LENGTH_CROP + padding long and inside the image
   const int loopCap = W + H;
-  while ((((incx < 0) == (cpx > pClose[0]) && (incy < 0) == (cpy > pClose[1])) || loopCounter == 0) && loopCounter < loopCap) {
-    val_cp_p2 = tap_plain_raw(a.curImg, a.sw, W, H, cpx + 2 * incx, cpy + 2 * incy, q[0]);
-#pragma unroll
-    for (int d = 0; d + 1 < AHEAD; d++) q[d] = q[d + 1];
-    q[AHEAD - 1] = raw_tap_load(a.curImg, a.sw, W, H, lx + 2 * incx, ly + 2 * incy);
+  bool alive = true;
+  // one step of the walk; PAR_A: an even value of the reference's loop counter. Returns false when no lane of the wave walks on.
+  auto walk_step = [&](RawTap& slot, const bool PAR_A) -> bool {
+    alive = alive && ((((incx < 0) == (cpx > pClose[0]) && (incy < 0) == (cpy > pClose[1])) || loopCounter == 0) && loopCounter < loopCap);
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return false;
+    float val_cp_p2 = 0.0f;
+    raw_tap_wait<6>(slot);   // the slot's two loads are followed by the six of the three younger slots
+    // (interior without a test: both ends of the segment lie more than SAMPLE_POINT_TO_BORDER = 7 pixels inside the image, a walking
+    // lane's position has not passed the far end by a whole step, and the tap sits two steps ahead of it: more than 4 pixels inside)
+    if (alive) val_cp_p2 = tap_interior_raw(cpx + 2 * incx, cpy + 2 * incy, slot);
+    raw_tap_issue(slot, a.curImg, a.sw, W, H, lx + 2 * incx, ly + 2 * incy);   // refilled behind its use, for the step four on
     lx += incx; ly += incy;
-    float ee = 0;
-    if (loopCounter % 2 == 0) {
-      e1A = val_cp_p2 - realVal_p2; ee += e1A * e1A;
-      e2A = val_cp_p1 - realVal_p1; ee += e2A * e2A;
-      e3A = val_cp - realVal;       ee += e3A * e3A;
-      e4A = val_cp_m1 - realVal_m1; ee += e4A * e4A;
-      e5A = val_cp_m2 - realVal_m2; ee += e5A * e5A;
-    } else {
-      e1B = val_cp_p2 - realVal_p2; ee += e1B * e1B;
-      e2B = val_cp_p1 - realVal_p1; ee += e2B * e2B;
-      e3B = val_cp - realVal;       ee += e3B * e3B;
-      e4B = val_cp_m1 - realVal_m1; ee += e4B * e4B;
-      e5B = val_cp_m2 - realVal_m2; ee += e5B * e5B;
-    }
-    if (ee < best_match_err) {
-      second_best_match_err = best_match_err;
-      loopCSecond = loopCBest;
-      best_match_err = ee;
-      loopCBest = loopCounter;
-      best_match_errPre = eeLast;
-      best_match_DiffErrPre = e1A * e1B + e2A * e2B + e3A * e3B + e4A * e4B + e5A * e5B;
-      best_match_errPost = -1;
-      best_match_DiffErrPost = -1;
-      best_match_x = cpx;
-      best_match_y = cpy;
-      bestWasLastLoop = true;
-    } else {
-      if (bestWasLastLoop) {
-        best_match_errPost = ee;
-        best_match_DiffErrPost = e1A * e1B + e2A * e2B + e3A * e3B + e4A * e4B + e5A * e5B;
-        bestWasLastLoop = false;
+    if (alive) {
+      float ee = 0;
+      if (PAR_A) {
+        e1A = val_cp_p2 - realVal_p2; ee += e1A * e1A;
+        e2A = val_cp_p1 - realVal_p1; ee += e2A * e2A;
+        e3A = val_cp - realVal;       ee += e3A * e3A;
+        e4A = val_cp_m1 - realVal_m1; ee += e4A * e4A;
+        e5A = val_cp_m2 - realVal_m2; ee += e5A * e5A;
+      } else {
+        e1B = val_cp_p2 - realVal_p2; ee += e1B * e1B;
+        e2B = val_cp_p1 - realVal_p1; ee += e2B * e2B;
+        e3B = val_cp - realVal;       ee += e3B * e3B;
+        e4B = val_cp_m1 - realVal_m1; ee += e4B * e4B;
+        e5B = val_cp_m2 - realVal_m2; ee += e5B * e5B;
       }
-      if (ee < second_best_match_err) {
-        second_best_match_err = ee;
-        loopCSecond = loopCounter;
+      if (ee < best_match_err) {
+        second_best_match_err = best_match_err;
+        loopCSecond = loopCBest;
+        best_match_err = ee;
+        loopCBest = loopCounter;
+        best_match_errPre = eeLast;
+        best_match_DiffErrPre = e1A * e1B + e2A * e2B + e3A * e3B + e4A * e4B + e5A * e5B;
+        best_match_errPost = -1;
+        best_match_DiffErrPost = -1;
+        best_match_x = cpx;
+        best_match_y = cpy;
+        bestWasLastLoop = true;
+      } else {
+        if (bestWasLastLoop) {
+          best_match_errPost = ee;
+          best_match_DiffErrPost = e1A * e1B + e2A * e2B + e3A * e3B + e4A * e4B + e5A * e5B;
+          bestWasLastLoop = false;
+        }
+        if (ee < second_best_match_err) {
+          second_best_match_err = ee;
+          loopCSecond = loopCounter;
+        }
       }
+      eeLast = ee;
+      val_cp_m2 = val_cp_m1; val_cp_m1 = val_cp; val_cp = val_cp_p1; val_cp_p1 = val_cp_p2;
+      cpx += incx;
+      cpy += incy;
     }
-    eeLast = ee;
-    val_cp_m2 = val_cp_m1; val_cp_m1 = val_cp; val_cp = val_cp_p1; val_cp_p1 = val_cp_p2;
-    cpx += incx;
-    cpy += incy;
     loopCounter++;
+    return true;
+  };
+  for (;;) {
+    if (!walk_step(q0, true)) break;
+    if (!walk_step(q1, false)) break;
+    if (!walk_step(q2, true)) break;
+    if (!walk_step(q3, false)) break;
   }
+  raw_tap_wait<0>(q0); raw_tap_wait<0>(q1); raw_tap_wait<0>(q2); raw_tap_wait<0>(q3);   // nothing of the walk is in flight beyond this point
   if (best_match_err > 4.0f * DM_MAX_ERROR_STEREO) return -3.0f;
   {
     int dl = loopCBest - loopCSecond;
@@ -1166,13 +1218,13 @@ __global__ __launch_bounds__(256) void dm_observe_select(ObsArgs a) {
   const int lane = threadIdx.x & 63;
   const int idx = x + y * a.W;
   int kind = -1;   // 0: creation, 1: update
+  float epx = 0.0f, epy = 0.0f;
   if (x >= 3 && x < a.W - 3 && y >= 3 && y < a.H - 3) {
     const bool hasHypothesis = a.s.isValid[idx] != 0;
     const float mg = a.kfMaxGrad[idx];
     if (hasHypothesis && mg < DM_MIN_ABS_GRAD_DECREASE) {
       a.s.isValid[idx] = 0;
     } else if (!(mg < DM_MIN_ABS_GRAD_CREATE || a.s.blacklisted[idx] < DM_MIN_BLACKLIST)) {
-      float epx, epy;
       if (make_and_check_epl(a, x, y, epx, epy)) kind = hasHypothesis ? 1 : 0;   // (else create: -1 / update: -5, no state change)
     }
   }
@@ -1196,8 +1248,11 @@ __global__ __launch_bounds__(256) void dm_observe_select(ObsArgs a) {
   if (kind >= 0) {
     int pos = base[kind] + __popcll(mine & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
     for (int w = 0; w < wave; w++) pos += cnt[kind][w];
-    int* rlist = a.list + (size_t)region * a.region_cap;
-    if (pos < a.region_cap) rlist[kind == 0 ? pos : a.region_cap - 1 - pos] = idx;
+    if (pos < a.region_cap) {
+      const size_t e = (size_t)region * a.region_cap + (size_t)(kind == 0 ? pos : a.region_cap - 1 - pos);
+      a.list[e] = x | (y << 16);               // (W, H < 65536)
+      a.list_ep[e] = make_float2(epx, epy);
+    }
   }
 }
 
@@ -1226,20 +1281,27 @@ __global__ __launch_bounds__(256) void dm_observe_walk(ObsArgs a) {
   }
   __syncthreads();
   const int C = pre[0][DM_OBS_REGIONS], U = pre[1][DM_OBS_REGIONS];
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k < C + U) {
-    const int kind = (k < C) ? 0 : 1;
-    const int kk = kind ? k - C : k;
-    int lo = 0;   // the region r with pre[r] <= kk < pre[r + 1]
+  // A wave takes one chunk of 64 entries of ONE kind; the creation chunks first. (r04 measured the update chunks spread evenly among
+  // the creation chunks, so that every CU gets the same mix: 33.7 against 32.2 us — the launch is bound by its instructions, not by
+  // which SIMD draws which waves.)
+  const int nC = (C + 63) >> 6, nU = (U + 63) >> 6, nchunks = nC + nU;
+  const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  const int j = (int)blockIdx.x * 4 + wave;
+  if (j < nchunks) {
+    const int kind = (j < nC) ? 0 : 1;
+    const int kk = (kind ? j - nC : j) * 64 + lane;
+    if (kk < (kind ? U : C)) {
+      int lo = 0;   // the region r with pre[r] <= kk < pre[r + 1]
 #pragma unroll
-    for (int step = DM_OBS_REGIONS / 2; step >= 1; step >>= 1)
-      if (pre[kind][lo + step] <= kk) lo += step;
-    const int off = kk - pre[kind][lo];
-    const int* rlist = a.list + (size_t)lo * a.region_cap;
-    const int idx = kind ? rlist[a.region_cap - 1 - off] : rlist[off];
-    const int y = idx / a.W, x = idx - y * a.W;
-    float epx, epy;
-    if (make_and_check_epl(a, x, y, epx, epy)) observe_pixel(a, x, y, idx, epx, epy);   // (true again: it put the pixel on the list)
+      for (int step = DM_OBS_REGIONS / 2; step >= 1; step >>= 1)
+        if (pre[kind][lo + step] <= kk) lo += step;
+      const int off = kk - pre[kind][lo];
+      const size_t e = (size_t)lo * a.region_cap + (size_t)(kind ? a.region_cap - 1 - off : off);
+      const int xy = a.list[e];
+      const float2 ep = a.list_ep[e];
+      const int x = xy & 0xffff, y = xy >> 16;
+      observe_pixel(a, x, y, x + y * a.W, ep.x, ep.y);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
