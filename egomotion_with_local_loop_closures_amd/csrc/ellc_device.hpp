@@ -26,15 +26,17 @@ struct LevelGeom {
   const float* rowB;          // -((fx*v)/fy)             [rows]
 };
 
-// One valid (depth > 0) keyframe pixel as the FCA pixel pass reads it: 32 bytes, written by prep_scatter. Besides the
-// inputs it carries the two pose-independent results that are IEEE divisions in the reference, computed once per
-// keyframe update instead of once per pixel and iteration: the back-projection X = ((x - cx) Z) / fx, Y likewise
-// (PixelWisePyramid.cpp:236-240) and invZ = 1.0 / (double)Z, the reference's pow(depth, -1) (:296).
-struct __attribute__((aligned(16))) FcaRec {
-  uint32_t xy;                // y<<16 | x
-  float Z, var, Ikf;          // depth, variance, keyframe intensity (as f32)
-  float X, Y;
-  double invZ;
+// One valid (depth > 0) keyframe pixel as the exact FCA pixel pass reads it: 20 bytes, written by prep_scatter (r04; 32 bytes
+// before, and the dense 1280x960 launch moved 2.09 x its algorithmic bytes at the box's HBM ceiling). Position and keyframe
+// intensity share one word (x: bits 0-11, y: bits 12-23, intensity: bits 24-31: width, height <= 4096); Z, the variance, and
+// invZ = 1.0 / (double)Z, the reference's pow(depth, -1) (:296) — an IEEE f64 division computed once per keyframe update instead of
+// once per pixel and iteration. The back-projection X = ((x - cx) Z) / fx, Y likewise (PixelWisePyramid.cpp:236-240) is formed
+// again per pixel: with the level's verified division-by-constant (div_const) it costs three instructions a coordinate and gives
+// the correctly rounded quotient, the bits `/` gives.
+struct __attribute__((packed, aligned(4))) FcaRec {
+  uint32_t xyI;
+  float Z, var;
+  uint32_t invZ_lo, invZ_hi;   // the f64 as two words (the record is 4-byte aligned)
 };
 
 // The same pixel as the tolerance-mode FCA pass reads it (cfg.arith = ELLC_ARITH_FAST): 16 bytes. The first word is the row y AS

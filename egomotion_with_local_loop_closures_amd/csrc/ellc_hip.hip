@@ -747,7 +747,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   // converts a pixel index to f32 exactly: planes of at most 2^24 pixels
   if ((long long)cfg->width * cfg->height > (1ll << 24)) return ELLC_ERR_BAD_ARG;
   if (cfg->arith != ELLC_ARITH_EXACT && cfg->arith != ELLC_ARITH_FAST) return ELLC_ERR_BAD_ARG;
-  if (cfg->arith == ELLC_ARITH_FAST && (cfg->width > 4096 || cfg->height > 4096)) return ELLC_ERR_BAD_ARG;   // 12-bit x / y in FcaRecF
+  if (cfg->width > 4096 || cfg->height > 4096) return ELLC_ERR_BAD_ARG;   // 12-bit x / y in the compact records (FcaRec, FcaRecF)
   if (cfg->levels < 1 || cfg->levels > ELLC_MAX_LEVELS) return ELLC_ERR_BAD_ARG;
   if ((cfg->width >> (cfg->levels - 1)) < 4 || (cfg->height >> (cfg->levels - 1)) < 4) return ELLC_ERR_BAD_ARG;
   if (cfg->max_keyframes < 1 || cfg->max_frames < 1 || cfg->max_batch < 1) return ELLC_ERR_BAD_ARG;

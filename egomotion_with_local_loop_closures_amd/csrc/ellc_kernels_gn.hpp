@@ -510,13 +510,33 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float* __re
 // One pixel of the FCA pass (PixelWisePyramid.cpp:236-361): J, residual, weight.
 struct FcaPix { float J[6]; float residual, wgt; };
 
-typedef FcaRec FcaIn;   // one entry of the keyframe's compact pixel list
+// one entry of the keyframe's compact pixel list as the exact pass works on it (FcaRec, with the back-projection formed again)
+struct FcaIn { uint32_t xy; float Z, var, Ikf, X, Y; double invZ; };   // xy: y << 16 | x
 
-__device__ __forceinline__ FcaIn fca_load(const KfLevelDev& K, unsigned i) {
-  // uniform base + 32-bit byte offset (24 * i < 2^32 for any image this library accepts): SGPR-base addressing
-  const ELLC_GLOBAL FcaRec* r = (const ELLC_GLOBAL FcaRec*)((const ELLC_GLOBAL char*)K.crec + i * (unsigned)sizeof(FcaRec));
+template <bool DIVC>
+__device__ __forceinline__ FcaIn fca_load(const KfLevelDev& K, const LevelGeom& g, unsigned i) {
+  // uniform base + 32-bit byte offset (20 * i < 2^32 for any image this library accepts): SGPR-base addressing; 16 + 4 bytes
+  typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+  const ELLC_GLOBAL char* r = (const ELLC_GLOBAL char*)K.crec + i * (unsigned)sizeof(FcaRec);
+  const u32x4a v = *(const ELLC_GLOBAL u32x4a*)r;
+  const uint32_t hi = *(const ELLC_GLOBAL uint32_t*)(r + 16);
+  const uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;   // (copied to scalars first: bit_cast of a vector element expression reads element 0)
   FcaIn in;
-  in.xy = r->xy; in.Z = r->Z; in.var = r->var; in.Ikf = r->Ikf; in.X = r->X; in.Y = r->Y; in.invZ = r->invZ;
+  const int x = (int)(w0 & 0xfffu), y = (int)((w0 >> 12) & 0xfffu);
+  in.xy = ((uint32_t)y << 16) | (uint32_t)x;
+  in.Ikf = byte_f32<3>(w0);
+  in.Z = __builtin_bit_cast(float, w1);
+  in.var = __builtin_bit_cast(float, w2);
+  in.invZ = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)w3);
+  // PixelWisePyramid.cpp:236-240, the expressions prep_scatter used to store: ((x - cx) Z) / fx
+  const float aX = ((float)x - g.cx) * in.Z, aY = ((float)y - g.cy) * in.Z;
+  in.X = DIVC ? div_const(aX, g.fx, g.rfx) : aX / g.fx;
+  in.Y = DIVC ? div_const(aY, g.fy, g.rfy) : aY / g.fy;
+  return in;
+}
+__device__ __forceinline__ FcaIn fca_in_empty() {
+  FcaIn in;
+  in.xy = 0; in.Z = 1.0f; in.var = 0.0f; in.Ikf = 0.0f; in.X = 0.0f; in.Y = 0.0f; in.invZ = 1.0;
   return in;
 }
 
@@ -602,7 +622,7 @@ __device__ __forceinline__ FcaPix fca_pixel_in(const GnArgs& a, const KfLevelDev
 template <bool DEBUG, bool DIVC>
 __device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur,
                                             const float* S, unsigned i) {
-  return fca_pixel_in<DEBUG, DIVC>(a, K, g, cur, S, i, fca_load(K, i));
+  return fca_pixel_in<DEBUG, DIVC>(a, K, g, cur, S, i, fca_load<DIVC>(K, g, i));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1455,13 +1475,13 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
       FcaIn r0 = first, r1 = first;
       {
         const int i1 = i + stride;
-        auto prefetch = [&]() { r1 = fca_load(K, (unsigned)min(i1, end - 1)); };
+        auto prefetch = [&]() { r1 = fca_load<DIVC>(K, g, (unsigned)min(i1, end - 1)); };
         fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre, prefetch));
         i += stride;
       }
       auto step = [&](const FcaIn& in, FcaIn& fill) {
         const int i1 = i + stride;
-        auto prefetch = [&]() { fill = fca_load(K, (unsigned)min(i1, end - 1)); };
+        auto prefetch = [&]() { fill = fca_load<DIVC>(K, g, (unsigned)min(i1, end - 1)); };
         fca_accumulate_pixel(acc, fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, in, prefetch));
         i += stride;
       };
@@ -1542,15 +1562,14 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   }
   g_u8 cur = as_global(F.img);
   // this thread's first compact pixel, requested before the solve (exact mode: together with its pose-independent products)
-  FcaIn first;
-  first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.X = 0.0f; first.Y = 0.0f; first.invZ = 1.0;
+  FcaIn first = fca_in_empty();
   FcaInF firstf = fcaf_empty();
   FcaPre first_pre;
   if constexpr (FAST) {
     if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));   // (a thread past the chunk's end starts on a copy of its last record: the pixel loop is block-uniform)
   } else {
     if (begin + t < end) {
-      first = fca_load(K, (unsigned)(begin + t));
+      first = fca_load<DIVC>(K, g, (unsigned)(begin + t));
     }
     first_pre = fca_prepare<DIVC>(g, first);
     // pin the arithmetic here (the compiler would otherwise sink it below the solve, onto the critical path)
@@ -1656,14 +1675,13 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
     end = min(V, begin + chunk);
   }
   // this thread's first record (exact mode: and its pose-independent products), requested before the solve
-  FcaIn first;
-  first.xy = 0; first.Z = 1.0f; first.var = 0.0f; first.Ikf = 0.0f; first.X = 0.0f; first.Y = 0.0f; first.invZ = 1.0;
+  FcaIn first = fca_in_empty();
   FcaInF firstf = fcaf_empty();
   FcaPre first_pre;
   if constexpr (FAST) {
     if (sub < nb_l && begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));
   } else {
-    if (sub < nb_l && begin + t < end) first = fca_load(K, (unsigned)(begin + t));
+    if (sub < nb_l && begin + t < end) first = fca_load<DIVC>(K, g, (unsigned)(begin + t));
     first_pre = fca_prepare<DIVC>(g, first);
     asm volatile("" ::"v"(first_pre.c_t0), "v"(first_pre.c_b1), "v"(first_pre.d), "v"(first_pre.fxz), "v"(first_pre.fyz),
                  "v"(first_pre.nvz), "v"(first_pre.nuz));   // pinned above the solve, see gn_fca_fused
@@ -1705,7 +1723,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
     if constexpr (FAST) {
       if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));   // (a thread past the chunk's end starts on a copy of its last record: the pixel loop is block-uniform)
     } else {
-      if (begin + t < end) first = fca_load(K, (unsigned)(begin + t));
+      if (begin + t < end) first = fca_load<DIVC>(K, g, (unsigned)(begin + t));
       first_pre = fca_prepare<DIVC>(g, first);
     }
   } else if (sub >= nb_l) {
@@ -2084,8 +2102,8 @@ __global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slo
       fcaf_position(((const FcaRecF*)K.crec)[i], geom[level], x, y);
       p = (size_t)y * cols + x;
     } else {
-      const uint32_t xy = K.crec[i].xy;
-      p = (size_t)(xy >> 16) * cols + (xy & 0xffffu);
+      const uint32_t xyI = K.crec[i].xyI;
+      p = (size_t)((xyI >> 12) & 0xfffu) * cols + (xyI & 0xfffu);
     }
     K.weight[p] = K.weight[p] + K.wlast[i];
   }
@@ -2109,8 +2127,8 @@ __global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf
       fcaf_position(((const FcaRecF*)K.crec)[i], geom[level], x, y);
       p = (size_t)y * cols + x;
     } else {
-      const uint32_t xy = K.crec[i].xy;
-      p = (size_t)(xy >> 16) * cols + (xy & 0xffffu);
+      const uint32_t xyI = K.crec[i].xyI;
+      p = (size_t)((xyI >> 12) & 0xfffu) * cols + (xyI & 0xfffu);
     }
     K.weight[p] = K.weight[p] + K.wlast[i];
   }

@@ -196,17 +196,14 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
           const float dd = __builtin_amdgcn_rcpf(Z);
           const float pn = ((float)x - g.cx) * g.rfx;   // u / fx (fcaf_pixel forms v / fy from y)
           crec[pos] = (u32x4){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, vv[k]), __builtin_bit_cast(uint32_t, dd)};
-        } else {   // one 32-byte record per pixel (FcaRec), stored as two 16-byte words
-          const uint32_t xy = ((uint32_t)y << 16) | (uint32_t)x;
-          const float Ikf = (float)Ib[k];
-          const float X = (((float)x - cx) * Z) / fx;
-          const float Y = (((float)y - cy) * Z) / fy;
+        } else {   // one 20-byte record per pixel (FcaRec): a 16-byte word and a 4-byte word
+          const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)Ib[k] << 24);
           const double invZ = 1.0 / (double)Z;
           const unsigned long long zb = __builtin_bit_cast(unsigned long long, invZ);
-          const u32x4 lo = {xy, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, vv[k]), __builtin_bit_cast(uint32_t, Ikf)};
-          const u32x4 hi = {__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), (uint32_t)zb, (uint32_t)(zb >> 32)};
-          crec[2u * pos] = lo;
-          crec[2u * pos + 1u] = hi;
+          ELLC_GLOBAL char* r = (ELLC_GLOBAL char*)K.crec + pos * (unsigned)sizeof(FcaRec);
+          typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+          *(ELLC_GLOBAL u32x4a*)r = (u32x4a){xyI, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, vv[k]), (uint32_t)zb};
+          *(ELLC_GLOBAL uint32_t*)(r + 16) = (uint32_t)(zb >> 32);
         }
       }
     }
@@ -266,15 +263,14 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
       const float pn = ((float)x - g.cx) * g.rfx;   // u / fx (fcaf_pixel forms v / fy from y)
       crec[pos] = (u32x4){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, d)};
     }
-    if (need & 2) {   // FCA reads one 32-byte record per pixel (FcaRec), stored as two 16-byte words
-      const float X = (((float)x - cx) * Z) / fx;
-      const float Y = (((float)y - cy) * Z) / fy;
+    if (need & 2) {   // FCA reads one 20-byte record per pixel (FcaRec)
+      const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)img[(unsigned)(y * sw + x)] << 24);
       const double invZ = 1.0 / (double)Z;
       const unsigned long long zb = __builtin_bit_cast(unsigned long long, invZ);
-      const u32x4 lo = {xy, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, Ikf)};
-      const u32x4 hi = {__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), (uint32_t)zb, (uint32_t)(zb >> 32)};
-      crec[2u * pos] = lo;
-      crec[2u * pos + 1u] = hi;
+      ELLC_GLOBAL char* r = (ELLC_GLOBAL char*)K.crec + pos * (unsigned)sizeof(FcaRec);
+      typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+      *(ELLC_GLOBAL u32x4a*)r = (u32x4a){xyI, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, var[(unsigned)i]), (uint32_t)zb};
+      *(ELLC_GLOBAL uint32_t*)(r + 16) = (uint32_t)(zb >> 32);
     }
     }
     if ((NEED & 4) && !(NEED & 16)) {
