@@ -643,7 +643,7 @@ def depth_kernels(api, synth, dev_index):
         gbps = bpp * n / (ms * 1e-3) / 1e9
         rec["kernels"][name] = {"us_per_call": 1e3 * ms, "algorithmic_bytes_per_px": bpp, "algorithmic_bytes": bpp * n, "achieved_GBps": gbps,
                                 "frac_of_hbm_peak": gbps / PEAK_GBPS, "bound": bound}
-    # createKeyFrame: propagate (collision rounds with a host check every four) + regularise x2 + fill + rescale + export: wall time
+    # createKeyFrame: propagate (bucket + per-target fold) + regularise x2 + fill + rescale + export: eight launches, ONE host wait: wall time
     reps = 10
     tot = 0.0
     for _ in range(reps):
@@ -655,7 +655,7 @@ def depth_kernels(api, synth, dev_index):
     rec["create_keyframe"] = {"us_per_call_wall": 1e6 * tot / reps, "algorithmic_bytes": (61.0 + 3 * 50.0 + 9.0 + 12.0 + 8.0 / 3.0) * n,
                               "achieved_GBps": (61.0 + 3 * 50.0 + 9.0 + 12.0 + 8.0 / 3.0) * n / (tot / reps) / 1e9,
                               "note": "propagate 61 B/px + regularise, fill, regularise 50 B/px each + export; latency-bound at this size "
-                                      "(15 MB of state, launch chain with host-checked collision rounds)"}
+                                      "(15 MB of state; a chain of eight launches with one host wait, for the rescale factor it returns)"}
     ctx.close()
     return rec
 

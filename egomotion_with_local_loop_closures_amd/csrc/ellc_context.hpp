@@ -180,6 +180,7 @@ struct ellc_ctx {
   bool done_deferred = false;   // launch_group left the group's `done` event to its caller (ellc_track_frame records it behind the depth stages)
   bool track_call = false;   // the alignment being enqueued belongs to ellc_track_frame (set_track_fields)
   int* seed_acc = nullptr;   // dm_count_valid_block: sum and arrival ticket (zero between calls)
+  int obs_parity = 0;              // which of the two counter sets the next observation uses
   float2* obs_list_ep = nullptr;   // the epipolar direction of every list entry
   int *obs_list = nullptr, *obs_ctr = nullptr;   // work list of dm_observe_select / dm_observe_walk and its counters (zero between calls)
   int* track_h = nullptr;

@@ -236,7 +236,8 @@ static ObsArgs observe_args(const ellc_ctx* c, int frame_slot) {
   a.gate = nullptr;
   a.list = c->obs_list;
   a.list_ep = c->obs_list_ep;
-  a.ctr = c->obs_ctr;
+  a.ctr = c->obs_ctr + (c->obs_parity ? 2 * DM_OBS_REGIONS : 0);          // this call's counters ...
+  a.ctr_next = c->obs_ctr + (c->obs_parity ? 0 : 2 * DM_OBS_REGIONS);     // ... and the next call's (launch_observe alternates)
   {   // a region holds every pixel of the select blocks that append to it (block b -> region b mod DM_OBS_REGIONS)
     const int blocks = ((a.W + 31) / 32) * ((a.H + 7) / 8);
     a.region_cap = ((blocks + DM_OBS_REGIONS - 1) / DM_OBS_REGIONS) * 256;
@@ -247,6 +248,7 @@ static ObsArgs observe_args(const ellc_ctx* c, int frame_slot) {
 // observeDepthRow: candidate selection (a 32 x 8 tile per block), then the line stereo over the work list — a grid for the most
 // candidates there can be, the blocks past the list's end leave at once
 static void launch_observe(ellc_ctx* c, const ObsArgs& a, bool dev) {
+  c->obs_parity ^= 1;   // (observe_args built `a` for the set this call uses; the next call takes the other)
   const dim3 tiles((a.W + 31) / 32, (a.H + 7) / 8), blk(256);
   const int most = std::max(0, a.W - 6) * std::max(0, a.H - 6);
   const dim3 walk(std::max(1, (most + 255) / 256 + 1));   // a wave per chunk of 64 entries of one kind: at most two partial chunks more than most / 64

@@ -910,7 +910,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     const size_t blocks = (size_t)((cfg->width + 31) / 32) * ((cfg->height + 7) / 8);
     TRY(dev_alloc(c, &c->obs_list, ((blocks + DM_OBS_REGIONS - 1) / DM_OBS_REGIONS) * 256 * DM_OBS_REGIONS));
     TRY(dev_alloc(c, &c->obs_list_ep, ((blocks + DM_OBS_REGIONS - 1) / DM_OBS_REGIONS) * 256 * DM_OBS_REGIONS));
-    TRY(dev_alloc(c, &c->obs_ctr, 2 * DM_OBS_REGIONS + 1));
+    TRY(dev_alloc(c, &c->obs_ctr, 4 * DM_OBS_REGIONS));   // two sets of counters, alternating from call to call (zeroed by the arena)
   }
   // K and Kinv (EigenInitialization.cpp:20-34): cv 3x3 f32 inverse = f32 cofactors scaled by 1/det in double
   {

@@ -701,7 +701,8 @@ struct ObsArgs {
   int* list;                    // work list of the two observe kernels: DM_OBS_REGIONS regions of region_cap pixel indices each,
   int region_cap;               //   a region filled with creations from its front and updates from its back
   float2* list_ep;              //   beside every list entry: the epipolar direction makeAndCheckEPL gave its pixel (the walk does not compute it again)
-  int* ctr;                     //   [2 r + kind] entries of region r, [2 DM_OBS_REGIONS] blocks of dm_observe_walk that have finished
+  int* ctr;                     //   [2 r + kind] entries of region r: this call's counters (zero when dm_observe_select starts)
+  int* ctr_next;                //   the next call's counters: dm_observe_walk leaves them zero (the two sets alternate from call to call)
 };
 
 // The matrices of frame::calculateSE3poseOtherWrtThis (Frame.cpp:376-413) that observeDepthRow uses, for a frame whose
@@ -1205,9 +1206,9 @@ __device__ __forceinline__ void obs_load_mats(ObsArgs& b) {
 // creations from the region's front, updates from its back (a region holds every pixel of its blocks: the ends never meet).
 // (One list with one pair of counters and an atomic per wave: 9 600 atomics on two words serialise, the select launch took 98 us;
 // 64 regions: 24 us; with the waves' counts combined in LDS, one atomic per block and kind.) A walk block scans
-// the 2 x 64 counters in LDS and finds an entry's region by bisection. The counters are zero between calls: the last block of
-// dm_observe_walk to finish clears them (every block has read them by then). DEV: the tracked-frame call — nothing is done
-// while the gate is closed.
+// the 2 x 64 counters in LDS and finds an entry's region by bisection. Two sets of counters alternate from call to call: a call's
+// set is zero when its select launch starts, because the walk launch of the call before cleared it (ObsArgs::ctr_next). DEV: the
+// tracked-frame call — nothing else is done while the gate is closed.
 template <bool DEV>
 __global__ __launch_bounds__(256) void dm_observe_select(ObsArgs a) {
   if (DEV) {
@@ -1258,6 +1259,10 @@ __global__ __launch_bounds__(256) void dm_observe_select(ObsArgs a) {
 
 template <bool DEV>
 __global__ __launch_bounds__(256) void dm_observe_walk(ObsArgs a) {
+  // the NEXT call's counters (nobody reads or adds to them during this launch) — also when the gate is closed: the host alternates
+  // the two sets whether or not a call does anything. (r03: the last block to finish cleared the one set, found by a counter every
+  // block incremented: 1 200 atomics on one word per call.)
+  if (blockIdx.x == 0 && threadIdx.x < 2 * DM_OBS_REGIONS) a.ctr_next[threadIdx.x] = 0;
   if (DEV) {
     if (*a.gate == 0) return;
     obs_load_mats(a);
@@ -1302,12 +1307,6 @@ __global__ __launch_bounds__(256) void dm_observe_walk(ObsArgs a) {
       const int x = xy & 0xffff, y = xy >> 16;
       observe_pixel(a, x, y, x + y * a.W, ep.x, ep.y);
     }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int done = atomicAdd(&a.ctr[2 * DM_OBS_REGIONS], 1);
-    if (done == (int)gridDim.x - 1)   // every block has read the counters: ready for the next call
-      for (int i = 0; i <= 2 * DM_OBS_REGIONS; i++) a.ctr[i] = 0;
   }
 }
 
