@@ -630,7 +630,7 @@ __device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K
 // with fused multiply-adds and the hardware reciprocal / reciprocal square root (1 ulp) in place of the IEEE division and
 // sqrt sequences, and f32 products where the reference's pow() promotes to double. Per-pixel values agree with the
 // exact path to a few 1e-7 relative (tests/test_gpu_fast.py states the bounds); the final pose to well below the 1e-5 bar.
-// 16-byte records instead of 32; r04: written for the issue classes of the vector ALU (see tap_point_f).
+// 16-byte records instead of 32; r04: written for the issue classes of the vector ALU (see tap_request_f).
 // (kept as ONE 128-bit value: a record slot is carried around the pixel loop while its load is in flight, and a slot made of four
 // scalars makes the register allocator copy them at the loop's back edge — copies that wait for the load)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   for (int q = 0; q < 27; q++) hacc[q] = 0.0f;
   // The 48-byte ICA records leave through an LDS staging block of 256 records so that consecutive lanes store consecutive
   // 16-byte words (lane-per-record, every store instruction would touch a third of each line): -5 % on the kernel. The
-  // 32-byte FCA records are stored directly (r01 A/B: the two extra barriers per 256 records cost more than the half-line
+  // FCA records (20 bytes exact, 16 tolerance mode) are stored directly (r01 A/B: the two extra barriers per 256 records cost more than the partial-line
   // stores).
   constexpr int CH = 3;
   __shared__ u32x4 s_rec[((NEED & 4) && !(NEED & 16)) ? 256 * CH : 1];
