@@ -224,6 +224,10 @@ class Context:
     def depth_regularize(self, remove_occlusions=False):
         self._ck(self._l.ellc_depth_regularize(self.h, int(remove_occlusions)), "ellc_depth_regularize")
 
+    def depth_regularize_fill_regularize(self, remove_occlusions=True):
+        """regularise(remove_occlusions) + fill holes + regularise(False) in one launch (createKeyFrame's middle)"""
+        self._ck(self._l.ellc_depth_regularize_fill_regularize(self.h, int(remove_occlusions)), "ellc_depth_regularize_fill_regularize")
+
     def depth_make_inv_depth_one(self):
         f = C.c_float(0)
         self._ck(self._l.ellc_depth_make_inv_depth_one(self.h, C.byref(f)), "ellc_depth_make_inv_depth_one")
@@ -303,7 +307,8 @@ class Context:
         return ms.value
 
     def profile_depth_stage(self, stage, frame_slot, pose, reps=20):
-        """ms per call of one depth-map stage (0 regularize, 1 fill holes, 2 observe, 3 update depth image), HIP events."""
+        """ms per call of one depth-map stage (0 regularize, 1 fill holes, 2 observe, 3 update depth image, 4 createKeyFrame's
+        regularise + fill + regularise in one launch), HIP events."""
         pose = np.ascontiguousarray(pose, np.float32)
         ms = C.c_float(0)
         self._ck(self._l.ellc_profile_depth_stage(self.h, stage, frame_slot, _p(pose), reps, C.byref(ms)), "ellc_profile_depth_stage")

@@ -171,6 +171,7 @@ struct ellc_ctx {
   int *pr_tgt = nullptr, *pr_cnt = nullptr, *pr_slots = nullptr, *pr_val = nullptr, *pr_remaining = nullptr;   // pr_remaining: a counter word (ellc_depth_seeds)
   float *pr_id = nullptr, *pr_var = nullptr;
   double* red_scratch = nullptr;                            // reductions (rescale factor)
+  double* sum_parts = nullptr;                              // per-tile (sum, count) of dm_reg_fill_reg for the rescale in the export's launch
   // ellc_track_frame: the observation's matrices and the gate, built on the device behind the alignment; a host-visible record
   void* track_mats_d = nullptr;
   int* track_gate_d = nullptr;

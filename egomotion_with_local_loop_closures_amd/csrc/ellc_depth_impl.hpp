@@ -81,14 +81,26 @@ ellc_status do_rescale(ellc_ctx* c, float* factor_out) {
   return s != ELLC_OK ? s : do_rescale_finish(c, factor_out);
 }
 
-ellc_status do_update_depth_image(ellc_ctx* c) {
+// the tiles of dm_reg_fill_reg, whose per-tile sums dm_export_pyramid<true> finishes (every block re-reads them: bounded)
+#define DM_MAX_SUM_PARTS 4096
+static int depth_tiles(const ellc_ctx* c) { return ((c->cfg.width + DM_TX - 1) / DM_TX) * ((c->cfg.height + DM_TY - 1) / DM_TY); }
+static int export_pyramid_steps(const ellc_ctx* c) {   // levels the export's own launch produces (0: the per-level kernels)
+  const int W = c->cfg.width, H = c->cfg.height;
+  int steps = 0;
+  while (steps < 3 && steps + 1 < c->L && ((W >> steps) & 1) == 0 && ((H >> steps) & 1) == 0) steps++;
+  return (steps > 0 && (W % 32) == 0 && (H % 32) == 0) ? steps : 0;   // tiles of 32 x 32 must align with every level's 2 x 2 cells
+}
+static bool rescale_in_export(const ellc_ctx* c) { return export_pyramid_steps(c) > 0 && depth_tiles(c) <= DM_MAX_SUM_PARTS; }
+
+// with_rescale: makeInvDepthOne in the export's launch, from the per-tile sums the one-launch regularise / fill / regularise left
+ellc_status do_update_depth_image(ellc_ctx* c, bool with_rescale = false) {
   const int W = c->cfg.width, H = c->cfg.height;
   const KfLevelDev& k = c->kf_tab_h[c->dm_kf_slot];
   invalidate_records(c, c->dm_kf_slot);   // before the first write (a failure half-way must not leave a valid tag)
   // levels that halve exactly go into the export's own launch (dm_export_pyramid); the rest take the per-level kernel
-  int steps = 0;
-  while (steps < 3 && steps + 1 < c->L && ((W >> steps) & 1) == 0 && ((H >> steps) & 1) == 0) steps++;
-  if (steps > 0 && (W % 32) == 0 && (H % 32) == 0) {   // tiles of 32 x 32 must align with every level's 2 x 2 cells: true when the size is a multiple of 32
+  int steps = export_pyramid_steps(c);
+  if (with_rescale && !(steps > 0 && depth_tiles(c) <= DM_MAX_SUM_PARTS)) return fail(c, ELLC_ERR_BAD_ARG, "rescale in the export needs the tiled export");
+  if (steps > 0) {
     ExportPyrArgs ea;
     ea.W = W; ea.H = H; ea.steps = steps;
     for (int l = 0; l < 4; l++) {
@@ -96,9 +108,12 @@ ellc_status do_update_depth_image(ellc_ctx* c) {
       ea.depth[l] = kl.depth;
       ea.var[l] = kl.var;
     }
-    hipLaunchKernelGGL(dm_export_pyramid, dim3(W / 32, H / 32), dim3(256), 0, c->stream, c->dm_cur, ea);
+    float* factor_d = (float*)(c->red_scratch + 2 * 256 + 2);
+    if (with_rescale)
+      hipLaunchKernelGGL(dm_export_pyramid<true>, dim3(W / 32, H / 32), dim3(256), 0, c->stream, c->dm_cur, ea, c->sum_parts, depth_tiles(c), factor_d);
+    else
+      hipLaunchKernelGGL(dm_export_pyramid<false>, dim3(W / 32, H / 32), dim3(256), 0, c->stream, c->dm_cur, ea, (const double*)nullptr, 0, (float*)nullptr);
   } else {
-    steps = 0;
     dim3 blk(32, 8);
     hipLaunchKernelGGL(dm_export_level0, grid2(W, H, blk), blk, 0, c->stream, c->dm_cur, k.depth, k.var, W, H);
   }
@@ -106,6 +121,18 @@ ellc_status do_update_depth_image(ellc_ctx* c) {
   ellc_status s = build_depth_pyramid_from(c, c->dm_kf_slot, steps + 1);   // buildInvVarDepth + mapDepthArr2Mat: the remaining levels
   if (s != ELLC_OK) return s;
   c->kf_has_depth[c->dm_kf_slot] = 1;
+  return ELLC_OK;
+}
+
+// regularizeDepthMap(removeOcclusions) + fillDepthHoles + regularizeDepthMap(false) as createKeyFrame runs them (:1775-1777) in ONE
+// launch (dm_reg_fill_reg): the result goes to the other copy of the map, which becomes the map
+ellc_status do_reg_fill_reg(ellc_ctx* c, int removeOcclusions, bool with_sums = false) {
+  const int W = c->cfg.width, H = c->cfg.height;
+  const int tiles_x = (W + DM_TX - 1) / DM_TX, tiles = tiles_x * ((H + DM_TY - 1) / DM_TY);
+  hipLaunchKernelGGL(dm_reg_fill_reg, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth, c->kf_maxgrad[c->dm_kf_slot], W, H,
+                     removeOcclusions, tiles_x, tiles, with_sums ? c->sum_parts : (double*)nullptr);
+  ELLC_HIP(c, hipGetLastError());
+  swap_maps(c);
   return ELLC_OK;
 }
 
@@ -388,6 +415,14 @@ ellc_status ellc_depth_update_depth_image(ellc_ctx* c) {
   return do_update_depth_image(c);
 }
 
+ellc_status ellc_depth_regularize_fill_regularize(ellc_ctx* c, int remove_occlusions) {
+  ELLC_ENTER(c);
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  if (!c->kf_maxgrad_valid[c->dm_kf_slot] && (s = build_maxgrad(c, true, c->dm_kf_slot)) != ELLC_OK) return s;
+  return do_reg_fill_reg(c, remove_occlusions ? 1 : 0);
+}
+
 ellc_status ellc_depth_create_keyframe(ellc_ctx* c, int new_kf_slot, const float* pose_new_wrt_old, float* rescale_factor) {
   ELLC_ENTER(c);
   ellc_status s = need_map(c);
@@ -395,11 +430,12 @@ ellc_status ellc_depth_create_keyframe(ellc_ctx* c, int new_kf_slot, const float
   if ((s = do_propagate(c, new_kf_slot, pose_new_wrt_old)) != ELLC_OK) return s;   // :1769 (on failure the map is unchanged)
   const int old_slot = c->dm_kf_slot;
   c->dm_kf_slot = new_kf_slot;                                                     // :1772
-  if ((s = do_regularize(c, 1)) == ELLC_OK &&                                      // :1775
-      (s = do_fill_holes(c)) == ELLC_OK &&                                         // :1777 doRegularization(false)
-      (s = do_regularize(c, 0)) == ELLC_OK &&
-      (s = do_rescale_enqueue(c)) == ELLC_OK &&                                    // :1779
-      (s = do_update_depth_image(c)) == ELLC_OK)                                   // :1781
+  // :1775 regularizeDepthMap(true), :1777 doRegularization(false) = fill + regularise: one launch, which also leaves the per-tile
+  // sums of :1779 makeInvDepthOne; the export's launch (:1781 updateDepthImage) finishes that sum and rescales first
+  const bool merged = rescale_in_export(c);
+  if ((s = do_reg_fill_reg(c, 1, merged)) == ELLC_OK &&
+      (merged || (s = do_rescale_enqueue(c)) == ELLC_OK) &&
+      (s = do_update_depth_image(c, merged)) == ELLC_OK)
     s = do_rescale_finish(c, rescale_factor);   // the one host wait of the whole sequence: the factor the caller is handed
   if (s != ELLC_OK) {   // a device error part-way: the map no longer matches either keyframe
     c->dm_kf_slot = old_slot;
@@ -410,17 +446,18 @@ ellc_status ellc_depth_create_keyframe(ellc_ctx* c, int new_kf_slot, const float
 
 // measurement hook (bench.py): `reps` enqueues of one depth-map stage between two HIP events on the context's stream.
 // stage 0: regularizeDepthMap(false), 1: fillDepthHoles, 2: observeDepthRow against frame_slot / pose, 3: updateDepthImage
-// (export + depth / variance pyramid). The map keeps evolving from call to call, as it does from frame to frame.
+// (export + depth / variance pyramid), 4: createKeyFrame's regularise + fill + regularise in one launch. The map keeps evolving from call to call, as it does from frame to frame.
 ellc_status ellc_profile_depth_stage(ellc_ctx* c, int stage, int frame_slot, const float* pose_frame_wrt_kf, int reps, float* avg_ms) {
   ELLC_ENTER(c);
   ellc_status s = need_map(c);
   if (s != ELLC_OK) return s;
-  if (reps < 1 || stage < 0 || stage > 3) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (reps < 1 || stage < 0 || stage > 4) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   auto once = [&]() -> ellc_status {
     switch (stage) {
       case 0: return do_regularize(c, 0);
       case 1: return do_fill_holes(c);
       case 2: return do_observe(c, frame_slot, pose_frame_wrt_kf);
+      case 4: return do_reg_fill_reg(c, 1);
       default: return do_update_depth_image(c);
     }
   };

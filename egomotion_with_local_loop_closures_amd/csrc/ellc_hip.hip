@@ -905,6 +905,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   TRY(dev_alloc(c, &c->pr_tgt, n0)); TRY(dev_alloc(c, &c->pr_cnt, n0)); TRY(dev_alloc(c, &c->pr_slots, 4 * n0)); TRY(dev_alloc(c, &c->pr_val, n0));
   TRY(dev_alloc(c, &c->pr_id, n0)); TRY(dev_alloc(c, &c->pr_var, n0)); TRY(dev_alloc(c, &c->pr_remaining, 4));
   TRY(dev_alloc(c, &c->red_scratch, 4096));
+  TRY(dev_alloc(c, &c->sum_parts, 2 * (size_t)((cfg->width + 31) / 32) * ((cfg->height + 7) / 8)));   // the 32 x 8 tiles of the depth kernels
   TRY(dev_alloc(c, (char**)&c->track_mats_d, 256)); TRY(dev_alloc(c, &c->track_gate_d, 4)); TRY(dev_alloc(c, &c->seed_acc, 4));
   {   // (the arena is zeroed: the counters start at 0)
     const size_t blocks = (size_t)((cfg->width + 31) / 32) * ((cfg->height + 7) / 8);

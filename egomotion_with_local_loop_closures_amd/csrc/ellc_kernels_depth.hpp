@@ -155,15 +155,23 @@ __device__ __forceinline__ bool dm_tile_of_block(int tiles_x, int tiles_total, i
 }
 __device__ __forceinline__ void dm_tile_load_at(DmTile& t, const DepthSoA& in, int W, int H, int bx, int by) {
   const int x0 = bx * DM_TX - DM_HALO, y0 = by * DM_TY - DM_HALO;
-  for (int k = threadIdx.x; k < DM_TW * DM_TH; k += DM_TX * DM_TY) {
+  // (a fixed number of rounds over clamped cell numbers, every load unconditional: the loads of all rounds are in flight together —
+  // with the cell count as the loop bound each round waited for its own; a clamped lane rewrites the last cell with its own value)
+  constexpr int CELLS = DM_TW * DM_TH, NT = DM_TX * DM_TY;
+#pragma unroll
+  for (int r = 0; r < (CELLS + NT - 1) / NT; r++) {
+    const int k = min((int)threadIdx.x + r * NT, CELLS - 1);
     const int ty = k / DM_TW, tx = k - ty * DM_TW;
     const int x = x0 + tx, y = y0 + ty;
     const bool inside = (x >= 0 && x < W && y >= 0 && y < H);
     const int j = inside ? (x + y * W) : 0;
-    t.valid[ty][tx] = inside ? in.isValid[j] : (uint8_t)0;
-    t.id[ty][tx] = inside ? in.invDepth[j] : 0.0f;
-    t.var[ty][tx] = inside ? in.variance[j] : 0.0f;
-    t.validity[ty][tx] = inside ? in.validity[j] : 0;
+    const uint8_t v = in.isValid[j];
+    const float a = in.invDepth[j], b = in.variance[j];
+    const int n = in.validity[j];
+    t.valid[ty][tx] = inside ? v : (uint8_t)0;
+    t.id[ty][tx] = inside ? a : 0.0f;
+    t.var[ty][tx] = inside ? b : 0.0f;
+    t.validity[ty][tx] = inside ? n : 0;
   }
   __syncthreads();
 }
@@ -215,6 +223,57 @@ __device__ __forceinline__ void depth_pyr_merge(const float d[4], const float v[
   }
 }
 
+// regularizeDepthMap's 25-neighbour stencil (:1452-1530) for the pixel at index c of LDS planes with PITCH cells per row. The
+// reference's two `continue`s become per-lane selects: a wave runs every neighbour anyway (one lane with a hypothesis there is
+// enough, and a wave of gathered candidates always has one), and without the branches the 100 LDS reads of a pixel are issued
+// ahead of the arithmetic instead of one dependent round trip per test. A rejected neighbour's terms are computed and dropped
+// by the select, so every sum receives the same addends in the same order as the reference's loop. Returns 1: smoothed values in
+// out_ids / out_vars, 2: invalidated + blacklist step, 3: invalidated (occluded). REMOVE_OCC = the reference's removeOcclusions.
+// VALUES = false: only the verdict, which needs the validity sum and the occlusion counts but none of the 25 divisions — what
+// the one-launch form (dm_reg_fill_reg) owes the pixels of its ring, whose smoothed values nobody reads.
+template <int PITCH, bool REMOVE_OCC, bool VALUES>
+__device__ __forceinline__ int dm_stencil25(const float* id, const float* var, const int* validity, const uint8_t* valid, int c, float& out_ids, float& out_vars) {
+  const float did = id[c], dvar = var[c];
+  float sum = 0.0f, val_sum = 0.0f, sumIvar = 0.0f;
+  int numOccluding = 0, numNotOccluding = 0;
+#pragma unroll
+  for (int dx = -2; dx <= 2; dx++) {
+    // (one column's masks at a time: scheduled as one region, the 25 pairs of lane masks outgrow the scalar registers and are
+    // spilled through v_writelane)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dy = -2; dy <= 2; dy++) {
+      const int q = c + dy * PITCH + dx;
+      const bool there = valid[q] != 0;
+      const float sid = id[q], svar = var[q];
+      const float diff = sid - did;
+      const bool apart = 1.0f * diff * diff > svar + dvar;
+      const bool take = there && !apart;
+      if (REMOVE_OCC) {
+        numOccluding += (there && apart && sid > did) ? 1 : 0;
+        numNotOccluding += take ? 1 : 0;
+      }
+      const float vs = val_sum + (float)validity[q];
+      val_sum = take ? vs : val_sum;
+      if (VALUES) {
+        const float distFac = (float)(dx * dx + dy * dy) * DM_REG_DIST_VAR;
+        const float ivar = 1.0f / (svar + distFac);
+        const float s1 = sum + sid * ivar, s2 = sumIvar + ivar;
+        sum = take ? s1 : sum;
+        sumIvar = take ? s2 : sumIvar;
+      }
+    }
+  }
+  // (the values are formed whatever the verdict and the callers store them whatever the verdict: behind a test, the compiler
+  // moves the 25 divisions behind it as a second pass over the neighbours and carries the 50 lane masks there through spills)
+  if (VALUES) {
+    sum = sum / sumIvar;
+    out_ids = unzero_f(sum);
+    out_vars = 1.0f / sumIvar;
+  }
+  return (val_sum < (float)(int)DM_VAL_SUM_MIN_FOR_KEEP) ? 2 : (REMOVE_OCC && numOccluding > numNotOccluding) ? 3 : 1;
+}
+
 // depthMap::regularizeDepthMap (:1436-1543). The stencil reads the snapshot's invDepth / variance / validity / isValid, a
 // pixel's update writes only its own invDepthSmoothed / varianceSmoothed / blacklisted — which no stencil reads — and isValid:
 // so the map is updated IN PLACE and only the new validity flags go to a plane of their own (valid_out, which the caller then
@@ -244,36 +303,12 @@ __global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA s, uint8
   const int ncand = dm_compact_candidates(cand, list, wave_count);
   for (int k = threadIdx.x; k < ncand; k += DM_TX * DM_TY) {
     const int p = list[k];
-    const int cx = (p & (DM_TX - 1)) + DM_HALO, cy = p / DM_TX + DM_HALO;
-    const float did = t.id[cy][cx], dvar = t.var[cy][cx];
-    float sum = 0.0f, val_sum = 0.0f, sumIvar = 0.0f;
-    int numOccluding = 0, numNotOccluding = 0;
-    for (int dx = -2; dx <= 2; dx++)
-      for (int dy = -2; dy <= 2; dy++) {
-        if (!t.valid[cy + dy][cx + dx]) continue;
-        const float sid = t.id[cy + dy][cx + dx], svar = t.var[cy + dy][cx + dx];
-        const float diff = sid - did;
-        if (1.0f * diff * diff > svar + dvar) {
-          if (removeOcclusions && sid > did) numOccluding++;
-          continue;
-        }
-        val_sum += (float)t.validity[cy + dy][cx + dx];
-        if (removeOcclusions) numNotOccluding++;
-        const float distFac = (float)(dx * dx + dy * dy) * DM_REG_DIST_VAR;
-        const float ivar = 1.0f / (svar + distFac);
-        sum += sid * ivar;
-        sumIvar += ivar;
-      }
-    if (val_sum < (float)(int)DM_VAL_SUM_MIN_FOR_KEEP) {
-      r_code[p] = 2;
-    } else if (removeOcclusions && numOccluding > numNotOccluding) {
-      r_code[p] = 3;
-    } else {
-      sum = sum / sumIvar;
-      r_ids[p] = unzero_f(sum);
-      r_vars[p] = 1.0f / sumIvar;
-      r_code[p] = 1;
-    }
+    const int c = (p / DM_TX + DM_HALO) * DM_TW + (p & (DM_TX - 1)) + DM_HALO;
+    float ids = 0.0f, vars = 0.0f;
+    const int code = removeOcclusions ? dm_stencil25<DM_TW, true, true>(&t.id[0][0], &t.var[0][0], &t.validity[0][0], &t.valid[0][0], c, ids, vars)
+                                      : dm_stencil25<DM_TW, false, true>(&t.id[0][0], &t.var[0][0], &t.validity[0][0], &t.valid[0][0], c, ids, vars);
+    r_code[p] = (uint8_t)code;
+    r_ids[p] = ids; r_vars[p] = vars;   // read only where the code is 1
   }
   __syncthreads();
   if (!EXPORT && !inside) return;
@@ -396,6 +431,198 @@ __global__ __launch_bounds__(DM_TX * DM_TY) void dm_fill_holes(DepthSoA in, Dept
   hyp_store(out, i, d);
 }
 
+// ------------------------------------------------------------------------------------------------
+// createKeyFrame's three stencil stages in ONE launch (r04): regularizeDepthMap(removeOcclusions) -> fillDepthHoles ->
+// regularizeDepthMap(false) (DepthPropagation.cpp:1775-1777). A block owns a 32 x 8 tile and recomputes the earlier stages on the
+// ring of pixels the later ones read: the second regularisation reads the filled map two pixels around the tile, the fill reads
+// the first regularisation's validity flags two columns / three rows up and two down around that, and the first regularisation the
+// snapshot two pixels around that — a snapshot of (32 + 12) x (8 + 13) pixels in LDS (13 KB). Per pixel the operations and their
+// order are those of dm_regularize and dm_fill_holes (the three-launch form stays for the other callers and is what the tests
+// compare this one with, bit for bit); candidates of every stage are gathered first so that full waves run the 25-neighbour loops.
+// The result goes to the other copy of the map (the stencils of neighbouring blocks read this one).
+#define DM_FX 6                  // snapshot halo: columns left / right
+#define DM_FYU 7                 //   rows above
+#define DM_FYD 6                 //   rows below
+#define DM_FW (DM_TX + 2 * DM_FX)
+#define DM_FH (DM_TY + DM_FYU + DM_FYD)
+struct DmFused {
+  float id[DM_FH][DM_FW], var[DM_FH][DM_FW];
+  int validity[DM_FH][DM_FW];
+  uint8_t valid0[DM_FH][DM_FW], valid1[DM_FH][DM_FW], valid2[DM_FH][DM_FW];
+  uint8_t code1[DM_FH][DM_FW];            // first regularisation: 0 unchanged, 1 smoothed, 2 invalidated + blacklist step, 3 invalidated (occluded)
+  uint16_t list[DM_FH * DM_FW], list_own[DM_TX * DM_TY];
+  int count, count_own, count_fill;
+  float ids1[DM_TX * DM_TY], vars1[DM_TX * DM_TY];   // the tile's own smoothed values of the first / second regularisation
+  float ids3[DM_TX * DM_TY], vars3[DM_TX * DM_TY];
+  uint8_t code3[DM_TX * DM_TY];
+};
+// regularizeDepthMap's stencil for the pixel at (cx, cy) of the snapshot
+template <bool VALUES>
+__device__ __forceinline__ int dm_reg_stencil(const DmFused& t, const uint8_t (*valid)[DM_FW], int cx, int cy, int removeOcclusions, float& out_ids, float& out_vars) {
+  const int c = cy * DM_FW + cx;
+  return removeOcclusions ? dm_stencil25<DM_FW, true, VALUES>(&t.id[0][0], &t.var[0][0], &t.validity[0][0], &valid[0][0], c, out_ids, out_vars)
+                          : dm_stencil25<DM_FW, false, VALUES>(&t.id[0][0], &t.var[0][0], &t.validity[0][0], &valid[0][0], c, out_ids, out_vars);
+}
+__global__ __launch_bounds__(DM_TX * DM_TY) void dm_reg_fill_reg(DepthSoA in, DepthSoA out, const float* __restrict__ maxgrad, int W, int H, int removeOcclusions,
+                                                                 int tiles_x, int tiles_total, double* __restrict__ part) {
+  __shared__ DmFused t;
+  int bx, by;
+  if (!dm_tile_of_block(tiles_x, tiles_total, bx, by)) return;
+  constexpr int NT = DM_TX * DM_TY;
+  const int x0 = bx * DM_TX - DM_FX, y0 = by * DM_TY - DM_FYU;   // image position of snapshot cell (0, 0)
+#pragma unroll
+  for (int r = 0; r < (DM_FW * DM_FH + NT - 1) / NT; r++) {   // (as dm_tile_load_at: every round's loads in flight together)
+    const int k = min((int)threadIdx.x + r * NT, DM_FW * DM_FH - 1);
+    const int ty = k / DM_FW, tx = k - ty * DM_FW;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool inside = (x >= 0 && x < W && y >= 0 && y < H);
+    const int j = inside ? (x + y * W) : 0;
+    const uint8_t lv = in.isValid[j];
+    const float a = in.invDepth[j], b = in.variance[j];
+    const int n = in.validity[j];
+    const uint8_t v = inside ? lv : (uint8_t)0;
+    t.valid0[ty][tx] = v; t.valid1[ty][tx] = v; t.valid2[ty][tx] = v;
+    t.code1[ty][tx] = 0;
+    t.id[ty][tx] = inside ? a : 0.0f;
+    t.var[ty][tx] = inside ? b : 0.0f;
+    t.validity[ty][tx] = inside ? n : 0;
+  }
+  if (threadIdx.x == 0) { t.count = 0; t.count_own = 0; t.count_fill = 0; }
+  __syncthreads();
+  // ---- stage 1: regularizeDepthMap(removeOcclusions) where the fill will look: columns -4 .. +4, rows -5 .. +4 around the tile.
+  // The tile's own candidates (smoothed values wanted) and the ring's (verdict only) go to two lists, run by different waves.
+  constexpr int R1W = DM_TX + 8, R1H = DM_TY + 9;   // columns -4 .. +4, rows -5 .. +4
+  for (int q = threadIdx.x; q < R1W * R1H; q += NT) {
+    const int ry = q / R1W, tx = q - ry * R1W + (DM_FX - 4), ty = ry + (DM_FYU - 5);
+    const int k = ty * DM_FW + tx;
+    const int x = x0 + tx, y = y0 + ty;
+    if (!(x >= 2 && x < W - 2 && y >= 3 && y < H - 3 && t.valid0[ty][tx])) continue;
+    const int ox = tx - DM_FX, oy = ty - DM_FYU;
+    if (ox >= 0 && ox < DM_TX && oy >= 0 && oy < DM_TY) t.list_own[atomicAdd(&t.count_own, 1)] = (uint16_t)k;
+    else t.list[atomicAdd(&t.count, 1)] = (uint16_t)k;
+  }
+  __syncthreads();
+  const int n1_own = t.count_own, n1_own_pad = (n1_own + 63) & ~63, n1 = n1_own_pad + t.count;
+  for (int k = threadIdx.x; k < n1; k += NT) {
+    if (k < n1_own_pad) {   // wave-uniform: the padding is a whole number of waves
+      if (k >= n1_own) continue;
+      const int c = t.list_own[k], cy = c / DM_FW, cx = c - cy * DM_FW;
+      float ids = 0.0f, vars = 0.0f;
+      const int code = dm_reg_stencil<true>(t, t.valid0, cx, cy, removeOcclusions, ids, vars);
+      t.code1[cy][cx] = (uint8_t)code;
+      if (code >= 2) { t.valid1[cy][cx] = 0; t.valid2[cy][cx] = 0; }
+      const int o = (cy - DM_FYU) * DM_TX + (cx - DM_FX);
+      t.ids1[o] = ids; t.vars1[o] = vars;   // read only where the code is 1
+    } else {
+      const int c = t.list[k - n1_own_pad], cy = c / DM_FW, cx = c - cy * DM_FW;
+      float ids, vars;
+      const int code = dm_reg_stencil<false>(t, t.valid0, cx, cy, removeOcclusions, ids, vars);
+      t.code1[cy][cx] = (uint8_t)code;
+      if (code >= 2) { t.valid1[cy][cx] = 0; t.valid2[cy][cx] = 0; }
+    }
+  }
+  __syncthreads();
+  // ---- stage 2: fillDepthHoles two pixels around the tile (dm_fill_holes' test and average on the flags of stage 1)
+  constexpr int R2W = DM_TX + 4, R2H = DM_TY + 4;   // two pixels around the tile
+#pragma unroll
+  for (int r = 0; r < (R2W * R2H + NT - 1) / NT; r++) {
+    const int q = (int)threadIdx.x + r * NT;
+    const int qq = min(q, R2W * R2H - 1);
+    const int ry = qq / R2W, tx = qq - ry * R2W + (DM_FX - 2), ty = ry + (DM_FYU - 2);
+    const int k = ty * DM_FW + tx;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool in_test = q < R2W * R2H && x >= 3 && x < W - 2 && y >= 3 && y < H - 3;
+    const int i = in_test ? x + y * W : 0;
+    const float mg = maxgrad[i];            // both loads before the tests (one round trip, not one per test)
+    const int bl0 = in.blacklisted[i];
+    if (!in_test || t.valid1[ty][tx]) continue;
+    if (mg < DM_MIN_ABS_GRAD_DECREASE) continue;
+    int val = 0;
+    const int ya = y + 2, yb = y - 3;
+    if (ya >= 3 && ya < H - 3)
+      for (int dx = -2; dx <= 2; dx++) { if (t.valid1[ty + 2][tx + dx]) val += t.validity[ty + 2][tx + dx]; }
+    if (yb >= 3 && yb < H - 3)
+      for (int dx = -2; dx <= 2; dx++) { if (t.valid1[ty - 3][tx + dx]) val -= t.validity[ty - 3][tx + dx]; }
+    const int bl1 = bl0 - (t.code1[ty][tx] == 2 ? 1 : 0);   // the blacklist counter after stage 1
+    if ((bl1 >= DM_MIN_BLACKLIST && (float)val > DM_VAL_SUM_MIN_FOR_CREATE) || (float)val > DM_VAL_SUM_MIN_FOR_UNBLACKLIST)
+      t.list[atomicAdd(&t.count_fill, 1)] = (uint16_t)k;
+  }
+  __syncthreads();
+  const int n2 = t.count_fill;
+  for (int k = threadIdx.x; k < n2; k += NT) {
+    const int c = t.list[k], py = c / DM_FW, px = c - py * DM_FW;
+    float sumIdepthObs = 0.0f, sumIVarObs = 0.0f;
+    for (int dy = -2; dy < 3; dy++)
+      for (int dx = -2; dx < 3; dx++) {
+        if (!t.valid1[py + dy][px + dx]) continue;
+        const float v = t.var[py + dy][px + dx];
+        sumIdepthObs += t.id[py + dy][px + dx] / v;
+        sumIVarObs += 1.0f / v;
+      }
+    const float nid = unzero_f(sumIdepthObs / sumIVarObs);
+    // a filled pixel was invalid in stage 1's flags, which is all the averages above look at: its cell can be written at once
+    t.id[py][px] = nid;
+    t.var[py][px] = DM_VAR_RANDOM_INIT_INITIAL;
+    t.validity[py][px] = 0;
+    t.valid2[py][px] = 2;   // valid, and filled here
+  }
+  __syncthreads();
+  // ---- stage 3: regularizeDepthMap(false) on the tile, on the filled map
+  const int tx = threadIdx.x & (DM_TX - 1), ty = threadIdx.x / DM_TX;
+  const int cx = tx + DM_FX, cy = ty + DM_FYU;
+  const int x = bx * DM_TX + tx, y = by * DM_TY + ty;
+  const bool inside = (x < W && y < H);
+  t.code3[threadIdx.x] = 0;
+  const bool cand3 = inside && y >= 3 && y < H - 3 && x >= 2 && x < W - 2 && t.valid2[cy][cx];
+  __shared__ uint8_t list3[NT];
+  __shared__ int wave_count[NT / 64];
+  const int n3 = dm_compact_candidates(cand3, list3, wave_count);
+  for (int k = threadIdx.x; k < n3; k += NT) {
+    const int p = list3[k];
+    float ids = 0.0f, vars = 0.0f;
+    const int code = dm_reg_stencil<true>(t, t.valid2, (p & (DM_TX - 1)) + DM_FX, p / DM_TX + DM_FYU, 0, ids, vars);
+    t.code3[p] = (uint8_t)code;
+    t.ids3[p] = ids; t.vars3[p] = vars;   // read only where the code is 1
+  }
+  __syncthreads();
+  // ---- the pixel's state after the three stages, into the other copy of the map
+  double acc = 0.0, cnt = 0.0;
+  if (inside) {
+    const int i = x + y * W;
+    Hyp d = hyp_load(in, i);
+    const int c1 = t.code1[cy][cx], c3 = t.code3[threadIdx.x];
+    if (c1 == 1) { d.ids = t.ids1[threadIdx.x]; d.vars = t.vars1[threadIdx.x]; }
+    else if (c1 == 2) d.bl = d.bl - 1;
+    if (t.valid2[cy][cx] == 2) {   // filled by stage 2
+      d.id = t.id[cy][cx];
+      d.var = DM_VAR_RANDOM_INIT_INITIAL;
+      d.validity = 0;
+      d.bl = 0;
+      d.ids = -1.0f;
+      d.vars = -1.0f;
+    }
+    if (c3 == 1) { d.ids = t.ids3[threadIdx.x]; d.vars = t.vars3[threadIdx.x]; }
+    else if (c3 == 2) d.bl = d.bl - 1;
+    d.valid = t.valid2[cy][cx] != 0 && c3 < 2;
+    hyp_store(out, i, d);
+    if (d.valid) { acc = (double)d.ids; cnt = 1.0; }
+  }
+  // makeInvDepthOne's sum (:1546-1587), first stage: this tile's sum of the smoothed inverse depths and their count (f64, fixed
+  // order) for dm_export_pyramid<true>, which finishes the sum, rescales and exports
+  if (part == nullptr) return;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { acc += __shfl_xor(acc, m, 64); cnt += __shfl_xor(cnt, m, 64); }
+  __shared__ double wsum[NT / 64], wcnt[NT / 64];
+  if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = acc; wcnt[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = wsum[0], n = wcnt[0];
+    for (int w = 1; w < NT / 64; w++) { a += wsum[w]; n += wcnt[w]; }
+    const int tile = by * tiles_x + bx;
+    part[2 * tile] = a; part[2 * tile + 1] = n;
+  }
+}
+
 // depthMap::updateDepthImage (:1254-1315), per-pixel part: invalidate the 3-px border, export level 0
 __global__ void dm_export_level0(DepthSoA s, float* __restrict__ depthMat, float* __restrict__ vararr, int W, int H) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -422,10 +649,30 @@ __global__ void dm_export_level0(DepthSoA s, float* __restrict__ depthMat, float
 // through LDS, writing every level. Only for level sizes that halve exactly (W >> l == 2 (W >> (l + 1)) for the levels
 // produced): the reference reads a source level with the stride 2 * (destination width), which is the source's own width
 // exactly then; other sizes take the per-level kernels. Same operations per value as the kernels it replaces.
-__global__ __launch_bounds__(256) void dm_export_pyramid(DepthSoA s, ExportPyrArgs a) {
+// RESCALE (createKeyFrame): makeInvDepthOne (:1546-1587) goes first, in the same launch — every block finishes the sum over the
+// per-tile partials dm_reg_fill_reg left (fixed order: the same bits in every block), scales the four value fields of its valid
+// pixels as dm_rescale does and exports the scaled values; block (0, 0) leaves the factor at factor_out for the host.
+template <bool RESCALE>
+__global__ __launch_bounds__(256) void dm_export_pyramid(DepthSoA s, ExportPyrArgs a, const double* __restrict__ part, int nparts, float* __restrict__ factor_out) {
   __shared__ float ld[2][32 * 32], lv[2][32 * 32];   // ping-pong: level l in [l & 1]
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
   const int W = a.W, H = a.H;
+  float f = 1.0f, f2 = 1.0f;
+  if (RESCALE) {
+    __shared__ double sa[256], sc[256];
+    const int t = threadIdx.x;
+    double acc = 0.0, cnt = 0.0;
+    for (int p = t; p < nparts; p += 256) { acc += part[2 * p]; cnt += part[2 * p + 1]; }
+    sa[t] = acc; sc[t] = cnt;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (t < off) { sa[t] += sa[t + off]; sc[t] += sc[t + off]; }
+      __syncthreads();
+    }
+    f = (float)sc[0] / (float)sa[0];   // rescaleFactor = numIdepth / sumIdepth (f32)
+    f2 = f * f;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) *factor_out = f;
+  }
   for (int i = threadIdx.x; i < 1024; i += 256) {
     const int ty = i >> 5, tx = i & 31;
     const int x = bx + tx, y = by + ty;
@@ -433,14 +680,23 @@ __global__ __launch_bounds__(256) void dm_export_pyramid(DepthSoA s, ExportPyrAr
     if (x < W && y < H) {
       const int p = x + y * W;
       bool valid = s.isValid[p] != 0;
+      float ids = s.invDepthSmoothed[p];
+      float vs = 0.0f;
+      if (RESCALE && valid) {
+        s.invDepth[p] *= f;
+        ids *= f;
+        s.invDepthSmoothed[p] = ids;
+        s.variance[p] *= f2;
+        vs = s.varianceSmoothed[p] * f2;
+        s.varianceSmoothed[p] = vs;
+      }
       if (y < 3 || y >= H - 3 || x < 3 || x >= W - 3) {
         valid = false;
         s.isValid[p] = 0;
       }
-      const float ids = s.invDepthSmoothed[p];
       if (valid && ids >= -0.05f) {
         d = 1.0f / ids;
-        v = s.varianceSmoothed[p];
+        v = RESCALE ? vs : s.varianceSmoothed[p];
       }
       a.depth[0][p] = d;
       a.var[0][p] = v;

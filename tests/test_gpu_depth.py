@@ -200,6 +200,29 @@ def test_make_inv_depth_one(scene, oracle):
     assert abs(ctx.depth_get_state()["invDepthSmoothed"][m].mean() - 1) < 1e-4
 
 
+@pytest.mark.parametrize("remove_occlusions", [True, False])
+def test_regularize_fill_regularize_in_one_launch(scene, oracle, remove_occlusions):
+    """createKeyFrame's three stencil stages (DepthPropagation.cpp:1775-1777) as ONE launch, each block recomputing the earlier
+    stages on the ring the later ones read: every field of every pixel equals the three separate launches' and the oracle's."""
+    dm, ctx = fresh(scene, oracle)
+    dm.regularize(remove_occlusions); dm.fill_holes(); dm.regularize(False)
+    ref = dm.get_state()
+    ctx.depth_regularize(remove_occlusions); ctx.depth_fill_holes(); ctx.depth_regularize(False)
+    three = ctx.depth_get_state()
+    ctx.depth_set_keyframe(0); ctx.depth_set_state(scene["st"])
+    ctx.depth_regularize_fill_regularize(remove_occlusions)
+    one = ctx.depth_get_state()
+    filled = int(((ref["valid"] != 0) & (scene["st"]["valid"] == 0)).sum())
+    dropped = int(((ref["valid"] == 0) & (scene["st"]["valid"] != 0)).sum())
+    print("holes filled %d, hypotheses dropped %d" % (filled, dropped))
+    assert filled > 50 and dropped > 50
+    assert_state_equal(three, ref, "three launches")
+    assert_state_equal(one, ref, "one launch")
+    for f in FIELDS + ("blacklisted",):   # also where the hypothesis is invalid: the one launch leaves exactly what the three leave
+        assert bits_equal(one[f].astype(np.float32), three[f].astype(np.float32)), f
+    assert np.array_equal(one["valid"], three["valid"])
+
+
 def test_create_keyframe_sequence(scene, oracle):
     dm, ctx = fresh(scene, oracle)
     dm.regularize(False); ctx.depth_regularize(False)
