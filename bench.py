@@ -636,7 +636,8 @@ def depth_kernels(api, synth, dev_index):
               ("dm_fill_holes (fillDepthHoles + buildValIntegralBuffer, :1317-1432)", 1, 50.0, "hbm"),
               ("dm_observe_select + dm_observe_walk (observeDepthRow + line stereo, :191-999)", 2, 94.0, "valu (stereo walks; not a roofline kernel)"),
               ("dm_export_level0 + 3 x depth_pyr_level (updateDepthImage, :1254-1315, 1637-1746)", 3, 9.0 + 12.0 + 8.0 / 3.0, "hbm"),
-              ("dm_reg_fill_reg (createKeyFrame's regularise + fill + regularise in one launch, :1775-1777)", 4, 50.0, "valu (three 25-neighbour stencils, the first also on the ring)"))
+              ("dm_reg_fill_reg (createKeyFrame's regularise + fill + regularise in one launch, :1775-1777)", 4, 50.0, "valu (three 25-neighbour stencils, the first also on the ring)"),
+              ("dm_fill_reg<export> (a tracked frame's fill + regularise + updateDepthImage in one launch, :1627-1635, 1254-1315)", 5, 50.0 + 8.0 + 8.0 / 3.0, "hbm"))
     for name, stage, bpp, bound in stages:
         ctx.depth_set_keyframe(0); ctx.depth_set_state(st)
         ctx.depth_regularize(False)

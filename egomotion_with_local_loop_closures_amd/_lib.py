@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "ellc_keyframe_set_weights", "ellc_keyframe_get_weights", "ellc_keyframe_finalise_weights", "ellc_align", "ellc_align_enqueue",
     "ellc_align_fetch", "ellc_gn_iterate", "ellc_gn_display_planes", "ellc_concatenate_relative_pose", "ellc_concatenate_origin_pose", "ellc_se3_exp",
     "ellc_se3_log", "ellc_depth_set_state", "ellc_depth_get_state", "ellc_depth_set_keyframe", "ellc_depth_propagate",
-    "ellc_depth_observe", "ellc_depth_fill_holes", "ellc_depth_regularize", "ellc_depth_make_inv_depth_one", "ellc_depth_regularize_fill_regularize",
+    "ellc_depth_observe", "ellc_depth_fill_holes", "ellc_depth_regularize", "ellc_depth_make_inv_depth_one", "ellc_depth_regularize_fill_regularize", "ellc_depth_do_regularization",
     "ellc_depth_update_depth_image", "ellc_depth_create_keyframe", "ellc_depth_seeds", "ellc_track_frame", "ellc_profile_gn_kernel", "ellc_profile_align",
     "ellc_profile_calibrate_read", "ellc_profile_stream_read", "ellc_histogram", "ellc_kl_divergence", "ellc_copy_slot", "ellc_copy_slot_across", "ellc_selftest_div_pair",
     "ellc_ingest_configure", "ellc_frame_ingest_bgr", "ellc_selftest_lu", "ellc_profile_depth_stage",

@@ -224,6 +224,10 @@ class Context:
     def depth_regularize(self, remove_occlusions=False):
         self._ck(self._l.ellc_depth_regularize(self.h, int(remove_occlusions)), "ellc_depth_regularize")
 
+    def depth_do_regularization(self, remove_occlusions=False):
+        """doRegularization (:1627-1635): fill holes + regularise in one launch."""
+        self._ck(self._l.ellc_depth_do_regularization(self.h, int(remove_occlusions)), "ellc_depth_do_regularization")
+
     def depth_regularize_fill_regularize(self, remove_occlusions=True):
         """regularise(remove_occlusions) + fill holes + regularise(False) in one launch (createKeyFrame's middle)"""
         self._ck(self._l.ellc_depth_regularize_fill_regularize(self.h, int(remove_occlusions)), "ellc_depth_regularize_fill_regularize")
@@ -308,7 +312,8 @@ class Context:
 
     def profile_depth_stage(self, stage, frame_slot, pose, reps=20):
         """ms per call of one depth-map stage (0 regularize, 1 fill holes, 2 observe, 3 update depth image, 4 createKeyFrame's
-        regularise + fill + regularise in one launch), HIP events."""
+        regularise + fill + regularise in one launch, 5 the tracked frame's fill + regularise + update depth image in one launch),
+        HIP events."""
         pose = np.ascontiguousarray(pose, np.float32)
         ms = C.c_float(0)
         self._ck(self._l.ellc_profile_depth_stage(self.h, stage, frame_slot, _p(pose), reps, C.byref(ms)), "ellc_profile_depth_stage")

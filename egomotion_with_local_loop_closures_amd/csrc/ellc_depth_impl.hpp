@@ -36,11 +36,8 @@ ellc_status do_regularize(ellc_ctx* c, int removeOcclusions, const int* gate = n
   const int W = c->cfg.width, H = c->cfg.height;
   const int tiles_x = (W + DM_TX - 1) / DM_TX, tiles = tiles_x * ((H + DM_TY - 1) / DM_TY);
   // in place, except for the validity flags: they go to the other map's plane, which becomes this map's
-  ExportPyrArgs none;
-  for (int l = 0; l < 4; l++) { none.depth[l] = nullptr; none.var[l] = nullptr; }
-  none.W = W; none.H = H; none.steps = 0;
-  hipLaunchKernelGGL(dm_regularize<false>, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth.isValid, W, H, removeOcclusions,
-                     tiles_x, tiles, gate, none);
+  hipLaunchKernelGGL(dm_regularize, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth.isValid, W, H, removeOcclusions,
+                     tiles_x, tiles, gate);
   ELLC_HIP(c, hipGetLastError());
   std::swap(c->dm_cur.isValid, c->dm_oth.isValid);
   return ELLC_OK;
@@ -136,14 +133,28 @@ ellc_status do_reg_fill_reg(ellc_ctx* c, int removeOcclusions, bool with_sums = 
   return ELLC_OK;
 }
 
-// doRegularization(false) + updateDepthImage as one launch (dm_regularize<true>) when the image tiles into 32 x 8 blocks that halve
-// exactly for the pyramid levels the export's own launch would produce; otherwise the two stages one after the other
-ellc_status do_regularize_and_update_depth_image(ellc_ctx* c, int removeOcclusions, const int* gate) {
+// doRegularization (:1627-1635): fillDepthHoles + regularizeDepthMap in one launch (dm_fill_reg), into the other copy of the map
+ellc_status do_fill_regularize(ellc_ctx* c, int removeOcclusions, const int* gate = nullptr) {
+  const int W = c->cfg.width, H = c->cfg.height;
+  const int tiles_x = (W + DM_TX - 1) / DM_TX, tiles = tiles_x * ((H + DM_TY - 1) / DM_TY);
+  ExportPyrArgs none;
+  for (int l = 0; l < 4; l++) { none.depth[l] = nullptr; none.var[l] = nullptr; }
+  none.W = W; none.H = H; none.steps = 0;
+  hipLaunchKernelGGL(dm_fill_reg<false>, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth, c->kf_maxgrad[c->dm_kf_slot], W, H,
+                     removeOcclusions, tiles_x, tiles, gate, none);
+  ELLC_HIP(c, hipGetLastError());
+  swap_maps(c);
+  return ELLC_OK;
+}
+
+// doRegularization(false) + updateDepthImage of a tracked frame as ONE launch (dm_fill_reg<true>) when the image tiles into 32 x 8
+// blocks that halve exactly for the pyramid levels the export's own launch would produce; otherwise the stages one after the other
+ellc_status do_fill_regularize_and_update_depth_image(ellc_ctx* c, const int* gate) {
   const int W = c->cfg.width, H = c->cfg.height;
   int steps = 0;
   while (steps < 3 && steps + 1 < c->L && ((W >> steps) & 1) == 0 && ((H >> steps) & 1) == 0) steps++;
   if (!(steps > 0 && (W % DM_TX) == 0 && (H % DM_TY) == 0 && (DM_TX >> steps) >= 1 && (DM_TY >> steps) >= 1)) {
-    ellc_status s = do_regularize(c, removeOcclusions, gate);
+    ellc_status s = do_fill_regularize(c, 0, gate);
     return s != ELLC_OK ? s : do_update_depth_image(c);
   }
   invalidate_records(c, c->dm_kf_slot);   // before the first write (a failure half-way must not leave a valid tag)
@@ -155,10 +166,10 @@ ellc_status do_regularize_and_update_depth_image(ellc_ctx* c, int removeOcclusio
     ea.var[l] = kl.var;
   }
   const int tiles_x = W / DM_TX, tiles = tiles_x * (H / DM_TY);
-  hipLaunchKernelGGL(dm_regularize<true>, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth.isValid, W, H, removeOcclusions,
+  hipLaunchKernelGGL(dm_fill_reg<true>, dim3(8 * ((tiles + 7) / 8)), dim3(DM_TX * DM_TY), 0, c->stream, c->dm_cur, c->dm_oth, c->kf_maxgrad[c->dm_kf_slot], W, H, 0,
                      tiles_x, tiles, gate, ea);
   ELLC_HIP(c, hipGetLastError());
-  std::swap(c->dm_cur.isValid, c->dm_oth.isValid);
+  swap_maps(c);
   ellc_status s = build_depth_pyramid_from(c, c->dm_kf_slot, steps + 1);   // the remaining levels
   if (s != ELLC_OK) return s;
   c->kf_has_depth[c->dm_kf_slot] = 1;
@@ -360,8 +371,8 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
   a.gate = c->track_gate_d;
   launch_observe(c, a, true);
   ELLC_HIP(c, hipGetLastError());
-  if ((s = do_fill_holes(c, c->track_gate_d)) != ELLC_OK) return s;   // doRegularization(false) :1627-1635 ...
-  if ((s = do_regularize_and_update_depth_image(c, 0, c->track_gate_d)) != ELLC_OK) return s;   // ... and updateDepthImage (an unchanged map exports the same planes)
+  // doRegularization(false) :1627-1635 and updateDepthImage (an unchanged map exports the same planes): one launch
+  if ((s = do_fill_regularize_and_update_depth_image(c, c->track_gate_d)) != ELLC_OK) return s;
   // the frame slot's "last read" mark goes behind the whole chain, not behind the observation that reads it: an event record in the
   // middle of the chain held the next launch back ~10 us, and the next upload into this slot is a frame away either way
   if ((s = mark_frame_use(c, frame_slot)) != ELLC_OK) return s;
@@ -381,8 +392,8 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
     float pwo[6];
     const float zero[6] = {0, 0, 0, 0, 0, 0};
     concat_relative_f32(pose, zero, pwo);
-    if ((s = do_observe(c, frame_slot, pwo)) != ELLC_OK || (s = do_fill_holes(c)) != ELLC_OK || (s = do_regularize(c, 0)) != ELLC_OK) return s;
-    return do_update_depth_image(c);
+    if ((s = do_observe(c, frame_slot, pwo)) != ELLC_OK) return s;
+    return do_fill_regularize_and_update_depth_image(c, nullptr);
   }
   return ELLC_OK;
 }
@@ -413,6 +424,14 @@ ellc_status ellc_depth_update_depth_image(ellc_ctx* c) {
   ellc_status s = need_map(c);
   if (s != ELLC_OK) return s;
   return do_update_depth_image(c);
+}
+
+ellc_status ellc_depth_do_regularization(ellc_ctx* c, int remove_occlusions) {
+  ELLC_ENTER(c);
+  ellc_status s = need_map(c);
+  if (s != ELLC_OK) return s;
+  if (!c->kf_maxgrad_valid[c->dm_kf_slot] && (s = build_maxgrad(c, true, c->dm_kf_slot)) != ELLC_OK) return s;
+  return do_fill_regularize(c, remove_occlusions ? 1 : 0);
 }
 
 ellc_status ellc_depth_regularize_fill_regularize(ellc_ctx* c, int remove_occlusions) {
@@ -446,18 +465,20 @@ ellc_status ellc_depth_create_keyframe(ellc_ctx* c, int new_kf_slot, const float
 
 // measurement hook (bench.py): `reps` enqueues of one depth-map stage between two HIP events on the context's stream.
 // stage 0: regularizeDepthMap(false), 1: fillDepthHoles, 2: observeDepthRow against frame_slot / pose, 3: updateDepthImage
-// (export + depth / variance pyramid), 4: createKeyFrame's regularise + fill + regularise in one launch. The map keeps evolving from call to call, as it does from frame to frame.
+// (export + depth / variance pyramid), 4: createKeyFrame's regularise + fill + regularise in one launch, 5: the tracked frame's
+// fill + regularise + updateDepthImage in one launch. The map keeps evolving from call to call, as it does from frame to frame.
 ellc_status ellc_profile_depth_stage(ellc_ctx* c, int stage, int frame_slot, const float* pose_frame_wrt_kf, int reps, float* avg_ms) {
   ELLC_ENTER(c);
   ellc_status s = need_map(c);
   if (s != ELLC_OK) return s;
-  if (reps < 1 || stage < 0 || stage > 4) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (reps < 1 || stage < 0 || stage > 5) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
   auto once = [&]() -> ellc_status {
     switch (stage) {
       case 0: return do_regularize(c, 0);
       case 1: return do_fill_holes(c);
       case 2: return do_observe(c, frame_slot, pose_frame_wrt_kf);
       case 4: return do_reg_fill_reg(c, 1);
+      case 5: return do_fill_regularize_and_update_depth_image(c, nullptr);
       default: return do_update_depth_image(c);
     }
   };

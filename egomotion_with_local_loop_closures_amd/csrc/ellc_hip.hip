@@ -191,7 +191,12 @@ static ellc_status upload_pyramid(ellc_ctx* c, uint8_t* const* img, const uint8_
     ELLC_HIP(c, hipEventSynchronize(c->upload_done[k]));
   }
   std::memcpy(c->upload_stage[k], host, bytes);
-  ELLC_HIP(c, hipMemcpyAsync(img[0], c->upload_stage[k], bytes, hipMemcpyHostToDevice, st));
+  {   // the staging buffer is read by a kernel (ingest_copy_u8): no copy-engine hand-over in front of the pyramid launch
+    void* stage_dev = nullptr;
+    ELLC_HIP(c, hipHostGetDevicePointer(&stage_dev, c->upload_stage[k], 0));
+    const int blocks = (int)std::min<size_t>(1024, ((bytes >> 4) + 255) / 256 + 1);
+    hipLaunchKernelGGL(ingest_copy_u8, dim3(blocks), dim3(256), 0, st, img[0], (const uint8_t*)stage_dev, bytes);
+  }
   ELLC_HIP(c, hipEventRecord(c->upload_done[k], st));
   const ellc_status s = build_image_pyramid(c, img, st);
   if (s != ELLC_OK || frame_slot < 0) return s;

@@ -223,6 +223,51 @@ __device__ __forceinline__ void depth_pyr_merge(const float d[4], const float v[
   }
 }
 
+// updateDepthImage for a block's own 32 x 8 tile, at the end of the kernel that produced the values: level 0 of the keyframe's depth /
+// variance planes from the pixel's final smoothed values (nvalid: its flag after the border's invalidation, :1254-1315) and the
+// 16 x 4, 8 x 2 and 4 x 1 cells of the next `steps` pyramid levels the tile covers (dm_export_pyramid's arithmetic; image sizes
+// that are multiples of 32 x 8 and halve exactly `steps` times). Every thread of the block calls it.
+__device__ __forceinline__ void dm_tile_export(const ExportPyrArgs& ex, int W, int H, int bx, int by, bool inside, int i, bool nvalid, float ids, float vars) {
+  // ping-pong planes of the tile's pyramid cells: level l in [l & 1] (dm_export_pyramid with a 32 x 8 tile)
+  __shared__ float ld[2][DM_TX * DM_TY], lv[2][DM_TX * DM_TY];
+  float d = 0.0f, v = -1.0f;
+  if (inside) {
+    if (nvalid && ids >= -0.05f) {
+      d = 1.0f / ids;
+      v = vars;
+    }
+    ex.depth[0][i] = d;
+    ex.var[0][i] = v;
+  }
+  ld[0][threadIdx.x] = d;
+  lv[0][threadIdx.x] = v;
+  __syncthreads();
+  int ew = DM_TX, eh = DM_TY;
+  for (int l = 1; l <= ex.steps; l++) {
+    const int w2 = ew >> 1, h2 = eh >> 1;   // the tile's cells at level l
+    const int wl = W >> l, hl = H >> l;
+    const float* sd = ld[(l - 1) & 1];
+    const float* sv = lv[(l - 1) & 1];
+    if ((int)threadIdx.x < w2 * h2) {
+      const int cy = (int)threadIdx.x / w2, cx = (int)threadIdx.x - cy * w2;
+      const int q0 = (2 * cy) * ew + 2 * cx;
+      const float d4[4] = {sd[q0], sd[q0 + 1], sd[q0 + ew], sd[q0 + ew + 1]};
+      const float v4[4] = {sv[q0], sv[q0 + 1], sv[q0 + ew], sv[q0 + ew + 1]};
+      float od, ov;
+      depth_pyr_merge(d4, v4, od, ov);
+      const int gx = ((bx * DM_TX) >> l) + cx, gy = ((by * DM_TY) >> l) + cy;
+      if (gx < wl && gy < hl) {
+        ex.depth[l][gx + gy * wl] = od;
+        ex.var[l][gx + gy * wl] = ov;
+      }
+      ld[l & 1][cy * w2 + cx] = od;
+      lv[l & 1][cy * w2 + cx] = ov;
+    }
+    __syncthreads();
+    ew = w2; eh = h2;
+  }
+}
+
 // regularizeDepthMap's 25-neighbour stencil (:1452-1530) for the pixel at index c of LDS planes with PITCH cells per row. The
 // reference's two `continue`s become per-lane selects: a wave runs every neighbour anyway (one lane with a hypothesis there is
 // enough, and a wave of gathered candidates always has one), and without the branches the 100 LDS reads of a pixel are issued
@@ -278,13 +323,9 @@ __device__ __forceinline__ int dm_stencil25(const float* id, const float* var, c
 // pixel's update writes only its own invDepthSmoothed / varianceSmoothed / blacklisted — which no stencil reads — and isValid:
 // so the map is updated IN PLACE and only the new validity flags go to a plane of their own (valid_out, which the caller then
 // swaps in): 13 bytes read (x the halo) and at most 13 written per pixel instead of 25 + 25 through a second copy of the map.
-// EXPORT (the tracked frame's last regularisation, ellc_track_frame): the block goes on to updateDepthImage for its tile — level 0 of
-// the keyframe's depth / variance planes from the values it has just computed, and the 16 x 4, 8 x 2 and 4 x 1 cells of the next
-// three pyramid levels its 32 x 8 pixels cover (dm_export_pyramid's arithmetic; image sizes that are multiples of 32 x 8 and halve
-// exactly `steps` times) — one launch less behind it.
-template <bool EXPORT>
+// (The tracked frame's and createKeyFrame's regularisations run inside dm_fill_reg / dm_reg_fill_reg; this is the stage alone.)
 __global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA s, uint8_t* __restrict__ valid_out, int W, int H, int removeOcclusions,
-                                                               int tiles_x, int tiles_total, const int* __restrict__ gate, ExportPyrArgs ex) {
+                                                               int tiles_x, int tiles_total, const int* __restrict__ gate) {
   __shared__ DmTile t;
   __shared__ uint8_t list[DM_TX * DM_TY];
   __shared__ int wave_count[(DM_TX * DM_TY) / 64];
@@ -297,7 +338,7 @@ __global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA s, uint8
   const int x = bx * DM_TX + tx, y = by * DM_TY + ty;
   const bool inside = (x < W && y < H);
   const bool dvalid = t.valid[ty + DM_HALO][tx + DM_HALO] != 0;
-  const bool open = (gate == nullptr) || (*gate != 0);   // a closed gate (ellc_track_frame): the map passes through unchanged
+  const bool open = (gate == nullptr) || (*gate != 0);   // a closed gate: the map passes through unchanged
   const bool cand = open && inside && y >= 3 && y < H - 3 && x >= 2 && x < W - 2 && dvalid;
   r_code[threadIdx.x] = 0;
   const int ncand = dm_compact_candidates(cand, list, wave_count);
@@ -311,60 +352,15 @@ __global__ __launch_bounds__(DM_TX * DM_TY) void dm_regularize(DepthSoA s, uint8
     r_ids[p] = ids; r_vars[p] = vars;   // read only where the code is 1
   }
   __syncthreads();
-  if (!EXPORT && !inside) return;
+  if (!inside) return;
   const int i = x + y * W;
   const int code = r_code[threadIdx.x];
-  bool nvalid = dvalid && code < 2;
-  if (EXPORT && inside && (y < 3 || y >= H - 3 || x < 3 || x >= W - 3)) nvalid = false;   // updateDepthImage clears the border's flags (:1254-1315)
-  if (inside) {
-    valid_out[i] = nvalid ? 1 : 0;
-    if (code == 1) {
-      s.invDepthSmoothed[i] = r_ids[threadIdx.x];
-      s.varianceSmoothed[i] = r_vars[threadIdx.x];
-    } else if (code == 2) {
-      s.blacklisted[i] = s.blacklisted[i] - 1;
-    }
-  }
-  if constexpr (EXPORT) {
-    // ping-pong planes of the tile's pyramid cells: level l in [l & 1] (dm_export_pyramid with a 32 x 8 tile)
-    __shared__ float ld[2][DM_TX * DM_TY], lv[2][DM_TX * DM_TY];
-    float d = 0.0f, v = -1.0f;
-    if (inside) {
-      const float ids = (code == 1) ? r_ids[threadIdx.x] : s.invDepthSmoothed[i];
-      if (nvalid && ids >= -0.05f) {
-        d = 1.0f / ids;
-        v = (code == 1) ? r_vars[threadIdx.x] : s.varianceSmoothed[i];
-      }
-      ex.depth[0][i] = d;
-      ex.var[0][i] = v;
-    }
-    ld[0][threadIdx.x] = d;
-    lv[0][threadIdx.x] = v;
-    __syncthreads();
-    int ew = DM_TX, eh = DM_TY;
-    for (int l = 1; l <= ex.steps; l++) {
-      const int w2 = ew >> 1, h2 = eh >> 1;   // the tile's cells at level l
-      const int wl = W >> l, hl = H >> l;
-      const float* sd = ld[(l - 1) & 1];
-      const float* sv = lv[(l - 1) & 1];
-      if ((int)threadIdx.x < w2 * h2) {
-        const int cy = (int)threadIdx.x / w2, cx = (int)threadIdx.x - cy * w2;
-        const int q0 = (2 * cy) * ew + 2 * cx;
-        const float d4[4] = {sd[q0], sd[q0 + 1], sd[q0 + ew], sd[q0 + ew + 1]};
-        const float v4[4] = {sv[q0], sv[q0 + 1], sv[q0 + ew], sv[q0 + ew + 1]};
-        float od, ov;
-        depth_pyr_merge(d4, v4, od, ov);
-        const int gx = ((bx * DM_TX) >> l) + cx, gy = ((by * DM_TY) >> l) + cy;
-        if (gx < wl && gy < hl) {
-          ex.depth[l][gx + gy * wl] = od;
-          ex.var[l][gx + gy * wl] = ov;
-        }
-        ld[l & 1][cy * w2 + cx] = od;
-        lv[l & 1][cy * w2 + cx] = ov;
-      }
-      __syncthreads();
-      ew = w2; eh = h2;
-    }
+  valid_out[i] = (dvalid && code < 2) ? 1 : 0;
+  if (code == 1) {
+    s.invDepthSmoothed[i] = r_ids[threadIdx.x];
+    s.varianceSmoothed[i] = r_vars[threadIdx.x];
+  } else if (code == 2) {
+    s.blacklisted[i] = s.blacklisted[i] - 1;
   }
 }
 
@@ -621,6 +617,140 @@ __global__ __launch_bounds__(DM_TX * DM_TY) void dm_reg_fill_reg(DepthSoA in, De
     const int tile = by * tiles_x + bx;
     part[2 * tile] = a; part[2 * tile + 1] = n;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// doRegularization(removeOcclusions) = fillDepthHoles + regularizeDepthMap (:1627-1635) in ONE launch, the tracked frame's form (and,
+// with EXPORT, updateDepthImage for the tile behind it: dm_tile_export): dm_reg_fill_reg without its first stage. The
+// regularisation reads the filled map two pixels around the tile and the fill the flags two columns / three rows up and two down
+// around that: a snapshot of (32 + 8) x (8 + 9) pixels. A closed gate (ellc_track_frame) passes the map through unchanged — to the
+// other copy, which the caller swaps in either way.
+#define DM_GX 4
+#define DM_GYU 5
+#define DM_GYD 4
+#define DM_GW (DM_TX + 2 * DM_GX)
+#define DM_GH (DM_TY + DM_GYU + DM_GYD)
+struct DmFillReg {
+  float id[DM_GH][DM_GW], var[DM_GH][DM_GW];
+  int validity[DM_GH][DM_GW];
+  uint8_t valid0[DM_GH][DM_GW], valid2[DM_GH][DM_GW];   // flags before / after the fill (2: filled here)
+  uint16_t list[(DM_TX + 4) * (DM_TY + 4)];
+  int count_fill;
+  float ids3[DM_TX * DM_TY], vars3[DM_TX * DM_TY];
+  uint8_t code3[DM_TX * DM_TY];
+};
+template <bool EXPORT>
+__global__ __launch_bounds__(DM_TX * DM_TY) void dm_fill_reg(DepthSoA in, DepthSoA out, const float* __restrict__ maxgrad, int W, int H, int removeOcclusions,
+                                                             int tiles_x, int tiles_total, const int* __restrict__ gate, ExportPyrArgs ex) {
+  __shared__ DmFillReg t;
+  int bx, by;
+  if (!dm_tile_of_block(tiles_x, tiles_total, bx, by)) return;
+  constexpr int NT = DM_TX * DM_TY;
+  const int x0 = bx * DM_TX - DM_GX, y0 = by * DM_TY - DM_GYU;   // image position of snapshot cell (0, 0)
+  const bool open = (gate == nullptr) || (*gate != 0);
+#pragma unroll
+  for (int r = 0; r < (DM_GW * DM_GH + NT - 1) / NT; r++) {   // (as dm_tile_load_at: every round's loads in flight together)
+    const int k = min((int)threadIdx.x + r * NT, DM_GW * DM_GH - 1);
+    const int ty = k / DM_GW, tx = k - ty * DM_GW;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool inside = (x >= 0 && x < W && y >= 0 && y < H);
+    const int j = inside ? (x + y * W) : 0;
+    const uint8_t lv = in.isValid[j];
+    const float a = in.invDepth[j], b = in.variance[j];
+    const int n = in.validity[j];
+    const uint8_t v = inside ? lv : (uint8_t)0;
+    t.valid0[ty][tx] = v; t.valid2[ty][tx] = v;
+    t.id[ty][tx] = inside ? a : 0.0f;
+    t.var[ty][tx] = inside ? b : 0.0f;
+    t.validity[ty][tx] = inside ? n : 0;
+  }
+  if (threadIdx.x == 0) t.count_fill = 0;
+  __syncthreads();
+  // ---- fillDepthHoles two pixels around the tile (dm_fill_holes' test and average)
+  constexpr int R2W = DM_TX + 4, R2H = DM_TY + 4;
+#pragma unroll
+  for (int r = 0; r < (R2W * R2H + NT - 1) / NT; r++) {
+    const int q = (int)threadIdx.x + r * NT;
+    const int qq = min(q, R2W * R2H - 1);
+    const int ry = qq / R2W, tx = qq - ry * R2W + (DM_GX - 2), ty = ry + (DM_GYU - 2);
+    const int x = x0 + tx, y = y0 + ty;
+    const bool in_test = open && q < R2W * R2H && x >= 3 && x < W - 2 && y >= 3 && y < H - 3;
+    const int i = in_test ? x + y * W : 0;
+    const float mg = maxgrad[i];            // both loads before the tests (one round trip, not one per test)
+    const int bl0 = in.blacklisted[i];
+    if (!in_test || t.valid0[ty][tx]) continue;
+    if (mg < DM_MIN_ABS_GRAD_DECREASE) continue;
+    int val = 0;
+    const int ya = y + 2, yb = y - 3;
+    if (ya >= 3 && ya < H - 3)
+      for (int dx = -2; dx <= 2; dx++) { if (t.valid0[ty + 2][tx + dx]) val += t.validity[ty + 2][tx + dx]; }
+    if (yb >= 3 && yb < H - 3)
+      for (int dx = -2; dx <= 2; dx++) { if (t.valid0[ty - 3][tx + dx]) val -= t.validity[ty - 3][tx + dx]; }
+    if ((bl0 >= DM_MIN_BLACKLIST && (float)val > DM_VAL_SUM_MIN_FOR_CREATE) || (float)val > DM_VAL_SUM_MIN_FOR_UNBLACKLIST)
+      t.list[atomicAdd(&t.count_fill, 1)] = (uint16_t)(ty * DM_GW + tx);
+  }
+  __syncthreads();
+  const int n2 = t.count_fill;
+  for (int k = threadIdx.x; k < n2; k += NT) {
+    const int c = t.list[k], py = c / DM_GW, px = c - py * DM_GW;
+    float sumIdepthObs = 0.0f, sumIVarObs = 0.0f;
+    for (int dy = -2; dy < 3; dy++)
+      for (int dx = -2; dx < 3; dx++) {
+        if (!t.valid0[py + dy][px + dx]) continue;
+        const float v = t.var[py + dy][px + dx];
+        sumIdepthObs += t.id[py + dy][px + dx] / v;
+        sumIVarObs += 1.0f / v;
+      }
+    const float nid = unzero_f(sumIdepthObs / sumIVarObs);
+    // a filled pixel was invalid in the flags the averages look at: its cell can be written at once
+    t.id[py][px] = nid;
+    t.var[py][px] = DM_VAR_RANDOM_INIT_INITIAL;
+    t.validity[py][px] = 0;
+    t.valid2[py][px] = 2;   // valid, and filled here
+  }
+  __syncthreads();
+  // ---- regularizeDepthMap on the tile, on the filled map
+  const int tx = threadIdx.x & (DM_TX - 1), ty = threadIdx.x / DM_TX;
+  const int cx = tx + DM_GX, cy = ty + DM_GYU;
+  const int x = bx * DM_TX + tx, y = by * DM_TY + ty;
+  const bool inside = (x < W && y < H);
+  t.code3[threadIdx.x] = 0;
+  const bool cand3 = open && inside && y >= 3 && y < H - 3 && x >= 2 && x < W - 2 && t.valid2[cy][cx];
+  __shared__ uint8_t list3[NT];
+  __shared__ int wave_count[NT / 64];
+  const int n3 = dm_compact_candidates(cand3, list3, wave_count);
+  for (int k = threadIdx.x; k < n3; k += NT) {
+    const int p = list3[k];
+    float ids = 0.0f, vars = 0.0f;
+    const int c = (p / DM_TX + DM_GYU) * DM_GW + (p & (DM_TX - 1)) + DM_GX;
+    const int code = removeOcclusions ? dm_stencil25<DM_GW, true, true>(&t.id[0][0], &t.var[0][0], &t.validity[0][0], &t.valid2[0][0], c, ids, vars)
+                                      : dm_stencil25<DM_GW, false, true>(&t.id[0][0], &t.var[0][0], &t.validity[0][0], &t.valid2[0][0], c, ids, vars);
+    t.code3[p] = (uint8_t)code;
+    t.ids3[p] = ids; t.vars3[p] = vars;   // read only where the code is 1
+  }
+  __syncthreads();
+  // ---- the pixel's state after both stages, into the other copy of the map
+  const int i = x + y * W;
+  Hyp d;
+  d.valid = false; d.ids = 0.0f; d.vars = 0.0f;
+  if (inside) {
+    d = hyp_load(in, i);
+    const int c3 = t.code3[threadIdx.x];
+    if (t.valid2[cy][cx] == 2) {   // filled
+      d.id = t.id[cy][cx];
+      d.var = DM_VAR_RANDOM_INIT_INITIAL;
+      d.validity = 0;
+      d.bl = 0;
+      d.ids = -1.0f;
+      d.vars = -1.0f;
+    }
+    if (c3 == 1) { d.ids = t.ids3[threadIdx.x]; d.vars = t.vars3[threadIdx.x]; }
+    else if (c3 == 2) d.bl = d.bl - 1;
+    d.valid = t.valid2[cy][cx] != 0 && c3 < 2;
+    if (EXPORT && (y < 3 || y >= H - 3 || x < 3 || x >= W - 3)) d.valid = false;   // updateDepthImage clears the border's flags (:1254-1315)
+    hyp_store(out, i, d);
+  }
+  if constexpr (EXPORT) dm_tile_export(ex, W, H, bx, by, inside, i, d.valid, d.ids, d.vars);
 }
 
 // depthMap::updateDepthImage (:1254-1315), per-pixel part: invalidate the 3-px border, export level 0

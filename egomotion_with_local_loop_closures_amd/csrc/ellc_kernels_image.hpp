@@ -188,6 +188,17 @@ __global__ __launch_bounds__(256) void pyr_down_chain_u8(PyrChainArgs a) {
   }
 }
 
+// The uploaded image, from its pinned staging buffer (host memory, read across PCIe by the kernel itself) to level 0 of the slot: 16
+// bytes per lane. In place of a copy-engine transfer in front of the pyramid launch: copy engine -> compute queue is a hand-over
+// between hardware queues on the same stream, which cost the upload path tens of microseconds per frame.
+typedef uint32_t ingest_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void ingest_copy_u8(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src_host, size_t bytes) {
+  const size_t n16 = bytes >> 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+    ((ingest_u32x4*)dst)[i] = __builtin_nontemporal_load((const ingest_u32x4*)src_host + i);
+  if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) dst[(n16 << 4) + threadIdx.x] = src_host[(n16 << 4) + threadIdx.x];
+}
+
 // frame::buildMaxGradients (Frame.cpp:618-674) in one launch: a 32 x 8 tile of outputs per block; the gradient magnitude of
 // the tile plus a one-pixel ring goes through LDS, then the vertical and the horizontal 3-maximum with the reference's
 // border rules (maxgrad_magnitude / _vertical / _horizontal above are the three-pass form it replaces: same operations per

@@ -255,6 +255,10 @@ ellc_status ellc_depth_observe(ellc_ctx* ctx, int frame_slot, const float* pose_
 ellc_status ellc_depth_fill_holes(ellc_ctx* ctx);                         /* fillDepthHoles :1317-1400 */
 ellc_status ellc_depth_regularize(ellc_ctx* ctx, int remove_occlusions);  /* regularizeDepthMap :1436-1543 */
 ellc_status ellc_depth_make_inv_depth_one(ellc_ctx* ctx, float* rescale_factor); /* makeInvDepthOne :1546-1587 */
+/* depthMap::doRegularization (DepthPropagation.cpp:1627-1635) = fillDepthHoles + regularizeDepthMap(remove_occlusions) in ONE
+ * launch; the state afterwards is that of ellc_depth_fill_holes followed by ellc_depth_regularize(remove_occlusions), bit for
+ * bit (v7). */
+ellc_status ellc_depth_do_regularization(ellc_ctx* ctx, int remove_occlusions);
 /* regularizeDepthMap(remove_occlusions) + fillDepthHoles + regularizeDepthMap(false), the three stencil stages in the order
  * createKeyFrame runs them (DepthPropagation.cpp:1775-1777), in ONE launch; the state afterwards is that of the three calls
  * ellc_depth_regularize(remove_occlusions), ellc_depth_fill_holes, ellc_depth_regularize(0), bit for bit (v7). */
@@ -310,7 +314,8 @@ ellc_status ellc_profile_align(ellc_ctx* ctx, int B, const int* kf_slots, const 
 
 /* `reps` enqueues of one depth-map stage between two HIP events on the context stream (ms per call). stage 0:
  * regularizeDepthMap(false), 1: fillDepthHoles, 2: observeDepthRow against frame_slot / pose, 3: updateDepthImage, 4: createKeyFrame's
- * regularise(remove occlusions) + fill + regularise in one launch. */
+ * regularise(remove occlusions) + fill + regularise in one launch, 5: the tracked frame's fill + regularise + updateDepthImage in
+ * one launch. */
 ellc_status ellc_profile_depth_stage(ellc_ctx* ctx, int stage, int frame_slot, const float* pose_frame_wrt_kf, int reps, float* avg_ms);
 
 /* Counter calibration: stream `bytes` of device memory once per launch with 4-byte-per-lane loads (the access

@@ -234,8 +234,7 @@ class depthMap {
   }
   void updateDepthImage(bool = false) { rt->check(ellc_depth_update_depth_image(rt->ctx), "ellc_depth_update_depth_image"); }
   void doRegularization(bool removeOcclusions = false) {   // :1627-1635
-    rt->check(ellc_depth_fill_holes(rt->ctx), "ellc_depth_fill_holes");
-    rt->check(ellc_depth_regularize(rt->ctx, removeOcclusions ? 1 : 0), "ellc_depth_regularize");
+    rt->check(ellc_depth_do_regularization(rt->ctx, removeOcclusions ? 1 : 0), "ellc_depth_do_regularization");   // fill + regularise: one launch
   }
   void finaliseKeyframe() { doRegularization(); updateDepthImage(); }   // :1749-1755
   void updateKeyFrame() {}   // :1796-1802: the Sim3-scaled pose it computes is overwritten before use (:1935)

@@ -200,6 +200,26 @@ def test_make_inv_depth_one(scene, oracle):
     assert abs(ctx.depth_get_state()["invDepthSmoothed"][m].mean() - 1) < 1e-4
 
 
+@pytest.mark.parametrize("remove_occlusions", [False, True])
+def test_do_regularization_in_one_launch(scene, oracle, remove_occlusions):
+    """doRegularization (DepthPropagation.cpp:1627-1635) = fill + regularise as ONE launch (each block redoes the fill on the ring
+    its regularisation reads): every field of every pixel equals the two separate launches' and the oracle's."""
+    dm, ctx = fresh(scene, oracle)
+    dm.fill_holes(); dm.regularize(remove_occlusions)
+    ref = dm.get_state()
+    ctx.depth_fill_holes(); ctx.depth_regularize(remove_occlusions)
+    two = ctx.depth_get_state()
+    ctx.depth_set_keyframe(0); ctx.depth_set_state(scene["st"])
+    ctx.depth_do_regularization(remove_occlusions)
+    one = ctx.depth_get_state()
+    assert int(((ref["valid"] != 0) & (scene["st"]["valid"] == 0)).sum()) > 50   # the scene does fill holes
+    assert_state_equal(two, ref, "two launches")
+    assert_state_equal(one, ref, "one launch")
+    for f in FIELDS + ("blacklisted",):   # also where the hypothesis is invalid
+        assert bits_equal(one[f].astype(np.float32), two[f].astype(np.float32)), f
+    assert np.array_equal(one["valid"], two["valid"])
+
+
 @pytest.mark.parametrize("remove_occlusions", [True, False])
 def test_regularize_fill_regularize_in_one_launch(scene, oracle, remove_occlusions):
     """createKeyFrame's three stencil stages (DepthPropagation.cpp:1775-1777) as ONE launch, each block recomputing the earlier
