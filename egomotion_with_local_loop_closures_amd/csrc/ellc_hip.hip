@@ -197,8 +197,10 @@ static ellc_status upload_pyramid(ellc_ctx* c, uint8_t* const* img, const uint8_
     const int blocks = (int)std::min<size_t>(1024, ((bytes >> 4) + 255) / 256 + 1);
     hipLaunchKernelGGL(ingest_copy_u8, dim3(blocks), dim3(256), 0, st, img[0], (const uint8_t*)stage_dev, bytes);
   }
-  ELLC_HIP(c, hipEventRecord(c->upload_done[k], st));
   const ellc_status s = build_image_pyramid(c, img, st);
+  // (behind the pyramid launch, not between the two kernels: an event record there held the pyramid back ~7 us; the staging buffer is
+  // one of a ring of four and is free by the time its turn comes again either way)
+  ELLC_HIP(c, hipEventRecord(c->upload_done[k], st));
   if (s != ELLC_OK || frame_slot < 0) return s;
   if (!c->fr_ready_ev[frame_slot]) ELLC_HIP(c, hipEventCreateWithFlags(&c->fr_ready_ev[frame_slot], hipEventDisableTiming));
   ELLC_HIP(c, hipEventRecord(c->fr_ready_ev[frame_slot], st));
