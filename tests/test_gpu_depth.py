@@ -305,3 +305,48 @@ def test_observe_chain_bit_exact_on_random_scenes(oracle, ellc, case):
     dm.regularize(False); ctx.depth_regularize(False)
     assert_state_equal(ctx.depth_get_state(), dm.get_state(), "fill + regularise (case %d)" % case)
     ctx.close()
+
+
+@pytest.mark.parametrize("case", range(max(4, _depth_fuzz)))
+def test_keyframe_chain_on_random_scenes_and_odd_sizes(oracle, ellc, case):
+    """The one-launch stencil chains (doRegularization; createKeyFrame's regularise + fill + regularise with its per-tile sums, rescale
+    and export) on random scenes whose sizes do not tile: widths that are not multiples of 32, heights that are not multiples of 8 —
+    partial tiles, rings that leave the image, the un-merged rescale / export path — against the oracle."""
+    rng = np.random.default_rng(7000 + case)
+    W, H = [(328, 250), (200, 152), (480, 270), (104, 76), (640, 480), (352, 288)][case % 6]
+    levels = 3 if min(W, H) < 128 else L
+    pair = synth.make_pair(W, H, seed=900 + case, rot=float(rng.uniform(0.001, 0.01)), trans=float(rng.uniform(0.005, 0.05)))
+    fx, fy, cx, cy = pair["intrinsics"]
+    ocfg = oracle.make_config(W, H, levels, fx, fy, cx, cy)
+    kf = oracle.Frame(ocfg, pair["kf_image"], 1)
+    cur = oracle.Frame(ocfg, pair["cur_image"], 2)
+    cur.set_pose(origin=pair["xi_true"], world=pair["xi_true"])
+    st = synth.make_depth_state(W, H, 70 + case, pair["kf_image"], pair["idepth_true"])
+    st["valid"][rng.random(st["valid"].shape) < rng.uniform(0.0, 0.5)] = 0
+    ctx = ellc.Context(ellc.default_config(W, H, levels, fx=fx, fy=fy, cx=cx, cy=cy, max_keyframes=2, max_frames=1))
+    ctx.keyframe_upload(0, pair["kf_image"]); ctx.frame_upload(0, pair["cur_image"]); ctx.keyframe_from_frame(1, 0)
+    for remove_occlusions in (False, True):
+        dm = oracle.DepthMap(ocfg)
+        dm.set_keyframe(kf); dm.set_current(cur); dm.set_state(st)
+        ctx.depth_set_keyframe(0); ctx.depth_set_state(st)
+        dm.fill_holes(); dm.regularize(remove_occlusions); ctx.depth_do_regularization(remove_occlusions)
+        assert_state_equal(ctx.depth_get_state(), dm.get_state(), "doRegularization(%s) %dx%d" % (remove_occlusions, W, H))
+        dm.regularize(remove_occlusions); dm.fill_holes(); dm.regularize(False); ctx.depth_regularize_fill_regularize(remove_occlusions)
+        assert_state_equal(ctx.depth_get_state(), dm.get_state(), "regularise + fill + regularise(%s) %dx%d" % (remove_occlusions, W, H))
+    newkf = oracle.Frame(ocfg, pair["cur_image"], 5)
+    newkf.set_pose(origin=pair["xi_true"])
+    dm.create_keyframe(newkf)
+    f = ctx.depth_create_keyframe(1, pair["xi_true"])
+    assert abs(f / newkf.rescale_factor() - 1) < 5e-5   # the factor makeInvDepthOne leaves on the new keyframe (:1779, 1583)
+    ref, got = dm.get_state(), ctx.depth_get_state()
+    assert np.array_equal(got["valid"], ref["valid"]) and np.array_equal(got["blacklisted"], ref["blacklisted"])
+    m = ref["valid"] != 0
+    for fld in ("invDepth", "invDepthSmoothed", "variance", "varianceSmoothed"):
+        assert np.allclose(got[fld][m], ref[fld][m], rtol=2e-4), fld
+    for l in range(levels):
+        d_ref, v_ref = dm.pyr_level(l)
+        d, v = ctx.keyframe_depth_level(1, l)
+        if l == 0:
+            d_ref = np.where(d_ref < 0, 0, d_ref)
+        assert np.allclose(d, d_ref, rtol=2e-4) and np.allclose(v, v_ref, rtol=4e-4), l
+    ctx.close()
