@@ -38,9 +38,10 @@ for r in range(reps):
     timed("fill_holes", lambda: ctx.depth_fill_holes())
     timed("regularize", lambda: ctx.depth_regularize(False))
     timed("update_depth_image (+pyramid)", lambda: ctx.depth_update_depth_image())
+    timed("do_regularization (fill + regularise, one launch)", lambda: ctx.depth_do_regularization(False))
     timed("create_keyframe (propagate..export)", lambda: ctx.depth_create_keyframe(1, xi))
 print("valid hypotheses: %d of %d" % (int(st["valid"].sum()), W * H))
 for k, v in t.items():
     n = reps * (2 if k == "regularize" else 1)
-    print("%-38s %8.1f us per call (host wall incl. launch + sync)" % (k, 1e6 * v / n))
+    print("%-52s %8.1f us per call (host wall incl. launch + sync)" % (k, 1e6 * v / n))
 ctx.close()

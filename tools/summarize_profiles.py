@@ -126,7 +126,9 @@ f = newest(os.path.join("depth_trace", "*", "*_kernel_trace.csv"))
 if f:
     N = 640 * 480
     bpp = {"dm_regularize": 50.0, "dm_fill_holes": 50.0, "dm_observe_walk": 94.0, "dm_observe_select": None, "dm_export_level0": 21.0, "depth_pyr_level": None,
-           "dm_prop_project": 61.0, "dm_prop_fold": None, "dm_rescale": None, "dm_sum_stage1": None}
+           "dm_prop_project": 61.0, "dm_prop_fold": None, "dm_rescale": None, "dm_sum_stage1": None,
+           # the one-launch chains: a full map in and out (25 + 25 B/px), the export's planes where it rides along
+           "dm_reg_fill_reg": 50.0, "dm_fill_reg": 50.0, "dm_export_pyramid": 9.0 + 12.0 + 8.0 / 3.0}
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"].split("(")[0].split("<")[0].replace("ellc::", "").replace("void ", "")
