@@ -313,7 +313,8 @@ def test_keyframe_chain_on_random_scenes_and_odd_sizes(oracle, ellc, case):
     and export) on random scenes whose sizes do not tile: widths that are not multiples of 32, heights that are not multiples of 8 —
     partial tiles, rings that leave the image, the un-merged rescale / export path — against the oracle."""
     rng = np.random.default_rng(7000 + case)
-    W, H = [(328, 250), (200, 152), (480, 270), (104, 76), (640, 480), (352, 288)][case % 6]
+    # (2048 x 1056: 8 448 tiles — more than the export's launch re-reduces (4 096): createKeyFrame takes the un-merged sum / rescale / export path)
+    W, H = [(328, 250), (200, 152), (480, 270), (2048, 1056), (104, 76), (640, 480), (352, 288)][case % 7]
     levels = 3 if min(W, H) < 128 else L
     pair = synth.make_pair(W, H, seed=900 + case, rot=float(rng.uniform(0.001, 0.01)), trans=float(rng.uniform(0.005, 0.05)))
     fx, fy, cx, cy = pair["intrinsics"]
