@@ -8,11 +8,10 @@
 //                    keyframe switch (ImageFunc.cpp:73-87, Frame.cpp:697-871); --replicate DIR reads them back (:58-66)
 // --init-poses FILE  FLAG_INITIALIZE_NONZERO_POSE (main.cpp:207-225): one line "frameNo wx wy wz vx vy vz" (world pose,
 //                    the so3poses7.txt of the rotation-averaging step) per tracked frame; supplies the initial rotation
-// --fused            tracked frames through ellc_track_frame: the depth stages are enqueued behind the alignment and read its pose on the
-//                    device (same files, same bits). Default (--no-fused): every stage as its own call, the pose through the host —
-//                    since the host polls the alignment's result record (r03) the round trip costs less than the device-side
-//                    matrices and gates: 0.217-0.222 against 0.224-0.234 ms per frame in bench.py's loop; the fused call is for hosts
-//                    that cannot answer within microseconds
+// --no-fused         every stage of a tracked frame as its own call, the pose through the host (GetImagePoseEstimate, then observe /
+//                    regularise / export). Default (--fused): tracked frames through ellc_track_frame — the depth stages are enqueued
+//                    behind the alignment and read its pose on the device (same files, same bits); since r04 (fill + regularise +
+//                    export in one launch behind the observation) 0.207-0.209 against 0.213-0.217 ms per frame in bench.py's loop
 // --bgr              the input holds decoded full-size BGR frames (4W x 4H x 3 bytes each): grey conversion, undistortion with
 //                    the reference's hard-coded camera (ExternVariable.h:53-62, scaled to the input size) and the 1/4
 //                    resize run on the device (Frame.cpp:45-75); --no-undistort = FLAG_DO_UNDISTORTION off
@@ -45,7 +44,7 @@ int main(int argc, char** argv) {
   bool lc = false;
   int levels = 4;
   std::string save_mats, replicate, init_poses;
-  bool bgr = false, undistort = true, no_fused = true;
+  bool bgr = false, undistort = true, no_fused = false;
   int world = 1, rank = 0, device = 0, comm_port = 0;
   std::string comm_id_file;
   for (int i = 6; i < argc; i++) {
@@ -56,8 +55,8 @@ int main(int argc, char** argv) {
     else if (a == "--init-poses" && i + 1 < argc) init_poses = argv[++i];
     else if (a == "--bgr") bgr = true;
     else if (a == "--no-undistort") undistort = false;
-    else if (a == "--fused") no_fused = false;   // tracked frames through ellc_track_frame (alignment + depth stages as one device sequence)
-    else if (a == "--no-fused") no_fused = true;   // (default) every stage as its own call: GetImagePoseEstimate, then observe / regularise / export
+    else if (a == "--fused") no_fused = false;   // (default) tracked frames through ellc_track_frame (alignment + depth stages as one device sequence)
+    else if (a == "--no-fused") no_fused = true;   // every stage as its own call: GetImagePoseEstimate, then observe / regularise / export
     else if (a == "--world" && i + 1 < argc) world = std::atoi(argv[++i]);
     else if (a == "--rank" && i + 1 < argc) rank = std::atoi(argv[++i]);
     else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);

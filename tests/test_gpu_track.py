@@ -59,7 +59,7 @@ def test_track_frame_errors(ellc):
 
 
 def test_driver_fused_and_unfused_write_the_same_files(tmp_path):
-    """ellc_main --fused tracks through ellc_track_frame; by default (--no-fused) every stage is its own call: identical files."""
+    """ellc_main tracks through ellc_track_frame (--fused, the default); with --no-fused every stage is its own call: identical files."""
     from test_gpu_driver import make_sequence, W as DW, H as DH, N
     frames, _ = make_sequence()
     raw = tmp_path / "frames.raw"
