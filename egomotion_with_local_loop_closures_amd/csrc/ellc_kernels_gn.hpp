@@ -1752,20 +1752,20 @@ __device__ __forceinline__ IcaIn ica_load(const IcaRec* irec, unsigned i) {
   in.sd[3] = c.x; in.sd[4] = c.y; in.sd[5] = c.z;
   return in;
 }
-// Tolerance mode: the pixel as a 20-byte record — one 16-byte word {x | y << 12 | I << 24, d = 1 / Z, saved weight, A} in the
-// slot's crec list and B in its cZ plane, A = fx gradx, B = fy grady of the KEYFRAME image at the integer pixel — instead of the
-// 48-byte IcaRec: the pass is bound by streaming its records (r02: 203 us for a level-0 launch over 128 alignments), and the
-// row of the template Jacobian is a handful of multiply-adds of (A, B, p, q, d):  J = [-(q T + B), p T + A, B p - A q, A d,
-// B d, -d T], T = A p + B q (PixelWisePyramid.cpp:561-680 in the form fcaf_pixel uses). H^-1 still comes from the
-// compaction's exact row (ica_hinv).
-struct IcaInF { uint32_t xyI; float d, W, A, B; };
+// Tolerance mode: the pixel as ONE 16-byte record {x | y << 12 | I << 24, d = 1 / Z, saved weight, 2 gradx | 2 grady << 16} in the
+// slot's crec list instead of the 48-byte IcaRec: the pass is bound by streaming its records (r02: 203 us for a level-0 launch over
+// 128 alignments), and the row of the template Jacobian is a handful of multiply-adds of (A, B, p, q, d):  J = [-(q T + B),
+// p T + A, B p - A q, A d, B d, -d T], T = A p + B q, A = fx gradx, B = fy grady (PixelWisePyramid.cpp:561-680 in the form
+// fcaf_pixel uses). The central differences of a u8 image are multiples of one half below 256 in size: twice each is a 16-bit
+// integer, exactly (r04; r03 carried A in the record and B in a plane of its own, 20 bytes and two loads per pixel — same values:
+// fx (0.5 g2) is the product the compaction formed). H^-1 still comes from the compaction's exact row (ica_hinv).
+struct IcaInF { uint32_t xyI; float d, W; uint32_t gxy; };
 __device__ __forceinline__ IcaInF ica_load_fast(const KfLevelDev& K, unsigned i) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 v = *(const ELLC_GLOBAL u32x4*)((const ELLC_GLOBAL char*)K.crec + i * 16u);
   IcaInF in;
   const uint32_t w1 = v.y, w2 = v.z, w3 = v.w;   // (copied first: bit_cast of a vector element expression reads element 0)
-  in.xyI = v.x; in.d = __builtin_bit_cast(float, w1); in.W = __builtin_bit_cast(float, w2); in.A = __builtin_bit_cast(float, w3);
-  in.B = *(const ELLC_GLOBAL float*)((const ELLC_GLOBAL char*)K.cZ + i * 4u);
+  in.xyI = v.x; in.d = __builtin_bit_cast(float, w1); in.W = __builtin_bit_cast(float, w2); in.gxy = w3;
   return in;
 }
 template <bool FAST> struct IcaInOf { typedef IcaIn type; };
@@ -1779,7 +1779,7 @@ template <bool FAST>
 __device__ __forceinline__ typename IcaInOf<FAST>::type ica_in_empty() {
   typename IcaInOf<FAST>::type in;
   if constexpr (FAST) {
-    in.xyI = 0; in.d = 1.0f; in.W = 0.0f; in.A = 0.0f; in.B = 0.0f;
+    in.xyI = 0; in.d = 1.0f; in.W = 0.0f; in.gxy = 0u;
   } else {
     in.X = 0.0f; in.Y = 0.0f; in.Z = 1.0f; in.Ikf = 0.0f; in.W = 0.0f;
 #pragma unroll
@@ -1806,7 +1806,7 @@ __device__ __forceinline__ void ica_accumulate_pixel(float (&acc)[6], const type
     const bool oob = (t.I == -1.0f);
     const float residual = oob ? 0.0f : (t.I - byte_f32<3>(in.xyI));
     const float rw = residual * in.W;
-    const float A = in.A, B = in.B;
+    const float A = g.fx * ((float)(int)(short)(in.gxy & 0xffffu) * 0.5f), B = g.fy * ((float)((int)in.gxy >> 16) * 0.5f);   // fx gradx, fy grady
     const float T = __builtin_fmaf(A, p, B * q);
     acc[0] = __builtin_fmaf(-__builtin_fmaf(q, T, B), rw, acc[0]);
     acc[1] = __builtin_fmaf(__builtin_fmaf(p, T, A), rw, acc[1]);

@@ -21,7 +21,7 @@ struct PrepArgs {
   int need;                    // bit 0: planes Z / I / saved weight (unfused ICA kernels); bit 1: FcaRec records (FCA);
                                // bit 2: IcaRec records + per-tile sums of H (fused ICA schedule); bit 3: FcaRecF records
                                // (FCA in tolerance mode, cfg.arith = ELLC_ARITH_FAST); bit 4 (with bit 2): the ICA records in
-                               // the tolerance mode's 20-byte form (IcaInF) instead of IcaRec
+                               // the tolerance mode's 16-byte form (IcaInF) instead of IcaRec
   int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
   int tile0, level0;           // this launch covers tiles tile0 + blockIdx.x (count / scatter), levels level0 + blockIdx.x (scan)
 };
@@ -238,11 +238,10 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
       const float wsave = wgt[(unsigned)i];
       const float X = (((float)x - cx) * Z) / fx;
       const float Y = (((float)y - cy) * Z) / fy;
-      if (need & 16) {   // tolerance mode: 16-byte word + B (ica_load_fast)
+      if (need & 16) {   // tolerance mode: one 16-byte word (ica_load_fast); twice a central difference of bytes is an integer below 2^15
         const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)img[(unsigned)(y * sw + x)] << 24);
-        crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, __builtin_amdgcn_rcpf(Z)), __builtin_bit_cast(uint32_t, wsave),
-                            __builtin_bit_cast(uint32_t, fx * gradx)};
-        cZ[pos] = fy * grady;
+        const uint32_t gxy = ((uint32_t)(int)(2.0f * gradx) & 0xffffu) | ((uint32_t)(int)(2.0f * grady) << 16);
+        crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, __builtin_amdgcn_rcpf(Z)), __builtin_bit_cast(uint32_t, wsave), gxy};
       } else {
         const unsigned t3 = 3u * threadIdx.x;
         s_rec[t3] = (u32x4){__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, Ikf)};
