@@ -9,11 +9,12 @@
 typedef uint32_t u32a1 __attribute__((aligned(1)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-enum { P_TAP_UNALIGNED, P_TAP_ALIGNED, P_ROW_COALESCED, P_TAP_BYTE, P_TAP_X2, P_REC_X4, P_TAP_SCATTER, P_TAP_1ROW, P_TAP_2ROWS, P_SAMEADDR, P_TAP_STRIDE2, P_N };
+enum { P_TAP_UNALIGNED, P_TAP_ALIGNED, P_ROW_COALESCED, P_TAP_BYTE, P_TAP_X2, P_REC_X4, P_TAP_SCATTER, P_TAP_1ROW, P_TAP_2ROWS, P_SAMEADDR, P_TAP_STRIDE2, P_TAP_4COPIES, P_SCATTER_4COPIES, P_N };
 template <int PAT>
 __global__ __launch_bounds__(1024) void k(const uint8_t* __restrict__ img, int pitch, int rows, uint32_t* out) {
   const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   uint32_t acc = 0;
+  const unsigned copy_stride = (unsigned)pitch * (unsigned)rows + 1024u;   // (the four shifted copies of P_*_4COPIES)
   // a wave walks along a row band: 64 neighbouring pixels per step, like the taps of 64 neighbouring pixels of a dense level
   unsigned y = (wave * 7) % (rows - 8) + 2;
   unsigned x = 3 + lane;
@@ -45,6 +46,12 @@ __global__ __launch_bounds__(1024) void k(const uint8_t* __restrict__ img, int p
       acc ^= *(const u32a1*)(img + o - 1) ^ *(const u32a1*)(img + o - 1 + pitch);
     } else if (PAT == P_SAMEADDR) {   // every lane the same dword, 4 rows
       const unsigned oa = y * pitch + ((x - lane) & ~3u);
+      acc ^= *(const uint32_t*)(img + oa - pitch) ^ *(const uint32_t*)(img + oa) ^ *(const uint32_t*)(img + oa + pitch) ^ *(const uint32_t*)(img + oa + 2 * pitch);
+    } else if (PAT == P_TAP_4COPIES || PAT == P_SCATTER_4COPIES) {
+      // four copies of the image shifted by 0..3 bytes: the window [x - 1, x + 2] of a row is an ALIGNED dword of copy (x - 1) & 3
+      // (r04 idea; lanes 1 px apart / the semi-dense pattern of P_TAP_SCATTER)
+      const unsigned os = (PAT == P_TAP_4COPIES) ? o : (y + (lane & 3)) * pitch + 3 + lane * 5 + (x - 3 - lane);
+      const unsigned s0 = os - 1, c = s0 & 3u, oa = (s0 & ~3u) + c * copy_stride;
       acc ^= *(const uint32_t*)(img + oa - pitch) ^ *(const uint32_t*)(img + oa) ^ *(const uint32_t*)(img + oa + pitch) ^ *(const uint32_t*)(img + oa + 2 * pitch);
     } else if (PAT == P_TAP_STRIDE2) {   // lanes 2 pixels apart
       const unsigned os = y * pitch + 3 + lane * 2 + (x - 3 - lane);
@@ -80,8 +87,8 @@ void run(const char* name, int nloads, const uint8_t* img, int pitch, int rows, 
 int main() {
   const int pitch = 1280, rows = 960;
   uint8_t* img; uint32_t* out;
-  (void)hipMalloc(&img, (size_t)pitch * rows + 4096); (void)hipMalloc(&out, 64);
-  (void)hipMemset(img, 0x5a, (size_t)pitch * rows + 4096);
+  (void)hipMalloc(&img, 4 * ((size_t)pitch * rows + 1024) + 4096); (void)hipMalloc(&out, 64);
+  (void)hipMemset(img, 0x5a, 4 * ((size_t)pitch * rows + 1024) + 4096);
   run<P_TAP_UNALIGNED>("4 rows, unaligned dword, lanes 1 px apart", 4, img, pitch, rows, out);
   run<P_TAP_ALIGNED>("4 rows, dword rounded to 4 (shared by 4)", 4, img, pitch, rows, out);
   run<P_ROW_COALESCED>("4 rows, lane k = dword k (coalesced)", 4, img, pitch, rows, out);
@@ -90,6 +97,8 @@ int main() {
   run<P_TAP_X2>("4 rows, 8 bytes 4-aligned", 4, img, pitch, rows, out);
   run<P_TAP_STRIDE2>("4 rows, unaligned dword, lanes 2 px apart", 4, img, pitch, rows, out);
   run<P_TAP_SCATTER>("4 rows, unaligned dword, 5 px apart, 4 rows", 4, img, pitch, rows, out);
+  run<P_TAP_4COPIES>("4 rows, aligned dword of 4 shifted copies, 1 px apart", 4, img, pitch, rows, out);
+  run<P_SCATTER_4COPIES>("4 rows, aligned dword of 4 shifted copies, scattered", 4, img, pitch, rows, out);
   run<P_TAP_1ROW>("1 row, unaligned dword", 1, img, pitch, rows, out);
   run<P_TAP_2ROWS>("2 rows, unaligned dword", 2, img, pitch, rows, out);
   run<P_REC_X4>("16-byte records, consecutive lanes", 1, img, pitch, rows, out);
