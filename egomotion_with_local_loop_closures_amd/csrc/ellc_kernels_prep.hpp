@@ -219,7 +219,16 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
     if ((y + 1) * cols <= i) y++;
     const int x = i - y * cols;
     const uint32_t xy = ((uint32_t)y << 16) | (uint32_t)x;
-    const float Ikf = (float)img[(unsigned)(y * sw + x)];
+    // the pixel and its two row neighbours (clamped at the image's edges, Frame.cpp:185-285) from ONE unaligned dword starting at
+    // max(x - 1, 0) — three byte gathers cost the vector cache three times what the dword costs (the row's stored width and the
+    // slack behind the last level's image cover the read past x + 1)
+    typedef uint32_t u32a1 __attribute__((aligned(1)));
+    const uint32_t rowq = (need & 4) ? *(const ELLC_GLOBAL u32a1*)(img + (unsigned)(y * sw + max(x - 1, 0))) : 0u;
+    const uint32_t b0 = rowq & 0xffu, b1 = (rowq >> 8) & 0xffu, b2 = (rowq >> 16) & 0xffu;
+    const uint32_t pc = (x == 0) ? b0 : b1;                                  // I(x, y)
+    const uint32_t pxm = b0;                                                 // I(max(x - 1, 0), y)
+    const uint32_t pxp = (x == 0) ? b1 : ((x == cols - 1) ? b1 : b2);        // I(min(x + 1, cols - 1), y)
+    const float Ikf = (need & 4) ? (float)pc : (float)img[(unsigned)(y * sw + x)];
     if (need & 1) {   // unfused ICA kernels read planes
       cxy[pos] = xy;
       cZ[pos] = Z;
@@ -231,7 +240,8 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
       const int xm = max(x - 1, 0), xp = min(x + 1, cols - 1), ym = max(y - 1, 0), yp = min(y + 1, g.rows - 1);
       const float sx = (x == 0 || x == cols - 1) ? 1.0f : 0.5f;
       const float sy = (y == 0 || y == g.rows - 1) ? 1.0f : 0.5f;
-      const float gradx = sx * ((float)img[(unsigned)(y * sw + xp)] - (float)img[(unsigned)(y * sw + xm)]);
+      const float gradx = sx * ((float)pxp - (float)pxm);
+      (void)xm; (void)xp;
       const float grady = sy * ((float)img[(unsigned)(yp * sw + x)] - (float)img[(unsigned)(ym * sw + x)]);
       float J[6];
       jacobian_row<false>(gradx, grady, x, y, 1.0 / (double)Z, g, J);
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
       const float X = (((float)x - cx) * Z) / fx;
       const float Y = (((float)y - cy) * Z) / fy;
       if (need & 16) {   // tolerance mode: one 16-byte word (ica_load_fast); twice a central difference of bytes is an integer below 2^15
-        const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)img[(unsigned)(y * sw + x)] << 24);
+        const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | (pc << 24);
         const uint32_t gxy = ((uint32_t)(int)(2.0f * gradx) & 0xffffu) | ((uint32_t)(int)(2.0f * grady) << 16);
         crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, __builtin_amdgcn_rcpf(Z)), __builtin_bit_cast(uint32_t, wsave), gxy};
       } else {
