@@ -72,6 +72,8 @@ def parse():
                     "graph-capture rehearsal; 0: none)")
     ap.add_argument("--streams", type=int, default=3, help="diagnostic: batch streams the loaded library build has (ELLC_STREAMS)")
     ap.add_argument("--no-affinity", action="store_true", help="N>1: do not pin the rank to its share of the host's CPUs")
+    ap.add_argument("--cache-records", action="store_true", help="diagnostic only (NOT the contract's workload): cfg.cache_records on the main workload — the compact "
+                    "lists are kept with the keyframe slots, so the timed steps contain no compaction at all: the ceiling of what hiding it can give")
     ap.add_argument("--lib", default=None, help="diagnostic A/B only: load this build of the library instead of csrc/libellc_hip.so")
     return ap.parse_args()
 
@@ -305,7 +307,7 @@ def main():
         scenes = [synth.make_pair(W, H, seed=0x5EED + 1000 * rank + i, dense=True) for i in range(2)]
     else:
         scenes = synth.make_shared_frame_batch(W, H, B, seed=0x5EED + 1000 * rank)
-    wl = Workload(api, a, scenes, a.arith, dev_index, shared_frame=not a.dense, prime=[a.warmup, a.steps])
+    wl = Workload(api, a, scenes, a.arith, dev_index, shared_frame=not a.dense, prime=[a.warmup, a.steps], cache_records=int(a.cache_records))
     G, sched = wl.G, wl.sched
     iters_per_alignment = sum(sched)
     # ---- the gather of the resulting se(3) poses (8 floats per alignment): the batches of one launch group complete together,

@@ -51,6 +51,7 @@ struct ellc_ctx {
   struct LayoutSet {
     int id = 0;
     int nblk[ELLC_MAX_LEVELS] = {0};
+    int max_tiles[ELLC_MAX_LEVELS] = {0};       // the largest number of tiles a wave owns
     int age_rounds[ELLC_MAX_LEVELS] = {0};
     int age_cum[ELLC_MAX_LEVELS][5] = {{0}};
     ellc::LevelLayout lv_h[ELLC_MAX_LEVELS];
@@ -65,6 +66,9 @@ struct ellc_ctx {
   int *kf_slot_d = nullptr, *fr_slot_d = nullptr, *uniq_slot_d = nullptr;
   int *kf_slot_h = nullptr, *fr_slot_h = nullptr, *uniq_slot_h = nullptr;   // pinned
   float *init_pose_d = nullptr, *init_pose_h = nullptr;
+  int *build_d = nullptr, *build_h = nullptr;       // per alignment: 1 = its schedule builds the keyframe's compact lists (GnArgs::build)
+  bool ride_along = true;                           // ride-along compaction in the level-bound FCA schedule (ELLC_NO_RIDE=1, diag: every level builds in its own first launch)
+  bool cur_fused_build = false;                     // the schedule being enqueued has no compaction launch: its first launch of every level builds
   ellc::AlignState *state_d = nullptr, *state_h = nullptr;
   ellc::AlignResult* result_h = nullptr;            // pinned; written by the last kernel of a schedule through result_dev_alias
   ellc::AlignResult* result_dev_alias = nullptr;
@@ -90,7 +94,7 @@ struct ellc_ctx {
   static constexpr int STREAMS = ELLC_STREAMS;
   static constexpr int SETS = (STREAMS + 1) * MAX_COALESCE + 1;   // of which max_inflight + 1 are used (n_sets): every batch in flight may be a group of its own
   struct BatchSet {
-    int* stage_h = nullptr;                         // 9 * cap ints: kf slots, frame slots, unique slots, initial poses (cap = coalesce * max_batch)
+    int* stage_h = nullptr;                         // 10 * cap ints: kf slots, frame slots, unique slots, initial poses, build flags (cap = coalesce * max_batch)
     const int* stage_dev_alias = nullptr;
     ellc::AlignResult* result_h = nullptr;
     ellc::AlignResult* result_dev_alias = nullptr;

@@ -266,10 +266,10 @@ static int age_split_of(const ellc_ctx* c, int level, int nblk, int Bgrid, int (
 }
 
 // The layout set for launches whose grids are chosen for a batch of Bgrid alignments (ellc::LevelLayout, ellc_device.hpp): per
-// level the block count (choose_nblk), the tile size — 256 * ppt pixels, the largest of 2048 / 1024 / 512 / 256 that still gives
-// a block eight tiles on average, so that whole tiles balance — and the owner of every tile: tiles are dealt to the blocks in
-// proportion to their share of the level (1 / nblk each, or the age-balanced shares of the launch: age_split_of) by largest
-// remaining credit, i.e. interleaved over the plane. Must not be called while a stream of the context is capturing (it
+// level the block count (choose_nblk), the tile size — 64 * ppt pixels, the largest of 512 / 256 / 128 / 64 that still gives a
+// wave four tiles on average, so that whole tiles balance — and the owner of every tile: tiles are dealt to the waves of the
+// blocks in proportion to their block's share of the level (1 / nblk each, or the age-balanced shares of the launch:
+// age_split_of) by largest remaining credit, i.e. interleaved over the plane. Must not be called while a stream of the context is capturing (it
 // allocates and copies): every entry point calls ensure_layout before it enqueues.
 static ellc_status ensure_layout(ellc_ctx* c, int Bgrid, const ellc_ctx::LayoutSet** out = nullptr) {
   auto it = c->layouts.find(Bgrid);
@@ -283,18 +283,23 @@ static ellc_status ensure_layout(ellc_ctx* c, int Bgrid, const ellc_ctx::LayoutS
       const int nblk = choose_nblk(c, l, Bgrid);
       ls.nblk[l] = nblk;
       ls.age_rounds[l] = age_split_of(c, l, nblk, Bgrid, ls.age_cum[l]);
+      constexpr int WPB = ELLC_GN_THREADS / 64;   // waves per block: every wave of a block owns tiles of its own
+      const int nvb = nblk * WPB;
       int ppt = 8;
-      while (ppt > 1 && (double)n / (256.0 * ppt * nblk) < 8.0) ppt >>= 1;
-      const int T = 256 * ppt, ntiles = (n + T - 1) / T;
-      std::vector<double> w(nblk, 1.0 / nblk), credit(nblk, 0.0);
+      while (ppt > 1 && (double)n / (64.0 * ppt * nvb) < 4.0) ppt >>= 1;
+      const int T = 64 * ppt, ntiles = (n + T - 1) / T;
+      std::vector<double> w(nvb, 1.0 / nvb), credit(nvb, 0.0);
       if (ls.age_rounds[l] > 1) {
         const int per_age = nblk / ls.age_rounds[l];
-        for (int s = 0; s < nblk; s++) w[s] = (ls.age_cum[l][s / per_age + 1] - ls.age_cum[l][s / per_age]) / 65536.0 / per_age;
+        for (int s = 0; s < nvb; s++) {
+          const int q = (s / WPB) / per_age;
+          w[s] = (ls.age_cum[l][q + 1] - ls.age_cum[l][q]) / 65536.0 / per_age / WPB;
+        }
       }
-      std::vector<std::vector<int>> owned(nblk);
+      std::vector<std::vector<int>> owned(nvb);
       for (int t = 0; t < ntiles; t++) {
         int best = 0;
-        for (int s = 0; s < nblk; s++) {
+        for (int s = 0; s < nvb; s++) {
           credit[s] += w[s];
           if (credit[s] > credit[best] + 1e-12) best = s;
         }
@@ -303,10 +308,11 @@ static ellc_status ensure_layout(ellc_ctx* c, int Bgrid, const ellc_ctx::LayoutS
       }
       off_begin[l] = flat.size();
       int acc = 0;
-      for (int s = 0; s < nblk; s++) { flat.push_back(acc); acc += (int)owned[s].size(); }
+      ls.max_tiles[l] = 0;
+      for (int s = 0; s < nvb; s++) { flat.push_back(acc); acc += (int)owned[s].size(); ls.max_tiles[l] = std::max(ls.max_tiles[l], (int)owned[s].size()); }
       flat.push_back(acc);
       off_tiles[l] = flat.size();
-      for (int s = 0; s < nblk; s++) flat.insert(flat.end(), owned[s].begin(), owned[s].end());
+      for (int s = 0; s < nvb; s++) flat.insert(flat.end(), owned[s].begin(), owned[s].end());
       ls.lv_h[l].nblk = nblk; ls.lv_h[l].ppt = ppt; ls.lv_h[l].ntiles = ntiles; ls.lv_h[l].pad = 0;
     }
     int* flat_d = nullptr;
@@ -403,6 +409,7 @@ static GnArgs make_gn_args(ellc_ctx* c, int level, int B, int save_w, float* pla
   a.planes = planes;
   const ellc_ctx::LayoutSet& ls = layout_of(c, B);
   a.lay = ls.lv_d;
+  a.build = c->build_d;
   a.level = level;
   a.max_kf = c->cfg.max_keyframes;
   a.max_fr = c->cfg.max_frames;
@@ -477,6 +484,7 @@ static void select_batch_set(ellc_ctx* c, int p, int slice = 0) {
   c->fr_slot_h = bs.stage_h + cap + slice * MB;
   c->uniq_slot_h = bs.stage_h + 2 * cap;
   c->init_pose_h = (float*)(bs.stage_h + 3 * cap) + 6 * slice * MB;
+  c->build_h = bs.stage_h + 9 * cap + slice * MB;
   c->stage_dev_alias = bs.stage_dev_alias;
   c->result_h = bs.result_h + slice * MB;
   c->result_dev_alias = bs.result_dev_alias;
@@ -484,6 +492,7 @@ static void select_batch_set(ellc_ctx* c, int p, int slice = 0) {
   c->fr_slot_d = bs.stage_d + cap;
   c->uniq_slot_d = bs.stage_d + 2 * cap;
   c->init_pose_d = (float*)(bs.stage_d + 3 * cap);
+  c->build_d = bs.stage_d + 9 * cap;
   c->state_d = bs.state_d;
   c->partials_d = bs.partials_d;
 }
@@ -516,6 +525,7 @@ static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const in
     for (int u = 0; u < nu; u++) seen = seen || (un[u] == kf_slots[b]);
     if (!seen) { un.push_back(kf_slots[b]); nu++; }
     for (int i = 0; i < 6; i++) c->init_pose_h[b * 6 + i] = init_pose ? init_pose[b * 6 + i] : 0.0f;
+    c->build_h[b] = 0;         // (launch_group decides which alignments build their lists inside their schedule)
     c->result_h[b].pad = -1;   // the kernel that exports the result clears it
   }
   // The pinned staging record is read by the first kernel of the schedule (enqueue_stage_in); it may still be in flight
@@ -535,6 +545,7 @@ static void enqueue_stage_in(ellc_ctx* c, int B) {
       ss.kf[b] = b < B ? c->kf_slot_h[b] : 0;
       ss.fr[b] = b < B ? c->fr_slot_h[b] : 0;
       ss.uniq[b] = b < c->direct_nu ? c->uniq_slot_h[b] : 0;   // the slots whose lists this launch (re)builds (launch_group)
+      ss.build[b] = b < B ? c->build_h[b] : 0;
       for (int i = 0; i < 6; i++) ss.pose[b * 6 + i] = b < B ? c->init_pose_h[b * 6 + i] : 0.0f;
     }
     // (ellc_track_frame's count of the valid hypotheses rides along in further blocks of the same launch)
@@ -544,7 +555,7 @@ static void enqueue_stage_in(ellc_ctx* c, int B) {
     c->track_count_n = 0;   // done (the caller launches the count by itself if this launch did not take it)
     return;
   }
-  const int n = 9 * c->group_cap;
+  const int n = 10 * c->group_cap;
   const int copy_blocks = (n + 255) / 256;
   hipLaunchKernelGGL(stage_in, dim3(copy_blocks + (B + 255) / 256), dim3(256), 0, c->stream, c->kf_slot_d, c->stage_dev_alias, n, copy_blocks,
                      c->state_d, B, c->group_cap, c->L - 1);
@@ -557,19 +568,29 @@ static void set_age_split(ellc_ctx* c, FusedArgs& fa, int B) {
   for (int i = 0; i < 5; i++) fa.age_cum[i] = ls.age_cum[fa.g.level][i];
 }
 
-static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
+// build: the first launch of a level of a schedule whose alignments build their lists in it (GnArgs::build); ride: the launch
+// carries ride-along blocks (grd.z > 1, FusedArgs::ride_level)
+template <bool BUILD, bool RIDE>
+static void launch_fused_variant(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
   const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
   const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
   if (c->fast) {
-    if (fa.g.save_w) hipLaunchKernelGGL((gn_fca_fused<false, true, true, 1>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
-    else hipLaunchKernelGGL((gn_fca_fused<false, true, true, 0>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
-  } else if (c->pipe) {
-    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, true>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
-    else hipLaunchKernelGGL((gn_fca_fused<false, true>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    if (fa.g.save_w) hipLaunchKernelGGL((gn_fca_fused<false, true, true, 1, BUILD, RIDE>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, true, true, 0, BUILD, RIDE>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+  } else if (c->pipe || BUILD || RIDE) {
+    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, true, false, -1, BUILD, RIDE>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, true, false, -1, BUILD, RIDE>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
   } else {
     if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, false>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
     else hipLaunchKernelGGL((gn_fca_fused<false, false>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
   }
+}
+static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st, bool build = false) {
+  const bool ride = fa.ride_n > 0;
+  if (build && ride) launch_fused_variant<true, true>(c, grd, blk, fa, st);
+  else if (build) launch_fused_variant<true, false>(c, grd, blk, fa, st);
+  else if (ride) launch_fused_variant<false, true>(c, grd, blk, fa, st);
+  else launch_fused_variant<false, false>(c, grd, blk, fa, st);
 }
 
 static void launch_finish(ellc_ctx* c, int B, const FusedArgs& fa, bool adaptive = false) {
@@ -645,6 +666,8 @@ static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weight
   fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);
   fa.res = c->result_dev_alias;
   fa.ica = 0;
+  fa.prev_first = 0;
+  fa.ride_n = 0;
   fa.xcd_map = (B % 8 == 0) ? 1 : 0;
   fa.age_rounds = 0;
   for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
@@ -693,22 +716,70 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
   fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);
   fa.res = c->result_dev_alias;
   fa.ica = 0;
+  fa.prev_first = 0;
+  fa.ride_n = 0;
   fa.xcd_map = (B % 8 == 0) ? 1 : 0;
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) { fa.nblk_lv[l] = 1; fa.max_it[l] = 0; }
   fa.nblk_grid = 1;
   fa.age_rounds = 0;
   for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
+  // Ride-along compaction (gn_ride_build): the lists of every level but the coarsest are built, tile by tile, by extra blocks of the
+  // launches in front of the level's first one — the coarsest level's first launch builds its own (fcaf_build_pass). Tile k of every
+  // region of a level rides in the k-th launch of the window given to the level: the window ends at the level's first launch and is
+  // as long as the level's largest region has tiles (a shorter window — few iterations at the coarser levels — gives a wave several
+  // tiles per launch). No window at all: every level builds in its own first launch instead.
+  struct RideJob { int level, tile0, tiles; };
+  std::vector<std::vector<RideJob>> ride;
+  std::vector<char> level_rides(c->L, 0);
+  const ellc_ctx::LayoutSet& lset = layout_of(c, B);
+  if (c->cur_fused_build && c->ride_along) {
+    std::vector<int> first(c->L, 0), act;
+    int total = 0;
+    for (int l = c->L - 1; l >= 0; l--) {
+      first[l] = total;
+      total += c->cfg.max_iter[l];
+      if (c->cfg.max_iter[l] > 0) act.push_back(l);
+    }
+    ride.assign(total, std::vector<RideJob>());
+    for (size_t k = 1; k < act.size(); k++) {
+      const int l = act[k], window = first[l];   // launches in front of the level's first
+      if (window < 1) continue;
+      const int max_m = lset.max_tiles[l];
+      const int q = (max_m + window - 1) / window;           // tiles of a region per launch (1 where the window allows)
+      const int steps = (max_m + q - 1) / q;
+      const int start = window - steps;                       // as late as the level allows: the coarser levels' tiles come first
+      bool room = true;
+      for (int i = 0; i < steps; i++) room = room && ride[start + i].size() < 3;
+      if (!room) continue;
+      for (int i = 0; i < steps; i++) ride[start + i].push_back(RideJob{l, i * q, q});
+      level_rides[l] = 1;
+    }
+  }
   for (int level = c->L - 1; level >= 0; level--) {
     fa.g = make_gn_args(c, level, B, save_weights ? 1 : 0, nullptr);
     set_age_split(c, fa, B);
-    const dim3 grd(fa.g.nblk, B), blk(ELLC_GN_THREADS);
+    const dim3 blk(ELLC_GN_THREADS);
     for (int it = 0; it < c->cfg.max_iter[level]; it++) {
-      launch_fused(c, grd, blk, fa, c->stream);
+      dim3 grd(fa.g.nblk, B);
+      fa.ride_n = 0;
+      fa.ride_blocks[0] = 0;
+      if (!ride.empty())
+        for (const RideJob& j : ride[fa.seq]) {
+          const int e = fa.ride_n++;
+          fa.ride_level[e] = j.level; fa.ride_tile0[e] = j.tile0; fa.ride_tiles[e] = j.tiles;
+          fa.ride_blocks[e + 1] = fa.ride_blocks[e] + lset.nblk[j.level] * B;   // one wave per region: nblk * 4 regions per alignment, 4 waves per block
+        }
+      if (fa.ride_n > 0) {
+        const int per_layer = fa.g.nblk * B;
+        grd.z = 1 + (unsigned)((fa.ride_blocks[fa.ride_n] + per_layer - 1) / per_layer);
+      }
+      launch_fused(c, grd, blk, fa, c->stream, it == 0 && c->cur_fused_build && !level_rides[level]);
       fa.prev_level = level;
       fa.prev_nblk = fa.g.nblk;
       fa.seq++;
     }
   }
+  fa.ride_n = 0;
   launch_finish(c, B, fa);
   if (save_weights) launch_add_saved_weights(c, B);
   ELLC_HIP(c, hipGetLastError());
@@ -729,6 +800,8 @@ static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
   fa.stride_part = (size_t)c->group_cap * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
   fa.res = c->result_dev_alias;
   fa.ica = 1;
+  fa.prev_first = 0;
+  fa.ride_n = 0;
   fa.xcd_map = 0;
   fa.age_rounds = 0;
   for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
@@ -739,8 +812,14 @@ static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
     for (int it = 0; it < c->cfg.max_iter[level]; it++) {
       const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
       const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
-      if (c->fast) hipLaunchKernelGGL(gn_ica_fused<true>, grd, blk, 0, c->stream, src_state, prev_part, fa.prev_nblk, fa);
-      else hipLaunchKernelGGL(gn_ica_fused<false>, grd, blk, 0, c->stream, src_state, prev_part, fa.prev_nblk, fa);
+      if (it == 0 && c->cur_fused_build) {
+        if (c->fast) hipLaunchKernelGGL((gn_ica_fused<true, true>), grd, blk, 0, c->stream, src_state, prev_part, fa.prev_nblk, fa);
+        else hipLaunchKernelGGL((gn_ica_fused<false, true>), grd, blk, 0, c->stream, src_state, prev_part, fa.prev_nblk, fa);
+      } else {
+        if (c->fast) hipLaunchKernelGGL((gn_ica_fused<true, false>), grd, blk, 0, c->stream, src_state, prev_part, fa.prev_nblk, fa);
+        else hipLaunchKernelGGL((gn_ica_fused<false, false>), grd, blk, 0, c->stream, src_state, prev_part, fa.prev_nblk, fa);
+      }
+      fa.prev_first = (it == 0) ? 1 : 0;
       fa.prev_level = level;
       fa.prev_nblk = fa.g.nblk;
       fa.seq++;
@@ -920,7 +999,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       TRY(dev_alloc(c, &k.depth, n)); TRY(dev_alloc(c, &k.var, n)); TRY(dev_alloc(c, &k.weight, n));
       TRY(dev_alloc(c, &k.cxy, cp)); TRY(dev_alloc(c, &k.cZ, cp)); TRY(dev_alloc(c, &k.cI, cp));
       TRY(dev_alloc(c, &k.crec, cp)); TRY(dev_alloc(c, &k.cW, cp)); TRY(dev_alloc(c, &k.wlast, cp)); TRY(dev_alloc(c, &k.sd, 6 * cp));
-      TRY(dev_alloc(c, &k.blk_count, ELLC_NBLK_MAX));
+      TRY(dev_alloc(c, &k.blk_count, ELLC_NBLK_MAX * (ELLC_GN_THREADS / 64)));
       TRY(dev_alloc(c, &k.irec, cp)); TRY(dev_alloc(c, &k.hpart, (size_t)ELLC_NBLK_MAX * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
     }
     for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni + 16));
@@ -954,8 +1033,9 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   // copy), the result records (pinned), the alignment states (two launch-parity buffers), the block partials
   for (int p = 0; p < c->n_sets; p++) {
     ellc_ctx::BatchSet& bs = c->batch_set[p];
-    TRY(dev_alloc(c, &bs.stage_d, 9 * CAP));
-    TRY(host_alloc(c, &bs.stage_h, 9 * CAP));
+    TRY(dev_alloc(c, &bs.stage_d, 10 * CAP));
+    TRY(host_alloc(c, &bs.stage_h, 10 * CAP));
+    std::memset(bs.stage_h, 0, 10 * CAP * sizeof(int));
     TRY(host_alloc(c, &bs.result_h, CAP));
     TRY(dev_alloc(c, &bs.state_d, 2 * CAP));
     TRY(dev_alloc(c, &bs.partials_d, 2 * CAP * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
@@ -1040,6 +1120,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     }
     if (const char* ng = getenv("ELLC_NO_GRAPH")) c->use_graph = !(ng[0] == '1');
     if (const char* np = getenv("ELLC_NO_POLL")) c->poll_results = !(np[0] == '1');
+    if (const char* nr = getenv("ELLC_NO_RIDE")) c->ride_along = !(nr[0] == '1');
     if (const char* ga = getenv("ELLC_GRAPH_ADAPTIVE")) c->graph_adaptive = (ga[0] == '1');
     if (const char* nb = getenv("ELLC_NBLK")) {
       int l = 0;
@@ -1417,6 +1498,7 @@ static int need_of(const ellc_ctx* c, int mode) {
 // nu: keyframe slots whose compact lists are (re)built — all the unique slots of the batch, or with cfg.cache_records only
 // those whose lists are stale (possibly none)
 static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int save_weights) {
+  c->cur_fused_build = (nu < 0);   // no compaction launch: the schedule's first launch of every level builds (launch_group)
   enqueue_stage_in(c, B);   // also initialises the B alignment states
   // mask / count per level (updationOnPyrChange, ImageFunc.cpp:158) and the pose-independent per-pixel records. (Folding the
   // staging into the count launch — its tile blocks then read their keyframe slot from the pinned record, one PCIe round trip
@@ -1590,8 +1672,21 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
   bs.built_slots.clear();
   for (int v : bs.kf_slots)
     if (!c->cache_records || c->kf_rec_tag[v] != need) bs.built_slots.push_back(v);
-  const int nu = (int)bs.built_slots.size();
+  int nu = (int)bs.built_slots.size();
   for (int u = 0; u < nu; u++) c->uniq_slot_h[u] = bs.built_slots[u];
+  // r05: when every alignment of the launch has a keyframe slot of its own, no compaction launch runs: the first launch of every
+  // level builds the stale slots' lists while it makes its pixel pass (nu = -1; GnArgs::build marks those alignments). Alignments
+  // that share a slot would write the same regions side by side, and the state-driven schedule changes levels inside a launch:
+  // both keep the compaction launch (prep_build) in front of their schedule.
+  const bool fused_build = nu > 0 && c->use_fused && (int)bs.kf_slots.size() == B && !schedule_is_adaptive(c, bs.mode, B);
+  if (fused_build) {
+    for (int b = 0; b < B; b++) {
+      bool stale = false;
+      for (int v : bs.built_slots) stale = stale || (v == c->kf_slot_h[b]);
+      c->build_h[b] = stale ? 1 : 0;
+    }
+    nu = -1;
+  }
   // stream
   bool busy[ellc_ctx::STREAMS] = {};
   for (int p = 0; p < ellc_ctx::SETS; p++)
@@ -1698,6 +1793,10 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
     for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);   // rebuilt here, outside the cache's bookkeeping
     s = ensure_layout(c, grid_batch(c, B));
     if (s != ELLC_OK) return s;
+    if (nu == B && c->use_fused && !schedule_is_adaptive(c, mode, B)) {   // as launch_group: the schedule builds the lists itself
+      for (int b = 0; b < B; b++) c->build_h[b] = 1;
+      nu = -1;
+    }
     c->cur_adaptive_first = adaptive_first_launches(c, B);
     return launch_align_graph(c, B, nu, mode, save_weights, 0, false);
   }
@@ -1954,10 +2053,11 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     FusedArgs fa;
     fa.continuation = 0;
     set_track_fields(c, fa, false);
-  set_track_fields(c, fa, false);
     fa.g = a;
     fa.res = nullptr;
     fa.ica = 0;
+    fa.prev_first = 0;
+  fa.ride_n = 0;
     fa.xcd_map = (B % 8 == 0) ? 1 : 0;
     set_age_split(c, fa, B);
     fa.seq = 0;
@@ -2005,9 +2105,10 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   if (avg_ms) *avg_ms = ms / reps;
   long long V = 0;
   for (int b = 0; b < B; b++) {   // the regions of the level's layout
-    int v[ELLC_NBLK_MAX];
-    ELLC_HIP(c, copy_blocking(c, v, c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + kf_slots[b]].blk_count, sizeof(int) * a.nblk, hipMemcpyDeviceToHost));
-    for (int k = 0; k < a.nblk; k++) V += v[k];
+    int v[ELLC_NBLK_MAX * (ELLC_GN_THREADS / 64)];
+    const int nvb = a.nblk * (ELLC_GN_THREADS / 64);
+    ELLC_HIP(c, copy_blocking(c, v, c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + kf_slots[b]].blk_count, sizeof(int) * nvb, hipMemcpyDeviceToHost));
+    for (int k = 0; k < nvb; k++) V += v[k];
   }
   if (valid_pixels) *valid_pixels = V;
   if (algorithmic_bytes) *algorithmic_bytes = 4.0 * (double)c->geom_h[level].n * B + 14.0 * (double)V;

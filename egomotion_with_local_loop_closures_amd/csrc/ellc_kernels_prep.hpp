@@ -31,9 +31,11 @@ struct PrepArgs {
   int level0;                  // ica_hinv: levels level0 + blockIdx.x
 };
 
-// Second half, dense over the parked entries — every lane has a valid pixel — computes the record (three IEEE divisions in the
+// Every wave compacts the tiles it owns into its own region (tile_park: ballot ranks, the valid pixels parked in the wave's LDS
+// ring), then runs densely over the parked entries — every lane has a valid pixel — computes the record (three IEEE divisions in the
 // exact forms) and stores it; consecutive lanes write consecutive records. Without the LDS step the divisions would run for every
-// wave that holds at least one valid pixel, i.e. about four times as often on a semi-dense map.
+// wave that holds at least one valid pixel, i.e. about four times as often on a semi-dense map. No block barrier but the one in
+// front of the final sums of H.
 template <int NEED>   // compile-time copy of PrepArgs::need: the FCA variant carries no Jacobian / H-sum code (and registers)
 __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
   int level = 0;
@@ -43,12 +45,14 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
   const LevelLayout Lay = a.lay[level];
   const LevelGeom& g = a.geom[level];
   const int n = g.n;
-  const int tb = Lay.blk_begin[sub], te = Lay.blk_begin[sub + 1];
-  const int ppt = Lay.ppt, T = ppt << 8;
+  const int lane = threadIdx.x & 63;
+  int tb, te;
+  wave_tiles(Lay, sub, tb, te);
+  const int ppt = Lay.ppt, T = ppt << 6;
   const unsigned region = (unsigned)tb * (unsigned)T;
-  constexpr int QCAP = ELLC_TILE_MAX;   // (a tile's entries are consumed before the next tile is parked: the ring never wraps here)
-  __shared__ int cnt[33];
-  __shared__ uint2 ring[QCAP];
+  __shared__ BuildShared bsh;
+  uint2* ring = bsh.ring[wave_index()];
+  float* vring = bsh.vring[wave_index()];
   const float inv_cols = 1.0f / (float)g.cols;
   const ELLC_GLOBAL float* var = gptr(K.var);
   const ELLC_GLOBAL float* wgt = gptr(K.weight);
@@ -65,70 +69,52 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
   float hacc[27];
 #pragma unroll
   for (int q = 0; q < 27; q++) hacc[q] = 0.0f;
-  // The 48-byte ICA records leave through an LDS staging block of 256 records so that consecutive lanes store consecutive
-  // 16-byte words (lane-per-record, every store instruction would touch a third of each line): -5 % on the kernel. The
-  // FCA records (20 bytes exact, 16 tolerance mode) are stored directly (r01 A/B: the two extra barriers per 256 records cost more than the partial-line
-  // stores).
-  constexpr int CH = 3;
-  __shared__ u32x4 s_rec[((NEED & 4) && !(NEED & 16)) ? 256 * CH : 1];
-  ELLC_GLOBAL u32x4* rec_out = (ELLC_GLOBAL u32x4*)K.irec;
-  int running = 0;   // records of this block's region so far
-  float d[8];
-  if (tb < te) tile_load(gptr(K.depth), n, ppt, (unsigned)Lay.tiles[tb] * (unsigned)T + threadIdx.x, d);
-  for (int jt = tb; jt < te; jt++) {   // block-uniform
-    const unsigned pix0 = (unsigned)Lay.tiles[jt] * (unsigned)T + threadIdx.x;
-    const int nvalid = tile_park<QCAP>(d, ppt, pix0, 0, cnt, ring);
-    // the next tile's depths are requested before this tile's records are formed (a block's life is a chain of memory round trips)
-    if (jt + 1 < te) tile_load(gptr(K.depth), n, ppt, (unsigned)Lay.tiles[jt + 1] * (unsigned)T + threadIdx.x, d);
+  int running = 0;   // records of this wave's region so far
+  // the second plane the records need rides with the depths: the variance (FCA) or the saved weights (constant-weight records)
+  const ELLC_GLOBAL float* plane2 = (NEED == 8 || NEED == 2) ? var : wgt;
+  TileRegs tr;
+  if (tb < te) tile_load(gptr(K.depth), plane2, img, n, g.cols, g.sw, inv_cols, ppt, (unsigned)as_const(Lay.tiles)[tb] * (unsigned)T + (unsigned)lane, tr);
+  for (int jt = tb; jt < te; jt++) {   // wave-uniform
+    const unsigned pix0 = (unsigned)as_const(Lay.tiles)[jt] * (unsigned)T + (unsigned)lane;
+    const int nvalid = tile_park(tr, ppt, pix0, 0, ring, vring);
+    // the next tile's planes are requested before this tile's records are formed (a wave's life is a chain of memory round trips)
+    if (jt + 1 < te) tile_load(gptr(K.depth), plane2, img, n, g.cols, g.sw, inv_cols, ppt, (unsigned)as_const(Lay.tiles)[jt + 1] * (unsigned)T + (unsigned)lane, tr);
     const unsigned tile_off = region + (unsigned)running;
   if constexpr (NEED == 8 || NEED == 2) {
-    // FCA records: up to four records per thread and trip, all their gathers (the image byte and the variance of each) issued
-    // before the first is used — one memory round trip per 1024 records instead of one per 256
-    constexpr int U = 4;
-    for (int r0 = 0; r0 < nvalid; r0 += U * 256) {   // block-uniform trip count
-      int ii[U], xx[U], yy[U];
-      float ZZ[U], vv[U];
-      uint8_t Ib[U];
-      bool act[U];
-#pragma unroll
-      for (int k = 0; k < U; k++) {
-        const int r = r0 + k * 256 + (int)threadIdx.x;
-        act[k] = r < nvalid;
-        const uint2 e = ring[act[k] ? r : 0];   // (an idle lane reads entry 0: a valid address, nothing is stored)
-        ii[k] = (int)e.x;
-        ZZ[k] = __builtin_bit_cast(float, e.y);
-        pix_xy(ii[k], cols, inv_cols, xx[k], yy[k]);
-        Ib[k] = img[(unsigned)(yy[k] * sw + xx[k])];
-        vv[k] = var[(unsigned)ii[k]];
-      }
-#pragma unroll
-      for (int k = 0; k < U; k++) {
-        if (!act[k]) continue;
-        const unsigned pos = tile_off + (unsigned)(r0 + k * 256) + threadIdx.x;
-        const int x = xx[k], y = yy[k];
-        const float Z = ZZ[k];
+    // FCA records: everything a record needs was parked with the pixel
+    for (int r0 = 0; r0 < nvalid; r0 += 64) {   // wave-uniform trip count
+      const int r = r0 + lane;
+      if (r < nvalid) {
+        const uint2 e = ring[r];
+        const float Z = __builtin_bit_cast(float, e.y), vv = vring[r];
+        const uint32_t Ib = e.x >> 24;
+        int x, y;
+        pix_xy((int)(e.x & 0xffffffu), cols, inv_cols, x, y);
+        const unsigned pos = tile_off + (unsigned)r;
         if constexpr (NEED == 8) {   // tolerance mode: one 16-byte record per pixel (FcaRecF)
-          const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | (uint32_t)Ib[k];   // FcaRecF: y < 4096 as f32 has its 12 low bits clear
+          const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | Ib;   // FcaRecF: y < 4096 as f32 has its 12 low bits clear
           const float dd = __builtin_amdgcn_rcpf(Z);
           const float pn = ((float)x - g.cx) * g.rfx;   // u / fx (fcaf_pixel forms v / fy from y)
-          crec[pos] = (u32x4){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, vv[k]), __builtin_bit_cast(uint32_t, dd)};
+          crec[pos] = (u32x4){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, vv), __builtin_bit_cast(uint32_t, dd)};
         } else {   // one 20-byte record per pixel (FcaRec): a 16-byte word and a 4-byte word
-          const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)Ib[k] << 24);
+          const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | (Ib << 24);
           const double invZ = 1.0 / (double)Z;
           const unsigned long long zb = __builtin_bit_cast(unsigned long long, invZ);
-          ELLC_GLOBAL char* r = (ELLC_GLOBAL char*)K.crec + pos * (unsigned)sizeof(FcaRec);
+          ELLC_GLOBAL char* rp = (ELLC_GLOBAL char*)K.crec + pos * (unsigned)sizeof(FcaRec);
           typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
-          *(ELLC_GLOBAL u32x4a*)r = (u32x4a){xyI, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, vv[k]), (uint32_t)zb};
-          *(ELLC_GLOBAL uint32_t*)(r + 16) = (uint32_t)(zb >> 32);
+          *(ELLC_GLOBAL u32x4a*)rp = (u32x4a){xyI, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, vv), (uint32_t)zb};
+          *(ELLC_GLOBAL uint32_t*)(rp + 16) = (uint32_t)(zb >> 32);
         }
       }
     }
   } else
-  for (int r0 = 0; r0 < nvalid; r0 += 256) {   // block-uniform trip count
-    const int r = r0 + (int)threadIdx.x;
+  for (int r0 = 0; r0 < nvalid; r0 += 64) {   // wave-uniform trip count
+    // the record at position p of the wave's region belongs to lane p mod 64, as in the Gauss-Newton launches that walk the region and
+    // in the one that builds it itself (ica_build_pass): the per-lane sums of H — hence the bits of H^-1 — do not depend on who built the lists
+    const int r = r0 + ((lane - running) & 63);
     if (r < nvalid) {
     const uint2 e = ring[r];
-    const int i = (int)e.x;
+    const int i = (int)(e.x & 0xffffffu);
     const float Z = __builtin_bit_cast(float, e.y);
     const unsigned pos = tile_off + (unsigned)r;
     int x, y;
@@ -148,7 +134,7 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
       cxy[pos] = xy;
       cZ[pos] = Z;
       cI[pos] = Ikf;
-      cW[pos] = wgt[(unsigned)i];
+      cW[pos] = vring[r];
     }
     if (need & 4) {   // ICA record: template-gradient Jacobian at the integer pixel (PixelWisePyramid.cpp:561-680)
       // frame::calculateGradient of the keyframe level image at (y,x)  (Frame.cpp:185-285)
@@ -159,18 +145,18 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
       const float grady = sy * ((float)img[(unsigned)(yp * sw + x)] - (float)img[(unsigned)(ym * sw + x)]);
       float J[6];
       jacobian_row<false>(gradx, grady, x, y, 1.0 / (double)Z, g, J);
-      const float wsave = wgt[(unsigned)i];
+      const float wsave = vring[r];
       const float X = (((float)x - cx) * Z) / fx;
       const float Y = (((float)y - cy) * Z) / fy;
       if (need & 16) {   // tolerance mode: one 16-byte word (ica_load_fast); twice a central difference of bytes is an integer below 2^15
         const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | (pc << 24);
         const uint32_t gxy = ((uint32_t)(int)(2.0f * gradx) & 0xffffu) | ((uint32_t)(int)(2.0f * grady) << 16);
         crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, __builtin_amdgcn_rcpf(Z)), __builtin_bit_cast(uint32_t, wsave), gxy};
-      } else {
-        const unsigned t3 = 3u * threadIdx.x;
-        s_rec[t3] = (u32x4){__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, Ikf)};
-        s_rec[t3 + 1] = (u32x4){__builtin_bit_cast(uint32_t, wsave), __builtin_bit_cast(uint32_t, J[0]), __builtin_bit_cast(uint32_t, J[1]), __builtin_bit_cast(uint32_t, J[2])};
-        s_rec[t3 + 2] = (u32x4){__builtin_bit_cast(uint32_t, J[3]), __builtin_bit_cast(uint32_t, J[4]), __builtin_bit_cast(uint32_t, J[5]), 0u};
+      } else {   // IcaRec: three 16-byte words
+        ELLC_GLOBAL u32x4* ro = (ELLC_GLOBAL u32x4*)((ELLC_GLOBAL char*)K.irec + pos * (unsigned)sizeof(IcaRec));
+        ro[0] = (u32x4){__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, Ikf)};
+        ro[1] = (u32x4){__builtin_bit_cast(uint32_t, wsave), __builtin_bit_cast(uint32_t, J[0]), __builtin_bit_cast(uint32_t, J[1]), __builtin_bit_cast(uint32_t, J[2])};
+        ro[2] = (u32x4){__builtin_bit_cast(uint32_t, J[3]), __builtin_bit_cast(uint32_t, J[4]), __builtin_bit_cast(uint32_t, J[5]), 0u};
       }
       int q = 0;
 #pragma unroll
@@ -181,18 +167,11 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
       }
     }
     }
-    if ((NEED & 4) && !(NEED & 16)) {
-      __syncthreads();
-      const int chunks = min(256, nvalid - r0) * CH;
-      const unsigned obase = (tile_off + (unsigned)r0) * CH;
-      for (int cidx = (int)threadIdx.x; cidx < chunks; cidx += 256) rec_out[obase + (unsigned)cidx] = s_rec[cidx];
-      __syncthreads();
-    }
   }
     running += nvalid;
-    __syncthreads();   // the ring and the counts are reused by the next tile
+    __builtin_amdgcn_wave_barrier();   // (the ring is reused by the next tile)
   }
-  if (threadIdx.x == 0) K.blk_count[sub] = running;
+  if (lane == 0) K.blk_count[sub * (ELLC_GN_THREADS / 64) + wave_index()] = running;
   if (need & 4) block_reduce_store<27>(hacc, K.hpart + (size_t)sub * ELLC_PART_STRIDE);   // block-uniform condition
 }
 
