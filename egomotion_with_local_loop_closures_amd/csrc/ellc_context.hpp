@@ -51,7 +51,6 @@ struct ellc_ctx {
   struct LayoutSet {
     int id = 0;
     int nblk[ELLC_MAX_LEVELS] = {0};
-    int max_tiles[ELLC_MAX_LEVELS] = {0};       // the largest number of tiles a wave owns
     int age_rounds[ELLC_MAX_LEVELS] = {0};
     int age_cum[ELLC_MAX_LEVELS][5] = {{0}};
     ellc::LevelLayout lv_h[ELLC_MAX_LEVELS];
@@ -67,7 +66,6 @@ struct ellc_ctx {
   int *kf_slot_h = nullptr, *fr_slot_h = nullptr, *uniq_slot_h = nullptr;   // pinned
   float *init_pose_d = nullptr, *init_pose_h = nullptr;
   int *build_d = nullptr, *build_h = nullptr;       // per alignment: 1 = its schedule builds the keyframe's compact lists (GnArgs::build)
-  bool ride_along = true;                           // ride-along compaction in the level-bound FCA schedule (ELLC_NO_RIDE=1, diag: every level builds in its own first launch)
   bool cur_fused_build = false;                     // the schedule being enqueued has no compaction launch: its first launch of every level builds
   ellc::AlignState *state_d = nullptr, *state_h = nullptr;
   ellc::AlignResult* result_h = nullptr;            // pinned; written by the last kernel of a schedule through result_dev_alias

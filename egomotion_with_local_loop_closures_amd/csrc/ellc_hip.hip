@@ -308,8 +308,7 @@ static ellc_status ensure_layout(ellc_ctx* c, int Bgrid, const ellc_ctx::LayoutS
       }
       off_begin[l] = flat.size();
       int acc = 0;
-      ls.max_tiles[l] = 0;
-      for (int s = 0; s < nvb; s++) { flat.push_back(acc); acc += (int)owned[s].size(); ls.max_tiles[l] = std::max(ls.max_tiles[l], (int)owned[s].size()); }
+      for (int s = 0; s < nvb; s++) { flat.push_back(acc); acc += (int)owned[s].size(); }
       flat.push_back(acc);
       off_tiles[l] = flat.size();
       for (int s = 0; s < nvb; s++) flat.insert(flat.end(), owned[s].begin(), owned[s].end());
@@ -568,29 +567,25 @@ static void set_age_split(ellc_ctx* c, FusedArgs& fa, int B) {
   for (int i = 0; i < 5; i++) fa.age_cum[i] = ls.age_cum[fa.g.level][i];
 }
 
-// build: the first launch of a level of a schedule whose alignments build their lists in it (GnArgs::build); ride: the launch
-// carries ride-along blocks (grd.z > 1, FusedArgs::ride_level)
-template <bool BUILD, bool RIDE>
+// build: the first launch of a level of a schedule whose alignments build their lists in it (GnArgs::build)
+template <bool BUILD>
 static void launch_fused_variant(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
   const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
   const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
   if (c->fast) {
-    if (fa.g.save_w) hipLaunchKernelGGL((gn_fca_fused<false, true, true, 1, BUILD, RIDE>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
-    else hipLaunchKernelGGL((gn_fca_fused<false, true, true, 0, BUILD, RIDE>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
-  } else if (c->pipe || BUILD || RIDE) {
-    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, true, false, -1, BUILD, RIDE>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
-    else hipLaunchKernelGGL((gn_fca_fused<false, true, false, -1, BUILD, RIDE>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    if (fa.g.save_w) hipLaunchKernelGGL((gn_fca_fused<false, true, true, 1, BUILD>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, true, true, 0, BUILD>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+  } else if (c->pipe || BUILD) {
+    if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, true, false, -1, BUILD>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    else hipLaunchKernelGGL((gn_fca_fused<false, true, false, -1, BUILD>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
   } else {
     if (c->geom_h[0].divc_ok) hipLaunchKernelGGL((gn_fca_fused<true, false>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
     else hipLaunchKernelGGL((gn_fca_fused<false, false>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
   }
 }
 static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st, bool build = false) {
-  const bool ride = fa.ride_n > 0;
-  if (build && ride) launch_fused_variant<true, true>(c, grd, blk, fa, st);
-  else if (build) launch_fused_variant<true, false>(c, grd, blk, fa, st);
-  else if (ride) launch_fused_variant<false, true>(c, grd, blk, fa, st);
-  else launch_fused_variant<false, false>(c, grd, blk, fa, st);
+  if (build) launch_fused_variant<true>(c, grd, blk, fa, st);
+  else launch_fused_variant<false>(c, grd, blk, fa, st);
 }
 
 static void launch_finish(ellc_ctx* c, int B, const FusedArgs& fa, bool adaptive = false) {
@@ -607,7 +602,7 @@ static void launch_finish(ellc_ctx* c, int B, const FusedArgs& fa, bool adaptive
 static void launch_add_saved_weights(ellc_ctx* c, int B) {
   // (blocks per alignment and level: enough for ~2 records per thread at level 0 of a semi-dense map when the batch is small —
   // the loop is a chain of three dependent memory operations per record)
-  hipLaunchKernelGGL(gn_add_saved_weights_all, dim3(B <= 4 ? 128 : 32, B, c->L), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d,
+  hipLaunchKernelGGL(gn_add_saved_weights_all, dim3(B <= 4 ? 256 : 32, B, c->L), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d,
                      layout_of(c, B).lv_d, c->state_d, c->cfg.max_keyframes, c->fast ? 1 : 0);
 }
 
@@ -667,7 +662,6 @@ static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weight
   fa.res = c->result_dev_alias;
   fa.ica = 0;
   fa.prev_first = 0;
-  fa.ride_n = 0;
   fa.xcd_map = (B % 8 == 0) ? 1 : 0;
   fa.age_rounds = 0;
   for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
@@ -717,69 +711,25 @@ static ellc_status enqueue_schedule_fused(ellc_ctx* c, int B, int save_weights) 
   fa.res = c->result_dev_alias;
   fa.ica = 0;
   fa.prev_first = 0;
-  fa.ride_n = 0;
   fa.xcd_map = (B % 8 == 0) ? 1 : 0;
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) { fa.nblk_lv[l] = 1; fa.max_it[l] = 0; }
   fa.nblk_grid = 1;
   fa.age_rounds = 0;
   for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
-  // Ride-along compaction (gn_ride_build): the lists of every level but the coarsest are built, tile by tile, by extra blocks of the
-  // launches in front of the level's first one — the coarsest level's first launch builds its own (fcaf_build_pass). Tile k of every
-  // region of a level rides in the k-th launch of the window given to the level: the window ends at the level's first launch and is
-  // as long as the level's largest region has tiles (a shorter window — few iterations at the coarser levels — gives a wave several
-  // tiles per launch). No window at all: every level builds in its own first launch instead.
-  struct RideJob { int level, tile0, tiles; };
-  std::vector<std::vector<RideJob>> ride;
-  std::vector<char> level_rides(c->L, 0);
-  const ellc_ctx::LayoutSet& lset = layout_of(c, B);
-  if (c->cur_fused_build && c->ride_along) {
-    std::vector<int> first(c->L, 0), act;
-    int total = 0;
-    for (int l = c->L - 1; l >= 0; l--) {
-      first[l] = total;
-      total += c->cfg.max_iter[l];
-      if (c->cfg.max_iter[l] > 0) act.push_back(l);
-    }
-    ride.assign(total, std::vector<RideJob>());
-    for (size_t k = 1; k < act.size(); k++) {
-      const int l = act[k], window = first[l];   // launches in front of the level's first
-      if (window < 1) continue;
-      const int max_m = lset.max_tiles[l];
-      const int q = (max_m + window - 1) / window;           // tiles of a region per launch (1 where the window allows)
-      const int steps = (max_m + q - 1) / q;
-      const int start = window - steps;                       // as late as the level allows: the coarser levels' tiles come first
-      bool room = true;
-      for (int i = 0; i < steps; i++) room = room && ride[start + i].size() < 3;
-      if (!room) continue;
-      for (int i = 0; i < steps; i++) ride[start + i].push_back(RideJob{l, i * q, q});
-      level_rides[l] = 1;
-    }
-  }
+  // (r05, measured and not kept — commit 2f26880: the finer levels' lists built tile by tile by extra blocks of the coarse levels'
+  // launches, "ride-along": the compaction costs its HBM time wherever it runs — the launches that carried it took 20-30 us instead of
+  // 15, the other streams' level-0 launches 66 instead of 55: 0.1418 against 0.1299 ms per step)
   for (int level = c->L - 1; level >= 0; level--) {
     fa.g = make_gn_args(c, level, B, save_weights ? 1 : 0, nullptr);
     set_age_split(c, fa, B);
-    const dim3 blk(ELLC_GN_THREADS);
+    const dim3 grd(fa.g.nblk, B), blk(ELLC_GN_THREADS);
     for (int it = 0; it < c->cfg.max_iter[level]; it++) {
-      dim3 grd(fa.g.nblk, B);
-      fa.ride_n = 0;
-      fa.ride_blocks[0] = 0;
-      if (!ride.empty())
-        for (const RideJob& j : ride[fa.seq]) {
-          const int e = fa.ride_n++;
-          fa.ride_level[e] = j.level; fa.ride_tile0[e] = j.tile0; fa.ride_tiles[e] = j.tiles;
-          fa.ride_blocks[e + 1] = fa.ride_blocks[e] + lset.nblk[j.level] * B;   // one wave per region: nblk * 4 regions per alignment, 4 waves per block
-        }
-      if (fa.ride_n > 0) {
-        const int per_layer = fa.g.nblk * B;
-        grd.z = 1 + (unsigned)((fa.ride_blocks[fa.ride_n] + per_layer - 1) / per_layer);
-      }
-      launch_fused(c, grd, blk, fa, c->stream, it == 0 && c->cur_fused_build && !level_rides[level]);
+      launch_fused(c, grd, blk, fa, c->stream, it == 0 && c->cur_fused_build);
       fa.prev_level = level;
       fa.prev_nblk = fa.g.nblk;
       fa.seq++;
     }
   }
-  fa.ride_n = 0;
   launch_finish(c, B, fa);
   if (save_weights) launch_add_saved_weights(c, B);
   ELLC_HIP(c, hipGetLastError());
@@ -801,7 +751,6 @@ static ellc_status enqueue_schedule_ica_fused(ellc_ctx* c, int B) {
   fa.res = c->result_dev_alias;
   fa.ica = 1;
   fa.prev_first = 0;
-  fa.ride_n = 0;
   fa.xcd_map = 0;
   fa.age_rounds = 0;
   for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
@@ -1120,7 +1069,6 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     }
     if (const char* ng = getenv("ELLC_NO_GRAPH")) c->use_graph = !(ng[0] == '1');
     if (const char* np = getenv("ELLC_NO_POLL")) c->poll_results = !(np[0] == '1');
-    if (const char* nr = getenv("ELLC_NO_RIDE")) c->ride_along = !(nr[0] == '1');
     if (const char* ga = getenv("ELLC_GRAPH_ADAPTIVE")) c->graph_adaptive = (ga[0] == '1');
     if (const char* nb = getenv("ELLC_NBLK")) {
       int l = 0;
@@ -1517,6 +1465,20 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
   return ELLC_OK;
 }
 
+// true: a schedule over B alignments (each with a keyframe slot of its own) builds the compact lists in the first launch of every
+// level; false: a compaction launch (prep_build) runs in front of it. Small launches keep the compaction launch: all levels' tiles
+// at once, one trip to memory deep, where the first launch of each level would walk its few tiles one trip after the other
+// (a single 640x480 alignment: 0.223 ms with the launch, 0.234 fused).
+#ifndef ELLC_FUSE_MASK
+#define ELLC_FUSE_MASK 15   // bit 0: FCA tolerance mode, 1: FCA exact, 2: ICA tolerance mode, 3: ICA exact (A/B builds)
+#endif
+static bool builds_in_schedule(const ellc_ctx* c, int mode, int B) {
+  if (!c->use_fused || schedule_is_adaptive(c, mode, B)) return false;
+  const int bit = (mode == ELLC_MODE_ICA ? 4 : 1) << (c->fast ? 0 : 1);
+  if (!(ELLC_FUSE_MASK & bit)) return false;
+  return grid_batch(c, B) >= 8;
+}
+
 // true: the batch's launch sequence is launched kernel by kernel; false: replayed from a captured graph
 static bool launches_directly(const ellc_ctx* c, int mode, int B) {
   return !c->use_graph || (!c->graph_adaptive && (schedule_is_adaptive(c, mode, B) || B <= c->direct_max_batch));
@@ -1678,7 +1640,7 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
   // level builds the stale slots' lists while it makes its pixel pass (nu = -1; GnArgs::build marks those alignments). Alignments
   // that share a slot would write the same regions side by side, and the state-driven schedule changes levels inside a launch:
   // both keep the compaction launch (prep_build) in front of their schedule.
-  const bool fused_build = nu > 0 && c->use_fused && (int)bs.kf_slots.size() == B && !schedule_is_adaptive(c, bs.mode, B);
+  const bool fused_build = nu > 0 && (int)bs.kf_slots.size() == B && builds_in_schedule(c, bs.mode, B);
   if (fused_build) {
     for (int b = 0; b < B; b++) {
       bool stale = false;
@@ -1793,7 +1755,7 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
     for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);   // rebuilt here, outside the cache's bookkeeping
     s = ensure_layout(c, grid_batch(c, B));
     if (s != ELLC_OK) return s;
-    if (nu == B && c->use_fused && !schedule_is_adaptive(c, mode, B)) {   // as launch_group: the schedule builds the lists itself
+    if (nu == B && builds_in_schedule(c, mode, B)) {   // as launch_group: the schedule builds the lists itself
       for (int b = 0; b < B; b++) c->build_h[b] = 1;
       nu = -1;
     }
@@ -2057,7 +2019,6 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     fa.res = nullptr;
     fa.ica = 0;
     fa.prev_first = 0;
-  fa.ride_n = 0;
     fa.xcd_map = (B % 8 == 0) ? 1 : 0;
     set_age_split(c, fa, B);
     fa.seq = 0;

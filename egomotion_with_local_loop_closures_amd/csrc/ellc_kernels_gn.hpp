@@ -1517,11 +1517,6 @@ struct FusedArgs {
   int xcd_map;          // 1: blocks are renumbered so that all blocks of an alignment run on one XCD (see gn_fca_fused)
   AlignResult* res;     // gn_fused_finish: host-visible result records (null: none)
   int ica;              // 1: constant-weight schedule (gn_ica_fused): the pending sums are b only, H^-1 comes from the keyframe slot
-  // ride-along compaction (gn_ride_build): the blocks of this launch with blockIdx.z > 0 build, for up to ELLC_RIDE_MAX levels at
-  // once, the tiles [ride_tile0, ride_tile0 + ride_tiles) of every region of level ride_level[e] for the alignments that build their
-  // lists (GnArgs::build); ride_blocks[e]: prefix of the blocks each entry takes. ride_n = 0: none.
-  int ride_n;
-  int ride_level[3], ride_tile0[3], ride_tiles[3], ride_blocks[4];
   int prev_first;       // 1: the launch whose sums are pending was the first of its level: for the alignments that built their lists in it
                         // (GnArgs::build) the sums hold H as well (solve mode 3) and block 0 leaves the level's H^-1 with the keyframe slot
   // state-driven schedule (gn_fca_adaptive): blocks and iteration caps per level, the grid's x extent
@@ -1745,100 +1740,15 @@ __device__ __forceinline__ void fca_build_pass_exact(const GnArgs& a, const KfLe
   fca_acc_unpack<false>(acc, sums);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Ride-along compaction (r05). The launches of the coarse levels are chains of latency — a solve, a handful of pixel steps, a
-// reduction — that leave the memory system and most wave slots of the device idle, and the compaction of the finer levels does not
-// depend on the pose: so the blocks with blockIdx.z > 0 of those launches build the finer levels' lists while the blocks with
-// blockIdx.z = 0 iterate. Tile k of every region of a level rides in the k-th of the launches given to that level, in stream
-// order before the level's first launch (enqueue_schedule_fused lays them out); a wave builds the tile(s) of one region:
-// running count from blk_count (left by the previous chunk's launch), ppt coalesced loads of depth / variance / intensity per tile,
-// ballot ranks, the records stored straight at region + running + rank (no LDS: the record is formed by the lane that loaded the
-// pixel), the new count back to blk_count. What a launch group's schedule spent on compaction before — two launches in front of
-// it (r01-r04), or a first launch per level bound by the planes' way from memory (fcaf_build_pass) — now runs in the shadow of
-// launches that were there anyway: the same batch pipeline without any compaction takes 0.100 ms per step, with it in front 0.131.
-// A wave takes ONE tile per launch where the iteration caps allow it (one trip to memory: a first version gave a wave two tiles of
-// level 1 per launch and the launches that carried them took 30 us instead of 15), and a launch carries tiles of several levels.
-template <bool FAST>
-__device__ __forceinline__ void gn_ride_build(const FusedArgs& fa) {
-  const GnArgs& a = fa.g;
-  int r = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * (blockIdx.z - 1)));
-  int e = 0;
-  while (e < fa.ride_n && r >= fa.ride_blocks[e + 1]) e++;
-  if (e >= fa.ride_n) return;
-  r -= fa.ride_blocks[e];
-  const int lvl = fa.ride_level[e], tile0 = fa.ride_tile0[e], ntile = fa.ride_tiles[e];
-  const LevelLayout lay = a.lay[lvl];
-  const int nvb = lay.nblk * (ELLC_GN_THREADS / 64);
-  const int u = r * (ELLC_GN_THREADS / 64) + wave_index();
-  const int B = (int)gridDim.y;
-  if (u >= nvb * B) return;
-  const int b = u / nvb, vb = u - b * nvb;
-  if (as_global(a.build)[b] == 0) return;
-  const KfLevelDev K = a.kf_tab[lvl * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
-  const LevelGeom g = a.geom[lvl];
-  const int tb = as_const(lay.blk_begin)[vb], te = as_const(lay.blk_begin)[vb + 1];
-  const int t0 = tb + tile0, t1 = min(te, t0 + ntile);
-  if (t0 >= t1 && tile0 != 0) return;   // nothing of this region in this launch (the launch with tile 0 always leaves a count)
-  const int lane = threadIdx.x & 63;
-  const int ppt = lay.ppt, T = ppt << 6;
-  const float inv_cols = 1.0f / (float)g.cols;
-  int running = tile0 == 0 ? 0 : __builtin_amdgcn_readfirstlane(as_global(K.blk_count)[vb]);
-  const unsigned region = (unsigned)tb * (unsigned)T;
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  TileRegs tr;
-  if (t0 < t1) tile_load(as_global(K.depth), as_global(K.var), as_global(K.img), g.n, g.cols, g.sw, inv_cols, ppt, (unsigned)as_const(lay.tiles)[t0] * (unsigned)T + (unsigned)lane, tr);
-  for (int jt = t0; jt < t1; jt++) {
-    const unsigned pix0 = (unsigned)as_const(lay.tiles)[jt] * (unsigned)T + (unsigned)lane;
-    TileRegs cur = tr;
-    if (jt + 1 < t1) tile_load(as_global(K.depth), as_global(K.var), as_global(K.img), g.n, g.cols, g.sw, inv_cols, ppt, (unsigned)as_const(lay.tiles)[jt + 1] * (unsigned)T + (unsigned)lane, tr);
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      if (j < ppt) {   // wave-uniform
-        const float Z = cur.d[j];
-        const unsigned long long mk = __ballot(Z > 0.0f);
-        if (Z > 0.0f) {
-          const unsigned pos = region + (unsigned)(running + __popcll(mk & lt));
-          int x, y;
-          pix_xy((int)(pix0 + (unsigned)(j * 64)), g.cols, inv_cols, x, y);
-          if constexpr (FAST) {   // FcaRecF (prep_build's expressions)
-            const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | cur.I[j];
-            const float dd = __builtin_amdgcn_rcpf(Z);
-            const float pn = ((float)x - g.cx) * g.rfx;
-            ((ELLC_GLOBAL u32x4*)K.crec)[pos] = (u32x4){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, cur.v[j]), __builtin_bit_cast(uint32_t, dd)};
-          } else {                // FcaRec
-            const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | (cur.I[j] << 24);
-            const double invZ = 1.0 / (double)Z;
-            const unsigned long long zb = __builtin_bit_cast(unsigned long long, invZ);
-            ELLC_GLOBAL char* rp = (ELLC_GLOBAL char*)K.crec + pos * (unsigned)sizeof(FcaRec);
-            typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
-            *(ELLC_GLOBAL u32x4a*)rp = (u32x4a){xyI, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, cur.v[j]), (uint32_t)zb};
-            *(ELLC_GLOBAL uint32_t*)(rp + 16) = (uint32_t)(zb >> 32);
-          }
-        }
-        running += __popcll(mk);
-      }
-    }
-  }
-  if (lane == 0) as_global_rw(K.blk_count)[vb] = running;
-}
-
 // The leading scalar parameters repeat what the prologue's first loads need (addresses of the state record and of the
 // pending partial sums, block counts): the library is built with kernel-argument preloading, so they arrive in SGPRs with
 // the wave instead of through a scalar load from the argument buffer — one memory round trip less at the head of a
 // latency-bound kernel. Everything else stays in the by-value struct.
 // BUILD: the first launch of a level — alignments whose keyframe slot has no valid lists (GnArgs::build) build their regions in this
 // launch (fcaf_build_pass / fca_build_pass_exact); the others walk their lists as in every later launch.
-// RIDE: the launch carries ride-along blocks (blockIdx.z > 0: gn_ride_build)
-template <bool DIVC, bool PIPE, bool FAST = false, int SAVEW = -1, bool BUILD = false, bool RIDE = false>   // SAVEW: see fcaf_pixel (tolerance mode only)
+template <bool DIVC, bool PIPE, bool FAST = false, int SAVEW = -1, bool BUILD = false>   // SAVEW: see fcaf_pixel (tolerance mode only)
 __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignState* src_state, const float* prev_part, int prev_nblk,
                                                                    int nblk, int age_rounds, FusedArgs fa) {   // 4 waves per SIMD: at most 128 VGPRs
-  if constexpr (RIDE) {
-    if (blockIdx.z > 0) {
-      gn_ride_build<FAST>(fa);
-      return;
-    }
-  }
   const GnArgs& a = fa.g;
   int b = blockIdx.y, sub = blockIdx.x;
   if (age_rounds > 1) {
@@ -2540,9 +2450,11 @@ __device__ inline void init_state_record(AlignState& st, const float* init_pose,
 // list is walked region by region (LevelLayout): blockIdx.x strides over the blocks of the layout.
 __device__ __forceinline__ void add_saved_weights_level(const KfLevelDev& K, const LevelGeom& g, const LevelLayout& lay, int fast_records) {
   const int cols = g.cols;
-  for (int vb = blockIdx.x; vb < lay.nblk * (ELLC_GN_THREADS / 64); vb += gridDim.x) {   // the regions of the level's layout
+  // a wave per region of the level's layout (a region of a small batch holds about as many records as a wave has lanes)
+  const int wpb = (int)(blockDim.x >> 6);
+  for (int vb = (int)blockIdx.x * wpb + wave_index(); vb < lay.nblk * (ELLC_GN_THREADS / 64); vb += (int)gridDim.x * wpb) {
     const int begin = as_const(lay.blk_begin)[vb] * (lay.ppt << 6), end = begin + as_global(K.blk_count)[vb];
-    for (int i = begin + (int)threadIdx.x; i < end; i += blockDim.x) {
+    for (int i = begin + (int)(threadIdx.x & 63); i < end; i += 64) {
       // saved weights exist in the FCA schedule only: its records carry the pixel position
       size_t p;
       if (fast_records) {
