@@ -71,11 +71,12 @@ struct KfLevelDev {
   float* cI;                  // compact keyframe intensity as f32 (ICA)
   FcaRec* crec;               // compact FCA records (same order as cxy)
   IcaRec* irec;               // compact ICA records (same order as cxy)
-  float* hpart;               // ICA: per-block partial sums of H = sum W J^T J (prep_build), 32 floats per block (21 used)
+  float* hpart;               // ICA: partial sums of H = sum W J^T J per block of prep_scatter (four tiles), 32 floats each (21 used)
   float* hinv;                // ICA: inverse of the level's H (36 floats), one per keyframe slot and level
   float* cW;                  // compact saved weight (ICA)
   float* wlast;               // compact weight of the most recent iteration (for saveWeights)
   float* sd;                  // ICA steepest-descent planes, 6 x cap (plane k at sd + k*cap)
+  int* tile_count;            // [tiles] valid pixels per tile, by position in the layout's tile table (prep_count -> prep_scatter)
   int* blk_count;             // [4 ELLC_NBLK_MAX] compact entries in the region of every wave of the level's layout (LevelLayout)
 };
 
@@ -91,6 +92,7 @@ struct KfLevelDev {
 struct LevelLayout {
   const int* blk_begin;       // [4 nblk + 1] prefix of the number of tiles per wave
   const int* tiles;           // [ntiles] tile ids grouped by owning wave, ascending inside a wave
+  const int* owner;           // [ntiles] the wave (vb) that owns the tile at this position of `tiles` (prep_scatter)
   int nblk, ppt, ntiles, pad; // ppt: pixels per lane and tile (1, 2, 4 or 8): a tile is 64 * ppt pixels
 };
 

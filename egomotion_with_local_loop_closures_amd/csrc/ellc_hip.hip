@@ -277,7 +277,7 @@ static ellc_status ensure_layout(ellc_ctx* c, int Bgrid, const ellc_ctx::LayoutS
     ellc_ctx::LayoutSet ls;
     ls.id = (int)c->layouts.size() + 1;
     std::vector<int> flat;
-    std::vector<size_t> off_begin(c->L), off_tiles(c->L);
+    std::vector<size_t> off_begin(c->L), off_tiles(c->L), off_owner(c->L);
     for (int l = 0; l < c->L; l++) {
       const int n = c->geom_h[l].n;
       const int nblk = choose_nblk(c, l, Bgrid);
@@ -312,6 +312,8 @@ static ellc_status ensure_layout(ellc_ctx* c, int Bgrid, const ellc_ctx::LayoutS
       flat.push_back(acc);
       off_tiles[l] = flat.size();
       for (int s = 0; s < nvb; s++) flat.insert(flat.end(), owned[s].begin(), owned[s].end());
+      off_owner[l] = flat.size();
+      for (int s = 0; s < nvb; s++) flat.insert(flat.end(), owned[s].size(), s);
       ls.lv_h[l].nblk = nblk; ls.lv_h[l].ppt = ppt; ls.lv_h[l].ntiles = ntiles; ls.lv_h[l].pad = 0;
     }
     int* flat_d = nullptr;
@@ -320,6 +322,7 @@ static ellc_status ensure_layout(ellc_ctx* c, int Bgrid, const ellc_ctx::LayoutS
     for (int l = 0; l < c->L; l++) {
       ls.lv_h[l].blk_begin = flat_d + off_begin[l];
       ls.lv_h[l].tiles = flat_d + off_tiles[l];
+      ls.lv_h[l].owner = flat_d + off_owner[l];
     }
     for (int l = c->L; l < ELLC_MAX_LEVELS; l++) ls.lv_h[l] = ls.lv_h[c->L - 1];
     st = dev_alloc(c, &ls.lv_d, ELLC_MAX_LEVELS);
@@ -335,7 +338,7 @@ static ellc_status ensure_layout(ellc_ctx* c, int Bgrid, const ellc_ctx::LayoutS
 // the layout set of launches over B alignments; it exists (ensure_layout ran at the head of the entry point)
 static const ellc_ctx::LayoutSet& layout_of(ellc_ctx* c, int B);
 
-// compaction of the listed keyframes into the regions of the layout that launches over B alignments walk (prep_build): ONE launch
+// compaction of the listed keyframes into the regions of the layout that launches over B alignments walk: count + scatter, a wave per tile
 ellc_status run_prep(ellc_ctx* c, int n_unique, int need, int B) {
   const ellc_ctx::LayoutSet& ls = layout_of(c, B);
   PrepArgs a;
@@ -348,15 +351,17 @@ ellc_status run_prep(ellc_ctx* c, int n_unique, int need, int B) {
   a.max_kf = c->cfg.max_keyframes;
   a.level0 = 0;
   a.blk_prefix[0] = 0;
-  for (int l = 0; l < ELLC_MAX_LEVELS; l++) a.blk_prefix[l + 1] = a.blk_prefix[l] + (l < c->L ? ls.nblk[l] : 0);
+  constexpr int WPB = ELLC_GN_THREADS / 64;
+  for (int l = 0; l < ELLC_MAX_LEVELS; l++) a.blk_prefix[l + 1] = a.blk_prefix[l] + (l < c->L ? (ls.lv_h[l].ntiles + WPB - 1) / WPB : 0);
   const dim3 grd(a.blk_prefix[c->L], n_unique), blk(256);
   hipStream_t st = c->stream;
+  hipLaunchKernelGGL(prep_count, grd, blk, 0, st, a);
   switch (need) {
-    case 1: hipLaunchKernelGGL(prep_build<1>, grd, blk, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(prep_build<2>, grd, blk, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(prep_build<4>, grd, blk, 0, st, a); break;
-    case 20: hipLaunchKernelGGL(prep_build<20>, grd, blk, 0, st, a); break;
-    case 8: hipLaunchKernelGGL(prep_build<8>, grd, blk, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(prep_scatter<1>, grd, blk, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(prep_scatter<2>, grd, blk, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(prep_scatter<4>, grd, blk, 0, st, a); break;
+    case 20: hipLaunchKernelGGL(prep_scatter<20>, grd, blk, 0, st, a); break;
+    case 8: hipLaunchKernelGGL(prep_scatter<8>, grd, blk, 0, st, a); break;
     default: return fail(c, ELLC_ERR_BAD_ARG, "run_prep: unknown record set");
   }
   ELLC_HIP(c, hipGetLastError());
@@ -948,8 +953,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       TRY(dev_alloc(c, &k.depth, n)); TRY(dev_alloc(c, &k.var, n)); TRY(dev_alloc(c, &k.weight, n));
       TRY(dev_alloc(c, &k.cxy, cp)); TRY(dev_alloc(c, &k.cZ, cp)); TRY(dev_alloc(c, &k.cI, cp));
       TRY(dev_alloc(c, &k.crec, cp)); TRY(dev_alloc(c, &k.cW, cp)); TRY(dev_alloc(c, &k.wlast, cp)); TRY(dev_alloc(c, &k.sd, 6 * cp));
-      TRY(dev_alloc(c, &k.blk_count, ELLC_NBLK_MAX * (ELLC_GN_THREADS / 64)));
-      TRY(dev_alloc(c, &k.irec, cp)); TRY(dev_alloc(c, &k.hpart, (size_t)ELLC_NBLK_MAX * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
+      TRY(dev_alloc(c, &k.blk_count, ELLC_NBLK_MAX * (ELLC_GN_THREADS / 64))); TRY(dev_alloc(c, &k.tile_count, cp / 64 + 1));
+      TRY(dev_alloc(c, &k.irec, cp)); TRY(dev_alloc(c, &k.hpart, (cp / 256 + 1) * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
     }
     for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni + 16));
   }

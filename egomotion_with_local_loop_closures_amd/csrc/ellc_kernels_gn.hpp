@@ -596,8 +596,9 @@ __device__ __forceinline__ void wave_tiles(const LevelLayout& lay, int sub, int&
 // [begin, end) in record units; the wave walks it with a stride of 64
 __device__ __forceinline__ void wave_range(const LevelLayout& lay, const KfLevelDev& K, int sub, int& begin, int& end) {
   const int vb = sub * (ELLC_GN_THREADS / 64) + wave_index();
-  begin = __builtin_amdgcn_readfirstlane(as_const(lay.blk_begin)[vb] * (lay.ppt << 6));
-  end = begin + __builtin_amdgcn_readfirstlane(as_global(K.blk_count)[vb]);
+  const int tb = as_const(lay.blk_begin)[vb], te = as_const(lay.blk_begin)[vb + 1];
+  begin = __builtin_amdgcn_readfirstlane(tb * (lay.ppt << 6));
+  end = begin + (tb < te ? __builtin_amdgcn_readfirstlane(as_global(K.blk_count)[vb]) : 0);   // (a wave without tiles has no count: nobody writes one)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2453,7 +2454,8 @@ __device__ __forceinline__ void add_saved_weights_level(const KfLevelDev& K, con
   // a wave per region of the level's layout (a region of a small batch holds about as many records as a wave has lanes)
   const int wpb = (int)(blockDim.x >> 6);
   for (int vb = (int)blockIdx.x * wpb + wave_index(); vb < lay.nblk * (ELLC_GN_THREADS / 64); vb += (int)gridDim.x * wpb) {
-    const int begin = as_const(lay.blk_begin)[vb] * (lay.ppt << 6), end = begin + as_global(K.blk_count)[vb];
+    const int tb = as_const(lay.blk_begin)[vb], te = as_const(lay.blk_begin)[vb + 1];
+    const int begin = tb * (lay.ppt << 6), end = begin + (tb < te ? as_global(K.blk_count)[vb] : 0);
     for (int i = begin + (int)(threadIdx.x & 63); i < end; i += 64) {
       // saved weights exist in the FCA schedule only: its records carry the pixel position
       size_t p;

@@ -9,14 +9,17 @@
 namespace ellc {
 
 // ---------------------------------------------------------------------------------------------------
-// Compaction of the keyframe's valid pixels (mask = depth_pyramid[l] > 0, Frame.cpp:295-301) into the block-owned regions of
-// the level's layout (LevelLayout, ellc_device.hpp). r05: ONE launch, no count pass, no prefix over tiles — the block that builds a
-// region is the only one that needs its count (r01-r04: a count launch per tile of 2048 pixels, then a scatter launch whose blocks
-// summed the counts of the tiles before theirs; 18 % of a launch group's kernel time and the depth planes read twice). The
-// production schedules do not even launch this kernel: the first Gauss-Newton launch of a level builds the regions it then walks
-// (fca_build_pass / ica_build_pass, ellc_kernels_gn.hpp). It remains for the single-step API, for batches in which alignments share
-// a keyframe slot (their blocks would write the same regions side by side), and for the state-driven tracking schedule.
-
+// Compaction of the keyframe's valid pixels (mask = depth_pyramid[l] > 0, Frame.cpp:295-301) into the wave-owned regions of the
+// level's layout (LevelLayout, ellc_device.hpp) as launches of its own: a count launch and a scatter launch, a WAVE per tile in both,
+// every tile of every level of every listed keyframe at once — the form for schedules that cannot build their lists themselves
+// (launches over fewer than eight alignments, where a wave's handful of tiles walked one after the other costs more than two
+// launches: a single 640x480 alignment 0.223 ms against 0.234; alignments that share a keyframe slot, whose blocks would write the
+// same regions side by side; the state-driven tracking schedule; the single-step API) and for the modes whose pixel pass does not
+// hide a build (exact arithmetic, constant weights: measured). The tolerance-mode FCA schedule of a batch builds its
+// lists in the first launch of every level instead (fcaf_build_pass, ellc_kernels_gn.hpp) and launches neither kernel.
+// Tiles are addressed by their position p in the layout's tile table: tiles[p] is the tile, owner[p] the wave region it belongs
+// to, and the tiles of one region are consecutive in p — the offset of a tile inside its region is the sum of the counts of the
+// region's earlier tiles (at most a few dozen words, read by the scatter wave itself: no prefix pass).
 struct PrepArgs {
   const LevelGeom* geom;
   const KfLevelDev* kf_tab;
@@ -27,29 +30,66 @@ struct PrepArgs {
                                // bit 2: IcaRec records + per-block sums of H (fused ICA schedule); bit 3: FcaRecF records
                                // (FCA in tolerance mode, cfg.arith = ELLC_ARITH_FAST); bit 4 (with bit 2): the ICA records in
                                // the tolerance mode's 16-byte form (IcaInF) instead of IcaRec
-  int blk_prefix[ELLC_MAX_LEVELS + 1];   // prefix of the blocks per level (prep_build: blockIdx.x -> level, block)
+  int blk_prefix[ELLC_MAX_LEVELS + 1];   // prefix of the blocks (four tiles each) per level: blockIdx.x -> level, first tile position
   int level0;                  // ica_hinv: levels level0 + blockIdx.x
 };
 
-// Every wave compacts the tiles it owns into its own region (tile_park: ballot ranks, the valid pixels parked in the wave's LDS
-// ring), then runs densely over the parked entries — every lane has a valid pixel — computes the record (three IEEE divisions in the
-// exact forms) and stores it; consecutive lanes write consecutive records. Without the LDS step the divisions would run for every
-// wave that holds at least one valid pixel, i.e. about four times as often on a semi-dense map. No block barrier but the one in
-// front of the final sums of H.
-template <int NEED>   // compile-time copy of PrepArgs::need: the FCA variant carries no Jacobian / H-sum code (and registers)
-__global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
+// inclusive scan inside a wave; returns the wave total through `total`
+__device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  total = __shfl(v, 63, 64);
+  return v;
+}
+
+// blockIdx.x -> level and the tile position p of this wave (p >= ntiles: nothing to do)
+__device__ __forceinline__ int prep_locate(const PrepArgs& a, int& p) {
   int level = 0;
   while (level + 1 < a.levels && (int)blockIdx.x >= a.blk_prefix[level + 1]) level++;
-  const int sub = (int)blockIdx.x - a.blk_prefix[level];
-  const KfLevelDev K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  p = ((int)blockIdx.x - a.blk_prefix[level]) * (ELLC_GN_THREADS / 64) + wave_index();
+  return level;
+}
+
+__global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
+  int p;
+  const int level = prep_locate(a, p);
   const LevelLayout Lay = a.lay[level];
+  if (p >= Lay.ntiles) return;
+  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const int n = a.geom[level].n, ppt = Lay.ppt;
+  const unsigned pix0 = (unsigned)as_const(Lay.tiles)[p] * (unsigned)(ppt << 6) + (threadIdx.x & 63u);
+  const ELLC_GLOBAL float* depth = gptr(K.depth);
+  float d[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const unsigned i = pix0 + (unsigned)(j * 64);
+    d[j] = (j < ppt && i < (unsigned)n) ? depth[i] : 0.0f;
+  }
+  int tot = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) tot += __popcll(__ballot(d[j] > 0.0f));
+  if ((threadIdx.x & 63) == 0) K.tile_count[p] = tot;
+}
+
+// Scatter: the wave parks the valid pixels of its tile in its LDS ring by ballot rank (tile_park), then runs densely over the
+// parked entries — every lane has a valid pixel — computes the record (three IEEE divisions in the exact forms) and stores it;
+// consecutive lanes write consecutive records. Without the LDS step the divisions would run for every wave that holds at least one
+// valid pixel, i.e. about four times as often on a semi-dense map. No block barrier but the one in front of the sums of H.
+template <int NEED>   // compile-time copy of PrepArgs::need: the FCA variant carries no Jacobian / H-sum code (and registers)
+__global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
+  int p;
+  const int level = prep_locate(a, p);
+  const LevelLayout Lay = a.lay[level];
+  const KfLevelDev K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
   const LevelGeom& g = a.geom[level];
   const int n = g.n;
   const int lane = threadIdx.x & 63;
-  int tb, te;
-  wave_tiles(Lay, sub, tb, te);
+  const bool on = p < Lay.ntiles;   // wave-uniform (a block's last waves may have no tile; they still take part in the H sums)
   const int ppt = Lay.ppt, T = ppt << 6;
-  const unsigned region = (unsigned)tb * (unsigned)T;
   __shared__ BuildShared bsh;
   uint2* ring = bsh.ring[wave_index()];
   float* vring = bsh.vring[wave_index()];
@@ -69,17 +109,26 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
   float hacc[27];
 #pragma unroll
   for (int q = 0; q < 27; q++) hacc[q] = 0.0f;
-  int running = 0;   // records of this wave's region so far
+  if (on) {
   // the second plane the records need rides with the depths: the variance (FCA) or the saved weights (constant-weight records)
   const ELLC_GLOBAL float* plane2 = (NEED == 8 || NEED == 2) ? var : wgt;
+  const unsigned pix0 = (unsigned)as_const(Lay.tiles)[p] * (unsigned)T + (unsigned)lane;
   TileRegs tr;
-  if (tb < te) tile_load(gptr(K.depth), plane2, img, n, g.cols, g.sw, inv_cols, ppt, (unsigned)as_const(Lay.tiles)[tb] * (unsigned)T + (unsigned)lane, tr);
-  for (int jt = tb; jt < te; jt++) {   // wave-uniform
-    const unsigned pix0 = (unsigned)as_const(Lay.tiles)[jt] * (unsigned)T + (unsigned)lane;
-    const int nvalid = tile_park(tr, ppt, pix0, 0, ring, vring);
-    // the next tile's planes are requested before this tile's records are formed (a wave's life is a chain of memory round trips)
-    if (jt + 1 < te) tile_load(gptr(K.depth), plane2, img, n, g.cols, g.sw, inv_cols, ppt, (unsigned)as_const(Lay.tiles)[jt + 1] * (unsigned)T + (unsigned)lane, tr);
-    const unsigned tile_off = region + (unsigned)running;
+  tile_load(gptr(K.depth), plane2, img, n, g.cols, g.sw, inv_cols, ppt, pix0, tr);
+  // this tile's offset in its region = the counts prep_count left for the region's earlier tiles
+  const int vb = as_const(Lay.owner)[p];
+  const int tb = as_const(Lay.blk_begin)[vb], te = as_const(Lay.blk_begin)[vb + 1];
+  int running = 0;
+  for (int j0 = tb; j0 < p; j0 += 64) {   // wave-uniform
+    int part = (j0 + lane < p) ? gptr(K.tile_count)[j0 + lane] : 0, tot;
+    wave_inclusive_scan(part, tot);
+    running += tot;
+  }
+  running = __builtin_amdgcn_readfirstlane(running);
+  const unsigned region = (unsigned)tb * (unsigned)T;
+  const int nvalid = tile_park(tr, ppt, pix0, 0, ring, vring);
+  if (lane == 0 && p == te - 1) K.blk_count[vb] = running + nvalid;   // the region's last tile: its total
+  const unsigned tile_off = region + (unsigned)running;
   if constexpr (NEED == 8 || NEED == 2) {
     // FCA records: everything a record needs was parked with the pixel
     for (int r0 = 0; r0 < nvalid; r0 += 64) {   // wave-uniform trip count
@@ -109,8 +158,7 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
     }
   } else
   for (int r0 = 0; r0 < nvalid; r0 += 64) {   // wave-uniform trip count
-    // the record at position p of the wave's region belongs to lane p mod 64, as in the Gauss-Newton launches that walk the region and
-    // in the one that builds it itself (ica_build_pass): the per-lane sums of H — hence the bits of H^-1 — do not depend on who built the lists
+    // the record at position p of the wave's region belongs to lane p mod 64, as in the Gauss-Newton launches that walk the region
     const int r = r0 + ((lane - running) & 63);
     if (r < nvalid) {
     const uint2 e = ring[r];
@@ -129,7 +177,7 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
     const uint32_t pc = (x == 0) ? b0 : b1;                                  // I(x, y)
     const uint32_t pxm = b0;                                                 // I(max(x - 1, 0), y)
     const uint32_t pxp = (x == 0) ? b1 : ((x == cols - 1) ? b1 : b2);        // I(min(x + 1, cols - 1), y)
-    const float Ikf = (need & 4) ? (float)pc : (float)img[(unsigned)(y * sw + x)];
+    const float Ikf = (need & 4) ? (float)pc : (float)(e.x >> 24);
     if (need & 1) {   // unfused ICA kernels read planes
       cxy[pos] = xy;
       cZ[pos] = Z;
@@ -168,19 +216,16 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
     }
     }
   }
-    running += nvalid;
-    __builtin_amdgcn_wave_barrier();   // (the ring is reused by the next tile)
   }
-  if (lane == 0) K.blk_count[sub * (ELLC_GN_THREADS / 64) + wave_index()] = running;
-  if (need & 4) block_reduce_store<27>(hacc, K.hpart + (size_t)sub * ELLC_PART_STRIDE);   // block-uniform condition
+  if (need & 4) block_reduce_store<27>(hacc, K.hpart + (size_t)((int)blockIdx.x - a.blk_prefix[level]) * ELLC_PART_STRIDE);   // block-uniform condition
 }
 
-// ICA: H of one (keyframe slot, level) from the per-block sums (fixed-order f64 combine), then cv::Mat::inv(DECOMP_LU)
+// ICA: H of one (keyframe slot, level) from the scatter blocks' sums (fixed-order f64 combine), then cv::Mat::inv(DECOMP_LU)
 // (PixelWisePyramid.cpp:938-939). One block per (level, unique slot); the level's inverse is kept with the slot.
 __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void ica_hinv(PrepArgs a) {
   const int level = a.level0 + (int)blockIdx.x;
   const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
-  const int T = a.lay[level].nblk;
+  const int T = (a.lay[level].ntiles + ELLC_GN_THREADS / 64 - 1) / (ELLC_GN_THREADS / 64);   // the blocks of prep_scatter
   __shared__ SolveShared sh;
   const int t = threadIdx.x;
   sh.part[t >> 5][t & 31] = partial_group_sum(K.hpart, T);
