@@ -71,29 +71,13 @@ struct KfLevelDev {
   float* cI;                  // compact keyframe intensity as f32 (ICA)
   FcaRec* crec;               // compact FCA records (same order as cxy)
   IcaRec* irec;               // compact ICA records (same order as cxy)
-  float* hpart;               // ICA: partial sums of H = sum W J^T J per block of prep_scatter (four tiles), 32 floats each (21 used)
+  float* hpart;               // ICA: per-tile partial sums of H = sum W J^T J, 32 floats per tile (21 used)
   float* hinv;                // ICA: inverse of the level's H (36 floats), one per keyframe slot and level
   float* cW;                  // compact saved weight (ICA)
   float* wlast;               // compact weight of the most recent iteration (for saveWeights)
   float* sd;                  // ICA steepest-descent planes, 6 x cap (plane k at sd + k*cap)
-  int* tile_count;            // [tiles] valid pixels per tile, by position in the layout's tile table (prep_count -> prep_scatter)
-  int* blk_count;             // [4 ELLC_NBLK_MAX] compact entries in the region of every wave of the level's layout (LevelLayout)
-};
-
-// How the compact list of one level is laid out for the launches that walk it (r05). The level's plane is cut into tiles of
-// 64 * ppt consecutive pixels; every WAVE of every block of a Gauss-Newton launch OWNS whole tiles (interleaved over the plane, so
-// that all waves see the same mix of dense and empty image regions; weighted by the age-balanced split of the launch, FusedArgs)
-// and the records of its tiles lie contiguously in its own region of the slot's record arrays: wave w of block `sub` has index
-// vb = 4 sub + w, owns the tiles tiles[blk_begin[vb] .. blk_begin[vb + 1]) and the records [blk_begin[vb] * 64 * ppt, ... +
-// blk_count[vb]). Nothing about the list crosses a wave: no prefix over tiles, no count pass, no barrier — the wave that builds a
-// region (prep_build, or the first Gauss-Newton launch of the level itself: fcaf_build_pass and its siblings) counts it, and every
-// later launch of the same layout walks [begin, begin + count) with a stride of 64. The order of the records inside a region is the
-// raster order of the wave's tiles; the 27 sums are order-dependent in their last bits only (the per-pixel values are not).
-struct LevelLayout {
-  const int* blk_begin;       // [4 nblk + 1] prefix of the number of tiles per wave
-  const int* tiles;           // [ntiles] tile ids grouped by owning wave, ascending inside a wave
-  const int* owner;           // [ntiles] the wave (vb) that owns the tile at this position of `tiles` (prep_scatter)
-  int nblk, ppt, ntiles, pad; // ppt: pixels per lane and tile (1, 2, 4 or 8): a tile is 64 * ppt pixels
+  int* count;                 // V = number of compact entries
+  int* tile_count;            // per-tile (ELLC_TILE pixels) counts, then exclusive offsets
 };
 
 struct FrLevelDev {

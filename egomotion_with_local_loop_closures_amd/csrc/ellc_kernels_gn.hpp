@@ -50,12 +50,6 @@ template <class T>
 __device__ __forceinline__ const ELLC_GLOBAL T* as_global(const T* p) { return (const ELLC_GLOBAL T*)p; }
 template <class T>
 __device__ __forceinline__ ELLC_GLOBAL T* as_global_rw(T* p) { return (ELLC_GLOBAL T*)p; }
-// Tables that no kernel of the library writes (the layouts): read through the constant address space, i.e. by SCALAR loads when
-// the address is uniform — they wait on lgkmcnt, not on the vector-memory counter behind which a wave's prefetched tiles and
-// records are queued. (r05: read as ordinary global memory the tile ids became two dependent vector loads with s_waitcnt vmcnt(0)
-// at the head of every tile of the fused build: 11 us per tile.)
-#define ELLC_CONST __attribute__((address_space(4)))
-__device__ __forceinline__ const ELLC_CONST int* as_const(const int* p) { return (const ELLC_CONST int*)p; }
 
 // ---------------------------------------------------------------------------------------------------
 // one DPP step of a wave-wide sum (see wave_sum_rows)
@@ -448,9 +442,6 @@ struct GnArgs {
   AlignState* state;            // [B]
   float* partials;              // [B][ELLC_NBLK_MAX][ELLC_PART_STRIDE]
   float* planes;                // debug: 10 planes of n floats (B must be 1), else null
-  const LevelLayout* lay;       // [levels] how the compact lists are split over the blocks of these launches
-  const int* build;             // [B] 1: the alignment's keyframe slot has no (valid) compact lists: the first launch of every level builds
-                                // the regions it walks (fca_build_pass / ica_build_pass); 0: the lists are there (prep_build, or kept: cfg.cache_records)
   int level, max_kf, max_fr, nblk;
   int save_w;                   // write per-pixel weights of this iteration into kf.wlast
 };
@@ -513,92 +504,6 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float* __re
     for (int w = 1; w < ELLC_GN_THREADS / 64; w++) s += red[w][threadIdx.x];
     out[threadIdx.x] = s;
   }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Tile compaction shared by prep_build (ellc_kernels_prep.hpp) and the first Gauss-Newton launch of a level, which builds its
-// regions of the compact list while it runs its first pixel pass (fcaf_build_pass / fca_build_pass_exact / ica_build_pass below).
-// Everything here is per WAVE: a tile is 64 * ppt consecutive pixels owned by one wave (LevelLayout), its valid pixels are ranked
-// by ballots (scalar popcounts, no LDS, no barrier) and parked in the wave's own LDS ring; waves never wait for each other.
-#define ELLC_TILE_MAX 512       // pixels per tile at most: 64 lanes x 8 pixels (LevelLayout::ppt <= 8)
-#define ELLC_QCAP 640           // ring capacity per wave: a tile of up to 512 pixels on top of fewer than 128 entries held back
-struct BuildShared {
-  uint2 ring[ELLC_GN_THREADS / 64][ELLC_QCAP];   // pixel index | keyframe intensity << 24, depth
-  float vring[ELLC_GN_THREADS / 64][ELLC_QCAP];  // variance (FCA) / saved weight (ICA) of the parked pixel
-};
-// What a lane holds of one tile between its request and its parking: depth, the second plane (variance / saved weight) and the
-// keyframe's intensity of its ppt pixels — all three read with the tile's coalesced pattern, valid or not (a gather of the valid
-// 30 % touches nearly every sector anyway, and it would sit as a cold-memory round trip in front of every pixel step: the first
-// version of the fused build gathered per step and its level-0 launch took 168 us against 48).
-struct TileRegs { float d[8], v[8]; uint32_t I[8]; };
-__device__ __forceinline__ int ring_wrap(int pos) { return pos >= ELLC_QCAP ? pos - ELLC_QCAP : pos; }
-
-// One tile of a wave's compaction: lane l owns pixels pix0 + j * 64 (pix0 = tile start + l, j < ppt), so every load of the wave
-// is contiguous; (pixel index | intensity << 24, depth) and the second plane's value of the valid pixels are parked at ring
-// positions q_tail + rank (mod ELLC_QCAP), rank = raster order inside the tile. Returns the number of valid pixels of the tile
-// (wave-uniform).
-__device__ __forceinline__ int tile_park(const TileRegs& r, int ppt, unsigned pix0, int q_tail, uint2* ring, float* vring) {
-  const int lane = threadIdx.x & 63;
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  int tot = 0;
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    if (j < ppt) {   // wave-uniform
-      const unsigned long long m = __ballot(r.d[j] > 0.0f);
-      if (r.d[j] > 0.0f) {
-        const int pos = ring_wrap(q_tail + tot + __popcll(m & lt));
-        ring[pos] = make_uint2((pix0 + (unsigned)(j * 64)) | (r.I[j] << 24), __builtin_bit_cast(uint32_t, r.d[j]));
-        vring[pos] = r.v[j];
-      }
-      tot += __popcll(m);
-    }
-  }
-  __builtin_amdgcn_wave_barrier();   // (the wave's LDS operations execute in program order: the entries are there for the reads that follow)
-  return tot;
-}
-// requests the planes of this lane's pixels of a tile (zeros past the end of the plane and for j >= ppt); the image rows are stored
-// with a pitch of sw >= cols. plane2: the variance (FCA) or the saved weights (ICA)
-__device__ __forceinline__ void tile_load(const ELLC_GLOBAL float* depth, const ELLC_GLOBAL float* plane2, const ELLC_GLOBAL uint8_t* img, int n, int cols,
-                                          int sw, float inv_cols, int ppt, unsigned pix0, TileRegs& r) {
-  int x, y;
-  {   // pixel index -> (x, y) of the lane's first pixel; the others follow by adding 64 (cols may be smaller than 64)
-    const int i = (int)min(pix0, (unsigned)(n - 1));
-    y = (int)(((float)i + 0.5f) * inv_cols);
-    if (y * cols > i) y--;
-    if ((y + 1) * cols <= i) y++;
-    x = i - y * cols;
-  }
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const unsigned i = pix0 + (unsigned)(j * 64);
-    const bool on = j < ppt && i < (unsigned)n;
-    r.d[j] = on ? depth[i] : 0.0f;
-    r.v[j] = on ? plane2[i] : 0.0f;
-    r.I[j] = on ? (uint32_t)img[(unsigned)(y * sw + x)] : 0u;
-    x += 64;
-    while (x >= cols) { x -= cols; y++; }
-  }
-}
-// pixel index -> (x, y) (i < 2^24: exact conversion; corrected to the exact quotient)
-__device__ __forceinline__ void pix_xy(int i, int cols, float inv_cols, int& x, int& y) {
-  y = (int)(((float)i + 0.5f) * inv_cols);
-  if (y * cols > i) y--;
-  if ((y + 1) * cols <= i) y++;
-  x = i - y * cols;
-}
-// wave `wave` of block `sub` of a launch: its index in the level's layout, its tiles and its region of the compact list
-__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
-__device__ __forceinline__ void wave_tiles(const LevelLayout& lay, int sub, int& tb, int& te) {
-  const int vb = sub * (ELLC_GN_THREADS / 64) + wave_index();
-  tb = as_const(lay.blk_begin)[vb];
-  te = as_const(lay.blk_begin)[vb + 1];
-}
-// [begin, end) in record units; the wave walks it with a stride of 64
-__device__ __forceinline__ void wave_range(const LevelLayout& lay, const KfLevelDev& K, int sub, int& begin, int& end) {
-  const int vb = sub * (ELLC_GN_THREADS / 64) + wave_index();
-  const int tb = as_const(lay.blk_begin)[vb], te = as_const(lay.blk_begin)[vb + 1];
-  begin = __builtin_amdgcn_readfirstlane(tb * (lay.ppt << 6));
-  end = begin + (tb < te ? __builtin_amdgcn_readfirstlane(as_global(K.blk_count)[vb]) : 0);   // (a wave without tiles has no count: nobody writes one)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -916,8 +821,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   const LevelGeom g = a.geom[a.level];
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
-  int begin, end;
-  { const LevelLayout lay = a.lay[a.level]; wave_range(lay, K, (int)blockIdx.x, begin, end); }
+  const int V = *K.count;
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = blockIdx.x * chunk;
+  const int end = min(V, begin + chunk);
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = st.S[i];
@@ -926,7 +833,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   fca_acc_zero(acc);
   const TapRows tr = tap_rows(cur, g.sw);
   const FcafConst fc = fcaf_const(g, S);
-  for (int i = begin + (int)(threadIdx.x & 63); i < end; i += 64) {
+  for (int i = begin + (int)threadIdx.x; i < end; i += ELLC_GN_THREADS) {
     FcaPix p;
     if constexpr (FAST) p = fcaf_pixel<DEBUG>(a, K, g, cur, tr, fc, (unsigned)i, fcaf_load(K, (unsigned)i));
     else p = fca_pixel<DEBUG, DIVC>(a, K, g, cur, S, i);
@@ -946,14 +853,19 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_precompute(GnArgs a, i
   if (st.level_done == a.level) return;
   const LevelGeom g = a.geom[a.level];
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
-  int begin, end;
-  { const LevelLayout lay = a.lay[a.level]; wave_range(lay, K, (int)blockIdx.x, begin, end); }
-  const int stride = 64;
+  const int V = *K.count;
+  // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
+  // split, which was tried in r01 and did not change the run time — co-resident blocks finish staggered because the
+  // SIMD arbiter serves the oldest wave first, not because their pixels differ)
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = blockIdx.x * chunk;
+  const int end = min(V, begin + chunk);
+  const int stride = ELLC_GN_THREADS;
   g_u8 img = as_global(K.img);
   float acc[21];
 #pragma unroll
   for (int i = 0; i < 21; i++) acc[i] = 0.0f;
-  for (int i = begin + (int)(threadIdx.x & 63); i < end; i += stride) {
+  for (int i = begin + (int)threadIdx.x; i < end; i += stride) {
     const uint32_t xy = as_global(K.cxy)[i];
     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
     const float Z = as_global(K.cZ)[i];
@@ -993,9 +905,14 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
   const LevelGeom g = a.geom[a.level];
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
-  int begin, end;
-  { const LevelLayout lay = a.lay[a.level]; wave_range(lay, K, (int)blockIdx.x, begin, end); }
-  const int stride = 64;
+  const int V = *K.count;
+  // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
+  // split, which was tried in r01 and did not change the run time — co-resident blocks finish staggered because the
+  // SIMD arbiter serves the oldest wave first, not because their pixels differ)
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = blockIdx.x * chunk;
+  const int end = min(V, begin + chunk);
+  const int stride = ELLC_GN_THREADS;
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = st.S[i];
@@ -1004,7 +921,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
   float acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0.0f;
-  for (int i = begin + (int)(threadIdx.x & 63); i < end; i += stride) {
+  for (int i = begin + (int)threadIdx.x; i < end; i += stride) {
     const uint32_t xy = as_global(K.cxy)[i];
     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
     const float Z = as_global(K.cZ)[i];
@@ -1147,8 +1064,7 @@ struct SolveArgs {
   AlignState* state;
   const float* partials;
   int level, nblk;
-  int mode;         // 0 FCA: H and b from partials; 1 ICA-precompute: H only (stores Hinv); 2 ICA-iterate: b only;
-                    // 3 ICA, first iteration of a level that built its lists: H and b — H^-1 by LU as mode 1, then the update of mode 2
+  int mode;         // 0 FCA: H and b from partials; 1 ICA-precompute: H only (stores Hinv); 2 ICA-iterate: b only
   int early_exit;
 };
 
@@ -1437,29 +1353,6 @@ __device__ __forceinline__ void solve_step(SolveShared& sh, double group_sum, in
   }
   __syncthreads();
   ELLC_STAMP(2);
-  if (FAST && mode == 3) {   // H^-1 of the level by the LU of cv::Mat::inv on the f32 H, as ica_hinv forms it; then the update from it
-    if (t < 64) {
-      float Hm[36];
-      int q = 0;
-#pragma unroll
-      for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int cc = r; cc < 6; cc++) {
-          const float v = (float)sh.sums[q++];
-          Hm[r * 6 + cc] = v;
-          Hm[cc * 6 + r] = v;
-        }
-      float x[6];
-      lu_inverse6_lanes(Hm, t < 6 ? t : 0, x);
-      if (t < 6) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) sh.Hinv[i * 6 + t] = x[i];
-      }
-    }
-    __syncthreads();
-    solve_finish_fast(sh, 2, level, early_exit, src, src.S, src.level_done, dst);
-    return;
-  }
   if (FAST && mode != 1) solve_finish_fast(sh, mode, level, early_exit, src, src.S, src.level_done, dst);
   else solve_finish(sh, mode, level, early_exit, src, src.S, src.level_done, dst);
 }
@@ -1518,8 +1411,6 @@ struct FusedArgs {
   int xcd_map;          // 1: blocks are renumbered so that all blocks of an alignment run on one XCD (see gn_fca_fused)
   AlignResult* res;     // gn_fused_finish: host-visible result records (null: none)
   int ica;              // 1: constant-weight schedule (gn_ica_fused): the pending sums are b only, H^-1 comes from the keyframe slot
-  int prev_first;       // 1: the launch whose sums are pending was the first of its level: for the alignments that built their lists in it
-                        // (GnArgs::build) the sums hold H as well (solve mode 3) and block 0 leaves the level's H^-1 with the keyframe slot
   // state-driven schedule (gn_fca_adaptive): blocks and iteration caps per level, the grid's x extent
   int nblk_lv[ELLC_MAX_LEVELS];
   int max_it[ELLC_MAX_LEVELS];
@@ -1534,14 +1425,14 @@ struct FusedArgs {
                         // of the alignments that ended there): its first launch marks those records cur_level = -2
 };
 
-// The pixel pass of one WAVE of a fused launch over its region [begin, end) of the compact list (wave_range), lane l taking the
-// entries begin + l, begin + l + 64, ...; the thread's first record (and, in the exact mode, its pose-independent products)
+// The pixel pass of one block of a fused launch over its chunk [begin, end) of the compact list, thread t taking the
+// entries begin + t, begin + t + 256, ...; the thread's first record (and, in the exact mode, its pose-independent products)
 // was requested by the caller before the solve. newS: exp(pose) of this iteration (LDS). Leaves the thread's 27 sums.
 template <bool DIVC, bool PIPE, bool FAST, int SAVEW>
 __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const float* newS, int begin,
                                                int end, const FcaIn& first, const FcaInF& firstf, const FcaPre& first_pre, float (&sums)[27]) {
-  constexpr int stride = 64;
-  const int t = threadIdx.x & 63;
+  constexpr int stride = ELLC_GN_THREADS;
+  const int t = threadIdx.x;
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = newS[i];
@@ -1549,7 +1440,7 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
   fca_acc_zero(acc);
   int i = begin + t;
   if constexpr (FAST) {
-    if (begin < end) {   // wave-uniform
+    if (begin < end) {   // block-uniform
       const TapRows tr = tap_rows(cur, g.sw);
       const FcafConst fc = fcaf_const(g, S);
       // One pixel per step: the rows are requested and used in the same step; the next pixel's record is requested behind them. The
@@ -1610,153 +1501,20 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
   fca_acc_unpack<FAST>(acc, sums);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// r05: the first launch of a level BUILDS its regions of the compact list while it runs the level's first pixel pass — there is
-// no compaction launch in front of a production schedule any more (r01-r04: a count launch and a scatter launch per ellc_align,
-// 18 % of a launch group's kernel time, the depth planes read twice and every record written, then read back).
-// Every WAVE walks the tiles it owns (LevelLayout): ppt coalesced depth loads per lane, ballot ranks, (pixel, depth) of the valid
-// pixels parked in the wave's LDS ring (tile_park); full steps of 64 parked entries are then consumed exactly as the list loop
-// consumes records — gather the keyframe's intensity and variance, form the record, STORE it at the region's next position for
-// the later launches of the level, run the pixel step on it — while fewer than 128 entries stay parked, so that a step never runs
-// short and the next step's entries are there to be requested one step ahead (the gathers ride behind the tap loads like the
-// record prefetch of fca_chunk_pass). The next tile's depths are requested before the steps of the current one. No block
-// barrier anywhere: the waves of a block drift apart as they do in the list loop (a first version compacted per BLOCK, two barriers
-// per tile: its waves marched in step and every memory round trip of every step was exposed — the level-0 launch took 174 us
-// against 48). The wave that builds a region is the only one that needs its count before the launch ends (blk_count).
-
-// tolerance-mode FCA record (FcaRecF) of a parked entry (prep_build's expressions)
-__device__ __forceinline__ FcaInF fcaf_build_form(const LevelGeom& g, float inv_cols, uint2 e, float var) {
-  int x, y;
-  pix_xy((int)(e.x & 0xffffffu), g.cols, inv_cols, x, y);
-  FcaInF in;
-  const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | (e.x >> 24);   // FcaRecF: y < 4096 as f32 has its 12 low bits clear
-  const float dd = __builtin_amdgcn_rcpf(__builtin_bit_cast(float, e.y));
-  const float pn = ((float)x - g.cx) * g.rfx;   // u / fx
-  in.v = (u32x4_t){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, var), __builtin_bit_cast(uint32_t, dd)};
-  return in;
-}
-
-// tr: the planes of the wave's first tile, requested by the caller before the solve. Leaves the thread's 27 sums.
-template <int SAVEW>
-__device__ __forceinline__ void fcaf_build_pass(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, const LevelLayout& lay, int sub, int tb, int te,
-                                                g_u8 cur, const float* newS, TileRegs& tr, BuildShared& bsh, float (&sums)[27]) {
-  const int lane = threadIdx.x & 63;
-  uint2* ring = bsh.ring[wave_index()];
-  float* vring = bsh.vring[wave_index()];
-  float S[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) S[i] = newS[i];
-  FcaAcc acc;
-  fca_acc_zero(acc);
-  const TapRows rows = tap_rows(cur, g.sw);
-  const FcafConst fc = fcaf_const(g, S);
-  const int ppt = lay.ppt, T = ppt << 6;
-  const unsigned region = (unsigned)tb * (unsigned)T;
-  const float inv_cols = 1.0f / (float)g.cols;
-  ELLC_GLOBAL u32x4_t* crec = (ELLC_GLOBAL u32x4_t*)K.crec;
-  int q_head = 0, q_cnt = 0, running = 0;   // wave-uniform
-  for (int jt = tb; jt < te; jt++) {
-    const unsigned pix0 = (unsigned)as_const(lay.tiles)[jt] * (unsigned)T + (unsigned)lane;
-    q_cnt += tile_park(tr, ppt, pix0, ring_wrap(q_head + q_cnt), ring, vring);
-    const bool last = (jt + 1 == te);
-    // the next tile's planes are requested before the steps of this one: a tile's worth of pixel steps hides their way from memory
-    if (!last) tile_load(as_global(K.depth), as_global(K.var), as_global(K.img), g.n, g.cols, g.sw, inv_cols, ppt,
-                         (unsigned)as_const(lay.tiles)[jt + 1] * (unsigned)T + (unsigned)lane, tr);
-    while (q_cnt >= 64 || (last && q_cnt > 0)) {
-      const int n_act = min(64, q_cnt);
-      const int pos_q = ring_wrap(q_head + min(lane, n_act - 1));   // (a lane past the end of the last step takes a copy of the last entry)
-      const FcaInF rec = fcaf_build_form(g, inv_cols, ring[pos_q], vring[pos_q]);
-      const FcafStage st = fcaf_stage_a(g, rows, fc, rec);
-      if (lane < n_act) {
-        const unsigned pos = region + (unsigned)running + (unsigned)lane;
-        crec[pos] = rec.v;
-        fca_accumulate_pixel(acc, fcaf_stage_b<false, SAVEW>(a, K, g, cur, fc, pos, st));
-      }
-      q_head = ring_wrap(q_head + n_act);
-      q_cnt -= n_act;
-      running += n_act;
-    }
-  }
-  if (lane == 0) as_global_rw(K.blk_count)[sub * (ELLC_GN_THREADS / 64) + wave_index()] = running;
-  fca_acc_unpack<true>(acc, sums);
-}
-
-// The same in the exact arithmetic: a step forms the FcaRec of its entry (with the f64 reciprocal the record carries), stores it
-// and runs the exact pixel step on it; no request ahead (the exact pass is bound by its instructions, the entries come from LDS).
-template <bool DIVC>
-__device__ __forceinline__ void fca_build_pass_exact(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, const LevelLayout& lay, int sub, int tb, int te,
-                                                     g_u8 cur, const float* newS, TileRegs& tr, BuildShared& bsh, float (&sums)[27]) {
-  const int lane = threadIdx.x & 63;
-  uint2* ring = bsh.ring[wave_index()];
-  float* vring = bsh.vring[wave_index()];
-  float S[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) S[i] = newS[i];
-  FcaAcc acc;
-  fca_acc_zero(acc);
-  const int ppt = lay.ppt, T = ppt << 6;
-  const unsigned region = (unsigned)tb * (unsigned)T;
-  const float inv_cols = 1.0f / (float)g.cols;
-  int q_head = 0, q_cnt = 0, running = 0;   // wave-uniform
-  for (int jt = tb; jt < te; jt++) {
-    const unsigned pix0 = (unsigned)as_const(lay.tiles)[jt] * (unsigned)T + (unsigned)lane;
-    q_cnt += tile_park(tr, ppt, pix0, ring_wrap(q_head + q_cnt), ring, vring);
-    const bool last = (jt + 1 == te);
-    if (!last) tile_load(as_global(K.depth), as_global(K.var), as_global(K.img), g.n, g.cols, g.sw, inv_cols, ppt,
-                         (unsigned)as_const(lay.tiles)[jt + 1] * (unsigned)T + (unsigned)lane, tr);
-    while (q_cnt >= 64 || (last && q_cnt > 0)) {
-      const int n_act = min(64, q_cnt);
-      if (lane < n_act) {
-        const int pos_q = ring_wrap(q_head + lane);
-        const uint2 e = ring[pos_q];
-        int x, y;
-        pix_xy((int)(e.x & 0xffffffu), g.cols, inv_cols, x, y);
-        FcaIn in;
-        in.xy = ((uint32_t)y << 16) | (uint32_t)x;
-        in.Z = __builtin_bit_cast(float, e.y);
-        in.var = vring[pos_q];
-        const uint32_t Ib = e.x >> 24;
-        in.Ikf = (float)Ib;
-        in.invZ = 1.0 / (double)in.Z;
-        const float aX = ((float)x - g.cx) * in.Z, aY = ((float)y - g.cy) * in.Z;
-        in.X = DIVC ? div_const(aX, g.fx, g.rfx) : aX / g.fx;
-        in.Y = DIVC ? div_const(aY, g.fy, g.rfy) : aY / g.fy;
-        const unsigned pos = region + (unsigned)running + (unsigned)lane;
-        {   // FcaRec: a 16-byte word and a 4-byte word (prep_build)
-          const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | (Ib << 24);
-          const unsigned long long zb = __builtin_bit_cast(unsigned long long, in.invZ);
-          ELLC_GLOBAL char* r = (ELLC_GLOBAL char*)K.crec + pos * (unsigned)sizeof(FcaRec);
-          typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
-          *(ELLC_GLOBAL u32x4a*)r = (u32x4a){xyI, __builtin_bit_cast(uint32_t, in.Z), __builtin_bit_cast(uint32_t, in.var), (uint32_t)zb};
-          *(ELLC_GLOBAL uint32_t*)(r + 16) = (uint32_t)(zb >> 32);
-        }
-        fca_accumulate_pixel(acc, fca_pixel_in<false, DIVC>(a, K, g, cur, S, pos, in));
-      }
-      q_head = ring_wrap(q_head + n_act);
-      q_cnt -= n_act;
-      running += n_act;
-    }
-  }
-  if (lane == 0) as_global_rw(K.blk_count)[sub * (ELLC_GN_THREADS / 64) + wave_index()] = running;
-  fca_acc_unpack<false>(acc, sums);
-}
-
 // The leading scalar parameters repeat what the prologue's first loads need (addresses of the state record and of the
 // pending partial sums, block counts): the library is built with kernel-argument preloading, so they arrive in SGPRs with
 // the wave instead of through a scalar load from the argument buffer — one memory round trip less at the head of a
 // latency-bound kernel. Everything else stays in the by-value struct.
-// BUILD: the first launch of a level — alignments whose keyframe slot has no valid lists (GnArgs::build) build their regions in this
-// launch (fcaf_build_pass / fca_build_pass_exact); the others walk their lists as in every later launch.
-template <bool DIVC, bool PIPE, bool FAST = false, int SAVEW = -1, bool BUILD = false>   // SAVEW: see fcaf_pixel (tolerance mode only)
+template <bool DIVC, bool PIPE, bool FAST = false, int SAVEW = -1>   // SAVEW: see fcaf_pixel (tolerance mode only)
 __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignState* src_state, const float* prev_part, int prev_nblk,
                                                                    int nblk, int age_rounds, FusedArgs fa) {   // 4 waves per SIMD: at most 128 VGPRs
   const GnArgs& a = fa.g;
-  int b = blockIdx.y, sub = blockIdx.x;
+  int b = blockIdx.y, sub = blockIdx.x, age = 0, per_age = nblk;
   if (age_rounds > 1) {
     const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
     const int per_round = (int)(gridDim.x * gridDim.y) / age_rounds;
-    const int per_age = nblk / age_rounds;          // blocks of one alignment in each round
-    const int age = lin / per_round;
+    per_age = nblk / age_rounds;          // blocks of one alignment in each round
+    age = lin / per_round;
     const int j = lin - age * per_round;
     b = j / per_age;
     sub = age * per_age + (j - b * per_age);
@@ -1784,35 +1542,34 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   // the solve runs. None of it depends on the pose.
   const LevelGeom g = a.geom[a.level];
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
-  const LevelLayout lay = a.lay[a.level];                             // likewise
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int pending = src.pending;
-  // this block's region of the slot's compact list (LevelLayout: whole tiles, interleaved over the plane, the age-balanced split
-  // in the number of tiles a block owns)
-  int begin = 0, end = 0;
-  bool build = false;
-  int tb = 0, te = 0;
-  TileRegs tr8;
-  if constexpr (BUILD) {
-    build = as_global(a.build)[b] != 0;
-    if (build) {   // block-uniform: the tiles this wave owns, and the planes of the first of them (requested before the solve)
-      wave_tiles(lay, sub, tb, te);
-      if (tb < te) tile_load(as_global(K.depth), as_global(K.var), as_global(K.img), g.n, g.cols, g.sw, 1.0f / (float)g.cols, lay.ppt,
-                             (unsigned)as_const(lay.tiles)[tb] * (unsigned)(lay.ppt << 6) + (threadIdx.x & 63u), tr8);
-    }
-  }
-  if (!build) wave_range(lay, K, sub, begin, end);
+  const int V = *as_global(K.count);
   const double group_sum = partial_group_sum(prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, prev_nblk);
+  // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
+  // split, which was tried in r01 and did not change the run time — co-resident blocks finish staggered because the
+  // SIMD arbiter serves the oldest wave first, not because their pixels differ)
+  int begin, end;
+  if (age_rounds > 1) {
+    const int gb = (int)(((long long)V * fa.age_cum[age]) >> 16), ge = (int)(((long long)V * fa.age_cum[age + 1]) >> 16);
+    const int chunk = (ge - gb + per_age - 1) / per_age;
+    begin = gb + (sub - age * per_age) * chunk;
+    end = min(ge, begin + chunk);
+  } else {
+    const int chunk = (V + nblk - 1) / nblk;
+    begin = sub * chunk;
+    end = min(V, begin + chunk);
+  }
   g_u8 cur = as_global(F.img);
   // this thread's first compact pixel, requested before the solve (exact mode: together with its pose-independent products)
   FcaIn first = fca_in_empty();
   FcaInF firstf = fcaf_empty();
   FcaPre first_pre;
   if constexpr (FAST) {
-    if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + (t & 63), end - 1));   // (a lane past the region's end starts on a copy of its last record: the pixel loop is wave-uniform)
+    if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));   // (a thread past the chunk's end starts on a copy of its last record: the pixel loop is block-uniform)
   } else {
-    if (begin + (t & 63) < end) {
-      first = fca_load<DIVC>(K, g, (unsigned)(begin + (t & 63)));
+    if (begin + t < end) {
+      first = fca_load<DIVC>(K, g, (unsigned)(begin + t));
     }
     first_pre = fca_prepare<DIVC>(g, first);
     // pin the arithmetic here (the compiler would otherwise sink it below the solve, onto the critical path)
@@ -1844,17 +1601,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   }
   if (skip) return;
   float sums[27];
-  if constexpr (BUILD) {
-    __shared__ BuildShared bsh;
-    if (build) {
-      if constexpr (FAST) fcaf_build_pass<SAVEW>(a, K, g, lay, sub, tb, te, cur, sh.newS, tr8, bsh, sums);
-      else fca_build_pass_exact<DIVC>(a, K, g, lay, sub, tb, te, cur, sh.newS, tr8, bsh, sums);
-    } else {
-      fca_chunk_pass<DIVC, PIPE, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
-    }
-  } else {
-    fca_chunk_pass<DIVC, PIPE, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
-  }
+  fca_chunk_pass<DIVC, PIPE, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
   ELLC_STAMP(7);
   ELLC_BSTAMP(2);
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
@@ -1919,17 +1666,22 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
   LevelGeom g = a.geom[lvl];
   KfLevelDev K = a.kf_tab[lvl * a.max_kf + slot];
   const FrLevelDev* F = &a.fr_tab[lvl * a.max_fr + frs];
-  int begin = 0, end = 0;
-  if (sub < nb_l) { const LevelLayout lay = a.lay[lvl]; wave_range(lay, K, sub, begin, end); }
+  int V = *as_global(K.count);
   const double group_sum = partial_group_sum_from(pend, pv, nb_l);
+  int begin, end;
+  {
+    const int chunk = (V + nb_l - 1) / nb_l;
+    begin = sub * chunk;
+    end = min(V, begin + chunk);
+  }
   // this thread's first record (exact mode: and its pose-independent products), requested before the solve
   FcaIn first = fca_in_empty();
   FcaInF firstf = fcaf_empty();
   FcaPre first_pre;
   if constexpr (FAST) {
-    if (sub < nb_l && begin < end) firstf = fcaf_load(K, (unsigned)min(begin + (t & 63), end - 1));
+    if (sub < nb_l && begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));
   } else {
-    if (sub < nb_l && begin + (t & 63) < end) first = fca_load<DIVC>(K, g, (unsigned)(begin + (t & 63)));
+    if (sub < nb_l && begin + t < end) first = fca_load<DIVC>(K, g, (unsigned)(begin + t));
     first_pre = fca_prepare<DIVC>(g, first);
     asm volatile("" ::"v"(first_pre.c_t0), "v"(first_pre.c_b1), "v"(first_pre.d), "v"(first_pre.fxz), "v"(first_pre.fyz),
                  "v"(first_pre.nvz), "v"(first_pre.nuz));   // pinned above the solve, see gn_fca_fused
@@ -1964,11 +1716,14 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
     g = a.geom[nl];
     K = a.kf_tab[nl * a.max_kf + slot];
     F = &a.fr_tab[nl * a.max_fr + frs];
-    { const LevelLayout lay = a.lay[nl]; wave_range(lay, K, sub, begin, end); }
+    V = *as_global(K.count);
+    const int chunk = (V + nb_n - 1) / nb_n;
+    begin = sub * chunk;
+    end = min(V, begin + chunk);
     if constexpr (FAST) {
-      if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + (t & 63), end - 1));   // (a lane past the region's end starts on a copy of its last record: the pixel loop is wave-uniform)
+      if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));   // (a thread past the chunk's end starts on a copy of its last record: the pixel loop is block-uniform)
     } else {
-      if (begin + (t & 63) < end) first = fca_load<DIVC>(K, g, (unsigned)(begin + (t & 63)));
+      if (begin + t < end) first = fca_load<DIVC>(K, g, (unsigned)(begin + t));
       first_pre = fca_prepare<DIVC>(g, first);
     }
   } else if (sub >= nb_l) {
@@ -2070,98 +1825,7 @@ __device__ __forceinline__ void ica_accumulate_pixel(float (&acc)[6], const type
   }
 }
 
-// The constant-weight path's first launch of a level for an alignment without lists (see fcaf_build_pass): a step forms the ICA
-// record of its entry — prep_build's expressions: the template gradient at the integer pixel, the exact steepest-descent row, the
-// saved weight —, stores it, adds w J^T J to the 21 sums of H (PixelWisePyramid.cpp:664-669, :938) and runs the pixel step.
-// The 27 sums go out like an FCA launch's; the next launch's prologue inverts H (solve mode 3).
 template <bool FAST>
-__device__ __forceinline__ void ica_build_pass(const KfLevelDev& K, const LevelGeom& g, const LevelLayout& lay, int sub, int tb, int te, g_u8 cur,
-                                               const float* newS, TileRegs& tr, BuildShared& bsh, float (&sums)[27]) {
-  const int t = threadIdx.x & 63;   // lane: every wave builds its own region
-  uint2* ring = bsh.ring[wave_index()];
-  float* vring = bsh.vring[wave_index()];
-  float S[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) S[i] = newS[i];
-#pragma unroll
-  for (int i = 0; i < 27; i++) sums[i] = 0.0f;
-  float acc[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) acc[i] = 0.0f;
-  const int ppt = lay.ppt, T = ppt << 6;
-  const unsigned region = (unsigned)tb * (unsigned)T;
-  const int cols = g.cols, sw = g.sw;
-  const float inv_cols = 1.0f / (float)cols;
-  g_u8 img = as_global(K.img);
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  int q_head = 0, q_cnt = 0, running = 0;   // block-uniform
-  for (int jt = tb; jt < te; jt++) {
-    const unsigned pix0 = (unsigned)as_const(lay.tiles)[jt] * (unsigned)T + (unsigned)t;
-    q_cnt += tile_park(tr, ppt, pix0, ring_wrap(q_head + q_cnt), ring, vring);
-    const bool last = (jt + 1 == te);
-    if (!last) tile_load(as_global(K.depth), as_global(K.weight), img, g.n, cols, sw, inv_cols, ppt,
-                         (unsigned)as_const(lay.tiles)[jt + 1] * (unsigned)T + (unsigned)t, tr);
-    while (q_cnt >= 64 || (last && q_cnt > 0)) {
-      const int n_act = min(64, q_cnt);
-      if (t < n_act) {
-        const int pos_q = ring_wrap(q_head + t);
-        const uint2 e = ring[pos_q];
-        const float Z = __builtin_bit_cast(float, e.y);
-        int x, y;
-        pix_xy((int)(e.x & 0xffffffu), cols, inv_cols, x, y);
-        // the pixel and its two row neighbours from ONE unaligned dword starting at max(x - 1, 0) (prep_build)
-        const uint32_t rowq = load_u32_unaligned(img, (unsigned)(y * sw + max(x - 1, 0)));
-        const uint32_t b0 = rowq & 0xffu, b1 = (rowq >> 8) & 0xffu, b2 = (rowq >> 16) & 0xffu;
-        const uint32_t pc = (x == 0) ? b0 : b1;
-        const uint32_t pxm = b0;
-        const uint32_t pxp = (x == 0) ? b1 : ((x == cols - 1) ? b1 : b2);
-        const int ym = max(y - 1, 0), yp = min(y + 1, g.rows - 1);
-        const float sx = (x == 0 || x == cols - 1) ? 1.0f : 0.5f;
-        const float sy = (y == 0 || y == g.rows - 1) ? 1.0f : 0.5f;
-        const float gradx = sx * ((float)pxp - (float)pxm);
-        const float grady = sy * ((float)img[(unsigned)(yp * sw + x)] - (float)img[(unsigned)(ym * sw + x)]);
-        const float wsave = vring[pos_q];
-        float J[6];
-        jacobian_row<false>(gradx, grady, x, y, 1.0 / (double)Z, g, J);
-        const unsigned pos = region + (unsigned)running + (unsigned)t;
-        typename IcaInOf<FAST>::type in;
-        if constexpr (FAST) {
-          in.xyI = (uint32_t)x | ((uint32_t)y << 12) | (pc << 24);
-          in.d = __builtin_amdgcn_rcpf(Z);
-          in.W = wsave;
-          in.gxy = ((uint32_t)(int)(2.0f * gradx) & 0xffffu) | ((uint32_t)(int)(2.0f * grady) << 16);
-          ((ELLC_GLOBAL u32x4*)K.crec)[pos] = (u32x4){in.xyI, __builtin_bit_cast(uint32_t, in.d), __builtin_bit_cast(uint32_t, wsave), in.gxy};
-        } else {
-          in.X = (((float)x - g.cx) * Z) / g.fx;
-          in.Y = (((float)y - g.cy) * Z) / g.fy;
-          in.Z = Z; in.Ikf = (float)pc; in.W = wsave;
-#pragma unroll
-          for (int r = 0; r < 6; r++) in.sd[r] = J[r];
-          ELLC_GLOBAL u32x4* ro = (ELLC_GLOBAL u32x4*)((ELLC_GLOBAL char*)K.irec + pos * (unsigned)sizeof(IcaRec));
-          ro[0] = (u32x4){__builtin_bit_cast(uint32_t, in.X), __builtin_bit_cast(uint32_t, in.Y), __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, in.Ikf)};
-          ro[1] = (u32x4){__builtin_bit_cast(uint32_t, wsave), __builtin_bit_cast(uint32_t, J[0]), __builtin_bit_cast(uint32_t, J[1]), __builtin_bit_cast(uint32_t, J[2])};
-          ro[2] = (u32x4){__builtin_bit_cast(uint32_t, J[3]), __builtin_bit_cast(uint32_t, J[4]), __builtin_bit_cast(uint32_t, J[5]), 0u};
-        }
-        int q = 0;
-#pragma unroll
-        for (int rr = 0; rr < 6; rr++) {
-          const float wJ = J[rr] * wsave;   // weightedSteepestDescent (:664-669); H = WSD * SD^T (:938)
-#pragma unroll
-          for (int cc = rr; cc < 6; cc++) { sums[q] = __builtin_fmaf(wJ, J[cc], sums[q]); q++; }
-        }
-        ica_accumulate_pixel<FAST>(acc, in, g, cur, S);
-      }
-      q_head = ring_wrap(q_head + n_act);
-      q_cnt -= n_act;
-      running += n_act;
-    }
-  }
-  if (t == 0) as_global_rw(K.blk_count)[sub * (ELLC_GN_THREADS / 64) + wave_index()] = running;
-#pragma unroll
-  for (int i = 0; i < 6; i++) sums[21 + i] = acc[i];
-}
-
-template <bool FAST, bool BUILD = false>
 __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState* src_state, const float* prev_part, int prev_nblk, FusedArgs fa) {
   const GnArgs& a = fa.g;   // leading scalars: preloaded kernel arguments, see gn_fca_fused
   const int b = blockIdx.y, sub = blockIdx.x;
@@ -2173,31 +1837,19 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
   const LevelGeom g = a.geom[a.level];
   const int slot = a.kf_slot[b];
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + slot];   // by value: uniform, lives in SGPRs
-  const LevelLayout lay = a.lay[a.level];                     // likewise
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int pending = src.pending;
-  int begin = 0, end = 0;
-  const bool built = as_global(a.build)[b] != 0;   // this alignment builds its lists in the first launch of every level
-  const bool build = BUILD && built;
-  int tb = 0, te = 0;
-  TileRegs tr8;
-  if constexpr (BUILD) {
-    if (build) {   // block-uniform: the tiles this wave owns, and the planes of the first of them (requested before the solve)
-      wave_tiles(lay, sub, tb, te);
-      if (tb < te) tile_load(as_global(K.depth), as_global(K.weight), as_global(K.img), g.n, g.cols, g.sw, 1.0f / (float)g.cols, lay.ppt,
-                             (unsigned)as_const(lay.tiles)[tb] * (unsigned)(lay.ppt << 6) + (threadIdx.x & 63u), tr8);
-    }
-  }
-  if (!build) wave_range(lay, K, sub, begin, end);
+  const int V = *as_global(K.count);
   const double group_sum = partial_group_sum(prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, prev_nblk);
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = sub * chunk;
+  const int end = min(V, begin + chunk);
   g_u8 cur = as_global(F.img);
   typename IcaInOf<FAST>::type first = ica_in_empty<FAST>();
-  if (begin + (t & 63) < end) first = ica_load_any<FAST>(K, (unsigned)(begin + (t & 63)));
+  if (begin + t < end) first = ica_load_any<FAST>(K, (unsigned)(begin + t));
   if (pending) {
-    float* hinv = a.kf_tab[fa.prev_level * a.max_kf + slot].hinv;
-    const bool with_h = fa.prev_first && built;   // the pending sums hold H as well: invert it here, block 0 keeps it for the level's later launches
-    solve_step<FAST>(sh, group_sum, with_h ? 3 : 2, fa.prev_level, fa.early_exit, src, nullptr, hinv);
-    if (with_h && writer && t < 36) hinv[t] = sh.Hinv[t];
+    const float* hinv = a.kf_tab[fa.prev_level * a.max_kf + slot].hinv;
+    solve_step<FAST>(sh, group_sum, 2, fa.prev_level, fa.early_exit, src, nullptr, hinv);
   } else {
     if (t < 6) sh.newpose[t] = src.pose[t];
     if (t < 12) sh.newS[t] = src.S[t];
@@ -2217,27 +1869,18 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
     }
   }
   if (skip) return;
-  float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
-  if constexpr (BUILD) {
-    __shared__ BuildShared bsh;
-    if (build) {
-      float sums[27];
-      ica_build_pass<FAST>(K, g, lay, sub, tb, te, cur, sh.newS, tr8, bsh, sums);
-      block_reduce_store<27>(sums, out);
-      return;
-    }
-  }
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
   float acc[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) acc[i] = 0.0f;
-  int i = begin + (t & 63);
+  int i = begin + t;
   if (i < end) {
     ica_accumulate_pixel<FAST>(acc, first, g, cur, S);
-    for (i += 64; i < end; i += 64) ica_accumulate_pixel<FAST>(acc, ica_load_any<FAST>(K, (unsigned)i), g, cur, S);
+    for (i += ELLC_GN_THREADS; i < end; i += ELLC_GN_THREADS) ica_accumulate_pixel<FAST>(acc, ica_load_any<FAST>(K, (unsigned)i), g, cur, S);
   }
+  float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
   block_reduce_store<6>(acc, out + 21);   // the b slots of the partial record; the H slots are not read by a mode-2 solve
 }
 
@@ -2259,10 +1902,8 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
   if (t < ELLC_MAX_LEVELS) it_copy[t] = src.iters[t];
   if (pending) {
     const float* prev = a.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
-    float* hinv = fa.ica ? a.kf_tab[lvl * a.max_kf + a.kf_slot[b]].hinv : nullptr;
-    const bool with_h = fa.ica && fa.prev_first && as_global(a.build)[b] != 0;   // see gn_ica_fused
-    solve_step<FAST>(sh, partial_group_sum(prev, ADAPT ? fa.nblk_lv[lvl] : fa.prev_nblk), fa.ica ? (with_h ? 3 : 2) : 0, lvl, fa.early_exit, src, dst, hinv);
-    if (with_h && t < 36) hinv[t] = sh.Hinv[t];
+    const float* hinv = fa.ica ? a.kf_tab[lvl * a.max_kf + a.kf_slot[b]].hinv : nullptr;
+    solve_step<FAST>(sh, partial_group_sum(prev, ADAPT ? fa.nblk_lv[lvl] : fa.prev_nblk), fa.ica ? 2 : 0, lvl, fa.early_exit, src, dst, hinv);
   } else {
     if (t < 6) sh.newpose[t] = src.pose[t];
     if (t < 12) sh.newS[t] = src.S[t];
@@ -2387,7 +2028,7 @@ __global__ void stage_in(int* __restrict__ dst, const int* __restrict__ src_host
 // The same for a schedule that is launched kernel by kernel (the tracking call, one or two alignments): the staged record
 // arrives in the kernel arguments instead of being read from pinned host memory (a PCIe round trip at the head of the chain)
 struct StageSmall {
-  int kf[2], fr[2], uniq[2], build[2];
+  int kf[2], fr[2], uniq[2];
   float pose[12];
 };
 // count_*: ellc_track_frame's seeds figure rides along — blocks 1.. count the depth map's valid hypotheses (dm_count_valid_body,
@@ -2401,7 +2042,7 @@ __global__ __launch_bounds__(1024) void stage_in_args(int* __restrict__ dst, Sta
   }
   const int t = threadIdx.x;
   if (t >= 64) return;
-  if (t < B) { dst[t] = s.kf[t]; dst[cap + t] = s.fr[t]; dst[9 * cap + t] = s.build[t]; }
+  if (t < B) { dst[t] = s.kf[t]; dst[cap + t] = s.fr[t]; }
   if (t < n_unique) dst[2 * cap + t] = s.uniq[t];
   if (t < 6 * B) ((float*)(dst + 3 * cap))[t] = s.pose[t];
   // init_state_record with exp(pose) spread over nine lanes per alignment (lane 3 r + k of a group of 16 evaluates entry (r, k):
@@ -2447,44 +2088,50 @@ __device__ inline void init_state_record(AlignState& st, const float* init_pose,
   for (int i = 0; i < 6; i++) st.b[i] = 0.0f;
 }
 
-// PixelWisePyramid::saveWeights(true) (:544-549): weight_pyramid[l] += display_weightimg (masked pixels add 0). The compact
-// list is walked region by region (LevelLayout): blockIdx.x strides over the blocks of the layout.
-__device__ __forceinline__ void add_saved_weights_level(const KfLevelDev& K, const LevelGeom& g, const LevelLayout& lay, int fast_records) {
-  const int cols = g.cols;
-  // a wave per region of the level's layout (a region of a small batch holds about as many records as a wave has lanes)
-  const int wpb = (int)(blockDim.x >> 6);
-  for (int vb = (int)blockIdx.x * wpb + wave_index(); vb < lay.nblk * (ELLC_GN_THREADS / 64); vb += (int)gridDim.x * wpb) {
-    const int tb = as_const(lay.blk_begin)[vb], te = as_const(lay.blk_begin)[vb + 1];
-    const int begin = tb * (lay.ppt << 6), end = begin + (tb < te ? as_global(K.blk_count)[vb] : 0);
-    for (int i = begin + (int)(threadIdx.x & 63); i < end; i += 64) {
-      // saved weights exist in the FCA schedule only: its records carry the pixel position
-      size_t p;
-      if (fast_records) {
-        int x, y;
-        fcaf_position(((const FcaRecF*)K.crec)[i], g, x, y);
-        p = (size_t)y * cols + x;
-      } else {
-        const uint32_t xyI = K.crec[i].xyI;
-        p = (size_t)((xyI >> 12) & 0xfffu) * cols + (xyI & 0xfffu);
-      }
-      K.weight[p] = K.weight[p] + K.wlast[i];
+// PixelWisePyramid::saveWeights(true) (:544-549): weight_pyramid[l] += display_weightimg (masked pixels add 0)
+__global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, int level, int max_kf, int fast_records) {
+  const int b = blockIdx.y;
+  const KfLevelDev& K = kf_tab[level * max_kf + kf_slot[b]];
+  const int V = *K.count;
+  const int cols = geom[level].cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+    // saved weights exist in the FCA schedule only: its records carry the pixel position
+    size_t p;
+    if (fast_records) {
+      int x, y;
+      fcaf_position(((const FcaRecF*)K.crec)[i], geom[level], x, y);
+      p = (size_t)y * cols + x;
+    } else {
+      const uint32_t xyI = K.crec[i].xyI;
+      p = (size_t)((xyI >> 12) & 0xfffu) * cols + (xyI & 0xfffu);
     }
+    K.weight[p] = K.weight[p] + K.wlast[i];
   }
-}
-__global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, const LevelLayout* lay, int level, int max_kf,
-                                     int fast_records) {
-  add_saved_weights_level(kf_tab[level * max_kf + kf_slot[blockIdx.y]], geom[level], lay[level], fast_records);
 }
 
 // The same for every level in ONE launch at the end of a fused schedule (grid (x, B, L)): each level's wlast holds the
 // weights of that level's last executed pixel pass. Only once the alignment's schedule has ended (the state-driven schedule
 // may stop short of it and be continued: cur_level of the record the finish kernel wrote is -1 at the end) and only ONCE per
 // alignment: a continuation graph carries the alignments its first graph already ended as cur_level = -2 (gn_fca_adaptive).
-__global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, const LevelLayout* lay,
-                                         const AlignState* state, int max_kf, int fast_records) {
+__global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, const AlignState* state, int max_kf,
+                                         int fast_records) {
   const int b = blockIdx.y, level = blockIdx.z;
   if (state[b].cur_level != -1) return;
-  add_saved_weights_level(kf_tab[level * max_kf + kf_slot[b]], geom[level], lay[level], fast_records);
+  const KfLevelDev& K = kf_tab[level * max_kf + kf_slot[b]];
+  const int V = *K.count;
+  const int cols = geom[level].cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+    size_t p;
+    if (fast_records) {
+      int x, y;
+      fcaf_position(((const FcaRecF*)K.crec)[i], geom[level], x, y);
+      p = (size_t)y * cols + x;
+    } else {
+      const uint32_t xyI = K.crec[i].xyI;
+      p = (size_t)((xyI >> 12) & 0xfffu) * cols + (xyI & 0xfffu);
+    }
+    K.weight[p] = K.weight[p] + K.wlast[i];
+  }
 }
 
 }  // namespace ellc

@@ -9,30 +9,41 @@
 namespace ellc {
 
 // ---------------------------------------------------------------------------------------------------
-// Compaction of the keyframe's valid pixels (mask = depth_pyramid[l] > 0, Frame.cpp:295-301) into the wave-owned regions of the
-// level's layout (LevelLayout, ellc_device.hpp) as launches of its own: a count launch and a scatter launch, a WAVE per tile in both,
-// every tile of every level of every listed keyframe at once — the form for schedules that cannot build their lists themselves
-// (launches over fewer than eight alignments, where a wave's handful of tiles walked one after the other costs more than two
-// launches: a single 640x480 alignment 0.223 ms against 0.234; alignments that share a keyframe slot, whose blocks would write the
-// same regions side by side; the state-driven tracking schedule; the single-step API) and for the modes whose pixel pass does not
-// hide a build (exact arithmetic, constant weights: measured). The tolerance-mode FCA schedule of a batch builds its
-// lists in the first launch of every level instead (fcaf_build_pass, ellc_kernels_gn.hpp) and launches neither kernel.
-// Tiles are addressed by their position p in the layout's tile table: tiles[p] is the tile, owner[p] the wave region it belongs
-// to, and the tiles of one region are consecutive in p — the offset of a tile inside its region is the sum of the counts of the
-// region's earlier tiles (at most a few dozen words, read by the scatter wave itself: no prefix pass).
+// Compaction of the keyframe's valid pixels (mask = depth_pyramid[l] > 0, Frame.cpp:295-301), raster
+// order preserved. Two launches (count per tile, then scatter) cover all levels of all listed keyframe slots.
+#define ELLC_TILE 2048          // pixels per block: 256 threads x 8 consecutive pixels (two float4 loads)
+
 struct PrepArgs {
   const LevelGeom* geom;
   const KfLevelDev* kf_tab;
-  const LevelLayout* lay;      // [levels] the layout the consumers of these lists use
   const int* slots;            // unique keyframe slots
   int levels, max_kf;
   int need;                    // bit 0: planes Z / I / saved weight (unfused ICA kernels); bit 1: FcaRec records (FCA);
-                               // bit 2: IcaRec records + per-block sums of H (fused ICA schedule); bit 3: FcaRecF records
+                               // bit 2: IcaRec records + per-tile sums of H (fused ICA schedule); bit 3: FcaRecF records
                                // (FCA in tolerance mode, cfg.arith = ELLC_ARITH_FAST); bit 4 (with bit 2): the ICA records in
                                // the tolerance mode's 16-byte form (IcaInF) instead of IcaRec
-  int blk_prefix[ELLC_MAX_LEVELS + 1];   // prefix of the blocks (four tiles each) per level: blockIdx.x -> level, first tile position
-  int level0;                  // ica_hinv: levels level0 + blockIdx.x
+  int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
+  int tile0, level0;           // this launch covers tiles tile0 + blockIdx.x (count / scatter), levels level0 + blockIdx.x (scan)
 };
+
+__device__ __forceinline__ int prep_level_of(const PrepArgs& a, int tile, int& local) {
+  int l = 0;
+  while (l + 1 < a.levels && tile >= a.tile_begin[l + 1]) l++;
+  local = tile - a.tile_begin[l];
+  return l;
+}
+
+// eight consecutive depths of this thread (zeros past the end of the plane)
+__device__ __forceinline__ void prep_load8(const float* __restrict__ depth, int i0, int n, float (&d)[8]) {
+  if (i0 + 7 < n) {
+    const float4 a = *reinterpret_cast<const float4*>(depth + i0);
+    const float4 b = *reinterpret_cast<const float4*>(depth + i0 + 4);
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) d[j] = (i0 + j < n) ? depth[i0 + j] : 0.0f;
+  }
+}
 
 // inclusive scan inside a wave; returns the wave total through `total`
 __device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
@@ -46,53 +57,87 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
   return v;
 }
 
-// blockIdx.x -> level and the tile position p of this wave (p >= ntiles: nothing to do)
-__device__ __forceinline__ int prep_locate(const PrepArgs& a, int& p) {
-  int level = 0;
-  while (level + 1 < a.levels && (int)blockIdx.x >= a.blk_prefix[level + 1]) level++;
-  p = ((int)blockIdx.x - a.blk_prefix[level]) * (ELLC_GN_THREADS / 64) + wave_index();
-  return level;
-}
-
 __global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
-  int p;
-  const int level = prep_locate(a, p);
-  const LevelLayout Lay = a.lay[level];
-  if (p >= Lay.ntiles) return;
+  int local;
+  const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
   const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
-  const int n = a.geom[level].n, ppt = Lay.ppt;
-  const unsigned pix0 = (unsigned)as_const(Lay.tiles)[p] * (unsigned)(ppt << 6) + (threadIdx.x & 63u);
-  const ELLC_GLOBAL float* depth = gptr(K.depth);
+  const int n = a.geom[level].n;
+  const int i0 = local * ELLC_TILE + threadIdx.x * 8;
   float d[8];
+  prep_load8(K.depth, i0, n, d);
+  int c = 0;
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const unsigned i = pix0 + (unsigned)(j * 64);
-    d[j] = (j < ppt && i < (unsigned)n) ? depth[i] : 0.0f;
+  for (int j = 0; j < 8; j++) c += (d[j] > 0.0f) ? 1 : 0;
+  __shared__ int ws[4];
+  int tot;
+  wave_inclusive_scan(c, tot);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    K.tile_count[local] = ws[0] + ws[1] + ws[2] + ws[3];
   }
-  int tot = 0;
-#pragma unroll
-  for (int j = 0; j < 8; j++) tot += __popcll(__ballot(d[j] > 0.0f));
-  if ((threadIdx.x & 63) == 0) K.tile_count[p] = tot;
 }
 
-// Scatter: the wave parks the valid pixels of its tile in its LDS ring by ballot rank (tile_park), then runs densely over the
-// parked entries — every lane has a valid pixel — computes the record (three IEEE divisions in the exact forms) and stores it;
-// consecutive lanes write consecutive records. Without the LDS step the divisions would run for every wave that holds at least one
-// valid pixel, i.e. about four times as often on a semi-dense map. No block barrier but the one in front of the sums of H.
+// Scatter, two phases per tile of ELLC_TILE pixels. Phase 1: thread t owns pixels base + j*256 + t (j = 0..7), so the
+// depth loads of a wave are contiguous; ballot ranks give every valid pixel its raster-order rank inside the tile
+// (order = (j, wave, lane)), and (pixel index, depth) are parked in LDS at that rank. Phase 2 runs densely over the
+// parked entries — every lane has a valid pixel — computes the record (three IEEE divisions) and stores it; consecutive
+// lanes write consecutive records. Without the LDS step the divisions would run for every wave that holds at least one
+// valid pixel, i.e. about four times as often on a semi-dense map.
 template <int NEED>   // compile-time copy of PrepArgs::need: the FCA variant carries no Jacobian / H-sum code (and registers)
 __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
-  int p;
-  const int level = prep_locate(a, p);
-  const LevelLayout Lay = a.lay[level];
+  int local;
+  const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
   const KfLevelDev K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
   const LevelGeom& g = a.geom[level];
   const int n = g.n;
-  const int lane = threadIdx.x & 63;
-  const bool on = p < Lay.ntiles;   // wave-uniform (a block's last waves may have no tile; they still take part in the H sums)
-  const int ppt = Lay.ppt, T = ppt << 6;
-  __shared__ BuildShared bsh;
-  uint2* ring = bsh.ring[wave_index()];
-  float* vring = bsh.vring[wave_index()];
+  const int base = local * ELLC_TILE + (int)threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int cnt[33];   // [j][wave] exclusive offsets, [32] = tile total
+  __shared__ int before[4]; // per wave: valid pixels in the tiles of this level that precede this one
+  __shared__ uint32_t s_idx[ELLC_TILE];
+  __shared__ float s_Z[ELLC_TILE];
+  // the eight depth loads first, then the loads of the tile counts: both sets are in flight together (r03: a block's life is a
+  // chain of memory round trips of 2-3 us each under load — table entry, counts, depths, gathers, stores: 12 us for 2048 pixels)
+  float d[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int i = base + j * 256;
+    d[j] = (i < n) ? gptr(K.depth)[(unsigned)i] : 0.0f;
+  }
+  {   // this tile's offset in the level's list = sum of the counts prep_count left for the tiles before it (at most a few hundred)
+    int part = 0, tot;
+    for (int i = (int)threadIdx.x; i < local; i += 256) part += gptr(K.tile_count)[(unsigned)i];
+    wave_inclusive_scan(part, tot);
+    if (lane == 0) before[wave] = tot;
+  }
+  unsigned long long m[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    m[j] = __ballot(d[j] > 0.0f);
+    if (lane == 0) cnt[j * 4 + wave] = __popcll(m[j]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {   // exclusive scan of the 32 (j, wave) counts
+    int v = (lane < 32) ? cnt[lane] : 0, tot;
+    const int inc = wave_inclusive_scan(v, tot);
+    if (lane < 32) cnt[lane] = inc - v;
+    if (lane == 0) cnt[32] = tot;
+  }
+  __syncthreads();
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if (d[j] > 0.0f) {
+      const int r = cnt[j * 4 + wave] + __popcll(m[j] & lt);
+      s_idx[r] = (uint32_t)(base + j * 256);
+      s_Z[r] = d[j];
+    }
+  }
+  __syncthreads();
+  const int nvalid = cnt[32];
+  const unsigned tile_off = (unsigned)(before[0] + before[1] + before[2] + before[3]);
+  if (threadIdx.x == 0 && local == a.tile_begin[level + 1] - a.tile_begin[level] - 1) *K.count = (int)tile_off + nvalid;   // last tile: the level's total
   const float inv_cols = 1.0f / (float)g.cols;
   const ELLC_GLOBAL float* var = gptr(K.var);
   const ELLC_GLOBAL float* wgt = gptr(K.weight);
@@ -109,64 +154,70 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   float hacc[27];
 #pragma unroll
   for (int q = 0; q < 27; q++) hacc[q] = 0.0f;
-  if (on) {
-  // the second plane the records need rides with the depths: the variance (FCA) or the saved weights (constant-weight records)
-  const ELLC_GLOBAL float* plane2 = (NEED == 8 || NEED == 2) ? var : wgt;
-  const unsigned pix0 = (unsigned)as_const(Lay.tiles)[p] * (unsigned)T + (unsigned)lane;
-  TileRegs tr;
-  tile_load(gptr(K.depth), plane2, img, n, g.cols, g.sw, inv_cols, ppt, pix0, tr);
-  // this tile's offset in its region = the counts prep_count left for the region's earlier tiles
-  const int vb = as_const(Lay.owner)[p];
-  const int tb = as_const(Lay.blk_begin)[vb], te = as_const(Lay.blk_begin)[vb + 1];
-  int running = 0;
-  for (int j0 = tb; j0 < p; j0 += 64) {   // wave-uniform
-    int part = (j0 + lane < p) ? gptr(K.tile_count)[j0 + lane] : 0, tot;
-    wave_inclusive_scan(part, tot);
-    running += tot;
-  }
-  running = __builtin_amdgcn_readfirstlane(running);
-  const unsigned region = (unsigned)tb * (unsigned)T;
-  const int nvalid = tile_park(tr, ppt, pix0, 0, ring, vring);
-  if (lane == 0 && p == te - 1) K.blk_count[vb] = running + nvalid;   // the region's last tile: its total
-  const unsigned tile_off = region + (unsigned)running;
+  // The 48-byte ICA records leave through an LDS staging block of 256 records so that consecutive lanes store consecutive
+  // 16-byte words (lane-per-record, every store instruction would touch a third of each line): -5 % on the kernel. The
+  // FCA records (20 bytes exact, 16 tolerance mode) are stored directly (r01 A/B: the two extra barriers per 256 records cost more than the partial-line
+  // stores).
+  constexpr int CH = 3;
+  __shared__ u32x4 s_rec[((NEED & 4) && !(NEED & 16)) ? 256 * CH : 1];
+  ELLC_GLOBAL u32x4* rec_out = (ELLC_GLOBAL u32x4*)K.irec;
   if constexpr (NEED == 8 || NEED == 2) {
-    // FCA records: everything a record needs was parked with the pixel
-    for (int r0 = 0; r0 < nvalid; r0 += 64) {   // wave-uniform trip count
-      const int r = r0 + lane;
-      if (r < nvalid) {
-        const uint2 e = ring[r];
-        const float Z = __builtin_bit_cast(float, e.y), vv = vring[r];
-        const uint32_t Ib = e.x >> 24;
-        int x, y;
-        pix_xy((int)(e.x & 0xffffffu), cols, inv_cols, x, y);
-        const unsigned pos = tile_off + (unsigned)r;
+    // FCA records: up to four records per thread and trip, all their gathers (the image byte and the variance of each) issued
+    // before the first is used — one memory round trip per 1024 records instead of one per 256
+    constexpr int U = 4;
+    for (int r0 = 0; r0 < nvalid; r0 += U * 256) {   // block-uniform trip count
+      int ii[U], xx[U], yy[U];
+      float ZZ[U], vv[U];
+      uint8_t Ib[U];
+      bool act[U];
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        const int r = r0 + k * 256 + (int)threadIdx.x;
+        act[k] = r < nvalid;
+        const int rr = act[k] ? r : 0;   // (an idle lane reads entry 0: a valid address, nothing is stored)
+        ii[k] = (int)s_idx[rr];
+        ZZ[k] = s_Z[rr];
+        int y = (int)(((float)ii[k] + 0.5f) * inv_cols);   // i < 2^24: exact conversion; corrected below
+        if (y * cols > ii[k]) y--;
+        if ((y + 1) * cols <= ii[k]) y++;
+        yy[k] = y;
+        xx[k] = ii[k] - y * cols;
+        Ib[k] = img[(unsigned)(y * sw + xx[k])];
+        vv[k] = var[(unsigned)ii[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        if (!act[k]) continue;
+        const unsigned pos = tile_off + (unsigned)(r0 + k * 256) + threadIdx.x;
+        const int x = xx[k], y = yy[k];
+        const float Z = ZZ[k];
         if constexpr (NEED == 8) {   // tolerance mode: one 16-byte record per pixel (FcaRecF)
-          const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | Ib;   // FcaRecF: y < 4096 as f32 has its 12 low bits clear
+          const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | (uint32_t)Ib[k];   // FcaRecF: y < 4096 as f32 has its 12 low bits clear
           const float dd = __builtin_amdgcn_rcpf(Z);
           const float pn = ((float)x - g.cx) * g.rfx;   // u / fx (fcaf_pixel forms v / fy from y)
-          crec[pos] = (u32x4){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, vv), __builtin_bit_cast(uint32_t, dd)};
+          crec[pos] = (u32x4){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, vv[k]), __builtin_bit_cast(uint32_t, dd)};
         } else {   // one 20-byte record per pixel (FcaRec): a 16-byte word and a 4-byte word
-          const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | (Ib << 24);
+          const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)Ib[k] << 24);
           const double invZ = 1.0 / (double)Z;
           const unsigned long long zb = __builtin_bit_cast(unsigned long long, invZ);
-          ELLC_GLOBAL char* rp = (ELLC_GLOBAL char*)K.crec + pos * (unsigned)sizeof(FcaRec);
+          ELLC_GLOBAL char* r = (ELLC_GLOBAL char*)K.crec + pos * (unsigned)sizeof(FcaRec);
           typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
-          *(ELLC_GLOBAL u32x4a*)rp = (u32x4a){xyI, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, vv), (uint32_t)zb};
-          *(ELLC_GLOBAL uint32_t*)(rp + 16) = (uint32_t)(zb >> 32);
+          *(ELLC_GLOBAL u32x4a*)r = (u32x4a){xyI, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, vv[k]), (uint32_t)zb};
+          *(ELLC_GLOBAL uint32_t*)(r + 16) = (uint32_t)(zb >> 32);
         }
       }
     }
   } else
-  for (int r0 = 0; r0 < nvalid; r0 += 64) {   // wave-uniform trip count
-    // the record at position p of the wave's region belongs to lane p mod 64, as in the Gauss-Newton launches that walk the region
-    const int r = r0 + ((lane - running) & 63);
+  for (int r0 = 0; r0 < nvalid; r0 += 256) {   // block-uniform trip count
+    const int r = r0 + (int)threadIdx.x;
     if (r < nvalid) {
-    const uint2 e = ring[r];
-    const int i = (int)(e.x & 0xffffffu);
-    const float Z = __builtin_bit_cast(float, e.y);
+    const int i = (int)s_idx[r];
+    const float Z = s_Z[r];
     const unsigned pos = tile_off + (unsigned)r;
-    int x, y;
-    pix_xy(i, cols, inv_cols, x, y);
+    int y = (int)(((float)i + 0.5f) * inv_cols);   // i < 2^24: exact conversion; corrected below
+    if (y * cols > i) y--;
+    if ((y + 1) * cols <= i) y++;
+    const int x = i - y * cols;
     const uint32_t xy = ((uint32_t)y << 16) | (uint32_t)x;
     // the pixel and its two row neighbours (clamped at the image's edges, Frame.cpp:185-285) from ONE unaligned dword starting at
     // max(x - 1, 0) — three byte gathers cost the vector cache three times what the dword costs (the row's stored width and the
@@ -177,34 +228,35 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
     const uint32_t pc = (x == 0) ? b0 : b1;                                  // I(x, y)
     const uint32_t pxm = b0;                                                 // I(max(x - 1, 0), y)
     const uint32_t pxp = (x == 0) ? b1 : ((x == cols - 1) ? b1 : b2);        // I(min(x + 1, cols - 1), y)
-    const float Ikf = (need & 4) ? (float)pc : (float)(e.x >> 24);
+    const float Ikf = (need & 4) ? (float)pc : (float)img[(unsigned)(y * sw + x)];
     if (need & 1) {   // unfused ICA kernels read planes
       cxy[pos] = xy;
       cZ[pos] = Z;
       cI[pos] = Ikf;
-      cW[pos] = vring[r];
+      cW[pos] = wgt[(unsigned)i];
     }
     if (need & 4) {   // ICA record: template-gradient Jacobian at the integer pixel (PixelWisePyramid.cpp:561-680)
       // frame::calculateGradient of the keyframe level image at (y,x)  (Frame.cpp:185-285)
-      const int ym = max(y - 1, 0), yp = min(y + 1, g.rows - 1);
+      const int xm = max(x - 1, 0), xp = min(x + 1, cols - 1), ym = max(y - 1, 0), yp = min(y + 1, g.rows - 1);
       const float sx = (x == 0 || x == cols - 1) ? 1.0f : 0.5f;
       const float sy = (y == 0 || y == g.rows - 1) ? 1.0f : 0.5f;
       const float gradx = sx * ((float)pxp - (float)pxm);
+      (void)xm; (void)xp;
       const float grady = sy * ((float)img[(unsigned)(yp * sw + x)] - (float)img[(unsigned)(ym * sw + x)]);
       float J[6];
       jacobian_row<false>(gradx, grady, x, y, 1.0 / (double)Z, g, J);
-      const float wsave = vring[r];
+      const float wsave = wgt[(unsigned)i];
       const float X = (((float)x - cx) * Z) / fx;
       const float Y = (((float)y - cy) * Z) / fy;
       if (need & 16) {   // tolerance mode: one 16-byte word (ica_load_fast); twice a central difference of bytes is an integer below 2^15
         const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | (pc << 24);
         const uint32_t gxy = ((uint32_t)(int)(2.0f * gradx) & 0xffffu) | ((uint32_t)(int)(2.0f * grady) << 16);
         crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, __builtin_amdgcn_rcpf(Z)), __builtin_bit_cast(uint32_t, wsave), gxy};
-      } else {   // IcaRec: three 16-byte words
-        ELLC_GLOBAL u32x4* ro = (ELLC_GLOBAL u32x4*)((ELLC_GLOBAL char*)K.irec + pos * (unsigned)sizeof(IcaRec));
-        ro[0] = (u32x4){__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, Ikf)};
-        ro[1] = (u32x4){__builtin_bit_cast(uint32_t, wsave), __builtin_bit_cast(uint32_t, J[0]), __builtin_bit_cast(uint32_t, J[1]), __builtin_bit_cast(uint32_t, J[2])};
-        ro[2] = (u32x4){__builtin_bit_cast(uint32_t, J[3]), __builtin_bit_cast(uint32_t, J[4]), __builtin_bit_cast(uint32_t, J[5]), 0u};
+      } else {
+        const unsigned t3 = 3u * threadIdx.x;
+        s_rec[t3] = (u32x4){__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, Ikf)};
+        s_rec[t3 + 1] = (u32x4){__builtin_bit_cast(uint32_t, wsave), __builtin_bit_cast(uint32_t, J[0]), __builtin_bit_cast(uint32_t, J[1]), __builtin_bit_cast(uint32_t, J[2])};
+        s_rec[t3 + 2] = (u32x4){__builtin_bit_cast(uint32_t, J[3]), __builtin_bit_cast(uint32_t, J[4]), __builtin_bit_cast(uint32_t, J[5]), 0u};
       }
       int q = 0;
 #pragma unroll
@@ -214,18 +266,39 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
         for (int cc = rr; cc < 6; cc++) { hacc[q] = __builtin_fmaf(wJ, J[cc], hacc[q]); q++; }
       }
     }
+    if (need & 8) {   // FCA in tolerance mode: one 16-byte record per pixel (FcaRecF)
+      const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | (uint32_t)img[(unsigned)(y * sw + x)];
+      const float d = __builtin_amdgcn_rcpf(Z);
+      const float pn = ((float)x - g.cx) * g.rfx;   // u / fx (fcaf_pixel forms v / fy from y)
+      crec[pos] = (u32x4){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, d)};
+    }
+    if (need & 2) {   // FCA reads one 20-byte record per pixel (FcaRec)
+      const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)img[(unsigned)(y * sw + x)] << 24);
+      const double invZ = 1.0 / (double)Z;
+      const unsigned long long zb = __builtin_bit_cast(unsigned long long, invZ);
+      ELLC_GLOBAL char* r = (ELLC_GLOBAL char*)K.crec + pos * (unsigned)sizeof(FcaRec);
+      typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+      *(ELLC_GLOBAL u32x4a*)r = (u32x4a){xyI, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, var[(unsigned)i]), (uint32_t)zb};
+      *(ELLC_GLOBAL uint32_t*)(r + 16) = (uint32_t)(zb >> 32);
+    }
+    }
+    if ((NEED & 4) && !(NEED & 16)) {
+      __syncthreads();
+      const int chunks = min(256, nvalid - r0) * CH;
+      const unsigned obase = (tile_off + (unsigned)r0) * CH;
+      for (int cidx = (int)threadIdx.x; cidx < chunks; cidx += 256) rec_out[obase + (unsigned)cidx] = s_rec[cidx];
+      __syncthreads();
     }
   }
-  }
-  if (need & 4) block_reduce_store<27>(hacc, K.hpart + (size_t)((int)blockIdx.x - a.blk_prefix[level]) * ELLC_PART_STRIDE);   // block-uniform condition
+  if (need & 4) block_reduce_store<27>(hacc, K.hpart + (size_t)local * ELLC_PART_STRIDE);   // block-uniform condition
 }
 
-// ICA: H of one (keyframe slot, level) from the scatter blocks' sums (fixed-order f64 combine), then cv::Mat::inv(DECOMP_LU)
+// ICA: H of one (keyframe slot, level) from the per-tile sums (fixed-order f64 combine), then cv::Mat::inv(DECOMP_LU)
 // (PixelWisePyramid.cpp:938-939). One block per (level, unique slot); the level's inverse is kept with the slot.
 __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void ica_hinv(PrepArgs a) {
   const int level = a.level0 + (int)blockIdx.x;
   const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
-  const int T = (a.lay[level].ntiles + ELLC_GN_THREADS / 64 - 1) / (ELLC_GN_THREADS / 64);   // the blocks of prep_scatter
+  const int T = a.tile_begin[level + 1] - a.tile_begin[level];
   __shared__ SolveShared sh;
   const int t = threadIdx.x;
   sh.part[t >> 5][t & 31] = partial_group_sum(K.hpart, T);

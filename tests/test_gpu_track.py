@@ -22,7 +22,9 @@ def make_ctx(ellc, pair, **kw):
 
 @pytest.mark.parametrize("arith", ["exact", "fast"])
 @pytest.mark.parametrize("case", [(21, 0.02, 0.05), (22, 0.03, 0.08)])   # 16 iterations; 29: the state-driven schedule needs its continuation
-def test_track_frame_equals_the_separate_calls(ellc, arith, case):
+def test_track_frame_equals_the_separate_calls(ellc, oracle, arith, case):
+    """... and, on the first frame, the oracle running the same sequence (r05: comparing the fused call with the separate calls alone
+    is a self-comparison)."""
     seed, rot, trans = case
     pair = synth.make_pair(W, H, seed=seed, rot=rot, trans=trans)
     kw = dict(arith=ellc.ARITH_FAST) if arith == "fast" else {}
@@ -44,9 +46,97 @@ def test_track_frame_equals_the_separate_calls(ellc, arith, case):
             da, va = a.keyframe_depth_level(0, l); db, vb = b.keyframe_depth_level(0, l)
             assert np.array_equal(da, db) and np.array_equal(va, vb)
             assert np.array_equal(a.keyframe_weights(0, l)[0], b.keyframe_weights(0, l)[0])
+        if rep == 0:   # against the oracle: the alignment to the metric's tolerance, the depth cycle from the returned pose bit for bit
+            from test_gpu_depth import assert_state_equal
+            st0 = synth.make_depth_state(W, H, 9, pair["kf_image"], pair["idepth_true"])
+            _, _, _, dm, pose_ref, iters_ref = oracle_track_cycle(oracle, pair, st0, p2, W, H)
+            assert float(np.linalg.norm(p2 - pose_ref)) <= 1e-5
+            assert np.abs(np.asarray(i2) - np.asarray(iters_ref)).max() <= (0 if arith == "exact" else 1), (i2, iters_ref)
+            assert_state_equal(sb, dm.get_state(), "track_frame vs oracle")
     if case[0] == 22:
         assert int(iters.sum()) > 20 or rep   # (the continuation path was exercised on the first frame)
     a.close(); b.close()
+
+
+def oracle_track_cycle(O, pair, st, pose_gpu, Wd, Hd, save_weights=True):
+    """The reference's tracked-frame sequence on the CPU oracle (main.cpp:330 alignment with saved weights; :391 / :499-502 update of the
+    depth map with the new frame: observeDepthRowParallel, doRegularization = fill holes + regularise, updateDepthImage). The depth
+    stages take the pose the GPU returned: the alignments agree to the stated tolerance (1e-5), and from one and the same pose the
+    depth stages must agree bit for bit."""
+    from helpers import oracle_problem
+    cfg, kf, cur, dm = oracle_problem(O, Wd, Hd, L, pair, early_exit=1)
+    dm.set_state(st)
+    pose_ref, iters_ref, _ = O.align(kf, cur, dm.depth_pyr(), save_weights=save_weights)
+    pwo = np.asarray(O.concat_relative(np.asarray(pose_gpu, np.float32), np.zeros(6, np.float32)), np.float32)
+    cur.set_pose(origin=pwo, world=pwo)
+    dm.set_current(cur)
+    dm.observe(); dm.fill_holes(); dm.regularize(False); dm.update_depth_image()
+    return cfg, kf, cur, dm, pose_ref, iters_ref
+
+
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_c1_tracked_frame_640x480_early_exit_against_the_oracle(ellc, oracle, arith):
+    """BASELINE configs[1] as it is worded — one keyframe against one frame, 640x480, 4 levels, Gauss-Newton TO CONVERGENCE (the
+    reference's early exit on, ImageFunc.cpp:251-252) plus the depth cycle — through ONE ellc_track_frame call, against the oracle
+    running the same sequence: iteration counts, pose <= 1e-5, every field of every pixel of the depth map, the exported depth /
+    variance pyramid, the saved weights; then createKeyFrame onto the tracked frame (main.cpp:404-436)."""
+    from test_gpu_depth import assert_state_equal
+    from helpers import bits_equal
+    Wd, Hd = 640, 480
+    pair = synth.make_pair(Wd, Hd, seed=77, rot=0.006, trans=0.03)
+    st = synth.make_depth_state(Wd, Hd, 9, pair["kf_image"], pair["idepth_true"])
+    fx, fy, cx, cy = pair["intrinsics"]
+    kw = dict(arith=ellc.ARITH_FAST) if arith == "fast" else {}
+    ctx = ellc.Context(ellc.default_config(Wd, Hd, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=2, max_frames=2, **kw))
+    ctx.keyframe_upload(0, pair["kf_image"]); ctx.keyframe_set_depth(0, pair["depth0"], pair["var0"])
+    ctx.depth_set_keyframe(0); ctx.depth_set_state(st)
+    ctx.frame_upload(0, pair["cur_image"])
+    pose, iters, wgt, seeds = ctx.track_frame(0, save_weights=True)
+    cfg, kf, cur, dm, pose_ref, iters_ref = oracle_track_cycle(oracle, pair, st, pose, Wd, Hd)
+    # the alignment: to convergence, the oracle's iteration counts (the tolerance mode's termination test sits at the scale of its
+    # tolerance: a count may differ by one there), the pose within the metric's bar
+    assert int(np.sum(iters_ref)) < 32, "the scene must converge before the caps: early exit is what this test is about"
+    if arith == "exact":
+        assert list(iters) == list(iters_ref), (iters, iters_ref)
+    else:
+        assert np.abs(np.asarray(iters) - np.asarray(iters_ref)).max() <= 1, (iters, iters_ref)
+    assert float(np.linalg.norm(pose - pose_ref)) <= 1e-5
+    # the depth cycle from the same pose: bit for bit
+    assert_state_equal(ctx.depth_get_state(), dm.get_state(), "tracked frame: observe + fill + regularise + border")
+    for l in range(L):
+        d_ref, v_ref = dm.pyr_level(l)
+        d, v = ctx.keyframe_depth_level(0, l)
+        if l == 0:
+            d_ref = np.where(d_ref < 0, 0, d_ref)   # arrays hold -1, the Mat (what the tracker reads) holds 0
+        assert bits_equal(d, d_ref) and bits_equal(v, v_ref), l
+    # saved weights of the last executed iteration of every level (PixelWisePyramid.cpp:544-549): same pixels, values to the tolerance
+    # the poses agree to (exact mode: the per-pixel weights are bit-identical for identical poses; the poses differ in their last bits)
+    if list(iters) == list(iters_ref):
+        for l in range(L):
+            w_ref, n_ref = kf.weights(l)
+            w_gpu, n_gpu = ctx.keyframe_weights(0, l)
+            assert n_gpu == n_ref
+            assert np.array_equal(w_gpu > 0, w_ref > 0) or np.mean((w_gpu > 0) != (w_ref > 0)) < 1e-4, l
+            assert np.allclose(w_gpu, w_ref, rtol=2e-3, atol=1e-6), (l, float(np.abs(w_gpu - w_ref).max()))
+    # createKeyFrame onto the tracked frame (propagate, regularise x2, fill, rescale, export); the rescale's sum order differs (5e-5)
+    newkf = oracle.Frame(cfg, pair["cur_image"], 5)
+    pwo = np.asarray(oracle.concat_relative(pose, np.zeros(6, np.float32)), np.float32)
+    newkf.set_pose(origin=pwo)
+    dm.create_keyframe(newkf)
+    ctx.keyframe_from_frame(1, 0)
+    ctx.depth_create_keyframe(1, pwo)
+    ref, got = dm.get_state(), ctx.depth_get_state()
+    assert np.array_equal(got["valid"], ref["valid"]) and np.array_equal(got["blacklisted"], ref["blacklisted"])
+    m = ref["valid"] != 0
+    for fld in ("invDepth", "invDepthSmoothed", "variance", "varianceSmoothed"):
+        assert np.allclose(got[fld][m], ref[fld][m], rtol=2e-4), fld
+    for l in range(L):
+        d_ref, v_ref = dm.pyr_level(l)
+        d, v = ctx.keyframe_depth_level(1, l)
+        if l == 0:
+            d_ref = np.where(d_ref < 0, 0, d_ref)
+        assert np.allclose(d, d_ref, rtol=2e-4) and np.allclose(v, v_ref, rtol=4e-4), l
+    ctx.close()
 
 
 def test_track_frame_errors(ellc):
