@@ -74,6 +74,10 @@ class Context:
     def set_poll_timeout_us(self, us):
         self._ck(self._l.ellc_ctx_set_poll_timeout_us(self.h, int(us)), "ellc_ctx_set_poll_timeout_us")
 
+    def set_grid_batch(self, n):
+        """cfg.grid_batch for the calls that follow (ellc_ctx_set_grid_batch)."""
+        self._ck(self._l.ellc_ctx_set_grid_batch(self.h, int(n)), "ellc_ctx_set_grid_batch")
+
     def level_shape(self, level):
         return (self.cfg.height >> level, self.cfg.width >> level)
 

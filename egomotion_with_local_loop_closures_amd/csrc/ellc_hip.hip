@@ -1031,6 +1031,17 @@ ellc_status ellc_ctx_set_poll_timeout_us(ellc_ctx* c, int us) {
 }
 
 // ---- frame side ----------------------------------------------------------------------------------
+ellc_status ellc_ctx_set_grid_batch(ellc_ctx* c, int n) {
+  ELLC_ENTER_BATCH(c);
+  if (!c || n < 0 || n > 65536) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");
+  if (c->open_set >= 0) {   // a group still waiting for batches to join was staged under the old value: it runs as it is
+    const ellc_status s = launch_group(c, c->open_set);
+    if (s != ELLC_OK) return s;
+  }
+  c->cfg.grid_batch = n;
+  return ELLC_OK;
+}
+
 ellc_status ellc_frame_upload(ellc_ctx* c, int slot, const uint8_t* image) {
   ELLC_ENTER(c);
   if (!c || !image || !slot_ok(slot, c->cfg.max_frames)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_frame_upload: bad argument");
@@ -1387,7 +1398,7 @@ static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int 
   // (cur_adaptive_first: launches of the first graph of a state-driven schedule; it varies with the context's hint)
   const int first = schedule_is_adaptive(c, mode, B) ? c->cur_adaptive_first : 0;
   const auto key = std::make_tuple(B, continuation ? 0 : nu, mode,
-                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0) | (c->track_call ? 4 : 0) | (c->cur_pollable ? 8 : 0) | (first << 4), set);
+                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0) | (c->track_call ? 4 : 0) | (c->cur_pollable ? 8 : 0) | (first << 4) | (c->cfg.grid_batch << 12), set);
   auto it = c->graphs.find(key);
   if (it == c->graphs.end()) {
     hipGraph_t graph = nullptr;

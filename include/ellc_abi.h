@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define ELLC_MAX_LEVELS 8
-#define ELLC_ABI_VERSION 7
+#define ELLC_ABI_VERSION 8
 
 typedef enum {
   ELLC_OK = 0,
@@ -108,6 +108,12 @@ enum {
 };
 ellc_status ellc_ctx_counters(ellc_ctx* ctx, long long* out, int n);
 ellc_status ellc_ctx_set_poll_timeout_us(ellc_ctx* ctx, int microseconds);
+/* cfg.grid_batch for the calls that follow (v8; 0: grids follow each call's B again). The loop-closure batch of
+ * globalOptimize::findMatchParallel (GlobalOptimize.cpp:454-646, call :566) has 1 .. 43 candidates, usually a handful: every rank
+ * of a sharded run sets the same N — the smallest of {4, 8, 16, 43} that holds the WHOLE batch — before it aligns its block, so the
+ * bits stay independent of the world size (ellc_shard_range) while a batch of three candidates no longer runs on grids sized for
+ * 43. Batches in flight keep the grids they were launched with. */
+ellc_status ellc_ctx_set_grid_batch(ellc_ctx* ctx, int n);
 void* ellc_stream(ellc_ctx* ctx);                   /* the context's hipStream_t (for event timing by callers) */
 
 /* ---- frame side: frame::frame / constructImagePyramids / calculateGradient / buildMaxGradients

@@ -90,10 +90,11 @@ class Runtime {
   // ranks and its results gathered once per batch (ellc_gather_results). comm == nullptr: single process.
   ellc_comm* comm = nullptr;
   int world = 1, rank = 0;
-  // The loop-closure context's launch grids are fixed (cfg.grid_batch = max_batch) so that the files a run writes do not depend on how
-  // many ranks shared the batch — including one (ellc_main --world 2 equals the single process byte for byte). A single process that
-  // does not need that may clear this before it constructs globalOptimize: its small batches (usually 1-5 candidates) then get grids
-  // of their own size and the state-driven schedule (r03 advisor finding).
+  // The loop-closure context's launch grids are fixed per batch — for the smallest of {4, 8, 16, 43} candidates that holds the WHOLE
+  // batch (ellc_ctx_set_grid_batch before every batch, the same value on every rank) — so that the files a run writes do not depend
+  // on how many ranks shared the batch, including one (ellc_main --world 2 equals the single process byte for byte), while the usual
+  // batch of a handful of candidates no longer runs on grids sized for the ring's 43 (r03 advisor finding; r04 fixed them at 43).
+  // A single process that does not need that may clear this before it constructs globalOptimize: grids then follow each call's B.
   bool lc_fixed_grids = true;
   int frame_ring = 3;             // tracking uses frame slots [0, frame_ring): current, t-1 and one spare
   int next_frame_slot() { int s = frame_cursor_; frame_cursor_ = (frame_cursor_ + 1) % frame_ring; return s; }
@@ -367,7 +368,7 @@ inline std::vector<float> TrackFrameAndObserve(frame* prev_frame, frame* current
 // (:161) — and when the object goes away. The ring lives in a Runtime of its own (`ring`: a second context with its own
 // streams, so its batch overlaps the tracking context's work on the device); pushToArray deep-copies the finished keyframe
 // into it (ellc_copy_slot_across = new frame(*currentframe) / new depthMap(*currentDepthMap), :185-186) and the thread only
-// ever touches the ring context. The ring context fixes its launch grids (cfg.grid_batch = max_batch; Runtime::lc_fixed_grids):
+// ever touches the ring context. The ring context fixes its launch grids per batch (ellc_ctx_set_grid_batch; Runtime::lc_fixed_grids):
 // a rank's shard of a batch has the bits of the whole batch.
 class globalOptimize {
  public:
@@ -382,6 +383,7 @@ class globalOptimize {
     float rescaleFactor = 1.0f;   // this_frame->rescaleFactor
     float seeds = 0.0f;           // this_currentDepthMap->calculate_no_of_Seeds()
     int kf_slot = -1;             // ring-context slot holding this_frame / this_currentDepthMap
+    bool isStray = false;         // pushed by findConnection: an image without a depth map (LoopFrame.h)
   };
   Runtime* rt;            // the tracking runtime (source of the finished keyframes; its comm / world / rank shard the batch)
   Runtime ring;           // the loop-closure context: keyframe slots [0, 43) = the ring, frame slot 0 = the test keyframe
@@ -401,15 +403,49 @@ class globalOptimize {
     c.max_keyframes = MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
     c.max_frames = 1;
     c.max_batch = MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
-    c.grid_batch = fixed_grids ? c.max_batch : 0;   // world-size invariant bits (ellc_abi.h; Runtime::lc_fixed_grids)
+    c.grid_batch = fixed_grids ? c.max_batch : 0;   // world-size invariant bits (ellc_abi.h; set per batch: lc_grid_bucket)
     c.concurrent_batches = 1;
     c.coalesce = 1;
     c.cache_records = 1;          // the ring's keyframes stay from push to push: only the slot a push replaces has its pixel lists rebuilt (same results)
     return c;
   }
-  globalOptimize(Runtime& r, const std::string& matchfilepath) : rt(&r), ring(ring_config(r.cfg, r.lc_fixed_grids || r.world > 1)) {
+  globalOptimize(Runtime& r, const std::string& matchfilepath)
+      : rt(&r), ring(ring_config(r.cfg, r.lc_fixed_grids || r.world > 1)), fixed_grids_(r.lc_fixed_grids || r.world > 1) {
     ring.BATCH_START_ID = r.BATCH_START_ID;
     match_file.open(matchfilepath.c_str());
+  }
+  // the grids of a loop-closure batch of B candidates: the smallest of {4, 8, 16, ring} that holds the whole batch
+  static int lc_grid_bucket(int B) {
+    const int buckets[4] = {4, 8, 16, MAX_LOOP_ARRAY_LENGTH_SCALE_AVG};
+    for (int k = 0; k < 4; k++)
+      if (B <= buckets[k]) return buckets[k];
+    return MAX_LOOP_ARRAY_LENGTH_SCALE_AVG;
+  }
+
+  // ---- tracking-loss recovery (FLAG_RESTORE_CONNECTION, ExternVariable.h:176: off as shipped; main.cpp:252-324) -------------------
+  // GlobalOptimize.cpp:934-943: the connection is lost when the depth map has no seeds left (MIN_SEEDS_FOR_CONNECTION_LOST = 0, ExternVariable.h:171)
+  static constexpr float MIN_SEEDS_FOR_CONNECTION_LOST = 0.0f;
+  depthMap* temp_depthMap = nullptr;   // the depth map a recovered connection would hand to main (main.cpp:270); never set as shipped
+  void checkConnection(depthMap* currentDepthMap) { connectionLost = currentDepthMap->calculate_no_of_Seeds() <= MIN_SEEDS_FOR_CONNECTION_LOST; }
+  // GlobalOptimize.cpp:717-760 AS SHIPPED: waits for the match thread, pushes the stray test frame (no depth map) into the ring at
+  // currentArrayId — histogram, ids, image — and returns: the search that follows in the source sits behind an unconditional return
+  // (:759), so connectionLost stays as checkConnection left it and temp_depthMap stays null.
+  void findConnection(frame* testFrame) {
+    join_all();   // :725 t_group.join_all()
+    loopFrame& slot = loopFrameArray[currentArrayId];
+    if (slot.isValid) { slot.isValid = false; slot.isStray = false; slot.frameId = 0; }   // resetArrayElement (:124-147)
+    slot.kf_slot = currentArrayId;
+    ring.check(ellc_copy_slot_across(ring.ctx, 1, slot.kf_slot, rt->ctx, 0, testFrame->slot), "ellc_copy_slot_across");   // this_frame = new frame(*testFrame): the image
+    TestFrame test;
+    test.frameId = testFrame->frameId;
+    test.ring_slot = slot.kf_slot;
+    std::memcpy(test.poseWrtWorld, testFrame->poseWrtWorld, 24);
+    std::memcpy(test.poseWrtOrigin, testFrame->poseWrtOrigin, 24);
+    calculateImageHistogram(test);
+    slot.isStray = true;   // :750 no depth map: findMatch never aligns against it (it needs one) until a keyframe replaces it
+    slot.frameId = currentLoopFrame.frameId;
+    slot.isValid = currentLoopFrame.isValid;
+    std::memcpy(slot.image_histogram, currentLoopFrame.image_histogram, sizeof(slot.image_histogram));
   }
   ~globalOptimize() {
     try { join_all(); } catch (...) {}
@@ -429,6 +465,7 @@ class globalOptimize {
     join_all();   // :161 wait for the match thread before pushing another frame
     loopFrame& slot = loopFrameArray[currentArrayId];
     slot.kf_slot = currentArrayId;
+    slot.isStray = false;
     // :185-186 deep copies of the keyframe and its depth map, into the ring context
     rt->check(ellc_copy_slot_across(ring.ctx, 1, slot.kf_slot, rt->ctx, 1, currentframe->kf_slot), "ellc_copy_slot_across");
     TestFrame test;
@@ -462,6 +499,7 @@ class globalOptimize {
   };
   std::thread t_group;
   std::string thread_error;
+  bool fixed_grids_ = true;
 
   // :40-100 (the histogram of the copy in the ring context: the same image)
   void calculateImageHistogram(const TestFrame& f) {
@@ -509,7 +547,9 @@ class globalOptimize {
       } else if (loopFrameArray[i].isValid == false) conditionToTerminateLoop = 1;
       if (conditionToTerminateLoop == 1) { lastTestedLoopClosureArrayId = -1; break; }
       if (loopFrameArray[i].isValid == 0) { lastTestedLoopClosureArrayId = -1; return false; }
-      if (currentframe.frameId - loopFrameArray[i].frameId > 8) {   // MIN_MATCH_DIFFERENCE = KEYFRAME_PROPAGATE_INTERVAL
+      // (a stray entry — an image findConnection pushed, no depth map — is never a candidate: the reference would hand its null
+      // depth map to GetImagePoseEstimate; unreachable as shipped, FLAG_RESTORE_CONNECTION is off)
+      if (!loopFrameArray[i].isStray && currentframe.frameId - loopFrameArray[i].frameId > 8) {   // MIN_MATCH_DIFFERENCE = KEYFRAME_PROPAGATE_INTERVAL
         matchValue = (float)ellc_kl_divergence(loopFrameArray[i].image_histogram, currentLoopFrame.image_histogram, 256);
         calculateRotationStats(loopFrameArray[i].poseWrtWorld, currentLoopFrame.poseWrtWorld);
         if (matchValue <= 0.1f) {                       // MATCH_THRESHOLD
@@ -554,6 +594,7 @@ class globalOptimize {
         kf[b] = m.kf_slot;
         ellc_concatenate_origin_pose(testFrame.poseWrtWorld, m.poseWrtWorld, &init[(size_t)b * 6]);   // ImageFunc.cpp:106
       }
+      if (fixed_grids_) ring.check(ellc_ctx_set_grid_batch(ring.ctx, lc_grid_bucket(B)), "ellc_ctx_set_grid_batch");   // of the WHOLE batch, on every rank
       if (rt->comm && rt->world > 1) {
         // this rank's contiguous block of the candidates on its own GPU, then the one exchange of the batch: 8 floats per
         // alignment [pose6, weightedPose, iterations] from every rank, in global order on every rank

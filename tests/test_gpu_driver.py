@@ -439,3 +439,100 @@ def test_loop_closure_batch_sharded_over_two_processes(tmp_path):
         assert (d / "matchframes_globalopt.txt").read_text() == (single / "matchframes_globalopt.txt").read_text()
         assert (d / "poses_orig.txt").read_text() == (single / "poses_orig.txt").read_text()
     assert (outs[0] / "matchframes_globalopt.txt").read_text() == (outs[1] / "matchframes_globalopt.txt").read_text()
+
+
+RECOVERY_PROGRAM = r"""
+// The tracking-loss recovery block of main.cpp:252-324 (FLAG_RESTORE_CONNECTION), as a driver that keeps it would write it against the facade.
+#include "ellc_facade.hpp"
+#include <cstdio>
+#include <vector>
+using namespace ellc;
+int main(int argc, char** argv) {
+  const int W = 160, H = 120;
+  std::vector<uint8_t> img((size_t)W * H);
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f || std::fread(img.data(), 1, img.size(), f) != img.size()) return 2;
+  std::fclose(f);
+  ellc_config cfg;
+  ellc_default_config(&cfg, W, H, 4);
+  Runtime rt(cfg);
+  globalOptimize globalOptimizeLoop(rt, std::string(argv[2]) + "/matchframes_globalopt.txt");
+  frame* f1 = new frame(rt, img.data());
+  depthMap* currentDepthMap = new depthMap(rt);
+  currentDepthMap->formDepthMap(f1);          // frame 1: random initialisation -> seeds > 0
+  currentDepthMap->updateDepthImage();
+  globalOptimizeLoop.checkConnection(currentDepthMap);
+  if (globalOptimizeLoop.connectionLost) return 3;
+  // an empty map: no seeds left -> the connection is lost (GlobalOptimize.cpp:934-943)
+  {
+    const size_t n = (size_t)W * H;
+    std::vector<float> z(n, 0.f);
+    std::vector<int32_t> zi(n, 0);
+    std::vector<uint8_t> zb(n, 0);
+    ellc_hypotheses h = {z.data(), z.data(), z.data(), z.data(), zi.data(), zi.data(), zb.data()};
+    rt.check(ellc_depth_set_state(rt.ctx, &h), "ellc_depth_set_state");
+  }
+  globalOptimizeLoop.checkConnection(currentDepthMap);
+  if (!globalOptimizeLoop.connectionLost) return 4;
+  frame* f2 = new frame(rt, img.data());
+  if (globalOptimizeLoop.connectionLost == true) {
+    globalOptimizeLoop.findConnection(f2);     // as shipped: pushes the stray frame and returns (GlobalOptimize.cpp:717-760)
+    if (globalOptimizeLoop.connectionLost == false) {   // never taken as shipped; must compile as main.cpp:265-311 writes it
+      delete currentDepthMap;
+      currentDepthMap = new depthMap(*globalOptimizeLoop.temp_depthMap);
+      delete globalOptimizeLoop.temp_depthMap;
+      globalOptimizeLoop.temp_depthMap = NULL;
+    }
+  }
+  const globalOptimize::loopFrame& s = globalOptimizeLoop.loopFrameArray[globalOptimizeLoop.currentArrayId];
+  std::printf("%d %d %d %d %d\n", (int)globalOptimizeLoop.connectionLost, (int)s.isStray, (int)s.isValid, s.frameId, globalOptimizeLoop.temp_depthMap == NULL);
+  std::printf("%d %d %d %d %d\n", globalOptimize::lc_grid_bucket(1), globalOptimize::lc_grid_bucket(4), globalOptimize::lc_grid_bucket(5),
+              globalOptimize::lc_grid_bucket(16), globalOptimize::lc_grid_bucket(17));
+  delete f2; delete f1; delete currentDepthMap;
+  return 0;
+}
+"""
+
+
+def test_connection_recovery_members_of_the_facade(tmp_path):
+    """globalOptimize::checkConnection / findConnection / connectionLost / temp_depthMap (SURVEY §8(b); main.cpp:252-324 behind
+    FLAG_RESTORE_CONNECTION, off as shipped): a driver that keeps that block compiles against the facade, seeds <= 0 loses the
+    connection, findConnection pushes the stray frame and returns as the shipped source does; and the loop-closure grids' buckets."""
+    frames, _ = make_sequence()
+    raw = tmp_path / "f.raw"
+    raw.write_bytes(np.ascontiguousarray(frames[0], np.uint8).tobytes())
+    src = tmp_path / "rec.cpp"
+    src.write_text(RECOVERY_PROGRAM)
+    exe = tmp_path / "rec"
+    csrc = os.path.join(ROOT, "egomotion_with_local_loop_closures_amd", "csrc")
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src), "-L", csrc, "-lellc_hip",
+                    "-Wl,-rpath," + csrc], check=True)
+    r = subprocess.run([str(exe), str(raw), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0, r.stdout.decode()
+    lines = r.stdout.decode().strip().split("\n")
+    assert lines[-2].split() == ["1", "1", "1", "2", "1"], lines
+    assert lines[-1].split() == ["4", "4", "8", "16", "43"], lines
+
+
+def test_set_grid_batch_makes_a_shard_equal_the_whole_batch(ellc):
+    """ellc_ctx_set_grid_batch (ABI v8): a context whose grids are set per call to the bucket of the WHOLE batch gives every
+    alignment the bits the whole batch gives it — the facade's loop-closure batches (globalOptimize::lc_grid_bucket) — and a
+    different bucket is a different (equally valid) summation order."""
+    from helpers import gpu_problem
+    w, h, L = 160, 120, 3
+    pairs = [synth.make_pair(w, h, seed=800 + i, rot=0.003, trans=0.01) for i in range(6)]
+    mi = (3, 4, 5)
+    ctx = gpu_problem(ellc, w, h, L, pairs, early_exit=0, max_iter=mi, max_batch=6)
+    for s in range(6):
+        for l in range(L):
+            ctx.keyframe_set_weights(s, l, np.full((h >> l, w >> l), 0.03, np.float32), 1)
+    kf = np.arange(6, dtype=np.int32)
+    ctx.set_grid_batch(8)
+    whole = ctx.align(kf, kf, mode=ellc.MODE_ICA)
+    parts = [ctx.align(kf[:2], kf[:2], mode=ellc.MODE_ICA), ctx.align(kf[2:], kf[2:], mode=ellc.MODE_ICA)]
+    got = np.concatenate([p[0] for p in parts])
+    assert np.array_equal(got, whole[0])
+    ctx.set_grid_batch(0)
+    own = ctx.align(kf, kf, mode=ellc.MODE_ICA)
+    assert np.allclose(own[0], whole[0], atol=1e-6)
+    ctx.close()
