@@ -40,6 +40,11 @@ struct ellc_ctx {
   ellc::KfLevelDev* kf_tab_d = nullptr;
   ellc::FrLevelDev* fr_tab_d = nullptr;
   std::vector<char> kf_has_image, kf_has_depth, fr_has_image;
+  // dense hint: the slot's level-0 depth plane was uploaded with at least nine tenths of its pixels valid (ellc_keyframe_set_depth
+  // counts them). A tolerance-mode FCA batch whose keyframes all carry the hint is aligned without compact lists (gn_fca_dense:
+  // thread <-> pixel, the planes read directly). A hint, not a promise: pixels without depth are skipped where they occur.
+  std::vector<char> kf_dense;
+  bool cur_dense = false;   // the schedule being enqueued is the list-free one
   // cfg.cache_records: which record set (PrepArgs::need) the compact lists of a keyframe slot hold, 0 = none / stale. The lists
   // are a pure function of the slot's image, depth pyramid and weight planes: every entry point that writes one of those
   // clears the tag (ellc::invalidate_records); a batch rebuilds only the slots whose tag differs from what it needs.

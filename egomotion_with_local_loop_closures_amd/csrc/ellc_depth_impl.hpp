@@ -118,6 +118,7 @@ ellc_status do_update_depth_image(ellc_ctx* c, bool with_rescale = false) {
   ellc_status s = build_depth_pyramid_from(c, c->dm_kf_slot, steps + 1);   // buildInvVarDepth + mapDepthArr2Mat: the remaining levels
   if (s != ELLC_OK) return s;
   c->kf_has_depth[c->dm_kf_slot] = 1;
+  c->kf_dense[c->dm_kf_slot] = 0;   // the map's export is semi-dense
   return ELLC_OK;
 }
 
@@ -173,6 +174,7 @@ ellc_status do_fill_regularize_and_update_depth_image(ellc_ctx* c, const int* ga
   ellc_status s = build_depth_pyramid_from(c, c->dm_kf_slot, steps + 1);   // the remaining levels
   if (s != ELLC_OK) return s;
   c->kf_has_depth[c->dm_kf_slot] = 1;
+  c->kf_dense[c->dm_kf_slot] = 0;   // the map's export is semi-dense
   return ELLC_OK;
 }
 

@@ -482,6 +482,10 @@ static void set_age_split(ellc_ctx* c, FusedArgs& fa, int B) {
 static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
   const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
   const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
+  if (c->cur_dense) {   // dense maps: no compact lists (gn_fca_dense; launch_group decided)
+    hipLaunchKernelGGL(gn_fca_dense, grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    return;
+  }
   if (c->fast) {
     if (fa.g.save_w) hipLaunchKernelGGL((gn_fca_fused<false, true, true, 1>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
     else hipLaunchKernelGGL((gn_fca_fused<false, true, true, 0>), grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
@@ -858,6 +862,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     return fail(c, ELLC_ERR_HIP, "cannot upload the slot tables");
   }
   c->kf_has_image.assign(MK, 0); c->kf_has_depth.assign(MK, 0); c->fr_has_image.assign(MF, 0);
+  c->kf_dense.assign(MK, 0);
   c->kf_num_weights.assign(MK, std::array<int, ELLC_MAX_LEVELS>{});
   c->kf_rec_tag.assign(MK, 0);
   c->cache_records = cfg->cache_records != 0;
@@ -1067,6 +1072,7 @@ ellc_status ellc_keyframe_upload(ellc_ctx* c, int slot, const uint8_t* image) {
   ellc_status s = upload_pyramid(c, img, image);
   if (s != ELLC_OK) return s;
   c->kf_has_image[slot] = 1;
+  c->kf_dense[slot] = 0;
   c->kf_has_depth[slot] = 0;         // a fresh frame has no depth yet (as ellc_keyframe_from_frame): set_depth / update_depth_image follow
   for (int l = 0; l < c->L; l++) {   // frame::frame zeroes weight_pyramid / numWeightsAdded (Frame.cpp:114-122)
     ELLC_HIP(c, hipMemsetAsync(c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + slot].weight, 0, (size_t)c->geom_h[l].n * 4, c->stream));
@@ -1089,6 +1095,7 @@ ellc_status ellc_keyframe_from_frame(ellc_ctx* c, int kf_slot, int frame_slot) {
   }
   c->kf_has_image[kf_slot] = 1;
   c->kf_has_depth[kf_slot] = 0;
+  c->kf_dense[kf_slot] = 0;
   const ellc_status ms = mark_frame_use(c, frame_slot);
   if (ms != ELLC_OK) return ms;
   return build_maxgrad(c, true, kf_slot);
@@ -1152,8 +1159,13 @@ ellc_status ellc_keyframe_set_depth(ellc_ctx* c, int slot, const float* depth0, 
   ELLC_HIP(c, hipMemcpyAsync(k.var, var0, n0 * 4, hipMemcpyHostToDevice, c->stream));
   ellc_status s = build_depth_pyramid(c, slot);
   if (s != ELLC_OK) return s;
+  // dense hint (see gn_fca_dense): counted here, on the host's copy, while the upload is in flight — a map uploaded (nearly) full is
+  // aligned without compact lists; maps the depth stages export are semi-dense by construction and never are
+  size_t nvalid = 0;
+  for (size_t i = 0; i < n0; i++) nvalid += depth0[i] > 0.0f ? 1 : 0;
   ELLC_HIP(c, hipStreamSynchronize(c->stream));
   c->kf_has_depth[slot] = 1;
+  c->kf_dense[slot] = (nvalid * 10 >= n0 * 9) ? 1 : 0;
   return ELLC_OK;
 }
 
@@ -1166,6 +1178,7 @@ ellc_status ellc_keyframe_set_depth_level(ellc_ctx* c, int slot, int level, cons
   ELLC_HIP(c, hipMemcpyAsync(k.var, var, (size_t)c->geom_h[level].n * 4, hipMemcpyHostToDevice, c->stream));
   ELLC_HIP(c, hipStreamSynchronize(c->stream));
   c->kf_has_depth[slot] = 1;
+  c->kf_dense[slot] = 0;   // (a level written by itself: no hint)
   return ELLC_OK;
 }
 
@@ -1278,6 +1291,7 @@ static ellc_status copy_slot_planes(ellc_ctx* dc, int dst_is_kf, int dst, ellc_c
   if (dst_is_kf) {
     dc->kf_has_image[dst] = 1;
     dc->kf_has_depth[dst] = src_is_kf ? sc->kf_has_depth[src] : 0;
+    dc->kf_dense[dst] = src_is_kf ? sc->kf_dense[src] : 0;
     if (src_is_kf && sc->kf_maxgrad_valid[src]) {
       const size_t n0 = (size_t)dc->cfg.width * dc->cfg.height;
       ELLC_HIP(c, hipMemcpyAsync(dc->kf_maxgrad[dst], sc->kf_maxgrad[src], n0 * 4, hipMemcpyDeviceToDevice, dc->stream));
@@ -1371,6 +1385,12 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
   return ELLC_OK;
 }
 
+// may a batch of B alignments run the list-free schedule (gn_fca_dense)? The tolerance-mode FCA schedule in its level-bound form,
+// without saved weights (they are kept per list entry); launch_group adds: every keyframe slot carries the dense hint
+static bool runs_dense(const ellc_ctx* c, int mode, int B, int save_weights) {
+  return c->fast && c->use_fused && mode == ELLC_MODE_FCA && !save_weights && !schedule_is_adaptive(c, mode, B);
+}
+
 // true: the batch's launch sequence is launched kernel by kernel; false: replayed from a captured graph
 static bool launches_directly(const ellc_ctx* c, int mode, int B) {
   return !c->use_graph || (!c->graph_adaptive && (schedule_is_adaptive(c, mode, B) || B <= c->direct_max_batch));
@@ -1398,7 +1418,7 @@ static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int 
   // (cur_adaptive_first: launches of the first graph of a state-driven schedule; it varies with the context's hint)
   const int first = schedule_is_adaptive(c, mode, B) ? c->cur_adaptive_first : 0;
   const auto key = std::make_tuple(B, continuation ? 0 : nu, mode,
-                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0) | (c->track_call ? 4 : 0) | (c->cur_pollable ? 8 : 0) | (first << 4) | (c->cfg.grid_batch << 12), set);
+                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0) | (c->track_call ? 4 : 0) | (c->cur_pollable ? 8 : 0) | (first << 4) | (c->cfg.grid_batch << 12) | (c->cur_dense ? (1 << 29) : 0), set);
   auto it = c->graphs.find(key);
   if (it == c->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -1520,6 +1540,10 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
   bs.built_slots.clear();
   for (int v : bs.kf_slots)
     if (!c->cache_records || c->kf_rec_tag[v] != need) bs.built_slots.push_back(v);
+  // dense maps (every keyframe of the launch carries the hint): the list-free schedule — no slot's lists are built or read
+  bool dense = runs_dense(c, bs.mode, B, bs.save_weights);
+  for (int v : bs.kf_slots) dense = dense && c->kf_dense[v];
+  if (dense) bs.built_slots.clear();
   const int nu = (int)bs.built_slots.size();
   for (int u = 0; u < nu; u++) c->uniq_slot_h[u] = bs.built_slots[u];
   // stream
@@ -1576,7 +1600,9 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
     StreamScope scope(c, run_stream);
     bs.pollable = polls_results(c, B, si);
     c->cur_pollable = bs.pollable;
+    c->cur_dense = dense;
     const ellc_status s = launch_align_graph(c, B, nu, bs.mode, bs.save_weights, set, false);
+    c->cur_dense = false;
     c->cur_pollable = false;
     if (s != ELLC_OK) {
       for (int v : bs.built_slots) invalidate_records(c, v);
@@ -1627,7 +1653,12 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
     if (s != ELLC_OK) return s;
     for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);   // rebuilt here, outside the cache's bookkeeping
     c->cur_adaptive_first = adaptive_first_launches(c, B);
-    return launch_align_graph(c, B, nu, mode, save_weights, 0, false);
+    bool dense = runs_dense(c, mode, B, save_weights);
+    for (int b = 0; b < B; b++) dense = dense && c->kf_dense[kf_slots[b]];
+    c->cur_dense = dense;
+    s = launch_align_graph(c, B, dense ? 0 : nu, mode, save_weights, 0, false);
+    c->cur_dense = false;
+    return s;
   }
   // may this batch share a launch with others? full batches of one mode, nothing per-slot written (saved weights), not the
   // state-driven tracking schedule
@@ -1865,9 +1896,13 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, nullptr, &nu, nullptr, true);   // up to a whole launch group (cfg.coalesce batches)
   if (s != ELLC_OK) return s;
+  bool dense = runs_dense(c, ELLC_MODE_FCA, B, 0);   // the kernel the production schedule would launch for these keyframes
+  for (int b = 0; b < B; b++) dense = dense && c->kf_dense[kf_slots[b]];
   enqueue_stage_in(c, 0);
-  s = run_prep(c, nu, c->fast ? 8 : 2);
-  if (s != ELLC_OK) return s;
+  if (!dense) {
+    s = run_prep(c, nu, c->fast ? 8 : 2);
+    if (s != ELLC_OK) return s;
+  }
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B, c->L - 1);
   GnArgs a = make_gn_args(c, level, B, 0, nullptr);
   const dim3 grd(a.nblk, B), blk(ELLC_GN_THREADS);
@@ -1888,6 +1923,7 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     fa.early_exit = 0;
     fa.stride_state = c->group_cap;
     fa.stride_part = (size_t)c->group_cap * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+    c->cur_dense = dense;
     auto launch = [&]() {
       launch_fused(c, grd, blk, fa, c->stream);
       fa.seq++;
@@ -1902,14 +1938,14 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
       hipError_t e = hipStreamEndCapture(c->stream, &graph);
       if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
       if (graph) (void)hipGraphDestroy(graph);
-      if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("profile graph capture: ") + hipGetErrorString(e));
+      if (e != hipSuccess) { c->cur_dense = false; return fail(c, ELLC_ERR_HIP, std::string("profile graph capture: ") + hipGetErrorString(e)); }
       e = hipGraphLaunch(exec, c->stream);   // warm
       if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
       if (e == hipSuccess) e = hipGraphLaunch(exec, c->stream);
       if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
       if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
       (void)hipGraphExecDestroy(exec);
-      if (e != hipSuccess) return fail(c, ELLC_ERR_HIP, std::string("profile graph: ") + hipGetErrorString(e));
+      if (e != hipSuccess) { c->cur_dense = false; return fail(c, ELLC_ERR_HIP, std::string("profile graph: ") + hipGetErrorString(e)); }
     } else {
       ELLC_HIP(c, hipEventRecord(c->ev0, c->stream));
       for (int i = 0; i < reps; i++) launch();
@@ -1921,13 +1957,15 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     for (int i = 0; i < reps; i++) launch_fca(c, grd, blk, a);
     ELLC_HIP(c, hipEventRecord(c->ev1, c->stream));
   }
+  c->cur_dense = false;
   ELLC_HIP(c, hipEventSynchronize(c->ev1));
   float ms = 0;
   ELLC_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   if (avg_ms) *avg_ms = ms / reps;
   long long V = 0;
   for (int b = 0; b < B; b++) {
-    int v = 0;
+    int v = dense ? c->geom_h[level].n : 0;   // (no list, no count: the hint says at least nine tenths; the figure is the plane's size)
+    if (!dense)
     ELLC_HIP(c, copy_blocking(c, &v, c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + kf_slots[b]].count, 4, hipMemcpyDeviceToHost));
     V += v;
   }

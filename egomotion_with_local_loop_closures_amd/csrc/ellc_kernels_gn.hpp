@@ -1611,6 +1611,155 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The list-free form of gn_fca_fused for DENSE maps (r05; BASELINE configs[4]: 1280x960, every pixel holds a depth). When at least
+// nine tenths of a keyframe's pixels are valid a compact list is the plane itself, only larger: the compaction moved 25 bytes per
+// pixel to turn 9 bytes of planes (depth 4, variance 4, intensity 1) into a 16-byte record that every later launch read back — 13 %
+// of a dense launch group's kernel time went into compacting a mask that is all ones. Here thread <-> pixel by index: a block owns
+// the contiguous chunk of the PLANE that it owned of the list (the same split, age-balanced where the list's was), thread t takes
+// pixels begin + t, begin + t + 256, ..., reads the three planes with coalesced loads one step ahead (requested behind the tap
+// loads, where the record prefetch sat), forms the record's four words in registers — the expressions prep_scatter stores, so the
+// per-pixel values are those of the list path bit for bit — and runs the same pixel step. A pixel without depth is skipped where it
+// occurs (it takes the step on a stand-in and accumulates nothing). No compaction launch, no record traffic: a full-schedule
+// alignment reads 9 bytes per pixel and iteration where the list path moved 16 + the compaction's 25 once per level.
+// Tolerance mode, no saved weights (the list path keeps both); schedules as gn_fca_fused (launch n solves launch n - 1's sums).
+struct DensePix { float Z, var; uint32_t I; };
+__device__ __forceinline__ DensePix dense_request(const KfLevelDev& K, unsigned i, unsigned img_off) {
+  DensePix p;
+  p.Z = as_global(K.depth)[i];
+  p.var = as_global(K.var)[i];
+  p.I = (uint32_t)as_global(K.img)[img_off];
+  return p;
+}
+__device__ __forceinline__ FcaInF dense_form(const LevelGeom& g, const DensePix& p, int x, int y, bool& valid) {
+  valid = p.Z > 0.0f;
+  FcaInF in;
+  const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | p.I;   // FcaRecF, prep_scatter's expressions
+  const float dd = __builtin_amdgcn_rcpf(valid ? p.Z : 1.0f);
+  const float pn = ((float)x - g.cx) * g.rfx;
+  in.v = (u32x4_t){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, p.var), __builtin_bit_cast(uint32_t, dd)};
+  return in;
+}
+
+__global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_dense(const AlignState* src_state, const float* prev_part, int prev_nblk, int nblk, int age_rounds,
+                                                                   FusedArgs fa) {
+  const GnArgs& a = fa.g;
+  int b = blockIdx.y, sub = blockIdx.x, age = 0, per_age = nblk;
+  if (age_rounds > 1) {   // see gn_fca_fused
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int per_round = (int)(gridDim.x * gridDim.y) / age_rounds;
+    per_age = nblk / age_rounds;
+    age = lin / per_round;
+    const int j = lin - age * per_round;
+    b = j / per_age;
+    sub = age * per_age + (j - b * per_age);
+  } else if (fa.xcd_map) {
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int w = lin >> 3, bl = w / nblk;
+    sub = w - bl * nblk;
+    b = bl * 8 + (lin & 7);
+  }
+  const AlignState& src = src_state[b];
+  AlignState* dst = a.state + (size_t)((fa.seq + 1) & 1) * fa.stride_state + b;
+  __shared__ SolveShared sh;
+  const int t = threadIdx.x;
+  const bool writer = (sub == 0);
+  const LevelGeom g = a.geom[a.level];
+  const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
+  const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
+  const int pending = src.pending;
+  const int V = g.n;   // the "list" is the plane
+  const double group_sum = partial_group_sum(prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, prev_nblk);
+  int begin, end;
+  if (age_rounds > 1) {
+    const int gb = (int)(((long long)V * fa.age_cum[age]) >> 16), ge = (int)(((long long)V * fa.age_cum[age + 1]) >> 16);
+    const int chunk = (ge - gb + per_age - 1) / per_age;
+    begin = gb + (sub - age * per_age) * chunk;
+    end = min(ge, begin + chunk);
+  } else {
+    const int chunk = (V + nblk - 1) / nblk;
+    begin = sub * chunk;
+    end = min(V, begin + chunk);
+  }
+  g_u8 cur = as_global(F.img);
+  // this thread's first pixel: position and planes, requested before the solve
+  const int cols = g.cols, sw = g.sw;
+  const int qstep = ELLC_GN_THREADS / cols, rstep = ELLC_GN_THREADS - qstep * cols;   // a step advances a thread by 256 pixels: qstep rows and rstep columns
+  int x = 0, y = 0;
+  DensePix pix;
+  pix.Z = 0.0f; pix.var = 0.0f; pix.I = 0u;
+  if (begin < end) {   // block-uniform (a thread past the chunk's end starts on a copy of its last pixel: the pixel loop is block-uniform)
+    const int i0 = min(begin + t, end - 1);
+    y = (int)(((float)i0 + 0.5f) * (1.0f / (float)cols));   // i < 2^24: exact conversion; corrected to the exact quotient
+    if (y * cols > i0) y--;
+    if ((y + 1) * cols <= i0) y++;
+    x = i0 - y * cols;
+    pix = dense_request(K, (unsigned)i0, (unsigned)(y * sw + x));
+  }
+  if (pending) {
+    solve_step<true>(sh, group_sum, 0, fa.prev_level, fa.early_exit, src, nullptr);
+  } else {
+    if (t < 6) sh.newpose[t] = src.pose[t];
+    if (t < 12) sh.newS[t] = src.S[t];
+    if (t == 0) { sh.weighted = src.weighted; sh.level_done = src.level_done; }
+    __syncthreads();
+  }
+  const int level_done = sh.level_done;
+  const bool skip = (level_done == a.level);
+  if (writer) {
+    if (t < 6) dst->pose[t] = sh.newpose[t];
+    if (t < 12) dst->S[t] = sh.newS[t];
+    if (t < ELLC_MAX_LEVELS) dst->iters[t] = src.iters[t] + ((pending && t == fa.prev_level) ? 1 : 0);
+    if (t == 0) {
+      dst->weighted = sh.weighted;
+      dst->level_done = level_done;
+      dst->pending = skip ? 0 : 1;
+    }
+  }
+  if (skip) return;
+  float sums[27];
+  {
+    float S[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
+    FcaAcc acc;
+    fca_acc_zero(acc);
+    if (begin < end) {   // block-uniform
+      const TapRows tr = tap_rows(cur, sw);
+      const FcafConst fc = fcaf_const(g, S);
+      const int n_full = __builtin_amdgcn_readfirstlane((end - begin) / ELLC_GN_THREADS);
+      const int rem = __builtin_amdgcn_readfirstlane((end - begin) - n_full * ELLC_GN_THREADS);
+      const int n_steps = n_full + (rem > 0 ? 1 : 0);
+      int i = begin + t;
+      for (int k = 0; k < n_steps; k++) {
+        const bool last = (k == n_steps - 1);
+        const bool active = !last || rem == 0 || t < rem;
+        bool valid;
+        const FcaInF rec = dense_form(g, pix, x, y, valid);
+        // the next pixel of this thread: 256 further on (clamped to the chunk's last pixel: every request is unconditional)
+        int xn = x + rstep, yn = y + qstep;
+        if (xn >= cols) { xn -= cols; yn++; }
+        const int in_ = i + ELLC_GN_THREADS;
+        if (in_ > end - 1) {   // past the end: the chunk's last pixel
+          const int il = end - 1;
+          yn = (int)(((float)il + 0.5f) * (1.0f / (float)cols));
+          if (yn * cols > il) yn--;
+          if ((yn + 1) * cols <= il) yn++;
+          xn = il - yn * cols;
+        }
+        const unsigned inext = (unsigned)min(in_, end - 1);
+        auto refill = [&]() { pix = dense_request(K, inext, (unsigned)(yn * sw + xn)); };
+        const FcafStage st = fcaf_stage_a(g, tr, fc, rec, refill);
+        if (active && valid) fca_accumulate_pixel(acc, fcaf_stage_b<false, 0>(a, K, g, cur, fc, (unsigned)i, st));
+        x = xn; y = yn; i = in_;
+      }
+    }
+    fca_acc_unpack<true>(acc, sums);
+  }
+  float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
+  block_reduce_store<27>(sums, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // State-driven form of the fused FCA schedule, for contexts with the reference's early exit on (ImageFunc.cpp:251-252). A
 // launch of gn_fca_fused is bound to a level when the schedule is captured: with early exit most of the 32 launches find
 // their level already ended and return at once, but each still costs a dependent launch (about 4.5 us; 17 of 32 for a

@@ -121,6 +121,34 @@ def test_c4_batch16_1280x960_dense(oracle, ellc, arith):
     ctx.close()
 
 
+def test_dense_path_skips_the_pixels_without_depth(oracle, ellc):
+    """The list-free schedule (gn_fca_dense: tolerance mode, every keyframe of the batch uploaded at least nine tenths full) on a map
+    with holes — a band and scattered pixels without depth, 94 % valid: the hint is not a promise, a pixel without depth contributes
+    nothing; pose within 1e-5 of the oracle's (which masks them, Frame.cpp:295-301). The same keyframe thinned below nine tenths takes
+    the list path: both must agree with the oracle, and with each other to the tolerance of the summation order."""
+    W, H, L = 640, 480, 4
+    pair = dict(synth.make_pair(W, H, seed=78, dense=True))
+    rng = np.random.default_rng(5)
+    d0 = pair["depth0"].copy()
+    d0[100:110, :] = 0.0
+    d0[rng.random(d0.shape) < 0.04] = 0.0
+    pair["depth0"] = d0
+    assert 0.9 < (d0 > 0).mean() < 0.97
+    _, kf, cur, dm = oracle_problem(oracle, W, H, L, pair)
+    p_ref, it_ref, _ = oracle.align(kf, cur, dm.depth_pyr())
+    ctx = gpu_problem(ellc, W, H, L, [pair], arith=ellc.ARITH_FAST)
+    p, it, _ = ctx.align([0], [0])
+    assert list(it[0]) == list(it_ref)
+    assert np.linalg.norm(p[0] - p_ref) <= 1e-5
+    # the list path on the same planes (a level written by itself drops the hint)
+    dl, vl = ctx.keyframe_depth_level(0, 0)
+    ctx.keyframe_set_depth_level(0, 0, dl, vl)
+    p2, it2, _ = ctx.align([0], [0])
+    assert list(it2[0]) == list(it_ref) and np.linalg.norm(p2[0] - p_ref) <= 1e-5
+    assert np.linalg.norm(p2[0] - p[0]) <= 2e-6
+    ctx.close()
+
+
 @pytest.fixture(scope="module")
 def lc_batch():
     """configs[2] in the reference's shape (GlobalOptimize.cpp:566): 32 keyframes of one scene, ONE current frame."""
