@@ -483,11 +483,7 @@ static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, h
   const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
   const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
   if (c->cur_dense) {   // dense maps: no compact lists (gn_fca_dense; launch_group decided)
-    // taps from an LDS window where a block has enough bands of 64 x 32 pixels to balance (gn_fca_dense<true>)
-    const LevelGeom& lg = c->geom_h[fa.g.level];
-    const int bands = ((lg.cols + 63) / 64) * ((lg.rows + 31) / 32);
-    if (bands >= 8 * fa.g.nblk) hipLaunchKernelGGL(gn_fca_dense<true>, grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
-    else hipLaunchKernelGGL(gn_fca_dense<false>, grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    hipLaunchKernelGGL(gn_fca_dense, grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
     return;
   }
   if (c->fast) {

@@ -295,17 +295,9 @@ __device__ __forceinline__ TapReq tap_request_f(const TapRows& tr, int sw, int c
   q.wb = 0; q.wc = 0;
   if (q.interior) {
     const unsigned off = __umul24((unsigned)y0, (unsigned)sw) + (unsigned)x0;
-#ifdef ELLC_X_LDSTAPS   // timing experiment only (garbage values): what the taps would cost from an LDS window — two aligned dwords + v_alignbit per row
-    __shared__ uint32_t xl[4 * 1024 + 4];
-    const unsigned o = (off >> 2) & 1023u, shb = (off & 3u) * 8u;
-    q.wb = __builtin_amdgcn_alignbit(xl[o + 1], xl[o], shb);
-    q.wc = __builtin_amdgcn_alignbit(xl[1024 + o + 1], xl[1024 + o], shb);
-    if (WANT_GRAD) { q.wa = __builtin_amdgcn_alignbit(xl[2048 + o + 1], xl[2048 + o], shb); q.wd = __builtin_amdgcn_alignbit(xl[3072 + o + 1], xl[3072 + o], shb); }
-#else
     q.wb = load_u32_unaligned(tr.rb, off);
     q.wc = load_u32_unaligned(tr.rc, off);
     if (WANT_GRAD) { q.wa = load_u32_unaligned(tr.ra, off); q.wd = load_u32_unaligned(tr.rd, off); }
-#endif
     __builtin_amdgcn_sched_barrier(0);
     after_issue();   // behind the row requests: vector loads return in issue order
     __builtin_amdgcn_sched_barrier(0);
@@ -689,16 +681,8 @@ struct FcafStage {
   float p, q, d, var, Ikf;
   float px, py, pz, rz;
 };
-// where the four rows of a warped point's 4 x 4 neighbourhood come from: global memory (tap_request_f), or a window of the current
-// image staged in LDS (WinTaps below: gn_fca_dense)
-struct GlobalTaps {
-  template <class PF>
-  __device__ __forceinline__ TapReq operator()(const TapRows& tr, int sw, int cols, int rows, float x1, float y1, PF pf) const {
-    return tap_request_f<true, PF>(tr, sw, cols, rows, x1, y1, pf);
-  }
-};
-template <class PF = NoPrefetch, class TAPS = GlobalTaps>
-__device__ __forceinline__ FcafStage fcaf_stage_a(const LevelGeom& g, const TapRows& tr, const FcafConst& c, const FcaInF& in, PF pf = PF(), TAPS taps = TAPS()) {
+template <class PF = NoPrefetch>
+__device__ __forceinline__ FcafStage fcaf_stage_a(const LevelGeom& g, const TapRows& tr, const FcafConst& c, const FcaInF& in, PF pf = PF()) {
   FcafStage s;
   // (elements are copied to scalars first: __builtin_bit_cast applied to a vector element expression reads element 0)
   const uint32_t yI = in.v.x, w1 = in.v.y, w2 = in.v.z, w3 = in.v.w;
@@ -714,7 +698,7 @@ __device__ __forceinline__ FcafStage fcaf_stage_a(const LevelGeom& g, const TapR
   // no clamp of pz away from zero (ExternVariable.h:232): 1/0 = inf sends the point out of bounds, as the clamped value does
   s.rz = __builtin_amdgcn_rcpf(s.pz);
   s.x1 = s.px * s.rz; s.y1 = s.py * s.rz;
-  s.tq = taps(tr, g.sw, g.cols, g.rows, s.x1, s.y1, pf);
+  s.tq = tap_request_f<true, PF>(tr, g.sw, g.cols, g.rows, s.x1, s.y1, pf);
   return s;
 }
 // SAVEW: 1 = store the weights (saved-weights call), 0 = do not, -1 = a.save_w decides at run time
@@ -1656,62 +1640,6 @@ __device__ __forceinline__ FcaInF dense_form(const LevelGeom& g, const DensePix&
   return in;
 }
 
-// WIN (the levels with enough pixels per block): the taps come from LDS. The block walks BANDS of 64 x 32 keyframe pixels (wave w
-// takes eight rows of the band, a row per step: 64 consecutive pixels, coalesced plane loads); per band it (1) reads its depths and
-// reduces the band's range of inverse depth, (2) warps the band's four corners at both ends of that range — the warp is a homography
-// for a fixed depth and moves a point monotonically along its epipolar line with the inverse depth, so the eight corner warps bound
-// every warped pixel of the band —, (3) stages the bounding box (+ the neighbourhoods' ring, clipped to the image) of the CURRENT
-// image in LDS with coalesced dword loads, (4) runs the eight pixel steps with the four rows of a 4 x 4 neighbourhood as two aligned
-// LDS dwords + v_alignbit each instead of an unaligned global dword gather each. The vector cache charges a wave 18 cycles for such
-// a gather whatever its lanes share (tools/micro/gather_rate.hip: 72 per pixel step, beside the record stream the largest item of the
-// step after its arithmetic); the same step with its taps from LDS — garbage values, no staging — ran 21 % faster at 1280x960 dense
-// and 14 % at 640x480 (-DELLC_X_LDSTAPS), which bounds what a window can give. A wave whose points do not all lie inside the
-// window (a stand-in lane of an image edge, a window that did not fit: large rotations about the optical axis) takes the global
-// path for that step — same values either way. (r03 built a window per list chunk for a VALU-heavier pixel step and lost 2 %.)
-#define ELLC_BAND_W 64
-#define ELLC_BAND_H 32
-#define ELLC_WIN_WORDS 4096   // window capacity: 16 KB
-struct WinShared {
-  float red[2][ELLC_GN_THREADS / 64];
-  uint32_t win[ELLC_WIN_WORDS + 8];
-};
-struct WinTaps {
-  const uint32_t* win;   // LDS
-  int wx0, wy0, ax0, WW; // window origin (pixels), its 4-aligned first column, words per row
-  unsigned xr, yr;       // wx1 - wx0 - 3, wy1 - wy0 - 3: the range of x0 - 1 - wx0 (y likewise) for which the neighbourhood is inside
-  bool on;               // block-uniform: a window is staged
-  template <class PF>
-  __device__ __forceinline__ TapReq operator()(const TapRows& tr, int sw, int cols, int rows, float x1, float y1, PF pf) const {
-    const int x0 = cvt_floor_i32(x1), y0 = cvt_floor_i32(y1);
-    // inside the window, which lies inside the image: all 16 neighbours in range, none of the four taps on a border column / row (a
-    // NaN coordinate converts to 0 and is never inside: wx0 >= 0)
-    const bool inwin = ((unsigned)(x0 - 1 - wx0) <= xr) & ((unsigned)(y0 - 1 - wy0) <= yr);
-    if (on && __builtin_amdgcn_ballot_w64(!inwin) == 0ull) {
-      TapReq q;
-      const unsigned bo = (unsigned)(y0 - 1 - wy0) * (unsigned)(WW << 2) + (unsigned)(x0 - 1 - ax0);
-      const unsigned wi = bo >> 2, shb = (bo & 3u) << 3;
-      const uint32_t* r = win + wi;
-      q.wa = __builtin_amdgcn_alignbit(r[1], r[0], shb);
-      q.wb = __builtin_amdgcn_alignbit(r[WW + 1], r[WW], shb);
-      q.wc = __builtin_amdgcn_alignbit(r[2 * WW + 1], r[2 * WW], shb);
-      q.wd = __builtin_amdgcn_alignbit(r[3 * WW + 1], r[3 * WW], shb);
-      q.interior = true;
-      pf();
-      return q;
-    }
-    return tap_request_f<true, PF>(tr, sw, cols, rows, x1, y1, pf);
-  }
-};
-// min and max of a value over the wave (every lane returns both)
-__device__ __forceinline__ void wave_minmax(float& lo, float& hi) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    lo = fminf(lo, __shfl_xor(lo, m, 64));
-    hi = fmaxf(hi, __shfl_xor(hi, m, 64));
-  }
-}
-
-template <bool WIN>
 __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_dense(const AlignState* src_state, const float* prev_part, int prev_nblk, int nblk, int age_rounds,
                                                                    FusedArgs fa) {
   const GnArgs& a = fa.g;
@@ -1739,10 +1667,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_dense(const AlignSt
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int pending = src.pending;
-  const int cols = g.cols, rows = g.rows, sw = g.sw;
-  // the "list" is the plane (pixels), or the plane's bands of 64 x 32 pixels in raster order (WIN): this block's share of it
-  const int nbx = (cols + ELLC_BAND_W - 1) / ELLC_BAND_W;
-  const int V = WIN ? nbx * ((rows + ELLC_BAND_H - 1) / ELLC_BAND_H) : g.n;
+  const int V = g.n;   // the "list" is the plane
   const double group_sum = partial_group_sum(prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, prev_nblk);
   int begin, end;
   if (age_rounds > 1) {
@@ -1756,30 +1681,13 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_dense(const AlignSt
     end = min(V, begin + chunk);
   }
   g_u8 cur = as_global(F.img);
-  const int lane = t & 63, wave = t >> 6;
-  // requested before the solve: this thread's first pixel (position and planes), or the depths of its eight pixels of the first band
+  // this thread's first pixel: position and planes, requested before the solve
+  const int cols = g.cols, sw = g.sw;
   const int qstep = ELLC_GN_THREADS / cols, rstep = ELLC_GN_THREADS - qstep * cols;   // a step advances a thread by 256 pixels: qstep rows and rstep columns
   int x = 0, y = 0;
   DensePix pix;
   pix.Z = 0.0f; pix.var = 0.0f; pix.I = 0u;
-  float Zn[8];
-  auto band_depths = [&](int band, float (&Z)[8]) {   // the depths of this thread's pixels of a band (0 outside the image)
-    const int bty = band / nbx, btx = band - bty * nbx;
-    const int xx = btx * ELLC_BAND_W + lane, y0 = bty * ELLC_BAND_H + wave * (ELLC_BAND_H / 4);
-#pragma unroll
-    for (int j = 0; j < 8; j++) Z[j] = (xx < cols && y0 + j < rows) ? as_global(K.depth)[(unsigned)((y0 + j) * cols + xx)] : 0.0f;
-  };
-  auto band_first = [&](int band) {   // variance and intensity of this thread's first pixel of a band (clamped into the image)
-    const int bty = band / nbx, btx = band - bty * nbx;
-    const int xx = min(btx * ELLC_BAND_W + lane, cols - 1), yy = min(bty * ELLC_BAND_H + wave * (ELLC_BAND_H / 4), rows - 1);
-    return dense_request(K, (unsigned)(yy * cols + xx), (unsigned)(yy * sw + xx));
-  };
-  DensePix pj0 = pix;
-  if constexpr (WIN) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) Zn[j] = 0.0f;
-    if (begin < end) { band_depths(begin, Zn); pj0 = band_first(begin); }
-  } else if (begin < end) {   // block-uniform (a thread past the chunk's end starts on a copy of its last pixel: the pixel loop is block-uniform)
+  if (begin < end) {   // block-uniform (a thread past the chunk's end starts on a copy of its last pixel: the pixel loop is block-uniform)
     const int i0 = min(begin + t, end - 1);
     y = (int)(((float)i0 + 0.5f) * (1.0f / (float)cols));   // i < 2^24: exact conversion; corrected to the exact quotient
     if (y * cols > i0) y--;
@@ -1815,97 +1723,9 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_dense(const AlignSt
     for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
     FcaAcc acc;
     fca_acc_zero(acc);
-    const TapRows tr = tap_rows(cur, sw);
-    const FcafConst fc = fcaf_const(g, S);
-    if constexpr (WIN) {
-      __shared__ WinShared ws;
-      for (int band = begin; band < end; band++) {   // block-uniform
-        const int bty = band / nbx, btx = band - bty * nbx;
-        const int bx = btx * ELLC_BAND_W, by = bty * ELLC_BAND_H;
-        const int px = bx + lane, py0 = by + wave * (ELLC_BAND_H / 4);
-        float Z[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) Z[j] = Zn[j];
-        // (1) the band's range of inverse depth
-        float dlo = __builtin_inff(), dhi = -__builtin_inff();
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const float dj = __builtin_amdgcn_rcpf(Z[j]);
-          if (Z[j] > 0.0f) { dlo = fminf(dlo, dj); dhi = fmaxf(dhi, dj); }
-        }
-        wave_minmax(dlo, dhi);
-        if (lane == 0) { ws.red[0][wave] = dlo; ws.red[1][wave] = dhi; }
-        __syncthreads();   // (also: every thread has finished the previous band's taps — the window may be overwritten)
-        dlo = fminf(fminf(ws.red[0][0], ws.red[0][1]), fminf(ws.red[0][2], ws.red[0][3]));
-        dhi = fmaxf(fmaxf(ws.red[1][0], ws.red[1][1]), fmaxf(ws.red[1][2], ws.red[1][3]));
-        const bool any = dhi >= dlo;   // block-uniform: the band holds a pixel with depth
-        WinTaps wt;
-        wt.win = ws.win; wt.on = false; wt.wx0 = 0; wt.wy0 = 0; wt.ax0 = 0; wt.WW = 1; wt.xr = 0; wt.yr = 0;
-        if (any) {
-          // (2) the eight corner warps (lane & 7: x end, y end, depth end), their bounding box
-          const float xc = (float)((lane & 1) ? min(bx + ELLC_BAND_W - 1, cols - 1) : bx), yc = (float)((lane & 2) ? min(by + ELLC_BAND_H - 1, rows - 1) : by);
-          const float dc = (lane & 4) ? dhi : dlo;
-          const float pc = (xc - g.cx) * g.rfx, qc = __builtin_fmaf(yc, fc.rfy, fc.qc);
-          const float wpx = __builtin_fmaf(fc.P[0], pc, __builtin_fmaf(fc.P[1], qc, __builtin_fmaf(fc.P[3], dc, fc.P[2])));
-          const float wpy = __builtin_fmaf(fc.P[4], pc, __builtin_fmaf(fc.P[5], qc, __builtin_fmaf(fc.P[7], dc, fc.P[6])));
-          const float wpz = __builtin_fmaf(fc.P[8], pc, __builtin_fmaf(fc.P[9], qc, __builtin_fmaf(fc.P[11], dc, fc.P[10])));
-          const float wrz = __builtin_amdgcn_rcpf(wpz);
-          float xlo = wpx * wrz, ylo = wpy * wrz;
-          const bool front = wpz > 1e-6f;   // a corner behind (or on) the camera plane: no window
-          xlo = front ? xlo : __builtin_nanf("");
-          float xhi = xlo, yhi = ylo;
-#pragma unroll
-          for (int m = 1; m < 8; m <<= 1) {   // over the eight lanes of the group (fminf / fmaxf drop a NaN: test it separately)
-            xlo = fminf(xlo, __shfl_xor(xlo, m, 64)); xhi = fmaxf(xhi, __shfl_xor(xhi, m, 64));
-            ylo = fminf(ylo, __shfl_xor(ylo, m, 64)); yhi = fmaxf(yhi, __shfl_xor(yhi, m, 64));
-          }
-          const bool finite = __builtin_amdgcn_ballot_w64(!(front && fabsf(xlo) < 1e6f && fabsf(xhi) < 1e6f && fabsf(ylo) < 1e6f && fabsf(yhi) < 1e6f) && lane < 8) == 0ull;
-          if (finite) {
-            // neighbourhood columns floor(x) - 1 .. floor(x) + 2, and a pixel of slack for the rounding of the corner warps
-            int wx0 = __builtin_amdgcn_readfirstlane((int)floorf(xlo)) - 2, wx1 = __builtin_amdgcn_readfirstlane((int)floorf(xhi)) + 3;
-            int wy0 = __builtin_amdgcn_readfirstlane((int)floorf(ylo)) - 2, wy1 = __builtin_amdgcn_readfirstlane((int)floorf(yhi)) + 3;
-            wx0 = max(wx0, 0); wy0 = max(wy0, 0); wx1 = min(wx1, cols - 1); wy1 = min(wy1, rows - 1);
-            const int ax0 = wx0 & ~3, WW = ((wx1 - ax0) >> 2) + 2, WH = wy1 - wy0 + 1;
-#ifdef ELLC_X_WINOFF
-            if (false) {
-#else
-            if (wx1 - wx0 >= 3 && wy1 - wy0 >= 3 && WW * WH <= ELLC_WIN_WORDS) {
-#endif
-              wt.on = true; wt.wx0 = wx0; wt.wy0 = wy0; wt.ax0 = ax0; wt.WW = WW;
-              wt.xr = (unsigned)(wx1 - wx0 - 3); wt.yr = (unsigned)(wy1 - wy0 - 3);
-              // (3) stage it: a row per wave and trip, a dword per lane (rows are read to the next multiple of four past wx1: inside the
-              // image buffer, which carries 16 spare bytes)
-#ifndef ELLC_X_NOSTAGE
-              for (int r = wave; r < WH; r += ELLC_GN_THREADS / 64)
-                for (int cidx = lane; cidx < WW; cidx += 64)
-                  ws.win[r * WW + cidx] = load_u32_unaligned(cur, (unsigned)((wy0 + r) * sw + ax0 + 4 * cidx));
-#endif
-            }
-          }
-        }
-        // the next band's depths and the planes of its first step go out behind the staging loads (vector loads return in order: in
-        // front of them the window would wait for cold memory)
-        DensePix pj = pj0;
-        if (band + 1 < end) {
-          band_depths(band + 1, Zn);
-          pj0 = band_first(band + 1);
-        }
-        __syncthreads();
-        if (!any) continue;   // block-uniform
-        // (4) the eight pixel steps of this thread: row py0 + j, column px
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int yy = py0 + j;
-          pj.Z = Z[j];
-          bool valid;
-          const FcaInF rec = dense_form(g, pj, min(px, cols - 1), min(yy, rows - 1), valid);
-          const int yn = min(yy + 1, rows - 1), xn = min(px, cols - 1);
-          auto refill = [&]() { if (j < 7) pj = dense_request(K, (unsigned)(yn * cols + xn), (unsigned)(yn * sw + xn)); };
-          const FcafStage st = fcaf_stage_a(g, tr, fc, rec, refill, wt);
-          if (valid) fca_accumulate_pixel(acc, fcaf_stage_b<false, 0>(a, K, g, cur, fc, 0u, st));
-        }
-      }
-    } else if (begin < end) {   // block-uniform
+    if (begin < end) {   // block-uniform
+      const TapRows tr = tap_rows(cur, sw);
+      const FcafConst fc = fcaf_const(g, S);
       const int n_full = __builtin_amdgcn_readfirstlane((end - begin) / ELLC_GN_THREADS);
       const int rem = __builtin_amdgcn_readfirstlane((end - begin) - n_full * ELLC_GN_THREADS);
       const int n_steps = n_full + (rem > 0 ? 1 : 0);
