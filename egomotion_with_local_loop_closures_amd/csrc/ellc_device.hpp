@@ -39,15 +39,15 @@ struct __attribute__((packed, aligned(4))) FcaRec {
   uint32_t invZ_lo, invZ_hi;   // the f64 as two words (the record is 4-byte aligned)
 };
 
-// The same pixel as the tolerance-mode FCA pass reads it (cfg.arith = ELLC_ARITH_FAST): 16 bytes. The first word is the row y AS
-// AN f32 with the keyframe intensity in its eight low mantissa bits (y < 4096 leaves the twelve low bits of its f32 zero; hence
-// width, height <= 4096 in this mode): the pass masks the byte off and has y ready for its multiply-add, no integer field to
-// extract and convert. p = (x - cx) / fx is stored (q comes from y with one fma; x itself is needed only where weights are saved or
-// planes are dumped, and comes back as rint(p fx + cx): fcaf_position), d = 1/Z in f32. Z itself is not needed: the pass warps
-// (p, q, 1) + t d, the point divided by Z (see fcaf_pixel).
-struct __attribute__((aligned(16))) FcaRecF {
-  uint32_t yI;
-  float p, var, d;
+// The same pixel as the tolerance-mode FCA pass reads it (cfg.arith = ELLC_ARITH_FAST): **12 bytes** (r05; 16 in r02-r04, 32 before):
+// {x | y << 12 | I << 24, variance, d = 1 / Z}. Z itself is not needed — the pass warps (p, q, 1) + t d, the point divided by Z (see
+// fcaf_pixel) — and p = (x - cx) / fx, q = (y - cy) / fy come from the integer fields with a conversion and one fma each
+// (width, height <= 4096). r04 stored p and y as floats to save those six instructions per pixel; r05 found the pipeline of three
+// streams ~80 % HBM-bound in aggregate — a launch group reads its records 32 times — and the quarter fewer bytes worth far more than
+// the instructions: batch pipeline 0.1323 -> 0.1251 ms per step, level-0 launch 48.1 -> 43.8 us (interleaved A/B on one box).
+struct __attribute__((packed, aligned(4))) FcaRecF {
+  uint32_t xyI;
+  float var, d;
 };
 
 // One valid keyframe pixel as the constant-weight (ICA) pixel pass reads it: 48 bytes. Everything here is independent

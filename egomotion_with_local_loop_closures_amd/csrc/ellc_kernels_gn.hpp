@@ -630,23 +630,27 @@ __device__ __forceinline__ FcaPix fca_pixel(const GnArgs& a, const KfLevelDev& K
 // with fused multiply-adds and the hardware reciprocal / reciprocal square root (1 ulp) in place of the IEEE division and
 // sqrt sequences, and f32 products where the reference's pow() promotes to double. Per-pixel values agree with the
 // exact path to a few 1e-7 relative (tests/test_gpu_fast.py states the bounds); the final pose to well below the 1e-5 bar.
-// 16-byte records instead of 32; r04: written for the issue classes of the vector ALU (see tap_request_f).
-// (kept as ONE 128-bit value: a record slot is carried around the pixel loop while its load is in flight, and a slot made of four
+// 12-byte records (FcaRecF, ellc_device.hpp; r05); r04: written for the issue classes of the vector ALU (see tap_request_f).
+// (a record slot is kept as ONE vector value: it is carried around the pixel loop while its load is in flight, and a slot made of
 // scalars makes the register allocator copy them at the loop's back edge — copies that wait for the load)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-struct FcaInF { u32x4_t v; };   // FcaRecF: f32(y) with I in its 8 low mantissa bits, p = (x - cx) / fx, variance, d = 1 / Z
-__device__ __forceinline__ FcaInF fcaf_empty() { FcaInF in; in.v = (u32x4_t){0u, 0u, 0u, 0x3f800000u}; return in; }   // y = 0, I = 0, p = 0, var = 0, d = 1
+struct FcaInF { u32x4_t v; };   // FcaRecF in registers: x | y << 12 | I << 24, variance, d = 1 / Z (the fourth word is unused)
+__device__ __forceinline__ FcaInF fcaf_empty() { FcaInF in; in.v = (u32x4_t){0u, 0u, 0x3f800000u, 0u}; return in; }   // x = y = 0, I = 0, var = 0, d = 1
 
+#define ELLC_FREC 12u
+typedef uint32_t Rec12 __attribute__((ext_vector_type(3), aligned(4)));
 __device__ __forceinline__ FcaInF fcaf_load_off(const KfLevelDev& K, unsigned byte_off) {
   FcaInF in;
-  in.v = *(const ELLC_GLOBAL u32x4_t*)((const ELLC_GLOBAL char*)K.crec + byte_off);
+  const Rec12 r = *(const ELLC_GLOBAL Rec12*)((const ELLC_GLOBAL char*)K.crec + byte_off);
+  const uint32_t a = r.x, b = r.y, c = r.z;
+  in.v = (u32x4_t){a, b, c, 0u};
   return in;
 }
-__device__ __forceinline__ FcaInF fcaf_load(const KfLevelDev& K, unsigned i) { return fcaf_load_off(K, i * 16u); }
-// position of a tolerance-mode record: y from the first word, x back from p = (x - cx) / fx (|p fx + cx - x| < 1e-3 for x < 4096)
-__device__ __forceinline__ void fcaf_position(const FcaRecF& r, const LevelGeom& g, int& x, int& y) {
-  y = (int)__builtin_bit_cast(float, r.yI & 0xffffff00u);
-  x = (int)rintf(__builtin_fmaf(r.p, g.fx, g.cx));
+__device__ __forceinline__ FcaInF fcaf_load(const KfLevelDev& K, unsigned i) { return fcaf_load_off(K, i * ELLC_FREC); }
+// position of a tolerance-mode record
+__device__ __forceinline__ void fcaf_position_at(const KfLevelDev& K, const LevelGeom& g, int i, int& x, int& y) {
+  const uint32_t w = *(const ELLC_GLOBAL uint32_t*)((const ELLC_GLOBAL char*)K.crec + (unsigned)i * 12u);
+  x = (int)(w & 0xfffu); y = (int)((w >> 12) & 0xfffu);
 }
 
 // What the pixel step needs of the level and of the pose, in VECTOR registers (an SGPR operand halves the issue rate of the f32
@@ -655,6 +659,7 @@ __device__ __forceinline__ void fcaf_position(const FcaRecF& r, const LevelGeom&
 struct FcafConst {
   float P[12];
   float rfy, qc;     // q = (y - cy) / fy = y rfy + qc
+  float rfx, pc;     // p = (x - cx) / fx = x rfx + pc
   float hfx, hfy;    // fx / 2, fy / 2 (the taps return twice the gradient)
 };
 __device__ __forceinline__ FcafConst fcaf_const(const LevelGeom& g, const float* S) {
@@ -666,6 +671,8 @@ __device__ __forceinline__ FcafConst fcaf_const(const LevelGeom& g, const float*
     c.P[8 + k] = S[8 + k];
   }
   c.rfy = g.rfy; c.qc = -(g.cy * g.rfy);
+  c.rfx = g.rfx; c.pc = -(g.cx * g.rfx);
+  asm volatile("" : "+v"(c.rfx), "+v"(c.pc));
   c.hfx = 0.5f * g.fx; c.hfy = 0.5f * g.fy;
 #pragma unroll
   for (int k = 0; k < 12; k++) asm volatile("" : "+v"(c.P[k]));
@@ -685,10 +692,11 @@ template <class PF = NoPrefetch>
 __device__ __forceinline__ FcafStage fcaf_stage_a(const LevelGeom& g, const TapRows& tr, const FcafConst& c, const FcaInF& in, PF pf = PF()) {
   FcafStage s;
   // (elements are copied to scalars first: __builtin_bit_cast applied to a vector element expression reads element 0)
-  const uint32_t yI = in.v.x, w1 = in.v.y, w2 = in.v.z, w3 = in.v.w;
-  const float yf = __builtin_bit_cast(float, yI & 0xffffff00u);
-  s.Ikf = cvt_ubyte<0>(yI);
-  s.p = __builtin_bit_cast(float, w1); s.var = __builtin_bit_cast(float, w2); s.d = __builtin_bit_cast(float, w3);
+  const uint32_t w0 = in.v.x, w1 = in.v.y, w2 = in.v.z;
+  const float xf = (float)(w0 & 0xfffu), yf = (float)((w0 >> 12) & 0xfffu);
+  s.Ikf = cvt_ubyte<3>(w0);
+  s.var = __builtin_bit_cast(float, w1); s.d = __builtin_bit_cast(float, w2);
+  s.p = __builtin_fmaf(xf, c.rfx, c.pc);
   s.q = __builtin_fmaf(yf, c.rfy, c.qc);   // p = u / fx, q = v / fy
   // K ((p, q, 1) + t d): the warped point divided by the keyframe depth Z, in pixel units times its own depth. The factors of Z
   // cancel in the projection and in the weight (1 / (pz^2 d) = Z rz^2 with the true pz; here pz is pz / Z).
@@ -1450,9 +1458,9 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
       // plain scalar loop: a per-lane exit in the middle of the unrolled body makes the compiler merge the two record slots at the
       // back edge with register copies, and a copy of a slot waits for the load that fills it. The two slots alternate through the
       // explicitly unrolled body.
-      unsigned off = (unsigned)i * 16u;
-      const unsigned off_last = (unsigned)(end - 1) * 16u;
-      constexpr unsigned S16 = stride * 16u;
+      unsigned off = (unsigned)i * ELLC_FREC, idx = (unsigned)i;
+      const unsigned off_last = (unsigned)(end - 1) * ELLC_FREC;
+      constexpr unsigned S16 = stride * ELLC_FREC;
       const int n_full = __builtin_amdgcn_readfirstlane((end - begin) / stride);
       const int rem = __builtin_amdgcn_readfirstlane((end - begin) - n_full * stride);
       const int n_steps = n_full + (rem > 0 ? 1 : 0);
@@ -1461,8 +1469,8 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
         const bool active = !last || rem == 0 || t < rem;
         auto refill = [&]() { next_rec = fcaf_load_off(K, min(off + S16, off_last)); };
         const FcafStage st = fcaf_stage_a(g, tr, fc, cur_rec, refill);
-        if (active) fca_accumulate_pixel(acc, fcaf_stage_b<false, SAVEW>(a, K, g, cur, fc, off >> 4, st));
-        off += S16;
+        if (active) fca_accumulate_pixel(acc, fcaf_stage_b<false, SAVEW>(a, K, g, cur, fc, idx, st));
+        off += S16; idx += stride;
       };
       for (int k = 0; k < n_steps; k += 2) {
         step(r0, r1, k == n_steps - 1);
@@ -1613,7 +1621,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
 // ---------------------------------------------------------------------------------------------------
 // The list-free form of gn_fca_fused for DENSE maps (r05; BASELINE configs[4]: 1280x960, every pixel holds a depth). When at least
 // nine tenths of a keyframe's pixels are valid a compact list is the plane itself, only larger: the compaction moved 25 bytes per
-// pixel to turn 9 bytes of planes (depth 4, variance 4, intensity 1) into a 16-byte record that every later launch read back — 13 %
+// pixel to turn 9 bytes of planes (depth 4, variance 4, intensity 1) into a record that every later launch read back — 13 %
 // of a dense launch group's kernel time went into compacting a mask that is all ones. Here thread <-> pixel by index: a block owns
 // the contiguous chunk of the PLANE that it owned of the list (the same split, age-balanced where the list's was), thread t takes
 // pixels begin + t, begin + t + 256, ..., reads the three planes with coalesced loads one step ahead (requested behind the tap
@@ -1633,10 +1641,8 @@ __device__ __forceinline__ DensePix dense_request(const KfLevelDev& K, unsigned 
 __device__ __forceinline__ FcaInF dense_form(const LevelGeom& g, const DensePix& p, int x, int y, bool& valid) {
   valid = p.Z > 0.0f;
   FcaInF in;
-  const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | p.I;   // FcaRecF, prep_scatter's expressions
   const float dd = __builtin_amdgcn_rcpf(valid ? p.Z : 1.0f);
-  const float pn = ((float)x - g.cx) * g.rfx;
-  in.v = (u32x4_t){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, p.var), __builtin_bit_cast(uint32_t, dd)};
+  in.v = (u32x4_t){(uint32_t)x | ((uint32_t)y << 12) | (p.I << 24), __builtin_bit_cast(uint32_t, p.var), __builtin_bit_cast(uint32_t, dd), 0u};
   return in;
 }
 
@@ -2248,7 +2254,7 @@ __global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slo
     size_t p;
     if (fast_records) {
       int x, y;
-      fcaf_position(((const FcaRecF*)K.crec)[i], geom[level], x, y);
+      fcaf_position_at(K, geom[level], i, x, y);
       p = (size_t)y * cols + x;
     } else {
       const uint32_t xyI = K.crec[i].xyI;
@@ -2273,7 +2279,7 @@ __global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf
     size_t p;
     if (fast_records) {
       int x, y;
-      fcaf_position(((const FcaRecF*)K.crec)[i], geom[level], x, y);
+      fcaf_position_at(K, geom[level], i, x, y);
       p = (size_t)y * cols + x;
     } else {
       const uint32_t xyI = K.crec[i].xyI;

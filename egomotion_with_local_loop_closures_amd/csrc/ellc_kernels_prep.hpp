@@ -191,11 +191,10 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
         const unsigned pos = tile_off + (unsigned)(r0 + k * 256) + threadIdx.x;
         const int x = xx[k], y = yy[k];
         const float Z = ZZ[k];
-        if constexpr (NEED == 8) {   // tolerance mode: one 16-byte record per pixel (FcaRecF)
-          const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | (uint32_t)Ib[k];   // FcaRecF: y < 4096 as f32 has its 12 low bits clear
+        if constexpr (NEED == 8) {   // tolerance mode: one 12-byte record per pixel (FcaRecF)
           const float dd = __builtin_amdgcn_rcpf(Z);
-          const float pn = ((float)x - g.cx) * g.rfx;   // u / fx (fcaf_pixel forms v / fy from y)
-          crec[pos] = (u32x4){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, vv[k]), __builtin_bit_cast(uint32_t, dd)};
+          *(ELLC_GLOBAL Rec12*)((ELLC_GLOBAL char*)K.crec + pos * 12u) =
+              (Rec12){(uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)Ib[k] << 24), __builtin_bit_cast(uint32_t, vv[k]), __builtin_bit_cast(uint32_t, dd)};
         } else {   // one 20-byte record per pixel (FcaRec): a 16-byte word and a 4-byte word
           const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)Ib[k] << 24);
           const double invZ = 1.0 / (double)Z;
@@ -266,11 +265,10 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
         for (int cc = rr; cc < 6; cc++) { hacc[q] = __builtin_fmaf(wJ, J[cc], hacc[q]); q++; }
       }
     }
-    if (need & 8) {   // FCA in tolerance mode: one 16-byte record per pixel (FcaRecF)
-      const uint32_t yI = __builtin_bit_cast(uint32_t, (float)y) | (uint32_t)img[(unsigned)(y * sw + x)];
+    if (need & 8) {   // FCA in tolerance mode: one 12-byte record per pixel (FcaRecF)
       const float d = __builtin_amdgcn_rcpf(Z);
-      const float pn = ((float)x - g.cx) * g.rfx;   // u / fx (fcaf_pixel forms v / fy from y)
-      crec[pos] = (u32x4){yI, __builtin_bit_cast(uint32_t, pn), __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, d)};
+      *(ELLC_GLOBAL Rec12*)((ELLC_GLOBAL char*)K.crec + pos * 12u) = (Rec12){(uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)img[(unsigned)(y * sw + x)] << 24),
+                                                                         __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, d)};
     }
     if (need & 2) {   // FCA reads one 20-byte record per pixel (FcaRec)
       const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)img[(unsigned)(y * sw + x)] << 24);
