@@ -71,12 +71,11 @@ struct KfLevelDev {
   float* cI;                  // compact keyframe intensity as f32 (ICA)
   FcaRec* crec;               // compact FCA records (same order as cxy)
   IcaRec* irec;               // compact ICA records (same order as cxy)
-  float* hpart;               // ICA: per-tile partial sums of H = sum W J^T J (prep_scatter), 32 floats per tile (21 used)
+  float* hpart;               // ICA: per-block partial sums of H = sum W J^T J (prep_build), 32 floats per block (21 used)
   float* hinv;                // ICA: inverse of the level's H (36 floats), one per keyframe slot and level
   float* cW;                  // compact saved weight (ICA)
   float* wlast;               // compact weight of the most recent iteration (for saveWeights)
   float* sd;                  // ICA steepest-descent planes, 6 x cap (plane k at sd + k*cap)
-  int* tile_count;            // [tiles] valid pixels per tile, by position in the layout's tile table (prep_count -> prep_scatter)
   int* blk_count;             // [ELLC_NBLK_MAX] compact entries in the region of every block of the level's layout (LevelLayout)
 };
 
@@ -92,9 +91,6 @@ struct KfLevelDev {
 struct LevelLayout {
   const int* blk_begin;       // [nblk + 1] prefix of the number of tiles per block
   const int* tiles;           // [ntiles] tile ids grouped by owning block, ascending inside a block
-  const int* owner;           // [ntiles] the block that owns the tile at this position of `tiles` (prep_scatter)
-  const int* tile_pos;        // [ntiles] the position of tile id t in `tiles`
-  const int* tile_info;       // [ntiles][4] per tile id: position, first and end position of its owner's tiles, owner (16-byte aligned)
   int nblk, ppt, ntiles, pad; // ppt: pixels per thread and tile (1, 2, 4 or 8): a tile is 256 * ppt pixels
 };
 

@@ -277,7 +277,7 @@ static ellc_status ensure_layout(ellc_ctx* c, int Bgrid, const ellc_ctx::LayoutS
     ellc_ctx::LayoutSet ls;
     ls.id = (int)c->layouts.size() + 1;
     std::vector<int> flat;
-    std::vector<size_t> off_begin(c->L), off_tiles(c->L), off_owner(c->L), off_pos(c->L), off_info(c->L);
+    std::vector<size_t> off_begin(c->L), off_tiles(c->L);
     for (int l = 0; l < c->L; l++) {
       const int n = c->geom_h[l].n;
       const int nblk = choose_nblk(c, l, Bgrid);
@@ -307,19 +307,6 @@ static ellc_status ensure_layout(ellc_ctx* c, int Bgrid, const ellc_ctx::LayoutS
       flat.push_back(acc);
       off_tiles[l] = flat.size();
       for (int s = 0; s < nblk; s++) flat.insert(flat.end(), owned[s].begin(), owned[s].end());
-      off_owner[l] = flat.size();
-      for (int s = 0; s < nblk; s++) flat.insert(flat.end(), owned[s].size(), s);
-      off_pos[l] = flat.size();
-      flat.resize(flat.size() + ntiles, 0);
-      for (int q = 0; q < ntiles; q++) flat[off_pos[l] + flat[off_tiles[l] + q]] = q;
-      while (flat.size() % 4) flat.push_back(0);   // 16-byte alignment of the packed entries (the buffer itself is 256-byte aligned)
-      off_info[l] = flat.size();
-      flat.resize(flat.size() + 4 * (size_t)ntiles, 0);
-      for (int q = 0; q < ntiles; q++) {
-        const int tile = flat[off_tiles[l] + q], own = flat[off_owner[l] + q];
-        int* e = &flat[off_info[l] + 4 * (size_t)tile];
-        e[0] = q; e[1] = flat[off_begin[l] + own]; e[2] = flat[off_begin[l] + own + 1]; e[3] = own;
-      }
       ls.lv_h[l].nblk = nblk; ls.lv_h[l].ppt = ppt; ls.lv_h[l].ntiles = ntiles; ls.lv_h[l].pad = 0;
     }
     int* flat_d = nullptr;
@@ -328,9 +315,6 @@ static ellc_status ensure_layout(ellc_ctx* c, int Bgrid, const ellc_ctx::LayoutS
     for (int l = 0; l < c->L; l++) {
       ls.lv_h[l].blk_begin = flat_d + off_begin[l];
       ls.lv_h[l].tiles = flat_d + off_tiles[l];
-      ls.lv_h[l].owner = flat_d + off_owner[l];
-      ls.lv_h[l].tile_pos = flat_d + off_pos[l];
-      ls.lv_h[l].tile_info = flat_d + off_info[l];
     }
     for (int l = c->L; l < ELLC_MAX_LEVELS; l++) ls.lv_h[l] = ls.lv_h[c->L - 1];
     st = dev_alloc(c, &ls.lv_d, ELLC_MAX_LEVELS);
@@ -359,35 +343,22 @@ ellc_status run_prep(ellc_ctx* c, int n_unique, int need, int B) {
   a.max_kf = c->cfg.max_keyframes;
   a.level0 = 0;
   a.blk_prefix[0] = 0;
-  a.pos_prefix[0] = 0;
-  for (int l = 0; l < ELLC_MAX_LEVELS; l++) {
-    a.blk_prefix[l + 1] = a.blk_prefix[l] + (l < c->L ? ls.nblk[l] : 0);
-    a.pos_prefix[l + 1] = a.pos_prefix[l] + (l < c->L ? ls.lv_h[l].ntiles : 0);
-    a.ppt[l] = ls.lv_h[std::min(l, c->L - 1)].ppt;
-  }
+  for (int l = 0; l < ELLC_MAX_LEVELS; l++) a.blk_prefix[l + 1] = a.blk_prefix[l] + (l < c->L ? ls.nblk[l] : 0);
+  const dim3 grd(a.blk_prefix[c->L], n_unique), blk(256);
   hipStream_t st = c->stream;
-#ifdef ELLC_PREP_REGION
-  if (need == 8) {   // tolerance-mode FCA records: ONE launch, a block per region, the depth plane read once
-    hipLaunchKernelGGL(prep_region, dim3(a.blk_prefix[c->L], n_unique), dim3(ELLC_PREP_THREADS), 0, st, a);
-    ELLC_HIP(c, hipGetLastError());
-    return ELLC_OK;
-  }
-#endif
-  const dim3 grd(a.pos_prefix[c->L], n_unique), blk(256);
-  hipLaunchKernelGGL(prep_count, grd, blk, 0, st, a);
   switch (need) {
-    case 1: hipLaunchKernelGGL(prep_scatter<1>, grd, blk, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(prep_scatter<2>, grd, blk, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(prep_scatter<4>, grd, blk, 0, st, a); break;
-    case 20: hipLaunchKernelGGL(prep_scatter<20>, grd, blk, 0, st, a); break;
-    case 8: hipLaunchKernelGGL(prep_scatter<8>, grd, blk, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(prep_build<1>, grd, blk, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(prep_build<2>, grd, blk, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(prep_build<4>, grd, blk, 0, st, a); break;
+    case 20: hipLaunchKernelGGL(prep_build<20>, grd, blk, 0, st, a); break;
+    case 8: hipLaunchKernelGGL(prep_build<8>, grd, blk, 0, st, a); break;
     default: return fail(c, ELLC_ERR_BAD_ARG, "run_prep: unknown record set");
   }
   ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
 }
 
-// ICA: H^-1 of every (unique keyframe, level) from the per-tile sums the compaction (need bit 2) left behind
+// ICA: H^-1 of every (unique keyframe, level) from the per-block sums the compaction (need bit 2) left behind
 static void enqueue_ica_hinv(ellc_ctx* c, int n_unique, int B) {
   PrepArgs a;
   a.need = 4;
@@ -953,8 +924,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       TRY(dev_alloc(c, &k.depth, n)); TRY(dev_alloc(c, &k.var, n)); TRY(dev_alloc(c, &k.weight, n));
       TRY(dev_alloc(c, &k.cxy, cp)); TRY(dev_alloc(c, &k.cZ, cp)); TRY(dev_alloc(c, &k.cI, cp));
       TRY(dev_alloc(c, &k.crec, cp)); TRY(dev_alloc(c, &k.cW, cp)); TRY(dev_alloc(c, &k.wlast, cp)); TRY(dev_alloc(c, &k.sd, 6 * cp));
-      TRY(dev_alloc(c, &k.blk_count, ELLC_NBLK_MAX)); TRY(dev_alloc(c, &k.tile_count, cp / 256 + 1));
-      TRY(dev_alloc(c, &k.irec, cp)); TRY(dev_alloc(c, &k.hpart, (cp / 256 + 1) * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
+      TRY(dev_alloc(c, &k.blk_count, ELLC_NBLK_MAX));
+      TRY(dev_alloc(c, &k.irec, cp)); TRY(dev_alloc(c, &k.hpart, (size_t)ELLC_NBLK_MAX * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
     }
     for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni + 16));
   }

@@ -50,12 +50,6 @@ template <class T>
 __device__ __forceinline__ const ELLC_GLOBAL T* as_global(const T* p) { return (const ELLC_GLOBAL T*)p; }
 template <class T>
 __device__ __forceinline__ ELLC_GLOBAL T* as_global_rw(T* p) { return (ELLC_GLOBAL T*)p; }
-// Tables that no kernel of the library writes (the layouts): read through the constant address space, i.e. by SCALAR loads when
-// the address is uniform — they wait on lgkmcnt, not on the vector-memory counter behind which a wave's prefetched records are
-// queued (read as ordinary global memory a uniform table entry is a VECTOR load with s_waitcnt vmcnt(0): the compiler cannot prove
-// that the kernel's own stores leave the table alone)
-#define ELLC_CONST __attribute__((address_space(4)))
-__device__ __forceinline__ const ELLC_CONST int* as_const(const int* p) { return (const ELLC_CONST int*)p; }
 
 // ---------------------------------------------------------------------------------------------------
 // one DPP step of a wave-wide sum (see wave_sum_rows)
@@ -514,12 +508,61 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The compact list of a level is laid out in block-owned regions (LevelLayout, ellc_device.hpp): this block's region, in records
+// Tile compaction shared by prep_build (ellc_kernels_prep.hpp) and the first Gauss-Newton launch of a level, which builds the
+// block's region of the compact list while it runs its first pixel pass (fca_build_pass / ica_build_pass below).
 #define ELLC_TILE_MAX 2048      // pixels per tile at most: 256 threads x 8 pixels (LevelLayout::ppt <= 8)
-__device__ __forceinline__ void block_range(const LevelLayout& lay, const KfLevelDev& K, int sub, int& begin, int& end) {
-  const int tb = as_const(lay.blk_begin)[sub], te = as_const(lay.blk_begin)[sub + 1];
-  begin = tb * (lay.ppt << 8);
-  end = begin + (tb < te ? as_global(K.blk_count)[sub] : 0);   // (a block without tiles has no count: nobody writes one)
+
+// inclusive scan inside a wave; returns the wave total through `total`
+__device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  total = __shfl(v, 63, 64);
+  return v;
+}
+
+// One tile of a block's compaction, first half: thread t owns pixels base + j*256 + t (j < ppt), so the depth loads of a wave
+// are contiguous; ballot ranks give every valid pixel its raster-order rank inside the tile (order = (j, wave, lane)), and
+// (pixel index, depth) are parked in LDS at ring position (q_tail + rank) & (QCAP - 1). Returns the number of valid pixels of the
+// tile. Two block barriers: after the per-(j, wave) counts, after the parking. cnt: 33 ints of LDS.
+template <int QCAP>
+__device__ __forceinline__ int tile_park(const float (&d)[8], int ppt, unsigned pix0, int q_tail, int* cnt, uint2* ring) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long m[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    m[j] = (j < ppt) ? __ballot(d[j] > 0.0f) : 0ull;
+    if (lane == 0) cnt[j * 4 + wave] = __popcll(m[j]);
+  }
+  __syncthreads();
+  int excl, tot;
+  {   // exclusive scan of the 32 (j, wave) counts, redundantly by every wave (no second barrier)
+    const int v = (lane < 32) ? cnt[lane] : 0;
+    const int inc = wave_inclusive_scan(v, tot);
+    excl = inc - v;
+  }
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int off = __shfl(excl, j * 4 + wave, 64);
+    if (j < ppt && d[j] > 0.0f) {
+      const int r = off + __popcll(m[j] & lt);
+      ring[(unsigned)(q_tail + r) & (unsigned)(QCAP - 1)] = make_uint2(pix0 + (unsigned)(j * 256), __builtin_bit_cast(uint32_t, d[j]));
+    }
+  }
+  __syncthreads();
+  return tot;
+}
+// the depths of this thread's pixels of tile `tile` (zeros past the end of the plane and for j >= ppt)
+__device__ __forceinline__ void tile_load(const ELLC_GLOBAL float* depth, int n, int ppt, unsigned pix0, float (&d)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const unsigned i = pix0 + (unsigned)(j * 256);
+    d[j] = (j < ppt && i < (unsigned)n) ? depth[i] : 0.0f;
+  }
 }
 // pixel index -> (x, y) (i < 2^24: exact conversion; corrected to the exact quotient)
 __device__ __forceinline__ void pix_xy(int i, int cols, float inv_cols, int& x, int& y) {
@@ -527,6 +570,12 @@ __device__ __forceinline__ void pix_xy(int i, int cols, float inv_cols, int& x, 
   if (y * cols > i) y--;
   if ((y + 1) * cols <= i) y++;
   x = i - y * cols;
+}
+
+// this block's region of the level's compact list: [begin, end) in record units (LevelLayout, ellc_device.hpp)
+__device__ __forceinline__ void block_range(const LevelLayout& lay, const KfLevelDev& K, int sub, int& begin, int& end) {
+  begin = as_global(lay.blk_begin)[sub] * (lay.ppt << 8);
+  end = begin + as_global(K.blk_count)[sub];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -853,7 +902,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   int begin, end;
-  { const LevelLayout lay = a.lay[a.level]; block_range(lay, K, (int)blockIdx.x, begin, end); }
+  block_range(a.lay[a.level], K, (int)blockIdx.x, begin, end);
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = st.S[i];
@@ -883,7 +932,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_precompute(GnArgs a, i
   const LevelGeom g = a.geom[a.level];
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   int begin, end;
-  { const LevelLayout lay = a.lay[a.level]; block_range(lay, K, (int)blockIdx.x, begin, end); }
+  block_range(a.lay[a.level], K, (int)blockIdx.x, begin, end);
   const int stride = ELLC_GN_THREADS;
   g_u8 img = as_global(K.img);
   float acc[21];
@@ -930,7 +979,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   int begin, end;
-  { const LevelLayout lay = a.lay[a.level]; block_range(lay, K, (int)blockIdx.x, begin, end); }
+  block_range(a.lay[a.level], K, (int)blockIdx.x, begin, end);
   const int stride = ELLC_GN_THREADS;
   float S[12];
 #pragma unroll
@@ -1566,7 +1615,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   // this block's region of the slot's compact list (LevelLayout: whole tiles, interleaved over the plane, the age-balanced split
   // in the number of tiles a block owns)
   int begin, end;
-  { const LevelLayout lay = a.lay[a.level]; block_range(lay, K, sub, begin, end); }
+  block_range(a.lay[a.level], K, sub, begin, end);
   const double group_sum = partial_group_sum(prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, prev_nblk);
   g_u8 cur = as_global(F.img);
   // this thread's first compact pixel, requested before the solve (exact mode: together with its pose-independent products)
@@ -1822,7 +1871,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
   KfLevelDev K = a.kf_tab[lvl * a.max_kf + slot];
   const FrLevelDev* F = &a.fr_tab[lvl * a.max_fr + frs];
   int begin = 0, end = 0;
-  if (sub < nb_l) { const LevelLayout lay = a.lay[lvl]; block_range(lay, K, sub, begin, end); }
+  if (sub < nb_l) block_range(a.lay[lvl], K, sub, begin, end);
   const double group_sum = partial_group_sum_from(pend, pv, nb_l);
   // this thread's first record (exact mode: and its pose-independent products), requested before the solve
   FcaIn first = fca_in_empty();
@@ -1866,7 +1915,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
     g = a.geom[nl];
     K = a.kf_tab[nl * a.max_kf + slot];
     F = &a.fr_tab[nl * a.max_fr + frs];
-    { const LevelLayout lay = a.lay[nl]; block_range(lay, K, sub, begin, end); }
+    block_range(a.lay[nl], K, sub, begin, end);
     if constexpr (FAST) {
       if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));   // (a thread past the chunk's end starts on a copy of its last record: the pixel loop is block-uniform)
     } else {
@@ -1987,7 +2036,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int pending = src.pending;
   int begin, end;
-  { const LevelLayout lay = a.lay[a.level]; block_range(lay, K, sub, begin, end); }
+  block_range(a.lay[a.level], K, sub, begin, end);
   const double group_sum = partial_group_sum(prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, prev_nblk);
   g_u8 cur = as_global(F.img);
   typename IcaInOf<FAST>::type first = ica_in_empty<FAST>();
