@@ -48,20 +48,8 @@ struct ellc_ctx {
   // cfg.cache_records: which record set (PrepArgs::need) the compact lists of a keyframe slot hold, 0 = none / stale. The lists
   // are a pure function of the slot's image, depth pyramid and weight planes: every entry point that writes one of those
   // clears the tag (ellc::invalidate_records); a batch rebuilds only the slots whose tag differs from what it needs.
-  std::vector<int> kf_rec_tag;   // need | layout id << 8 (the lists of a slot are laid out for ONE layout set, see layouts)
+  std::vector<int> kf_rec_tag;
   bool cache_records = false;
-  // Layout sets (ellc::LevelLayout per level), keyed by the batch size the launch grids are chosen for (grid_batch): block counts,
-  // age-balanced shares and tile sizes are functions of that size and of the context alone. Created on first use, outside any
-  // stream capture (ensure_layout), never freed before the context is.
-  struct LayoutSet {
-    int id = 0;
-    int nblk[ELLC_MAX_LEVELS] = {0};
-    int age_rounds[ELLC_MAX_LEVELS] = {0};
-    int age_cum[ELLC_MAX_LEVELS][5] = {{0}};
-    ellc::LevelLayout lv_h[ELLC_MAX_LEVELS];
-    ellc::LevelLayout* lv_d = nullptr;
-  };
-  std::map<int, LayoutSet> layouts;
   std::vector<std::array<int, ELLC_MAX_LEVELS>> kf_num_weights;
   std::vector<float*> kf_maxgrad, fr_maxgrad;
   std::vector<int*> kf_maxgrad_count, fr_maxgrad_count;
@@ -139,7 +127,8 @@ struct ellc_ctx {
   float* partials_d = nullptr;
   float* planes_d = nullptr;
   float *scratch_a = nullptr, *scratch_b = nullptr;   // W*H f32 each
-  int cap[ELLC_MAX_LEVELS];                            // compact capacity per level: n rounded up to whole tiles of ELLC_TILE_MAX pixels
+  int tile_begin[ELLC_MAX_LEVELS + 1];
+  int cap[ELLC_MAX_LEVELS];                            // compact capacity per level (= n)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // captured launch sequences of ellc_align, keyed by (B, unique keyframes, mode, flags: save_weights | persist | run | continuation, batch set)
   std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
@@ -228,7 +217,7 @@ ellc_status enter(ellc_ctx* c, bool join);
 #define ELLC_ENTER_BATCH(ctx) ELLC_ENTER_IMPL(ctx, false)   // ellc_align_enqueue / ellc_align_fetch
 
 int choose_nblk(const ellc_ctx* c, int level, int B);
-ellc_status run_prep(ellc_ctx* c, int n_unique, int need, int B);
+ellc_status run_prep(ellc_ctx* c, int n_unique, int need);
 ellc_status build_depth_pyramid(ellc_ctx* c, int slot);
 ellc_status build_depth_pyramid_from(ellc_ctx* c, int slot, int first_level);
 ellc_status build_maxgrad(ellc_ctx* c, bool is_kf, int slot);

@@ -71,27 +71,13 @@ struct KfLevelDev {
   float* cI;                  // compact keyframe intensity as f32 (ICA)
   FcaRec* crec;               // compact FCA records (same order as cxy)
   IcaRec* irec;               // compact ICA records (same order as cxy)
-  float* hpart;               // ICA: per-block partial sums of H = sum W J^T J (prep_build), 32 floats per block (21 used)
+  float* hpart;               // ICA: per-tile partial sums of H = sum W J^T J, 32 floats per tile (21 used)
   float* hinv;                // ICA: inverse of the level's H (36 floats), one per keyframe slot and level
   float* cW;                  // compact saved weight (ICA)
   float* wlast;               // compact weight of the most recent iteration (for saveWeights)
   float* sd;                  // ICA steepest-descent planes, 6 x cap (plane k at sd + k*cap)
-  int* blk_count;             // [ELLC_NBLK_MAX] compact entries in the region of every block of the level's layout (LevelLayout)
-};
-
-// How the compact list of one level is laid out for the launches that walk it (r05). The level's plane is cut into tiles of
-// 256 * ppt consecutive pixels; every block of a Gauss-Newton launch OWNS whole tiles (interleaved over the plane, so that the
-// blocks see the same mix of dense and empty image regions; weighted by the age-balanced split of the launch, FusedArgs) and the
-// records of its tiles lie contiguously in its own region of the slot's record arrays: block `sub` owns the tiles
-// tiles[blk_begin[sub] .. blk_begin[sub + 1]) and the records [blk_begin[sub] * 256 * ppt, ... + blk_count[sub]). Nothing about
-// the list crosses a block: no prefix over tiles, no count pass — the block that builds a region (prep_build, or the first
-// Gauss-Newton launch of the level itself, fca_build_pass) counts it, and every later launch of the same layout walks
-// [begin, begin + count) exactly as it walked its chunk of the global list before. The order of the records inside a region is
-// the raster order of the block's tiles; the 27 sums are order-dependent in their last bits only (the per-pixel values are not).
-struct LevelLayout {
-  const int* blk_begin;       // [nblk + 1] prefix of the number of tiles per block
-  const int* tiles;           // [ntiles] tile ids grouped by owning block, ascending inside a block
-  int nblk, ppt, ntiles, pad; // ppt: pixels per thread and tile (1, 2, 4 or 8): a tile is 256 * ppt pixels
+  int* count;                 // V = number of compact entries
+  int* tile_count;            // per-tile (ELLC_TILE pixels) counts, then exclusive offsets
 };
 
 struct FrLevelDev {

@@ -242,133 +242,46 @@ ellc_status build_depth_pyramid_from(ellc_ctx* c, int slot, int first_level) {
   return ELLC_OK;
 }
 
-// The age-balanced split of a level's launch (see FusedArgs::age_rounds): on when the grid is 2..4 full rounds of one block per
-// CU-slot. Decided for the batch size the grids are chosen for (grid_batch): the split is part of what fixes a batch's bits, so
-// a full batch gets the same one whether it runs alone or side by side with others (the balance is tuned for the full group).
-static int age_split_of(const ellc_ctx* c, int level, int nblk, int Bgrid, int (&cum)[5]) {
-  for (int i = 0; i < 5; i++) cum[i] = 0;
-  const int per_round = std::max(1, c->resident_blocks / 4);   // one block per CU
-  const int total = nblk * Bgrid;
-  if (!c->age_balance || total % per_round != 0) return 0;
-  const int R = total / per_round;
-  if (R < 2 || R > 4 || nblk % R != 0) return 0;
-  // only throughput-bound launches gain (several pixels per thread); a light level finishes before the arbitration matters
-  if (0.3 * c->geom_h[level].n / (256.0 * nblk) < c->age_min_px_per_thread) return 0;
-  double sum = 0;
-  for (int q = 0; q < R; q++) sum += c->age_weight[R][q];
-  double acc = 0;
-  for (int q = 0; q < R; q++) {
-    cum[q] = (int)(65536.0 * acc / sum + 0.5);
-    acc += c->age_weight[R][q];
-  }
-  cum[R] = 65536;
-  return R;
-}
-
-// The layout set for launches whose grids are chosen for a batch of Bgrid alignments (ellc::LevelLayout, ellc_device.hpp): per
-// level the block count (choose_nblk), the tile size — 256 * ppt pixels, the largest of 2048 / 1024 / 512 / 256 that still gives
-// a block eight tiles on average, so that whole tiles balance — and the owner of every tile: tiles are dealt to the blocks in
-// proportion to their share of the level (1 / nblk each, or the age-balanced shares of the launch: age_split_of) by largest
-// remaining credit, i.e. interleaved over the plane. Must not be called while a stream of the context is capturing (it
-// allocates and copies): every entry point calls ensure_layout before it enqueues.
-static ellc_status ensure_layout(ellc_ctx* c, int Bgrid, const ellc_ctx::LayoutSet** out = nullptr) {
-  auto it = c->layouts.find(Bgrid);
-  if (it == c->layouts.end()) {
-    ellc_ctx::LayoutSet ls;
-    ls.id = (int)c->layouts.size() + 1;
-    std::vector<int> flat;
-    std::vector<size_t> off_begin(c->L), off_tiles(c->L);
-    for (int l = 0; l < c->L; l++) {
-      const int n = c->geom_h[l].n;
-      const int nblk = choose_nblk(c, l, Bgrid);
-      ls.nblk[l] = nblk;
-      ls.age_rounds[l] = age_split_of(c, l, nblk, Bgrid, ls.age_cum[l]);
-      int ppt = 8;
-      while (ppt > 1 && (double)n / (256.0 * ppt * nblk) < 8.0) ppt >>= 1;
-      const int T = 256 * ppt, ntiles = (n + T - 1) / T;
-      std::vector<double> w(nblk, 1.0 / nblk), credit(nblk, 0.0);
-      if (ls.age_rounds[l] > 1) {
-        const int per_age = nblk / ls.age_rounds[l];
-        for (int s = 0; s < nblk; s++) w[s] = (ls.age_cum[l][s / per_age + 1] - ls.age_cum[l][s / per_age]) / 65536.0 / per_age;
-      }
-      std::vector<std::vector<int>> owned(nblk);
-      for (int t = 0; t < ntiles; t++) {
-        int best = 0;
-        for (int s = 0; s < nblk; s++) {
-          credit[s] += w[s];
-          if (credit[s] > credit[best] + 1e-12) best = s;
-        }
-        credit[best] -= 1.0;
-        owned[best].push_back(t);
-      }
-      off_begin[l] = flat.size();
-      int acc = 0;
-      for (int s = 0; s < nblk; s++) { flat.push_back(acc); acc += (int)owned[s].size(); }
-      flat.push_back(acc);
-      off_tiles[l] = flat.size();
-      for (int s = 0; s < nblk; s++) flat.insert(flat.end(), owned[s].begin(), owned[s].end());
-      ls.lv_h[l].nblk = nblk; ls.lv_h[l].ppt = ppt; ls.lv_h[l].ntiles = ntiles; ls.lv_h[l].pad = 0;
-    }
-    int* flat_d = nullptr;
-    ellc_status st = dev_alloc(c, &flat_d, flat.size());
-    if (st != ELLC_OK) return st;
-    for (int l = 0; l < c->L; l++) {
-      ls.lv_h[l].blk_begin = flat_d + off_begin[l];
-      ls.lv_h[l].tiles = flat_d + off_tiles[l];
-    }
-    for (int l = c->L; l < ELLC_MAX_LEVELS; l++) ls.lv_h[l] = ls.lv_h[c->L - 1];
-    st = dev_alloc(c, &ls.lv_d, ELLC_MAX_LEVELS);
-    if (st != ELLC_OK) return st;
-    if (copy_blocking(c, flat_d, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-        copy_blocking(c, ls.lv_d, ls.lv_h, sizeof(LevelLayout) * ELLC_MAX_LEVELS, hipMemcpyHostToDevice) != hipSuccess)
-      return fail(c, ELLC_ERR_HIP, "cannot upload a layout set");
-    it = c->layouts.emplace(Bgrid, ls).first;
-  }
-  if (out) *out = &it->second;
-  return ELLC_OK;
-}
-// the layout set of launches over B alignments; it exists (ensure_layout ran at the head of the entry point)
-static const ellc_ctx::LayoutSet& layout_of(ellc_ctx* c, int B);
-
-// compaction of the listed keyframes into the regions of the layout that launches over B alignments walk (prep_build): ONE launch
-ellc_status run_prep(ellc_ctx* c, int n_unique, int need, int B) {
-  const ellc_ctx::LayoutSet& ls = layout_of(c, B);
+// compaction for pyramid levels lvl_lo .. lvl_hi of the listed keyframes, on stream `st`
+ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int lvl_hi, hipStream_t st) {
+  if (lvl_lo > lvl_hi) return ELLC_OK;
   PrepArgs a;
   a.need = need;
   a.geom = c->geom_d;
   a.kf_tab = c->kf_tab_d;
-  a.lay = ls.lv_d;
   a.slots = c->uniq_slot_d;
   a.levels = c->L;
   a.max_kf = c->cfg.max_keyframes;
-  a.level0 = 0;
-  a.blk_prefix[0] = 0;
-  for (int l = 0; l < ELLC_MAX_LEVELS; l++) a.blk_prefix[l + 1] = a.blk_prefix[l] + (l < c->L ? ls.nblk[l] : 0);
-  const dim3 grd(a.blk_prefix[c->L], n_unique), blk(256);
-  hipStream_t st = c->stream;
+  for (int l = 0; l <= ELLC_MAX_LEVELS; l++) a.tile_begin[l] = c->tile_begin[std::min(l, c->L)];
+  a.tile0 = c->tile_begin[lvl_lo];
+  a.level0 = lvl_lo;
+  const int tiles = c->tile_begin[lvl_hi + 1] - c->tile_begin[lvl_lo];
+  hipLaunchKernelGGL(prep_count, dim3(tiles, n_unique), dim3(256), 0, st, a);
   switch (need) {
-    case 1: hipLaunchKernelGGL(prep_build<1>, grd, blk, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(prep_build<2>, grd, blk, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(prep_build<4>, grd, blk, 0, st, a); break;
-    case 20: hipLaunchKernelGGL(prep_build<20>, grd, blk, 0, st, a); break;
-    case 8: hipLaunchKernelGGL(prep_build<8>, grd, blk, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(prep_scatter<1>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(prep_scatter<2>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(prep_scatter<4>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
+    case 20: hipLaunchKernelGGL(prep_scatter<20>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(prep_scatter<8>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     default: return fail(c, ELLC_ERR_BAD_ARG, "run_prep: unknown record set");
   }
   ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
 }
 
-// ICA: H^-1 of every (unique keyframe, level) from the per-block sums the compaction (need bit 2) left behind
-static void enqueue_ica_hinv(ellc_ctx* c, int n_unique, int B) {
+ellc_status run_prep(ellc_ctx* c, int n_unique, int need) { return run_prep_levels(c, n_unique, need, 0, c->L - 1, c->stream); }
+
+// ICA: H^-1 of every (unique keyframe, level) from the per-tile sums the compaction (need bit 2) left behind
+static void enqueue_ica_hinv(ellc_ctx* c, int n_unique) {
   PrepArgs a;
   a.need = 4;
   a.geom = c->geom_d;
   a.kf_tab = c->kf_tab_d;
-  a.lay = layout_of(c, B).lv_d;
   a.slots = c->uniq_slot_d;
   a.levels = c->L;
   a.max_kf = c->cfg.max_keyframes;
-  for (int l = 0; l <= ELLC_MAX_LEVELS; l++) a.blk_prefix[l] = 0;
+  for (int l = 0; l <= ELLC_MAX_LEVELS; l++) a.tile_begin[l] = c->tile_begin[std::min(l, c->L)];
+  a.tile0 = 0;
   a.level0 = 0;
   hipLaunchKernelGGL(ica_hinv, dim3(c->L, n_unique), dim3(ELLC_SOLVE_THREADS), 0, c->stream, a);
 }
@@ -385,12 +298,6 @@ static int grid_batch(const ellc_ctx* c, int B) {
   return (c->coalesce > 1 && B % c->cfg.max_batch == 0) ? c->cfg.max_batch * c->coalesce : B;
 }
 
-static const ellc_ctx::LayoutSet& layout_of(ellc_ctx* c, int B) {
-  const ellc_ctx::LayoutSet* ls = nullptr;
-  (void)ensure_layout(c, grid_batch(c, B), &ls);   // a lookup: the entry points create it before they enqueue
-  return *ls;
-}
-
 static GnArgs make_gn_args(ellc_ctx* c, int level, int B, int save_w, float* planes) {
   GnArgs a;
   a.geom = c->geom_d;
@@ -401,12 +308,10 @@ static GnArgs make_gn_args(ellc_ctx* c, int level, int B, int save_w, float* pla
   a.state = c->state_d;
   a.partials = c->partials_d;
   a.planes = planes;
-  const ellc_ctx::LayoutSet& ls = layout_of(c, B);
-  a.lay = ls.lv_d;
   a.level = level;
   a.max_kf = c->cfg.max_keyframes;
   a.max_fr = c->cfg.max_frames;
-  a.nblk = ls.nblk[level];
+  a.nblk = choose_nblk(c, level, grid_batch(c, B));
   a.save_w = save_w;
   return a;
 }
@@ -550,11 +455,28 @@ static void enqueue_stage_in(ellc_ctx* c, int B) {
                      c->state_d, B, c->group_cap, c->L - 1);
 }
 
-// the age-balanced split of a launch (FusedArgs::age_rounds), as the level's layout was built with (ensure_layout)
+// fills the age-balanced split of a launch (FusedArgs::age_rounds): on when the grid is 2..4 full rounds of one block per CU-slot
 static void set_age_split(ellc_ctx* c, FusedArgs& fa, int B) {
-  const ellc_ctx::LayoutSet& ls = layout_of(c, B);
-  fa.age_rounds = ls.age_rounds[fa.g.level];
-  for (int i = 0; i < 5; i++) fa.age_cum[i] = ls.age_cum[fa.g.level][i];
+  fa.age_rounds = 0;
+  for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
+  const int per_round = std::max(1, c->resident_blocks / 4);   // one block per CU
+  // decided for the batch size the grids are chosen for (grid_batch): the split is part of what fixes a batch's bits, so a full
+  // batch gets the same one whether it runs alone or side by side with others (the balance is tuned for the full group)
+  const int total = fa.g.nblk * grid_batch(c, B);
+  if (!c->age_balance || total % per_round != 0) return;
+  const int R = total / per_round;
+  if (R < 2 || R > 4 || fa.g.nblk % R != 0) return;
+  // only throughput-bound launches gain (several pixels per thread); a light level finishes before the arbitration matters
+  if (0.3 * c->geom_h[fa.g.level].n / (256.0 * fa.g.nblk) < c->age_min_px_per_thread) return;
+  double sum = 0;
+  for (int q = 0; q < R; q++) sum += c->age_weight[R][q];
+  double cum = 0;
+  for (int q = 0; q < R; q++) {
+    fa.age_cum[q] = (int)(65536.0 * cum / sum + 0.5);
+    cum += c->age_weight[R][q];
+  }
+  fa.age_cum[R] = 65536;
+  fa.age_rounds = R;
 }
 
 static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, hipStream_t st) {
@@ -590,8 +512,8 @@ static void launch_finish(ellc_ctx* c, int B, const FusedArgs& fa, bool adaptive
 static void launch_add_saved_weights(ellc_ctx* c, int B) {
   // (blocks per alignment and level: enough for ~2 records per thread at level 0 of a semi-dense map when the batch is small —
   // the loop is a chain of three dependent memory operations per record)
-  hipLaunchKernelGGL(gn_add_saved_weights_all, dim3(B <= 4 ? 128 : 32, B, c->L), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d,
-                     layout_of(c, B).lv_d, c->state_d, c->cfg.max_keyframes, c->fast ? 1 : 0);
+  hipLaunchKernelGGL(gn_add_saved_weights_all, dim3(B <= 4 ? 128 : 32, B, c->L), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, c->state_d,
+                     c->cfg.max_keyframes, c->fast ? 1 : 0);
 }
 
 // The FCA schedule is state-driven (gn_fca_adaptive) for one or two alignments in contexts with early exit on — the tracking
@@ -654,7 +576,7 @@ static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weight
   for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
   int grid_x = 1;
   for (int l = 0; l < ELLC_MAX_LEVELS; l++) {
-    fa.nblk_lv[l] = l < c->L ? layout_of(c, B).nblk[l] : 1;
+    fa.nblk_lv[l] = l < c->L ? choose_nblk(c, l, grid_batch(c, B)) : 1;
     fa.max_it[l] = l < c->L ? c->cfg.max_iter[l] : 0;
     grid_x = std::max(grid_x, fa.nblk_lv[l]);
   }
@@ -777,7 +699,7 @@ static ellc_status enqueue_schedule(ellc_ctx* c, int B, int mode, int save_weigh
       }
     }
     if (save_weights && mode == ELLC_MODE_FCA) {
-      hipLaunchKernelGGL(gn_add_saved_weights, dim3(64, B), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, layout_of(c, B).lv_d, level,
+      hipLaunchKernelGGL(gn_add_saved_weights, dim3(64, B), dim3(256), 0, c->stream, c->kf_tab_d, c->kf_slot_d, c->geom_d, level,
                          c->cfg.max_keyframes, c->fast ? 1 : 0);
     }
   }
@@ -861,6 +783,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   }
   // ---- level geometry + Jacobian tables (UserDefinedFunc.cpp:34-50; PixelWisePyramid.cpp:296-303)
   int sw = cfg->width, sh = cfg->height;
+  c->tile_begin[0] = 0;
   for (int l = 0; l < c->L; l++) {
     LevelGeom& g = c->geom_h[l];
     g.cols = cfg->width >> l;
@@ -902,7 +825,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       return fail(c, ELLC_ERR_HIP, "cannot upload the Jacobian tables");
     }
     g.colA = dA; g.rowA = dR; g.colB = dB; g.rowB = dRB;
-    c->cap[l] = (g.n + ELLC_TILE_MAX - 1) / ELLC_TILE_MAX * ELLC_TILE_MAX;   // whole tiles: a block's region starts at a tile boundary (LevelLayout)
+    c->cap[l] = g.n;
+    c->tile_begin[l + 1] = c->tile_begin[l] + (g.n + ELLC_TILE - 1) / ELLC_TILE;
     sw = (sw + 1) / 2;
     sh = (sh + 1) / 2;
   }
@@ -917,15 +841,16 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   c->fr_tab_h.assign((size_t)c->L * MF, FrLevelDev());
   for (int l = 0; l < c->L; l++) {
     const LevelGeom& g = c->geom_h[l];
-    const size_t n = g.n, ni = (size_t)g.sw * g.sh, cp = (size_t)c->cap[l];
+    const size_t n = g.n, ni = (size_t)g.sw * g.sh;
+    const int tiles = c->tile_begin[l + 1] - c->tile_begin[l];
     for (int s = 0; s < MK; s++) {
       KfLevelDev& k = c->kf_tab_h[(size_t)l * MK + s];
       TRY(dev_alloc(c, &k.img, ni + 16));   // + 16: the window staging reads whole 16-byte words (stage_window), the last may reach past the image
       TRY(dev_alloc(c, &k.depth, n)); TRY(dev_alloc(c, &k.var, n)); TRY(dev_alloc(c, &k.weight, n));
-      TRY(dev_alloc(c, &k.cxy, cp)); TRY(dev_alloc(c, &k.cZ, cp)); TRY(dev_alloc(c, &k.cI, cp));
-      TRY(dev_alloc(c, &k.crec, cp)); TRY(dev_alloc(c, &k.cW, cp)); TRY(dev_alloc(c, &k.wlast, cp)); TRY(dev_alloc(c, &k.sd, 6 * cp));
-      TRY(dev_alloc(c, &k.blk_count, ELLC_NBLK_MAX));
-      TRY(dev_alloc(c, &k.irec, cp)); TRY(dev_alloc(c, &k.hpart, (size_t)ELLC_NBLK_MAX * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
+      TRY(dev_alloc(c, &k.cxy, n)); TRY(dev_alloc(c, &k.cZ, n)); TRY(dev_alloc(c, &k.cI, n));
+      TRY(dev_alloc(c, &k.crec, n)); TRY(dev_alloc(c, &k.cW, n)); TRY(dev_alloc(c, &k.wlast, n)); TRY(dev_alloc(c, &k.sd, 6 * n));
+      TRY(dev_alloc(c, &k.count, 4)); TRY(dev_alloc(c, &k.tile_count, tiles + 1));
+      TRY(dev_alloc(c, &k.irec, n)); TRY(dev_alloc(c, &k.hpart, (size_t)(tiles + 1) * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
     }
     for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni + 16));
   }
@@ -1449,9 +1374,9 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
   const int need = need_of(c, mode);
   ellc_status s = ELLC_OK;
   if (nu > 0) {
-    s = run_prep(c, nu, need, B);
+    s = run_prep(c, nu, need);
     if (s != ELLC_OK) return s;
-    if (need & 4) enqueue_ica_hinv(c, nu, B);
+    if (need & 4) enqueue_ica_hinv(c, nu);
   }
   s = enqueue_schedule(c, B, mode, save_weights);
   if (s != ELLC_OK) return s;
@@ -1609,14 +1534,8 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
     for (int v : bs.kf_slots) seen = seen || (v == c->kf_slot_h[b]);
     if (!seen) bs.kf_slots.push_back(c->kf_slot_h[b]);
   }
-  // the slots whose lists this launch (re)builds: all of them, or with cfg.cache_records those whose lists are stale (or laid
-  // out for launches of another size)
-  const ellc_ctx::LayoutSet* lset = nullptr;
-  {
-    const ellc_status ls_s = ensure_layout(c, grid_batch(c, B), &lset);
-    if (ls_s != ELLC_OK) return ls_s;
-  }
-  const int need = need_of(c, bs.mode) | (lset->id << 8);
+  // the slots whose lists this launch (re)builds: all of them, or with cfg.cache_records those whose lists are stale
+  const int need = need_of(c, bs.mode);
   const bool saves = bs.save_weights && bs.mode == ELLC_MODE_FCA;
   bs.built_slots.clear();
   for (int v : bs.kf_slots)
@@ -1697,7 +1616,7 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
   for (int v : bs.built_slots) c->kf_rec_tag[v] = need;
   if (saves)   // the weight planes change: lists that carry the saved weight (the constant-weight record sets) are stale
     for (int v : bs.kf_slots)
-      if ((c->kf_rec_tag[v] & 0xff) != 8 && (c->kf_rec_tag[v] & 0xff) != 2) invalidate_records(c, v);
+      if (c->kf_rec_tag[v] != 8 && c->kf_rec_tag[v] != 2) invalidate_records(c, v);
   bs.launched = true;
   bs.stream_idx = si;
   bs.B = B;
@@ -1733,8 +1652,6 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
     ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
     if (s != ELLC_OK) return s;
     for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);   // rebuilt here, outside the cache's bookkeeping
-    s = ensure_layout(c, grid_batch(c, B));
-    if (s != ELLC_OK) return s;
     c->cur_adaptive_first = adaptive_first_launches(c, B);
     bool dense = runs_dense(c, mode, B, save_weights);
     for (int b = 0; b < B; b++) dense = dense && c->kf_dense[kf_slots[b]];
@@ -1876,10 +1793,8 @@ ellc_status ellc_gn_iterate(ellc_ctx* c, int kf_slot, int frame_slot, int level,
   invalidate_records(c, kf_slot);   // the single-step API builds its own record set
   ellc_status s = stage_batch(c, 1, &kf_slot, &frame_slot, pose, &nu);
   if (s != ELLC_OK) return s;
-  s = ensure_layout(c, grid_batch(c, 1));
-  if (s != ELLC_OK) return s;
   enqueue_stage_in(c, 0);   // staging only: the state keeps the level's H^-1 (gn_set_pose0)
-  s = run_prep(c, nu, mode == ELLC_MODE_ICA ? 1 : (c->fast ? 8 : 2), 1);
+  s = run_prep(c, nu, mode == ELLC_MODE_ICA ? 1 : (c->fast ? 8 : 2));
   if (s != ELLC_OK) return s;
   hipLaunchKernelGGL(gn_set_pose0, dim3(1), dim3(1), 0, c->stream, c->state_d, c->init_pose_d);
   const size_t n = (size_t)c->geom_h[level].n;
@@ -1925,8 +1840,6 @@ ellc_status ellc_gn_display_planes(ellc_ctx* c, int kf_slot, int frame_slot, int
   int nu = 0;
   select_batch_set(c, 0);
   ellc_status s = stage_batch(c, 1, &kf_slot, &frame_slot, pose, &nu);
-  if (s != ELLC_OK) return s;
-  s = ensure_layout(c, grid_batch(c, 1));
   if (s != ELLC_OK) return s;
   enqueue_stage_in(c, 0);   // staging only
   hipLaunchKernelGGL(gn_set_pose0, dim3(1), dim3(1), 0, c->stream, c->state_d, c->init_pose_d);
@@ -1983,13 +1896,11 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);
   ellc_status s = stage_batch(c, B, kf_slots, frame_slots, nullptr, &nu, nullptr, true);   // up to a whole launch group (cfg.coalesce batches)
   if (s != ELLC_OK) return s;
-  s = ensure_layout(c, grid_batch(c, B));
-  if (s != ELLC_OK) return s;
   bool dense = runs_dense(c, ELLC_MODE_FCA, B, 0);   // the kernel the production schedule would launch for these keyframes
   for (int b = 0; b < B; b++) dense = dense && c->kf_dense[kf_slots[b]];
   enqueue_stage_in(c, 0);
   if (!dense) {
-    s = run_prep(c, nu, c->fast ? 8 : 2, B);
+    s = run_prep(c, nu, c->fast ? 8 : 2);
     if (s != ELLC_OK) return s;
   }
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B, c->L - 1);
@@ -2052,11 +1963,11 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
   ELLC_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   if (avg_ms) *avg_ms = ms / reps;
   long long V = 0;
-  for (int b = 0; b < B; b++) {   // the regions of the level's layout (a dense launch has no list: the figure is the plane's size)
-    if (dense) { V += c->geom_h[level].n; continue; }
-    int v[ELLC_NBLK_MAX];
-    ELLC_HIP(c, copy_blocking(c, v, c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + kf_slots[b]].blk_count, sizeof(int) * a.nblk, hipMemcpyDeviceToHost));
-    for (int k = 0; k < a.nblk; k++) V += v[k];
+  for (int b = 0; b < B; b++) {
+    int v = dense ? c->geom_h[level].n : 0;   // (no list, no count: the hint says at least nine tenths; the figure is the plane's size)
+    if (!dense)
+    ELLC_HIP(c, copy_blocking(c, &v, c->kf_tab_h[(size_t)level * c->cfg.max_keyframes + kf_slots[b]].count, 4, hipMemcpyDeviceToHost));
+    V += v;
   }
   if (valid_pixels) *valid_pixels = V;
   if (algorithmic_bytes) *algorithmic_bytes = 4.0 * (double)c->geom_h[level].n * B + 14.0 * (double)V;

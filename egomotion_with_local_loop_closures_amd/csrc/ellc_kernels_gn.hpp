@@ -442,7 +442,6 @@ struct GnArgs {
   AlignState* state;            // [B]
   float* partials;              // [B][ELLC_NBLK_MAX][ELLC_PART_STRIDE]
   float* planes;                // debug: 10 planes of n floats (B must be 1), else null
-  const LevelLayout* lay;       // [levels] how the compact lists are split over the blocks of these launches
   int level, max_kf, max_fr, nblk;
   int save_w;                   // write per-pixel weights of this iteration into kf.wlast
 };
@@ -505,77 +504,6 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float* __re
     for (int w = 1; w < ELLC_GN_THREADS / 64; w++) s += red[w][threadIdx.x];
     out[threadIdx.x] = s;
   }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Tile compaction shared by prep_build (ellc_kernels_prep.hpp) and the first Gauss-Newton launch of a level, which builds the
-// block's region of the compact list while it runs its first pixel pass (fca_build_pass / ica_build_pass below).
-#define ELLC_TILE_MAX 2048      // pixels per tile at most: 256 threads x 8 pixels (LevelLayout::ppt <= 8)
-
-// inclusive scan inside a wave; returns the wave total through `total`
-__device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
-  }
-  total = __shfl(v, 63, 64);
-  return v;
-}
-
-// One tile of a block's compaction, first half: thread t owns pixels base + j*256 + t (j < ppt), so the depth loads of a wave
-// are contiguous; ballot ranks give every valid pixel its raster-order rank inside the tile (order = (j, wave, lane)), and
-// (pixel index, depth) are parked in LDS at ring position (q_tail + rank) & (QCAP - 1). Returns the number of valid pixels of the
-// tile. Two block barriers: after the per-(j, wave) counts, after the parking. cnt: 33 ints of LDS.
-template <int QCAP>
-__device__ __forceinline__ int tile_park(const float (&d)[8], int ppt, unsigned pix0, int q_tail, int* cnt, uint2* ring) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned long long m[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    m[j] = (j < ppt) ? __ballot(d[j] > 0.0f) : 0ull;
-    if (lane == 0) cnt[j * 4 + wave] = __popcll(m[j]);
-  }
-  __syncthreads();
-  int excl, tot;
-  {   // exclusive scan of the 32 (j, wave) counts, redundantly by every wave (no second barrier)
-    const int v = (lane < 32) ? cnt[lane] : 0;
-    const int inc = wave_inclusive_scan(v, tot);
-    excl = inc - v;
-  }
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int off = __shfl(excl, j * 4 + wave, 64);
-    if (j < ppt && d[j] > 0.0f) {
-      const int r = off + __popcll(m[j] & lt);
-      ring[(unsigned)(q_tail + r) & (unsigned)(QCAP - 1)] = make_uint2(pix0 + (unsigned)(j * 256), __builtin_bit_cast(uint32_t, d[j]));
-    }
-  }
-  __syncthreads();
-  return tot;
-}
-// the depths of this thread's pixels of tile `tile` (zeros past the end of the plane and for j >= ppt)
-__device__ __forceinline__ void tile_load(const ELLC_GLOBAL float* depth, int n, int ppt, unsigned pix0, float (&d)[8]) {
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const unsigned i = pix0 + (unsigned)(j * 256);
-    d[j] = (j < ppt && i < (unsigned)n) ? depth[i] : 0.0f;
-  }
-}
-// pixel index -> (x, y) (i < 2^24: exact conversion; corrected to the exact quotient)
-__device__ __forceinline__ void pix_xy(int i, int cols, float inv_cols, int& x, int& y) {
-  y = (int)(((float)i + 0.5f) * inv_cols);
-  if (y * cols > i) y--;
-  if ((y + 1) * cols <= i) y++;
-  x = i - y * cols;
-}
-
-// this block's region of the level's compact list: [begin, end) in record units (LevelLayout, ellc_device.hpp)
-__device__ __forceinline__ void block_range(const LevelLayout& lay, const KfLevelDev& K, int sub, int& begin, int& end) {
-  begin = as_global(lay.blk_begin)[sub] * (lay.ppt << 8);
-  end = begin + as_global(K.blk_count)[sub];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -901,8 +829,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_fca_accumulate(GnArgs a) {
   const LevelGeom g = a.geom[a.level];
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
-  int begin, end;
-  block_range(a.lay[a.level], K, (int)blockIdx.x, begin, end);
+  const int V = *K.count;
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = blockIdx.x * chunk;
+  const int end = min(V, begin + chunk);
   float S[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) S[i] = st.S[i];
@@ -931,8 +861,13 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_precompute(GnArgs a, i
   if (st.level_done == a.level) return;
   const LevelGeom g = a.geom[a.level];
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
-  int begin, end;
-  block_range(a.lay[a.level], K, (int)blockIdx.x, begin, end);
+  const int V = *K.count;
+  // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
+  // split, which was tried in r01 and did not change the run time — co-resident blocks finish staggered because the
+  // SIMD arbiter serves the oldest wave first, not because their pixels differ)
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = blockIdx.x * chunk;
+  const int end = min(V, begin + chunk);
   const int stride = ELLC_GN_THREADS;
   g_u8 img = as_global(K.img);
   float acc[21];
@@ -978,8 +913,13 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_iterate(GnArgs a, int 
   const LevelGeom g = a.geom[a.level];
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
-  int begin, end;
-  block_range(a.lay[a.level], K, (int)blockIdx.x, begin, end);
+  const int V = *K.count;
+  // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
+  // split, which was tried in r01 and did not change the run time — co-resident blocks finish staggered because the
+  // SIMD arbiter serves the oldest wave first, not because their pixels differ)
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = blockIdx.x * chunk;
+  const int end = min(V, begin + chunk);
   const int stride = ELLC_GN_THREADS;
   float S[12];
 #pragma unroll
@@ -1577,12 +1517,12 @@ template <bool DIVC, bool PIPE, bool FAST = false, int SAVEW = -1>   // SAVEW: s
 __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignState* src_state, const float* prev_part, int prev_nblk,
                                                                    int nblk, int age_rounds, FusedArgs fa) {   // 4 waves per SIMD: at most 128 VGPRs
   const GnArgs& a = fa.g;
-  int b = blockIdx.y, sub = blockIdx.x;
+  int b = blockIdx.y, sub = blockIdx.x, age = 0, per_age = nblk;
   if (age_rounds > 1) {
     const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
     const int per_round = (int)(gridDim.x * gridDim.y) / age_rounds;
-    const int per_age = nblk / age_rounds;          // blocks of one alignment in each round
-    const int age = lin / per_round;
+    per_age = nblk / age_rounds;          // blocks of one alignment in each round
+    age = lin / per_round;
     const int j = lin - age * per_round;
     b = j / per_age;
     sub = age * per_age + (j - b * per_age);
@@ -1612,11 +1552,22 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int pending = src.pending;
-  // this block's region of the slot's compact list (LevelLayout: whole tiles, interleaved over the plane, the age-balanced split
-  // in the number of tiles a block owns)
-  int begin, end;
-  block_range(a.lay[a.level], K, sub, begin, end);
+  const int V = *as_global(K.count);
   const double group_sum = partial_group_sum(prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, prev_nblk);
+  // contiguous chunk per block (keeps a block's taps in a few image rows: 25 % less fetch traffic than a tile-cyclic
+  // split, which was tried in r01 and did not change the run time — co-resident blocks finish staggered because the
+  // SIMD arbiter serves the oldest wave first, not because their pixels differ)
+  int begin, end;
+  if (age_rounds > 1) {
+    const int gb = (int)(((long long)V * fa.age_cum[age]) >> 16), ge = (int)(((long long)V * fa.age_cum[age + 1]) >> 16);
+    const int chunk = (ge - gb + per_age - 1) / per_age;
+    begin = gb + (sub - age * per_age) * chunk;
+    end = min(ge, begin + chunk);
+  } else {
+    const int chunk = (V + nblk - 1) / nblk;
+    begin = sub * chunk;
+    end = min(V, begin + chunk);
+  }
   g_u8 cur = as_global(F.img);
   // this thread's first compact pixel, requested before the solve (exact mode: together with its pose-independent products)
   FcaIn first = fca_in_empty();
@@ -1870,9 +1821,14 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
   LevelGeom g = a.geom[lvl];
   KfLevelDev K = a.kf_tab[lvl * a.max_kf + slot];
   const FrLevelDev* F = &a.fr_tab[lvl * a.max_fr + frs];
-  int begin = 0, end = 0;
-  if (sub < nb_l) block_range(a.lay[lvl], K, sub, begin, end);
+  int V = *as_global(K.count);
   const double group_sum = partial_group_sum_from(pend, pv, nb_l);
+  int begin, end;
+  {
+    const int chunk = (V + nb_l - 1) / nb_l;
+    begin = sub * chunk;
+    end = min(V, begin + chunk);
+  }
   // this thread's first record (exact mode: and its pose-independent products), requested before the solve
   FcaIn first = fca_in_empty();
   FcaInF firstf = fcaf_empty();
@@ -1915,7 +1871,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
     g = a.geom[nl];
     K = a.kf_tab[nl * a.max_kf + slot];
     F = &a.fr_tab[nl * a.max_fr + frs];
-    block_range(a.lay[nl], K, sub, begin, end);
+    V = *as_global(K.count);
+    const int chunk = (V + nb_n - 1) / nb_n;
+    begin = sub * chunk;
+    end = min(V, begin + chunk);
     if constexpr (FAST) {
       if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));   // (a thread past the chunk's end starts on a copy of its last record: the pixel loop is block-uniform)
     } else {
@@ -2035,9 +1994,11 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
   const KfLevelDev K = a.kf_tab[a.level * a.max_kf + slot];   // by value: uniform, lives in SGPRs
   const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
   const int pending = src.pending;
-  int begin, end;
-  block_range(a.lay[a.level], K, sub, begin, end);
+  const int V = *as_global(K.count);
   const double group_sum = partial_group_sum(prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, prev_nblk);
+  const int chunk = (V + a.nblk - 1) / a.nblk;
+  const int begin = sub * chunk;
+  const int end = min(V, begin + chunk);
   g_u8 cur = as_global(F.img);
   typename IcaInOf<FAST>::type first = ica_in_empty<FAST>();
   if (begin + t < end) first = ica_load_any<FAST>(K, (unsigned)(begin + t));
@@ -2282,42 +2243,50 @@ __device__ inline void init_state_record(AlignState& st, const float* init_pose,
   for (int i = 0; i < 6; i++) st.b[i] = 0.0f;
 }
 
-// PixelWisePyramid::saveWeights(true) (:544-549): weight_pyramid[l] += display_weightimg (masked pixels add 0). The compact
-// list is walked region by region (LevelLayout): blockIdx.x strides over the blocks of the layout.
-__device__ __forceinline__ void add_saved_weights_level(const KfLevelDev& K, const LevelGeom& g, const LevelLayout& lay, int fast_records) {
-  const int cols = g.cols;
-  for (int sub = blockIdx.x; sub < lay.nblk; sub += gridDim.x) {
-    int begin, end;
-    block_range(lay, K, sub, begin, end);
-    for (int i = begin + (int)threadIdx.x; i < end; i += blockDim.x) {
-      // saved weights exist in the FCA schedule only: its records carry the pixel position
-      size_t p;
-      if (fast_records) {
-        int x, y;
-        fcaf_position_at(K, g, i, x, y);
-        p = (size_t)y * cols + x;
-      } else {
-        const uint32_t xyI = K.crec[i].xyI;
-        p = (size_t)((xyI >> 12) & 0xfffu) * cols + (xyI & 0xfffu);
-      }
-      K.weight[p] = K.weight[p] + K.wlast[i];
+// PixelWisePyramid::saveWeights(true) (:544-549): weight_pyramid[l] += display_weightimg (masked pixels add 0)
+__global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, int level, int max_kf, int fast_records) {
+  const int b = blockIdx.y;
+  const KfLevelDev& K = kf_tab[level * max_kf + kf_slot[b]];
+  const int V = *K.count;
+  const int cols = geom[level].cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+    // saved weights exist in the FCA schedule only: its records carry the pixel position
+    size_t p;
+    if (fast_records) {
+      int x, y;
+      fcaf_position_at(K, geom[level], i, x, y);
+      p = (size_t)y * cols + x;
+    } else {
+      const uint32_t xyI = K.crec[i].xyI;
+      p = (size_t)((xyI >> 12) & 0xfffu) * cols + (xyI & 0xfffu);
     }
+    K.weight[p] = K.weight[p] + K.wlast[i];
   }
-}
-__global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, const LevelLayout* lay, int level, int max_kf,
-                                     int fast_records) {
-  add_saved_weights_level(kf_tab[level * max_kf + kf_slot[blockIdx.y]], geom[level], lay[level], fast_records);
 }
 
 // The same for every level in ONE launch at the end of a fused schedule (grid (x, B, L)): each level's wlast holds the
 // weights of that level's last executed pixel pass. Only once the alignment's schedule has ended (the state-driven schedule
 // may stop short of it and be continued: cur_level of the record the finish kernel wrote is -1 at the end) and only ONCE per
 // alignment: a continuation graph carries the alignments its first graph already ended as cur_level = -2 (gn_fca_adaptive).
-__global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, const LevelLayout* lay,
-                                         const AlignState* state, int max_kf, int fast_records) {
+__global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, const AlignState* state, int max_kf,
+                                         int fast_records) {
   const int b = blockIdx.y, level = blockIdx.z;
   if (state[b].cur_level != -1) return;
-  add_saved_weights_level(kf_tab[level * max_kf + kf_slot[b]], geom[level], lay[level], fast_records);
+  const KfLevelDev& K = kf_tab[level * max_kf + kf_slot[b]];
+  const int V = *K.count;
+  const int cols = geom[level].cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+    size_t p;
+    if (fast_records) {
+      int x, y;
+      fcaf_position_at(K, geom[level], i, x, y);
+      p = (size_t)y * cols + x;
+    } else {
+      const uint32_t xyI = K.crec[i].xyI;
+      p = (size_t)((xyI >> 12) & 0xfffu) * cols + (xyI & 0xfffu);
+    }
+    K.weight[p] = K.weight[p] + K.wlast[i];
+  }
 }
 
 }  // namespace ellc

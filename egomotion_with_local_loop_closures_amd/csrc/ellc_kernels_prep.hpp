@@ -9,46 +9,135 @@
 namespace ellc {
 
 // ---------------------------------------------------------------------------------------------------
-// Compaction of the keyframe's valid pixels (mask = depth_pyramid[l] > 0, Frame.cpp:295-301) into the block-owned regions of
-// the level's layout (LevelLayout, ellc_device.hpp). r05: ONE launch, no count pass, no prefix over tiles — the block that builds a
-// region is the only one that needs its count (r01-r04: a count launch per tile of 2048 pixels, then a scatter launch whose blocks
-// summed the counts of the tiles before theirs; 18 % of a launch group's kernel time and the depth planes read twice). The
-// production schedules do not even launch this kernel: the first Gauss-Newton launch of a level builds the regions it then walks
-// (fca_build_pass / ica_build_pass, ellc_kernels_gn.hpp). It remains for the single-step API, for batches in which alignments share
-// a keyframe slot (their blocks would write the same regions side by side), and for the state-driven tracking schedule.
+// Compaction of the keyframe's valid pixels (mask = depth_pyramid[l] > 0, Frame.cpp:295-301), raster
+// order preserved. Two launches (count per tile, then scatter) cover all levels of all listed keyframe slots.
+#define ELLC_TILE 2048          // pixels per block: 256 threads x 8 consecutive pixels (two float4 loads)
 
 struct PrepArgs {
   const LevelGeom* geom;
   const KfLevelDev* kf_tab;
-  const LevelLayout* lay;      // [levels] the layout the consumers of these lists use
   const int* slots;            // unique keyframe slots
   int levels, max_kf;
   int need;                    // bit 0: planes Z / I / saved weight (unfused ICA kernels); bit 1: FcaRec records (FCA);
-                               // bit 2: IcaRec records + per-block sums of H (fused ICA schedule); bit 3: FcaRecF records
+                               // bit 2: IcaRec records + per-tile sums of H (fused ICA schedule); bit 3: FcaRecF records
                                // (FCA in tolerance mode, cfg.arith = ELLC_ARITH_FAST); bit 4 (with bit 2): the ICA records in
                                // the tolerance mode's 16-byte form (IcaInF) instead of IcaRec
-  int blk_prefix[ELLC_MAX_LEVELS + 1];   // prefix of the blocks per level (prep_build: blockIdx.x -> level, block)
-  int level0;                  // ica_hinv: levels level0 + blockIdx.x
+  int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
+  int tile0, level0;           // this launch covers tiles tile0 + blockIdx.x (count / scatter), levels level0 + blockIdx.x (scan)
 };
 
-// Second half, dense over the parked entries — every lane has a valid pixel — computes the record (three IEEE divisions in the
-// exact forms) and stores it; consecutive lanes write consecutive records. Without the LDS step the divisions would run for every
-// wave that holds at least one valid pixel, i.e. about four times as often on a semi-dense map.
+__device__ __forceinline__ int prep_level_of(const PrepArgs& a, int tile, int& local) {
+  int l = 0;
+  while (l + 1 < a.levels && tile >= a.tile_begin[l + 1]) l++;
+  local = tile - a.tile_begin[l];
+  return l;
+}
+
+// eight consecutive depths of this thread (zeros past the end of the plane)
+__device__ __forceinline__ void prep_load8(const float* __restrict__ depth, int i0, int n, float (&d)[8]) {
+  if (i0 + 7 < n) {
+    const float4 a = *reinterpret_cast<const float4*>(depth + i0);
+    const float4 b = *reinterpret_cast<const float4*>(depth + i0 + 4);
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) d[j] = (i0 + j < n) ? depth[i0 + j] : 0.0f;
+  }
+}
+
+// inclusive scan inside a wave; returns the wave total through `total`
+__device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  total = __shfl(v, 63, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
+  int local;
+  const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
+  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const int n = a.geom[level].n;
+  const int i0 = local * ELLC_TILE + threadIdx.x * 8;
+  float d[8];
+  prep_load8(K.depth, i0, n, d);
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) c += (d[j] > 0.0f) ? 1 : 0;
+  __shared__ int ws[4];
+  int tot;
+  wave_inclusive_scan(c, tot);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    K.tile_count[local] = ws[0] + ws[1] + ws[2] + ws[3];
+  }
+}
+
+// Scatter, two phases per tile of ELLC_TILE pixels. Phase 1: thread t owns pixels base + j*256 + t (j = 0..7), so the
+// depth loads of a wave are contiguous; ballot ranks give every valid pixel its raster-order rank inside the tile
+// (order = (j, wave, lane)), and (pixel index, depth) are parked in LDS at that rank. Phase 2 runs densely over the
+// parked entries — every lane has a valid pixel — computes the record (three IEEE divisions) and stores it; consecutive
+// lanes write consecutive records. Without the LDS step the divisions would run for every wave that holds at least one
+// valid pixel, i.e. about four times as often on a semi-dense map.
 template <int NEED>   // compile-time copy of PrepArgs::need: the FCA variant carries no Jacobian / H-sum code (and registers)
-__global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
-  int level = 0;
-  while (level + 1 < a.levels && (int)blockIdx.x >= a.blk_prefix[level + 1]) level++;
-  const int sub = (int)blockIdx.x - a.blk_prefix[level];
+__global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
+  int local;
+  const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
   const KfLevelDev K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
-  const LevelLayout Lay = a.lay[level];
   const LevelGeom& g = a.geom[level];
   const int n = g.n;
-  const int tb = Lay.blk_begin[sub], te = Lay.blk_begin[sub + 1];
-  const int ppt = Lay.ppt, T = ppt << 8;
-  const unsigned region = (unsigned)tb * (unsigned)T;
-  constexpr int QCAP = ELLC_TILE_MAX;   // (a tile's entries are consumed before the next tile is parked: the ring never wraps here)
-  __shared__ int cnt[33];
-  __shared__ uint2 ring[QCAP];
+  const int base = local * ELLC_TILE + (int)threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int cnt[33];   // [j][wave] exclusive offsets, [32] = tile total
+  __shared__ int before[4]; // per wave: valid pixels in the tiles of this level that precede this one
+  __shared__ uint32_t s_idx[ELLC_TILE];
+  __shared__ float s_Z[ELLC_TILE];
+  // the eight depth loads first, then the loads of the tile counts: both sets are in flight together (r03: a block's life is a
+  // chain of memory round trips of 2-3 us each under load — table entry, counts, depths, gathers, stores: 12 us for 2048 pixels)
+  float d[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int i = base + j * 256;
+    d[j] = (i < n) ? gptr(K.depth)[(unsigned)i] : 0.0f;
+  }
+  {   // this tile's offset in the level's list = sum of the counts prep_count left for the tiles before it (at most a few hundred)
+    int part = 0, tot;
+    for (int i = (int)threadIdx.x; i < local; i += 256) part += gptr(K.tile_count)[(unsigned)i];
+    wave_inclusive_scan(part, tot);
+    if (lane == 0) before[wave] = tot;
+  }
+  unsigned long long m[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    m[j] = __ballot(d[j] > 0.0f);
+    if (lane == 0) cnt[j * 4 + wave] = __popcll(m[j]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {   // exclusive scan of the 32 (j, wave) counts
+    int v = (lane < 32) ? cnt[lane] : 0, tot;
+    const int inc = wave_inclusive_scan(v, tot);
+    if (lane < 32) cnt[lane] = inc - v;
+    if (lane == 0) cnt[32] = tot;
+  }
+  __syncthreads();
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if (d[j] > 0.0f) {
+      const int r = cnt[j * 4 + wave] + __popcll(m[j] & lt);
+      s_idx[r] = (uint32_t)(base + j * 256);
+      s_Z[r] = d[j];
+    }
+  }
+  __syncthreads();
+  const int nvalid = cnt[32];
+  const unsigned tile_off = (unsigned)(before[0] + before[1] + before[2] + before[3]);
+  if (threadIdx.x == 0 && local == a.tile_begin[level + 1] - a.tile_begin[level] - 1) *K.count = (int)tile_off + nvalid;   // last tile: the level's total
   const float inv_cols = 1.0f / (float)g.cols;
   const ELLC_GLOBAL float* var = gptr(K.var);
   const ELLC_GLOBAL float* wgt = gptr(K.weight);
@@ -72,15 +161,6 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
   constexpr int CH = 3;
   __shared__ u32x4 s_rec[((NEED & 4) && !(NEED & 16)) ? 256 * CH : 1];
   ELLC_GLOBAL u32x4* rec_out = (ELLC_GLOBAL u32x4*)K.irec;
-  int running = 0;   // records of this block's region so far
-  float d[8];
-  if (tb < te) tile_load(gptr(K.depth), n, ppt, (unsigned)Lay.tiles[tb] * (unsigned)T + threadIdx.x, d);
-  for (int jt = tb; jt < te; jt++) {   // block-uniform
-    const unsigned pix0 = (unsigned)Lay.tiles[jt] * (unsigned)T + threadIdx.x;
-    const int nvalid = tile_park<QCAP>(d, ppt, pix0, 0, cnt, ring);
-    // the next tile's depths are requested before this tile's records are formed (a block's life is a chain of memory round trips)
-    if (jt + 1 < te) tile_load(gptr(K.depth), n, ppt, (unsigned)Lay.tiles[jt + 1] * (unsigned)T + threadIdx.x, d);
-    const unsigned tile_off = region + (unsigned)running;
   if constexpr (NEED == 8 || NEED == 2) {
     // FCA records: up to four records per thread and trip, all their gathers (the image byte and the variance of each) issued
     // before the first is used — one memory round trip per 1024 records instead of one per 256
@@ -94,11 +174,15 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
       for (int k = 0; k < U; k++) {
         const int r = r0 + k * 256 + (int)threadIdx.x;
         act[k] = r < nvalid;
-        const uint2 e = ring[act[k] ? r : 0];   // (an idle lane reads entry 0: a valid address, nothing is stored)
-        ii[k] = (int)e.x;
-        ZZ[k] = __builtin_bit_cast(float, e.y);
-        pix_xy(ii[k], cols, inv_cols, xx[k], yy[k]);
-        Ib[k] = img[(unsigned)(yy[k] * sw + xx[k])];
+        const int rr = act[k] ? r : 0;   // (an idle lane reads entry 0: a valid address, nothing is stored)
+        ii[k] = (int)s_idx[rr];
+        ZZ[k] = s_Z[rr];
+        int y = (int)(((float)ii[k] + 0.5f) * inv_cols);   // i < 2^24: exact conversion; corrected below
+        if (y * cols > ii[k]) y--;
+        if ((y + 1) * cols <= ii[k]) y++;
+        yy[k] = y;
+        xx[k] = ii[k] - y * cols;
+        Ib[k] = img[(unsigned)(y * sw + xx[k])];
         vv[k] = var[(unsigned)ii[k]];
       }
 #pragma unroll
@@ -126,12 +210,13 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
   for (int r0 = 0; r0 < nvalid; r0 += 256) {   // block-uniform trip count
     const int r = r0 + (int)threadIdx.x;
     if (r < nvalid) {
-    const uint2 e = ring[r];
-    const int i = (int)e.x;
-    const float Z = __builtin_bit_cast(float, e.y);
+    const int i = (int)s_idx[r];
+    const float Z = s_Z[r];
     const unsigned pos = tile_off + (unsigned)r;
-    int x, y;
-    pix_xy(i, cols, inv_cols, x, y);
+    int y = (int)(((float)i + 0.5f) * inv_cols);   // i < 2^24: exact conversion; corrected below
+    if (y * cols > i) y--;
+    if ((y + 1) * cols <= i) y++;
+    const int x = i - y * cols;
     const uint32_t xy = ((uint32_t)y << 16) | (uint32_t)x;
     // the pixel and its two row neighbours (clamped at the image's edges, Frame.cpp:185-285) from ONE unaligned dword starting at
     // max(x - 1, 0) — three byte gathers cost the vector cache three times what the dword costs (the row's stored width and the
@@ -151,10 +236,11 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
     }
     if (need & 4) {   // ICA record: template-gradient Jacobian at the integer pixel (PixelWisePyramid.cpp:561-680)
       // frame::calculateGradient of the keyframe level image at (y,x)  (Frame.cpp:185-285)
-      const int ym = max(y - 1, 0), yp = min(y + 1, g.rows - 1);
+      const int xm = max(x - 1, 0), xp = min(x + 1, cols - 1), ym = max(y - 1, 0), yp = min(y + 1, g.rows - 1);
       const float sx = (x == 0 || x == cols - 1) ? 1.0f : 0.5f;
       const float sy = (y == 0 || y == g.rows - 1) ? 1.0f : 0.5f;
       const float gradx = sx * ((float)pxp - (float)pxm);
+      (void)xm; (void)xp;
       const float grady = sy * ((float)img[(unsigned)(yp * sw + x)] - (float)img[(unsigned)(ym * sw + x)]);
       float J[6];
       jacobian_row<false>(gradx, grady, x, y, 1.0 / (double)Z, g, J);
@@ -179,6 +265,20 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
         for (int cc = rr; cc < 6; cc++) { hacc[q] = __builtin_fmaf(wJ, J[cc], hacc[q]); q++; }
       }
     }
+    if (need & 8) {   // FCA in tolerance mode: one 12-byte record per pixel (FcaRecF)
+      const float d = __builtin_amdgcn_rcpf(Z);
+      *(ELLC_GLOBAL Rec12*)((ELLC_GLOBAL char*)K.crec + pos * 12u) = (Rec12){(uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)img[(unsigned)(y * sw + x)] << 24),
+                                                                         __builtin_bit_cast(uint32_t, var[(unsigned)i]), __builtin_bit_cast(uint32_t, d)};
+    }
+    if (need & 2) {   // FCA reads one 20-byte record per pixel (FcaRec)
+      const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)img[(unsigned)(y * sw + x)] << 24);
+      const double invZ = 1.0 / (double)Z;
+      const unsigned long long zb = __builtin_bit_cast(unsigned long long, invZ);
+      ELLC_GLOBAL char* r = (ELLC_GLOBAL char*)K.crec + pos * (unsigned)sizeof(FcaRec);
+      typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+      *(ELLC_GLOBAL u32x4a*)r = (u32x4a){xyI, __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, var[(unsigned)i]), (uint32_t)zb};
+      *(ELLC_GLOBAL uint32_t*)(r + 16) = (uint32_t)(zb >> 32);
+    }
     }
     if ((NEED & 4) && !(NEED & 16)) {
       __syncthreads();
@@ -188,19 +288,15 @@ __global__ __launch_bounds__(256) void prep_build(PrepArgs a) {
       __syncthreads();
     }
   }
-    running += nvalid;
-    __syncthreads();   // the ring and the counts are reused by the next tile
-  }
-  if (threadIdx.x == 0) K.blk_count[sub] = running;
-  if (need & 4) block_reduce_store<27>(hacc, K.hpart + (size_t)sub * ELLC_PART_STRIDE);   // block-uniform condition
+  if (need & 4) block_reduce_store<27>(hacc, K.hpart + (size_t)local * ELLC_PART_STRIDE);   // block-uniform condition
 }
 
-// ICA: H of one (keyframe slot, level) from the per-block sums (fixed-order f64 combine), then cv::Mat::inv(DECOMP_LU)
+// ICA: H of one (keyframe slot, level) from the per-tile sums (fixed-order f64 combine), then cv::Mat::inv(DECOMP_LU)
 // (PixelWisePyramid.cpp:938-939). One block per (level, unique slot); the level's inverse is kept with the slot.
 __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void ica_hinv(PrepArgs a) {
   const int level = a.level0 + (int)blockIdx.x;
   const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
-  const int T = a.lay[level].nblk;
+  const int T = a.tile_begin[level + 1] - a.tile_begin[level];
   __shared__ SolveShared sh;
   const int t = threadIdx.x;
   sh.part[t >> 5][t & 31] = partial_group_sum(K.hpart, T);
