@@ -295,9 +295,18 @@ __device__ __forceinline__ TapReq tap_request_f(const TapRows& tr, int sw, int c
   q.wb = 0; q.wc = 0;
   if (q.interior) {
     const unsigned off = __umul24((unsigned)y0, (unsigned)sw) + (unsigned)x0;
+#ifdef ELLC_X_LDSTAPS   // variant builds only (tools/pmc_ldstaps.sh; WRONG values): what the four rows would cost as reads of an LDS
+                        // window that is already there — two aligned dwords + v_alignbit per row, no staging, no window arithmetic
+    __shared__ uint32_t xl[4 * 1024 + 4];
+    const unsigned o = (off >> 2) & 1023u, shb = (off & 3u) * 8u;
+    q.wb = __builtin_amdgcn_alignbit(xl[o + 1], xl[o], shb);
+    q.wc = __builtin_amdgcn_alignbit(xl[1024 + o + 1], xl[1024 + o], shb);
+    if (WANT_GRAD) { q.wa = __builtin_amdgcn_alignbit(xl[2048 + o + 1], xl[2048 + o], shb); q.wd = __builtin_amdgcn_alignbit(xl[3072 + o + 1], xl[3072 + o], shb); }
+#else
     q.wb = load_u32_unaligned(tr.rb, off);
     q.wc = load_u32_unaligned(tr.rc, off);
     if (WANT_GRAD) { q.wa = load_u32_unaligned(tr.ra, off); q.wd = load_u32_unaligned(tr.rd, off); }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     after_issue();   // behind the row requests: vector loads return in issue order
     __builtin_amdgcn_sched_barrier(0);
