@@ -1,5 +1,6 @@
 #!/bin/bash
 # The driver's 20-step window and the steady state against the launch-group size (cfg.coalesce) and the batches in flight.
+# (groups of more than four batches need a build with ellc_ctx::MAX_COALESCE raised and bench.py's clamp with it: NOTEBOOK 5.6)
 # usage: tools/sweep_groups.sh OUT "c:inflight c:inflight ..."   (one box; every point twice, interleaved)
 out=${1:-gpurun_out/sweep_groups.txt}; pts=${2:-"4:16 5:20 6:24 7:21 7:28 8:24 8:32"}
 mkdir -p $(dirname $out); : > $out
