@@ -2001,6 +2001,16 @@ __global__ __launch_bounds__(256) void calib_read_f32(const float* __restrict__ 
   if (acc == 1.2345e-30f) sink[0] = acc;   // keeps the loads alive
 }
 
+#ifdef ELLC_SEQ_STAMPS
+// experiment build only: entry / exit stamps of block (0, 0) of the 32 launches of the last FCA sequence (100 MHz)
+extern "C" ellc_status ellc_debug_seq_stamps(ellc_ctx* c, unsigned long long* out64) {
+  if (!c || !out64) return ELLC_ERR_BAD_ARG;
+  ELLC_ENTER(c);
+  ELLC_HIP(c, hipDeviceSynchronize());
+  ELLC_HIP(c, hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_seq_stamps), 64 * sizeof(unsigned long long)));
+  return ELLC_OK;
+}
+#endif
 #ifdef ELLC_STAMPS
 // diagnostic build only: copies the cycle stamps of block (0,0) of the last fused launch
 ellc_status ellc_debug_stamps(ellc_ctx* c, unsigned long long* out64) {

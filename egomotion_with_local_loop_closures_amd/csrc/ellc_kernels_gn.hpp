@@ -38,6 +38,21 @@ __device__ unsigned long long g_block_stamps[4 * 8192];   // per block: start, p
 #define ELLC_STAMP(id) do { } while (0)
 #define ELLC_BSTAMP(slot) do { } while (0)
 #endif
+// -DELLC_SEQ_STAMPS (tools/dbg/seq_stamps.py): the launches of ONE sequence on one clock — block (0, 0)'s entry into launch n of the
+// schedule in g_seq_stamps[n], its exit in g_seq_stamps[32 + n] (gn_fca_fused only)
+#ifdef ELLC_SEQ_STAMPS
+__device__ unsigned long long g_seq_stamps[64];
+#define ELLC_SEQSTAMP(off, seq)                                                                              \
+  do {                                                                                                       \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                                            \
+      unsigned long long t__;                                                                                \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                        \
+      g_seq_stamps[(off) + ((seq) & 31)] = t__;                                                              \
+    }                                                                                                        \
+  } while (0)
+#else
+#define ELLC_SEQSTAMP(off, seq) do { } while (0)
+#endif
 
 // Pointers read out of device-resident tables are "flat" to the compiler (it emits flat_load and 64-bit address
 // arithmetic per lane). Everything this library indexes lives in global memory, so the hot kernels say so.
@@ -1552,6 +1567,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   const bool writer = (sub == 0);
   ELLC_STAMP(0);
   ELLC_BSTAMP(0);
+  ELLC_SEQSTAMP(0, fa.seq);
   // Load order of the prologue (everything below depends on the kernel arguments only, or on the uniform table
   // entries): the scalar chain slot -> table entry -> count is started first, the pending partial sums are read
   // unconditionally next (prev_nblk is 0 on the first launch of a schedule) so that they share one memory round trip
@@ -1625,6 +1641,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_fused(const AlignSt
   block_reduce_store<27>(sums, out);
   ELLC_STAMP(8);
   ELLC_BSTAMP(3);
+  ELLC_SEQSTAMP(32, fa.seq);
 }
 
 // ---------------------------------------------------------------------------------------------------
