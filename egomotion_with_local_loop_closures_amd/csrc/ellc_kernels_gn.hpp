@@ -1346,7 +1346,7 @@ __device__ __forceinline__ void solve_finish_fast(SolveShared& sh, int mode, int
     const int l9 = min(lane, 8);
     const int r3 = l9 / 3, k3 = l9 - 3 * r3;
     double Rrk, Vv;
-    exp_se3_entry(x[0], x[1], x[2], x[3], x[4], x[5], r3, k3, Rrk, Vv);
+    exp_se3_entry<true>(x[0], x[1], x[2], x[3], x[4], x[5], r3, k3, Rrk, Vv);
     const double trow = (Vv + __shfl_down(Vv, 1)) + __shfl_down(Vv, 2);   // t[r] in lanes 0, 3, 6
     const float Df = (float)Rrk, Dt = (float)trow;
     const int e = min(lane, 11), r = e >> 2, c = e & 3;

@@ -35,13 +35,29 @@ ELLC_HD void sinc_family(double q, double& s1, double& s2, double& s3) {
   }
 }
 
+// The same three functions for the per-iteration update of the tolerance mode (solve_finish_fast), whose result is rounded to f32:
+// the series cut after q^3 (the next term is < 3e-14 for q < 0.01, seven orders below an f32 ulp) with reciprocal constants — a
+// dependent chain of 6 f64 multiply-adds per function where the full form has 10 and an f64 division (r05: the solve prologue is on
+// the critical path of every launch of a schedule).
+ELLC_HD void sinc_family_short(double q, double& s1, double& s2, double& s3) {
+  if (q < 1e-2) {
+    s1 = 1.0 - q * (1.0 / 6.0) * (1.0 - q * (1.0 / 20.0) * (1.0 - q * (1.0 / 42.0)));
+    s2 = 0.5 * (1.0 - q * (1.0 / 12.0) * (1.0 - q * (1.0 / 30.0) * (1.0 - q * (1.0 / 56.0))));
+    s3 = (1.0 / 6.0) * (1.0 - q * (1.0 / 20.0) * (1.0 - q * (1.0 / 42.0) * (1.0 - q * (1.0 / 72.0))));
+  } else {
+    sinc_family(q, s1, s2, s3);
+  }
+}
+
 // One entry of exp: R[r][k] and the product V[r][k] * v[k] (so that t[r] = (p_r0 + p_r1) + p_r2), written so that each
 // value is produced by exactly the operations exp_se3 uses for it — the solve kernel spreads the nine entries over
 // nine lanes (r = lane / 3, k = lane % 3) instead of evaluating all of them on one.
+template <bool SHORT = false>
 ELLC_HD void exp_se3_entry(double a, double b, double c, double vx, double vy, double vz, int r, int k, double& Rrk, double& Vv) {
   const double q = a * a + b * b + c * c;
   double s1, s2, s3;
-  sinc_family(q, s1, s2, s3);
+  if (SHORT) sinc_family_short(q, s1, s2, s3);
+  else sinc_family(q, s1, s2, s3);
   const double wr = (r == 0) ? a : ((r == 1) ? b : c);
   const double wk = (k == 0) ? a : ((k == 1) ? b : c);
   const bool diag = (r == k);

@@ -39,6 +39,7 @@ for r in range(10):
     acc += d
     n += 1
 print("level %d, B=%d: launch avg %.2f us (HIP events)" % (a.level, B, ms * 1e3))
+print("  block (0,0), us since its start: " + ", ".join("%s %.2f" % (names[i], acc[i] / n) for i in range(1, 9)))
 nb = 1024 if a.level == 0 else 256
 bs = (C.c_ulonglong * (4 * nb))()
 _lib.lib().ellc_debug_block_stamps(ctx.h, bs, nb)
