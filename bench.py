@@ -689,8 +689,10 @@ def tracked_frame(api, synth, a, dev_index, with_lc=False):
     arith = api.ARITH_FAST if a.arith == "fast" else api.ARITH_EXACT
     n_cand = 8
 
-    def loop(lc_mode, fused=False):   # lc_mode: None | "thread" | "inline"
+    def loop(lc_mode, fused=False, persist=1):   # lc_mode: None | "thread" | "inline"
         ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=2, max_frames=2, device=dev_index, arith=arith))
+        if persist != 1:
+            ctx.set_persistent_schedule(persist)   # 0: one launch per Gauss-Newton iteration (the schedule up to r04), for the A/B beside the default
         ctx.keyframe_upload(0, pair["kf_image"]); ctx.keyframe_set_depth(0, pair["depth0"], pair["var0"])
         st = synth.make_depth_state(W, H, 9, pair["kf_image"], pair["idepth_true"])
         ctx.depth_set_keyframe(0); ctx.depth_set_state(st)
@@ -750,11 +752,15 @@ def tracked_frame(api, synth, a, dev_index, with_lc=False):
     if not with_lc:
         d, its, _ = loop(None, fused=False)
         df, _, _ = loop(None, fused=True)
+        dl, _, _ = loop(None, fused=False, persist=0)
         return {"workload": "C1 loop: upload + pyramid, one FCA alignment (early exit on, saved weights), observe + fill holes + regularise + export, "
                             "640x480, 4 levels, arith %s, five calls per frame with the pose through the host (what ellc_main does); "
                             "ms_per_frame_fused_call: the same through ONE ellc_track_frame call per frame (the depth stages enqueued behind the "
-                            "alignment, matrices built on the device; same bits)" % a.arith,
-                "ms_per_frame": 1e3 * d, "frames_per_s": 1.0 / d, "mean_gn_iterations_per_frame": its, "ms_per_frame_fused_call": 1e3 * df}
+                            "alignment, matrices built on the device; same bits); ms_per_frame_launch_per_iteration: the five calls with the "
+                            "alignment's schedule as one launch per Gauss-Newton iteration (ellc_ctx_set_persistent_schedule(0), the schedule up to "
+                            "round 4; same bits) instead of one resident launch" % a.arith,
+                "ms_per_frame": 1e3 * d, "frames_per_s": 1.0 / d, "mean_gn_iterations_per_frame": its, "ms_per_frame_fused_call": 1e3 * df,
+                "ms_per_frame_launch_per_iteration": 1e3 * dl}
     dt_, its, nb = loop("thread")
     di_, _, _ = loop("inline")
     return {"workload": "the C1 loop with the loop-closure batch of every 8th frame (%d candidates, ICA, a context of its own): on a host thread beside "

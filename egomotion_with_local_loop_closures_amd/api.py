@@ -78,6 +78,11 @@ class Context:
         """cfg.grid_batch for the calls that follow (ellc_ctx_set_grid_batch)."""
         self._ck(self._l.ellc_ctx_set_grid_batch(self.h, int(n)), "ellc_ctx_set_grid_batch")
 
+    def set_persistent_schedule(self, mode):
+        """1: the state-driven schedule as one resident launch (default); 0: one launch per iteration; 2: test hook, every resident
+        launch is abandoned at its first hand-over (ellc_ctx_set_persistent_schedule)."""
+        self._ck(self._l.ellc_ctx_set_persistent_schedule(self.h, int(mode)), "ellc_ctx_set_persistent_schedule")
+
     def level_shape(self, level):
         return (self.cfg.height >> level, self.cfg.width >> level)
 

@@ -91,6 +91,7 @@ struct ellc_ctx {
     int* stage_d = nullptr;                         // device copy of the staging record
     ellc::AlignState* state_d = nullptr;            // two launch-parity buffers
     float* partials_d = nullptr;
+    unsigned* persist_bar_d = nullptr;              // gn_fca_persist's abort words (two alignments; zero between calls)
     // the group staged / in flight in this set
     int fill = 0;                                   // batches staged side by side: batch j = alignments [j * max_batch, ...)
     int fetched = 0;                                // of which fetched (the set is free again when fetched == fill)
@@ -125,6 +126,10 @@ struct ellc_ctx {
   int n_inflight = 0;
   int cur_set = 0;                                  // the batch set the per-batch pointers below refer to (select_batch_set)
   float* partials_d = nullptr;
+  unsigned* persist_bar_d = nullptr;
+  unsigned persist_spin_limit = 1u << 21;           // polls of a missing record before gn_fca_persist gives a launch up (0: at once — test hook)
+  unsigned persist_epoch = 0;                       // calls of gn_fca_persist so far (tags of its partial records)
+  bool use_persist = true;                          // the state-driven schedule as one resident launch (gn_fca_persist)
   float* planes_d = nullptr;
   float *scratch_a = nullptr, *scratch_b = nullptr;   // W*H f32 each
   int tile_begin[ELLC_MAX_LEVELS + 1];

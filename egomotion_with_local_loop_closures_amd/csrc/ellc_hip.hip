@@ -391,6 +391,7 @@ static void select_batch_set(ellc_ctx* c, int p, int slice = 0) {
   c->init_pose_d = (float*)(bs.stage_d + 3 * cap);
   c->state_d = bs.state_d;
   c->partials_d = bs.partials_d;
+  c->persist_bar_d = bs.persist_bar_d;
 }
 
 // stage slots / initial poses on the device and list the unique keyframe slots
@@ -538,6 +539,7 @@ static int schedule_total_iters(const ellc_ctx* c) {
 // — or, once the context has run such a call, what the previous one needed plus two (adaptive_hint: consecutive frames of a
 // tracked sequence need about the same; r03: 20 launches of which a tracked frame used 15, the other five still cost 4.8 us each)
 static int adaptive_first_launches(const ellc_ctx* c, int B) {
+  if (c->use_persist && B <= 2) return 0;   // one resident launch runs the whole schedule; a continuation (only after an abandoned launch) holds all of it
   const int total = schedule_total_iters(c);
   int first = c->adaptive_hint > 0 ? c->adaptive_hint : (total * 5 + 7) / 8;
 #ifdef ELLC_DIAG
@@ -558,7 +560,54 @@ static void set_track_fields(const ellc_ctx* c, FusedArgs& fa, bool continuation
 
 // State-driven FCA schedule: `launches` launches of gn_fca_adaptive and the finish kernel. continuation: the records were
 // left by an earlier graph of the same batch (buffer 0, nothing pending), otherwise by stage_in.
+// The state-driven schedule as one resident launch (gn_fca_persist). Blocks per alignment and level are the launch-per-iteration
+// schedule's own (the grid is the largest of them, ELLC_NBLK_MAX at most), so the sums are grouped and combined exactly as there:
+// the two forms, and a schedule that starts in one and is finished in the other, give the same bits. (Measured with the counts
+// capped at 32 / 64 / 128 / 256 blocks, one early-exit alignment 640x480, fast: 0.120 / 0.116 / 0.115 / 0.117 ms against 0.128 with
+// launches; exact 0.171 / 0.161 / 0.156 / 0.158 against 0.164; tracked frame 0.208 / 0.192 / 0.188 / 0.190 against 0.205.)
+static ellc_status enqueue_schedule_persist(ellc_ctx* c, int B, int save_weights) {
+  FusedArgs fa;
+  fa.continuation = 0;
+  set_track_fields(c, fa, false);
+  fa.seq = 0;
+  fa.prev_level = -1;
+  fa.prev_nblk = 0;
+  fa.early_exit = c->cfg.early_exit;
+  fa.stride_state = c->group_cap;
+  fa.stride_part = (size_t)c->group_cap * ELLC_NBLK_MAX * ELLC_PART_STRIDE;
+  fa.g = make_gn_args(c, 0, B, save_weights ? 1 : 0, nullptr);
+  fa.res = c->result_dev_alias;
+  fa.ica = 0;
+  fa.xcd_map = 0;
+  fa.age_rounds = 0;
+  for (int i = 0; i < 5; i++) fa.age_cum[i] = 0;
+  int G = 1;
+  for (int l = 0; l < ELLC_MAX_LEVELS; l++) {
+    fa.nblk_lv[l] = l < c->L ? choose_nblk(c, l, grid_batch(c, B)) : 1;
+    fa.max_it[l] = l < c->L ? c->cfg.max_iter[l] : 0;
+    G = std::max(G, fa.nblk_lv[l]);
+  }
+  fa.nblk_grid = G;
+  fa.persist_bar = c->persist_bar_d;
+  const int max_rounds = schedule_total_iters(c) + c->L + 2;
+  const unsigned epoch = (++c->persist_epoch) & 0xffffffu;   // the records of earlier calls never match (the round sits in the low byte)
+  const dim3 grd(G, B), blk(ELLC_GN_THREADS);
+  if (c->fast) {
+    if (save_weights) hipLaunchKernelGGL((gn_fca_persist<false, true, 1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit);
+    else hipLaunchKernelGGL((gn_fca_persist<false, true, 0>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit);
+  } else if (c->geom_h[0].divc_ok) {
+    hipLaunchKernelGGL((gn_fca_persist<true, false, -1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit);
+  } else {
+    hipLaunchKernelGGL((gn_fca_persist<false, false, -1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit);
+  }
+  launch_finish(c, B, fa, true);   // (fa.seq = 0: the record the launch left in buffer 0, nothing pending)
+  if (save_weights) launch_add_saved_weights(c, B);
+  ELLC_HIP(c, hipGetLastError());
+  return ELLC_OK;
+}
+
 static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weights, int launches, bool continuation = false) {
+  if (!continuation && c->use_persist && B <= 2) return enqueue_schedule_persist(c, B, save_weights);
   FusedArgs fa;
   fa.continuation = continuation ? 1 : 0;
   set_track_fields(c, fa, continuation);
@@ -889,6 +938,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     TRY(host_alloc(c, &bs.result_h, CAP));
     TRY(dev_alloc(c, &bs.state_d, 2 * CAP));
     TRY(dev_alloc(c, &bs.partials_d, 2 * CAP * ELLC_NBLK_MAX * ELLC_PART_STRIDE));
+    TRY(dev_alloc(c, &bs.persist_bar_d, 2 * ELLC_PERSIST_BAR_WORDS));   // gn_fca_persist's abort words (device memory comes zeroed)
     void *da = nullptr, *db = nullptr;
     if (hipHostGetDevicePointer(&da, bs.stage_h, 0) != hipSuccess || hipHostGetDevicePointer(&db, bs.result_h, 0) != hipSuccess ||
         hipEventCreateWithFlags(&bs.done, hipEventDisableTiming) != hipSuccess) {
@@ -955,6 +1005,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     if (const char* pp = getenv("ELLC_PIPE")) c->pipe = (pp[0] == '1');
     if (const char* am = getenv("ELLC_AGE_MIN_PX")) c->age_min_px_per_thread = atof(am);
     if (getenv("ELLC_NO_ADAPTIVE")) c->use_adaptive = false;
+    if (getenv("ELLC_NO_PERSIST")) c->use_persist = false;
     if (const char* ab = getenv("ELLC_ADAPTIVE_MAX_BATCH")) c->adaptive_max_batch = atoi(ab);
     if (const char* af = getenv("ELLC_ADAPTIVE_FIRST")) c->adaptive_first_override = atoi(af);
     if (const char* aw = getenv("ELLC_AGE_W")) {   // "R:w0,w1,..": weights for grids of R rounds
@@ -1036,6 +1087,16 @@ ellc_status ellc_ctx_set_poll_timeout_us(ellc_ctx* c, int us) {
 }
 
 // ---- frame side ----------------------------------------------------------------------------------
+ellc_status ellc_ctx_set_persistent_schedule(ellc_ctx* c, int mode) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  ELLC_ENTER(c);
+  if (mode < 0 || mode > 2) return fail(c, ELLC_ERR_BAD_ARG, "ellc_ctx_set_persistent_schedule: mode 0, 1 or 2");
+  c->use_persist = mode != 0;
+  c->persist_spin_limit = mode == 2 ? 0u : ELLC_PERSIST_SPIN_LIMIT;
+  c->adaptive_hint = 0;
+  return ELLC_OK;
+}
+
 ellc_status ellc_ctx_set_grid_batch(ellc_ctx* c, int n) {
   ELLC_ENTER_BATCH(c);
   if (!c || n < 0 || n > 65536) return fail(c, ELLC_ERR_BAD_ARG, "bad argument");

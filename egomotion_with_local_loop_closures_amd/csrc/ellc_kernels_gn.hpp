@@ -1453,6 +1453,8 @@ struct FusedArgs {
   struct ObsMats* track_mats;
   int* track_gate;
   float track_K[9];
+  unsigned* persist_bar = nullptr;   // gn_fca_persist's abort words of this batch set (ELLC_PERSIST_BAR_WORDS per alignment): the finish kernel
+                           // clears them for the next call; null: the schedule was launched kernel by kernel
   int continuation;     // 1: this graph continues a state-driven schedule whose first graph has already run (and added the saved weights
                         // of the alignments that ended there): its first launch marks those records cur_level = -2
 };
@@ -1918,6 +1920,227 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The state-driven schedule as ONE launch (r05): the tracking call's alignment is ~15 dependent iterations of 1-3 us of work each,
+// and as launches every one of them pays the kernel boundary and a first memory round trip into caches the boundary emptied
+// (tools/dbg/seq_stamps.py, tools/stamps.py). Here G blocks per alignment stay resident for the whole schedule; an iteration is
+// gn_fca_adaptive's body — combine the pending partial sums, solve, decide the level, pixel pass over the block's chunk, 27 sums
+// per block. There is NO barrier: the only thing that crosses blocks is the partial records, and a record carries the round it
+// belongs to. A block stores its record as ONE 128-byte line — 27 sums and, in the last word of each of the line's four 32-byte
+// sectors, the tag (call epoch << 8 | round) — with agent-scope write-through stores from 32 consecutive lanes; a reader loads
+// whole records with agent-scope loads (past its XCD's L2: the XCDs' L2s are not coherent with each other, and an agent-scope
+// FENCE would write the L2 back — tools/micro/grid_barrier.hip) and takes a record when all four tags say the round it waits
+// for, else asks again. Two memory hops per iteration (store becomes visible, load returns) where a counter barrier needs four
+// (stores acknowledged, arrival, poll, loads): 0.131 -> 0.122 ms per early-exit alignment with the barrier form, -> 0.114-0.118 with
+// this one. The two record buffers alternate by round: a block writes round r + 2 into the buffer of round r only after it has
+// read every record of round r + 1, which exist only once every block has read round r. The alignment's state record is not
+// shared at all: every block keeps its own copy in LDS and advances it by the same solve on the same sums, so all blocks take
+// the same level changes and leave the loop in the same iteration; block 0 writes the final record for gn_fused_finish, which
+// finds nothing pending. A wave that has asked ELLC_PERSIST_SPIN_LIMIT times for a record that does not come (a launch whose blocks
+// are not all resident: the device shared with more such launches than it holds) raises the abort word: every block leaves, the
+// record says "not ended, nothing pending", and the host finishes the schedule with ordinary launches (the continuation of the
+// state-driven schedule). Block counts per level, chunks and the order of the combine are the launch-per-iteration schedule's
+// (gn_fca_adaptive): the same bits, also for a schedule that is abandoned here and finished there. Three blocks per CU in
+// the tolerance mode, two in the exact mode (launch bounds; the exact pixel loop inside this loop wants 226 registers and spills
+// cost it more than the launches it saves): 768 / 512 resident blocks hold three / two such launches of one alignment each.
+#define ELLC_PERSIST_BAR_WORDS 32   // per alignment: the abort word in a 128-byte line of its own
+#define ELLC_PERSIST_SPIN_LIMIT (1u << 21)
+// word of a tagged record that holds sum s (the last word of every 32-byte sector is the tag)
+__device__ __forceinline__ int persist_word_of(int s) { return s + s / 7; }
+// block reduction of the 27 per-thread sums (as block_reduce_store) and the block's tagged record, stored by lanes 0..31 of wave 0
+__device__ __forceinline__ void persist_store_record(float (&acc)[27], unsigned* out, unsigned tag) {
+  __shared__ float red[ELLC_GN_THREADS / 64][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float rows[WaveRows<27>::N2];
+  wave_sum_rows<27>(acc, rows);
+  if ((lane & 15) == 0) {
+    const int q = lane >> 4, col = 2 * (q & 1) + (q >> 1);
+#pragma unroll
+    for (int j = 0; j < WaveRows<27>::N2; j++) red[wave][4 * j + col] = rows[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int w = (int)threadIdx.x, sidx = w - (w >> 3);
+    const bool tagl = (w & 7) == 7;
+    float v = 0.0f;
+    if (!tagl && sidx < 27) {
+      v = red[0][sidx];
+#pragma unroll
+      for (int k = 1; k < ELLC_GN_THREADS / 64; k++) v += red[k][sidx];
+    }
+    __hip_atomic_store(out + w, tagl ? tag : __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// partial_group_sum over tagged records of the round `tag` names: the same fixed-order combine, every record taken only once
+// its four tags match. Returns false when the launch is being abandoned.
+__device__ __forceinline__ bool persist_group_sum(const unsigned* recs, int nblk, unsigned tag, unsigned* abortw, unsigned spin_limit, double& out) {
+  const int lane = threadIdx.x & 63, comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const bool is_tag = (comp & 7) == 7;
+  const unsigned long long half = (lane < 32) ? 0x00000000ffffffffull : 0xffffffff00000000ull;
+  const int src_lane = (lane & 32) | (comp < 27 ? persist_word_of(comp) : 31);
+  double s = 0.0;
+  unsigned spins = 0;
+  if (spin_limit == 0u) {   // test hook (ellc_debug_persist_spin_limit): abandon at the first record
+    if (lane == 0) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out = 0.0;
+    return false;
+  }
+  for (int base = 0; base < nblk; base += 8 * (ELLC_SOLVE_THREADS / 32)) {
+    unsigned w[8];
+    unsigned okm = 0;   // bit j: record j of this thread's half-wave has been taken (or is not needed)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      w[j] = 0u;
+      if (base + grp + j * (ELLC_SOLVE_THREADS / 32) >= nblk) okm |= 1u << j;
+    }
+    for (;;) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {   // every record still missing is asked for again, all requests in flight together
+        const int k = base + grp + j * (ELLC_SOLVE_THREADS / 32);
+        if (!((okm >> j) & 1u)) w[j] = __hip_atomic_load(recs + (size_t)k * ELLC_PART_STRIDE + comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const bool miss = !((okm >> j) & 1u);
+        const unsigned long long badm = __ballot(miss && is_tag && w[j] != tag);
+        if (miss && (badm & half) == 0ull) okm |= 1u << j;
+      }
+      if (__ballot(okm != 0xffu) == 0ull) break;
+      __builtin_amdgcn_s_sleep(1);
+      spins++;
+      if ((spins & 63u) == 0u) {   // (wave-uniform)
+        if (spins > spin_limit && lane == 0) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { out = 0.0; return false; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = base + grp + j * (ELLC_SOLVE_THREADS / 32);
+      const unsigned v = (unsigned)__shfl((int)w[j], src_lane, 64);
+      s += (k < nblk && comp < 27) ? (double)__builtin_bit_cast(float, v) : 0.0;
+    }
+  }
+  out = s;
+  return true;
+}
+
+template <bool DIVC, bool FAST, int SAVEW>
+__global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(FusedArgs fa, int max_rounds, unsigned epoch, unsigned spin_limit) {
+  const GnArgs& a = fa.g;
+  const int b = blockIdx.y, sub = blockIdx.x, t = threadIdx.x;
+  __shared__ SolveShared sh;
+  __shared__ AlignState st;   // this block's copy of the alignment's record (see above)
+  __shared__ int s_flag;
+  unsigned* abortw = fa.persist_bar + (size_t)b * ELLC_PERSIST_BAR_WORDS;
+  AlignState* rec = a.state + b;   // buffer 0: initialised by the staging kernel; the final record for gn_fused_finish
+  {
+    const uint32_t* sp = (const uint32_t*)rec;
+    uint32_t* dp = (uint32_t*)&st;
+    for (int i = t; i < (int)(sizeof(AlignState) / 4); i += ELLC_GN_THREADS) dp[i] = sp[i];
+  }
+  __syncthreads();
+  const bool writer = (sub == 0);
+  const int slot = a.kf_slot[b], frs = a.fr_slot[b];
+  if (t == 0) s_flag = 0;
+  __syncthreads();
+  for (int seq = 0; seq < max_rounds; seq++) {
+    const int lvl = st.cur_level, pending = st.pending, it_in = st.it_in_level;
+    if (lvl < 0) break;
+    const int nb_l = fa.nblk_lv[lvl];
+    LevelGeom g = a.geom[lvl];
+    KfLevelDev K = a.kf_tab[lvl * a.max_kf + slot];
+    const FrLevelDev* F = &a.fr_tab[lvl * a.max_fr + frs];
+    int V = *as_global(K.count);
+    const unsigned* pend = (const unsigned*)(a.partials + (size_t)((seq + 1) & 1) * fa.stride_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE);
+    int begin, end;
+    {
+      const int chunk = (V + nb_l - 1) / nb_l;
+      begin = sub * chunk;
+      end = min(V, begin + chunk);
+    }
+    // this thread's first record of the level the record names, requested before the solve (as gn_fca_adaptive)
+    FcaIn first = fca_in_empty();
+    FcaInF firstf = fcaf_empty();
+    FcaPre first_pre;
+    if constexpr (FAST) {
+      if (sub < nb_l && begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));
+    } else {
+      if (sub < nb_l && begin + t < end) first = fca_load<DIVC>(K, g, (unsigned)(begin + t));
+      first_pre = fca_prepare<DIVC>(g, first);
+    }
+    if (pending) {
+      double group_sum;
+      if (!persist_group_sum(pend, nb_l, (epoch << 8) | (unsigned)seq, abortw, spin_limit, group_sum)) s_flag = 1;   // the records of round seq (the previous iteration's)
+      __syncthreads();
+      if (s_flag) break;   // abandoned (block-uniform); the record still names this iteration's level with its sums unsolved
+      solve_step<FAST>(sh, group_sum, 0, lvl, fa.early_exit, st, writer ? rec : nullptr);
+    } else {
+      if (t < 6) sh.newpose[t] = st.pose[t];
+      if (t < 12) sh.newS[t] = st.S[t];
+      if (t == 0) { sh.weighted = st.weighted; sh.level_done = st.level_done; }
+      __syncthreads();
+    }
+    const int it = it_in + (pending ? 1 : 0);
+    const bool over = pending && (sh.level_done == lvl || it >= fa.max_it[lvl]);   // the level has ended: early exit, or its cap
+    const int nl = over ? lvl - 1 : lvl;
+    // (every read of `st` of this iteration lies in front of the barrier that ends the solve)
+    if (t < 6) st.pose[t] = sh.newpose[t];
+    if (t < 12) st.S[t] = sh.newS[t];
+    if (t == lvl && pending) st.iters[t] += 1;
+    if (t == 0) {
+      st.weighted = sh.weighted;
+      st.level_done = sh.level_done;
+      st.pending = nl >= 0 ? 1 : 0;
+      st.cur_level = nl;
+      st.it_in_level = over ? 0 : it;
+    }
+    if (nl < 0) break;
+    bool work = sub < nb_l;
+    if (over) {   // a level change (at most L - 1 per alignment): tables, chunk and first record of the finer level
+      const int nb_n = fa.nblk_lv[nl];
+      work = sub < nb_n;
+      g = a.geom[nl];
+      K = a.kf_tab[nl * a.max_kf + slot];
+      F = &a.fr_tab[nl * a.max_fr + frs];
+      V = *as_global(K.count);
+      const int chunk = (V + nb_n - 1) / nb_n;
+      begin = sub * chunk;
+      end = min(V, begin + chunk);
+      if (work) {
+        if constexpr (FAST) {
+          if (begin < end) firstf = fcaf_load(K, (unsigned)min(begin + t, end - 1));
+        } else {
+          if (begin + t < end) first = fca_load<DIVC>(K, g, (unsigned)(begin + t));
+          first_pre = fca_prepare<DIVC>(g, first);
+        }
+      }
+    }
+    if (work) {   // block-uniform
+      g_u8 cur = as_global(F->img);
+      float sums[27];
+      fca_chunk_pass<DIVC, true, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
+      unsigned* out = (unsigned*)(a.partials + (size_t)(seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE);
+      persist_store_record(sums, out, (epoch << 8) | (unsigned)(seq + 1));
+    }
+    __syncthreads();   // (`st` is read again at the top)
+  }
+  __syncthreads();
+  if (writer) {   // the fields this kernel maintains (H, b, delta and H^-1 were written by the solves)
+    if (t < 6) rec->pose[t] = st.pose[t];
+    if (t < 12) rec->S[t] = st.S[t];
+    if (t < ELLC_MAX_LEVELS) rec->iters[t] = st.iters[t];
+    if (t == 0) {
+      rec->weighted = st.weighted;
+      rec->level_done = st.level_done;
+      // abandoned (or out of rounds, which max_rounds excludes): the sums of the round that was under way are lost — nothing
+      // pending, the continuation repeats that pixel pass
+      rec->pending = 0;
+      rec->cur_level = st.cur_level;
+      rec->it_in_level = st.it_in_level;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Fused schedule of the constant-weight path (PixelWisePyramid.cpp:687-913 + :941-974): the same launch structure as
 // gn_fca_fused — launch n first solves the sums launch n-1 left behind, then runs its own pixel pass — with the light
 // ICA pixel pass: warp, one u8 tap, residual, b += SD (r w). H^-1 of the level was computed once per keyframe by the
@@ -2136,6 +2359,7 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
       *(volatile int*)&r->pad = ended ? 0 : 1;
     }
   }
+  if (fa.persist_bar && t == 0) fa.persist_bar[(size_t)b * ELLC_PERSIST_BAR_WORDS] = 0u;   // gn_fca_persist's abort word, for the next call
   if (fa.track_mats && b == 0 && t < 64) {   // (sh.newpose is final: every path above ends in a block barrier before the stores)
     float p[6];
 #pragma unroll

@@ -119,6 +119,31 @@ def test_early_exit_schedule_is_state_driven_and_continues(oracle, ellc, arith):
     assert np.array_equal(p0[1], pose[3]) and w0[1] == wgt[3]
 
 
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_resident_schedule_equals_the_launches_and_survives_being_abandoned(ellc, arith):
+    """ellc_ctx_set_persistent_schedule (ABI v9): the state-driven schedule as ONE resident launch (mode 1, the default), as one
+    launch per iteration (mode 0), and with every resident launch abandoned at its first hand-over so that ordinary launches finish
+    the schedule (mode 2: what a device that cannot hold all the blocks falls back to) — the same poses, iteration counts and
+    weightedPose bit for bit, alone and in a batch of two, with and without saved weights; and the weights are saved exactly once."""
+    cases = [(21, 0.02, 0.05), (22, 0.03, 0.08), (25, 0.05, 0.15)]
+    pairs = [synth.make_pair(W, H, seed=s, rot=r, trans=t) for s, r, t in cases]
+    kw = dict(arith=ellc.ARITH_FAST) if arith == "fast" else {}
+    got = {}
+    for mode in (1, 0, 2):
+        ctx = gpu_problem(ellc, W, H, L, pairs, early_exit=1, **kw)
+        ctx.set_persistent_schedule(mode)
+        out = [ctx.align([0, 1], [0, 1]), ctx.align([2], [2]), ctx.align([1], [1], save_weights=True), ctx.align([0], [0])]
+        planes = [ctx.keyframe_weights(1, l) for l in range(L)]
+        got[mode] = (out, planes)
+        ctx.close()
+    for mode in (0, 2):
+        for a, b in zip(got[1][0], got[mode][0]):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), mode
+        for (wa, na), (wb, nb) in zip(got[1][1], got[mode][1]):
+            assert na == nb == 1 and np.array_equal(wa, wb), mode
+    assert int(np.sum(got[1][0][1][1])) == 32          # the third scene reaches every cap: the longest resident launch
+
+
 def test_ica_constant_weight_path(problem, oracle):
     """Loop-closure mode: template-gradient Jacobian, saved weights, H once per level (A9-A11)."""
     rng = np.random.default_rng(3)
