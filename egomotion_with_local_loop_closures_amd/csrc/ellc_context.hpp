@@ -105,6 +105,7 @@ struct ellc_ctx {
     bool joined = true;                             // the main stream already waits for `done`
     int mode = 0, save_weights = 0;
     bool adaptive = false;                          // the group (one batch) runs the state-driven schedule (gn_fca_adaptive)
+    bool resident = false;                          //   as one resident launch (gn_fca_persist)
     int adaptive_first = 0;                         //   whose first graph holds this many launches
     bool pollable = false;                          // its finish kernel ordered its result records for a polling host (FusedArgs::host_polls)
     bool resolved = true;                           // `done` has been waited for and the continuation, if one was needed, has run
@@ -127,8 +128,9 @@ struct ellc_ctx {
   int cur_set = 0;                                  // the batch set the per-batch pointers below refer to (select_batch_set)
   float* partials_d = nullptr;
   unsigned* persist_bar_d = nullptr;
-  unsigned persist_spin_limit = 1u << 21;           // polls of a missing record before gn_fca_persist gives a launch up (0: at once — test hook)
+  unsigned persist_spin_limit = 1u << 15;           // polls of a missing record before gn_fca_persist gives a launch up (0: at once — test hook)
   unsigned persist_epoch = 0;                       // calls of gn_fca_persist so far (tags of its partial records)
+  bool cur_resident = false;                        // the schedule being enqueued is the resident form
   bool use_persist = true;                          // the state-driven schedule as one resident launch (gn_fca_persist)
   float* planes_d = nullptr;
   float *scratch_a = nullptr, *scratch_b = nullptr;   // W*H f32 each

@@ -539,7 +539,7 @@ static int schedule_total_iters(const ellc_ctx* c) {
 // — or, once the context has run such a call, what the previous one needed plus two (adaptive_hint: consecutive frames of a
 // tracked sequence need about the same; r03: 20 launches of which a tracked frame used 15, the other five still cost 4.8 us each)
 static int adaptive_first_launches(const ellc_ctx* c, int B) {
-  if (c->use_persist && B <= 2) return 0;   // one resident launch runs the whole schedule; a continuation (only after an abandoned launch) holds all of it
+  if (c->cur_resident) return 0;   // one resident launch runs the whole schedule; a continuation (only after an abandoned launch) holds all of it
   const int total = schedule_total_iters(c);
   int first = c->adaptive_hint > 0 ? c->adaptive_hint : (total * 5 + 7) / 8;
 #ifdef ELLC_DIAG
@@ -600,14 +600,14 @@ static ellc_status enqueue_schedule_persist(ellc_ctx* c, int B, int save_weights
   } else {
     hipLaunchKernelGGL((gn_fca_persist<false, false, -1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit);
   }
-  launch_finish(c, B, fa, true);   // (fa.seq = 0: the record the launch left in buffer 0, nothing pending)
+  // (no finish kernel: the launch's first block per alignment has written the final record, the result and the tracking fields)
   if (save_weights) launch_add_saved_weights(c, B);
   ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
 }
 
 static ellc_status enqueue_schedule_adaptive(ellc_ctx* c, int B, int save_weights, int launches, bool continuation = false) {
-  if (!continuation && c->use_persist && B <= 2) return enqueue_schedule_persist(c, B, save_weights);
+  if (!continuation && c->cur_resident) return enqueue_schedule_persist(c, B, save_weights);
   FusedArgs fa;
   fa.continuation = continuation ? 1 : 0;
   set_track_fields(c, fa, continuation);
@@ -1563,6 +1563,7 @@ static ellc_status resolve_batch(ellc_ctx* c, int set) {
   const int selected = c->cur_set;
   select_batch_set(c, set);
   c->cur_adaptive_first = bs.adaptive_first;
+  c->cur_resident = false;   // (a continuation is launches)
   ellc_status s = ELLC_OK;
   {
     StreamScope scope(c, c->batch_stream[bs.stream_idx]);
@@ -1655,6 +1656,21 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
     }
     ELLC_HIP(c, hipStreamWaitEvent(run_stream, other.done, 0));
   }
+  // The state-driven schedule runs as ONE resident launch (gn_fca_persist) when the call finds the context's pipeline empty — the
+  // tracking call, whose latency it shortens — and as one launch per iteration when other groups are in flight: a resident launch
+  // wants all its blocks on the device at once, the dispatcher interleaves the blocks of launches on different streams, and two
+  // resident launches that each hold part of the device wait for each other until one gives up (r05 soak, three batches of two in
+  // flight, exact mode: one abandoned launch in 2 000; ordered one behind the other instead they lose the overlap of the three
+  // streams: 0.189 against 0.102 ms per batch). Same bits either way. Launches of other contexts or processes are not known here:
+  // against those the abandoned launch and its continuation are the safety net.
+  c->cur_resident = false;
+  if (c->use_persist && B <= 2 && schedule_is_adaptive(c, bs.mode, B)) {
+    bool alone = true;
+    for (int p = 0; p < ellc_ctx::SETS; p++)
+      if (p != set && c->batch_set[p].launched && !c->batch_set[p].resolved) alone = false;
+    c->cur_resident = alone;
+  }
+  bs.resident = c->cur_resident;
   c->cur_adaptive_first = adaptive_first_launches(c, B);
   bs.adaptive_first = c->cur_adaptive_first;
   {
@@ -1713,6 +1729,7 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
     ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
     if (s != ELLC_OK) return s;
     for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);   // rebuilt here, outside the cache's bookkeeping
+    c->cur_resident = c->use_persist && B <= 2 && schedule_is_adaptive(c, mode, B);   // (nothing in flight)
     c->cur_adaptive_first = adaptive_first_launches(c, B);
     bool dense = runs_dense(c, mode, B, save_weights);
     for (int b = 0; b < B; b++) dense = dense && c->kf_dense[kf_slots[b]];

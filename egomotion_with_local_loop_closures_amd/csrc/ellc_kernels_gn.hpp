@@ -1453,8 +1453,7 @@ struct FusedArgs {
   struct ObsMats* track_mats;
   int* track_gate;
   float track_K[9];
-  unsigned* persist_bar = nullptr;   // gn_fca_persist's abort words of this batch set (ELLC_PERSIST_BAR_WORDS per alignment): the finish kernel
-                           // clears them for the next call; null: the schedule was launched kernel by kernel
+  unsigned* persist_bar = nullptr;   // gn_fca_persist's abort words of this batch set (ELLC_PERSIST_BAR_WORDS per alignment)
   int continuation;     // 1: this graph continues a state-driven schedule whose first graph has already run (and added the saved weights
                         // of the alignments that ended there): its first launch marks those records cur_level = -2
 };
@@ -1934,16 +1933,17 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
 // this one. The two record buffers alternate by round: a block writes round r + 2 into the buffer of round r only after it has
 // read every record of round r + 1, which exist only once every block has read round r. The alignment's state record is not
 // shared at all: every block keeps its own copy in LDS and advances it by the same solve on the same sums, so all blocks take
-// the same level changes and leave the loop in the same iteration; block 0 writes the final record for gn_fused_finish, which
-// finds nothing pending. A wave that has asked ELLC_PERSIST_SPIN_LIMIT times for a record that does not come (a launch whose blocks
-// are not all resident: the device shared with more such launches than it holds) raises the abort word: every block leaves, the
+// the same level changes and leave the loop in the same iteration; block 0 then does what gn_fused_finish does (the final
+// record, the result for the host, the observation's matrices and the depth stages' gate): no second launch. A wave that has asked ELLC_PERSIST_SPIN_LIMIT times for a record that does not come (a launch whose blocks
+// are not all resident: the device shared with more such launches than it holds) raises the abort word (it names the call: nothing
+// has to clear it): every block leaves, the
 // record says "not ended, nothing pending", and the host finishes the schedule with ordinary launches (the continuation of the
 // state-driven schedule). Block counts per level, chunks and the order of the combine are the launch-per-iteration schedule's
 // (gn_fca_adaptive): the same bits, also for a schedule that is abandoned here and finished there. Three blocks per CU in
 // the tolerance mode, two in the exact mode (launch bounds; the exact pixel loop inside this loop wants 226 registers and spills
 // cost it more than the launches it saves): 768 / 512 resident blocks hold three / two such launches of one alignment each.
 #define ELLC_PERSIST_BAR_WORDS 32   // per alignment: the abort word in a 128-byte line of its own
-#define ELLC_PERSIST_SPIN_LIMIT (1u << 21)
+#define ELLC_PERSIST_SPIN_LIMIT (1u << 15)   // polls (~1 us each with their s_sleep): a record normally arrives within tens
 // word of a tagged record that holds sum s (the last word of every 32-byte sector is the tag)
 __device__ __forceinline__ int persist_word_of(int s) { return s + s / 7; }
 // block reduction of the 27 per-thread sums (as block_reduce_store) and the block's tagged record, stored by lanes 0..31 of wave 0
@@ -1972,7 +1972,7 @@ __device__ __forceinline__ void persist_store_record(float (&acc)[27], unsigned*
 }
 // partial_group_sum over tagged records of the round `tag` names: the same fixed-order combine, every record taken only once
 // its four tags match. Returns false when the launch is being abandoned.
-__device__ __forceinline__ bool persist_group_sum(const unsigned* recs, int nblk, unsigned tag, unsigned* abortw, unsigned spin_limit, double& out) {
+__device__ __forceinline__ bool persist_group_sum(const unsigned* recs, int nblk, unsigned tag, unsigned* abortw, unsigned abort_tag, unsigned spin_limit, double& out) {
   const int lane = threadIdx.x & 63, comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const bool is_tag = (comp & 7) == 7;
   const unsigned long long half = (lane < 32) ? 0x00000000ffffffffull : 0xffffffff00000000ull;
@@ -1980,7 +1980,7 @@ __device__ __forceinline__ bool persist_group_sum(const unsigned* recs, int nblk
   double s = 0.0;
   unsigned spins = 0;
   if (spin_limit == 0u) {   // test hook (ellc_debug_persist_spin_limit): abandon at the first record
-    if (lane == 0) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(abortw, abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out = 0.0;
     return false;
   }
@@ -2008,8 +2008,8 @@ __device__ __forceinline__ bool persist_group_sum(const unsigned* recs, int nblk
       __builtin_amdgcn_s_sleep(1);
       spins++;
       if ((spins & 63u) == 0u) {   // (wave-uniform)
-        if (spins > spin_limit && lane == 0) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { out = 0.0; return false; }
+        if (spins > spin_limit && lane == 0) __hip_atomic_store(abortw, abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == abort_tag) { out = 0.0; return false; }
       }
     }
 #pragma unroll
@@ -2022,6 +2022,9 @@ __device__ __forceinline__ bool persist_group_sum(const unsigned* recs, int nblk
   out = s;
   return true;
 }
+
+template <bool FAST, bool ADAPT>
+__device__ __forceinline__ void fused_finish_body(const FusedArgs& fa, int b, const AlignState& src, AlignState* dst, SolveShared& sh);
 
 template <bool DIVC, bool FAST, int SAVEW>
 __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(FusedArgs fa, int max_rounds, unsigned epoch, unsigned spin_limit) {
@@ -2069,7 +2072,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(
     }
     if (pending) {
       double group_sum;
-      if (!persist_group_sum(pend, nb_l, (epoch << 8) | (unsigned)seq, abortw, spin_limit, group_sum)) s_flag = 1;   // the records of round seq (the previous iteration's)
+      if (!persist_group_sum(pend, nb_l, (epoch << 8) | (unsigned)seq, abortw, epoch | 0x80000000u, spin_limit, group_sum)) s_flag = 1;   // the records of round seq (the previous iteration's)
       __syncthreads();
       if (s_flag) break;   // abandoned (block-uniform); the record still names this iteration's level with its sums unsolved
       solve_step<FAST>(sh, group_sum, 0, lvl, fa.early_exit, st, writer ? rec : nullptr);
@@ -2124,19 +2127,12 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(
     __syncthreads();   // (`st` is read again at the top)
   }
   __syncthreads();
-  if (writer) {   // the fields this kernel maintains (H, b, delta and H^-1 were written by the solves)
-    if (t < 6) rec->pose[t] = st.pose[t];
-    if (t < 12) rec->S[t] = st.S[t];
-    if (t < ELLC_MAX_LEVELS) rec->iters[t] = st.iters[t];
-    if (t == 0) {
-      rec->weighted = st.weighted;
-      rec->level_done = st.level_done;
-      // abandoned (or out of rounds, which max_rounds excludes): the sums of the round that was under way are lost — nothing
-      // pending, the continuation repeats that pixel pass
-      rec->pending = 0;
-      rec->cur_level = st.cur_level;
-      rec->it_in_level = st.it_in_level;
-    }
+  if (writer) {   // block-uniform: what gn_fused_finish does behind the launch-per-iteration schedule, on this block's copy of the record
+    // abandoned (or out of rounds, which max_rounds excludes): the sums of the round that was under way are lost — nothing
+    // pending, the continuation repeats that pixel pass
+    if (t == 0) st.pending = 0;
+    __syncthreads();
+    fused_finish_body<FAST, true>(fa, b, st, rec, sh);
   }
 }
 
@@ -2288,14 +2284,11 @@ __global__ __launch_bounds__(ELLC_GN_THREADS) void gn_ica_fused(const AlignState
   block_reduce_store<6>(acc, out + 21);   // the b slots of the partial record; the H slots are not read by a mode-2 solve
 }
 
-// Final solve of a fused schedule: consumes the last pending partials; result always lands in state buffer 0.
-template <bool FAST, bool ADAPT = false>
-__global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs fa) {
+// Final solve of a fused schedule: consumes the last pending partials; result always lands in state buffer 0. (The body of
+// gn_fused_finish; gn_fca_persist's first block runs it itself at the end of its launch, on its own copy of the record.)
+template <bool FAST, bool ADAPT>
+__device__ __forceinline__ void fused_finish_body(const FusedArgs& fa, int b, const AlignState& src, AlignState* dst, SolveShared& sh) {
   const GnArgs& a = fa.g;
-  const int b = blockIdx.x;
-  const AlignState& src = a.state[(size_t)(fa.seq & 1) * fa.stride_state + b];
-  AlignState* dst = a.state + b;
-  __shared__ SolveShared sh;
   const int t = threadIdx.x;
   // state-driven schedule (ADAPT, gn_fca_adaptive): the level of the pending sums comes from the record, and the schedule
   // may not have ended yet — the result record then says so (pad = 1) and the host replays a continuation
@@ -2359,7 +2352,6 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
       *(volatile int*)&r->pad = ended ? 0 : 1;
     }
   }
-  if (fa.persist_bar && t == 0) fa.persist_bar[(size_t)b * ELLC_PERSIST_BAR_WORDS] = 0u;   // gn_fca_persist's abort word, for the next call
   if (fa.track_mats && b == 0 && t < 64) {   // (sh.newpose is final: every path above ends in a block barrier before the stores)
     float p[6];
 #pragma unroll
@@ -2367,6 +2359,12 @@ __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs 
     track_setup_wave(p, fa.track_K, fa.track_mats);
     if (t == 0) *fa.track_gate = ended ? 1 : 0;   // closed: the schedule needs a continuation only the host can start
   }
+}
+template <bool FAST, bool ADAPT = false>
+__global__ __launch_bounds__(ELLC_SOLVE_THREADS) void gn_fused_finish(FusedArgs fa) {
+  const int b = blockIdx.x;
+  __shared__ SolveShared sh;
+  fused_finish_body<FAST, ADAPT>(fa, b, fa.g.state[(size_t)(fa.seq & 1) * fa.stride_state + b], fa.g.state + b, sh);
 }
 
 // PixelWisePyramid's display planes of one pass (PixelWisePyramid.cpp:209-225 and :275-284): for every pixel of the level where

@@ -115,9 +115,10 @@ ellc_status ellc_ctx_set_poll_timeout_us(ellc_ctx* ctx, int microseconds);
  * 43. Batches in flight keep the grids they were launched with. */
 ellc_status ellc_ctx_set_grid_batch(ellc_ctx* ctx, int n);
 /* How the state-driven schedule (early exit on, one or two alignments per call: the tracking call, main.cpp:330) reaches the device
- * (r05, ABI v9). 1 (default): as ONE resident launch — up to 128 blocks per alignment stay on the device for the whole schedule and
- * hand their partial sums to each other through tagged records in device memory (gn_fca_persist); a launch whose blocks do not all
- * become resident within ~2 s (a device shared with more such launches than it holds) is abandoned and the schedule finished with
+ * (r05, ABI v9). 1 (default): as ONE resident launch whenever the call finds the context's pipeline empty (with other batches of
+ * the context in flight: as mode 0, so that their launches keep overlapping) — the level's blocks stay on the device for the whole
+ * schedule and hand their partial sums to each other through tagged records in device memory (gn_fca_persist); a launch whose blocks do not all
+ * become resident within ~50 ms (a device shared with more such launches than it holds) is abandoned and the schedule finished with
  * ordinary launches, with the same results as mode 0 from the iteration it had reached. 0: one launch per iteration (as up to
  * ABI v8). 2: test hook — every resident launch is abandoned at its first hand-over. Takes effect with the next call; ends the
  * context's adaptive hint. */
