@@ -545,6 +545,47 @@ def test_two_contexts_on_two_threads(ellc):
     assert not bad, bad[:3]
 
 
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_resident_launches_of_more_contexts_than_the_device_holds(ellc, arith):
+    """Five contexts on five host threads, each aligning batches of two with early exit: five resident launches (gn_fca_persist) of
+    512 blocks each want the device at once, which holds two (exact) or three (fast) of them. Launches that cannot get all their
+    blocks resident give up and are finished by ordinary launches: every call returns, with the bits the context gives alone, and
+    no call takes as long as a second (a stall would be the poll limit, ~50 ms)."""
+    import threading
+    import time as _time
+    kw = dict(arith=ellc.ARITH_FAST) if arith == "fast" else {}
+    N, reps = 5, 20
+    ctxs, refs = [], []
+    for k in range(N):
+        pairs = [synth.make_pair(W, H, seed=140 + 2 * k + i, rot=0.01 + 0.004 * i, trans=0.03) for i in range(2)]
+        c = gpu_problem(ellc, W, H, L, pairs, early_exit=1, **kw)
+        ctxs.append(c)
+        refs.append(c.align([0, 1], [0, 1]))
+    bad, slow = [], []
+
+    def work(c, ref):
+        try:
+            for _ in range(reps):
+                t0 = _time.perf_counter()
+                pose, iters, wgt = c.align([0, 1], [0, 1])
+                slow.append(_time.perf_counter() - t0)
+                if not (np.array_equal(pose, ref[0]) and np.array_equal(iters, ref[1]) and np.array_equal(wgt, ref[2])):
+                    bad.append("result differs")
+        except Exception as e:   # noqa: BLE001
+            bad.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(c, r)) for c, r in zip(ctxs, refs)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for c in ctxs:
+        c.close()
+    assert not bad, bad[:3]
+    print("calls %d, slowest %.1f ms, median %.3f ms" % (len(slow), 1e3 * max(slow), 1e3 * float(np.median(slow))))
+    assert max(slow) < 1.0
+
+
 @pytest.mark.parametrize("seed,concurrent,coalesce,cache", [(1, 3, 1, 0), (2, 3, 1, 0), (3, 1, 1, 0), (4, 3, 3, 0), (5, 3, 2, 0), (6, 12, 3, 0),
                                                             (7, 16, 4, 0), (8, 3, 1, 1), (9, 16, 4, 1), (10, 8, 2, 1)])
 def test_pipelined_calls_equal_the_same_calls_made_one_by_one(ellc, seed, concurrent, coalesce, cache):
