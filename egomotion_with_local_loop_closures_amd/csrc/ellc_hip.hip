@@ -565,6 +565,12 @@ static void set_track_fields(const ellc_ctx* c, FusedArgs& fa, bool continuation
 // the two forms, and a schedule that starts in one and is finished in the other, give the same bits. (Measured with the counts
 // capped at 32 / 64 / 128 / 256 blocks, one early-exit alignment 640x480, fast: 0.120 / 0.116 / 0.115 / 0.117 ms against 0.128 with
 // launches; exact 0.171 / 0.161 / 0.156 / 0.158 against 0.164; tracked frame 0.208 / 0.192 / 0.188 / 0.190 against 0.205.)
+// blocks a resident launch of B alignments needs on the device at once
+static int persist_blocks(ellc_ctx* c, int B) {
+  int G = 1;
+  for (int l = 0; l < c->L; l++) G = std::max(G, choose_nblk(c, l, grid_batch(c, B)));
+  return G * B;
+}
 static ellc_status enqueue_schedule_persist(ellc_ctx* c, int B, int save_weights) {
   FusedArgs fa;
   fa.continuation = 0;
@@ -1034,6 +1040,15 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0)
       c->resident_blocks = cus * (c->use_fused ? 4 : 5);   // 256-thread blocks per CU: 126 VGPRs (fused) -> 4 waves/SIMD, 92 -> 5
+    // blocks of the resident schedule (gn_fca_persist) this device holds at once: a launch of more could never become resident
+    // (a partition of the device, e.g. one XCD's 32 CUs) and is not attempted
+    if (cus > 0) {
+      int per_cu = 0;
+      const hipError_t oe = c->fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_fca_persist<false, true, 1>, ELLC_GN_THREADS, 0)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_fca_persist<false, false, -1>, ELLC_GN_THREADS, 0);
+      c->persist_capacity = (oe == hipSuccess && per_cu > 0) ? per_cu * cus : 0;
+      if (oe != hipSuccess) (void)hipGetLastError();
+    }
   }
 #undef TRY
   *out = c;
@@ -1668,7 +1683,7 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
     bool alone = true;
     for (int p = 0; p < ellc_ctx::SETS; p++)
       if (p != set && c->batch_set[p].launched && !c->batch_set[p].resolved) alone = false;
-    c->cur_resident = alone;
+    c->cur_resident = alone && persist_blocks(c, B) <= c->persist_capacity;
   }
   bs.resident = c->cur_resident;
   c->cur_adaptive_first = adaptive_first_launches(c, B);
@@ -1729,7 +1744,7 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
     ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
     if (s != ELLC_OK) return s;
     for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);   // rebuilt here, outside the cache's bookkeeping
-    c->cur_resident = c->use_persist && B <= 2 && schedule_is_adaptive(c, mode, B);   // (nothing in flight)
+    c->cur_resident = c->use_persist && B <= 2 && schedule_is_adaptive(c, mode, B) && persist_blocks(c, B) <= c->persist_capacity;   // (nothing in flight)
     c->cur_adaptive_first = adaptive_first_launches(c, B);
     bool dense = runs_dense(c, mode, B, save_weights);
     for (int b = 0; b < B; b++) dense = dense && c->kf_dense[kf_slots[b]];
