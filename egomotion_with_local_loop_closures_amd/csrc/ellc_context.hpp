@@ -129,6 +129,7 @@ struct ellc_ctx {
   float* partials_d = nullptr;
   unsigned* persist_bar_d = nullptr;
   unsigned persist_spin_limit = 1u << 15;           // polls of a missing record before gn_fca_persist gives a launch up (0: at once — test hook)
+  unsigned prep_tag = 0;                            // tag of the last compaction without a count launch (PrepArgs::lb_tag)
   unsigned persist_epoch = 0;                       // calls of gn_fca_persist so far (tags of its partial records)
   int persist_capacity = 0;                         // blocks of gn_fca_persist the device holds at once (occupancy x CUs)
   bool cur_resident = false;                        // the schedule being enqueued is the resident form

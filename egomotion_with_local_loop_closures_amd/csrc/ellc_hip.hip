@@ -256,7 +256,13 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
   a.tile0 = c->tile_begin[lvl_lo];
   a.level0 = lvl_lo;
   const int tiles = c->tile_begin[lvl_hi + 1] - c->tile_begin[lvl_lo];
-  hipLaunchKernelGGL(prep_count, dim3(tiles, n_unique), dim3(256), 0, st, a);
+  a.lb_tag = 0;
+  if (c->direct_launch && n_unique <= 2 && lvl_lo == 0 && lvl_hi == c->L - 1 && tiles * n_unique <= c->resident_blocks) {
+    c->prep_tag = c->prep_tag % 0xfffffu + 1u;   // never 0, never what a count launch leaves in a word (its upper bits are 0)
+    a.lb_tag = c->prep_tag;
+  } else {
+    hipLaunchKernelGGL(prep_count, dim3(tiles, n_unique), dim3(256), 0, st, a);
+  }
   switch (need) {
     case 1: hipLaunchKernelGGL(prep_scatter<1>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL(prep_scatter<2>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
@@ -283,6 +289,7 @@ static void enqueue_ica_hinv(ellc_ctx* c, int n_unique) {
   for (int l = 0; l <= ELLC_MAX_LEVELS; l++) a.tile_begin[l] = c->tile_begin[std::min(l, c->L)];
   a.tile0 = 0;
   a.level0 = 0;
+  a.lb_tag = 0;
   hipLaunchKernelGGL(ica_hinv, dim3(c->L, n_unique), dim3(ELLC_SOLVE_THREADS), 0, c->stream, a);
 }
 

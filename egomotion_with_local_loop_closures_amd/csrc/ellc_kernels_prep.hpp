@@ -24,6 +24,12 @@ struct PrepArgs {
                                // the tolerance mode's 16-byte form (IcaInF) instead of IcaRec
   int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
   int tile0, level0;           // this launch covers tiles tile0 + blockIdx.x (count / scatter), levels level0 + blockIdx.x (scan)
+  unsigned lb_tag;             // 0: prep_count has left the tiles' counts. Else (r05, the tracking call: one or two keyframes, launched
+                               // kernel by kernel) there is NO count launch: a scatter block publishes `lb_tag << 12 | its tile's count`
+                               // as soon as it has it and sums the tagged counts of the tiles of its level in front of it as they
+                               // appear (agent-scope stores / loads, no fence; blocks are dispatched in tile order, so the tiles a block
+                               // waits for are resident or done). For launch groups the same was measured 17 % SLOWER (NOTEBOOK 5.1):
+                               // 25 000 waiting blocks; here they are 201.
 };
 
 __device__ __forceinline__ int prep_level_of(const PrepArgs& a, int tile, int& local) {
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
     const int i = base + j * 256;
     d[j] = (i < n) ? gptr(K.depth)[(unsigned)i] : 0.0f;
   }
-  {   // this tile's offset in the level's list = sum of the counts prep_count left for the tiles before it (at most a few hundred)
+  if (!a.lb_tag) {   // this tile's offset in the level's list = sum of the counts prep_count left for the tiles before it (at most a few hundred)
     int part = 0, tot;
     for (int i = (int)threadIdx.x; i < local; i += 256) part += gptr(K.tile_count)[(unsigned)i];
     wave_inclusive_scan(part, tot);
@@ -125,6 +131,27 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
     if (lane == 0) cnt[32] = tot;
   }
   __syncthreads();
+  if (a.lb_tag) {   // block-uniform: see PrepArgs::lb_tag
+    const unsigned tag = a.lb_tag << 12;
+    unsigned* tc = (unsigned*)K.tile_count;
+    if (threadIdx.x == 0) __hip_atomic_store(tc + local, tag | (unsigned)cnt[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int part = 0, tot;
+    for (int i = (int)threadIdx.x; i < local; i += 256) {
+      unsigned w = 0u, polls = 0u;
+      do { w = __hip_atomic_load(tc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w & 0xfffff000u) != tag && ++polls < 4096u);
+      if ((w & 0xfffff000u) == tag) {
+        part += (int)(w & 0xfffu);
+      } else {   // (does not happen with blocks dispatched in tile order; a count is a function of the plane: no wait can be endless)
+        const int e0 = i * ELLC_TILE, e1 = min(n, e0 + ELLC_TILE);
+        int cnt_i = 0;
+        for (int e = e0; e < e1; e++) cnt_i += (gptr(K.depth)[(unsigned)e] > 0.0f) ? 1 : 0;
+        part += cnt_i;
+      }
+    }
+    wave_inclusive_scan(part, tot);
+    if (lane == 0) before[wave] = tot;
+    __syncthreads();
+  }
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int j = 0; j < 8; j++) {
