@@ -45,6 +45,11 @@ struct ellc_ctx {
   // thread <-> pixel, the planes read directly). A hint, not a promise: pixels without depth are skipped where they occur.
   std::vector<char> kf_dense;
   bool cur_dense = false;   // the schedule being enqueued is the list-free one
+#ifdef ELLC_NO_DENSE_QUADS
+  bool dense_quads = false;   // (A/B builds: the r05 kernel, one pixel per thread)
+#else
+  bool dense_quads = true;    // list-free launches take four adjacent pixels per thread (gn_fca_dense4) at levels whose width allows
+#endif
   // cfg.cache_records: which record set (PrepArgs::need) the compact lists of a keyframe slot hold, 0 = none / stale. The lists
   // are a pure function of the slot's image, depth pyramid and weight planes: every entry point that writes one of those
   // clears the tag (ellc::invalidate_records); a batch rebuilds only the slots whose tag differs from what it needs.

@@ -104,6 +104,11 @@ static ellc_status host_alloc(ellc_ctx* c, T** p, size_t count) {
 // Blocks per alignment for the accumulate kernels. Enough blocks to give every thread about one pixel at the
 // coarse levels (those launches are latency-bound); at the fine levels exactly the number of blocks the device
 // holds at once, so every CU gets the same share and each block pays the 27-value reduction once.
+// does a list-free launch at this level take four adjacent pixels per thread (gn_fca_dense4)? A row must be a whole number of quads
+static bool dense_quads_at(const ellc_ctx* c, int level) {
+  const LevelGeom& lg = c->geom_h[level];
+  return c->dense_quads && lg.cols % 4 == 0 && lg.sw % 4 == 0 && lg.cols >= 16 && lg.rows >= 8;
+}
 int choose_nblk(const ellc_ctx* c, int level, int B) {
 #ifdef ELLC_DIAG
   if (c->nblk_override[level] > 0) return std::min(ELLC_NBLK_MAX, c->nblk_override[level]);   // tuning knob (ELLC_NBLK=l0,l1,..)
@@ -117,13 +122,17 @@ int choose_nblk(const ellc_ctx* c, int level, int B) {
   // (r03: a launch that covers a whole group of batches keeps the full round where that still leaves a thread plenty of pixels —
   // level 0 of 640x480 over 128 alignments: 8 blocks per alignment instead of 4, the launch 49 instead of 61 us alone, the
   // pipeline's rate unchanged (tools/dbg/nblk_bench.sh); level 1 is slower with the full round)
-  const int per_full = std::max(1, c->resident_blocks / B);
+  // (list-free launches with four pixels per thread hold three blocks per CU, not four: gn_fca_dense4)
+  const int blocks_per_cu = c->use_fused ? 4 : 5;
+  const bool quads = c->cur_dense && dense_quads_at(c, level);
+  const int resident = quads ? c->resident_blocks / blocks_per_cu * ELLC_QUAD_BLOCKS_PER_CU : c->resident_blocks;
+  const int per_full = std::max(1, resident / B);
   const bool share = c->cfg.concurrent_batches > 1 && (double)n / (256.0 * per_full) < 100.0;
   const int per = std::max(1, per_full / (share ? 2 : 1));
   int nblk = std::min(ELLC_NBLK_MAX, std::min(by_px, per));
   // small levels: one block per CU runs the (serial) solve prologue and the short pixel pass fastest, as long as a
   // thread does not get more than ~4 pixels (r01 sweep: level 2 at B=32, 8 blocks beat 30; level 1 keeps 32)
-  const int cus = std::max(1, c->resident_blocks / (c->use_fused ? 4 : 5));
+  const int cus = std::max(1, c->resident_blocks / blocks_per_cu);
   if (nblk * B > cus) {
     const int one_per_cu = std::max(1, cus / B);
     if (0.3 * n / (256.0 * one_per_cu) <= 4.0) nblk = std::min(nblk, one_per_cu);
@@ -491,7 +500,11 @@ static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, h
   const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
   const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
   if (c->cur_dense) {   // dense maps: no compact lists (gn_fca_dense; launch_group decided)
-    hipLaunchKernelGGL(gn_fca_dense, grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    // four adjacent pixels per thread where a row is a whole number of them (r06: one tap window per row for the four)
+    if (dense_quads_at(c, fa.g.level))
+      hipLaunchKernelGGL(gn_fca_dense4, grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+    else
+      hipLaunchKernelGGL(gn_fca_dense, grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
     return;
   }
   if (c->fast) {
@@ -914,7 +927,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       TRY(dev_alloc(c, &k.count, 4)); TRY(dev_alloc(c, &k.tile_count, tiles + 1));
       TRY(dev_alloc(c, &k.irec, n)); TRY(dev_alloc(c, &k.hpart, (size_t)(tiles + 1) * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
     }
-    for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni + 16));
+    // (+ one row: the fifth row of gn_fca_dense4's tap windows may be the one below the image)
+    for (int s = 0; s < MF; s++) TRY(dev_alloc(c, &c->fr_tab_h[(size_t)l * MF + s].img, ni + (size_t)g.sw + 32));
   }
   TRY(dev_alloc(c, &c->kf_tab_d, c->kf_tab_h.size()));
   TRY(dev_alloc(c, &c->fr_tab_d, c->fr_tab_h.size()));
@@ -1067,6 +1081,14 @@ ellc_status ellc_ctx_destroy(ellc_ctx* c) {
   (void)ellc::enter(c, true);   // launches an open group / resolves state-driven batches; whatever it reports, everything is torn down
   for (int i = 1; i < ellc_ctx::STREAMS; i++) if (c->batch_stream[i]) (void)hipStreamSynchronize(c->batch_stream[i]);
   (void)hipStreamSynchronize(c->stream);
+#ifdef ELLC_QUAD_STATS   // diagnostic variant builds only (tools/quad_stats.sh): how often gn_fca_dense4's quads did not fit their window
+  {
+    unsigned long long qs[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(qs, HIP_SYMBOL(ellc::g_quad_stats), sizeof(qs)) == hipSuccess)
+      std::fprintf(stderr, "ELLC_QUAD_STATS quads %llu nofit %llu (%.3f %%) queued_pixels %llu drain_rounds %llu\n", qs[0], qs[1],
+                   qs[0] ? 100.0 * (double)qs[1] / (double)qs[0] : 0.0, qs[2], qs[3]);
+  }
+#endif
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
   for (void* p : c->allocs) (void)hipFree(p);
   for (void* p : c->host_allocs) (void)hipHostFree(p);
@@ -2004,7 +2026,9 @@ ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, cons
     if (s != ELLC_OK) return s;
   }
   hipLaunchKernelGGL(gn_init_state, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->state_d, c->init_pose_d, B, c->L - 1);
+  c->cur_dense = dense;   // (the grids of list-free launches are sized for their kernel: choose_nblk)
   GnArgs a = make_gn_args(c, level, B, 0, nullptr);
+  c->cur_dense = false;
   const dim3 grd(a.nblk, B), blk(ELLC_GN_THREADS);
   if (c->use_fused) {
     // the production kernel of the FCA path: every launch first solves the previous launch's partial sums

@@ -1793,6 +1793,326 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_dense(const AlignSt
 }
 
 // ---------------------------------------------------------------------------------------------------
+// gn_fca_dense with FOUR ADJACENT PIXELS PER THREAD (r06), for levels whose width is a multiple of four. What the pixel pass of a
+// dense level pays for is the number of wave-level load instructions it hands the CU's vector cache — about 16.7 cycles each whatever
+// the lanes ask for, twice that when the lanes of a tap request sit on two image rows (tools/micro/quad_window.hip: the taps of 256
+// neighbouring pixels cost 253-520 cycles of the cache as 4 x 4 unaligned dwords, 139 as 5 rows of ONE 8-byte window per four
+// pixels) — against 424 cycles of the four SIMDs' arithmetic for the same 256 pixels. Here a thread owns pixels x .. x + 3 of one
+// keyframe row: depth and variance arrive as one dwordx4 each, the four intensities as one dword; the four points are warped
+// (the row's share of K exp(pose) (p, q, 1) is formed once per thread); and when their neighbourhoods "fit" — all interior, the four
+// floor(x) within 4 columns, the four floor(y) within 2 rows — FIVE 8-byte requests at (min floor(y) - 1 .. + 3, min floor(x) - 1)
+// serve all four: a pixel's row words are cut out with v_perm_b32 (its column offset as the byte selector) and chosen by its row
+// offset. 8 load instructions per four pixels instead of 28. From there on the pixel step is fcaf_stage_b's, unchanged.
+//   A thread whose four points do not fit (image border, a depth edge, a map with holes next to it) does not branch into the
+// per-tap path — one such lane would hold up its wave, and with 256 pixels of a row per wave two waves in five touch the border —
+// it appends its (valid) pixels to a queue of the WAVE in LDS, and whenever 64 are queued the wave runs them through
+// gn_fca_dense's step (dense_form + fcaf_stage_a / _b: the per-pixel values of that kernel), all lanes busy; the rest at the end of
+// the chunk. The queue's order is fixed by ballots: same inputs, same bits. Chunks are split in units of four pixels.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef u32x2_t u32x2_a1 __attribute__((aligned(1)));
+struct QuadPlanes { f32x4_t Z, var; uint32_t I; };
+__device__ __forceinline__ QuadPlanes quad_request(const KfLevelDev& K, unsigned i4, unsigned img_off) {
+  QuadPlanes p;
+  const unsigned boff = i4 << 2;   // 32-bit byte offsets: uniform base + lane offset, no 64-bit lane arithmetic (planes < 4 GiB)
+  p.Z = *(const ELLC_GLOBAL f32x4_t*)((const ELLC_GLOBAL char*)K.depth + boff);
+  p.var = *(const ELLC_GLOBAL f32x4_t*)((const ELLC_GLOBAL char*)K.var + boff);
+  p.I = *(const ELLC_GLOBAL uint32_t*)((const ELLC_GLOBAL char*)K.img + img_off);
+  return p;
+}
+// Three blocks per CU (168 registers a thread): with four pixels in flight per thread the step holds the planes of the NEXT quad (nine
+// registers, requested a whole step ahead: they come from HBM) beside everything of this one; at four per CU (128) that spills, and
+// with the variances and intensities requested in the step that uses them the tap rows wait behind them (vector loads return in
+// order): 412 us against the r05 kernel's 369. The host sizes the grids of list-free launches for three per CU (choose_nblk).
+#define ELLC_QUAD_BLOCKS_PER_CU 3
+#define ELLC_QUAD_QCAP (64 + 4 * 64)   // entries of a wave's queue: drained below 64 after every step, a step appends at most 256
+#ifdef ELLC_QUAD_STATS
+__device__ unsigned long long g_quad_stats[4];   // diagnostic builds: quads seen / quads that did not fit / pixels queued / drain rounds
+#endif
+
+__global__ __launch_bounds__(ELLC_GN_THREADS, ELLC_QUAD_BLOCKS_PER_CU) void gn_fca_dense4(const AlignState* src_state, const float* prev_part, int prev_nblk, int nblk, int age_rounds,
+                                                                    FusedArgs fa) {
+  const GnArgs& a = fa.g;
+  int b = blockIdx.y, sub = blockIdx.x, age = 0, per_age = nblk;
+  if (age_rounds > 1) {   // see gn_fca_fused
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int per_round = (int)(gridDim.x * gridDim.y) / age_rounds;
+    per_age = nblk / age_rounds;
+    age = lin / per_round;
+    const int j = lin - age * per_round;
+    b = j / per_age;
+    sub = age * per_age + (j - b * per_age);
+  } else if (fa.xcd_map) {
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int w = lin >> 3, bl = w / nblk;
+    sub = w - bl * nblk;
+    b = bl * 8 + (lin & 7);
+  }
+  const AlignState& src = src_state[b];
+  AlignState* dst = a.state + (size_t)((fa.seq + 1) & 1) * fa.stride_state + b;
+  __shared__ SolveShared sh;
+  __shared__ uint32_t qbuf[ELLC_GN_THREADS / 64][ELLC_QUAD_QCAP];
+  const int t = threadIdx.x;
+  const bool writer = (sub == 0);
+  const LevelGeom g = a.geom[a.level];
+  const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];   // by value: uniform, lives in SGPRs
+  const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
+  const int pending = src.pending;
+  const int cols = g.cols, sw = g.sw;
+  const int cols4 = cols >> 2;      // quads per row (the host launches this kernel for cols % 4 == 0 only)
+  const int V = g.n >> 2;           // the "list" is the plane, in quads
+  const double group_sum = partial_group_sum(prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, prev_nblk);
+  int begin, end;
+  if (age_rounds > 1) {
+    const int gb = (int)(((long long)V * fa.age_cum[age]) >> 16), ge = (int)(((long long)V * fa.age_cum[age + 1]) >> 16);
+    const int chunk = (ge - gb + per_age - 1) / per_age;
+    begin = gb + (sub - age * per_age) * chunk;
+    end = min(ge, begin + chunk);
+  } else {
+    const int chunk = (V + nblk - 1) / nblk;
+    begin = sub * chunk;
+    end = min(V, begin + chunk);
+  }
+  g_u8 cur = as_global(F.img);
+  // this thread's first quad: position and planes, requested before the solve
+  const int qstep = ELLC_GN_THREADS / cols4, rstep = ELLC_GN_THREADS - qstep * cols4;   // a step advances a thread by 256 quads: qstep rows and rstep quad columns
+  int xq = 0, y = 0;   // quad column, row
+  QuadPlanes pl;
+  pl.Z = (f32x4_t)(0.0f); pl.var = (f32x4_t)(0.0f); pl.I = 0u;
+  if (begin < end) {   // block-uniform (a thread past the chunk's end starts on a copy of its last quad: the loop is block-uniform)
+    const int i0 = min(begin + t, end - 1);
+    y = (int)(((float)i0 + 0.5f) * (1.0f / (float)cols4));   // i < 2^24: exact conversion; corrected to the exact quotient
+    if (y * cols4 > i0) y--;
+    if ((y + 1) * cols4 <= i0) y++;
+    xq = i0 - y * cols4;
+    pl = quad_request(K, 4u * (unsigned)i0, __umul24((unsigned)y, (unsigned)sw) + 4u * (unsigned)xq);
+  }
+  if (pending) {
+    solve_step<true>(sh, group_sum, 0, fa.prev_level, fa.early_exit, src, nullptr);
+  } else {
+    if (t < 6) sh.newpose[t] = src.pose[t];
+    if (t < 12) sh.newS[t] = src.S[t];
+    if (t == 0) { sh.weighted = src.weighted; sh.level_done = src.level_done; }
+    __syncthreads();
+  }
+  const int level_done = sh.level_done;
+  const bool skip = (level_done == a.level);
+  if (writer) {
+    if (t < 6) dst->pose[t] = sh.newpose[t];
+    if (t < 12) dst->S[t] = sh.newS[t];
+    if (t < ELLC_MAX_LEVELS) dst->iters[t] = src.iters[t] + ((pending && t == fa.prev_level) ? 1 : 0);
+    if (t == 0) {
+      dst->weighted = sh.weighted;
+      dst->level_done = level_done;
+      dst->pending = skip ? 0 : 1;
+    }
+  }
+  if (skip) return;
+  float sums[27];
+  {
+    // exp(pose) of this iteration: uniform, so into scalar registers (the per-pixel operands get vector copies below: an SGPR
+    // operand halves the issue rate of the f32 multiply-adds; what is used once per quad or per drain stays scalar)
+    float S[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) S[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sh.newS[i])));
+    FcaAcc acc;
+    fca_acc_zero(acc);
+    if (begin < end) {   // block-uniform
+      const TapRows tr = tap_rows(cur, sw);
+      const g_u8 row_e = tr.rd + sw;   // the fifth row of a window: y0 + 3
+      // P = K exp(pose) (fcaf_const), in scalar registers
+      float P[12];
+      {
+        const FcafConst f0 = fcaf_const(g, S);
+#pragma unroll
+        for (int i = 0; i < 12; i++) P[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f0.P[i])));
+      }
+      const float s_rfy = g.rfy, s_qc = -(g.cy * g.rfy), s_pc = -(g.cx * g.rfx);
+      float vP0 = P[0], vP3 = P[3], vP4 = P[4], vP7 = P[7], vP8 = P[8], vP11 = P[11], v_rfx = g.rfx, v_hfx = 0.5f * g.fx, v_hfy = 0.5f * g.fy;
+      asm volatile("" : "+v"(vP0), "+v"(vP3), "+v"(vP4), "+v"(vP7), "+v"(vP8), "+v"(vP11), "+v"(v_rfx), "+v"(v_hfx), "+v"(v_hfy));
+      const int n_full = __builtin_amdgcn_readfirstlane((end - begin) / ELLC_GN_THREADS);
+      const int rem = __builtin_amdgcn_readfirstlane((end - begin) - n_full * ELLC_GN_THREADS);
+      const int n_steps = n_full + (rem > 0 ? 1 : 0);
+      const int lane = t & 63;
+      uint32_t* const q = qbuf[t >> 6];
+      int qn = 0;   // wave-uniform: entries queued
+      int i = begin + t;
+      for (int k = 0;; k++) {
+        const bool more = (k < n_steps);   // block-uniform
+        if (more) {
+          const bool last = (k == n_steps - 1);
+          const bool active = !last || rem == 0 || t < rem;
+          const f32x4_t cZ = pl.Z, cvar = pl.var;
+          const uint32_t cI = pl.I;
+          const unsigned i4 = 4u * (unsigned)min(i, end - 1);
+          const int x = 4 * xq, yrow = y;
+          // the next quad of this thread: 256 further on (clamped to the chunk's last quad: every request is unconditional)
+          int xn = xq + rstep, yn = y + qstep;
+          if (xn >= cols4) { xn -= cols4; yn++; }
+          const int in_ = i + ELLC_GN_THREADS;
+          if (in_ > end - 1) {
+            const int il = end - 1;
+            yn = (int)(((float)il + 0.5f) * (1.0f / (float)cols4));
+            if (yn * cols4 > il) yn--;
+            if ((yn + 1) * cols4 <= il) yn++;
+            xn = il - yn * cols4;
+          }
+          const unsigned inext = 4u * (unsigned)min(in_, end - 1);
+          // inverse depths; a pixel without depth takes a neighbour's (its point then lands beside theirs and does not spoil the fit)
+          const bool v0 = cZ.x > 0.0f, v1 = cZ.y > 0.0f, v2 = cZ.z > 0.0f, v3 = cZ.w > 0.0f;
+          float d0 = __builtin_amdgcn_rcpf(v0 ? cZ.x : 1.0f), d1 = __builtin_amdgcn_rcpf(v1 ? cZ.y : 1.0f);
+          float d2 = __builtin_amdgcn_rcpf(v2 ? cZ.z : 1.0f), d3 = __builtin_amdgcn_rcpf(v3 ? cZ.w : 1.0f);
+          if (__builtin_amdgcn_ballot_w64(!(v0 && v1 && v2 && v3)) != 0ull) {
+            const float dref = v0 ? d0 : (v1 ? d1 : (v2 ? d2 : d3));
+            d0 = v0 ? d0 : dref; d1 = v1 ? d1 : dref; d2 = v2 ? d2 : dref; d3 = v3 ? d3 : dref;
+          }
+          const float dd[4] = {d0, d1, d2, d3};
+          const bool vv[4] = {v0, v1, v2, v3};
+          // the row's and the thread's share of K exp(pose) (p, q, 1): once per quad (scalar operands)
+          const float p0 = __builtin_fmaf((float)x, v_rfx, s_pc), qq = __builtin_fmaf((float)yrow, s_rfy, s_qc);
+          const float bqx = __builtin_fmaf(P[1], qq, P[2]), bqy = __builtin_fmaf(P[5], qq, P[6]), bqz = __builtin_fmaf(P[9], qq, P[10]);
+          // per pixel, what the second half needs of the warp: the position and half the reciprocal depth of the warped point
+          float x1[4], y1[4], hrz[4];
+          int x0[4], y0[4];
+          int xs, xm, ys, ym;
+          {
+            float pj = p0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const float px = __builtin_fmaf(vP0, pj, __builtin_fmaf(vP3, dd[j], bqx));
+              const float py = __builtin_fmaf(vP4, pj, __builtin_fmaf(vP7, dd[j], bqy));
+              const float pz = __builtin_fmaf(vP8, pj, __builtin_fmaf(vP11, dd[j], bqz));
+              const float rz = __builtin_amdgcn_rcpf(pz);   // no clamp of pz (fcaf_stage_a)
+              x1[j] = px * rz; y1[j] = py * rz; hrz[j] = 0.5f * rz;
+              x0[j] = cvt_floor_i32(x1[j]); y0[j] = cvt_floor_i32(y1[j]);
+              pj += v_rfx;
+            }
+            xs = min(min(x0[0], x0[1]), min(x0[2], x0[3])); xm = max(max(x0[0], x0[1]), max(x0[2], x0[3]));
+            ys = min(min(y0[0], y0[1]), min(y0[2], y0[3])); ym = max(max(y0[0], y0[1]), max(y0[2], y0[3]));
+          }
+          // all sixteen-neighbourhoods interior (x0 in [1, cols - 3], y0 in [1, rows - 3]; a NaN converts to 0, an infinity saturates:
+          // neither passes), the columns within one 8-byte window, the rows within five
+          const bool fit = ((unsigned)(xs - 1) <= (unsigned)(cols - 4)) & ((unsigned)(xm - 1) <= (unsigned)(cols - 4)) &
+                           ((unsigned)(ys - 1) <= (unsigned)(g.rows - 4)) & ((unsigned)(ym - 1) <= (unsigned)(g.rows - 4)) &
+                           (xm - xs <= 4) & (ym - ys <= 1);
+          const unsigned off = fit ? __umul24((unsigned)ys, (unsigned)sw) + (unsigned)xs : (unsigned)sw + 1u;
+          const u32x2_t wA = *(const ELLC_GLOBAL u32x2_a1*)(tr.ra + off);
+          const u32x2_t wB = *(const ELLC_GLOBAL u32x2_a1*)(tr.rb + off);
+          const u32x2_t wC = *(const ELLC_GLOBAL u32x2_a1*)(tr.rc + off);
+          const u32x2_t wD = *(const ELLC_GLOBAL u32x2_a1*)(tr.rd + off);
+          const u32x2_t wE = *(const ELLC_GLOBAL u32x2_a1*)(row_e + off);
+          __builtin_amdgcn_sched_barrier(0);
+          // the next quad's planes, behind the row requests (vector loads return in issue order)
+          pl = quad_request(K, inext, __umul24((unsigned)yn, (unsigned)sw) + 4u * (unsigned)xn);
+          __builtin_amdgcn_sched_barrier(0);
+          const float var[4] = {cvar.x, cvar.y, cvar.z, cvar.w};
+          const uint32_t wAx = wA.x, wAy = wA.y, wBx = wB.x, wBy = wB.y, wCx = wC.x, wCy = wC.y, wDx = wD.x, wDy = wD.y, wEx = wE.x, wEy = wE.y;
+          float pj = p0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            // bytes s .. s + 3 of a row's window are columns x0 - 1 .. x0 + 2 of this pixel; its rows start at the window's first or second
+            const float fx_ = __builtin_amdgcn_fractf(x1[j]), fy_ = __builtin_amdgcn_fractf(y1[j]);   // x - floor(x), exact for x >= 1
+            const uint32_t s1 = (uint32_t)(x0[j] - xs);            // 0 .. 4 where the quad fits
+            const uint32_t s2 = s1 | (s1 << 8);
+            const uint32_t sel = (s2 | (s2 << 16)) + 0x03020100u;
+            const bool dy = (y0[j] != ys);
+            const uint32_t r0 = __builtin_amdgcn_perm(wAy, wAx, sel), r1 = __builtin_amdgcn_perm(wBy, wBx, sel), r2 = __builtin_amdgcn_perm(wCy, wCx, sel);
+            const uint32_t r3 = __builtin_amdgcn_perm(wDy, wDx, sel), r4 = __builtin_amdgcn_perm(wEy, wEx, sel);
+            const uint32_t qa = dy ? r1 : r0, qb = dy ? r2 : r1, qc = dy ? r3 : r2, qd = dy ? r4 : r3;
+            // the taps (tap_finish_f's interior branch)
+            const float Pbb = cvt_ubyte<1>(qb), Pbc = cvt_ubyte<2>(qb), Pcb = cvt_ubyte<1>(qc), Pcc = cvt_ubyte<2>(qc);
+            const float top = __builtin_fmaf(fx_, Pbc - Pbb, Pbb);
+            const float btm = __builtin_fmaf(fx_, Pcc - Pcb, Pcb);
+            const float I = __builtin_fmaf(fy_, btm - top, top);
+            const float Pba = cvt_ubyte<0>(qb), Pbd = cvt_ubyte<3>(qb), Pca = cvt_ubyte<0>(qc), Pcd = cvt_ubyte<3>(qc);
+            const float Pab = cvt_ubyte<1>(qa), Pac = cvt_ubyte<2>(qa), Pdb = cvt_ubyte<1>(qd), Pdc = cvt_ubyte<2>(qd);
+            const float g00 = Pbc - Pba, g01 = Pbd - Pbb, g10 = Pcc - Pca, g11 = Pcd - Pcb;   // twice the central differences
+            float t2 = __builtin_fmaf(fx_, g01 - g00, g00);
+            float b2 = __builtin_fmaf(fx_, g11 - g10, g10);
+            const float gx = __builtin_fmaf(fy_, b2 - t2, t2);   // TWICE the gradient
+            const float h00 = Pcb - Pab, h01 = Pcc - Pac, h10 = Pdb - Pbb, h11 = Pdc - Pbc;
+            t2 = __builtin_fmaf(fx_, h01 - h00, h00);
+            b2 = __builtin_fmaf(fx_, h11 - h10, h10);
+            const float gy = __builtin_fmaf(fy_, b2 - t2, t2);
+            // Jacobian row, residual, weight (fcaf_stage_b; interior, so no out-of-bounds case)
+            FcaPix o;
+            const float A = v_hfx * gx, B = v_hfy * gy;
+            const float T = __builtin_fmaf(A, pj, B * qq);
+            const float d = dd[j];
+            o.J[0] = __builtin_fmaf(qq, T, B);   // -J[0]
+            o.J[1] = __builtin_fmaf(pj, T, A);
+            o.J[2] = __builtin_fmaf(B, pj, -(A * qq));
+            o.J[3] = A * d;
+            o.J[4] = B * d;
+            o.J[5] = d * T;                      // -J[5]
+            const float Ikf = (j == 0) ? cvt_ubyte<0>(cI) : (j == 1) ? cvt_ubyte<1>(cI) : (j == 2) ? cvt_ubyte<2>(cI) : cvt_ubyte<3>(cI);
+            const float res = I - Ikf;
+            // d(residual)/d(inverse depth) = (gx2 n0 + gy2 n1) rz^2 / 2 with n0 = P3 pz - P11 px = pz (P3 - P11 x1), n1 likewise, pz rz = 1:
+            const float drpdd = hrz[j] * __builtin_fmaf(gx, __builtin_fmaf(-vP11, x1[j], vP3), gy * __builtin_fmaf(-vP11, y1[j], vP7));
+            const float D = __builtin_fmaf(var[j] * drpdd, drpdd, 16.0f);
+            const float r = __builtin_amdgcn_rsqf(D);
+            o.wgt = __builtin_amdgcn_fmed3f(r * r, r * (1.5f * __builtin_amdgcn_rcpf(fabsf(res))), 0.0f);
+            o.residual = res;
+            if (active && fit && vv[j]) fca_accumulate_pixel(acc, o);
+            pj += v_rfx;
+            __builtin_amdgcn_sched_barrier(0);   // one pixel after the other: interleaved, the four second halves do not fit the registers
+          }
+          // a quad that does not fit: its pixels join the wave's queue
+          const bool nofit = active && !fit;
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(nofit) != 0ull, 0)) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              // (tap_general: a point with x < 0, x >= cols, y < 0 or y >= rows — or a NaN — has none of its four taps in bounds and adds
+              // nothing to any sum: not queued)
+              const bool inside = (x1[j] >= 0.0f) & (x1[j] < (float)cols) & (y1[j] >= 0.0f) & (y1[j] < (float)g.rows);
+              const bool push = nofit && vv[j] && inside;
+              const unsigned long long m = __builtin_amdgcn_ballot_w64(push);
+              if (push) q[qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = i4 + (unsigned)j;
+              qn += __builtin_popcountll(m);
+            }
+#ifdef ELLC_QUAD_STATS
+            if (lane == 0) atomicAdd(&g_quad_stats[1], (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(nofit)));
+#endif
+          }
+#ifdef ELLC_QUAD_STATS
+          { const unsigned long long ma = __builtin_amdgcn_ballot_w64(active); if (lane == 0) atomicAdd(&g_quad_stats[0], (unsigned long long)__builtin_popcountll(ma)); }
+#endif
+          xq = xn; y = yn; i = in_;
+        }
+        // the queue: 64 at a time through the per-pixel step while the chunk lasts, then what is left
+#ifdef ELLC_X_NODRAIN
+        qn = 0;
+#endif
+        while (__builtin_expect(qn >= (more ? 64 : 1), 0)) {   // (cold: what the register allocator must spill, it spills here)
+          const int n = min(qn, 64);
+          __builtin_amdgcn_wave_barrier();
+          const unsigned idx = q[qn - n + min(lane, n - 1)];   // (a lane without an entry runs on a copy of the last one and accumulates nothing)
+          __builtin_amdgcn_wave_barrier();
+          qn -= n;
+          int yy = (int)(((float)idx + 0.5f) * (1.0f / (float)cols));
+          if (yy * cols > (int)idx) yy--;
+          if ((yy + 1) * cols <= (int)idx) yy++;
+          const int xx = (int)idx - yy * cols;
+          const DensePix dp = dense_request(K, idx, (unsigned)(yy * sw + xx));
+          bool valid;
+          const FcaInF rec = dense_form(g, dp, xx, yy, valid);
+          const FcafConst fc = fcaf_const(g, S);   // (vector copies of the constants, made here: the main loop keeps them scalar)
+          const FcafStage st = fcaf_stage_a(g, tr, fc, rec);
+          if (lane < n && valid) fca_accumulate_pixel(acc, fcaf_stage_b<false, 0>(a, K, g, cur, fc, idx, st));
+#ifdef ELLC_QUAD_STATS
+          if (lane == 0) { atomicAdd(&g_quad_stats[2], (unsigned long long)n); atomicAdd(&g_quad_stats[3], 1ull); }
+#endif
+        }
+        if (!more) break;
+      }
+    }
+    fca_acc_unpack<true>(acc, sums);
+  }
+  float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
+  block_reduce_store<27>(sums, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // State-driven form of the fused FCA schedule, for contexts with the reference's early exit on (ImageFunc.cpp:251-252). A
 // launch of gn_fca_fused is bound to a level when the schedule is captured: with early exit most of the 32 launches find
 // their level already ended and return at once, but each still costs a dependent launch (about 4.5 us; 17 of 32 for a
