@@ -174,8 +174,13 @@ class Workload:
     """G slot groups of B keyframes + one frame each, resident on the device; step s works on group s % G."""
 
     def __init__(self, api, a, scenes, arith, dev_index, W=None, H=None, L=None, B=None, sched=None, early_exit=None, G=None, shared_frame=True,
-                 coalesce=None, prime=None, share_kf=False, cache_records=0):
+                 coalesce=None, prime=None, share_kf=False, cache_records=0, diag=False, upload_groups=None):
+        """diag: the context lives in libellc_hip_diag.so (the measurement hooks of include/ellc_abi_diag.h; same kernels, same launch
+        paths, same configuration, hence the same grids) with only the first upload_groups slot groups filled and nothing rehearsed:
+        what level0_kernel() times the dominant kernel on."""
         self.api = api
+        self._init_args = dict(a=a, scenes=scenes, arith=arith, dev_index=dev_index, W=W, H=H, L=L, B=B, sched=sched, early_exit=early_exit, G=G,
+                               shared_frame=shared_frame, coalesce=coalesce, share_kf=share_kf, cache_records=cache_records)
         self.W, self.H, self.L = W or a.width, H or a.height, L or a.levels
         self.B = B or a.batch
         self.coalesce = max(1, min(4, a.coalesce if coalesce is None else coalesce))
@@ -188,9 +193,9 @@ class Workload:
                                       max_iter=self.sched, max_keyframes=G * B, max_frames=(G if shared_frame else G * B), max_batch=B, device=dev_index,
                                       concurrent_batches=G, coalesce=self.coalesce, cache_records=int(cache_records),
                                       arith=api.ARITH_FAST if arith == "fast" else api.ARITH_EXACT)
-        self.ctx = api.Context(self.cfg)
+        self.ctx = api.Context(self.cfg, diag=diag)
         self.mode = api.MODE_FCA if a.mode == "fca" else api.MODE_ICA
-        for g in range(G):
+        for g in range(G if upload_groups is None else min(G, upload_groups)):
             if shared_frame:
                 self.ctx.frame_upload(g, scenes[0]["cur_image"])
             for b in range(B):
@@ -206,8 +211,9 @@ class Workload:
         self.fr = [np.full(B, g, np.int32) if shared_frame else self.kf[g] for g in range(G)]
         # set-up, not warm-up: launch sequences are captured into hipGraphs on first use, one per (buffer set, batches in the group);
         # a rehearsal of the step counts that will be run captures every one the measured runs replay (like the uploads above)
-        for n in sorted(set([G] + [int(x) for x in (prime or []) if x > 0])):
-            self.run(n)
+        if not diag:
+            for n in sorted(set([G] + [int(x) for x in (prime or []) if x > 0])):
+                self.run(n)
 
     def run(self, nsteps, on_fetch=None):
         """nsteps steps, software-pipelined through the asynchronous API: up to G batches in flight, each on its own stream and
@@ -231,15 +237,30 @@ class Workload:
         self.ctx.sync()
         return time.perf_counter() - t0, pose, iters
 
+    def diag_twin(self):
+        """This workload's twin in libellc_hip_diag.so (the shipping library exports no measurement hooks): same configuration — so
+        the same grids and launches — and the same scenes in the slot groups of one launch group."""
+        if self.ctx.diag:
+            return self
+        if getattr(self, "_twin", None) is None:
+            self._twin = Workload(self.api, diag=True, upload_groups=min(self.coalesce, self.G), **self._init_args)
+        return self._twin
+
     def level0_kernel(self, reps=50):
-        """The level-0 launch as the timed region issues it: over the alignments of one launch group (coalesce batches side by side)."""
+        """The level-0 launch as the timed region issues it: over the alignments of one launch group (coalesce batches side by side).
+        HIP events on the library's stream around a replayed graph of `reps` launches (ellc_profile_gn_kernel, include/ellc_abi_diag.h)."""
+        tw = self.diag_twin()
         k = min(self.coalesce, self.G)
-        ms, alg, V = self.ctx.profile_gn_kernel(np.concatenate(self.kf[:k]), np.concatenate(self.fr[:k]), 0, reps=reps)
+        ms, alg, V = tw.ctx.profile_gn_kernel(np.concatenate(self.kf[:k]), np.concatenate(self.fr[:k]), 0, reps=reps)
         gbps = alg / (ms * 1e-3) / 1e9
         return {"avg_launch_ms": ms, "alignments_per_launch": int(k * self.B), "algorithmic_bytes_per_launch": alg, "valid_pixels_per_launch": V,
-                "achieved": gbps, "frac": gbps / PEAK_GBPS, "valid_pixel_rate_Gpx_s": V / (ms * 1e-3) / 1e9}
+                "achieved": gbps, "frac": gbps / PEAK_GBPS, "valid_pixel_rate_Gpx_s": V / (ms * 1e-3) / 1e9,
+                "measured_in": "libellc_hip_diag.so (same sources + the measurement hooks; the shipping library exports none)"}
 
     def close(self):
+        if getattr(self, "_twin", None) is not None:
+            self._twin.close()
+            self._twin = None
         self.ctx.close()
 
 
@@ -460,7 +481,7 @@ def main():
             out["roofline"]["frac_profile"] = out["roofline"]["profile"]["frac"]
         # what a kernel that only reads reaches on this box (2 GiB, 16-byte lanes, far larger than the 256 MB Infinity Cache)
         cal_bytes = 2 << 30
-        cal_ms = wl.ctx.profile_stream_read(cal_bytes, reps=5)
+        cal_ms = wl.diag_twin().ctx.profile_stream_read(cal_bytes, reps=5)
         out["roofline"]["measured_stream_read_GBps"] = cal_bytes / (cal_ms * 1e-3) / 1e9
         if world == 1 and not a.no_extras:
             # ---- spread: further blocks of --steps steps, each bracketed like the timed region
@@ -639,7 +660,7 @@ def depth_kernels(api, synth, dev_index):
     pair = synth.make_pair(W, H, seed=31, rot=0.006, trans=0.03)
     fx, fy, cx, cy = pair["intrinsics"]
     st = synth.make_depth_state(W, H, 9, pair["kf_image"], pair["idepth_true"])
-    ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, max_keyframes=2, max_frames=1, device=dev_index))
+    ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, max_keyframes=2, max_frames=1, device=dev_index), diag=True)   # (ellc_profile_depth_stage)
     ctx.keyframe_upload(0, pair["kf_image"]); ctx.frame_upload(0, pair["cur_image"]); ctx.keyframe_from_frame(1, 0)
     xi = pair["xi_true"]
     n = W * H

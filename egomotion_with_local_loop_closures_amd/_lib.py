@@ -20,11 +20,18 @@ ABI_SYMBOLS = [
     "ellc_align_fetch", "ellc_gn_iterate", "ellc_gn_display_planes", "ellc_concatenate_relative_pose", "ellc_concatenate_origin_pose", "ellc_se3_exp",
     "ellc_se3_log", "ellc_depth_set_state", "ellc_depth_get_state", "ellc_depth_set_keyframe", "ellc_depth_propagate",
     "ellc_depth_observe", "ellc_depth_fill_holes", "ellc_depth_regularize", "ellc_depth_make_inv_depth_one", "ellc_depth_regularize_fill_regularize", "ellc_depth_do_regularization",
-    "ellc_depth_update_depth_image", "ellc_depth_create_keyframe", "ellc_depth_seeds", "ellc_track_frame", "ellc_profile_gn_kernel", "ellc_profile_align",
-    "ellc_profile_calibrate_read", "ellc_profile_stream_read", "ellc_histogram", "ellc_kl_divergence", "ellc_copy_slot", "ellc_copy_slot_across", "ellc_selftest_div_pair",
-    "ellc_ingest_configure", "ellc_frame_ingest_bgr", "ellc_selftest_lu", "ellc_profile_depth_stage",
+    "ellc_depth_update_depth_image", "ellc_depth_create_keyframe", "ellc_depth_seeds", "ellc_track_frame",
+    "ellc_histogram", "ellc_kl_divergence", "ellc_copy_slot", "ellc_copy_slot_across",
+    "ellc_ingest_configure", "ellc_frame_ingest_bgr",
     "ellc_shard_range", "ellc_comm_unique_id", "ellc_comm_init_rccl", "ellc_comm_init_tcp", "ellc_comm_destroy", "ellc_comm_last_error",
     "ellc_gather_start", "ellc_gather_finish", "ellc_gather_results",
+]
+
+
+# what include/ellc_abi_diag.h adds (measurement hooks, device self-tests, test hooks): exported by libellc_hip_diag.so only
+DIAG_SYMBOLS = [
+    "ellc_profile_gn_kernel", "ellc_profile_align", "ellc_profile_depth_stage", "ellc_profile_calibrate_read", "ellc_profile_stream_read",
+    "ellc_selftest_div_pair", "ellc_selftest_lu", "ellc_debug_persist_delay", "ellc_debug_set_persist_epoch", "ellc_debug_persist_counters",
 ]
 
 
@@ -73,28 +80,47 @@ def comm_lib():
 
 
 _lib = None
+_diag = None
+DIAG_SO_PATH = os.path.join(CSRC, "libellc_hip_diag.so")   # the same sources built with -DELLC_DIAG_ABI (csrc/Makefile)
 
 
 def use_library(path):
-    """Diagnostic tools only (tools/*.py with build/libellc_hip_diag.so or ..._stamps.so): load this build instead of the
-    shipping library. Must be called before the first lib(); the path is explicit, never taken from the environment."""
-    global SO_PATH
-    if _lib is not None:
+    """Diagnostic tools only (tools/*.py with an A/B variant, build/libellc_hip_envdiag.so or ..._stamps.so — all built with the
+    diagnostic ABI): load this build instead of the in-tree libraries, for the product entry points and the diagnostic ones
+    alike. Must be called before the first lib() / diag_lib(); the path is explicit, never taken from the environment."""
+    global SO_PATH, DIAG_SO_PATH
+    if _lib is not None or _diag is not None:
         raise EllcError("use_library: the library is already loaded")
-    SO_PATH = os.path.abspath(path)
+    SO_PATH = DIAG_SO_PATH = os.path.abspath(path)
+
+
+def _bind(path, symbols, what):
+    if not os.path.exists(path):
+        raise EllcError("%s is not built (%s). Run __graft_entry__.build() / make -C %s; "
+                        "there is no CPU fallback for the product path." % (what, path, CSRC))
+    h = C.CDLL(path)
+    h.ellc_last_error.restype = C.c_char_p
+    h.ellc_stream.restype = C.c_void_p
+    h.ellc_kl_divergence.restype = C.c_double
+    h.ellc_comm_last_error.restype = C.c_char_p
+    for name in symbols:
+        getattr(h, name)  # raises AttributeError if the library does not export it
+    return h
+
+
+def diag_lib():
+    """libellc_hip_diag.so: everything lib() has plus include/ellc_abi_diag.h (bench.py's roofline leg, tools/, self-tests)."""
+    global _diag
+    if _diag is None:
+        if DIAG_SO_PATH == SO_PATH:   # use_library(): one build serves both (an A/B build of an older revision may lack the newer hooks)
+            _diag = lib()
+        else:
+            _diag = _bind(DIAG_SO_PATH, ABI_SYMBOLS + DIAG_SYMBOLS, "libellc_hip_diag.so")
+    return _diag
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(SO_PATH):
-            raise EllcError("libellc_hip.so is not built (%s). Run __graft_entry__.build() / make -C %s; "
-                            "there is no CPU fallback for the product path." % (SO_PATH, CSRC))
-        _lib = C.CDLL(SO_PATH)
-        _lib.ellc_last_error.restype = C.c_char_p
-        _lib.ellc_stream.restype = C.c_void_p
-        _lib.ellc_kl_divergence.restype = C.c_double
-        _lib.ellc_comm_last_error.restype = C.c_char_p
-        for name in ABI_SYMBOLS:
-            getattr(_lib, name)  # raises AttributeError if the library does not export it
+        _lib = _bind(SO_PATH, ABI_SYMBOLS, "libellc_hip.so")
     return _lib

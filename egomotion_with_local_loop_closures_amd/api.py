@@ -28,14 +28,20 @@ def default_config(width, height, levels=4, **kw):
     return cfg
 
 
+default_diag = False   # tools/diaglib.py sets it: tools create their contexts in the diagnostic library
+
+
 class Context:
     """Resident keyframe / frame slots, one depth map and an in-order queue of work on the GPU (ellc_ctx); up to three
     alignment batches may be in flight at once (align_enqueue / align_fetch) — 4 x cfg.coalesce with cfg.coalesce > 1, where
     full batches enqueued one after the other run side by side in one launch sequence."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, diag=None):
+        """diag=True: the context lives in libellc_hip_diag.so (include/ellc_abi_diag.h: profile_* / selftest_* / debug_* below) — the
+        same kernels and launch paths as the shipping library, which does not export those hooks."""
         self.cfg = cfg
-        self._l = _lib.lib()
+        self.diag = default_diag if diag is None else bool(diag)
+        self._l = _lib.diag_lib() if self.diag else _lib.lib()
         h = C.c_void_p()
         st = self._l.ellc_ctx_create(C.byref(cfg), C.byref(h))
         self.h = h
@@ -294,8 +300,27 @@ class Context:
     def copy_slot(self, dst_is_kf, dst, src_is_kf, src):
         self._ck(self._l.ellc_copy_slot(self.h, int(dst_is_kf), dst, int(src_is_kf), src), "ellc_copy_slot")
 
-    # ---- measurement hooks
+    # ---- measurement hooks, self-tests, test hooks: contexts created with diag=True only (include/ellc_abi_diag.h)
+    def _need_diag(self, what):
+        if not self.diag and _lib.DIAG_SO_PATH != _lib.SO_PATH:
+            raise EllcError("%s is a diagnostic entry point (include/ellc_abi_diag.h): create the context with diag=True" % what)
+
+    def debug_persist_delay(self, first_block, polls):
+        self._need_diag("ellc_debug_persist_delay")
+        self._ck(self._l.ellc_debug_persist_delay(self.h, int(first_block), int(polls)), "ellc_debug_persist_delay")
+
+    def debug_set_persist_epoch(self, epoch):
+        self._need_diag("ellc_debug_set_persist_epoch")
+        self._ck(self._l.ellc_debug_set_persist_epoch(self.h, C.c_uint(epoch)), "ellc_debug_set_persist_epoch")
+
+    def debug_persist_counters(self):
+        self._need_diag("ellc_debug_persist_counters")
+        a = C.c_longlong(0); b = C.c_longlong(0); r = C.c_longlong(0)
+        self._ck(self._l.ellc_debug_persist_counters(self.h, C.byref(a), C.byref(b), C.byref(r)), "ellc_debug_persist_counters")
+        return a.value, b.value, r.value
+
     def profile_gn_kernel(self, kf_slots, frame_slots, level, reps=20):
+        self._need_diag("ellc_profile_gn_kernel")
         B, kf, fr, _ = self._batch(kf_slots, frame_slots, None)
         ms = C.c_float(0); by = C.c_double(0); v = C.c_longlong(0)
         self._ck(self._l.ellc_profile_gn_kernel(self.h, B, _p(kf), _p(fr), level, reps, C.byref(ms), C.byref(by), C.byref(v)),
@@ -303,18 +328,21 @@ class Context:
         return ms.value, by.value, v.value
 
     def selftest_div_pair(self, a, b):
+        self._need_diag("ellc_selftest_div_pair")
         a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
         qp = np.zeros_like(a); qr = np.zeros_like(a)
         self._ck(self._l.ellc_selftest_div_pair(self.h, int(a.size), _p(a), _p(b), _p(qp), _p(qr)), "ellc_selftest_div_pair")
         return qp, qr
 
     def selftest_lu(self, tri21):
+        self._need_diag("ellc_selftest_lu")
         tri21 = np.ascontiguousarray(tri21, np.float64).reshape(-1, 21)
         out = np.zeros((tri21.shape[0], 6, 6), np.float32)
         self._ck(self._l.ellc_selftest_lu(self.h, int(tri21.shape[0]), _p(tri21), _p(out)), "ellc_selftest_lu")
         return out
 
     def profile_calibrate_read(self, nbytes, reps=10):
+        self._need_diag("ellc_profile_calibrate_read")
         ms = C.c_float(0)
         self._ck(self._l.ellc_profile_calibrate_read(self.h, C.c_size_t(nbytes), reps, C.byref(ms)), "ellc_profile_calibrate_read")
         return ms.value
@@ -323,17 +351,20 @@ class Context:
         """ms per call of one depth-map stage (0 regularize, 1 fill holes, 2 observe, 3 update depth image, 4 createKeyFrame's
         regularise + fill + regularise in one launch, 5 the tracked frame's fill + regularise + update depth image in one launch),
         HIP events."""
+        self._need_diag("ellc_profile_depth_stage")
         pose = np.ascontiguousarray(pose, np.float32)
         ms = C.c_float(0)
         self._ck(self._l.ellc_profile_depth_stage(self.h, stage, frame_slot, _p(pose), reps, C.byref(ms)), "ellc_profile_depth_stage")
         return ms.value
 
     def profile_stream_read(self, nbytes, reps=10):
+        self._need_diag("ellc_profile_stream_read")
         ms = C.c_float(0)
         self._ck(self._l.ellc_profile_stream_read(self.h, C.c_size_t(nbytes), reps, C.byref(ms)), "ellc_profile_stream_read")
         return ms.value
 
     def profile_align(self, kf_slots, frame_slots, init_pose=None, mode=MODE_FCA, reps=5):
+        self._need_diag("ellc_profile_align")
         B, kf, fr, ip = self._batch(kf_slots, frame_slots, init_pose)
         ms = C.c_float(0)
         self._ck(self._l.ellc_profile_align(self.h, B, _p(kf), _p(fr), _p(ip), mode, reps, C.byref(ms)), "ellc_profile_align")
@@ -342,9 +373,11 @@ class Context:
 
 def copy_slot_across(dst_ctx, dst_is_kf, dst, src_ctx, src_is_kf, src):
     """ellc_copy_slot_across: a slot's planes from one context into another on the same device (the loop-closure ring's deep copy)."""
-    st = _lib.lib().ellc_copy_slot_across(dst_ctx.h, int(dst_is_kf), dst, src_ctx.h, int(src_is_kf), src)
+    if dst_ctx._l is not src_ctx._l:
+        raise EllcError("ellc_copy_slot_across: the two contexts live in different libraries")
+    st = dst_ctx._l.ellc_copy_slot_across(dst_ctx.h, int(dst_is_kf), dst, src_ctx.h, int(src_is_kf), src)
     if st != 0:
-        raise EllcError("ellc_copy_slot_across -> %d: %s" % (st, _lib.lib().ellc_last_error(dst_ctx.h).decode()))
+        raise EllcError("ellc_copy_slot_across -> %d: %s" % (st, dst_ctx._l.ellc_last_error(dst_ctx.h).decode()))
 
 
 def concatenate_relative_pose(a, b):

@@ -7,6 +7,9 @@
 #include <map>
 #include <tuple>
 #include "../../include/ellc_abi.h"
+#ifdef ELLC_DIAG_ABI
+#include "../../include/ellc_abi_diag.h"
+#endif
 #include "ellc_device.hpp"
 
 namespace ellc {
@@ -136,6 +139,9 @@ struct ellc_ctx {
   unsigned persist_spin_limit = 1u << 15;           // polls of a missing record before gn_fca_persist gives a launch up (0: at once — test hook)
   unsigned prep_tag = 0;                            // tag of the last compaction without a count launch (PrepArgs::lb_tag)
   unsigned persist_epoch = 0;                       // calls of gn_fca_persist so far (tags of its partial records)
+  int persist_delay_from = 0, persist_delay_polls = 0;   // test hook (ellc_debug_persist_delay): blocks from this index on start late
+  int persist_backoff = 0;                          // calls that still run as launches after a resident launch had to be abandoned
+  long long persist_launches = 0, persist_abandoned = 0;   // resident launches so far / those the host had to finish with launches
   int persist_capacity = 0;                         // blocks of gn_fca_persist the device holds at once (occupancy x CUs)
   bool cur_resident = false;                        // the schedule being enqueued is the resident form
   bool use_persist = true;                          // the state-driven schedule as one resident launch (gn_fca_persist)

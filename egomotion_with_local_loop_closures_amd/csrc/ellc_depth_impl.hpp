@@ -465,6 +465,7 @@ ellc_status ellc_depth_create_keyframe(ellc_ctx* c, int new_kf_slot, const float
   return s;
 }
 
+#ifdef ELLC_DIAG_ABI
 // measurement hook (bench.py): `reps` enqueues of one depth-map stage between two HIP events on the context's stream.
 // stage 0: regularizeDepthMap(false), 1: fillDepthHoles, 2: observeDepthRow against frame_slot / pose, 3: updateDepthImage
 // (export + depth / variance pyramid), 4: createKeyFrame's regularise + fill + regularise in one launch, 5: the tracked frame's
@@ -495,6 +496,7 @@ ellc_status ellc_profile_depth_stage(ellc_ctx* c, int stage, int frame_slot, con
   if (avg_ms) *avg_ms = ms / reps;
   return ELLC_OK;
 }
+#endif   // ELLC_DIAG_ABI
 
 ellc_status ellc_depth_seeds(ellc_ctx* c, float* percent) {
   ELLC_ENTER(c);

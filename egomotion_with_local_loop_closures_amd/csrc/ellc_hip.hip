@@ -585,6 +585,25 @@ static void set_track_fields(const ellc_ctx* c, FusedArgs& fa, bool continuation
 // the two forms, and a schedule that starts in one and is finished in the other, give the same bits. (Measured with the counts
 // capped at 32 / 64 / 128 / 256 blocks, one early-exit alignment 640x480, fast: 0.120 / 0.116 / 0.115 / 0.117 ms against 0.128 with
 // launches; exact 0.171 / 0.161 / 0.156 / 0.158 against 0.164; tracked frame 0.208 / 0.192 / 0.188 / 0.190 against 0.205.)
+// true: the batch's launch sequence is launched kernel by kernel; false: replayed from a captured graph
+static bool launches_directly(const ellc_ctx* c, int mode, int B) {
+  return !c->use_graph || (!c->graph_adaptive && (schedule_is_adaptive(c, mode, B) || B <= c->direct_max_batch));
+}
+// rounds of a resident launch: every iteration, a round per level change, the first and the last
+static int persist_rounds(const ellc_ctx* c) { return schedule_total_iters(c) + c->L + 2; }
+// May this call's state-driven schedule run as ONE resident launch? The round travels in the low byte of the records' tags
+// (call epoch << 8 | round): a schedule of more than 255 rounds would carry into the epoch and make round 256 + k of one call
+// the twin of round k of the next (cfg.max_iter has no upper bound) — such a schedule runs as launches. Not while a hipGraph is
+// being captured either (diagnostic builds, ELLC_GRAPH_ADAPTIVE): a replay would repeat the epoch baked into its arguments, and
+// with it every tag. And not for a while after a launch had to be abandoned (persist_backoff: another context or process holds
+// part of the device; each attempt costs a poll limit).
+static bool may_run_resident(ellc_ctx* c, int mode, int B) {
+  if (!(c->use_persist && B <= 2 && schedule_is_adaptive(c, mode, B))) return false;
+  if (persist_rounds(c) > 255) return false;
+  if (!launches_directly(c, mode, B)) return false;
+  if (c->persist_backoff > 0) { c->persist_backoff--; return false; }
+  return true;
+}
 // blocks a resident launch of B alignments needs on the device at once
 static int persist_blocks(ellc_ctx* c, int B) {
   int G = 1;
@@ -615,16 +634,17 @@ static ellc_status enqueue_schedule_persist(ellc_ctx* c, int B, int save_weights
   }
   fa.nblk_grid = G;
   fa.persist_bar = c->persist_bar_d;
-  const int max_rounds = schedule_total_iters(c) + c->L + 2;
-  const unsigned epoch = (++c->persist_epoch) & 0xffffffu;   // the records of earlier calls never match (the round sits in the low byte)
+  const int max_rounds = persist_rounds(c);   // <= 255 (may_run_resident)
+  const unsigned epoch = (++c->persist_epoch) & 0xffffffu;
+  c->persist_launches++;   // the records of earlier calls never match (the round sits in the low byte)
   const dim3 grd(G, B), blk(ELLC_GN_THREADS);
   if (c->fast) {
-    if (save_weights) hipLaunchKernelGGL((gn_fca_persist<false, true, 1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit);
-    else hipLaunchKernelGGL((gn_fca_persist<false, true, 0>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit);
+    if (save_weights) hipLaunchKernelGGL((gn_fca_persist<false, true, 1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls);
+    else hipLaunchKernelGGL((gn_fca_persist<false, true, 0>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls);
   } else if (c->geom_h[0].divc_ok) {
-    hipLaunchKernelGGL((gn_fca_persist<true, false, -1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit);
+    hipLaunchKernelGGL((gn_fca_persist<true, false, -1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls);
   } else {
-    hipLaunchKernelGGL((gn_fca_persist<false, false, -1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit);
+    hipLaunchKernelGGL((gn_fca_persist<false, false, -1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls);
   }
   // (no finish kernel: the launch's first block per alignment has written the final record, the result and the tracking fields)
   if (save_weights) launch_add_saved_weights(c, B);
@@ -1064,9 +1084,15 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
     // blocks of the resident schedule (gn_fca_persist) this device holds at once: a launch of more could never become resident
     // (a partition of the device, e.g. one XCD's 32 CUs) and is not attempted
     if (cus > 0) {
-      int per_cu = 0;
-      const hipError_t oe = c->fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_fca_persist<false, true, 1>, ELLC_GN_THREADS, 0)
-                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_fca_persist<false, false, -1>, ELLC_GN_THREADS, 0);
+      // (the smaller occupancy of the two variants this context may launch: with / without saved weights, with / without the
+      // verified division by a constant)
+      int per_cu = 0, per_cu2 = 0;
+      hipError_t oe = c->fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_fca_persist<false, true, 1>, ELLC_GN_THREADS, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_fca_persist<false, false, -1>, ELLC_GN_THREADS, 0);
+      if (oe == hipSuccess)
+        oe = c->fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, gn_fca_persist<false, true, 0>, ELLC_GN_THREADS, 0)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, gn_fca_persist<true, false, -1>, ELLC_GN_THREADS, 0);
+      per_cu = std::min(per_cu, per_cu2);
       c->persist_capacity = (oe == hipSuccess && per_cu > 0) ? per_cu * cus : 0;
       if (oe != hipSuccess) (void)hipGetLastError();
     }
@@ -1140,6 +1166,37 @@ ellc_status ellc_ctx_set_persistent_schedule(ellc_ctx* c, int mode) {
   c->adaptive_hint = 0;
   return ELLC_OK;
 }
+
+#ifdef ELLC_DIAG_ABI
+// test hooks of the resident schedule (include/ellc_abi_diag.h; libellc_hip_diag.so only)
+ellc_status ellc_debug_persist_delay(ellc_ctx* c, int first_block, int polls) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  ELLC_ENTER(c);
+  if (first_block < 0 || polls < 0 || polls > (1 << 16)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_debug_persist_delay: first_block >= 0, 0 <= polls <= 65536");
+  c->persist_delay_from = first_block;
+  c->persist_delay_polls = polls;
+  return ELLC_OK;
+}
+ellc_status ellc_debug_set_persist_epoch(ellc_ctx* c, unsigned epoch) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  ELLC_ENTER(c);
+  c->persist_epoch = epoch;
+  return ELLC_OK;
+}
+ellc_status ellc_debug_persist_counters(ellc_ctx* c, long long* resident_launches, long long* abandoned_launches, long long* rejoined_blocks) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  ELLC_ENTER(c);
+  if (resident_launches) *resident_launches = c->persist_launches;
+  if (abandoned_launches) *abandoned_launches = c->persist_abandoned;
+  if (rejoined_blocks) {   // (device-wide, since the library was loaded)
+    unsigned long long v = 0;
+    ELLC_HIP(c, hipDeviceSynchronize());
+    ELLC_HIP(c, hipMemcpyFromSymbol(&v, HIP_SYMBOL(ellc::g_persist_adoptions), sizeof(v)));
+    *rejoined_blocks = (long long)v;
+  }
+  return ELLC_OK;
+}
+#endif   // ELLC_DIAG_ABI
 
 ellc_status ellc_ctx_set_grid_batch(ellc_ctx* c, int n) {
   ELLC_ENTER_BATCH(c);
@@ -1496,10 +1553,6 @@ static bool runs_dense(const ellc_ctx* c, int mode, int B, int save_weights) {
   return c->fast && c->use_fused && mode == ELLC_MODE_FCA && !save_weights && !schedule_is_adaptive(c, mode, B);
 }
 
-// true: the batch's launch sequence is launched kernel by kernel; false: replayed from a captured graph
-static bool launches_directly(const ellc_ctx* c, int mode, int B) {
-  return !c->use_graph || (!c->graph_adaptive && (schedule_is_adaptive(c, mode, B) || B <= c->direct_max_batch));
-}
 
 // Enqueues the launch sequence of one batch on c->stream — replayed from a hipGraph captured on first use, keyed by
 // (B, unique keyframes, mode, save_weights, batch set, part). continuation: the rest of a state-driven schedule whose first
@@ -1604,6 +1657,10 @@ static ellc_status resolve_batch(ellc_ctx* c, int set) {
   bool unfinished = false;
   for (int b = 0; b < bs.B; b++) unfinished = unfinished || (bs.result_h[b].pad == 1);
   if (!unfinished) return ELLC_OK;
+  if (bs.resident) {   // a resident launch that was abandoned: the next calls do not try again at once (may_run_resident)
+    c->persist_abandoned++;
+    if (c->persist_spin_limit != 0u) c->persist_backoff = 16;   // (0: the test hook that abandons every launch on purpose)
+  }
   const int selected = c->cur_set;
   select_batch_set(c, set);
   c->cur_adaptive_first = bs.adaptive_first;
@@ -1708,7 +1765,7 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
   // streams: 0.189 against 0.102 ms per batch). Same bits either way. Launches of other contexts or processes are not known here:
   // against those the abandoned launch and its continuation are the safety net.
   c->cur_resident = false;
-  if (c->use_persist && B <= 2 && schedule_is_adaptive(c, bs.mode, B)) {
+  if (may_run_resident(c, bs.mode, B)) {
     bool alone = true;
     for (int p = 0; p < ellc_ctx::SETS; p++)
       if (p != set && c->batch_set[p].launched && !c->batch_set[p].resolved) alone = false;
@@ -1773,7 +1830,7 @@ static ellc_status align_enqueue_impl(ellc_ctx* c, int B, const int* kf_slots, c
     ellc_status s = stage_batch(c, B, kf_slots, frame_slots, init_pose, &nu);
     if (s != ELLC_OK) return s;
     for (int b = 0; b < B; b++) invalidate_records(c, kf_slots[b]);   // rebuilt here, outside the cache's bookkeeping
-    c->cur_resident = c->use_persist && B <= 2 && schedule_is_adaptive(c, mode, B) && persist_blocks(c, B) <= c->persist_capacity;   // (nothing in flight)
+    c->cur_resident = may_run_resident(c, mode, B) && persist_blocks(c, B) <= c->persist_capacity;   // (nothing in flight)
     c->cur_adaptive_first = adaptive_first_launches(c, B);
     bool dense = runs_dense(c, mode, B, save_weights);
     for (int b = 0; b < B; b++) dense = dense && c->kf_dense[kf_slots[b]];
@@ -2006,7 +2063,8 @@ void ellc_se3_log(const float* T16, float* pose6) {
   log_se3_f32(S, pose6);
 }
 
-// ---- measurement hooks -------------------------------------------------------------------------------
+// ---- measurement hooks and device self-tests: include/ellc_abi_diag.h, compiled into libellc_hip_diag.so only (-DELLC_DIAG_ABI) ----
+#ifdef ELLC_DIAG_ABI
 ellc_status ellc_profile_gn_kernel(ellc_ctx* c, int B, const int* kf_slots, const int* frame_slots, int level, int reps, float* avg_ms,
                                    double* algorithmic_bytes, long long* valid_pixels) {
   ELLC_ENTER(c);
@@ -2271,6 +2329,7 @@ ellc_status ellc_profile_stream_read(ellc_ctx* c, size_t bytes, int reps, float*
   if (avg_ms) *avg_ms = ms / reps;
   return ELLC_OK;
 }
+#endif   // ELLC_DIAG_ABI
 
 }  // extern "C"
 

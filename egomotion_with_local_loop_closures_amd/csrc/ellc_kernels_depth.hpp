@@ -1150,6 +1150,23 @@ __device__ __forceinline__ void wave_exp_se3_f32(const float* pose, float* S) {
     S[r * 4 + 3] = __shfl(Tf, 3 * r);
   }
 }
+// log as a real call with its operands in REGISTERS (twelve in, six out): through pointers the caller's arrays live in scratch, and a
+// kernel that calls it — gn_fca_persist, gn_fused_finish — carried 176 bytes of private memory per lane for this one call (r05 verdict)
+struct ObsF12 { float v[12]; };
+struct ObsF6 { float v[6]; };
+__device__ __attribute__((noinline)) ObsF6 obs_log_se3_regs(ObsF12 S) {
+  ObsF6 o;
+  log_se3_f32(S.v, o.v);
+  return o;
+}
+__device__ __forceinline__ void obs_log_se3_wave(const float* S, float* pose) {
+  ObsF12 a;
+#pragma unroll
+  for (int i = 0; i < 12; i++) a.v[i] = S[i];
+  const ObsF6 o = obs_log_se3_regs(a);
+#pragma unroll
+  for (int i = 0; i < 6; i++) pose[i] = o.v[i];
+}
 // build_obs_mats, every lane of the wave evaluating it on the same pose (the three exps through wave_exp_se3_f32)
 __device__ __forceinline__ void build_obs_mats_wave(const float* Kmat, const float* pose, ObsMats& m) {
   float rel[6], otw[12], two[12];
@@ -1157,7 +1174,7 @@ __device__ __forceinline__ void build_obs_mats_wave(const float* Kmat, const flo
     float B[12], Bi[12];
     wave_exp_se3_f32(pose, B);
     invert_f32(B, Bi);
-    obs_log_se3_f32(Bi, rel);
+    obs_log_se3_wave(Bi, rel);
   }
   wave_exp_se3_f32(rel, otw);
   invert_f32(otw, two);
@@ -1180,7 +1197,7 @@ __device__ __forceinline__ void build_obs_mats_wave(const float* Kmat, const flo
 __device__ void track_setup_wave(const float* pose, const float* Kmat, ObsMats* mats) {
   float pwo[6], E[12];
   wave_exp_se3_f32(pose, E);     // concat_relative_f32(pose, 0, pwo) = log(exp(pose) exp(0)): the product with the identity is exact
-  obs_log_se3_f32(E, pwo);
+  obs_log_se3_wave(E, pwo);
   ObsMats m;
   build_obs_mats_wave(Kmat, pwo, m);
   if ((threadIdx.x & 63) == 0) *mats = m;

@@ -2262,7 +2262,8 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
 // (gn_fca_adaptive): the same bits, also for a schedule that is abandoned here and finished there. Three blocks per CU in
 // the tolerance mode, two in the exact mode (launch bounds; the exact pixel loop inside this loop wants 226 registers and spills
 // cost it more than the launches it saves): 768 / 512 resident blocks hold three / two such launches of one alignment each.
-#define ELLC_PERSIST_BAR_WORDS 32   // per alignment: the abort word in a 128-byte line of its own
+#define ELLC_PERSIST_BAR_WORDS 64   // per alignment: the abort word in a 128-byte line of its own, then the state line (below)
+#define ELLC_PERSIST_STATE_WORD 32  //   first word of the state line
 #define ELLC_PERSIST_SPIN_LIMIT (1u << 15)   // polls (~1 us each with their s_sleep): a record normally arrives within tens
 // word of a tagged record that holds sum s (the last word of every 32-byte sector is the tag)
 __device__ __forceinline__ int persist_word_of(int s) { return s + s / 7; }
@@ -2291,8 +2292,14 @@ __device__ __forceinline__ void persist_store_record(float (&acc)[27], unsigned*
   }
 }
 // partial_group_sum over tagged records of the round `tag` names: the same fixed-order combine, every record taken only once
-// its four tags match. Returns false when the launch is being abandoned.
-__device__ __forceinline__ bool persist_group_sum(const unsigned* recs, int nblk, unsigned tag, unsigned* abortw, unsigned abort_tag, unsigned spin_limit, double& out) {
+// its four tags match. Returns PERSIST_OK, PERSIST_ABANDON when the launch is being abandoned, or PERSIST_LAPPED when a record's slot
+// already holds a LATER round of this call (same buffer, so two rounds on): the writers have gone on without this block, which can
+// only happen to a block that writes nothing at the level (nobody waits for its records) — see the state line in gn_fca_persist.
+enum { PERSIST_OK = 0, PERSIST_ABANDON = 1, PERSIST_LAPPED = 2 };
+#ifdef ELLC_DIAG_ABI
+__device__ unsigned long long g_persist_adoptions;   // blocks that were lapped and re-joined through the state line (ellc_debug_persist_counters)
+#endif
+__device__ __forceinline__ int persist_group_sum(const unsigned* recs, int nblk, unsigned tag, unsigned* abortw, unsigned abort_tag, unsigned spin_limit, double& out) {
   const int lane = threadIdx.x & 63, comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const bool is_tag = (comp & 7) == 7;
   const unsigned long long half = (lane < 32) ? 0x00000000ffffffffull : 0xffffffff00000000ull;
@@ -2302,7 +2309,7 @@ __device__ __forceinline__ bool persist_group_sum(const unsigned* recs, int nblk
   if (spin_limit == 0u) {   // test hook (ellc_debug_persist_spin_limit): abandon at the first record
     if (lane == 0) __hip_atomic_store(abortw, abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out = 0.0;
-    return false;
+    return PERSIST_ABANDON;
   }
   for (int base = 0; base < nblk; base += 8 * (ELLC_SOLVE_THREADS / 32)) {
     unsigned w[8];
@@ -2327,9 +2334,15 @@ __device__ __forceinline__ bool persist_group_sum(const unsigned* recs, int nblk
       if (__ballot(okm != 0xffu) == 0ull) break;
       __builtin_amdgcn_s_sleep(1);
       spins++;
+      if ((spins & 7u) == 0u) {   // (wave-uniform; off the path of a record that arrives in time) a slot that holds a later round of this call?
+        bool later = false;
+#pragma unroll
+        for (int j = 0; j < 8; j++) later |= !((okm >> j) & 1u) && is_tag && (w[j] >> 8) == (tag >> 8) && (w[j] & 0xffu) > (tag & 0xffu);
+        if (__ballot(later) != 0ull) { out = 0.0; return PERSIST_LAPPED; }
+      }
       if ((spins & 63u) == 0u) {   // (wave-uniform)
         if (spins > spin_limit && lane == 0) __hip_atomic_store(abortw, abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == abort_tag) { out = 0.0; return false; }
+        if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == abort_tag) { out = 0.0; return PERSIST_ABANDON; }
       }
     }
 #pragma unroll
@@ -2340,20 +2353,75 @@ __device__ __forceinline__ bool persist_group_sum(const unsigned* recs, int nblk
     }
   }
   out = s;
-  return true;
+  return PERSIST_OK;
+}
+
+// The state line of a resident launch: whenever a level ends, block 0 of the alignment publishes what every block's copy of the state
+// record holds at that point — pose, exp(pose), weightedPose, level_done, the round and the level that begins (-1: the schedule has
+// ended) — as one tagged 128-byte record (tag = call epoch << 8 | round, as the partial records). Nobody reads it in the normal
+// course of a launch. It is what a block that was LAPPED re-joins by: a block that writes no records at the current level (its
+// index is beyond the level's block count) is waited for by nobody, so if it is dispatched late or held up for two rounds the
+// records it wants are overwritten (r05 shipped that hole: such a block spun to the poll limit and abandoned the launch). It now
+// waits here for the next level's beginning instead, adopts the state and carries on — as a writer if the new level has work for
+// it: the writers of that level cannot pass its first round without its record, so the line it needs cannot be overwritten before
+// it has read it. Returns false when the launch is being abandoned.
+__device__ __forceinline__ void persist_publish_state(unsigned* line, unsigned tag, const SolveShared& sh, int seq, int next_level) {
+  if (threadIdx.x < 32) {
+    const int w = (int)threadIdx.x, sidx = w - (w >> 3);   // payload index of word w (the last word of every 32-byte sector is the tag)
+    unsigned v = 0u;
+    if ((w & 7) == 7) v = tag;
+    else if (sidx < 6) v = __builtin_bit_cast(unsigned, sh.newpose[sidx]);
+    else if (sidx < 18) v = __builtin_bit_cast(unsigned, sh.newS[sidx - 6]);
+    else if (sidx == 18) v = __builtin_bit_cast(unsigned, sh.weighted);
+    else if (sidx == 19) v = (unsigned)sh.level_done;
+    else if (sidx == 20) v = (unsigned)seq;
+    else if (sidx == 21) v = (unsigned)next_level;
+    __hip_atomic_store(line + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// wave 0 of a lapped block: waits for a state line of this call whose round is at least `seq`, leaves it in sh / s_seq / s_level
+__device__ __forceinline__ bool persist_adopt_state(const unsigned* line, unsigned epoch, int seq, unsigned* abortw, unsigned abort_tag, unsigned spin_limit,
+                                                    SolveShared& sh, int& s_seq, int& s_level) {
+  const int lane = threadIdx.x & 63, w = lane & 31, sidx = w - (w >> 3);
+  for (unsigned spins = 0;; spins++) {
+    const unsigned v = __hip_atomic_load(line + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool is_tag = (w & 7) == 7;
+    const unsigned t0 = (unsigned)__shfl((int)v, 7, 64);
+    const bool fresh = (t0 >> 8) == epoch && (int)(t0 & 0xffu) >= seq;
+    if (fresh && __ballot(is_tag && v != t0) == 0ull) {   // four equal tags of this call, not older than the round this block stands in
+      if (lane < 32 && !is_tag) {
+        if (sidx < 6) sh.newpose[sidx] = __builtin_bit_cast(float, v);
+        else if (sidx < 18) sh.newS[sidx - 6] = __builtin_bit_cast(float, v);
+        else if (sidx == 18) sh.weighted = __builtin_bit_cast(float, v);
+        else if (sidx == 19) sh.level_done = (int)v;
+        else if (sidx == 20) s_seq = (int)v;
+        else if (sidx == 21) s_level = (int)v;
+      }
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(2);
+    if ((spins & 63u) == 63u) {
+      if (spins > spin_limit && lane == 0) __hip_atomic_store(abortw, abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == abort_tag) return false;
+    }
+  }
 }
 
 template <bool FAST, bool ADAPT>
 __device__ __forceinline__ void fused_finish_body(const FusedArgs& fa, int b, const AlignState& src, AlignState* dst, SolveShared& sh);
 
 template <bool DIVC, bool FAST, int SAVEW>
-__global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(FusedArgs fa, int max_rounds, unsigned epoch, unsigned spin_limit) {
+__global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(FusedArgs fa, int max_rounds, unsigned epoch, unsigned spin_limit,
+                                                                              int delay_from, int delay_polls) {
   const GnArgs& a = fa.g;
   const int b = blockIdx.y, sub = blockIdx.x, t = threadIdx.x;
   __shared__ SolveShared sh;
   __shared__ AlignState st;   // this block's copy of the alignment's record (see above)
-  __shared__ int s_flag;
+  __shared__ int s_flag, s_seq, s_level;
   unsigned* abortw = fa.persist_bar + (size_t)b * ELLC_PERSIST_BAR_WORDS;
+  unsigned* state_line = abortw + ELLC_PERSIST_STATE_WORD;
+  if (delay_polls > 0 && sub >= delay_from)   // test hook (ellc_debug_persist_delay): these blocks start late, as if dispatched late
+    for (int i = 0; i < delay_polls; i++) __builtin_amdgcn_s_sleep(32);
   AlignState* rec = a.state + b;   // buffer 0: initialised by the staging kernel; the final record for gn_fused_finish
   {
     const uint32_t* sp = (const uint32_t*)rec;
@@ -2390,12 +2458,27 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(
       if (sub < nb_l && begin + t < end) first = fca_load<DIVC>(K, g, (unsigned)(begin + t));
       first_pre = fca_prepare<DIVC>(g, first);
     }
+    bool adopted = false;
     if (pending) {
       double group_sum;
-      if (!persist_group_sum(pend, nb_l, (epoch << 8) | (unsigned)seq, abortw, epoch | 0x80000000u, spin_limit, group_sum)) s_flag = 1;   // the records of round seq (the previous iteration's)
+      const int got = persist_group_sum(pend, nb_l, (epoch << 8) | (unsigned)seq, abortw, epoch | 0x80000000u, spin_limit, group_sum);   // the records of round seq (the previous iteration's)
+      if (got != PERSIST_OK && (t & 63) == 0) atomicMax(&s_flag, got == PERSIST_LAPPED && sub >= nb_l ? 2 : 1);   // (a writer cannot be lapped: treated as a reason to abandon)
       __syncthreads();
-      if (s_flag) break;   // abandoned (block-uniform); the record still names this iteration's level with its sums unsolved
-      solve_step<FAST>(sh, group_sum, 0, lvl, fa.early_exit, st, writer ? rec : nullptr);
+      if (s_flag == 1) break;   // abandoned (block-uniform); the record still names this iteration's level with its sums unsolved
+      if (s_flag == 2) {        // lapped (block-uniform; this block writes nothing at this level): re-join at the next level's beginning
+        if (t < 64 && !persist_adopt_state(state_line, epoch, seq, abortw, epoch | 0x80000000u, spin_limit, sh, s_seq, s_level)) s_flag = 1;
+        __syncthreads();
+        if (s_flag == 1) break;
+        adopted = true;
+#ifdef ELLC_DIAG_ABI
+        if (t == 0) atomicAdd(&g_persist_adoptions, 1ull);   // (diagnostic library: tests assert that the path was taken)
+#endif
+        seq = s_seq;
+        __syncthreads();
+        if (t == 0) s_flag = 0;
+      } else {
+        solve_step<FAST>(sh, group_sum, 0, lvl, fa.early_exit, st, writer ? rec : nullptr);
+      }
     } else {
       if (t < 6) sh.newpose[t] = st.pose[t];
       if (t < 12) sh.newS[t] = st.S[t];
@@ -2403,8 +2486,9 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(
       __syncthreads();
     }
     const int it = it_in + (pending ? 1 : 0);
-    const bool over = pending && (sh.level_done == lvl || it >= fa.max_it[lvl]);   // the level has ended: early exit, or its cap
-    const int nl = over ? lvl - 1 : lvl;
+    const bool over = adopted || (pending && (sh.level_done == lvl || it >= fa.max_it[lvl]));   // the level has ended: early exit, or its cap
+    const int nl = adopted ? s_level : (over ? lvl - 1 : lvl);
+    if (writer && over) persist_publish_state(state_line, (epoch << 8) | (unsigned)seq, sh, seq, nl);   // (see persist_publish_state)
     // (every read of `st` of this iteration lies in front of the barrier that ends the solve)
     if (t < 6) st.pose[t] = sh.newpose[t];
     if (t < 12) st.S[t] = sh.newS[t];

@@ -64,50 +64,6 @@ __global__ void gradient_planes(const uint8_t* __restrict__ img, int sw, int col
   gy[(size_t)y * cols + x] = b;
 }
 
-// frame::buildMaxGradients (Frame.cpp:618-674), three passes
-__global__ void maxgrad_magnitude(const uint8_t* __restrict__ img, int sw, int w, int h, float* __restrict__ mag) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= w || y >= h) return;
-  float gx, gy;
-  grad_at(img, sw, w, h, x, y, gx, gy);
-  const float a = gx * gx, b = gy * gy;
-  mag[(size_t)y * w + x] = sqrtf(a + b);
-}
-__global__ void maxgrad_vertical(const float* __restrict__ mag, int w, int h, float* __restrict__ tmp) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= w || y >= h) return;
-  float v = 0.0f;
-  if (y >= 1 && y < h - 1) {
-    const float g1 = fmaxf(mag[(size_t)y * w + x], mag[(size_t)(y - 1) * w + x]);
-    v = fmaxf(g1, mag[(size_t)(y + 1) * w + x]);
-  }
-  tmp[(size_t)y * w + x] = v;
-}
-__global__ __launch_bounds__(256) void maxgrad_horizontal(const float* __restrict__ mag, const float* __restrict__ tmp, int w, int h, float* __restrict__ out, int* count) {
-  int hits = 0;
-  const int n = w * h;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const int y = i / w, x = i - y * w;
-    float v = mag[i];   // border pixels keep the raw magnitude
-    if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
-      const float g1 = fmaxf(tmp[i - 1], tmp[i]);
-      v = fmaxf(g1, tmp[i + 1]);
-      if (v >= 5.0f) hits++;   // MIN_ABS_GRAD_DECREASE
-    }
-    out[i] = v;
-  }
-  __shared__ int sh[256];
-  sh[threadIdx.x] = hits;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && sh[0]) atomicAdd(count, sh[0]);
-}
-
 // The whole u8 pyramid below one source level in ONE launch (up to three pyrDown steps): a block owns a PT x PT tile of the
 // deepest level it produces and computes, through LDS, everything above it that the tile depends on — the (2PT+3)^2 region of
 // the level above, the (4PT+9)^2 region two above, from the (8PT+21)^2 region of the source — writing the part of each level
@@ -201,8 +157,8 @@ __global__ __launch_bounds__(256) void ingest_copy_u8(uint8_t* __restrict__ dst,
 
 // frame::buildMaxGradients (Frame.cpp:618-674) in one launch: a 32 x 8 tile of outputs per block; the gradient magnitude of
 // the tile plus a one-pixel ring goes through LDS, then the vertical and the horizontal 3-maximum with the reference's
-// border rules (maxgrad_magnitude / _vertical / _horizontal above are the three-pass form it replaces: same operations per
-// value, same order of the two fmaxf). count += pixels >= MIN_ABS_GRAD_DECREASE (zeroed by the caller).
+// border rules (the three-pass form of r01 — magnitude, vertical, horizontal — is in the history: same operations per value, same
+// order of the two fmaxf). count += pixels >= MIN_ABS_GRAD_DECREASE (zeroed by the caller).
 __global__ __launch_bounds__(256) void maxgrad_fused(const uint8_t* __restrict__ img, int sw, int w, int h, float* __restrict__ out, int* count) {
   constexpr int TW = 32, TH = 8;
   __shared__ float mag[(TH + 2) * (TW + 2)];

@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define ELLC_MAX_LEVELS 8
-#define ELLC_ABI_VERSION 9
+#define ELLC_ABI_VERSION 10   /* r06: measurement hooks and self-tests moved out (ellc_abi_diag.h) */
 
 typedef enum {
   ELLC_OK = 0,
@@ -316,39 +316,8 @@ ellc_status ellc_gather_start(ellc_comm* comm, int total, const float* local8, i
 ellc_status ellc_gather_finish(ellc_comm* comm, float* out8, int out_capacity);   /* out8 holds out_capacity records: ELLC_ERR_CAPACITY (the gather stays outstanding) if the oldest gather's total is larger */
 ellc_status ellc_gather_results(ellc_comm* comm, int total, const float* local8, int n_local, float* out8);
 
-/* ---- measurement hooks (bench.py) ------------------------------------------------------------------- */
-/* Launch the dominant kernel (FCA residual/Jacobian/accumulate at `level` over a batch) `reps` times on
- * the context stream between two HIP events; returns the average milliseconds per launch and the
- * algorithmic bytes one launch covers (4*N + 14*V summed over the batch). */
-ellc_status ellc_profile_gn_kernel(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, int level, int reps,
-                                   float* avg_ms, double* algorithmic_bytes, long long* valid_pixels);
-/* Time `reps` full ellc_align_enqueue passes with HIP events on the context stream (ms per pass). (A call that runs the
- * early-exit tracking schedule described above is timed without a remainder it might need.) */
-ellc_status ellc_profile_align(ellc_ctx* ctx, int B, const int* kf_slots, const int* frame_slots, const float* init_pose,
-                               int mode, int reps, float* avg_ms);
-
-/* `reps` enqueues of one depth-map stage between two HIP events on the context stream (ms per call). stage 0:
- * regularizeDepthMap(false), 1: fillDepthHoles, 2: observeDepthRow against frame_slot / pose, 3: updateDepthImage, 4: createKeyFrame's
- * regularise(remove occlusions) + fill + regularise in one launch, 5: the tracked frame's fill + regularise + updateDepthImage in
- * one launch. */
-ellc_status ellc_profile_depth_stage(ellc_ctx* ctx, int stage, int frame_slot, const float* pose_frame_wrt_kf, int reps, float* avg_ms);
-
-/* Counter calibration: stream `bytes` of device memory once per launch with 4-byte-per-lane loads (the access
- * width of the compacted pixel arrays), `reps` launches, so FETCH_SIZE can be scaled against a known byte count
- * (MI355X_MICROARCH.md, HBM section). Returns average milliseconds per launch. */
-ellc_status ellc_profile_calibrate_read(ellc_ctx* ctx, size_t bytes, int reps, float* avg_ms);
-/* Streaming-read rate with 16-byte lanes over `bytes` of device memory: the practical ceiling behind the nominal HBM peak;
- * bench.py reports it beside the roofline (SURVEY.md section 8d asks for the measured figure). */
-ellc_status ellc_profile_stream_read(ellc_ctx* ctx, size_t bytes, int reps, float* avg_ms);
-
-/* Device self-test: q_pair[i] from the kernels' packed two-at-a-time IEEE division, q_ref[i] = a[i] / b[i] as the
- * compiler emits it; n even. The per-pixel code relies on the two being bit-identical (tests/test_gpu_gn.py). */
-ellc_status ellc_selftest_div_pair(ellc_ctx* ctx, int n, const float* a, const float* b, float* q_pair, float* q_ref);
-
-/* Device self-test of the solve's 6x6 inverse (cv::Mat::inv(DECOMP_LU) restated, PixelWisePyramid.cpp:451): n symmetric
- * matrices, each given by its 21 upper-triangular entries by rows (f64, rounded to f32 as the solve does); inv36 receives
- * the row-major f32 inverses (all zeros for a singular matrix). */
-ellc_status ellc_selftest_lu(ellc_ctx* ctx, int n, const double* tri21, float* inv36);
+/* (Measurement hooks, device self-tests and test hooks are NOT part of this interface: include/ellc_abi_diag.h declares them and only
+ * libellc_hip_diag.so — the same sources built with -DELLC_DIAG_ABI — exports them. libellc_hip.so exports exactly what this header declares.) */
 
 #ifdef __cplusplus
 }

@@ -19,14 +19,14 @@ def oracle_problem(O, w, h, levels, pair, early_exit=0, max_iter=(4, 7, 9, 12)):
     return cfg, kf, cur, dm
 
 
-def gpu_problem(E, w, h, levels, pairs, early_exit=0, max_iter=(4, 7, 9, 12), **kw):
+def gpu_problem(E, w, h, levels, pairs, early_exit=0, max_iter=(4, 7, 9, 12), diag=False, **kw):
     """HIP-side context with pairs[i] resident in keyframe slot i / frame slot i."""
     fx, fy, cx, cy = pairs[0]["intrinsics"]
     n = len(pairs)
     cfg = E.default_config(w, h, levels, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=early_exit, max_iter=max_iter,
                            max_keyframes=max(n, kw.pop("max_keyframes", 1)), max_frames=max(n, kw.pop("max_frames", 1)),
                            max_batch=max(n, kw.pop("max_batch", 1)), **kw)
-    ctx = E.Context(cfg)
+    ctx = E.Context(cfg, diag=diag)
     for i, p in enumerate(pairs):
         ctx.keyframe_upload(i, p["kf_image"])
         ctx.keyframe_set_depth(i, p["depth0"], p["var0"])

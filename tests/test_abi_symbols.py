@@ -8,15 +8,26 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    txt = open(os.path.join(ROOT, "include", "ellc_abi.h")).read()
+def header_functions(name="ellc_abi.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(ellc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def exported_functions(so):
+    """the ellc_* functions a shared library exports (nm -D --defined-only)"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", so], check=True, capture_output=True, text=True).stdout
+    return sorted(set(line.split()[-1] for line in out.splitlines() if line.split()[-2:-1] == ["T"] and line.split()[-1].startswith("ellc_")))
 
 
 def test_header_and_python_binding_agree():
     from egomotion_with_local_loop_closures_amd import _lib
     assert sorted(_lib.ABI_SYMBOLS) == header_functions()
+    assert sorted(_lib.DIAG_SYMBOLS) == header_functions("ellc_abi_diag.h")
+    assert not set(_lib.ABI_SYMBOLS) & set(_lib.DIAG_SYMBOLS)
+    # nothing of the measurement / self-test / test-hook kind is left in the product interface
+    assert not [n for n in _lib.ABI_SYMBOLS if n.startswith(("ellc_profile_", "ellc_selftest_", "ellc_debug_"))]
 
 
 def test_library_builds_loads_and_exports_every_symbol():
@@ -29,6 +40,24 @@ def test_library_builds_loads_and_exports_every_symbol():
     import re
     header = open(os.path.join(ROOT, "include", "ellc_abi.h")).read()
     assert lib.ellc_abi_version() == int(re.search(r"#define ELLC_ABI_VERSION (\d+)", header).group(1))
+
+
+def test_shipping_library_exports_exactly_the_reference_facing_set():
+    """libellc_hip.so exports what include/ellc_abi.h declares and nothing else: the measurement hooks, device self-tests and test
+    hooks (include/ellc_abi_diag.h) exist in libellc_hip_diag.so only — the same sources with -DELLC_DIAG_ABI — and neither their
+    entry points nor their kernels are in the shipping binary."""
+    import __graft_entry__ as g
+    g.build()
+    from egomotion_with_local_loop_closures_amd import _lib
+    assert exported_functions(_lib.SO_PATH) == header_functions()
+    assert exported_functions(_lib.DIAG_SO_PATH) == sorted(header_functions() + header_functions("ellc_abi_diag.h"))
+    ship = open(_lib.SO_PATH, "rb").read()
+    for kernel in (b"calib_read_f32", b"stream_read_f32x4", b"selftest_div_pair", b"selftest_lu", b"maxgrad_vertical", b"maxgrad_horizontal"):
+        assert kernel not in ship, kernel
+    diag = _lib.diag_lib()
+    for name in header_functions("ellc_abi_diag.h"):
+        assert hasattr(diag, name), name
+    assert diag.ellc_abi_version() == _lib.lib().ellc_abi_version()
 
 
 def test_code_object_is_gfx950():
@@ -83,7 +112,7 @@ def test_header_is_plain_c_and_facade_is_cxx11(tmp_path):
     """The boundary is a C ABI: the header must compile as C99 without torch / HIP types; the facade as C++11."""
     import subprocess
     c = tmp_path / "abi.c"
-    c.write_text('#include "ellc_abi.h"\nint main(void) { ellc_config c; (void)c; return ELLC_OK; }\n')
+    c.write_text('#include "ellc_abi.h"\n#include "ellc_abi_diag.h"\nint main(void) { ellc_config c; (void)c; return ELLC_OK; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(c)])
     cc = tmp_path / "facade.cpp"
     cc.write_text('#include "ellc_facade.hpp"\nint main() { return 0; }\n')

@@ -144,6 +144,76 @@ def test_resident_schedule_equals_the_launches_and_survives_being_abandoned(ellc
     assert int(np.sum(got[1][0][1][1])) == 32          # the third scene reaches every cap: the longest resident launch
 
 
+def _resident_calls(ctx):
+    out = [ctx.align([0, 1], [0, 1]), ctx.align([2], [2]), ctx.align([1], [1], save_weights=True), ctx.align([0], [0])]
+    return out, [ctx.keyframe_weights(1, l) for l in range(ctx.levels)]
+
+
+def _same_results(a, b):
+    for x, y in zip(a[0], b[0]):
+        if not (np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])):
+            return False
+    return all(na == nb and np.array_equal(wa, wb) for (wa, na), (wb, nb) in zip(a[1], b[1]))
+
+
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_resident_schedule_survives_blocks_that_start_late(ellc, arith):
+    """r05's resident launch had a hole (advisor, r05): a block that writes no records at the coarse levels is waited for by nobody; if
+    it is dispatched late (another stream's kernels hold its CU) the writers overwrite the records it wants — it spun to the poll limit
+    and abandoned the launch. Since r06 it notices that it was lapped and re-joins through the state line block 0 publishes at every
+    level change. Here every block from index 7 on (640x480: 7 blocks write at level 3, 30 / 120 / 256 below) — and, in the second
+    context, every block from 31 on — starts tens to hundreds of microseconds late (ellc_debug_persist_delay): the same bits as one
+    launch per iteration, and NOT ONE launch abandoned."""
+    cases = [(21, 0.02, 0.05), (22, 0.03, 0.08), (25, 0.05, 0.15)]
+    WW, HH, LL = 640, 480, 4
+    pairs = [synth.make_pair(WW, HH, seed=s, rot=r, trans=t) for s, r, t in cases]
+    kw = dict(arith=ellc.ARITH_FAST) if arith == "fast" else {}
+    ctx = gpu_problem(ellc, WW, HH, LL, pairs, early_exit=1, diag=True, **kw)
+    ctx.set_persistent_schedule(0)
+    ref = _resident_calls(ctx)
+    ctx.close()
+    for first_block, polls in ((7, 40), (31, 150), (1, 25), (7, 400)):
+        ctx = gpu_problem(ellc, WW, HH, LL, pairs, early_exit=1, diag=True, **kw)
+        rejoined0 = ctx.debug_persist_counters()[2]
+        ctx.debug_persist_delay(first_block, polls)
+        got = _resident_calls(ctx)
+        launches, abandoned, rejoined = ctx.debug_persist_counters()
+        ctx.close()
+        assert _same_results(ref, got), (first_block, polls)
+        assert launches == 4 and abandoned == 0, (first_block, polls, launches, abandoned)
+        print("blocks from %d on %d polls late: %d blocks re-joined through the state line" % (first_block, polls, rejoined - rejoined0))
+        if first_block >= 7:
+            assert rejoined - rejoined0 >= 4 * 100, (first_block, polls, rejoined - rejoined0)   # most of the ~250 idle blocks of every launch
+
+
+def test_resident_schedule_is_refused_beyond_255_rounds_and_crosses_the_epoch_wrap(ellc):
+    """The records' tags are call epoch << 8 | round. (a) A schedule of more than 255 rounds (cfg.max_iter has no upper bound; r05
+    would have let round 256 + k of one call pass for round k of the next) runs as launches: max_iter {80, 80, 80, 80}, early exit
+    off in effect (the scenes' motion keeps the first levels busy), resident launches counted = 0, results = the launch path's.
+    (b) Three calls across the wrap of the 24-bit epoch (0xffffff -> 0 -> 1): the launch path's bits."""
+    cases = [(21, 0.02, 0.05), (22, 0.03, 0.08), (25, 0.05, 0.15)]
+    pairs = [synth.make_pair(W, H, seed=s, rot=r, trans=t) for s, r, t in cases]
+    res = {}
+    for mode in (1, 0):
+        ctx = gpu_problem(ellc, W, H, L, pairs, early_exit=1, max_iter=(80, 80, 80, 80), diag=True, arith=ellc.ARITH_FAST)
+        ctx.set_persistent_schedule(mode)
+        res[mode] = _resident_calls(ctx)
+        launches, abandoned, _ = ctx.debug_persist_counters()
+        assert launches == 0 and abandoned == 0      # 4 x 80 + 4 + 2 > 255 rounds: not attempted
+        ctx.close()
+    assert _same_results(res[0], res[1])
+    res = {}
+    for mode in (1, 0):
+        ctx = gpu_problem(ellc, W, H, L, pairs, early_exit=1, diag=True)
+        ctx.set_persistent_schedule(mode)
+        ctx.debug_set_persist_epoch(0xfffffe)
+        res[mode] = _resident_calls(ctx)               # four calls: epochs 0xffffff, 0, 1, 2 in the resident form
+        launches, abandoned, _ = ctx.debug_persist_counters()
+        assert (launches, abandoned) == ((4, 0) if mode == 1 else (0, 0))
+        ctx.close()
+    assert _same_results(res[0], res[1])
+
+
 def test_ica_constant_weight_path(problem, oracle):
     """Loop-closure mode: template-gradient Jacobian, saved weights, H once per level (A9-A11)."""
     rng = np.random.default_rng(3)
@@ -407,7 +477,7 @@ def test_packed_division_matches_ieee_division(ellc):
     a = np.concatenate([a, bits_a, mod_a]); b = np.concatenate([b, bits_b, mod_b])
     if a.size & 1:
         a = a[:-1]; b = b[:-1]
-    ctx = ellc.Context(ellc.default_config(64, 48, 3))
+    ctx = ellc.Context(ellc.default_config(64, 48, 3), diag=True)   # (the self-tests live in libellc_hip_diag.so)
     qp, qr = ctx.selftest_div_pair(a, b)
     ctx.close()
     same = (qp.view(np.uint32) == qr.view(np.uint32)) | (np.isnan(qp) & np.isnan(qr))
@@ -500,7 +570,7 @@ def test_lu_inverse_matches_the_scalar_algorithm_bit_for_bit(ellc, oracle):
     mats.append(np.eye(6))
     iu = np.triu_indices(6)
     tri = np.stack([m[iu] for m in mats])
-    ctx = ellc.Context(ellc.default_config(64, 48, 3))
+    ctx = ellc.Context(ellc.default_config(64, 48, 3), diag=True)
     got = ctx.selftest_lu(tri)
     ctx.close()
     nsing = 0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Early-exit FCA batches: state-driven schedule (production) against the level-bound one (ELLC_NO_ADAPTIVE=1, diagnostic
-build: ELLC_LIB_PATH=build/libellc_hip_diag.so; ELLC_ADAPTIVE_MAX_BATCH=32 lifts the batch-size limit), per batch size. Prints ms per batch and the iteration totals per alignment."""
+build: ELLC_LIB_PATH=build/libellc_hip_envdiag.so; ELLC_ADAPTIVE_MAX_BATCH=32 lifts the batch-size limit), per batch size. Prints ms per batch and the iteration totals per alignment."""
 import os
 import sys
 import time

@@ -4,7 +4,7 @@
 # usage: tools/sweep_nblk_group.sh OUT "8,4,4,2 16,4,4,2 ..."
 out=${1:-gpurun_out/sweep_nblk_group.txt}; pts=${2:-"8,4,4,2 12,4,4,2 16,4,4,2 8,8,4,2 16,8,4,2"}
 mkdir -p $(dirname $out); : > $out
-export ELLC_LIB_PATH=$PWD/egomotion_with_local_loop_closures_amd/csrc/variants/libellc_hip_diag.so
+export ELLC_LIB_PATH=$PWD/egomotion_with_local_loop_closures_amd/csrc/variants/libellc_hip_envdiag.so
 for rep in 1 2; do
   for p in $pts; do
     k=$(ELLC_NBLK=$p python3 tools/profile_kernel.py --calib-mb 16 | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.2f' % (1e3*d['avg_ms']))")
