@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "ellc_depth_update_depth_image", "ellc_depth_create_keyframe", "ellc_depth_seeds", "ellc_track_frame",
     "ellc_histogram", "ellc_kl_divergence", "ellc_copy_slot", "ellc_copy_slot_across",
     "ellc_ingest_configure", "ellc_frame_ingest_bgr",
-    "ellc_shard_range", "ellc_comm_unique_id", "ellc_comm_init_rccl", "ellc_comm_init_tcp", "ellc_comm_destroy", "ellc_comm_last_error",
+    "ellc_shard_range", "ellc_comm_unique_id", "ellc_comm_init_rccl", "ellc_comm_init_tcp", "ellc_comm_info", "ellc_comm_destroy", "ellc_comm_last_error",
     "ellc_gather_start", "ellc_gather_finish", "ellc_gather_results",
 ]
 
@@ -61,7 +61,7 @@ def build(verbose=False):
 
 
 COMM_SO_PATH = os.path.join(CSRC, "libellc_comm.so")   # csrc/ellc_comm.cpp alone (TCP transport): loads without a GPU
-COMM_SYMBOLS = ["ellc_shard_range", "ellc_comm_init_tcp", "ellc_comm_destroy", "ellc_comm_last_error", "ellc_gather_start", "ellc_gather_finish",
+COMM_SYMBOLS = ["ellc_shard_range", "ellc_comm_init_tcp", "ellc_comm_info", "ellc_comm_destroy", "ellc_comm_last_error", "ellc_gather_start", "ellc_gather_finish",
                 "ellc_gather_results"]
 _comm = None
 

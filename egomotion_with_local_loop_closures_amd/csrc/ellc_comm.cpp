@@ -35,6 +35,8 @@
 struct ellc_comm {
   int transport = 0;   // 1 RCCL, 2 TCP
   int world = 1, rank = 0, max_total = 0, per_max = 0;
+  int world_seen = 0, rank_seen = -1;   // what the TRANSPORT reports (ellc_comm_info): ncclCommCount / ncclCommUserRank; TCP: the ranks that joined rank 0
+  std::string pci_bus_id;               // RCCL: hipDeviceGetPCIBusId of the communicator's device
   std::string err;
   // ring of outstanding gathers
   struct Slot {
@@ -126,6 +128,7 @@ ellc_status ellc_comm_init_tcp(const char* host, int port, int world, int rank, 
   c->world = world; c->rank = rank; c->max_total = max_total;
   c->per_max = (max_total + world - 1) / world;
   *out = c;
+  c->world_seen = 1; c->rank_seen = rank;
   if (world == 1) return ELLC_OK;
   sockaddr_in addr;
   std::memset(&addr, 0, sizeof(addr));
@@ -160,6 +163,12 @@ ellc_status ellc_comm_init_tcp(const char* host, int port, int world, int rank, 
       c->peer[r] = fd;
       k++;
     }
+    // every peer learns how many ranks joined (its own view of the world: ellc_comm_info)
+    int joined = 1;
+    for (int r = 1; r < world; r++) joined += c->peer[r] >= 0 ? 1 : 0;
+    c->world_seen = joined;
+    for (int r = 1; r < world; r++)
+      if (!send_all(c->peer[r], &joined, sizeof(joined))) return cfail(c, ELLC_ERR_HIP, "cannot acknowledge a rank");
   } else {
     int fd = -1;
     for (int attempt = 0; attempt < 600; attempt++) {   // rank 0 may not be listening yet: retry for up to a minute
@@ -175,6 +184,23 @@ ellc_status ellc_comm_init_tcp(const char* host, int port, int world, int rank, 
     set_socket_timeouts(fd);
     if (!send_all(fd, &rank, sizeof(rank))) return cfail(c, ELLC_ERR_HIP, "cannot announce the rank");
     c->peer.assign(1, fd);
+    int joined = 0;
+    if (!recv_all(fd, &joined, sizeof(joined))) return cfail(c, ELLC_ERR_HIP, "rank 0 did not acknowledge this rank (not every rank joined within 60 s?)");
+    c->world_seen = joined;
+  }
+  if (c->world_seen != world) return cfail(c, ELLC_ERR_HIP, "ellc_comm_init_tcp: " + std::to_string(c->world_seen) + " ranks joined, " + std::to_string(world) + " expected");
+  return ELLC_OK;
+}
+
+// What the transport itself saw: the self-check of a multi-rank run (bench.py carries it in the N > 1 line).
+ellc_status ellc_comm_info(const ellc_comm* c, int* transport, int* world_seen, int* rank_seen, char* pci_bus_id, int pci_capacity) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  if (transport) *transport = c->transport;
+  if (world_seen) *world_seen = c->world_seen;
+  if (rank_seen) *rank_seen = c->rank_seen;
+  if (pci_bus_id && pci_capacity > 0) {
+    std::strncpy(pci_bus_id, c->pci_bus_id.c_str(), (size_t)pci_capacity - 1);
+    pci_bus_id[pci_capacity - 1] = 0;
   }
   return ELLC_OK;
 }
@@ -204,6 +230,19 @@ ellc_status ellc_comm_init_rccl(int device, const unsigned char* id128, int worl
   std::memcpy(&id, id128, sizeof(id));
   const ncclResult_t r = ncclCommInitRank(&c->nccl, world, id, rank);
   if (r != ncclSuccess) return cfail(c, ELLC_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  // what RCCL itself says about the communicator (a launcher that starts fewer ranks than it claims, or two ranks on one
+  // device, must not pass for an N-GPU run): kept for ellc_comm_info, and checked here
+  {
+    int n = 0, ur = -1, dev = -1;
+    if (ncclCommCount(c->nccl, &n) != ncclSuccess || ncclCommUserRank(c->nccl, &ur) != ncclSuccess || ncclCommCuDevice(c->nccl, &dev) != ncclSuccess)
+      return cfail(c, ELLC_ERR_HIP, "ncclCommCount / ncclCommUserRank / ncclCommCuDevice failed");
+    c->world_seen = n; c->rank_seen = ur;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) == hipSuccess) c->pci_bus_id = bus;
+    if (n != world || ur != rank || dev != device)
+      return cfail(c, ELLC_ERR_HIP, "RCCL reports " + std::to_string(n) + " ranks / rank " + std::to_string(ur) + " / device " + std::to_string(dev) + ", expected " +
+                                        std::to_string(world) + " / " + std::to_string(rank) + " / " + std::to_string(device));
+  }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return cfail(c, ELLC_ERR_HIP, "cannot create the gather stream");
   const size_t in_b = (size_t)c->per_max * ELLC_RECORD * sizeof(float), out_b = in_b * world;
   for (auto& s : c->slot) {

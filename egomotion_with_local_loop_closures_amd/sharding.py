@@ -66,6 +66,16 @@ class Comm:
             raise _lib.EllcError("ellc_comm_unique_id -> %d" % st)
         return bytes(buf)
 
+    def info(self):
+        """What the transport itself reports (ellc_comm_info): {'transport', 'world_seen', 'rank_seen', 'pci_bus_id'}."""
+        C = self._C
+        t, w, r = C.c_int(0), C.c_int(0), C.c_int(-1)
+        bus = C.create_string_buffer(64)
+        st = self._l.ellc_comm_info(self.h, C.byref(t), C.byref(w), C.byref(r), bus, 64)
+        if st != 0:
+            raise RuntimeError("ellc_comm_info -> %d" % st)
+        return {"transport": {1: "rccl", 2: "tcp"}.get(t.value, str(t.value)), "world_seen": w.value, "rank_seen": r.value, "pci_bus_id": bus.value.decode()}
+
     def shard_range(self, total):
         C = self._C
         lo, hi = C.c_int(0), C.c_int(0)

@@ -310,6 +310,10 @@ void ellc_shard_range(int total, int world, int rank, int* lo, int* hi);
 ellc_status ellc_comm_unique_id(unsigned char* id128);   /* rank 0 creates it (ncclGetUniqueId); the host program hands the 128 bytes to the other ranks */
 ellc_status ellc_comm_init_rccl(int device, const unsigned char* id128, int world, int rank, int max_total, ellc_comm** out);
 ellc_status ellc_comm_init_tcp(const char* host_ipv4, int port, int world, int rank, int max_total, ellc_comm** out);
+/* What the TRANSPORT itself reports, for the self-check of a multi-rank run: transport (1 RCCL, 2 TCP); the number of ranks and this
+ * process's rank as RCCL sees them (ncclCommCount / ncclCommUserRank; TCP: the ranks that joined rank 0 / the rank announced) — both
+ * init calls fail unless they equal `world` / `rank`; the PCI bus id of the communicator's device (RCCL; "" for TCP). */
+ellc_status ellc_comm_info(const ellc_comm* comm, int* transport, int* world_seen, int* rank_seen, char* pci_bus_id, int pci_capacity);
 ellc_status ellc_comm_destroy(ellc_comm* comm);
 const char* ellc_comm_last_error(const ellc_comm* comm);
 ellc_status ellc_gather_start(ellc_comm* comm, int total, const float* local8, int n_local);

@@ -1,6 +1,7 @@
 // ELLC ORACLE (test infrastructure) — flat C entry points so tests/ and bench.py's cpu_baseline leg can
 // drive the restatement through ctypes. Nothing in the product path links this file.
 #include "ellc_oracle.hpp"
+#include <malloc.h>
 #include <cstring>
 #include <chrono>
 #include <thread>
@@ -226,6 +227,38 @@ double orc_align_timed(Frame* kf, Frame* cur, DepthPyr* dp, const float* init_po
   }
   auto t1 = std::chrono::steady_clock::now();
   if (gn_iterations) *gn_iterations = its;
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+// CPU baseline, batch-parallel: n_align independent alignments (each with its OWN frame / pyramid objects: GetImagePoseEstimate
+// changes the frames' level state) spread over n_outer host threads, alignment i on thread i % n_outer, every alignment repeated
+// `reps` times; inside an alignment the row bands run as `flags` says (bit2: three threads created / joined per iteration as the
+// reference does; otherwise one after the other on the alignment's thread). The reference itself runs a loop-closure batch's
+// alignments one after the other (GlobalOptimize.cpp:480-610): this is the strongest fair use of the host, not the reference's.
+double orc_align_batch_timed(Frame** kfs, Frame** curs, DepthPyr** dps, int n_align, int n_outer, int flags, int n_threads, int reps,
+                             long long* gn_iterations) {
+  // (the alignment allocates its working planes per level as the reference does; as mmap / munmap of fresh pages those calls
+  // serialise the threads on the process's address-space lock — keep freed blocks in the heap instead)
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  std::vector<long long> its((size_t)n_outer, 0);
+  std::vector<std::thread> th;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int j = 0; j < n_outer; j++)
+    th.emplace_back([&, j]() {
+      const float zero[6] = {0, 0, 0, 0, 0, 0};
+      long long mine = 0;
+      for (int i = j; i < n_align; i += n_outer)
+        for (int r = 0; r < reps; r++) {
+          AlignResult a = GetImagePoseEstimate(kfs[i], curs[i], dps[i], curs[i], zero, (flags & 1) != 0, false, SUM_F32_BANDS, (flags & 4) ? 1 : 0, n_threads);
+          for (int l = 0; l < kfs[i]->cfg.levels; l++) mine += a.iters[l];
+        }
+      its[(size_t)j] = mine;
+    });
+  for (auto& t : th) t.join();
+  auto t1 = std::chrono::steady_clock::now();
+  long long tot = 0;
+  for (long long v : its) tot += v;
+  if (gn_iterations) *gn_iterations = tot;
   return std::chrono::duration<double>(t1 - t0).count();
 }
 int orc_hardware_threads() { return (int)std::thread::hardware_concurrency(); }

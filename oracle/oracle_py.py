@@ -38,6 +38,7 @@ def lib():
         _lib.orc_dm_create.restype = C.c_void_p
         _lib.orc_dm_pyr.restype = C.c_void_p
         _lib.orc_align_timed.restype = C.c_double
+        _lib.orc_align_batch_timed.restype = C.c_double
         _lib.orc_dm_make_inv_depth_one.restype = C.c_float
         _lib.orc_dm_seeds.restype = C.c_float
         _lib.orc_dm_line_stereo.restype = C.c_float
@@ -341,6 +342,19 @@ def align_timed(kf, cur, dpyr, init_pose=None, loop_closure=False, spawn_threads
     return sec, its.value
 
 
+def align_batch_timed(problems, n_outer, loop_closure=False, spawn_threads=False, n_threads=3, reps=1):
+    """CPU baseline, batch-parallel (orc_align_batch_timed): problems = [(kf, cur, dpyr), ...], each with objects of its own;
+    alignment i runs on host thread i % n_outer. Returns (seconds, GN iterations executed)."""
+    n = len(problems)
+    kfs = (C.c_void_p * n)(*[p[0].h for p in problems])
+    curs = (C.c_void_p * n)(*[p[1].h for p in problems])
+    dps = (C.c_void_p * n)(*[p[2].h for p in problems])
+    its = C.c_longlong(0)
+    flags = (1 if loop_closure else 0) | (4 if spawn_threads else 0)
+    sec = lib().orc_align_batch_timed(kfs, curs, dps, n, int(n_outer), flags, n_threads, reps, C.byref(its))
+    return sec, its.value
+
+
 def hardware_threads():
     return lib().orc_hardware_threads()
 
@@ -420,7 +434,9 @@ class DepthMap:
         return out
 
     def depth_pyr(self):
-        return DepthPyr(self.cfg, handle=C.c_void_p(lib().orc_dm_pyr(self.h)))
+        dp = DepthPyr(self.cfg, handle=C.c_void_p(lib().orc_dm_pyr(self.h)))
+        dp._map = self   # the pyramid lives inside the map: keep the map alive as long as the view
+        return dp
 
     def set_pyr0(self, deptharr0, vararr0):
         a = np.ascontiguousarray(deptharr0, np.float32); b = np.ascontiguousarray(vararr0, np.float32)

@@ -17,6 +17,10 @@ WORKER = textwrap.dedent("""
     from egomotion_with_local_loop_closures_amd import sharding, _lib
     world, rank, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     comm = sharding.Comm(world, rank, max_total=40, transport="tcp", port=port, host_only=True)
+    # what the transport itself saw (ellc_comm_info: the self-check bench.py carries in its N > 1 line; RCCL reports ncclCommCount /
+    # ncclCommUserRank / the device's PCI bus id through the same call)
+    info = comm.info()
+    assert info == {"transport": "tcp", "world_seen": world, "rank_seen": rank, "pci_bus_id": ""}, info
 
     def shard(total, salt):
         lo, hi = comm.shard_range(total)
@@ -88,6 +92,7 @@ def test_gather_entry_points_over_tcp(tmp_path, world):
 def test_single_rank_is_a_copy():
     from egomotion_with_local_loop_closures_amd import sharding
     comm = sharding.Comm(1, 0, max_total=16, transport="tcp", host_only=True)
+    assert comm.info()["world_seen"] == 1 and comm.info()["rank_seen"] == 0
     t = np.arange(40, dtype=np.float32).reshape(5, 8)
     assert np.array_equal(comm.gather(5, t), t)
     comm.close()
