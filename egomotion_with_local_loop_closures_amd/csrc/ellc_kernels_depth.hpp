@@ -1241,6 +1241,10 @@ __global__ __launch_bounds__(1024) void dm_count_valid_block(const uint8_t* __re
 }
 
 __device__ __forceinline__ float dot3f(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+// Vector3f::dot of the reference (DepthPropagation.cpp:835-848): Eigen's fixed-size redux sums three terms as e0 + (e1 + e2)
+// (Redux.h, redux_novec_unroller: func(first half, second half)) — not the left-to-right sum of a coefficient-based matrix product
+// (dot3f). r06; through the cancellation in (dot0 - oldX dot2) / nominator the two orders differ by up to ~1e-6 relative in the depth.
+__device__ __forceinline__ float dot3f_redux(const float* a, const float* b) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
 
 __device__ inline bool make_and_check_epl(const ObsArgs& a, int x, int y, float& pepx, float& pepy) {
   const float epx = -a.fx * a.otw_t[0] + a.otw_t[2] * ((float)x - a.cx);
@@ -1498,15 +1502,15 @@ __device__ inline float do_line_stereo(const ObsArgs& a, float u, float v, float
   if (incx * incx > incy * incy) {
     const float oldX = a.fxi * best_match_x + a.cxi;
     const float nominator = (oldX * a.tt[2] - a.tt[0]);
-    const float dot0 = dot3f(KinvP, a.Rr);
-    const float dot2 = dot3f(KinvP, a.Rr + 6);
+    const float dot0 = dot3f_redux(KinvP, a.Rr);
+    const float dot2 = dot3f_redux(KinvP, a.Rr + 6);
     idnew_best_match = (dot0 - oldX * dot2) / nominator;
     alpha = incx * a.fxi * (dot0 * a.tt[2] - dot2 * a.tt[0]) / (nominator * nominator);
   } else {
     const float oldY = a.fyi * best_match_y + a.cyi;
     const float nominator = (oldY * a.tt[2] - a.tt[1]);
-    const float dot1 = dot3f(KinvP, a.Rr + 3);
-    const float dot2 = dot3f(KinvP, a.Rr + 6);
+    const float dot1 = dot3f_redux(KinvP, a.Rr + 3);
+    const float dot2 = dot3f_redux(KinvP, a.Rr + 6);
     idnew_best_match = (dot1 - oldY * dot2) / nominator;
     alpha = incy * a.fxi * (dot1 * a.tt[2] - dot2 * a.tt[1]) / (nominator * nominator);   // FX_INV, as the reference (Q19)
   }

@@ -320,5 +320,19 @@ float orc_dm_line_stereo(DepthMap* d, float u, float v, float epxn, float epyn, 
   return e;
 }
 int orc_dm_check_epl(DepthMap* d, int x, int y, float* ep2) { return d->makeAndCheckEPL(x, y, ep2, ep2 + 1) ? 1 : 0; }
+// inputs of the depth side's second source (tests/second_source_depth.py): the frame-to-frame matrices of Frame.cpp:376-413 and
+// the inverse-intrinsics constants of EigenInitialization.cpp:20-34 (third-party arithmetic — Eigen exp / inverse, cv::Mat::inv —
+// that the second source takes as given)
+void orc_frame_calc_se3(Frame* f, Frame* other) { f->calculateSE3poseOtherWrtThis(*other); }
+void orc_frame_get_se3(Frame* f, float* out44) {
+  std::memcpy(out44, f->SE3poseOtherWrtThis, 64);
+  std::memcpy(out44 + 16, f->SE3poseThisWrtOther, 64);
+  std::memcpy(out44 + 32, f->K_SE3poseThisWrtOther_r, 36);
+  std::memcpy(out44 + 41, f->K_SE3poseThisWrtOther_t, 12);
+}
+void orc_kmats_inv(Frame* f, float* out4) {
+  KMats km = make_kmats(f->cfg);
+  out4[0] = km.fx_inv; out4[1] = km.fy_inv; out4[2] = km.cx_inv; out4[3] = km.cy_inv;
+}
 
 }  // extern "C"

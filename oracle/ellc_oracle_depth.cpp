@@ -61,6 +61,11 @@ void DepthMap::init(const Config& c) {
 }
 
 static inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+// Eigen's Vector3f::dot (DepthPropagation.cpp:835-848) is a fixed-size REDUX, which Eigen 3.2 unrolls as a binary tree (Redux.h,
+// redux_novec_unroller: func(first half, second half), HalfLength = Length / 2): for three terms e0 + (e1 + e2) — NOT the left-to-right
+// sum of a coefficient-based matrix product (dot3 above). Found by the second source (tests/second_source_depth.py, r06); through the
+// cancellation in (dot0 - oldX dot2) / nominator the two orders differ by up to ~1e-6 relative in the new inverse depth.
+static inline float dot3_redux(const float* a, const float* b) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
 
 // DepthPropagation.cpp:1003-1157
 void DepthMap::propagateDepth(Frame* nk) {
@@ -340,15 +345,15 @@ float DepthMap::doLineStereo(float u, float v, float epxn, float epyn, float min
   if (incx * incx > incy * incy) {
     float oldX = km.fx_inv * best_match_x + km.cx_inv;
     float nominator = (oldX * tt[2] - tt[0]);
-    float dot0 = dot3(KinvP, Rr);
-    float dot2 = dot3(KinvP, Rr + 6);
+    float dot0 = dot3_redux(KinvP, Rr);
+    float dot2 = dot3_redux(KinvP, Rr + 6);
     idnew_best_match = (dot0 - oldX * dot2) / nominator;
     alpha = incx * km.fx_inv * (dot0 * tt[2] - dot2 * tt[0]) / (nominator * nominator);
   } else {
     float oldY = km.fy_inv * best_match_y + km.cy_inv;
     float nominator = (oldY * tt[2] - tt[1]);
-    float dot1 = dot3(KinvP, Rr + 3);
-    float dot2 = dot3(KinvP, Rr + 6);
+    float dot1 = dot3_redux(KinvP, Rr + 3);
+    float dot2 = dot3_redux(KinvP, Rr + 6);
     idnew_best_match = (dot1 - oldY * dot2) / nominator;
     alpha = incy * km.fx_inv * (dot1 * tt[2] - dot2 * tt[1]) / (nominator * nominator);  // FX_INV (Q19)
   }

@@ -232,6 +232,20 @@ class Frame:
         w = None if world is None else np.ascontiguousarray(world, np.float32)
         lib().orc_frame_set_pose(self.h, _p(o), _p(w))
 
+    def calc_se3(self, other):
+        """calculateSE3poseOtherWrtThis(other) (Frame.cpp:376-413); returns the matrices it leaves in this frame."""
+        lib().orc_frame_calc_se3(self.h, other.h)
+        m = np.zeros(44, np.float32)
+        lib().orc_frame_get_se3(self.h, _p(m))
+        return {"OtherWrtThis": m[:16].reshape(4, 4).copy(), "ThisWrtOther": m[16:32].reshape(4, 4).copy(), "K_r": m[32:41].reshape(3, 3).copy(),
+                "K_t": m[41:44].copy()}
+
+    def kinv(self):
+        """ORIG_FX_INV, ORIG_FY_INV, ORIG_CX_INV, ORIG_CY_INV (EigenInitialization.cpp:20-34)"""
+        o = np.zeros(4, np.float32)
+        lib().orc_kmats_inv(self.h, _p(o))
+        return o
+
     def pose(self):
         o = np.zeros(6, np.float32); w = np.zeros(6, np.float32)
         lib().orc_frame_get_pose(self.h, _p(o), _p(w))
