@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
 # what include/ellc_abi_diag.h adds (measurement hooks, device self-tests, test hooks): exported by libellc_hip_diag.so only
 DIAG_SYMBOLS = [
     "ellc_profile_gn_kernel", "ellc_profile_align", "ellc_profile_depth_stage", "ellc_profile_calibrate_read", "ellc_profile_stream_read",
-    "ellc_selftest_div_pair", "ellc_selftest_lu", "ellc_debug_persist_delay", "ellc_debug_set_persist_epoch", "ellc_debug_persist_counters",
+    "ellc_selftest_div_pair", "ellc_selftest_lu", "ellc_debug_persist_delay", "ellc_debug_set_persist_epoch", "ellc_debug_persist_counters", "ellc_debug_set_eager_lists",
 ]
 
 
@@ -88,10 +88,14 @@ def use_library(path):
     """Diagnostic tools only (tools/*.py with an A/B variant, build/libellc_hip_envdiag.so or ..._stamps.so — all built with the
     diagnostic ABI): load this build instead of the in-tree libraries, for the product entry points and the diagnostic ones
     alike. Must be called before the first lib() / diag_lib(); the path is explicit, never taken from the environment."""
-    global SO_PATH, DIAG_SO_PATH
+    global SO_PATH, DIAG_SO_PATH, _external
+    _external = True
     if _lib is not None or _diag is not None:
         raise EllcError("use_library: the library is already loaded")
     SO_PATH = DIAG_SO_PATH = os.path.abspath(path)
+
+
+_external = False   # use_library(): an A/B build, possibly of an older revision that lacks the newest entry points
 
 
 def _bind(path, symbols, what):
@@ -104,6 +108,8 @@ def _bind(path, symbols, what):
     h.ellc_kl_divergence.restype = C.c_double
     h.ellc_comm_last_error.restype = C.c_char_p
     for name in symbols:
+        if _external and not hasattr(h, name):
+            continue          # (diagnostic A/B builds only; the in-tree libraries must export every symbol)
         getattr(h, name)  # raises AttributeError if the library does not export it
     return h
 

@@ -313,6 +313,10 @@ class Context:
         self._need_diag("ellc_debug_set_persist_epoch")
         self._ck(self._l.ellc_debug_set_persist_epoch(self.h, C.c_uint(epoch)), "ellc_debug_set_persist_epoch")
 
+    def debug_set_eager_lists(self, on):
+        self._need_diag("ellc_debug_set_eager_lists")
+        self._ck(self._l.ellc_debug_set_eager_lists(self.h, int(bool(on))), "ellc_debug_set_eager_lists")
+
     def debug_persist_counters(self):
         self._need_diag("ellc_debug_persist_counters")
         a = C.c_longlong(0); b = C.c_longlong(0); r = C.c_longlong(0)

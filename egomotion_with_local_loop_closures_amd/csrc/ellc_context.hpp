@@ -57,6 +57,8 @@ struct ellc_ctx {
   // are a pure function of the slot's image, depth pyramid and weight planes: every entry point that writes one of those
   // clears the tag (ellc::invalidate_records); a batch rebuilds only the slots whose tag differs from what it needs.
   std::vector<int> kf_rec_tag;
+  std::vector<char> kf_rec_eager;   // the slot's lists were built behind the depth map's export and are valid whatever cfg.cache_records says (enqueue_eager_lists)
+  bool eager_lists = true;
   bool cache_records = false;
   std::vector<std::array<int, ELLC_MAX_LEVELS>> kf_num_weights;
   std::vector<float*> kf_maxgrad, fr_maxgrad;
@@ -216,6 +218,7 @@ struct ellc_ctx {
 
 namespace ellc {
 ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg);
+ellc_status enqueue_eager_lists(ellc_ctx* c, int slot);   // the tracking call's lists of a keyframe slot, built behind the export of its planes
 void invalidate_records(ellc_ctx* c, int slot);   // cfg.cache_records: the slot's compact lists no longer match its planes
 #define ELLC_HIP(ctx, expr)                                                                               \
   do {                                                                                                    \

@@ -119,7 +119,7 @@ ellc_status do_update_depth_image(ellc_ctx* c, bool with_rescale = false) {
   if (s != ELLC_OK) return s;
   c->kf_has_depth[c->dm_kf_slot] = 1;
   c->kf_dense[c->dm_kf_slot] = 0;   // the map's export is semi-dense
-  return ELLC_OK;
+  return enqueue_eager_lists(c, c->dm_kf_slot);   // (a tracking context: the next alignment's lists, off its critical path)
 }
 
 // regularizeDepthMap(removeOcclusions) + fillDepthHoles + regularizeDepthMap(false) as createKeyFrame runs them (:1775-1777) in ONE
@@ -175,7 +175,7 @@ ellc_status do_fill_regularize_and_update_depth_image(ellc_ctx* c, const int* ga
   if (s != ELLC_OK) return s;
   c->kf_has_depth[c->dm_kf_slot] = 1;
   c->kf_dense[c->dm_kf_slot] = 0;   // the map's export is semi-dense
-  return ELLC_OK;
+  return enqueue_eager_lists(c, c->dm_kf_slot);   // (a tracking context: the next alignment's lists, off its critical path)
 }
 
 ellc_status do_propagate(ellc_ctx* c, int new_kf_slot, const float* pose_new_wrt_old) {

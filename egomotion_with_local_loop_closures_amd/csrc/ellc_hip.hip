@@ -27,7 +27,7 @@ ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg) {
 
 // the compact lists of a keyframe slot no longer match its planes (cfg.cache_records)
 void invalidate_records(ellc_ctx* c, int slot) {
-  if (slot >= 0 && slot < (int)c->kf_rec_tag.size()) c->kf_rec_tag[slot] = 0;
+  if (slot >= 0 && slot < (int)c->kf_rec_tag.size()) { c->kf_rec_tag[slot] = 0; c->kf_rec_eager[slot] = 0; }
 }
 
 // blocking copy on the context's own stream: the legacy default stream would synchronise with every other stream of the
@@ -265,6 +265,7 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
   a.tile0 = c->tile_begin[lvl_lo];
   a.level0 = lvl_lo;
   const int tiles = c->tile_begin[lvl_hi + 1] - c->tile_begin[lvl_lo];
+  a.slot_inline[0] = a.slot_inline[1] = 0;
   a.lb_tag = 0;
   if (c->direct_launch && n_unique <= 2 && lvl_lo == 0 && lvl_hi == c->L - 1 && tiles * n_unique <= c->resident_blocks) {
     c->prep_tag = c->prep_tag % 0xfffffu + 1u;   // never 0, never what a count launch leaves in a word (its upper bits are 0)
@@ -293,6 +294,7 @@ static void enqueue_ica_hinv(ellc_ctx* c, int n_unique) {
   a.geom = c->geom_d;
   a.kf_tab = c->kf_tab_d;
   a.slots = c->uniq_slot_d;
+  a.slot_inline[0] = a.slot_inline[1] = 0;
   a.levels = c->L;
   a.max_kf = c->cfg.max_keyframes;
   for (int l = 0; l <= ELLC_MAX_LEVELS; l++) a.tile_begin[l] = c->tile_begin[std::min(l, c->L)];
@@ -549,6 +551,40 @@ static bool schedule_is_adaptive(const ellc_ctx* c, int mode, int B) {
     if (c->cfg.max_iter[l] < 1) return false;   // a level without iterations: the level-bound schedule simply has no launch for it
   return true;
 }
+// Eager lists (r06): a tracked frame's alignment was preceded by the staging kernel AND the compaction of the keyframe's planes
+// (prep_scatter: 6.7 us, and a kernel boundary of ~5 us) although those planes were written by the PREVIOUS frame's export launch,
+// which runs beside the next frame's upload (tools/dbg/track_kernels.sh). In a context that tracks (state-driven schedule) the
+// export therefore builds the tracking call's lists right behind itself — the same kernel, the count-free form, the same order and
+// chunks, hence the same bits — and marks them as the cached lists of cfg.cache_records are marked: the next alignment against
+// that keyframe finds them (launch_group) and starts with its first Gauss-Newton launch; any other writer of the slot's planes
+// clears the mark (invalidate_records). Matches Frame.cpp:295-301, 316-327 fed by DepthPropagation.cpp:1254-1315, 1637-1746.
+ellc_status enqueue_eager_lists(ellc_ctx* c, int slot) {
+  if (!c->eager_lists || !schedule_is_adaptive(c, ELLC_MODE_FCA, 1)) return ELLC_OK;
+  const int tiles = c->tile_begin[c->L] - c->tile_begin[0];
+  if (tiles > c->resident_blocks) return ELLC_OK;   // (the count-free form needs the tiles a block waits for resident or done)
+  const int need = c->fast ? 8 : 2;   // the FCA record set of the context's arithmetic mode (need_of)
+  PrepArgs a;
+  a.need = need;
+  a.geom = c->geom_d;
+  a.kf_tab = c->kf_tab_d;
+  a.slots = nullptr;
+  a.slot_inline[0] = a.slot_inline[1] = slot;
+  a.levels = c->L;
+  a.max_kf = c->cfg.max_keyframes;
+  for (int l = 0; l <= ELLC_MAX_LEVELS; l++) a.tile_begin[l] = c->tile_begin[std::min(l, c->L)];
+  a.tile0 = c->tile_begin[0];
+  a.level0 = 0;
+  c->prep_tag = c->prep_tag % 0xfffffu + 1u;
+  a.lb_tag = c->prep_tag;
+  if (need == 8) hipLaunchKernelGGL(prep_scatter<8>, dim3(tiles, 1), dim3(256), 0, c->stream, a);
+  else if (need == 2) hipLaunchKernelGGL(prep_scatter<2>, dim3(tiles, 1), dim3(256), 0, c->stream, a);
+  else return ELLC_OK;
+  ELLC_HIP(c, hipGetLastError());
+  c->kf_rec_tag[slot] = need;
+  c->kf_rec_eager[slot] = 1;
+  return ELLC_OK;
+}
+
 static int schedule_total_iters(const ellc_ctx* c) {
   int total = 0;
   for (int l = 0; l < c->L; l++) total += c->cfg.max_iter[l];
@@ -961,6 +997,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   c->kf_dense.assign(MK, 0);
   c->kf_num_weights.assign(MK, std::array<int, ELLC_MAX_LEVELS>{});
   c->kf_rec_tag.assign(MK, 0);
+  c->kf_rec_eager.assign(MK, 0);
   c->cache_records = cfg->cache_records != 0;
   c->kf_maxgrad.assign(MK, nullptr); c->fr_maxgrad.assign(MF, nullptr);
   c->kf_maxgrad_count.assign(MK, nullptr); c->fr_maxgrad_count.assign(MF, nullptr);
@@ -1181,6 +1218,13 @@ ellc_status ellc_debug_set_persist_epoch(ellc_ctx* c, unsigned epoch) {
   if (!c) return ELLC_ERR_BAD_ARG;
   ELLC_ENTER(c);
   c->persist_epoch = epoch;
+  return ELLC_OK;
+}
+ellc_status ellc_debug_set_eager_lists(ellc_ctx* c, int on) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  ELLC_ENTER(c);
+  c->eager_lists = on != 0;
+  if (!on) std::fill(c->kf_rec_eager.begin(), c->kf_rec_eager.end(), 0);
   return ELLC_OK;
 }
 ellc_status ellc_debug_persist_counters(ellc_ctx* c, long long* resident_launches, long long* abandoned_launches, long long* rejoined_blocks) {
@@ -1702,7 +1746,7 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
   const bool saves = bs.save_weights && bs.mode == ELLC_MODE_FCA;
   bs.built_slots.clear();
   for (int v : bs.kf_slots)
-    if (!c->cache_records || c->kf_rec_tag[v] != need) bs.built_slots.push_back(v);
+    if (!(c->cache_records || c->kf_rec_eager[v]) || c->kf_rec_tag[v] != need) bs.built_slots.push_back(v);   // (kf_rec_eager: built behind the map's export)
   // dense maps (every keyframe of the launch carries the hint): the list-free schedule — no slot's lists are built or read
   bool dense = runs_dense(c, bs.mode, B, bs.save_weights);
   for (int v : bs.kf_slots) dense = dense && c->kf_dense[v];

@@ -16,7 +16,7 @@ namespace ellc {
 struct PrepArgs {
   const LevelGeom* geom;
   const KfLevelDev* kf_tab;
-  const int* slots;            // unique keyframe slots
+  const int* slots;            // unique keyframe slots (null: slot_inline — a launch outside an alignment, see enqueue_eager_lists)
   int levels, max_kf;
   int need;                    // bit 0: planes Z / I / saved weight (unfused ICA kernels); bit 1: FcaRec records (FCA);
                                // bit 2: IcaRec records + per-tile sums of H (fused ICA schedule); bit 3: FcaRecF records
@@ -24,6 +24,7 @@ struct PrepArgs {
                                // the tolerance mode's 16-byte form (IcaInF) instead of IcaRec
   int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
   int tile0, level0;           // this launch covers tiles tile0 + blockIdx.x (count / scatter), levels level0 + blockIdx.x (scan)
+  int slot_inline[2];          // the slots themselves when `slots` is null
   unsigned lb_tag;             // 0: prep_count has left the tiles' counts. Else (r05, the tracking call: one or two keyframes, launched
                                // kernel by kernel) there is NO count launch: a scatter block publishes `lb_tag << 12 | its tile's count`
                                // as soon as it has it and sums the tagged counts of the tiles of its level in front of it as they
@@ -31,6 +32,8 @@ struct PrepArgs {
                                // waits for are resident or done). For launch groups the same was measured 17 % SLOWER (NOTEBOOK 5.1):
                                // 25 000 waiting blocks; here they are 201.
 };
+__device__ __forceinline__ int prep_slot(const PrepArgs& a, unsigned k) { return a.slots ? a.slots[k] : a.slot_inline[k & 1u]; }
+
 
 __device__ __forceinline__ int prep_level_of(const PrepArgs& a, int tile, int& local) {
   int l = 0;
@@ -66,7 +69,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int& total) {
 __global__ __launch_bounds__(256) void prep_count(PrepArgs a) {
   int local;
   const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
-  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const KfLevelDev& K = a.kf_tab[level * a.max_kf + prep_slot(a, blockIdx.y)];
   const int n = a.geom[level].n;
   const int i0 = local * ELLC_TILE + threadIdx.x * 8;
   float d[8];
@@ -94,7 +97,7 @@ template <int NEED>   // compile-time copy of PrepArgs::need: the FCA variant ca
 __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
   int local;
   const int level = prep_level_of(a, a.tile0 + (int)blockIdx.x, local);
-  const KfLevelDev K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const KfLevelDev K = a.kf_tab[level * a.max_kf + prep_slot(a, blockIdx.y)];
   const LevelGeom& g = a.geom[level];
   const int n = g.n;
   const int base = local * ELLC_TILE + (int)threadIdx.x;
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
 // (PixelWisePyramid.cpp:938-939). One block per (level, unique slot); the level's inverse is kept with the slot.
 __global__ __launch_bounds__(ELLC_SOLVE_THREADS) void ica_hinv(PrepArgs a) {
   const int level = a.level0 + (int)blockIdx.x;
-  const KfLevelDev& K = a.kf_tab[level * a.max_kf + a.slots[blockIdx.y]];
+  const KfLevelDev& K = a.kf_tab[level * a.max_kf + prep_slot(a, blockIdx.y)];
   const int T = a.tile_begin[level + 1] - a.tile_begin[level];
   __shared__ SolveShared sh;
   const int t = threadIdx.x;

@@ -51,6 +51,10 @@ ellc_status ellc_selftest_lu(ellc_ctx* ctx, int n, const double* tri21, float* i
 ellc_status ellc_debug_persist_delay(ellc_ctx* ctx, int first_block, int polls);
 /* The call counter the records' tags are made of (24 bits are used): tests set it just below the wrap. */
 ellc_status ellc_debug_set_persist_epoch(ellc_ctx* ctx, unsigned epoch);
+/* Eager lists (default on in a context that tracks): the depth map's export builds the tracking call's compact lists of its keyframe
+ * right behind itself, so that the next alignment against that keyframe starts without the compaction. 0 switches that off (every
+ * alignment builds its lists itself, as up to r05): the results must not change by a bit (tests). */
+ellc_status ellc_debug_set_eager_lists(ellc_ctx* ctx, int on);
 /* Resident launches of this context so far, how many of them the host had to finish with launches (abandoned), and — device-wide,
  * since the library was loaded — how many blocks were lapped and re-joined through the state line. Any pointer may be NULL. */
 ellc_status ellc_debug_persist_counters(ellc_ctx* ctx, long long* resident_launches, long long* abandoned_launches, long long* rejoined_blocks);

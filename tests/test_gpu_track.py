@@ -10,9 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W, H, L = 320, 240, 4
 
 
-def make_ctx(ellc, pair, **kw):
+def make_ctx(ellc, pair, diag=False, **kw):
     fx, fy, cx, cy = pair["intrinsics"]
-    ctx = ellc.Context(ellc.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=2, max_frames=2, **kw))
+    ctx = ellc.Context(ellc.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=2, max_frames=2, **kw), diag=diag)
     ctx.keyframe_upload(0, pair["kf_image"]); ctx.keyframe_set_depth(0, pair["depth0"], pair["var0"])
     st = synth.make_depth_state(W, H, 9, pair["kf_image"], pair["idepth_true"])
     ctx.depth_set_keyframe(0); ctx.depth_set_state(st)
@@ -55,6 +55,61 @@ def test_track_frame_equals_the_separate_calls(ellc, oracle, arith, case):
             assert_state_equal(sb, dm.get_state(), "track_frame vs oracle")
     if case[0] == 22:
         assert int(iters.sum()) > 20 or rep   # (the continuation path was exercised on the first frame)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_eager_lists_change_no_bit_and_every_writer_invalidates_them(ellc, arith):
+    """r06: in a tracking context the depth map's export builds the next alignment's compact lists right behind itself (the alignment
+    then starts without staging's compaction). Same kernel, same order, same chunks: against a context with that switched off
+    (ellc_debug_set_eager_lists(0): every alignment builds its lists itself, as up to r05) not a bit may differ — over tracked
+    frames, through the fused call and the separate calls, across a keyframe switch, and after every other writer of the slot's
+    planes (the lists built behind the export are then stale and must not be used)."""
+    pair = synth.make_pair(W, H, seed=21, rot=0.02, trans=0.05)
+    pair2 = synth.make_pair(W, H, seed=23, rot=0.015, trans=0.04)
+    kw = dict(arith=ellc.ARITH_FAST) if arith == "fast" else {}
+    a = make_ctx(ellc, pair, diag=True, **kw)
+    b = make_ctx(ellc, pair, diag=True, **kw)
+    b.debug_set_eager_lists(False)
+
+    def same(what):
+        ra, rb = a.align([0], [0]), b.align([0], [0])
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb)), what
+        sa, sb = a.depth_get_state(), b.depth_get_state()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k], equal_nan=True), (what, k)
+
+    for rep in range(3):                                    # tracked frames: from the second on, a's alignment finds its lists built
+        ra, rb = a.track_frame(0, save_weights=True), b.track_frame(0, save_weights=True)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]) and ra[2] == rb[2] and ra[3] == rb[3], rep
+    same("after three tracked frames")
+    for ctx in (a, b):                                      # the separate calls (what ellc_main's unfused loop does)
+        pose, _, _ = ctx.align([0], [0], save_weights=True)
+        pwo = ellc.concatenate_relative_pose(pose[0], np.zeros(6, np.float32))
+        ctx.depth_observe(0, pwo); ctx.depth_fill_holes(); ctx.depth_regularize(False); ctx.depth_update_depth_image()
+    same("after the separate calls")
+    writers = [
+        ("keyframe_set_depth_level", lambda c: c.keyframe_set_depth_level(0, 1, *[x.copy() for x in c.keyframe_depth_level(0, 1)])),
+        ("keyframe_set_depth", lambda c: c.keyframe_set_depth(0, pair2["depth0"], pair2["var0"])),
+        ("update_depth_image again", lambda c: c.depth_update_depth_image()),
+        ("keyframe_upload + depth", lambda c: (c.keyframe_upload(0, pair2["kf_image"]), c.keyframe_set_depth(0, pair2["depth0"], pair2["var0"]))),
+        ("copy_slot", lambda c: (c.keyframe_upload(1, pair["kf_image"]), c.keyframe_set_depth(1, pair["depth0"], pair["var0"]), c.copy_slot(1, 0, 1, 1))),
+        ("single-step API", lambda c: c.gn_iterate(0, 0, 1, np.zeros(6, np.float32))),
+        ("export, then tracked frame", lambda c: (c.depth_update_depth_image(), c.track_frame(0, save_weights=True))),
+    ]
+    for name, fn in writers:
+        fn(a); fn(b)
+        same(name)
+    # a keyframe switch: propagate + regularise + export into slot 1, the next frames are aligned against it
+    for ctx in (a, b):
+        ctx.keyframe_upload(1, pair["cur_image"])
+        ctx.depth_create_keyframe(1, pair["xi_true"])
+        ctx.frame_upload(1, pair["kf_image"])
+    for rep in range(2):
+        ra, rb = a.align([1], [1], save_weights=True), b.align([1], [1], save_weights=True)
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb)), ("new keyframe", rep)
+        ra, rb = a.track_frame(1), b.track_frame(1)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]), ("new keyframe, tracked", rep)
     a.close(); b.close()
 
 

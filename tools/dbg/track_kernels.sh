@@ -1,5 +1,5 @@
 #!/bin/bash
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r05b/track_trace
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r06}/track_trace
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/bench_track.py 120 fast > $OUT/run.log 2>&1
