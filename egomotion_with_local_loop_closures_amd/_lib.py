@@ -13,7 +13,7 @@ MAX_LEVELS = 8
 
 # every symbol include/ellc_abi.h declares (checked by tests/test_abi_symbols.py against the header text)
 ABI_SYMBOLS = [
-    "ellc_abi_version", "ellc_device_count", "ellc_default_config", "ellc_ctx_create", "ellc_ctx_destroy", "ellc_last_error", "ellc_sync", "ellc_stream", "ellc_ctx_counters", "ellc_ctx_set_poll_timeout_us", "ellc_ctx_set_grid_batch", "ellc_ctx_set_persistent_schedule",
+    "ellc_abi_version", "ellc_device_count", "ellc_default_config", "ellc_ctx_create", "ellc_ctx_destroy", "ellc_last_error", "ellc_sync", "ellc_stream", "ellc_ctx_counters", "ellc_ctx_set_poll_timeout_us", "ellc_ctx_set_grid_batch", "ellc_ctx_set_dense_maps", "ellc_ctx_set_persistent_schedule",
     "ellc_frame_upload", "ellc_keyframe_upload", "ellc_keyframe_from_frame", "ellc_get_image_level", "ellc_get_gradient",
     "ellc_get_max_gradient", "ellc_keyframe_set_depth", "ellc_keyframe_set_depth_level", "ellc_keyframe_get_depth_level",
     "ellc_keyframe_set_weights", "ellc_keyframe_get_weights", "ellc_keyframe_finalise_weights", "ellc_align", "ellc_align_enqueue",
@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
 # what include/ellc_abi_diag.h adds (measurement hooks, device self-tests, test hooks): exported by libellc_hip_diag.so only
 DIAG_SYMBOLS = [
     "ellc_profile_gn_kernel", "ellc_profile_align", "ellc_profile_depth_stage", "ellc_profile_calibrate_read", "ellc_profile_stream_read",
-    "ellc_selftest_div_pair", "ellc_selftest_lu", "ellc_debug_persist_delay", "ellc_debug_set_persist_epoch", "ellc_debug_persist_counters", "ellc_debug_set_eager_lists",
+    "ellc_selftest_div_pair", "ellc_selftest_lu", "ellc_debug_persist_delay", "ellc_debug_set_persist_epoch", "ellc_debug_persist_counters", "ellc_debug_set_eager_lists", "ellc_debug_set_hinv_cache",
 ]
 
 

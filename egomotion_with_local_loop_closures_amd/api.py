@@ -84,6 +84,10 @@ class Context:
         """cfg.grid_batch for the calls that follow (ellc_ctx_set_grid_batch)."""
         self._ck(self._l.ellc_ctx_set_grid_batch(self.h, int(n)), "ellc_ctx_set_grid_batch")
 
+    def set_dense_maps(self, mode):
+        """0: dense maps take the list-free kernels (default); 1: always the compact lists (ellc_ctx_set_dense_maps)."""
+        self._ck(self._l.ellc_ctx_set_dense_maps(self.h, int(mode)), "ellc_ctx_set_dense_maps")
+
     def set_persistent_schedule(self, mode):
         """1: the state-driven schedule as one resident launch (default); 0: one launch per iteration; 2: test hook, every resident
         launch is abandoned at its first hand-over (ellc_ctx_set_persistent_schedule)."""
@@ -316,6 +320,10 @@ class Context:
     def debug_set_eager_lists(self, on):
         self._need_diag("ellc_debug_set_eager_lists")
         self._ck(self._l.ellc_debug_set_eager_lists(self.h, int(bool(on))), "ellc_debug_set_eager_lists")
+
+    def debug_set_hinv_cache(self, on):
+        self._need_diag("ellc_debug_set_hinv_cache")
+        self._ck(self._l.ellc_debug_set_hinv_cache(self.h, int(bool(on))), "ellc_debug_set_hinv_cache")
 
     def debug_persist_counters(self):
         self._need_diag("ellc_debug_persist_counters")

@@ -48,6 +48,7 @@ struct ellc_ctx {
   // thread <-> pixel, the planes read directly). A hint, not a promise: pixels without depth are skipped where they occur.
   std::vector<char> kf_dense;
   bool cur_dense = false;   // the schedule being enqueued is the list-free one
+  bool dense_maps_off = false;   // ellc_ctx_set_dense_maps(1): dense maps take the list path too (bit-comparison runs)
 #ifdef ELLC_NO_DENSE_QUADS
   bool dense_quads = false;   // (A/B builds: the r05 kernel, one pixel per thread)
 #else
@@ -59,6 +60,12 @@ struct ellc_ctx {
   std::vector<int> kf_rec_tag;
   std::vector<char> kf_rec_eager;   // the slot's lists were built behind the depth map's export and are valid whatever cfg.cache_records says (enqueue_eager_lists)
   bool eager_lists = true;
+  // ICA, tolerance mode: H^-1 per (slot, level) — the inverse of sum W J^T J over the keyframe's valid pixels (PixelWisePyramid.cpp:938-939)
+  // — is a function of the keyframe's planes alone. kf_hinv_ok[slot]: the inverses the last compaction of the slot left are still
+  // current (every writer of the planes clears it through invalidate_records): the next compaction builds the records only (r06)
+  std::vector<char> kf_hinv_ok;
+  bool hinv_cache = true;
+  int cur_need = 0;   // record set of the launch being enqueued when it differs from need_of() (16: records without the H sums)
   bool cache_records = false;
   std::vector<std::array<int, ELLC_MAX_LEVELS>> kf_num_weights;
   std::vector<float*> kf_maxgrad, fr_maxgrad;

@@ -27,7 +27,7 @@ ellc_status fail(ellc_ctx* c, ellc_status s, const std::string& msg) {
 
 // the compact lists of a keyframe slot no longer match its planes (cfg.cache_records)
 void invalidate_records(ellc_ctx* c, int slot) {
-  if (slot >= 0 && slot < (int)c->kf_rec_tag.size()) { c->kf_rec_tag[slot] = 0; c->kf_rec_eager[slot] = 0; }
+  if (slot >= 0 && slot < (int)c->kf_rec_tag.size()) { c->kf_rec_tag[slot] = 0; c->kf_rec_eager[slot] = 0; c->kf_hinv_ok[slot] = 0; }
 }
 
 // blocking copy on the context's own stream: the legacy default stream would synchronise with every other stream of the
@@ -278,6 +278,7 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
     case 2: hipLaunchKernelGGL(prep_scatter<2>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL(prep_scatter<4>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     case 20: hipLaunchKernelGGL(prep_scatter<20>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(prep_scatter<16>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;   // fast ICA records only: the slots' H^-1 are current
     case 8: hipLaunchKernelGGL(prep_scatter<8>, dim3(tiles, n_unique), dim3(256), 0, st, a); break;
     default: return fail(c, ELLC_ERR_BAD_ARG, "run_prep: unknown record set");
   }
@@ -998,6 +999,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
   c->kf_num_weights.assign(MK, std::array<int, ELLC_MAX_LEVELS>{});
   c->kf_rec_tag.assign(MK, 0);
   c->kf_rec_eager.assign(MK, 0);
+  c->kf_hinv_ok.assign(MK, 0);
   c->cache_records = cfg->cache_records != 0;
   c->kf_maxgrad.assign(MK, nullptr); c->fr_maxgrad.assign(MF, nullptr);
   c->kf_maxgrad_count.assign(MK, nullptr); c->fr_maxgrad_count.assign(MF, nullptr);
@@ -1227,6 +1229,12 @@ ellc_status ellc_debug_set_eager_lists(ellc_ctx* c, int on) {
   if (!on) std::fill(c->kf_rec_eager.begin(), c->kf_rec_eager.end(), 0);
   return ELLC_OK;
 }
+ellc_status ellc_debug_set_hinv_cache(ellc_ctx* c, int on) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  ELLC_ENTER(c);
+  c->hinv_cache = on != 0;
+  return ELLC_OK;
+}
 ellc_status ellc_debug_persist_counters(ellc_ctx* c, long long* resident_launches, long long* abandoned_launches, long long* rejoined_blocks) {
   if (!c) return ELLC_ERR_BAD_ARG;
   ELLC_ENTER(c);
@@ -1241,6 +1249,17 @@ ellc_status ellc_debug_persist_counters(ellc_ctx* c, long long* resident_launche
   return ELLC_OK;
 }
 #endif   // ELLC_DIAG_ABI
+
+ellc_status ellc_ctx_set_dense_maps(ellc_ctx* c, int mode) {
+  ELLC_ENTER_BATCH(c);
+  if (!c || mode < 0 || mode > 1) return fail(c, ELLC_ERR_BAD_ARG, "ellc_ctx_set_dense_maps: mode 0 (automatic) or 1 (always the lists)");
+  if (c->open_set >= 0) {   // a group still waiting for batches to join was staged under the old value: it runs as it is
+    const ellc_status s = launch_group(c, c->open_set);
+    if (s != ELLC_OK) return s;
+  }
+  c->dense_maps_off = mode == 1;
+  return ELLC_OK;
+}
 
 ellc_status ellc_ctx_set_grid_batch(ellc_ctx* c, int n) {
   ELLC_ENTER_BATCH(c);
@@ -1577,7 +1596,7 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
   // mask / count per level (updationOnPyrChange, ImageFunc.cpp:158) and the pose-independent per-pixel records. (Folding the
   // staging into the count launch — its tile blocks then read their keyframe slot from the pinned record, one PCIe round trip
   // per block — was measured in r02: the count launch went from 10 to 29 us at 32 keyframes; the separate 8 us launch stays.)
-  const int need = need_of(c, mode);
+  const int need = c->cur_need ? c->cur_need : need_of(c, mode);   // (cur_need: launch_group's choice — 16 instead of 20 when every rebuilt slot's H^-1 is current)
   ellc_status s = ELLC_OK;
   if (nu > 0) {
     s = run_prep(c, nu, need);
@@ -1594,7 +1613,7 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
 // may a batch of B alignments run the list-free schedule (gn_fca_dense)? The tolerance-mode FCA schedule in its level-bound form,
 // without saved weights (they are kept per list entry); launch_group adds: every keyframe slot carries the dense hint
 static bool runs_dense(const ellc_ctx* c, int mode, int B, int save_weights) {
-  return c->fast && c->use_fused && mode == ELLC_MODE_FCA && !save_weights && !schedule_is_adaptive(c, mode, B);
+  return !c->dense_maps_off && c->fast && c->use_fused && mode == ELLC_MODE_FCA && !save_weights && !schedule_is_adaptive(c, mode, B);
 }
 
 
@@ -1620,7 +1639,7 @@ static ellc_status launch_align_graph(ellc_ctx* c, int B, int nu, int mode, int 
   // (cur_adaptive_first: launches of the first graph of a state-driven schedule; it varies with the context's hint)
   const int first = schedule_is_adaptive(c, mode, B) ? c->cur_adaptive_first : 0;
   const auto key = std::make_tuple(B, continuation ? 0 : nu, mode,
-                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0) | (c->track_call ? 4 : 0) | (c->cur_pollable ? 8 : 0) | (first << 4) | (c->cfg.grid_batch << 12) | (c->cur_dense ? (1 << 29) : 0), set);
+                                   (save_weights ? 1 : 0) | (continuation ? 2 : 0) | (c->track_call ? 4 : 0) | (c->cur_pollable ? 8 : 0) | (first << 4) | (c->cfg.grid_batch << 12) | (c->cur_dense ? (1 << 29) : 0) | (c->cur_need == 16 ? (1 << 28) : 0), set);
   auto it = c->graphs.find(key);
   if (it == c->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -1753,6 +1772,14 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
   if (dense) bs.built_slots.clear();
   const int nu = (int)bs.built_slots.size();
   for (int u = 0; u < nu; u++) c->uniq_slot_h[u] = bs.built_slots[u];
+  // constant-weight path, tolerance mode: when the H^-1 of every slot that is rebuilt are current (kf_hinv_ok), the compaction
+  // builds the records only (prep_scatter<16>: no exact template row, no sums, no ica_hinv)
+  int need_run = need;
+  if (need == 20 && c->hinv_cache && nu > 0) {
+    bool all_ok = true;
+    for (int v : bs.built_slots) all_ok = all_ok && c->kf_hinv_ok[v];
+    if (all_ok) need_run = 16;
+  }
   // stream
   bool busy[ellc_ctx::STREAMS] = {};
   for (int p = 0; p < ellc_ctx::SETS; p++)
@@ -1823,7 +1850,9 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
     bs.pollable = polls_results(c, B, si);
     c->cur_pollable = bs.pollable;
     c->cur_dense = dense;
+    c->cur_need = (need_run != need) ? need_run : 0;
     const ellc_status s = launch_align_graph(c, B, nu, bs.mode, bs.save_weights, set, false);
+    c->cur_need = 0;
     c->cur_dense = false;
     c->cur_pollable = false;
     if (s != ELLC_OK) {
@@ -1836,9 +1865,13 @@ static ellc_status launch_group(ellc_ctx* c, int set) {
     if (!c->done_deferred) ELLC_HIP(c, hipEventRecord(bs.done, c->stream));
   }
   for (int v : bs.built_slots) c->kf_rec_tag[v] = need;
-  if (saves)   // the weight planes change: lists that carry the saved weight (the constant-weight record sets) are stale
-    for (int v : bs.kf_slots)
+  if (need == 20)
+    for (int v : bs.built_slots) c->kf_hinv_ok[v] = 1;   // (computed by this launch, or already current)
+  if (saves)   // the weight planes change: lists that carry the saved weight (the constant-weight record sets) are stale, and so are the H^-1
+    for (int v : bs.kf_slots) {
+      c->kf_hinv_ok[v] = 0;
       if (c->kf_rec_tag[v] != 8 && c->kf_rec_tag[v] != 2) invalidate_records(c, v);
+    }
   bs.launched = true;
   bs.stream_idx = si;
   bs.B = B;

@@ -252,19 +252,19 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
     // max(x - 1, 0) — three byte gathers cost the vector cache three times what the dword costs (the row's stored width and the
     // slack behind the last level's image cover the read past x + 1)
     typedef uint32_t u32a1 __attribute__((aligned(1)));
-    const uint32_t rowq = (need & 4) ? *(const ELLC_GLOBAL u32a1*)(img + (unsigned)(y * sw + max(x - 1, 0))) : 0u;
+    const uint32_t rowq = (need & (4 | 16)) ? *(const ELLC_GLOBAL u32a1*)(img + (unsigned)(y * sw + max(x - 1, 0))) : 0u;
     const uint32_t b0 = rowq & 0xffu, b1 = (rowq >> 8) & 0xffu, b2 = (rowq >> 16) & 0xffu;
     const uint32_t pc = (x == 0) ? b0 : b1;                                  // I(x, y)
     const uint32_t pxm = b0;                                                 // I(max(x - 1, 0), y)
     const uint32_t pxp = (x == 0) ? b1 : ((x == cols - 1) ? b1 : b2);        // I(min(x + 1, cols - 1), y)
-    const float Ikf = (need & 4) ? (float)pc : (float)img[(unsigned)(y * sw + x)];
+    const float Ikf = (need & (4 | 16)) ? (float)pc : (float)img[(unsigned)(y * sw + x)];
     if (need & 1) {   // unfused ICA kernels read planes
       cxy[pos] = xy;
       cZ[pos] = Z;
       cI[pos] = Ikf;
       cW[pos] = wgt[(unsigned)i];
     }
-    if (need & 4) {   // ICA record: template-gradient Jacobian at the integer pixel (PixelWisePyramid.cpp:561-680)
+    if (need & (4 | 16)) {   // ICA record: template-gradient Jacobian at the integer pixel (PixelWisePyramid.cpp:561-680)
       // frame::calculateGradient of the keyframe level image at (y,x)  (Frame.cpp:185-285)
       const int xm = max(x - 1, 0), xp = min(x + 1, cols - 1), ym = max(y - 1, 0), yp = min(y + 1, g.rows - 1);
       const float sx = (x == 0 || x == cols - 1) ? 1.0f : 0.5f;
@@ -272,16 +272,21 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
       const float gradx = sx * ((float)pxp - (float)pxm);
       (void)xm; (void)xp;
       const float grady = sy * ((float)img[(unsigned)(yp * sw + x)] - (float)img[(unsigned)(ym * sw + x)]);
-      float J[6];
-      jacobian_row<false>(gradx, grady, x, y, 1.0 / (double)Z, g, J);
       const float wsave = wgt[(unsigned)i];
-      const float X = (((float)x - cx) * Z) / fx;
-      const float Y = (((float)y - cy) * Z) / fy;
       if (need & 16) {   // tolerance mode: one 16-byte word (ica_load_fast); twice a central difference of bytes is an integer below 2^15
         const uint32_t xyI = (uint32_t)x | ((uint32_t)y << 12) | (pc << 24);
         const uint32_t gxy = ((uint32_t)(int)(2.0f * gradx) & 0xffffu) | ((uint32_t)(int)(2.0f * grady) << 16);
         crec[pos] = (u32x4){xyI, __builtin_bit_cast(uint32_t, __builtin_amdgcn_rcpf(Z)), __builtin_bit_cast(uint32_t, wsave), gxy};
-      } else {
+      }
+      // NEED = 16 alone (r06): the records only — the slot's H^-1 of this level is still the one an earlier call left (it is a
+      // function of the keyframe's planes alone, and every writer of those clears kf_hinv_ok): no exact template row, no f64 and
+      // IEEE f32 divisions, no 21 sums per pixel
+      if constexpr ((NEED & 4) != 0) {
+      float J[6];
+      jacobian_row<false>(gradx, grady, x, y, 1.0 / (double)Z, g, J);
+      const float X = (((float)x - cx) * Z) / fx;
+      const float Y = (((float)y - cy) * Z) / fy;
+      if (!(need & 16)) {
         const unsigned t3 = 3u * threadIdx.x;
         s_rec[t3] = (u32x4){__builtin_bit_cast(uint32_t, X), __builtin_bit_cast(uint32_t, Y), __builtin_bit_cast(uint32_t, Z), __builtin_bit_cast(uint32_t, Ikf)};
         s_rec[t3 + 1] = (u32x4){__builtin_bit_cast(uint32_t, wsave), __builtin_bit_cast(uint32_t, J[0]), __builtin_bit_cast(uint32_t, J[1]), __builtin_bit_cast(uint32_t, J[2])};
@@ -293,6 +298,7 @@ __global__ __launch_bounds__(256) void prep_scatter(PrepArgs a) {
         const float wJ = J[rr] * wsave;   // weightedSteepestDescent (:664-669); H = WSD * SD^T (:938)
 #pragma unroll
         for (int cc = rr; cc < 6; cc++) { hacc[q] = __builtin_fmaf(wJ, J[cc], hacc[q]); q++; }
+      }
       }
     }
     if (need & 8) {   // FCA in tolerance mode: one 12-byte record per pixel (FcaRecF)

@@ -114,6 +114,14 @@ ellc_status ellc_ctx_set_poll_timeout_us(ellc_ctx* ctx, int microseconds);
  * bits stay independent of the world size (ellc_shard_range) while a batch of three candidates no longer runs on grids sized for
  * 43. Batches in flight keep the grids they were launched with. */
 ellc_status ellc_ctx_set_grid_batch(ellc_ctx* ctx, int n);
+/* The list-free path for dense maps (v10). A keyframe whose level-0 depth plane was uploaded with at least nine tenths of its
+ * pixels valid (ellc_keyframe_set_depth counts them) is aligned — tolerance mode, FCA, no saved weights, every keyframe of the
+ * batch dense — by kernels that read its planes directly instead of compact lists (gn_fca_dense / gn_fca_dense4). The two paths
+ * chunk the pixels differently (plane index / list index), so their sums differ in the last bits: within the mode's tolerance
+ * (pose <= 1e-5 vs the CPU path either way), but NOT bit-identical — and a batch flips to the list path as soon as one of its
+ * keyframes is not dense. A caller that compares runs bit for bit (world-size invariance, regression hashes) pins the choice:
+ * mode 0 = automatic (default), 1 = always the lists. Batches in flight keep the path they were launched with. */
+ellc_status ellc_ctx_set_dense_maps(ellc_ctx* ctx, int mode);
 /* How the state-driven schedule (early exit on, one or two alignments per call: the tracking call, main.cpp:330) reaches the device
  * (r05, ABI v9). 1 (default): as ONE resident launch whenever the call finds the context's pipeline empty (with other batches of
  * the context in flight: as mode 0, so that their launches keep overlapping) — the level's blocks stay on the device for the whole

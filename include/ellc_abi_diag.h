@@ -55,6 +55,10 @@ ellc_status ellc_debug_set_persist_epoch(ellc_ctx* ctx, unsigned epoch);
  * right behind itself, so that the next alignment against that keyframe starts without the compaction. 0 switches that off (every
  * alignment builds its lists itself, as up to r05): the results must not change by a bit (tests). */
 ellc_status ellc_debug_set_eager_lists(ellc_ctx* ctx, int on);
+/* Constant-weight path, tolerance mode: the per-(slot, level) H^-1 are kept while the keyframe's planes are unchanged and the
+ * per-call compaction then builds the records only (default on). 0: every compaction recomputes them, as up to r05 — the results
+ * must not change by a bit (tests). */
+ellc_status ellc_debug_set_hinv_cache(ellc_ctx* ctx, int on);
 /* Resident launches of this context so far, how many of them the host had to finish with launches (abandoned), and — device-wide,
  * since the library was loaded — how many blocks were lapped and re-joined through the state line. Any pointer may be NULL. */
 ellc_status ellc_debug_persist_counters(ellc_ctx* ctx, long long* resident_launches, long long* abandoned_launches, long long* rejoined_blocks);

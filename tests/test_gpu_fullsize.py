@@ -147,6 +147,15 @@ def test_dense_path_skips_the_pixels_without_depth(oracle, ellc):
     assert list(it2[0]) == list(it_ref) and np.linalg.norm(p2[0] - p_ref) <= 1e-5
     assert np.linalg.norm(p2[0] - p[0]) <= 2e-6
     ctx.close()
+    # ellc_ctx_set_dense_maps(1) pins the list path for a dense map: bit for bit what the list path gave above
+    ctx = gpu_problem(ellc, W, H, L, [pair], arith=ellc.ARITH_FAST)
+    ctx.set_dense_maps(1)
+    p3, it3, _ = ctx.align([0], [0])
+    assert np.array_equal(p3, p2) and np.array_equal(it3, it2)
+    ctx.set_dense_maps(0)
+    p4, _, _ = ctx.align([0], [0])
+    assert np.array_equal(p4, p)
+    ctx.close()
 
 
 @pytest.fixture(scope="module")

@@ -752,6 +752,8 @@ def test_record_cache_is_invalidated_by_every_writer(ellc):
     a = gpu_problem(ellc, w, h, L, pairs, cache_records=1, **kw)
     b = gpu_problem(ellc, w, h, L, pairs, **kw)
     st = synth.make_depth_state(w, h, 7, pairs[1]["kf_image"], pairs[1]["idepth_true"])
+    # (r06: in the tolerance mode the constant-weight path also keeps the per-slot H^-1 while the planes are unchanged — see
+    # test_hinv_cache_changes_no_bit, which runs these writers against a context that recomputes them every call)
     rng = np.random.default_rng(4)
     planes = [rng.uniform(0.01, 0.06, size=(h >> l, w >> l)).astype(np.float32) for l in range(L)]
 
@@ -781,6 +783,53 @@ def test_record_cache_is_invalidated_by_every_writer(ellc):
         ("depth map -> update_depth_image", lambda c: (c.depth_set_keyframe(1), c.depth_set_state(st), c.depth_regularize(False),
                                                       c.depth_update_depth_image())),
         ("saved weights", lambda c: c.align([0, 1], [1, 0], mode=0, save_weights=True)),
+        ("single-step API", lambda c: c.gn_iterate(0, 1, 1, np.zeros(6, np.float32))),
+    ]
+    for name, fn in writers:
+        fn(a); fn(b)
+        check(name)
+    a.close(); b.close()
+
+
+def test_hinv_cache_changes_no_bit(ellc):
+    """r06, constant-weight path in the tolerance mode: H^-1 per (slot, level) is a function of the keyframe's planes alone; while
+    they are unchanged the per-call compaction builds the records only (prep_scatter<16>). Against a context that recomputes the
+    inverses every call (ellc_debug_set_hinv_cache(0), the r05 behaviour) not a bit may differ — first calls, repeated calls, and
+    after every writer of image, depth or weight planes (incl. the FCA call that saves weights)."""
+    w, h, L = 160, 120, 3
+    pairs = [synth.make_pair(w, h, seed=500 + i, rot=0.004, trans=0.012) for i in range(3)]
+    kw = dict(early_exit=0, max_iter=(3, 4, 5), max_batch=2, max_keyframes=4, max_frames=4, arith=ellc.ARITH_FAST, diag=True)
+    a = gpu_problem(ellc, w, h, L, pairs, **kw)
+    b = gpu_problem(ellc, w, h, L, pairs, **kw)
+    b.debug_set_hinv_cache(False)
+    st = synth.make_depth_state(w, h, 7, pairs[1]["kf_image"], pairs[1]["idepth_true"])
+    rng = np.random.default_rng(4)
+    planes = [rng.uniform(0.01, 0.06, size=(h >> l, w >> l)).astype(np.float32) for l in range(L)]
+
+    def check(what):
+        for rep in range(3):   # the first call computes the inverses, the next ones find them
+            ra = a.align([0, 1], [0, 1], mode=1)
+            rb = b.align([0, 1], [0, 1], mode=1)
+            assert all(np.array_equal(x, y) for x, y in zip(ra, rb)), (what, rep)
+        ra, rb = a.align([1, 2], [1, 2], mode=1), b.align([1, 2], [1, 2], mode=1)   # one slot current, one not
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb)), (what, "mixed")
+
+    for ctx in (a, b):
+        for s in range(3):
+            for l in range(L):
+                ctx.keyframe_set_weights(s, l, np.full((h >> l, w >> l), 0.03, np.float32), 1)
+    check("initial")
+    writers = [
+        ("keyframe_set_depth", lambda c: c.keyframe_set_depth(0, pairs[2]["depth0"], pairs[2]["var0"])),
+        ("keyframe_set_depth_level", lambda c: c.keyframe_set_depth_level(1, 1, *[x.copy() for x in c.keyframe_depth_level(0, 1)])),
+        ("keyframe_set_weights", lambda c: [c.keyframe_set_weights(0, l, planes[l], 2) for l in range(L)]),
+        ("keyframe_finalise_weights", lambda c: c.keyframe_finalise_weights(0)),
+        ("keyframe_upload + depth", lambda c: (c.keyframe_upload(1, pairs[2]["kf_image"]), c.keyframe_set_depth(1, pairs[2]["depth0"], pairs[2]["var0"]),
+                                              [c.keyframe_set_weights(1, l, planes[l], 1) for l in range(L)])),
+        ("copy_slot", lambda c: c.copy_slot(1, 0, 1, 2)),
+        ("depth map -> update_depth_image", lambda c: (c.depth_set_keyframe(1), c.depth_set_state(st), c.depth_regularize(False),
+                                                      c.depth_update_depth_image())),
+        ("saved weights (FCA)", lambda c: c.align([0, 1], [1, 0], mode=0, save_weights=True)),
         ("single-step API", lambda c: c.gn_iterate(0, 1, 1, np.zeros(6, np.float32))),
     ]
     for name, fn in writers:
