@@ -2055,7 +2055,9 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, ELLC_QUAD_BLOCKS_PER_CU) void gn_f
             o.residual = res;
             if (active && fit && vv[j]) fca_accumulate_pixel(acc, o);
             pj += v_rfx;
-            __builtin_amdgcn_sched_barrier(0);   // one pixel after the other: interleaved, the four second halves do not fit the registers
+            // two pixels at a time: the compiler may interleave the second halves of a pair (dependent arithmetic of one fills the
+            // latencies of the other: 339.5 against 344.0 us at C4, three interleaved runs), not all four (registers)
+            if (j == 1) __builtin_amdgcn_sched_barrier(0);
           }
           // a quad that does not fit: its pixels join the wave's queue
           const bool nofit = active && !fit;
@@ -2071,7 +2073,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, ELLC_QUAD_BLOCKS_PER_CU) void gn_f
               qn += __builtin_popcountll(m);
             }
 #ifdef ELLC_QUAD_STATS
-            if (lane == 0) atomicAdd(&g_quad_stats[1], (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(nofit)));
+            { const unsigned long long mn = __builtin_amdgcn_ballot_w64(nofit); if (lane == 0) atomicAdd(&g_quad_stats[1], (unsigned long long)__builtin_popcountll(mn)); }
 #endif
           }
 #ifdef ELLC_QUAD_STATS
