@@ -78,6 +78,7 @@ struct KfLevelDev {
   float* sd;                  // ICA steepest-descent planes, 6 x cap (plane k at sd + k*cap)
   int* count;                 // V = number of compact entries
   int* tile_count;            // per-tile (ELLC_TILE pixels) counts, then exclusive offsets
+  float* idepth;              // n: v_rcp_f32 of `depth` where depth > 0, else 0 — kept for slots with the dense hint only (gn_fca_dense4 reads it in place of `depth`)
 };
 
 struct FrLevelDev {

@@ -981,7 +981,7 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       TRY(dev_alloc(c, &k.depth, n)); TRY(dev_alloc(c, &k.var, n)); TRY(dev_alloc(c, &k.weight, n));
       TRY(dev_alloc(c, &k.cxy, n)); TRY(dev_alloc(c, &k.cZ, n)); TRY(dev_alloc(c, &k.cI, n));
       TRY(dev_alloc(c, &k.crec, n)); TRY(dev_alloc(c, &k.cW, n)); TRY(dev_alloc(c, &k.wlast, n)); TRY(dev_alloc(c, &k.sd, 6 * n));
-      TRY(dev_alloc(c, &k.count, 4)); TRY(dev_alloc(c, &k.tile_count, tiles + 1));
+      TRY(dev_alloc(c, &k.count, 4)); TRY(dev_alloc(c, &k.tile_count, tiles + 1)); TRY(dev_alloc(c, &k.idepth, n));
       TRY(dev_alloc(c, &k.irec, n)); TRY(dev_alloc(c, &k.hpart, (size_t)(tiles + 1) * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
     }
     // (+ one row: the fifth row of gn_fca_dense4's tap windows may be the one below the image)
@@ -1391,6 +1391,13 @@ ellc_status ellc_keyframe_set_depth(ellc_ctx* c, int slot, const float* depth0, 
   ELLC_HIP(c, hipStreamSynchronize(c->stream));
   c->kf_has_depth[slot] = 1;
   c->kf_dense[slot] = (nvalid * 10 >= n0 * 9) ? 1 : 0;
+  if (c->kf_dense[slot])   // the reciprocal planes gn_fca_dense4 reads (KfLevelDev::idepth)
+    for (int l = 0; l < c->L; l++) {
+      const KfLevelDev& kl = c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + slot];
+      const int n = c->geom_h[l].n;
+      hipLaunchKernelGGL(idepth_plane, dim3((n + 255) / 256), dim3(256), 0, c->stream, kl.depth, kl.idepth, n);
+    }
+  ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
 }
 
@@ -1505,6 +1512,7 @@ static ellc_status copy_slot_planes(ellc_ctx* dc, int dst_is_kf, int dst, ellc_c
         const KfLevelDev& k = sc->kf_tab_h[(size_t)l * SK + src];
         ELLC_HIP(c, hipMemcpyAsync(d.depth, k.depth, (size_t)g.n * 4, hipMemcpyDeviceToDevice, dc->stream));
         ELLC_HIP(c, hipMemcpyAsync(d.var, k.var, (size_t)g.n * 4, hipMemcpyDeviceToDevice, dc->stream));
+        if (sc->kf_dense[src]) ELLC_HIP(c, hipMemcpyAsync(d.idepth, k.idepth, (size_t)g.n * 4, hipMemcpyDeviceToDevice, dc->stream));   // (the dense hint travels with the slot)
         ELLC_HIP(c, hipMemcpyAsync(d.weight, k.weight, (size_t)g.n * 4, hipMemcpyDeviceToDevice, dc->stream));
         dc->kf_num_weights[dst][l] = sc->kf_num_weights[src][l];
       } else {

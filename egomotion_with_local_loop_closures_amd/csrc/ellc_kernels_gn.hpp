@@ -1815,7 +1815,7 @@ struct QuadPlanes { f32x4_t Z, var; uint32_t I; };
 __device__ __forceinline__ QuadPlanes quad_request(const KfLevelDev& K, unsigned i4, unsigned img_off) {
   QuadPlanes p;
   const unsigned boff = i4 << 2;   // 32-bit byte offsets: uniform base + lane offset, no 64-bit lane arithmetic (planes < 4 GiB)
-  p.Z = *(const ELLC_GLOBAL f32x4_t*)((const ELLC_GLOBAL char*)K.depth + boff);
+  p.Z = *(const ELLC_GLOBAL f32x4_t*)((const ELLC_GLOBAL char*)K.idepth + boff);   // 1 / depth (0: none): KfLevelDev::idepth
   p.var = *(const ELLC_GLOBAL f32x4_t*)((const ELLC_GLOBAL char*)K.var + boff);
   p.I = *(const ELLC_GLOBAL uint32_t*)((const ELLC_GLOBAL char*)K.img + img_off);
   return p;
@@ -1958,12 +1958,12 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, ELLC_QUAD_BLOCKS_PER_CU) void gn_f
             xn = il - yn * cols4;
           }
           const unsigned inext = 4u * (unsigned)min(in_, end - 1);
-          // inverse depths; a pixel without depth takes a neighbour's (its point then lands beside theirs and does not spoil the fit)
+          // inverse depths (the slot's reciprocal planes: the v_rcp_f32 the compaction would store; 0 = no depth); a pixel without
+          // depth takes a neighbour's (its point then lands beside theirs and does not spoil the fit)
           const bool v0 = cZ.x > 0.0f, v1 = cZ.y > 0.0f, v2 = cZ.z > 0.0f, v3 = cZ.w > 0.0f;
-          float d0 = __builtin_amdgcn_rcpf(v0 ? cZ.x : 1.0f), d1 = __builtin_amdgcn_rcpf(v1 ? cZ.y : 1.0f);
-          float d2 = __builtin_amdgcn_rcpf(v2 ? cZ.z : 1.0f), d3 = __builtin_amdgcn_rcpf(v3 ? cZ.w : 1.0f);
+          float d0 = cZ.x, d1 = cZ.y, d2 = cZ.z, d3 = cZ.w;
           if (__builtin_amdgcn_ballot_w64(!(v0 && v1 && v2 && v3)) != 0ull) {
-            const float dref = v0 ? d0 : (v1 ? d1 : (v2 ? d2 : d3));
+            const float dref = v0 ? d0 : (v1 ? d1 : (v2 ? d2 : (v3 ? d3 : 1.0f)));
             d0 = v0 ? d0 : dref; d1 = v1 ? d1 : dref; d2 = v2 ? d2 : dref; d3 = v3 ? d3 : dref;
           }
           const float dd[4] = {d0, d1, d2, d3};

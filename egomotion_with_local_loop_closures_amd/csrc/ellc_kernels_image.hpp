@@ -210,6 +210,17 @@ __global__ __launch_bounds__(256) void maxgrad_fused(const uint8_t* __restrict__
   }
 }
 
+// 1 / depth of a dense keyframe level as the list-free kernels use it: the reciprocal the compaction stores in a tolerance-mode
+// record (v_rcp_f32), 0 where the pixel holds no depth. Written once per upload (ellc_keyframe_set_depth) for slots that carry the
+// dense hint; gn_fca_dense4 then reads it in place of the depth plane (four reciprocals and four selects per thread and step less).
+__global__ __launch_bounds__(256) void idepth_plane(const float* __restrict__ depth, float* __restrict__ idepth, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float z = depth[i];
+    idepth[i] = z > 0.0f ? __builtin_amdgcn_rcpf(z) : 0.0f;
+  }
+}
+
 // depthMap::buildInvVarDepth, one level (DepthPropagation.cpp:1637-1719); the reference's source stride
 // is 2*width of the destination. src_depth_is_mat: level-0 source holds keyFrame->depth (0 = invalid).
 __global__ void depth_pyr_level(const float* __restrict__ sd, const float* __restrict__ sv, float* __restrict__ dd, float* __restrict__ dv,
