@@ -265,7 +265,7 @@ ellc_status run_prep_levels(ellc_ctx* c, int n_unique, int need, int lvl_lo, int
   a.tile0 = c->tile_begin[lvl_lo];
   a.level0 = lvl_lo;
   const int tiles = c->tile_begin[lvl_hi + 1] - c->tile_begin[lvl_lo];
-  a.slot_inline[0] = a.slot_inline[1] = 0;
+  a.slot_inline = 0;
   a.lb_tag = 0;
   if (c->direct_launch && n_unique <= 2 && lvl_lo == 0 && lvl_hi == c->L - 1 && tiles * n_unique <= c->resident_blocks) {
     c->prep_tag = c->prep_tag % 0xfffffu + 1u;   // never 0, never what a count launch leaves in a word (its upper bits are 0)
@@ -295,7 +295,7 @@ static void enqueue_ica_hinv(ellc_ctx* c, int n_unique) {
   a.geom = c->geom_d;
   a.kf_tab = c->kf_tab_d;
   a.slots = c->uniq_slot_d;
-  a.slot_inline[0] = a.slot_inline[1] = 0;
+  a.slot_inline = 0;
   a.levels = c->L;
   a.max_kf = c->cfg.max_keyframes;
   for (int l = 0; l <= ELLC_MAX_LEVELS; l++) a.tile_begin[l] = c->tile_begin[std::min(l, c->L)];
@@ -569,7 +569,7 @@ ellc_status enqueue_eager_lists(ellc_ctx* c, int slot) {
   a.geom = c->geom_d;
   a.kf_tab = c->kf_tab_d;
   a.slots = nullptr;
-  a.slot_inline[0] = a.slot_inline[1] = slot;
+  a.slot_inline = slot;
   a.levels = c->L;
   a.max_kf = c->cfg.max_keyframes;
   for (int l = 0; l <= ELLC_MAX_LEVELS; l++) a.tile_begin[l] = c->tile_begin[std::min(l, c->L)];

@@ -24,7 +24,7 @@ struct PrepArgs {
                                // the tolerance mode's 16-byte form (IcaInF) instead of IcaRec
   int tile_begin[ELLC_MAX_LEVELS + 1];   // prefix of tiles per level
   int tile0, level0;           // this launch covers tiles tile0 + blockIdx.x (count / scatter), levels level0 + blockIdx.x (scan)
-  int slot_inline[2];          // the slots themselves when `slots` is null
+  int slot_inline;             // the slot itself when `slots` is null (one keyframe; a scalar: a dynamically indexed member would send the whole argument struct through private memory)
   unsigned lb_tag;             // 0: prep_count has left the tiles' counts. Else (r05, the tracking call: one or two keyframes, launched
                                // kernel by kernel) there is NO count launch: a scatter block publishes `lb_tag << 12 | its tile's count`
                                // as soon as it has it and sums the tagged counts of the tiles of its level in front of it as they
@@ -32,7 +32,10 @@ struct PrepArgs {
                                // waits for are resident or done). For launch groups the same was measured 17 % SLOWER (NOTEBOOK 5.1):
                                // 25 000 waiting blocks; here they are 201.
 };
-__device__ __forceinline__ int prep_slot(const PrepArgs& a, unsigned k) { return a.slots ? a.slots[k] : a.slot_inline[k & 1u]; }
+// (the value is block-uniform; said explicitly, because behind the null test the compiler loads a.slots[k] with a VECTOR load and then
+// carries the slot's table entry — every plane pointer of the kernel — in vector registers: prep_count 45.7 -> 58.3 us, prep_scatter
+// 122.8 -> 134.5 us per launch group, the batch pipeline 0.1245 -> 0.1317 ms per step, found by tools/ab_trace.sh in r06)
+__device__ __forceinline__ int prep_slot(const PrepArgs& a, unsigned k) { return __builtin_amdgcn_readfirstlane(a.slots ? a.slots[k] : a.slot_inline); }
 
 
 __device__ __forceinline__ int prep_level_of(const PrepArgs& a, int tile, int& local) {
