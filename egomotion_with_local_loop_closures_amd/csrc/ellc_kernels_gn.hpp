@@ -2013,8 +2013,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, ELLC_QUAD_BLOCKS_PER_CU) void gn_f
             // bytes s .. s + 3 of a row's window are columns x0 - 1 .. x0 + 2 of this pixel; its rows start at the window's first or second
             const float fx_ = __builtin_amdgcn_fractf(x1[j]), fy_ = __builtin_amdgcn_fractf(y1[j]);   // x - floor(x), exact for x >= 1
             const uint32_t s1 = (uint32_t)(x0[j] - xs);            // 0 .. 4 where the quad fits
-            const uint32_t s2 = s1 | (s1 << 8);
-            const uint32_t sel = (s2 | (s2 << 16)) + 0x03020100u;
+            const uint32_t sel = __builtin_amdgcn_perm(s1, s1, 0u) + 0x03020100u;   // (byte 0 of s1 four times: s .. s + 3)
             const bool dy = (y0[j] != ys);
             const uint32_t r0 = __builtin_amdgcn_perm(wAy, wAx, sel), r1 = __builtin_amdgcn_perm(wBy, wBx, sel), r2 = __builtin_amdgcn_perm(wCy, wCx, sel);
             const uint32_t r3 = __builtin_amdgcn_perm(wDy, wDx, sel), r4 = __builtin_amdgcn_perm(wEy, wEx, sel);
