@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
 # what include/ellc_abi_diag.h adds (measurement hooks, device self-tests, test hooks): exported by libellc_hip_diag.so only
 DIAG_SYMBOLS = [
     "ellc_profile_gn_kernel", "ellc_profile_align", "ellc_profile_depth_stage", "ellc_profile_calibrate_read", "ellc_profile_stream_read",
-    "ellc_selftest_div_pair", "ellc_selftest_lu", "ellc_debug_persist_delay", "ellc_debug_set_persist_epoch", "ellc_debug_persist_counters", "ellc_debug_set_eager_lists", "ellc_debug_set_hinv_cache",
+    "ellc_selftest_div_pair", "ellc_selftest_lu", "ellc_debug_persist_delay", "ellc_debug_set_persist_epoch", "ellc_debug_persist_counters", "ellc_debug_set_eager_lists", "ellc_debug_set_hinv_cache", "ellc_debug_set_fold_staging",
 ]
 
 

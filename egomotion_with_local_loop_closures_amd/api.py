@@ -321,6 +321,10 @@ class Context:
         self._need_diag("ellc_debug_set_eager_lists")
         self._ck(self._l.ellc_debug_set_eager_lists(self.h, int(bool(on))), "ellc_debug_set_eager_lists")
 
+    def debug_set_fold_staging(self, on):
+        self._need_diag("ellc_debug_set_fold_staging")
+        self._ck(self._l.ellc_debug_set_fold_staging(self.h, int(bool(on))), "ellc_debug_set_fold_staging")
+
     def debug_set_hinv_cache(self, on):
         self._need_diag("ellc_debug_set_hinv_cache")
         self._ck(self._l.ellc_debug_set_hinv_cache(self.h, int(bool(on))), "ellc_debug_set_hinv_cache")

@@ -60,6 +60,8 @@ struct ellc_ctx {
   std::vector<int> kf_rec_tag;
   std::vector<char> kf_rec_eager;   // the slot's lists were built behind the depth map's export and are valid whatever cfg.cache_records says (enqueue_eager_lists)
   bool eager_lists = true;
+  bool fold_staging = true;   // a tracking call whose lists are there leaves its staging to the resident launch (PersistStage)
+  bool stage_folded = false;  // ... decided by enqueue_stage_in for the launch being enqueued
   // ICA, tolerance mode: H^-1 per (slot, level) — the inverse of sum W J^T J over the keyframe's valid pixels (PixelWisePyramid.cpp:938-939)
   // — is a function of the keyframe's planes alone. kf_hinv_ok[slot]: the inverses the last compaction of the slot left are still
   // current (every writer of the planes clears it through invalidate_records): the next compaction builds the records only (r06)

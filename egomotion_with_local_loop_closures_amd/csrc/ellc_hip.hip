@@ -454,6 +454,13 @@ static ellc_status stage_batch(ellc_ctx* c, int B, const int* kf_slots, const in
 
 // device copy of the staged batch description, as a kernel reading the pinned record (part of the captured graph)
 static void enqueue_stage_in(ellc_ctx* c, int B) {
+  c->stage_folded = false;
+  if (c->direct_launch && B <= 2 && c->cur_resident && c->direct_nu == 0 && c->fold_staging) {
+    // the tracking call whose lists are already there (built behind the export): no staging launch — the resident launch builds the
+    // state records itself and takes the batch description and the seeds count along (PersistStage, enqueue_schedule_persist)
+    c->stage_folded = true;
+    return;
+  }
   if (c->direct_launch && B <= 2) {   // not being captured: the record travels in the kernel arguments (stage_in_args)
     StageSmall ss;
     for (int b = 0; b < 2; b++) {
@@ -672,16 +679,38 @@ static ellc_status enqueue_schedule_persist(ellc_ctx* c, int B, int save_weights
   fa.nblk_grid = G;
   fa.persist_bar = c->persist_bar_d;
   const int max_rounds = persist_rounds(c);   // <= 255 (may_run_resident)
-  const unsigned epoch = (++c->persist_epoch) & 0xffffffu;
-  c->persist_launches++;   // the records of earlier calls never match (the round sits in the low byte)
-  const dim3 grd(G, B), blk(ELLC_GN_THREADS);
+  const unsigned epoch = (++c->persist_epoch) & 0xffffffu;   // the records of earlier calls never match (the round sits in the low byte)
+  c->persist_launches++;
+  PersistStage ps;
+  std::memset(&ps, 0, sizeof(ps));
+  ps.persist_blocks = G;
+  if (c->stage_folded) {   // (enqueue_stage_in left the staging to this launch)
+    ps.on = 1;
+    for (int b = 0; b < 2; b++) {
+      ps.s.kf[b] = b < B ? c->kf_slot_h[b] : 0;
+      ps.s.fr[b] = b < B ? c->fr_slot_h[b] : 0;
+      ps.s.uniq[b] = 0;
+      for (int i = 0; i < 6; i++) ps.s.pose[b * 6 + i] = b < B ? c->init_pose_h[b * 6 + i] : 0.0f;
+    }
+    ps.dst = c->kf_slot_d;
+    ps.cap = c->group_cap;
+    ps.top_level = c->L - 1;
+    ps.count_valid = (const uint8_t*)c->track_count_valid;
+    ps.count_n = c->track_count_n;
+    ps.count_blocks = c->track_count_n > 0 ? std::max(1, ((c->track_count_n >> 4) + ELLC_GN_THREADS - 1) / ELLC_GN_THREADS) : 0;
+    ps.count_acc = c->seed_acc;
+    ps.count_host = c->track_dev_alias;
+    c->track_count_n = 0;   // (taken along)
+    c->stage_folded = false;
+  }
+  const dim3 grd(G + ps.count_blocks, B), blk(ELLC_GN_THREADS);
   if (c->fast) {
-    if (save_weights) hipLaunchKernelGGL((gn_fca_persist<false, true, 1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls);
-    else hipLaunchKernelGGL((gn_fca_persist<false, true, 0>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls);
+    if (save_weights) hipLaunchKernelGGL((gn_fca_persist<false, true, 1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls, ps);
+    else hipLaunchKernelGGL((gn_fca_persist<false, true, 0>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls, ps);
   } else if (c->geom_h[0].divc_ok) {
-    hipLaunchKernelGGL((gn_fca_persist<true, false, -1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls);
+    hipLaunchKernelGGL((gn_fca_persist<true, false, -1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls, ps);
   } else {
-    hipLaunchKernelGGL((gn_fca_persist<false, false, -1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls);
+    hipLaunchKernelGGL((gn_fca_persist<false, false, -1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls, ps);
   }
   // (no finish kernel: the launch's first block per alignment has written the final record, the result and the tracking fields)
   if (save_weights) launch_add_saved_weights(c, B);
@@ -1227,6 +1256,12 @@ ellc_status ellc_debug_set_eager_lists(ellc_ctx* c, int on) {
   ELLC_ENTER(c);
   c->eager_lists = on != 0;
   if (!on) std::fill(c->kf_rec_eager.begin(), c->kf_rec_eager.end(), 0);
+  return ELLC_OK;
+}
+ellc_status ellc_debug_set_fold_staging(ellc_ctx* c, int on) {
+  if (!c) return ELLC_ERR_BAD_ARG;
+  ELLC_ENTER(c);
+  c->fold_staging = on != 0;
   return ELLC_OK;
 }
 ellc_status ellc_debug_set_hinv_cache(ellc_ctx* c, int on) {

@@ -1210,7 +1210,8 @@ __device__ void dm_count_valid_body(const uint8_t* __restrict__ valid, int n, in
   int mine = 0;
   const int n16 = n >> 4;
   const uint4* v16 = (const uint4*)valid;   // plane buffers are 256-byte aligned
-  const int i = block * 1024 + threadIdx.x;
+  const int bd = (int)blockDim.x;   // 1024 (dm_count_valid_block, the staging launch) or 256 (riding in gn_fca_persist's launch)
+  const int i = block * bd + threadIdx.x;
   if (i < n16) {
     const uint4 w = v16[i];
     const unsigned q[4] = {w.x, w.y, w.z, w.w};
@@ -1219,8 +1220,10 @@ __device__ void dm_count_valid_body(const uint8_t* __restrict__ valid, int n, in
       mine += ((q[k] & 0xffu) != 0) + ((q[k] & 0xff00u) != 0) + ((q[k] & 0xff0000u) != 0) + ((q[k] & 0xff000000u) != 0);
   }
   if (block == 0)
-    for (int k = (n16 << 4) + threadIdx.x; k < n; k += 1024) mine += valid[k] ? 1 : 0;
+    for (int k = (n16 << 4) + threadIdx.x; k < n; k += bd) mine += valid[k] ? 1 : 0;
   __shared__ int part[16];
+  if (threadIdx.x < 16) part[threadIdx.x] = 0;
+  __syncthreads();
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) mine += __shfl_xor(mine, m, 64);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;

@@ -2411,11 +2411,39 @@ __device__ __forceinline__ bool persist_adopt_state(const unsigned* line, unsign
 template <bool FAST, bool ADAPT>
 __device__ __forceinline__ void fused_finish_body(const FusedArgs& fa, int b, const AlignState& src, AlignState* dst, SolveShared& sh);
 
+// The staging of a tracking call folded into its resident launch (r06): when the call's lists are already there (built behind the
+// depth map's export) the staging kernel's only work is the batch description (two slots, the initial pose) and the state records
+// — a 5 us launch and a kernel boundary in front of the alignment of every tracked frame. With `on` every block builds its copy of
+// the state record itself from the kernel arguments (exp(pose) by nine lanes, exactly stage_in_args's operations), block 0 of each
+// alignment writes the device-side batch description for the kernels behind the launch, and ellc_track_frame's count of the valid
+// hypotheses rides in `count_blocks` extra blocks of this launch (blockIdx.x >= the persist blocks, first alignment) instead.
+struct StageSmall {
+  int kf[2], fr[2], uniq[2];
+  float pose[12];
+};
+struct PersistStage {
+  int on;
+  StageSmall s;
+  int* dst;            // the device-side batch description (kf slots | frame slots | unique slots | initial poses), `cap` apart
+  int cap, top_level;
+  int persist_blocks;  // blocks per alignment of the schedule itself (the grid's x extent may be larger: count blocks)
+  const uint8_t* count_valid;
+  int count_n, count_blocks;
+  int* count_acc;
+  int* count_host;
+};
+__device__ void dm_count_valid_body(const uint8_t* valid, int n, int* acc, int* host_visible, int block, int nblocks);
+
 template <bool DIVC, bool FAST, int SAVEW>
 __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(FusedArgs fa, int max_rounds, unsigned epoch, unsigned spin_limit,
-                                                                              int delay_from, int delay_polls) {
+                                                                              int delay_from, int delay_polls, PersistStage ps) {
   const GnArgs& a = fa.g;
   const int b = blockIdx.y, sub = blockIdx.x, t = threadIdx.x;
+  if (ps.on && sub >= ps.persist_blocks) {   // block-uniform: a count block (see PersistStage)
+    if (b == 0 && sub - ps.persist_blocks < ps.count_blocks)
+      dm_count_valid_body(ps.count_valid, ps.count_n, ps.count_acc, ps.count_host, sub - ps.persist_blocks, ps.count_blocks);
+    return;
+  }
   __shared__ SolveShared sh;
   __shared__ AlignState st;   // this block's copy of the alignment's record (see above)
   __shared__ int s_flag, s_seq, s_level;
@@ -2424,14 +2452,38 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(
   if (delay_polls > 0 && sub >= delay_from)   // test hook (ellc_debug_persist_delay): these blocks start late, as if dispatched late
     for (int i = 0; i < delay_polls; i++) __builtin_amdgcn_s_sleep(32);
   AlignState* rec = a.state + b;   // buffer 0: initialised by the staging kernel; the final record for gn_fused_finish
-  {
+  const bool writer = (sub == 0);
+  if (ps.on) {   // (block-uniform) the record the staging kernel would have left, built here
+    uint32_t* dp = (uint32_t*)&st;
+    for (int i = t; i < (int)(sizeof(AlignState) / 4); i += ELLC_GN_THREADS) dp[i] = 0u;   // delta, b, H, Hinv, iters, pending, it_in_level
+    __syncthreads();
+    if (t < 16) {   // stage_in_args's lanes of one alignment
+      const int l = t, l9 = min(l, 8), r3 = l9 / 3, k3 = l9 - 3 * r3;
+      const float* p = ps.s.pose + min(b, 1) * 6;
+      double Rrk, Vv;
+      exp_se3_entry((double)p[0], (double)p[1], (double)p[2], (double)p[3], (double)p[4], (double)p[5], r3, k3, Rrk, Vv);
+      const double trow = (Vv + __shfl_down(Vv, 1)) + __shfl_down(Vv, 2);
+      if (l < 9) {
+        st.S[r3 * 4 + k3] = (float)Rrk;
+        if (k3 == 0) st.S[r3 * 4 + 3] = (float)trow;
+      }
+      if (l < 6) st.pose[l] = p[l];
+      if (l == 9) { st.weighted = 0.0f; st.level_done = -1; st.pending = 0; st.cur_level = ps.top_level; st.it_in_level = 0; }
+    }
+    if (writer && t >= 64 && t < 64 + 16) {   // the batch description for the kernels behind this launch (saved weights, ...)
+      const int k = t - 64;
+      if (k == 0) { ps.dst[b] = ps.s.kf[min(b, 1)]; ps.dst[ps.cap + b] = ps.s.fr[min(b, 1)]; }
+      if (k < 6) ((float*)(ps.dst + 3 * ps.cap))[b * 6 + k] = ps.s.pose[min(b, 1) * 6 + k];
+    }
+  } else {
     const uint32_t* sp = (const uint32_t*)rec;
     uint32_t* dp = (uint32_t*)&st;
     for (int i = t; i < (int)(sizeof(AlignState) / 4); i += ELLC_GN_THREADS) dp[i] = sp[i];
   }
   __syncthreads();
-  const bool writer = (sub == 0);
-  const int slot = a.kf_slot[b], frs = a.fr_slot[b];
+  // (block-uniform, said so: a slot in a vector register would drag every table entry behind it into vector registers — NOTEBOOK 6.4)
+  const int slot = __builtin_amdgcn_readfirstlane(ps.on ? ps.s.kf[min(b, 1)] : a.kf_slot[b]);
+  const int frs = __builtin_amdgcn_readfirstlane(ps.on ? ps.s.fr[min(b, 1)] : a.fr_slot[b]);
   if (t == 0) s_flag = 0;
   __syncthreads();
   for (int seq = 0; seq < max_rounds; seq++) {
@@ -2835,13 +2887,9 @@ __global__ void stage_in(int* __restrict__ dst, const int* __restrict__ src_host
 
 // The same for a schedule that is launched kernel by kernel (the tracking call, one or two alignments): the staged record
 // arrives in the kernel arguments instead of being read from pinned host memory (a PCIe round trip at the head of the chain)
-struct StageSmall {
-  int kf[2], fr[2], uniq[2];
-  float pose[12];
-};
+// (StageSmall: defined in front of gn_fca_persist, which can take the staging along)
 // count_*: ellc_track_frame's seeds figure rides along — blocks 1.. count the depth map's valid hypotheses (dm_count_valid_body,
 // ellc_kernels_depth.hpp) while block 0 stages; count_valid == nullptr: a launch of one block
-__device__ void dm_count_valid_body(const uint8_t* valid, int n, int* acc, int* host_visible, int block, int nblocks);
 __global__ __launch_bounds__(1024) void stage_in_args(int* __restrict__ dst, StageSmall s, int B, int n_unique, int cap, AlignState* state, int top_level,
                                                       const uint8_t* count_valid, int count_n, int* count_acc, int* count_host) {
   if (blockIdx.x > 0) {
