@@ -2321,6 +2321,15 @@ ellc_status ellc_debug_stamps(ellc_ctx* c, unsigned long long* out64) {
   ELLC_HIP(c, hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_stamps), 64 * sizeof(unsigned long long)));
   return ELLC_OK;
 }
+// the last resident launch's rounds as eight of its blocks saw them (g_ptrace): 8 x 64 x 12 words
+ellc_status ellc_debug_persist_trace(ellc_ctx* c, unsigned long long* out) {
+  ELLC_ENTER(c);
+  ELLC_HIP(c, hipStreamSynchronize(c->stream));
+  ELLC_HIP(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ptrace), sizeof(unsigned long long) * 8 * 64 * 12));
+  unsigned long long* z = (unsigned long long*)calloc(8 * 64 * 12, sizeof(unsigned long long));
+  if (z) { ELLC_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(g_ptrace), z, sizeof(unsigned long long) * 8 * 64 * 12)); free(z); }
+  return ELLC_OK;
+}
 ellc_status ellc_debug_block_stamps(ellc_ctx* c, unsigned long long* out, int nblocks) {
   ELLC_ENTER(c);
   ELLC_HIP(c, hipStreamSynchronize(c->stream));

@@ -34,9 +34,35 @@ __device__ unsigned long long g_block_stamps[4 * 8192];   // per block: start, p
       g_stamps[id] = t__;                                                                                    \
     }                                                                                                        \
   } while (0)
+// gn_fca_persist, per round of eight of its blocks (alignment 0), 12 words: 0 loop top, 1 level tables read + first record requested,
+// 2 records gathered, 3 solved, 4 pass: constants formed, 5 taps used, 6 pixel done, 7 pass returned, 8 wave sums, 9 block barrier,
+// 10 record stored, 11 level << 8 | works  (tools/dbg/persist_trace.py)
+__device__ unsigned long long g_ptrace[8 * 64 * 12];
+__device__ __forceinline__ int ptrace_slot(int sub) {
+  return sub == 0 ? 0 : sub == 1 ? 1 : sub == 8 ? 2 : sub == 16 ? 3 : sub == 48 ? 4 : sub == 100 ? 5 : sub == 200 ? 6 : sub == 255 ? 7 : -1;
+}
+__device__ int* ptrace_base_ptr() { __shared__ int base; return &base; }
+#define ELLC_PTRACE_ROUND(sub, round)                                                                        \
+  do {                                                                                                       \
+    const int ps__ = ptrace_slot(sub);                                                                       \
+    if (threadIdx.x == 0) *ptrace_base_ptr() = (blockIdx.y == 0 && ps__ >= 0 && (round) < 64) ? (ps__ * 64 + (round)) * 12 : -1; \
+  } while (0)
+#define ELLC_PTRACE(k, val)                                                                                  \
+  do {                                                                                                       \
+    if (threadIdx.x == 0) {                                                                                  \
+      const int pb__ = *ptrace_base_ptr();                                                                   \
+      if (pb__ >= 0 && pb__ <= (8 * 64 - 1) * 12) {                                                          \
+        unsigned long long t__;                                                                              \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                     \
+        g_ptrace[pb__ + (k)] = (k) == 11 ? (unsigned long long)(val) : t__;                                  \
+      }                                                                                                      \
+    }                                                                                                        \
+  } while (0)
 #else
 #define ELLC_STAMP(id) do { } while (0)
 #define ELLC_BSTAMP(slot) do { } while (0)
+#define ELLC_PTRACE(k, val) do { } while (0)
+#define ELLC_PTRACE_ROUND(sub, round) do { } while (0)
 #endif
 // -DELLC_SEQ_STAMPS (tools/dbg/seq_stamps.py): the launches of ONE sequence on one clock — block (0, 0)'s entry into launch n of the
 // schedule in g_seq_stamps[n], its exit in g_seq_stamps[32 + n] (gn_fca_fused only)
@@ -129,8 +155,40 @@ __device__ __forceinline__ Taps tap_general(g_u8 img, int sw, int cols, int rows
   const int yb = clampi(y0, 0, rows - 1), yc = clampi(y0 + 1, 0, rows - 1);
   // uniform base pointer + unsigned 32-bit lane offsets (SGPR-base global loads, no 64-bit lane arithmetic)
   const unsigned rb = __umul24((unsigned)yb, (unsigned)sw), rc = __umul24((unsigned)yc, (unsigned)sw);   // rows are clamped to >= 0
-  const float Pbb = (float)img[rb + (unsigned)xb], Pbc = (float)img[rb + (unsigned)xc];
-  const float Pcb = (float)img[rc + (unsigned)xb], Pcc = (float)img[rc + (unsigned)xc];
+  const int xa = clampi(x0 - 1, 0, cols - 1), xd = clampi(x0 + 2, 0, cols - 1);
+  const int ya = clampi(y0 - 1, 0, rows - 1), yd = clampi(y0 + 2, 0, rows - 1);
+  const unsigned ra = __umul24((unsigned)ya, (unsigned)sw), rd = __umul24((unsigned)yd, (unsigned)sw);
+  float Pbb, Pbc, Pcb, Pcc, Pba = 0.0f, Pbd = 0.0f, Pca = 0.0f, Pcd = 0.0f, Pab = 0.0f, Pac = 0.0f, Pdb = 0.0f, Pdc = 0.0f;
+  if (cols >= 4) {   // (uniform)
+    // The clamped columns x0 - 1 .. x0 + 2 of a point whose cell touches the image lie in ONE four-byte window that starts at
+    // xs = clamp(x0 - 1, 0, cols - 4): one unaligned dword per (clamped) row and a byte pick per sample instead of twelve byte
+    // loads — which the register allocator of the 128- and 168-register kernels turned into load, wait, load, wait (r06:
+    // tools/dbg/persist_trace.py — a wave on the image border, i.e. every wave of the two coarse levels, took 0.65 us longer
+    // per pixel than an interior one). The same bytes, hence the same taps.
+    const int xs = clampi(x0 - 1, 0, cols - 4);
+    const unsigned sa = 8u * (unsigned)clampi(xa - xs, 0, 3), sb = 8u * (unsigned)clampi(xb - xs, 0, 3);
+    const unsigned sc = 8u * (unsigned)clampi(xc - xs, 0, 3), sd = 8u * (unsigned)clampi(xd - xs, 0, 3);
+    const uint32_t wb = load_u32_unaligned(img, rb + (unsigned)xs), wc = load_u32_unaligned(img, rc + (unsigned)xs);
+    uint32_t wa = 0, wd = 0;
+    if (WANT_GRAD) { wa = load_u32_unaligned(img, ra + (unsigned)xs); wd = load_u32_unaligned(img, rd + (unsigned)xs); }
+    Pbb = (float)((wb >> sb) & 0xffu); Pbc = (float)((wb >> sc) & 0xffu);
+    Pcb = (float)((wc >> sb) & 0xffu); Pcc = (float)((wc >> sc) & 0xffu);
+    if (WANT_GRAD) {
+      Pba = (float)((wb >> sa) & 0xffu); Pbd = (float)((wb >> sd) & 0xffu);
+      Pca = (float)((wc >> sa) & 0xffu); Pcd = (float)((wc >> sd) & 0xffu);
+      Pab = (float)((wa >> sb) & 0xffu); Pac = (float)((wa >> sc) & 0xffu);
+      Pdb = (float)((wd >> sb) & 0xffu); Pdc = (float)((wd >> sc) & 0xffu);
+    }
+  } else {
+    Pbb = (float)img[rb + (unsigned)xb]; Pbc = (float)img[rb + (unsigned)xc];
+    Pcb = (float)img[rc + (unsigned)xb]; Pcc = (float)img[rc + (unsigned)xc];
+    if (WANT_GRAD) {
+      Pba = (float)img[rb + (unsigned)xa]; Pbd = (float)img[rb + (unsigned)xd];
+      Pca = (float)img[rc + (unsigned)xa]; Pcd = (float)img[rc + (unsigned)xd];
+      Pab = (float)img[ra + (unsigned)xb]; Pac = (float)img[ra + (unsigned)xc];
+      Pdb = (float)img[rd + (unsigned)xb]; Pdc = (float)img[rd + (unsigned)xc];
+    }
+  }
   {
     const float p00 = v00 ? Pbb : 0.0f, p01 = v01 ? Pbc : 0.0f, p10 = v10 ? Pcb : 0.0f, p11 = v11 ? Pcc : 0.0f;
     const float top = (omx * p00) + (wx * p01);
@@ -138,13 +196,6 @@ __device__ __forceinline__ Taps tap_general(g_u8 img, int sw, int cols, int rows
     o.I = (omy * top) + (wy * btm);
   }
   if (WANT_GRAD) {
-    const int xa = clampi(x0 - 1, 0, cols - 1), xd = clampi(x0 + 2, 0, cols - 1);
-    const int ya = clampi(y0 - 1, 0, rows - 1), yd = clampi(y0 + 2, 0, rows - 1);
-    const unsigned ra = __umul24((unsigned)ya, (unsigned)sw), rd = __umul24((unsigned)yd, (unsigned)sw);
-    const float Pba = (float)img[rb + (unsigned)xa], Pbd = (float)img[rb + (unsigned)xd];
-    const float Pca = (float)img[rc + (unsigned)xa], Pcd = (float)img[rc + (unsigned)xd];
-    const float Pab = (float)img[ra + (unsigned)xb], Pac = (float)img[ra + (unsigned)xc];
-    const float Pdb = (float)img[rd + (unsigned)xb], Pdc = (float)img[rd + (unsigned)xc];
     // scale 1 on the border column/row of the tap itself, 0.5 inside
     const float sx0 = (x0 <= 0 || x0 >= cols - 1) ? 1.0f : 0.5f;
     const float sx1 = (x0 + 1 <= 0 || x0 + 1 >= cols - 1) ? 1.0f : 0.5f;
@@ -304,12 +355,19 @@ __device__ __forceinline__ TapReq tap_request_f(const TapRows& tr, int sw, int c
   // NaN coordinate converts to 0 and an infinite one saturates: neither is interior
   const bool interior = ((unsigned)(x0 - 1) <= (unsigned)(cols - 4)) & ((unsigned)(y0 - 1) <= (unsigned)(rows - 4));
   q.interior = (__builtin_amdgcn_ballot_w64(!interior) == 0ull);
+#ifdef ELLC_X_FORCE_INTERIOR   // experiment (WRONG values on the border): what the general path costs the coarse levels
+  q.interior = true;
+#endif
   // (r04 measured the straight-line form — the rows requested unconditionally, a lane that is not interior asking for the image's
   // first bytes — which a software pipeline over pixels needs: 5 % slower on the batch pipeline, the coarse levels' waves on the
   // image border pay for four requests they do not use)
   q.wb = 0; q.wc = 0;
   if (q.interior) {
+#ifdef ELLC_X_FORCE_INTERIOR
+    const unsigned off = __umul24((unsigned)min(max(y0, 1), rows - 3), (unsigned)sw) + (unsigned)min(max(x0, 1), cols - 3);
+#else
     const unsigned off = __umul24((unsigned)y0, (unsigned)sw) + (unsigned)x0;
+#endif
 #ifdef ELLC_X_LDSTAPS   // variant builds only (tools/pmc_ldstaps.sh; WRONG values): what the four rows would cost as reads of an LDS
                         // window that is already there — two aligned dwords + v_alignbit per row, no staging, no window arithmetic
     __shared__ uint32_t xl[4 * 1024 + 4];
@@ -1476,6 +1534,7 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
     if (begin < end) {   // block-uniform
       const TapRows tr = tap_rows(cur, g.sw);
       const FcafConst fc = fcaf_const(g, S);
+      ELLC_PTRACE(4, 0);
       // One pixel per step: the rows are requested and used in the same step; the next pixel's record is requested behind them. The
       // record stream is walked by byte offset, clamped to the chunk's last record, so that every request is unconditional, and the
       // trip count is block-uniform — every thread of the block has n_full pixels, the first `rem` threads one more, and a thread
@@ -1494,7 +1553,9 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
         const bool active = !last || rem == 0 || t < rem;
         auto refill = [&]() { next_rec = fcaf_load_off(K, min(off + S16, off_last)); };
         const FcafStage st = fcaf_stage_a(g, tr, fc, cur_rec, refill);
+        ELLC_PTRACE(5, 0);
         if (active) fca_accumulate_pixel(acc, fcaf_stage_b<false, SAVEW>(a, K, g, cur, fc, idx, st));
+        ELLC_PTRACE(6, 0);
         off += S16; idx += stride;
       };
       for (int k = 0; k < n_steps; k += 2) {
@@ -2274,12 +2335,14 @@ __device__ __forceinline__ void persist_store_record(float (&acc)[27], unsigned*
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float rows[WaveRows<27>::N2];
   wave_sum_rows<27>(acc, rows);
+  ELLC_PTRACE(8, 0);
   if ((lane & 15) == 0) {
     const int q = lane >> 4, col = 2 * (q & 1) + (q >> 1);
 #pragma unroll
     for (int j = 0; j < WaveRows<27>::N2; j++) red[wave][4 * j + col] = rows[j];
   }
   __syncthreads();
+  ELLC_PTRACE(9, 0);
   if (threadIdx.x < 32) {
     const int w = (int)threadIdx.x, sidx = w - (w >> 3);
     const bool tagl = (w & 7) == 7;
@@ -2487,6 +2550,8 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(
   if (t == 0) s_flag = 0;
   __syncthreads();
   for (int seq = 0; seq < max_rounds; seq++) {
+    ELLC_PTRACE_ROUND(sub, seq);
+    ELLC_PTRACE(0, 0);
     const int lvl = st.cur_level, pending = st.pending, it_in = st.it_in_level;
     if (lvl < 0) break;
     const int nb_l = fa.nblk_lv[lvl];
@@ -2512,10 +2577,13 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(
       first_pre = fca_prepare<DIVC>(g, first);
     }
     bool adopted = false;
+    ELLC_PTRACE(1, 0);
+    ELLC_PTRACE(11, (lvl << 8) | (sub < nb_l ? 1 : 0));
     if (pending) {
       double group_sum;
       const int got = persist_group_sum(pend, nb_l, (epoch << 8) | (unsigned)seq, abortw, epoch | 0x80000000u, spin_limit, group_sum);   // the records of round seq (the previous iteration's)
       if (got != PERSIST_OK && (t & 63) == 0) atomicMax(&s_flag, got == PERSIST_LAPPED && sub >= nb_l ? 2 : 1);   // (a writer cannot be lapped: treated as a reason to abandon)
+      ELLC_PTRACE(2, 0);
       __syncthreads();
       if (s_flag == 1) break;   // abandoned (block-uniform); the record still names this iteration's level with its sums unsolved
       if (s_flag == 2) {        // lapped (block-uniform; this block writes nothing at this level): re-join at the next level's beginning
@@ -2538,6 +2606,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(
       if (t == 0) { sh.weighted = st.weighted; sh.level_done = st.level_done; }
       __syncthreads();
     }
+    ELLC_PTRACE(3, 0);
     const int it = it_in + (pending ? 1 : 0);
     const bool over = adopted || (pending && (sh.level_done == lvl || it >= fa.max_it[lvl]));   // the level has ended: early exit, or its cap
     const int nl = adopted ? s_level : (over ? lvl - 1 : lvl);
@@ -2578,8 +2647,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(
       g_u8 cur = as_global(F->img);
       float sums[27];
       fca_chunk_pass<DIVC, true, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
+      ELLC_PTRACE(7, 0);
       unsigned* out = (unsigned*)(a.partials + (size_t)(seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE);
       persist_store_record(sums, out, (epoch << 8) | (unsigned)(seq + 1));
+      ELLC_PTRACE(10, 0);
     }
     __syncthreads();   // (`st` is read again at the top)
   }
