@@ -129,7 +129,7 @@ struct Taps {
 
 // The general path of the taps: per-tap bounds tests of the reference (Frame.h:211-275). FAST: the gradients are returned twice
 // their value, as the interior branches of that mode return them.
-template <bool WANT_GRAD, bool FAST>
+template <bool WANT_GRAD, bool FAST, bool LAT = false>
 __device__ __forceinline__ Taps tap_general(g_u8 img, int sw, int cols, int rows, float x1, float y1) {
   Taps o;
   const float fx0 = floorf(x1), fy0 = floorf(y1);
@@ -155,40 +155,57 @@ __device__ __forceinline__ Taps tap_general(g_u8 img, int sw, int cols, int rows
   const int yb = clampi(y0, 0, rows - 1), yc = clampi(y0 + 1, 0, rows - 1);
   // uniform base pointer + unsigned 32-bit lane offsets (SGPR-base global loads, no 64-bit lane arithmetic)
   const unsigned rb = __umul24((unsigned)yb, (unsigned)sw), rc = __umul24((unsigned)yc, (unsigned)sw);   // rows are clamped to >= 0
-  const int xa = clampi(x0 - 1, 0, cols - 1), xd = clampi(x0 + 2, 0, cols - 1);
-  const int ya = clampi(y0 - 1, 0, rows - 1), yd = clampi(y0 + 2, 0, rows - 1);
-  const unsigned ra = __umul24((unsigned)ya, (unsigned)sw), rd = __umul24((unsigned)yd, (unsigned)sw);
-  float Pbb, Pbc, Pcb, Pcc, Pba = 0.0f, Pbd = 0.0f, Pca = 0.0f, Pcd = 0.0f, Pab = 0.0f, Pac = 0.0f, Pdb = 0.0f, Pdc = 0.0f;
-  if (cols >= 4) {   // (uniform)
-    // The clamped columns x0 - 1 .. x0 + 2 of a point whose cell touches the image lie in ONE four-byte window that starts at
-    // xs = clamp(x0 - 1, 0, cols - 4): one unaligned dword per (clamped) row and a byte pick per sample instead of twelve byte
-    // loads — which the register allocator of the 128- and 168-register kernels turned into load, wait, load, wait (r06:
-    // tools/dbg/persist_trace.py — a wave on the image border, i.e. every wave of the two coarse levels, took 0.65 us longer
-    // per pixel than an interior one). The same bytes, hence the same taps.
-    const int xs = clampi(x0 - 1, 0, cols - 4);
-    const unsigned sa = 8u * (unsigned)clampi(xa - xs, 0, 3), sb = 8u * (unsigned)clampi(xb - xs, 0, 3);
-    const unsigned sc = 8u * (unsigned)clampi(xc - xs, 0, 3), sd = 8u * (unsigned)clampi(xd - xs, 0, 3);
-    const uint32_t wb = load_u32_unaligned(img, rb + (unsigned)xs), wc = load_u32_unaligned(img, rc + (unsigned)xs);
-    uint32_t wa = 0, wd = 0;
-    if (WANT_GRAD) { wa = load_u32_unaligned(img, ra + (unsigned)xs); wd = load_u32_unaligned(img, rd + (unsigned)xs); }
-    Pbb = (float)((wb >> sb) & 0xffu); Pbc = (float)((wb >> sc) & 0xffu);
-    Pcb = (float)((wc >> sb) & 0xffu); Pcc = (float)((wc >> sc) & 0xffu);
+  if constexpr (LAT) {
+    // The latency regime (gn_fca_persist: one pixel per thread and round, nothing else in flight): all the samples are requested
+    // TOGETHER, whatever the register allocator would like (the barrier) — in the 168-register resident kernel it had turned the
+    // first four into load, wait, load, wait, and a wave on the image border, i.e. every wave of the two coarse levels (the depth
+    // pyramid's border shrinks with the level), took 0.65 us longer per pixel than an interior one (tools/dbg/persist_trace.py,
+    // r06). The same loads and the same arithmetic as below: the same taps. NOT for the batch pipeline's kernels: with the
+    // barrier their coarse-level launches were 12 % slower (and 4.5 % of a whole step), NOTEBOOK 6.8.
+    const int xa = clampi(x0 - 1, 0, cols - 1), xd = clampi(x0 + 2, 0, cols - 1);
+    const int ya = clampi(y0 - 1, 0, rows - 1), yd = clampi(y0 + 2, 0, rows - 1);
+    const unsigned ra = __umul24((unsigned)ya, (unsigned)sw), rd = __umul24((unsigned)yd, (unsigned)sw);
+    const uint32_t bbb = img[rb + (unsigned)xb], bbc = img[rb + (unsigned)xc], bcb = img[rc + (unsigned)xb], bcc = img[rc + (unsigned)xc];
+    uint32_t bba = 0, bbd = 0, bca = 0, bcd = 0, bab = 0, bac = 0, bdb = 0, bdc = 0;
     if (WANT_GRAD) {
-      Pba = (float)((wb >> sa) & 0xffu); Pbd = (float)((wb >> sd) & 0xffu);
-      Pca = (float)((wc >> sa) & 0xffu); Pcd = (float)((wc >> sd) & 0xffu);
-      Pab = (float)((wa >> sb) & 0xffu); Pac = (float)((wa >> sc) & 0xffu);
-      Pdb = (float)((wd >> sb) & 0xffu); Pdc = (float)((wd >> sc) & 0xffu);
+      bba = img[rb + (unsigned)xa]; bbd = img[rb + (unsigned)xd];
+      bca = img[rc + (unsigned)xa]; bcd = img[rc + (unsigned)xd];
+      bab = img[ra + (unsigned)xb]; bac = img[ra + (unsigned)xc];
+      bdb = img[rd + (unsigned)xb]; bdc = img[rd + (unsigned)xc];
     }
-  } else {
-    Pbb = (float)img[rb + (unsigned)xb]; Pbc = (float)img[rb + (unsigned)xc];
-    Pcb = (float)img[rc + (unsigned)xb]; Pcc = (float)img[rc + (unsigned)xc];
+    __builtin_amdgcn_sched_barrier(0);
+    const float Pbb = (float)bbb, Pbc = (float)bbc, Pcb = (float)bcb, Pcc = (float)bcc;
+    {
+      const float p00 = v00 ? Pbb : 0.0f, p01 = v01 ? Pbc : 0.0f, p10 = v10 ? Pcb : 0.0f, p11 = v11 ? Pcc : 0.0f;
+      const float top = (omx * p00) + (wx * p01);
+      const float btm = (omx * p10) + (wx * p11);
+      o.I = (omy * top) + (wy * btm);
+    }
     if (WANT_GRAD) {
-      Pba = (float)img[rb + (unsigned)xa]; Pbd = (float)img[rb + (unsigned)xd];
-      Pca = (float)img[rc + (unsigned)xa]; Pcd = (float)img[rc + (unsigned)xd];
-      Pab = (float)img[ra + (unsigned)xb]; Pac = (float)img[ra + (unsigned)xc];
-      Pdb = (float)img[rd + (unsigned)xb]; Pdc = (float)img[rd + (unsigned)xc];
+      const float Pba = (float)bba, Pbd = (float)bbd, Pca = (float)bca, Pcd = (float)bcd;
+      const float Pab = (float)bab, Pac = (float)bac, Pdb = (float)bdb, Pdc = (float)bdc;
+      const float sx0 = (x0 <= 0 || x0 >= cols - 1) ? 1.0f : 0.5f;
+      const float sx1 = (x0 + 1 <= 0 || x0 + 1 >= cols - 1) ? 1.0f : 0.5f;
+      const float sy0 = (y0 <= 0 || y0 >= rows - 1) ? 1.0f : 0.5f;
+      const float sy1 = (y0 + 1 <= 0 || y0 + 1 >= rows - 1) ? 1.0f : 0.5f;
+      float g00 = sx0 * (Pbc - Pba), g01 = sx1 * (Pbd - Pbb), g10 = sx0 * (Pcc - Pca), g11 = sx1 * (Pcd - Pcb);
+      g00 = v00 ? g00 : 0.0f; g01 = v01 ? g01 : 0.0f; g10 = v10 ? g10 : 0.0f; g11 = v11 ? g11 : 0.0f;
+      float top = (omx * g00) + (wx * g01);
+      float btm = (omx * g10) + (wx * g11);
+      o.gx = (omy * top) + (wy * btm);
+      float h00 = sy0 * (Pcb - Pab), h01 = sy0 * (Pcc - Pac), h10 = sy1 * (Pdb - Pbb), h11 = sy1 * (Pdc - Pbc);
+      h00 = v00 ? h00 : 0.0f; h01 = v01 ? h01 : 0.0f; h10 = v10 ? h10 : 0.0f; h11 = v11 ? h11 : 0.0f;
+      top = (omx * h00) + (wx * h01);
+      btm = (omx * h10) + (wx * h11);
+      o.gy = (omy * top) + (wy * btm);
+      if (FAST) { o.gx *= 2.0f; o.gy *= 2.0f; }
+    } else {
+      o.gx = 0.0f; o.gy = 0.0f;
     }
+    return o;
   }
+  const float Pbb = (float)img[rb + (unsigned)xb], Pbc = (float)img[rb + (unsigned)xc];
+  const float Pcb = (float)img[rc + (unsigned)xb], Pcc = (float)img[rc + (unsigned)xc];
   {
     const float p00 = v00 ? Pbb : 0.0f, p01 = v01 ? Pbc : 0.0f, p10 = v10 ? Pcb : 0.0f, p11 = v11 ? Pcc : 0.0f;
     const float top = (omx * p00) + (wx * p01);
@@ -196,6 +213,13 @@ __device__ __forceinline__ Taps tap_general(g_u8 img, int sw, int cols, int rows
     o.I = (omy * top) + (wy * btm);
   }
   if (WANT_GRAD) {
+    const int xa = clampi(x0 - 1, 0, cols - 1), xd = clampi(x0 + 2, 0, cols - 1);
+    const int ya = clampi(y0 - 1, 0, rows - 1), yd = clampi(y0 + 2, 0, rows - 1);
+    const unsigned ra = __umul24((unsigned)ya, (unsigned)sw), rd = __umul24((unsigned)yd, (unsigned)sw);
+    const float Pba = (float)img[rb + (unsigned)xa], Pbd = (float)img[rb + (unsigned)xd];
+    const float Pca = (float)img[rc + (unsigned)xa], Pcd = (float)img[rc + (unsigned)xd];
+    const float Pab = (float)img[ra + (unsigned)xb], Pac = (float)img[ra + (unsigned)xc];
+    const float Pdb = (float)img[rd + (unsigned)xb], Pdc = (float)img[rd + (unsigned)xc];
     // scale 1 on the border column/row of the tap itself, 0.5 inside
     const float sx0 = (x0 <= 0 || x0 >= cols - 1) ? 1.0f : 0.5f;
     const float sx1 = (x0 + 1 <= 0 || x0 + 1 >= cols - 1) ? 1.0f : 0.5f;
@@ -233,6 +257,11 @@ __device__ __forceinline__ Taps tap_general(g_u8 img, int sw, int cols, int rows
 // to come back from HBM before the (cache-resident) taps count as complete; issued behind them it stays in flight while
 // this pixel's arithmetic runs.
 struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+// A prefetch functor that also says "latency regime" (tap_general<.., LAT>): how gn_fca_persist's passes mark their taps
+template <class F> struct LatPF { F f; __device__ __forceinline__ void operator()() const { f(); } };
+template <class T> struct is_lat_pf { static constexpr bool value = false; };
+template <class F> struct is_lat_pf<LatPF<F>> { static constexpr bool value = true; };
+template <class F> __device__ __forceinline__ LatPF<F> lat_pf(F f) { return LatPF<F>{f}; }
 template <bool WANT_GRAD, bool FAST = false, class AfterIssue = NoPrefetch>
 __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, float x1, float y1, AfterIssue after_issue = AfterIssue()) {
   Taps o;
@@ -295,7 +324,7 @@ __device__ __forceinline__ Taps tap_point(g_u8 img, int sw, int cols, int rows, 
     return o;
   }
   after_issue();
-  return tap_general<WANT_GRAD, FAST>(img, sw, cols, rows, x1, y1);
+  return tap_general<WANT_GRAD, FAST, is_lat_pf<AfterIssue>::value>(img, sw, cols, rows, x1, y1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -388,7 +417,7 @@ __device__ __forceinline__ TapReq tap_request_f(const TapRows& tr, int sw, int c
   }
   return q;
 }
-template <bool WANT_GRAD>
+template <bool WANT_GRAD, bool LAT = false>
 __device__ __forceinline__ Taps tap_finish_f(const TapReq& q, g_u8 img, int sw, int cols, int rows, float x1, float y1) {
   if (q.interior) {
     Taps o;
@@ -413,7 +442,7 @@ __device__ __forceinline__ Taps tap_finish_f(const TapReq& q, g_u8 img, int sw, 
     }
     return o;
   }
-  return tap_general<WANT_GRAD, true>(img, sw, cols, rows, x1, y1);
+  return tap_general<WANT_GRAD, true, LAT>(img, sw, cols, rows, x1, y1);
 }
 
 // a / b for a per-level constant b with rb = RN(1/b): q = RN(a rb), e = a - b q (exact, fma), RN(q + e rb).
@@ -792,10 +821,10 @@ __device__ __forceinline__ FcafStage fcaf_stage_a(const LevelGeom& g, const TapR
   return s;
 }
 // SAVEW: 1 = store the weights (saved-weights call), 0 = do not, -1 = a.save_w decides at run time
-template <bool DEBUG, int SAVEW = -1>
+template <bool DEBUG, int SAVEW = -1, bool LAT = false>
 __device__ __forceinline__ FcaPix fcaf_stage_b(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const FcafConst& c, unsigned i,
                                                const FcafStage& s) {
-  const Taps t = tap_finish_f<true>(s.tq, cur, g.sw, g.cols, g.rows, s.x1, s.y1);
+  const Taps t = tap_finish_f<true, LAT>(s.tq, cur, g.sw, g.cols, g.rows, s.x1, s.y1);
   const float p = s.p, q = s.q, d = s.d;
   FcaPix o;
   // 1x6 row (:296-320) with A = fx gradx, B = fy grady, T = A p + B q:
@@ -1519,7 +1548,7 @@ struct FusedArgs {
 // The pixel pass of one block of a fused launch over its chunk [begin, end) of the compact list, thread t taking the
 // entries begin + t, begin + t + 256, ...; the thread's first record (and, in the exact mode, its pose-independent products)
 // was requested by the caller before the solve. newS: exp(pose) of this iteration (LDS). Leaves the thread's 27 sums.
-template <bool DIVC, bool PIPE, bool FAST, int SAVEW>
+template <bool DIVC, bool PIPE, bool FAST, int SAVEW, bool LAT = false>   // LAT: the latency regime (tap_general)
 __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev& K, const LevelGeom& g, g_u8 cur, const float* newS, int begin,
                                                int end, const FcaIn& first, const FcaInF& firstf, const FcaPre& first_pre, float (&sums)[27]) {
   constexpr int stride = ELLC_GN_THREADS;
@@ -1554,7 +1583,7 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
         auto refill = [&]() { next_rec = fcaf_load_off(K, min(off + S16, off_last)); };
         const FcafStage st = fcaf_stage_a(g, tr, fc, cur_rec, refill);
         ELLC_PTRACE(5, 0);
-        if (active) fca_accumulate_pixel(acc, fcaf_stage_b<false, SAVEW>(a, K, g, cur, fc, idx, st));
+        if (active) fca_accumulate_pixel(acc, fcaf_stage_b<false, SAVEW, LAT>(a, K, g, cur, fc, idx, st));
         ELLC_PTRACE(6, 0);
         off += S16; idx += stride;
       };
@@ -1570,13 +1599,15 @@ __device__ __forceinline__ void fca_chunk_pass(const GnArgs& a, const KfLevelDev
       {
         const int i1 = i + stride;
         auto prefetch = [&]() { r1 = fca_load<DIVC>(K, g, (unsigned)min(i1, end - 1)); };
-        fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre, prefetch));
+        if constexpr (LAT) fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre, lat_pf(prefetch)));
+        else fca_accumulate_pixel(acc, fca_pixel_pre<false>(a, K, g, cur, S, (unsigned)i, first, first_pre, prefetch));
         i += stride;
       }
       auto step = [&](const FcaIn& in, FcaIn& fill) {
         const int i1 = i + stride;
         auto prefetch = [&]() { fill = fca_load<DIVC>(K, g, (unsigned)min(i1, end - 1)); };
-        fca_accumulate_pixel(acc, fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, in, prefetch));
+        if constexpr (LAT) fca_accumulate_pixel(acc, fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, in, lat_pf(prefetch)));
+        else fca_accumulate_pixel(acc, fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, in, prefetch));
         i += stride;
       };
       while (i < end) {
@@ -2646,7 +2677,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(
     if (work) {   // block-uniform
       g_u8 cur = as_global(F->img);
       float sums[27];
-      fca_chunk_pass<DIVC, true, FAST, SAVEW>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
+      fca_chunk_pass<DIVC, true, FAST, SAVEW, true>(a, K, g, cur, sh.newS, begin, end, first, firstf, first_pre, sums);
       ELLC_PTRACE(7, 0);
       unsigned* out = (unsigned*)(a.partials + (size_t)(seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE);
       persist_store_record(sums, out, (epoch << 8) | (unsigned)(seq + 1));
