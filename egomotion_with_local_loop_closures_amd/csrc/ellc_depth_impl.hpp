@@ -359,6 +359,7 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
   c->track_count_n = 0;
   if (s != ELLC_OK) return s;
   if (!counted) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the staging launch did not take the count along");
+  c->track_counts++;   // (one count per call, whichever launch carried it)
   const int set = c->inflight[0] / ellc_ctx::MAX_COALESCE;
   ellc_ctx::BatchSet& bs = c->batch_set[set];
   // (launch_group may have left the group's `done` event to this call: it is recorded behind the depth stages, on every way out)
@@ -389,6 +390,16 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
   s = ellc_align_fetch(c, 1, pose, out_iters, out_weighted);   // (runs the continuation when one is needed)
   if (s != ELLC_OK) return s;
   if (out_pose) std::memcpy(out_pose, pose, sizeof(pose));
+  {   // the count of this call (dm_count_valid_body numbers its counts): normally there long before the alignment has ended
+    const volatile int* th = (const volatile int*)c->track_h;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0; (int)((unsigned)th[1] - (unsigned)c->track_counts) < 0; spin++) {   // (not behind: a call that failed after its count leaves the device ahead)
+      if ((spin & 1023u) == 1023u) {
+        std::this_thread::yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) return fail(c, ELLC_ERR_HIP, "ellc_track_frame: the count of the valid hypotheses did not arrive");
+      }
+    }
+  }
   if (seeds_percent) *seeds_percent = (float)c->track_h[0] / (float)n * 100;
   if (continued) {   // rare: the depth stages again, the usual way
     float pwo[6];

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <map>
 #include <chrono>
+#include <thread>
 #include <atomic>
 #include <mutex>
 
@@ -137,6 +138,11 @@ int choose_nblk(const ellc_ctx* c, int level, int B) {
     const int one_per_cu = std::max(1, cus / B);
     if (0.3 * n / (256.0 * one_per_cu) <= 4.0) nblk = std::min(nblk, one_per_cu);
   }
+  // One or two alignments on their own (the tracking call): an iteration is a latency chain, and every block reads every block's
+  // record — with 256 blocks a level-0 round waits 4.3 us for 8 MB of records, with 128 it waits 2.3 and its pixel pass is one
+  // step longer (tools/dbg/persist_trace.py, tools/dbg/sweep_persist_nblk.sh: one early-exit alignment 0.1132 -> 0.1100 ms, tracked
+  // frame 0.1850 -> 0.1826; 64 blocks: 0.1108 / 0.187). Resident launch and launch-per-iteration path alike (the same bits).
+  if (B <= 2) nblk = std::min(nblk, 128);
   return nblk;
 }
 
@@ -1240,7 +1246,7 @@ ellc_status ellc_ctx_set_persistent_schedule(ellc_ctx* c, int mode) {
 ellc_status ellc_debug_persist_delay(ellc_ctx* c, int first_block, int polls) {
   if (!c) return ELLC_ERR_BAD_ARG;
   ELLC_ENTER(c);
-  if (first_block < 0 || polls < 0 || polls > (1 << 16)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_debug_persist_delay: first_block >= 0, 0 <= polls <= 65536");
+  if (first_block < 0 || polls < -255 || polls > (1 << 16)) return fail(c, ELLC_ERR_BAD_ARG, "ellc_debug_persist_delay: first_block >= 0, -255 <= polls <= 65536");
   c->persist_delay_from = first_block;
   c->persist_delay_polls = polls;
   return ELLC_OK;
@@ -1765,7 +1771,7 @@ static ellc_status resolve_batch(ellc_ctx* c, int set) {
   if (!unfinished) return ELLC_OK;
   if (bs.resident) {   // a resident launch that was abandoned: the next calls do not try again at once (may_run_resident)
     c->persist_abandoned++;
-    if (c->persist_spin_limit != 0u) c->persist_backoff = 16;   // (0: the test hook that abandons every launch on purpose)
+    if (c->persist_spin_limit != 0u && c->persist_delay_polls >= 0) c->persist_backoff = 16;   // (not for the test hooks that abandon launches on purpose)
   }
   const int selected = c->cur_set;
   select_batch_set(c, set);

@@ -750,7 +750,9 @@ __global__ __launch_bounds__(DM_TX * DM_TY) void dm_fill_reg(DepthSoA in, DepthS
     if (EXPORT && (y < 3 || y >= H - 3 || x < 3 || x >= W - 3)) d.valid = false;   // updateDepthImage clears the border's flags (:1254-1315)
     hyp_store(out, i, d);
   }
-  if constexpr (EXPORT) dm_tile_export(ex, W, H, bx, by, inside, i, d.valid, d.ids, d.vars);
+  // (a closed gate leaves the keyframe's planes alone as well: the alignment that has not ended yet — its continuation — reads them,
+  // and they need not be this map's export: ellc_keyframe_set_depth. Block-uniform.)
+  if constexpr (EXPORT) { if (open) dm_tile_export(ex, W, H, bx, by, inside, i, d.valid, d.ids, d.vars); }
 }
 
 // depthMap::updateDepthImage (:1254-1315), per-pixel part: invalidate the 3-px border, export level 0
@@ -1234,8 +1236,17 @@ __device__ void dm_count_valid_body(const uint8_t* __restrict__ valid, int n, in
     atomicAdd(&acc[0], tot);
     __threadfence();
     if (atomicAdd(&acc[1], 1) == nblocks - 1) {
-      *host_visible = atomicExch(&acc[0], 0);
+      // the count, then the number of counts this context has made (acc[2]): the host takes the figure when the number is the one
+      // it expects (ellc_track_frame) — the counting blocks that ride in the alignment's resident launch (r06) are not ordered
+      // against the block that writes the alignment's result, and a host that polls that result could read the previous frame's
+      // count (seen once in six runs with two processes on one GPU: test_loop_closure_batch_sharded_over_two_processes)
+      const int count = atomicExch(&acc[0], 0);
       acc[1] = 0;
+      const int seq = acc[2] + 1;
+      acc[2] = seq;
+      *(volatile int*)host_visible = count;
+      __threadfence_system();
+      *(volatile int*)(host_visible + 1) = seq;
     }
   }
 }

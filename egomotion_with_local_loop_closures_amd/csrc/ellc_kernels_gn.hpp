@@ -2583,6 +2583,10 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 3 : 2) void gn_fca_persist(
   for (int seq = 0; seq < max_rounds; seq++) {
     ELLC_PTRACE_ROUND(sub, seq);
     ELLC_PTRACE(0, 0);
+    if (delay_polls < 0 && seq >= -delay_polls && st.cur_level >= 0) {   // test hook (ellc_debug_persist_delay, polls < 0): the launch is
+      if (t == 0 && sub == 0) __hip_atomic_store(abortw, epoch | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // abandoned in round -polls:
+      break;   // every block leaves where a block that had read the abort word in this round's gather would (block-uniform)
+    }
     const int lvl = st.cur_level, pending = st.pending, it_in = st.it_in_level;
     if (lvl < 0) break;
     const int nb_l = fa.nblk_lv[lvl];

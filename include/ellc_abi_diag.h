@@ -47,7 +47,9 @@ ellc_status ellc_selftest_lu(ellc_ctx* ctx, int n, const double* tri21, float* i
 /* ---- test hooks of the resident schedule (gn_fca_persist, the tracking call's one-launch form) ------------------------------ */
 /* Blocks with index >= first_block of every later resident launch start `polls` sleeps (about a microsecond each) late, as if the
  * dispatcher had placed them late: what a block that writes no records at the coarse levels must survive (it is lapped by the
- * writers and re-joins through the state line). polls = 0 switches the delay off. */
+ * writers and re-joins through the state line). polls = 0 switches the delay off. polls = -r (1 .. 255): no delay; block 0 raises
+ * the abort word at the top of round r of every later resident launch — a launch abandoned half-way, which the launch path has to
+ * finish with the same bits. */
 ellc_status ellc_debug_persist_delay(ellc_ctx* ctx, int first_block, int polls);
 /* The call counter the records' tags are made of (24 bits are used): tests set it just below the wrap. */
 ellc_status ellc_debug_set_persist_epoch(ellc_ctx* ctx, unsigned epoch);

@@ -186,6 +186,34 @@ def test_resident_schedule_survives_blocks_that_start_late(ellc, arith):
             assert rejoined - rejoined0 >= 4 * 100, (first_block, polls, rejoined - rejoined0)   # most of the ~250 idle blocks of every launch
 
 
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_resident_schedule_abandoned_half_way_is_finished_by_the_launches(ellc, arith):
+    """The safety net of the resident launch at every depth (r05 tested it at round 0 only): block 0 raises the abort word at the
+    top of round r (ellc_debug_persist_delay(0, -r): in the first level, at a level change, in the last level, in a round past the
+    schedule's end), every block leaves, the record says "not ended, nothing pending" and the host finishes the schedule with
+    ordinary launches — the bits of one launch per iteration, saved weights exactly once, every launch counted as abandoned
+    unless the schedule was over before round r."""
+    cases = [(21, 0.02, 0.05), (22, 0.03, 0.08), (25, 0.05, 0.15)]
+    WW, HH, LL = 640, 480, 4
+    pairs = [synth.make_pair(WW, HH, seed=s, rot=r, trans=t) for s, r, t in cases]
+    kw = dict(arith=ellc.ARITH_FAST) if arith == "fast" else {}
+    ctx = gpu_problem(ellc, WW, HH, LL, pairs, early_exit=1, diag=True, **kw)
+    ctx.set_persistent_schedule(0)
+    ref = _resident_calls(ctx)
+    ctx.close()
+    for r in (1, 2, 4, 7, 9, 12, 15, 40):
+        ctx = gpu_problem(ellc, WW, HH, LL, pairs, early_exit=1, diag=True, **kw)
+        ctx.debug_persist_delay(0, -r)
+        got = _resident_calls(ctx)
+        launches, abandoned, _ = ctx.debug_persist_counters()
+        ctx.close()
+        assert _same_results(ref, got), r
+        assert launches == 4, (r, launches)
+        assert (abandoned == 4) if r <= 9 else (abandoned <= 4), (r, abandoned)   # (these scenes run 11 to 20 rounds)
+        if r == 40:
+            assert abandoned == 0
+
+
 def test_resident_schedule_is_refused_beyond_255_rounds_and_crosses_the_epoch_wrap(ellc):
     """The records' tags are call epoch << 8 | round. (a) A schedule of more than 255 rounds (cfg.max_iter has no upper bound; r05
     would have let round 256 + k of one call pass for round k of the next) runs as launches: max_iter {80, 80, 80, 80}, early exit

@@ -59,6 +59,32 @@ def test_track_frame_equals_the_separate_calls(ellc, oracle, arith, case):
 
 
 @pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_tracking_call_abandoned_half_way_equals_the_call_that_is_not(ellc, arith):
+    """The tracking call's resident launch carries the staging and the count of the valid hypotheses (r06) and, behind it, the depth
+    stages read what its block 0 left: a launch abandoned in round r (ellc_debug_persist_delay(0, -r)) and finished by the launch
+    path must leave every tracked frame and the whole depth map as the undisturbed call does."""
+    pair = synth.make_pair(W, H, seed=21, rot=0.02, trans=0.05)
+    kw = dict(arith=ellc.ARITH_FAST) if arith == "fast" else {}
+    a = make_ctx(ellc, pair, diag=True, **kw)
+    ref = [a.track_frame(0, save_weights=True) for _ in range(3)]
+    sa = a.depth_get_state()
+    assert a.debug_persist_counters()[:2] == (3, 0)
+    a.close()
+    for r in (1, 3, 8, 12):
+        b = make_ctx(ellc, pair, diag=True, **kw)
+        b.debug_persist_delay(0, -r)
+        got = [b.track_frame(0, save_weights=True) for _ in range(3)]
+        sb = b.depth_get_state()
+        launches, abandoned, _ = b.debug_persist_counters()
+        b.close()
+        assert launches == 3 and abandoned >= 1, (r, launches, abandoned)
+        for x, y in zip(ref, got):
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] and x[3] == y[3], r
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k], equal_nan=True), (r, k)
+
+
+@pytest.mark.parametrize("arith", ["exact", "fast"])
 def test_eager_lists_change_no_bit_and_every_writer_invalidates_them(ellc, arith):
     """r06: in a tracking context the depth map's export builds the next alignment's compact lists right behind itself (the alignment
     then starts without staging's compaction). Same kernel, same order, same chunks: against a context with that switched off
