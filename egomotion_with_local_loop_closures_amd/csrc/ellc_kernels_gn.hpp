@@ -384,19 +384,12 @@ __device__ __forceinline__ TapReq tap_request_f(const TapRows& tr, int sw, int c
   // NaN coordinate converts to 0 and an infinite one saturates: neither is interior
   const bool interior = ((unsigned)(x0 - 1) <= (unsigned)(cols - 4)) & ((unsigned)(y0 - 1) <= (unsigned)(rows - 4));
   q.interior = (__builtin_amdgcn_ballot_w64(!interior) == 0ull);
-#ifdef ELLC_X_FORCE_INTERIOR   // experiment (WRONG values on the border): what the general path costs the coarse levels
-  q.interior = true;
-#endif
   // (r04 measured the straight-line form — the rows requested unconditionally, a lane that is not interior asking for the image's
   // first bytes — which a software pipeline over pixels needs: 5 % slower on the batch pipeline, the coarse levels' waves on the
   // image border pay for four requests they do not use)
   q.wb = 0; q.wc = 0;
   if (q.interior) {
-#ifdef ELLC_X_FORCE_INTERIOR
-    const unsigned off = __umul24((unsigned)min(max(y0, 1), rows - 3), (unsigned)sw) + (unsigned)min(max(x0, 1), cols - 3);
-#else
     const unsigned off = __umul24((unsigned)y0, (unsigned)sw) + (unsigned)x0;
-#endif
 #ifdef ELLC_X_LDSTAPS   // variant builds only (tools/pmc_ldstaps.sh; WRONG values): what the four rows would cost as reads of an LDS
                         // window that is already there — two aligned dwords + v_alignbit per row, no staging, no window arithmetic
     __shared__ uint32_t xl[4 * 1024 + 4];
@@ -2173,9 +2166,6 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, ELLC_QUAD_BLOCKS_PER_CU) void gn_f
           xq = xn; y = yn; i = in_;
         }
         // the queue: 64 at a time through the per-pixel step while the chunk lasts, then what is left
-#ifdef ELLC_X_NODRAIN
-        qn = 0;
-#endif
         while (__builtin_expect(qn >= (more ? 64 : 1), 0)) {   // (cold: what the register allocator must spill, it spills here)
           const int n = min(qn, 64);
           __builtin_amdgcn_wave_barrier();
