@@ -141,8 +141,10 @@ int choose_nblk(const ellc_ctx* c, int level, int B) {
   // One or two alignments on their own (the tracking call): an iteration is a latency chain, and every block reads every block's
   // record — with 256 blocks a level-0 round waits 4.3 us for 8 MB of records, with 128 it waits 2.3 and its pixel pass is one
   // step longer (tools/dbg/persist_trace.py, tools/dbg/sweep_persist_nblk.sh: one early-exit alignment 0.1132 -> 0.1100 ms, tracked
-  // frame 0.1850 -> 0.1826; 64 blocks: 0.1108 / 0.187). Resident launch and launch-per-iteration path alike (the same bits).
-  if (B <= 2) nblk = std::min(nblk, 128);
+  // frame 0.1850 -> 0.1826; 64 blocks: 0.1108 / 0.187). Resident launch and launch-per-iteration path alike (the same bits). Only
+  // where the state-driven schedule runs (a context with the early exit): a fixed schedule of one alignment is throughput-bound at
+  // level 0 and lost 4 % with the cap (C1 with 32 iterations: 0.211 -> 0.219 ms).
+  if (B <= 2 && c->use_fused && c->use_adaptive && c->cfg.early_exit && c->cfg.grid_batch == 0) nblk = std::min(nblk, 128);
   return nblk;
 }
 
