@@ -802,8 +802,8 @@ def tracked_frame(api, synth, a, dev_index, with_lc=False):
         df, _, _ = loop(None, fused=True)
         dl, _, _ = loop(None, fused=False, persist=0)
         return {"workload": "C1 loop: upload + pyramid, one FCA alignment (early exit on, saved weights), observe + fill holes + regularise + export, "
-                            "640x480, 4 levels, arith %s, five calls per frame with the pose through the host (what ellc_main does); "
-                            "ms_per_frame_fused_call: the same through ONE ellc_track_frame call per frame (the depth stages enqueued behind the "
+                            "640x480, 4 levels, arith %s, five calls per frame with the pose through the host (ellc_main --no-fused); "
+                            "ms_per_frame_fused_call: the same through ONE ellc_track_frame call per frame, ellc_main's default (the depth stages enqueued behind the "
                             "alignment, matrices built on the device; same bits); ms_per_frame_launch_per_iteration: the five calls with the "
                             "alignment's schedule as one launch per Gauss-Newton iteration (ellc_ctx_set_persistent_schedule(0), the schedule up to "
                             "round 4; same bits) instead of one resident launch" % a.arith,

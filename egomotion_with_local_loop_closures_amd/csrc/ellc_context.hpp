@@ -221,6 +221,8 @@ struct ellc_ctx {
   float2* obs_list_ep = nullptr;   // the epipolar direction of every list entry
   int *obs_list = nullptr, *obs_ctr = nullptr;   // work list of dm_observe_select / dm_observe_walk and its counters (zero between calls)
   int* track_h = nullptr;    // host-visible: [0] the valid hypotheses before the observation, [1] the number of the count that wrote it
+  bool track_ride_weights = false;   // the enqueued tracking call's saved weights wait for its selection launch (launch_observe)
+  bool ride_saved_weights = true;    //   (ellc_debug_set_fold_staging(0) keeps the launch of their own as well)
   int track_counts = 0;      // counts launched so far (ellc_track_frame waits for [1] to say this one)
   int* track_dev_alias = nullptr;
   float Kinv[9], Kmat[9];

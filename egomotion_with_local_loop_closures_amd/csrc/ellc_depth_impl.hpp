@@ -292,11 +292,21 @@ static void launch_observe(ellc_ctx* c, const ObsArgs& a, bool dev) {
   const dim3 tiles((a.W + 31) / 32, (a.H + 7) / 8), blk(256);
   const int most = std::max(0, a.W - 6) * std::max(0, a.H - 6);
   const dim3 walk(std::max(1, (most + 255) / 256 + 1));   // a wave per chunk of 64 entries of one kind: at most two partial chunks more than most / 64
+  RideWeights rw;
   if (dev) {
-    hipLaunchKernelGGL(dm_observe_select<true>, tiles, blk, 0, c->stream, a);
+    dim3 grid = tiles;
+    if (c->track_ride_weights) {   // the tracking call's saved weights (enqueue_schedule_persist left them to this launch)
+      c->track_ride_weights = false;
+      rw.per_level = 128;
+      rw.n = rw.per_level * c->L;
+      rw.kf_tab = c->kf_tab_d; rw.kf_slot = c->kf_slot_d; rw.geom = c->geom_d; rw.state = c->state_d;
+      rw.max_kf = c->cfg.max_keyframes; rw.fast_records = c->fast ? 1 : 0;
+      grid.y += (rw.n + tiles.x - 1) / tiles.x;
+    }
+    hipLaunchKernelGGL(dm_observe_select<true>, grid, blk, 0, c->stream, a, rw);
     hipLaunchKernelGGL(dm_observe_walk<true>, walk, blk, 0, c->stream, a);
   } else {
-    hipLaunchKernelGGL(dm_observe_select<false>, tiles, blk, 0, c->stream, a);
+    hipLaunchKernelGGL(dm_observe_select<false>, tiles, blk, 0, c->stream, a, rw);
     hipLaunchKernelGGL(dm_observe_walk<false>, walk, blk, 0, c->stream, a);
   }
 }
@@ -350,6 +360,7 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
     hipLaunchKernelGGL(dm_count_valid_block, dim3(std::max(1, ((n >> 4) + 1023) / 1024)), dim3(1024), 0, c->stream, c->dm_cur.isValid, n, c->seed_acc,
                        c->track_dev_alias);
   c->done_deferred = false;
+  c->track_ride_weights = false;
   c->track_call = true;   // this alignment's finish kernel builds the observation's matrices and sets the gate
   c->track_count_valid = c->dm_cur.isValid;
   c->track_count_n = rides ? n : 0;

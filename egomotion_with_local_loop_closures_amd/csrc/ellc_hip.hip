@@ -721,7 +721,11 @@ static ellc_status enqueue_schedule_persist(ellc_ctx* c, int B, int save_weights
     hipLaunchKernelGGL((gn_fca_persist<false, false, -1>), grd, blk, 0, c->stream, fa, max_rounds, epoch, c->persist_spin_limit, c->persist_delay_from, c->persist_delay_polls, ps);
   }
   // (no finish kernel: the launch's first block per alignment has written the final record, the result and the tracking fields)
-  if (save_weights) launch_add_saved_weights(c, B);
+  if (save_weights) {
+    // (the tracking call: its observation's selection launch, the next one in this stream, takes them along — launch_observe)
+    if (c->track_call && B == 1 && c->ride_saved_weights) c->track_ride_weights = true;
+    else launch_add_saved_weights(c, B);
+  }
   ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
 }
@@ -1270,6 +1274,7 @@ ellc_status ellc_debug_set_fold_staging(ellc_ctx* c, int on) {
   if (!c) return ELLC_ERR_BAD_ARG;
   ELLC_ENTER(c);
   c->fold_staging = on != 0;
+  c->ride_saved_weights = on != 0;   // (the other launch the tracking call has folded away: the saved weights in the selection launch)
   return ELLC_OK;
 }
 ellc_status ellc_debug_set_hinv_cache(ellc_ctx* c, int on) {

@@ -1631,8 +1631,16 @@ __device__ __forceinline__ void obs_load_mats(ObsArgs& b) {
 // set is zero when its select launch starts, because the walk launch of the call before cleared it (ObsArgs::ctr_next). DEV: the
 // tracked-frame call — nothing else is done while the gate is closed.
 template <bool DEV>
-__global__ __launch_bounds__(256) void dm_observe_select(ObsArgs a) {
+__global__ __launch_bounds__(256) void dm_observe_select(ObsArgs a, RideWeights rw) {
   if (DEV) {
+    const int tiles_y = (a.H + 7) / 8;
+    if ((int)blockIdx.y >= tiles_y) {   // (block-uniform) the tracking call's saved weights, riding along (RideWeights): whatever the gate says
+      const int r = ((int)blockIdx.y - tiles_y) * (int)gridDim.x + (int)blockIdx.x;
+      if (r < rw.n)
+        saved_weights_all_body(rw.kf_tab, rw.kf_slot, rw.geom, rw.state, rw.max_kf, rw.fast_records, 0, r / rw.per_level, r % rw.per_level, rw.per_level,
+                               (int)threadIdx.x, 256);
+      return;
+    }
     if (*a.gate == 0) return;
     obs_load_mats(a);
   }

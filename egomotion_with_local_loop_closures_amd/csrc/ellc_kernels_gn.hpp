@@ -3065,14 +3065,13 @@ __global__ void gn_add_saved_weights(const KfLevelDev* kf_tab, const int* kf_slo
 // weights of that level's last executed pixel pass. Only once the alignment's schedule has ended (the state-driven schedule
 // may stop short of it and be continued: cur_level of the record the finish kernel wrote is -1 at the end) and only ONCE per
 // alignment: a continuation graph carries the alignments its first graph already ended as cur_level = -2 (gn_fca_adaptive).
-__global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, const AlignState* state, int max_kf,
-                                         int fast_records) {
-  const int b = blockIdx.y, level = blockIdx.z;
+__device__ __forceinline__ void saved_weights_all_body(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, const AlignState* state, int max_kf,
+                                                       int fast_records, int b, int level, int bx, int nbx, int tid, int nthreads) {
   if (state[b].cur_level != -1) return;
   const KfLevelDev& K = kf_tab[level * max_kf + kf_slot[b]];
   const int V = *K.count;
   const int cols = geom[level].cols;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+  for (int i = bx * nthreads + tid; i < V; i += nbx * nthreads) {
     size_t p;
     if (fast_records) {
       int x, y;
@@ -3085,5 +3084,21 @@ __global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf
     K.weight[p] = K.weight[p] + K.wlast[i];
   }
 }
+__global__ void gn_add_saved_weights_all(const KfLevelDev* kf_tab, const int* kf_slot, const LevelGeom* geom, const AlignState* state, int max_kf,
+                                         int fast_records) {
+  saved_weights_all_body(kf_tab, kf_slot, geom, state, max_kf, fast_records, (int)blockIdx.y, (int)blockIdx.z, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x,
+                         (int)blockDim.x);
+}
+// ellc_track_frame (r06): the tracking call's saved weights ride in its observation's selection launch (dm_observe_select<true>) —
+// further blocks of that launch, which is the next one behind the resident launch either way — instead of a launch of their own
+// between the alignment and the depth stages (5 us and a kernel boundary of every tracked frame).
+struct RideWeights {
+  int n = 0, per_level = 0;   // n further blocks (0: none), per_level of them for each pyramid level
+  const KfLevelDev* kf_tab = nullptr;
+  const int* kf_slot = nullptr;
+  const LevelGeom* geom = nullptr;
+  const AlignState* state = nullptr;
+  int max_kf = 0, fast_records = 0;
+};
 
 }  // namespace ellc

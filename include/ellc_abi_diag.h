@@ -58,8 +58,9 @@ ellc_status ellc_debug_set_persist_epoch(ellc_ctx* ctx, unsigned epoch);
  * alignment builds its lists itself, as up to r05): the results must not change by a bit (tests). */
 ellc_status ellc_debug_set_eager_lists(ellc_ctx* ctx, int on);
 /* A tracking call whose compact lists are already there (eager lists) has no staging launch: its resident launch builds the state
- * records from its arguments and takes the batch description and the seeds count along (default on). 0: the staging kernel runs as
- * up to r05 — the results must not change by a bit (tests). */
+ * records from its arguments and takes the batch description and the seeds count along, and ellc_track_frame's saved weights are
+ * added by further blocks of its selection launch (default on). 0: the staging kernel and gn_add_saved_weights_all run as up to r05 —
+ * the results must not change by a bit (tests). */
 ellc_status ellc_debug_set_fold_staging(ellc_ctx* ctx, int on);
 /* Constant-weight path, tolerance mode: the per-(slot, level) H^-1 are kept while the keyframe's planes are unchanged and the
  * per-call compaction then builds the records only (default on). 0: every compaction recomputes them, as up to r05 — the results

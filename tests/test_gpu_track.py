@@ -110,6 +110,12 @@ def test_eager_lists_change_no_bit_and_every_writer_invalidates_them(ellc, arith
         for k in sa:
             assert np.array_equal(sa[k], sb[k], equal_nan=True), (what, k)
             assert np.array_equal(sa[k], sf[k], equal_nan=True), (what, k, "staging kept")
+        for slot in (0, 1):   # the saved weights: added by blocks of the selection launch (a, b) or by their own launch (f)
+            for l in range(L):
+                wa, na = a.keyframe_weights(slot, l)
+                for other, tag in ((b, "eager off"), (f, "staging and the weights' launch kept")):
+                    wo, no = other.keyframe_weights(slot, l)
+                    assert na == no and np.array_equal(wa, wo), (what, slot, l, tag)
 
     for rep in range(3):                                    # tracked frames: from the second on, a's alignment finds its lists built
         ra, rb, rf = a.track_frame(0, save_weights=True), b.track_frame(0, save_weights=True), f.track_frame(0, save_weights=True)

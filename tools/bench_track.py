@@ -18,7 +18,8 @@ W, H, L = 640, 480, 4
 pair = synth.make_pair(W, H, seed=31, rot=0.006, trans=0.03)
 fx, fy, cx, cy = pair["intrinsics"]
 st = synth.make_depth_state(W, H, 9, pair["kf_image"], pair["idepth_true"])
-ARITH = sys.argv[2] if len(sys.argv) > 2 else "fast"   # usage: bench_track.py [frames] [fast|exact]
+ARITH = sys.argv[2] if len(sys.argv) > 2 else "fast"   # usage: bench_track.py [frames] [fast|exact] [fused]
+FUSED = len(sys.argv) > 3 and sys.argv[3] == "fused"
 ctx = api.Context(api.default_config(W, H, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=1, max_keyframes=2, max_frames=2,
                                      arith=api.ARITH_FAST if ARITH == "fast" else api.ARITH_EXACT))
 ctx.keyframe_upload(0, pair["kf_image"])
@@ -34,12 +35,16 @@ for f in range(N):
     t0 = time.perf_counter()
     ctx.frame_upload(f & 1, pair["cur_image"])
     t1 = time.perf_counter()
-    pose, it, _ = ctx.align([0], [f & 1])
-    t2 = time.perf_counter()
-    ctx.depth_observe(f & 1, pose[0])
-    ctx.depth_fill_holes()
-    ctx.depth_regularize(False)
-    ctx.depth_update_depth_image()
+    if FUSED:   # one ellc_track_frame call per frame: the depth stages behind the alignment on the device, saved weights
+        pose, it, _, _ = ctx.track_frame(f & 1, save_weights=True)
+        t2 = time.perf_counter()
+    else:
+        pose, it, _ = ctx.align([0], [f & 1])
+        t2 = time.perf_counter()
+        ctx.depth_observe(f & 1, pose[0])
+        ctx.depth_fill_holes()
+        ctx.depth_regularize(False)
+        ctx.depth_update_depth_image()
     t3 = time.perf_counter()
     t["upload"] += t1 - t0; t["align"] += t2 - t1; t["depth"] += t3 - t2
     iters += int(np.asarray(it).sum())

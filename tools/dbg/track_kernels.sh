@@ -2,7 +2,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r06}/track_trace
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/bench_track.py 120 fast > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/bench_track.py 120 fast ${2:-} > $OUT/run.log 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, sys, os
 f = glob.glob(os.path.join(sys.argv[1], "*", "*kernel_trace.csv"))[0]
