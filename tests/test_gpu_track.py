@@ -68,6 +68,7 @@ def test_tracking_call_abandoned_half_way_equals_the_call_that_is_not(ellc, arit
     a = make_ctx(ellc, pair, diag=True, **kw)
     ref = [a.track_frame(0, save_weights=True) for _ in range(3)]
     sa = a.depth_get_state()
+    wa = [a.keyframe_weights(0, l) for l in range(L)]   # (saved once per frame: by the selection launch's riders, or by the continuation)
     assert a.debug_persist_counters()[:2] == (3, 0)
     a.close()
     for r in (1, 3, 8, 12):
@@ -75,8 +76,11 @@ def test_tracking_call_abandoned_half_way_equals_the_call_that_is_not(ellc, arit
         b.debug_persist_delay(0, -r)
         got = [b.track_frame(0, save_weights=True) for _ in range(3)]
         sb = b.depth_get_state()
+        wb = [b.keyframe_weights(0, l) for l in range(L)]
         launches, abandoned, _ = b.debug_persist_counters()
         b.close()
+        for l in range(L):
+            assert wa[l][1] == wb[l][1] and np.array_equal(wa[l][0], wb[l][0]), (r, l)
         assert launches == 3 and abandoned >= 1, (r, launches, abandoned)
         for x, y in zip(ref, got):
             assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] and x[3] == y[3], r
