@@ -105,11 +105,16 @@ def test_eager_lists_change_no_bit_and_every_writer_invalidates_them(ellc, arith
     # takes the seeds count along; `f` keeps the staging kernel: a third way to the same bits)
     f = make_ctx(ellc, pair, diag=True, **kw)
     f.debug_set_fold_staging(False)
+    for ctx in (a, b, f):
+        ctx.frame_upload(1, pair2["cur_image"])   # a second frame: calls of two alignments (one keyframe, two frames) take the folded path too
 
     def same(what):
         ra, rb, rf = a.align([0], [0]), b.align([0], [0]), f.align([0], [0])
         assert all(np.array_equal(x, y) for x, y in zip(ra, rb)), what
         assert all(np.array_equal(x, y) for x, y in zip(ra, rf)), (what, "staging kept")
+        ra, rb, rf = a.align([0, 0], [0, 1]), b.align([0, 0], [0, 1]), f.align([0, 0], [0, 1])
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb)), (what, "two alignments")
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rf)), (what, "two alignments, staging kept")
         sa, sb, sf = a.depth_get_state(), b.depth_get_state(), f.depth_get_state()
         for k in sa:
             assert np.array_equal(sa[k], sb[k], equal_nan=True), (what, k)
