@@ -347,6 +347,7 @@ ellc_status ellc_track_frame(ellc_ctx* c, int frame_slot, const float* init_pose
   const int n = c->cfg.width * c->cfg.height;
   if (!c->track_h) {   // host-visible record: [0] valid hypotheses before the observation
     ELLC_HIP(c, hipHostMalloc((void**)&c->track_h, 64, hipHostMallocDefault));
+    std::memset(c->track_h, 0, 64);   // ([1], the number of the last count, starts at 0 as the device's counter does)
     c->host_allocs.push_back(c->track_h);
     void* da = nullptr;
     ELLC_HIP(c, hipHostGetDevicePointer(&da, c->track_h, 0));
