@@ -79,6 +79,7 @@ struct KfLevelDev {
   int* count;                 // V = number of compact entries
   int* tile_count;            // per-tile (ELLC_TILE pixels) counts, then exclusive offsets
   float* idepth;              // n: v_rcp_f32 of `depth` where depth > 0, else 0 — kept for slots with the dense hint only (gn_fca_dense4 reads it in place of `depth`)
+  double* invz;               // n: 1.0 / (double)depth, the exact record's pow(depth, -1) — contexts of the exact mode only, slots with the dense hint only (gn_fca_dense_x)
 };
 
 struct FrLevelDev {

@@ -108,7 +108,7 @@ static ellc_status host_alloc(ellc_ctx* c, T** p, size_t count) {
 // does a list-free launch at this level take four adjacent pixels per thread (gn_fca_dense4)? A row must be a whole number of quads
 static bool dense_quads_at(const ellc_ctx* c, int level) {
   const LevelGeom& lg = c->geom_h[level];
-  return c->dense_quads && lg.cols % 4 == 0 && lg.sw % 4 == 0 && lg.cols >= 16 && lg.rows >= 8;
+  return c->fast && c->dense_quads && lg.cols % 4 == 0 && lg.sw % 4 == 0 && lg.cols >= 16 && lg.rows >= 8;   // (tolerance mode only)
 }
 int choose_nblk(const ellc_ctx* c, int level, int B) {
 #ifdef ELLC_DIAG
@@ -518,6 +518,11 @@ static void launch_fused(ellc_ctx* c, dim3 grd, dim3 blk, const FusedArgs& fa, h
   const AlignState* src_state = fa.g.state + (size_t)(fa.seq & 1) * fa.stride_state;
   const float* prev_part = fa.g.partials + (size_t)((fa.seq + 1) & 1) * fa.stride_part;
   if (c->cur_dense) {   // dense maps: no compact lists (gn_fca_dense; launch_group decided)
+    if (!c->fast) {   // the exact mode: a thread per pixel, the planes and the slot's 1 / Z plane in double (no 20-byte records)
+      if (c->geom_h[0].divc_ok) hipLaunchKernelGGL(gn_fca_dense_x<true>, grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+      else hipLaunchKernelGGL(gn_fca_dense_x<false>, grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
+      return;
+    }
     // four adjacent pixels per thread where a row is a whole number of them (r06: one tap window per row for the four)
     if (dense_quads_at(c, fa.g.level))
       hipLaunchKernelGGL(gn_fca_dense4, grd, blk, 0, st, src_state, prev_part, fa.prev_nblk, fa.g.nblk, fa.age_rounds, fa);
@@ -1023,6 +1028,8 @@ ellc_status ellc_ctx_create(const ellc_config* cfg, ellc_ctx** out) {
       TRY(dev_alloc(c, &k.cxy, n)); TRY(dev_alloc(c, &k.cZ, n)); TRY(dev_alloc(c, &k.cI, n));
       TRY(dev_alloc(c, &k.crec, n)); TRY(dev_alloc(c, &k.cW, n)); TRY(dev_alloc(c, &k.wlast, n)); TRY(dev_alloc(c, &k.sd, 6 * n));
       TRY(dev_alloc(c, &k.count, 4)); TRY(dev_alloc(c, &k.tile_count, tiles + 1)); TRY(dev_alloc(c, &k.idepth, n));
+      k.invz = nullptr;
+      if (!c->fast) TRY(dev_alloc(c, &k.invz, n));   // (the exact mode's list-free kernel: KfLevelDev::invz)
       TRY(dev_alloc(c, &k.irec, n)); TRY(dev_alloc(c, &k.hpart, (size_t)(tiles + 1) * ELLC_PART_STRIDE)); TRY(dev_alloc(c, &k.hinv, 36));
     }
     // (+ one row: the fifth row of gn_fca_dense4's tap windows may be the one below the image)
@@ -1444,6 +1451,7 @@ ellc_status ellc_keyframe_set_depth(ellc_ctx* c, int slot, const float* depth0, 
       const KfLevelDev& kl = c->kf_tab_h[(size_t)l * c->cfg.max_keyframes + slot];
       const int n = c->geom_h[l].n;
       hipLaunchKernelGGL(idepth_plane, dim3((n + 255) / 256), dim3(256), 0, c->stream, kl.depth, kl.idepth, n);
+      if (kl.invz) hipLaunchKernelGGL(invz_plane, dim3((n + 255) / 256), dim3(256), 0, c->stream, kl.depth, kl.invz, n);
     }
   ELLC_HIP(c, hipGetLastError());
   return ELLC_OK;
@@ -1561,6 +1569,10 @@ static ellc_status copy_slot_planes(ellc_ctx* dc, int dst_is_kf, int dst, ellc_c
         ELLC_HIP(c, hipMemcpyAsync(d.depth, k.depth, (size_t)g.n * 4, hipMemcpyDeviceToDevice, dc->stream));
         ELLC_HIP(c, hipMemcpyAsync(d.var, k.var, (size_t)g.n * 4, hipMemcpyDeviceToDevice, dc->stream));
         if (sc->kf_dense[src]) ELLC_HIP(c, hipMemcpyAsync(d.idepth, k.idepth, (size_t)g.n * 4, hipMemcpyDeviceToDevice, dc->stream));   // (the dense hint travels with the slot)
+        if (sc->kf_dense[src] && d.invz) {
+          if (k.invz) ELLC_HIP(c, hipMemcpyAsync(d.invz, k.invz, (size_t)g.n * 8, hipMemcpyDeviceToDevice, dc->stream));
+          else hipLaunchKernelGGL(invz_plane, dim3((g.n + 255) / 256), dim3(256), 0, dc->stream, d.depth, d.invz, g.n);   // (a tolerance-mode source context keeps none)
+        }
         ELLC_HIP(c, hipMemcpyAsync(d.weight, k.weight, (size_t)g.n * 4, hipMemcpyDeviceToDevice, dc->stream));
         dc->kf_num_weights[dst][l] = sc->kf_num_weights[src][l];
       } else {
@@ -1669,7 +1681,8 @@ static ellc_status enqueue_align_body(ellc_ctx* c, int B, int nu, int mode, int 
 // may a batch of B alignments run the list-free schedule (gn_fca_dense)? The tolerance-mode FCA schedule in its level-bound form,
 // without saved weights (they are kept per list entry); launch_group adds: every keyframe slot carries the dense hint
 static bool runs_dense(const ellc_ctx* c, int mode, int B, int save_weights) {
-  return !c->dense_maps_off && c->fast && c->use_fused && mode == ELLC_MODE_FCA && !save_weights && !schedule_is_adaptive(c, mode, B);
+  // (r06: the exact mode too — gn_fca_dense_x over the planes and the slot's 1 / Z plane in double)
+  return !c->dense_maps_off && c->use_fused && c->pipe && mode == ELLC_MODE_FCA && !save_weights && !schedule_is_adaptive(c, mode, B);
 }
 
 

@@ -1878,6 +1878,147 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_dense(const AlignSt
 }
 
 // ---------------------------------------------------------------------------------------------------
+// gn_fca_dense in the EXACT arithmetic (r06; r05's verdict: the exact mode's C4 launch moved 1.28 x its algorithmic bytes as 20-byte
+// records, and its batch spent 12 % of its time compacting a mask that is all ones). The same thread <-> pixel walk over the block's
+// chunk of the plane; the record's four values come from the planes — depth, variance, intensity and the slot's 1 / Z plane in
+// double (KfLevelDev::invz, written once per upload: the f64 division is the compaction's expression, per pixel and ITERATION it
+// would be a seventh of this instruction-bound pass) — and go through fca_load's and fca_pixel_in's expressions: per-pixel values
+// bit for bit those of the list path, sums in another order. No saved weights (the list path keeps them), level-bound schedule.
+struct DensePixX { float Z, var; uint32_t I; double invZ; };
+__device__ __forceinline__ DensePixX dense_request_x(const KfLevelDev& K, unsigned i, unsigned img_off) {
+  DensePixX p;
+  p.Z = as_global(K.depth)[i];
+  p.var = as_global(K.var)[i];
+  p.I = (uint32_t)as_global(K.img)[img_off];
+  p.invZ = ((const ELLC_GLOBAL double*)K.invz)[i];
+  return p;
+}
+template <bool DIVC>
+__global__ __launch_bounds__(ELLC_GN_THREADS, 4) void gn_fca_dense_x(const AlignState* src_state, const float* prev_part, int prev_nblk, int nblk, int age_rounds,
+                                                                     FusedArgs fa) {
+  const GnArgs& a = fa.g;
+  int b = blockIdx.y, sub = blockIdx.x, age = 0, per_age = nblk;
+  if (age_rounds > 1) {   // see gn_fca_fused
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int per_round = (int)(gridDim.x * gridDim.y) / age_rounds;
+    per_age = nblk / age_rounds;
+    age = lin / per_round;
+    const int j = lin - age * per_round;
+    b = j / per_age;
+    sub = age * per_age + (j - b * per_age);
+  } else if (fa.xcd_map) {
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int w = lin >> 3, bl = w / nblk;
+    sub = w - bl * nblk;
+    b = bl * 8 + (lin & 7);
+  }
+  const AlignState& src = src_state[b];
+  AlignState* dst = a.state + (size_t)((fa.seq + 1) & 1) * fa.stride_state + b;
+  __shared__ SolveShared sh;
+  const int t = threadIdx.x;
+  const bool writer = (sub == 0);
+  const LevelGeom g = a.geom[a.level];
+  const KfLevelDev K = a.kf_tab[a.level * a.max_kf + a.kf_slot[b]];
+  const FrLevelDev& F = a.fr_tab[a.level * a.max_fr + a.fr_slot[b]];
+  const int pending = src.pending;
+  const int V = g.n;   // the "list" is the plane
+  const double group_sum = partial_group_sum(prev_part + (size_t)b * ELLC_NBLK_MAX * ELLC_PART_STRIDE, prev_nblk);
+  int begin, end;
+  if (age_rounds > 1) {
+    const int gb = (int)(((long long)V * fa.age_cum[age]) >> 16), ge = (int)(((long long)V * fa.age_cum[age + 1]) >> 16);
+    const int chunk = (ge - gb + per_age - 1) / per_age;
+    begin = gb + (sub - age * per_age) * chunk;
+    end = min(ge, begin + chunk);
+  } else {
+    const int chunk = (V + nblk - 1) / nblk;
+    begin = sub * chunk;
+    end = min(V, begin + chunk);
+  }
+  g_u8 cur = as_global(F.img);
+  const int cols = g.cols, sw = g.sw;
+  const int qstep = ELLC_GN_THREADS / cols, rstep = ELLC_GN_THREADS - qstep * cols;
+  int x = 0, y = 0;
+  DensePixX pix;
+  pix.Z = 0.0f; pix.var = 0.0f; pix.I = 0u; pix.invZ = 1.0;
+  if (begin < end) {   // block-uniform (a thread past the chunk's end starts on a copy of its last pixel: the pixel loop is block-uniform)
+    const int i0 = min(begin + t, end - 1);
+    y = (int)(((float)i0 + 0.5f) * (1.0f / (float)cols));
+    if (y * cols > i0) y--;
+    if ((y + 1) * cols <= i0) y++;
+    x = i0 - y * cols;
+    pix = dense_request_x(K, (unsigned)i0, (unsigned)(y * sw + x));
+  }
+  if (pending) {
+    solve_step<false>(sh, group_sum, 0, fa.prev_level, fa.early_exit, src, nullptr);
+  } else {
+    if (t < 6) sh.newpose[t] = src.pose[t];
+    if (t < 12) sh.newS[t] = src.S[t];
+    if (t == 0) { sh.weighted = src.weighted; sh.level_done = src.level_done; }
+    __syncthreads();
+  }
+  const int level_done = sh.level_done;
+  const bool skip = (level_done == a.level);
+  if (writer) {
+    if (t < 6) dst->pose[t] = sh.newpose[t];
+    if (t < 12) dst->S[t] = sh.newS[t];
+    if (t < ELLC_MAX_LEVELS) dst->iters[t] = src.iters[t] + ((pending && t == fa.prev_level) ? 1 : 0);
+    if (t == 0) {
+      dst->weighted = sh.weighted;
+      dst->level_done = level_done;
+      dst->pending = skip ? 0 : 1;
+    }
+  }
+  if (skip) return;
+  float sums[27];
+  {
+    float S[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) S[i] = sh.newS[i];
+    FcaAcc acc;
+    fca_acc_zero(acc);
+    if (begin < end) {   // block-uniform
+      const int n_full = __builtin_amdgcn_readfirstlane((end - begin) / ELLC_GN_THREADS);
+      const int rem = __builtin_amdgcn_readfirstlane((end - begin) - n_full * ELLC_GN_THREADS);
+      const int n_steps = n_full + (rem > 0 ? 1 : 0);
+      int i = begin + t;
+      for (int k = 0; k < n_steps; k++) {
+        const bool last = (k == n_steps - 1);
+        const bool active = !last || rem == 0 || t < rem;
+        const bool valid = pix.Z > 0.0f;
+        FcaIn in;   // fca_load's values, from the planes
+        in.xy = ((uint32_t)y << 16) | (uint32_t)x;
+        in.Ikf = (float)pix.I;
+        in.Z = valid ? pix.Z : 1.0f;
+        in.var = pix.var;
+        in.invZ = valid ? pix.invZ : 1.0;
+        const float aX = ((float)x - g.cx) * in.Z, aY = ((float)y - g.cy) * in.Z;
+        in.X = DIVC ? div_const(aX, g.fx, g.rfx) : aX / g.fx;
+        in.Y = DIVC ? div_const(aY, g.fy, g.rfy) : aY / g.fy;
+        // the next pixel of this thread: 256 further on (clamped to the chunk's last pixel: every request is unconditional)
+        int xn = x + rstep, yn = y + qstep;
+        if (xn >= cols) { xn -= cols; yn++; }
+        const int in_ = i + ELLC_GN_THREADS;
+        if (in_ > end - 1) {
+          const int il = end - 1;
+          yn = (int)(((float)il + 0.5f) * (1.0f / (float)cols));
+          if (yn * cols > il) yn--;
+          if ((yn + 1) * cols <= il) yn++;
+          xn = il - yn * cols;
+        }
+        const unsigned inext = (unsigned)min(in_, end - 1);
+        auto refill = [&]() { pix = dense_request_x(K, inext, (unsigned)(yn * sw + xn)); };
+        const FcaPix q = fca_pixel_in<false, DIVC>(a, K, g, cur, S, (unsigned)i, in, refill);
+        if (active && valid) fca_accumulate_pixel(acc, q);
+        x = xn; y = yn; i = in_;
+      }
+    }
+    fca_acc_unpack<false>(acc, sums);
+  }
+  float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
+  block_reduce_store<27>(sums, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // gn_fca_dense with FOUR ADJACENT PIXELS PER THREAD (r06), for levels whose width is a multiple of four. What the pixel pass of a
 // dense level pays for is the number of wave-level load instructions it hands the CU's vector cache — about 16.7 cycles each whatever
 // the lanes ask for, twice that when the lanes of a tap request sit on two image rows (tools/micro/quad_window.hip: the taps of 256

@@ -221,6 +221,16 @@ __global__ __launch_bounds__(256) void idepth_plane(const float* __restrict__ de
   }
 }
 
+// The exact mode's counterpart: pow(depth, -1) in double as the compaction stores it in a 20-byte record (1.0 / (double)Z: the same
+// expression, the same bits), for the list-free exact kernel (gn_fca_dense_x) — an f64 division per pixel and ITERATION otherwise.
+__global__ __launch_bounds__(256) void invz_plane(const float* __restrict__ depth, double* __restrict__ invz, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float z = depth[i];
+    invz[i] = z > 0.0f ? 1.0 / (double)z : 1.0;
+  }
+}
+
 // depthMap::buildInvVarDepth, one level (DepthPropagation.cpp:1637-1719); the reference's source stride
 // is 2*width of the destination. src_depth_is_mat: level-0 source holds keyFrame->depth (0 = invalid).
 __global__ void depth_pyr_level(const float* __restrict__ sd, const float* __restrict__ sv, float* __restrict__ dd, float* __restrict__ dv,

@@ -121,8 +121,9 @@ def test_c4_batch16_1280x960_dense(oracle, ellc, arith):
     ctx.close()
 
 
-def test_dense_path_skips_the_pixels_without_depth(oracle, ellc):
-    """The list-free schedule (gn_fca_dense: tolerance mode, every keyframe of the batch uploaded at least nine tenths full) on a map
+@pytest.mark.parametrize("arith", ["fast", "exact"])
+def test_dense_path_skips_the_pixels_without_depth(oracle, ellc, arith):
+    """The list-free schedule (gn_fca_dense / gn_fca_dense4 in the tolerance mode, r06: gn_fca_dense_x in the exact mode; every keyframe of the batch uploaded at least nine tenths full) on a map
     with holes — a band and scattered pixels without depth, 94 % valid: the hint is not a promise, a pixel without depth contributes
     nothing; pose within 1e-5 of the oracle's (which masks them, Frame.cpp:295-301). The same keyframe thinned below nine tenths takes
     the list path: both must agree with the oracle, and with each other to the tolerance of the summation order."""
@@ -136,7 +137,8 @@ def test_dense_path_skips_the_pixels_without_depth(oracle, ellc):
     assert 0.9 < (d0 > 0).mean() < 0.97
     _, kf, cur, dm = oracle_problem(oracle, W, H, L, pair)
     p_ref, it_ref, _ = oracle.align(kf, cur, dm.depth_pyr())
-    ctx = gpu_problem(ellc, W, H, L, [pair], arith=ellc.ARITH_FAST)
+    mode = ellc.ARITH_FAST if arith == "fast" else ellc.ARITH_EXACT
+    ctx = gpu_problem(ellc, W, H, L, [pair], arith=mode)
     p, it, _ = ctx.align([0], [0])
     assert list(it[0]) == list(it_ref)
     assert np.linalg.norm(p[0] - p_ref) <= 1e-5
@@ -148,7 +150,7 @@ def test_dense_path_skips_the_pixels_without_depth(oracle, ellc):
     assert np.linalg.norm(p2[0] - p[0]) <= 2e-6
     ctx.close()
     # ellc_ctx_set_dense_maps(1) pins the list path for a dense map: bit for bit what the list path gave above
-    ctx = gpu_problem(ellc, W, H, L, [pair], arith=ellc.ARITH_FAST)
+    ctx = gpu_problem(ellc, W, H, L, [pair], arith=mode)
     ctx.set_dense_maps(1)
     p3, it3, _ = ctx.align([0], [0])
     assert np.array_equal(p3, p2) and np.array_equal(it3, it2)
