@@ -115,10 +115,11 @@ ellc_status ellc_ctx_set_poll_timeout_us(ellc_ctx* ctx, int microseconds);
  * 43. Batches in flight keep the grids they were launched with. */
 ellc_status ellc_ctx_set_grid_batch(ellc_ctx* ctx, int n);
 /* The list-free path for dense maps (v10). A keyframe whose level-0 depth plane was uploaded with at least nine tenths of its
- * pixels valid (ellc_keyframe_set_depth counts them) is aligned — tolerance mode, FCA, no saved weights, every keyframe of the
- * batch dense — by kernels that read its planes directly instead of compact lists (gn_fca_dense / gn_fca_dense4). The two paths
- * chunk the pixels differently (plane index / list index), so their sums differ in the last bits: within the mode's tolerance
- * (pose <= 1e-5 vs the CPU path either way), but NOT bit-identical — and a batch flips to the list path as soon as one of its
+ * pixels valid (ellc_keyframe_set_depth counts them) is aligned — FCA, no saved weights, every keyframe of the batch dense — by
+ * kernels that read its planes directly instead of compact lists (gn_fca_dense / gn_fca_dense4 in the tolerance mode, gn_fca_dense_x
+ * in the exact mode: there every per-pixel value is the list path's bit for bit). The two paths chunk the pixels differently (plane
+ * index / list index), so their SUMS differ in the last bits: within the mode's tolerance (pose <= 1e-5 vs the CPU path either
+ * way; measured <= 2e-6 between the paths), but NOT bit-identical — and a batch flips to the list path as soon as one of its
  * keyframes is not dense. A caller that compares runs bit for bit (world-size invariance, regression hashes) pins the choice:
  * mode 0 = automatic (default), 1 = always the lists. Batches in flight keep the path they were launched with. */
 ellc_status ellc_ctx_set_dense_maps(ellc_ctx* ctx, int mode);
