@@ -149,3 +149,37 @@ def test_random_scene_full_alignment(oracle, ellc, w, h, L, seed, ica, arith):
     assert list(itg[0]) == list(itr) == list(mi)
     assert np.linalg.norm(pg[0] - pr) <= 1e-5, (pg[0], pr)
     ctx.close()
+
+
+DENSE_CASES = [(320, 200, 3, 301), (322, 202, 3, 302), (404, 300, 4, 303), (333, 250, 3, 304), (480, 270, 4, 305)]   # (large enough that the 3-pixel border leaves nine tenths)
+
+
+@pytest.mark.parametrize("w,h,L,seed", DENSE_CASES)
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_random_dense_map_list_free_path(oracle, ellc, w, h, L, seed, arith):
+    """The list-free schedules on random DENSE maps of odd geometry (widths that are and are not multiples of four, levels too small
+    for the four-pixel kernel, scattered holes): gn_fca_dense / gn_fca_dense4 (tolerance mode), gn_fca_dense_x (exact mode, r06).
+    Final pose within 1e-5 of the oracle's; the same planes through the compact lists (ellc_ctx_set_dense_maps(1)) within 2e-6 of
+    the list-free result (the sums' order is all that differs), iteration counts equal."""
+    mi = (4, 7, 9, 12)[:L]
+    rng = np.random.default_rng(seed)
+    pair = dict(synth.make_pair(w, h, seed=seed, dense=True, rot=float(rng.uniform(0.002, 0.01)), trans=float(rng.uniform(0.005, 0.025))))
+    d0 = pair["depth0"].copy()
+    d0[rng.random(d0.shape) < 0.01] = 0.0
+    pair["depth0"] = d0
+    assert (d0 > 0).mean() > 0.91   # (the dense hint: at least nine tenths)
+    _, kf, cur, dm = oracle_problem(oracle, w, h, L, pair, early_exit=0, max_iter=mi)
+    pr, itr, _ = oracle.align(kf, cur, dm.depth_pyr())
+    fx, fy, cx, cy = pair["intrinsics"]
+    res = []
+    for pin in (0, 1):
+        ctx = ellc.Context(ellc.default_config(w, h, L, fx=fx, fy=fy, cx=cx, cy=cy, early_exit=0, max_iter=mi,
+                                               arith=ellc.ARITH_FAST if arith == "fast" else ellc.ARITH_EXACT))
+        ctx.set_dense_maps(pin)
+        ctx.keyframe_upload(0, pair["kf_image"]); ctx.keyframe_set_depth(0, pair["depth0"], pair["var0"]); ctx.frame_upload(0, pair["cur_image"])
+        pg, itg, _ = ctx.align([0], [0])
+        assert list(itg[0]) == list(itr) == list(mi)
+        assert np.linalg.norm(pg[0] - pr) <= 1e-5, (pin, pg[0], pr)
+        res.append(pg[0].copy())
+        ctx.close()
+    assert np.linalg.norm(res[0] - res[1]) <= 2e-6, (res[0], res[1])
