@@ -2485,7 +2485,8 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, FAST ? 4 : 3) void gn_fca_adaptive
 // state-driven schedule). Block counts per level, chunks and the order of the combine are the launch-per-iteration schedule's
 // (gn_fca_adaptive): the same bits, also for a schedule that is abandoned here and finished there. Three blocks per CU in
 // the tolerance mode, two in the exact mode (launch bounds; the exact pixel loop inside this loop wants 226 registers and spills
-// cost it more than the launches it saves): 768 / 512 resident blocks hold three / two such launches of one alignment each.
+// cost it more than the launches it saves): 768 / 512 resident blocks hold three / two such launches of one alignment each
+// (r06: an alignment takes at most 128 blocks — every block reads every block's record, choose_nblk — so six / four).
 #define ELLC_PERSIST_BAR_WORDS 64   // per alignment: the abort word in a 128-byte line of its own, then the state line (below)
 #define ELLC_PERSIST_STATE_WORD 32  //   first word of the state line
 #define ELLC_PERSIST_SPIN_LIMIT (1u << 15)   // polls (~1 us each with their s_sleep): a record normally arrives within tens

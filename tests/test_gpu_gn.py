@@ -161,7 +161,7 @@ def test_resident_schedule_survives_blocks_that_start_late(ellc, arith):
     """r05's resident launch had a hole (advisor, r05): a block that writes no records at the coarse levels is waited for by nobody; if
     it is dispatched late (another stream's kernels hold its CU) the writers overwrite the records it wants — it spun to the poll limit
     and abandoned the launch. Since r06 it notices that it was lapped and re-joins through the state line block 0 publishes at every
-    level change. Here every block from index 7 on (640x480: 7 blocks write at level 3, 30 / 120 / 256 below) — and, in the second
+    level change. Here every block from index 7 on (640x480: 7 blocks write at level 3, 30 / 120 / 128 below) — and, in the second
     context, every block from 31 on — starts tens to hundreds of microseconds late (ellc_debug_persist_delay): the same bits as one
     launch per iteration, and NOT ONE launch abandoned."""
     cases = [(21, 0.02, 0.05), (22, 0.03, 0.08), (25, 0.05, 0.15)]
@@ -183,7 +183,7 @@ def test_resident_schedule_survives_blocks_that_start_late(ellc, arith):
         assert launches == 4 and abandoned == 0, (first_block, polls, launches, abandoned)
         print("blocks from %d on %d polls late: %d blocks re-joined through the state line" % (first_block, polls, rejoined - rejoined0))
         if first_block >= 7:
-            assert rejoined - rejoined0 >= 4 * 100, (first_block, polls, rejoined - rejoined0)   # most of the ~250 idle blocks of every launch
+            assert rejoined - rejoined0 >= 4 * 100, (first_block, polls, rejoined - rejoined0)   # most of the ~120 idle blocks of every launch
 
 
 @pytest.mark.parametrize("arith", ["exact", "fast"])
