@@ -2058,6 +2058,7 @@ __device__ unsigned long long g_quad_stats[4];   // diagnostic builds: quads see
 
 __global__ __launch_bounds__(ELLC_GN_THREADS, ELLC_QUAD_BLOCKS_PER_CU) void gn_fca_dense4(const AlignState* src_state, const float* prev_part, int prev_nblk, int nblk, int age_rounds,
                                                                     FusedArgs fa) {
+  ELLC_BSTAMP(0);
   const GnArgs& a = fa.g;
   int b = blockIdx.y, sub = blockIdx.x, age = 0, per_age = nblk;
   if (age_rounds > 1) {   // see gn_fca_fused
@@ -2133,6 +2134,7 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, ELLC_QUAD_BLOCKS_PER_CU) void gn_f
       dst->pending = skip ? 0 : 1;
     }
   }
+  ELLC_BSTAMP(1);
   if (skip) return;
   float sums[27];
   {
@@ -2333,7 +2335,9 @@ __global__ __launch_bounds__(ELLC_GN_THREADS, ELLC_QUAD_BLOCKS_PER_CU) void gn_f
     fca_acc_unpack<true>(acc, sums);
   }
   float* out = a.partials + (size_t)(fa.seq & 1) * fa.stride_part + ((size_t)b * ELLC_NBLK_MAX + sub) * ELLC_PART_STRIDE;
+  ELLC_BSTAMP(2);
   block_reduce_store<27>(sums, out);
+  ELLC_BSTAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------------
