@@ -3164,11 +3164,13 @@ __global__ __launch_bounds__(1024) void stage_in_args(int* __restrict__ dst, Sta
   }
 }
 
+#ifdef ELLC_DIAG_ABI   // (the measurement hooks' staging: ellc_profile_gn_kernel)
 __global__ void gn_init_state(AlignState* state, const float* init_pose, int B, int top_level) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   init_state_record(state[b], init_pose, b, top_level);
 }
+#endif
 
 __device__ inline void init_state_record(AlignState& st, const float* init_pose, int b, int top_level) {
   float p[6];
