@@ -878,24 +878,7 @@ __global__ __launch_bounds__(256) void dm_sum_stage1(DepthSoA s, int n, double* 
   }
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = sa[0]; part[2 * blockIdx.x + 1] = sc[0]; }
 }
-__global__ __launch_bounds__(256) void dm_sum_stage2(const double* __restrict__ part, int nblocks, double* __restrict__ out) {   // one block, nblocks <= 256
-  __shared__ double sa[256], sc[256];
-  const int t = threadIdx.x;
-  sa[t] = (t < nblocks) ? part[2 * t] : 0.0;
-  sc[t] = (t < nblocks) ? part[2 * t + 1] : 0.0;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {   // the same fixed tree as stage 1
-    if (t < off) { sa[t] += sa[t + off]; sc[t] += sc[t + off]; }
-    __syncthreads();
-  }
-  if (t == 0) {
-    out[0] = sa[0];
-    out[1] = sc[0];
-    const float num = (float)sc[0], sum = (float)sa[0];
-    ((float*)(out + 2))[0] = num / sum;   // rescaleFactor = numIdepth / sumIdepth (f32)
-  }
-}
-// every block redoes the second stage of the sum (dm_sum_stage2's fixed tree over the nblocks <= 256 partials: same bits) and
+// every block redoes the second stage of the sum (the fixed tree of stage 1 again, over the nblocks <= 256 partials: same bits everywhere) and
 // rescales its pixels; block 0 leaves the factor at factor_out for the host
 __global__ __launch_bounds__(256) void dm_rescale(DepthSoA s, int n, const double* __restrict__ part, int nblocks, float* __restrict__ factor_out) {
   __shared__ double sa[256], sc[256];

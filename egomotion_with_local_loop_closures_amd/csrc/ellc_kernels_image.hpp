@@ -19,28 +19,6 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p;
 }
 
-// frame::constructImagePyramids (Frame.cpp:170-182) — cv::pyrDown on CV_8UC1: separable [1 4 6 4 1],
-// BORDER_REFLECT_101, integer accumulation, (sum + 128) >> 8, dst = ((w+1)/2, (h+1)/2).
-__global__ void pyr_down_u8(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst, int dw, int dh) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= dw || y >= dh) return;
-  const int wk[5] = {1, 4, 6, 4, 1};
-  int cxs[5];
-#pragma unroll
-  for (int k = 0; k < 5; k++) cxs[k] = reflect101(2 * x + k - 2, sw);
-  int v = 0;
-#pragma unroll
-  for (int j = 0; j < 5; j++) {
-    const uint8_t* r = src + (size_t)reflect101(2 * y + j - 2, sh) * sw;
-    int h = 0;
-#pragma unroll
-    for (int k = 0; k < 5; k++) h += wk[k] * (int)r[cxs[k]];
-    v += wk[j] * h;
-  }
-  dst[(size_t)y * dw + x] = (uint8_t)((v + 128) >> 8);
-}
-
 // frame::calculateGradient (Frame.cpp:185-285) at one level, planes rows x cols
 __device__ __forceinline__ void grad_at(const uint8_t* __restrict__ img, int sw, int cols, int rows, int x, int y, float& gx, float& gy) {
   const int xm = x > 0 ? x - 1 : 0, xp = x < cols - 1 ? x + 1 : cols - 1;
@@ -68,7 +46,7 @@ __global__ void gradient_planes(const uint8_t* __restrict__ img, int sw, int col
 // deepest level it produces and computes, through LDS, everything above it that the tile depends on — the (2PT+3)^2 region of
 // the level above, the (4PT+9)^2 region two above, from the (8PT+21)^2 region of the source — writing the part of each level
 // it owns (a 2x / 4x larger tile; the halo is recomputed by the neighbours: 1.9x / 2.4x redundant arithmetic at PT = 4 on images
-// of a few hundred KB, against two kernel boundaries saved; PT = 8 gave 80 blocks at 640x480 and a 17 us launch). Same integer arithmetic as pyr_down_u8, so the same bytes.
+// of a few hundred KB, against two kernel boundaries saved; PT = 8 gave 80 blocks at 640x480 and a 17 us launch). cv::pyrDown on CV_8UC1 (frame::constructImagePyramids, Frame.cpp:170-182): separable [1 4 6 4 1], BORDER_REFLECT_101, integer accumulation, (sum + 128) >> 8, dst = ((w + 1) / 2, (h + 1) / 2).
 // (r03, measured and dropped: the separable 5 + 5 form — row sums of the region above in LDS, then the column pass, 10 reads per value
 // instead of 25 — 12.96 against 11.45 us at 640x480: the launch is bound by its barriers and index arithmetic, not by its LDS reads.)
 // Regions are kept in image coordinates clipped to the level (REFLECT_101 is applied to coordinates, and a reflected

@@ -64,7 +64,7 @@ def test_code_object_is_gfx950():
     so = os.path.join(ROOT, "egomotion_with_local_loop_closures_amd", "csrc", "libellc_hip.so")
     data = open(so, "rb").read()
     assert b"gfx950" in data
-    assert b"gn_fca_accumulate" in data and b"dm_observe" in data and b"pyr_down_u8" in data
+    assert b"gn_fca_accumulate" in data and b"dm_observe" in data and b"pyr_down_chain_u8" in data
 
 
 def test_struct_layouts_match_header(tmp_path):
